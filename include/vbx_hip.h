@@ -1,0 +1,180 @@
+/* vbx_hip.h — C-ABI of libvbx_hip.so, the MI355X (gfx950) TSDF/ESDF integration hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, int status codes, no C++ or torch
+ * types.  voxblox has no FFI of its own for this path — the "operator API" is the C++ class
+ * surface of /root/reference/voxblox/include/voxblox/integrator/{tsdf,esdf}_integrator.h — so
+ * each entry point below names the reference member it stands in for.  A C++ shim with the
+ * reference's class names and signatures on top of this ABI is in voxblox_amd/host/ and the
+ * binding a voxblox maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every call returns VBX_OK (0) or a negative error; vbx_last_error() gives the text.  The
+ *     C++ shim turns a non-zero status into the reference's abort-on-error convention
+ *     (glog CHECK / LOG(FATAL), tsdf_integrator.cc:11,22,29,41,247).
+ *   - one handle = one (Layer<TsdfVoxel>, Layer<EsdfVoxel>) pair resident in HBM; calls on a
+ *     handle come from one host thread at a time (integratePointCloud is documented
+ *     "NOT thread safe", tsdf_integrator.h:94-95).
+ *   - there is NO CPU fallback: without a HIP device vbx_create() fails.
+ */
+#ifndef VBX_HIP_H_
+#define VBX_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBX_OK 0
+#define VBX_ERR_INVALID (-1)   /* bad argument */
+#define VBX_ERR_HIP (-2)       /* HIP runtime error */
+#define VBX_ERR_CAPACITY (-3)  /* block pool / hash map full */
+#define VBX_ERR_UNSUPPORTED (-4)
+
+/* Layer geometry — Layer<V>::Layer(voxel_size, voxels_per_side), core/layer.h:34-44. */
+typedef struct vbx_map_cfg {
+  float voxel_size;
+  uint32_t voxels_per_side; /* power of two, 4..32 (reference default 16) */
+  uint32_t max_blocks;      /* capacity of the HBM block pool; 0 = default (65536) */
+} vbx_map_cfg;
+
+/* TsdfIntegratorBase::Config, tsdf_integrator.h:56-89 (same fields, same defaults via
+ * vbx_tsdf_cfg_default).  integrator_threads is accepted and ignored (the GPU result equals
+ * the reference's 1-thread result); integration_order_mode: 0 "mixed", 1 "sorted". */
+typedef struct vbx_tsdf_cfg {
+  float default_truncation_distance;
+  float max_weight;
+  int32_t voxel_carving_enabled;
+  float min_ray_length_m;
+  float max_ray_length_m;
+  int32_t use_const_weight;
+  int32_t allow_clear;
+  int32_t use_weight_dropoff;
+  int32_t use_sparsity_compensation_factor;
+  float sparsity_compensation_factor;
+  int32_t integrator_threads;
+  int32_t integration_order_mode;
+  int32_t enable_anti_grazing;
+  float start_voxel_subsampling_factor;
+  int32_t max_consecutive_ray_collisions;
+  int32_t clear_checks_every_n_frames;
+  float max_integration_time_s; /* accepted; the GPU path never truncates a frame */
+} vbx_tsdf_cfg;
+
+/* EsdfIntegrator::Config, esdf_integrator.h:29-78. */
+typedef struct vbx_esdf_cfg {
+  int32_t full_euclidean_distance;
+  float max_distance_m;
+  float min_distance_m;
+  float default_distance_m;
+  float min_diff_m;
+  float min_weight;
+  int32_t num_buckets;
+  int32_t multi_queue;
+  int32_t add_occupied_crust;
+  float clear_sphere_radius;
+  float occupied_sphere_radius;
+} vbx_esdf_cfg;
+
+void vbx_tsdf_cfg_default(vbx_tsdf_cfg* cfg);
+void vbx_esdf_cfg_default(vbx_esdf_cfg* cfg);
+
+typedef struct vbx_ctx vbx_ctx;
+
+/* Layer<TsdfVoxel>/Layer<EsdfVoxel> construction (core/layer.h:34-44) on HIP device `device`. */
+vbx_ctx* vbx_create(const vbx_map_cfg* cfg, int device);
+void vbx_destroy(vbx_ctx* ctx);
+const char* vbx_last_error(vbx_ctx* ctx); /* ctx may be NULL: error of the last failed vbx_create */
+
+/* Run all work of this handle on an existing HIP stream (e.g. torch's current stream);
+ * NULL restores the handle's own stream. */
+int vbx_set_stream(vbx_ctx* ctx, void* hip_stream);
+
+/* TsdfIntegratorType, tsdf_integrator.h:30-34 */
+#define VBX_TSDF_SIMPLE 1
+#define VBX_TSDF_MERGED 2
+#define VBX_TSDF_FAST 3
+
+/* {Simple,Merged,Fast}TsdfIntegrator::integratePointCloud(T_G_C, points_C, colors,
+ * freespace_points) — tsdf_integrator.h:100-103, tsdf_integrator.cc:242-267, 307-338, 555-590.
+ * T_G_C is passed as translation + unit quaternion (w,x,y,z) (kindr QuatTransformation).
+ * points_C: n x 3 float (12-byte stride, i.e. Pointcloud::data()); rgba: n x 4 bytes
+ * (Colors::data()).  Host pointers; returns after the map in HBM has been updated. */
+int vbx_tsdf_integrate(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float T_G_C_pos[3],
+                       const float T_G_C_quat_wxyz[4], const float* points_C, const uint8_t* rgba,
+                       size_t n, int freespace_points);
+/* Same, with points_C / rgba already resident in HBM (device pointers); asynchronous on the
+ * handle's stream apart from the size read-backs the algorithm needs. */
+int vbx_tsdf_integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg,
+                              const float T_G_C_pos[3], const float T_G_C_quat_wxyz[4],
+                              const float* d_points_C, const uint8_t* d_rgba, size_t n,
+                              int freespace_points);
+
+/* EsdfIntegrator::updateFromTsdfLayer(clear_updated_flag) (esdf_integrator.cc:104-122) when
+ * batch == 0, EsdfIntegrator::updateFromTsdfLayerBatch() (:94-102) when batch != 0. */
+int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag);
+
+/* ---- host <-> HBM coherence for the callers that read/modify the Layer directly
+ *      (mesher, publishers, removeDistantBlocks, load_map) ---- */
+#define VBX_LAYER_TSDF 0
+#define VBX_LAYER_ESDF 1
+/* Update::Status bits, core/block.h:15-18 */
+#define VBX_UPDATE_MAP 1
+#define VBX_UPDATE_MESH 2
+#define VBX_UPDATE_ESDF 4
+
+/* Layer::getNumberOfAllocatedBlocks / getAllAllocatedBlocks (layer.h:184-193, 205).  Indices
+ * are returned in ascending (z,y,x) order. */
+int vbx_num_blocks(vbx_ctx* ctx, int layer, size_t* n);
+int vbx_block_indices(vbx_ctx* ctx, int layer, int32_t* idx_xyz, size_t cap, size_t* n);
+/* Layer::getAllUpdatedBlocks(bit) (layer.h:194-203); update_mask = OR of VBX_UPDATE_*. */
+int vbx_blocks_updated(vbx_ctx* ctx, int layer, int update_mask, int32_t* idx_xyz, size_t cap,
+                       size_t* n);
+/* Block<V> voxel array in the reference's AoS layout: TsdfVoxel = {float distance; float
+ * weight; uint8 r,g,b,a} (12 B, voxel.h:12-16); EsdfVoxel = {float distance; uint8 observed,
+ * hallucinated, in_queue, fixed; int32 parent[3]} (20 B, voxel.h:18-37).  Returns
+ * VBX_ERR_INVALID if the block is not allocated. */
+int vbx_block_download(vbx_ctx* ctx, int layer, const int32_t idx[3], void* aos_voxels,
+                       uint8_t* updated_bits, uint8_t* has_data);
+/* Layer::allocateBlockPtrByIndex + overwrite (load_map / tsdfMapCallback path). */
+int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos_voxels,
+                     uint8_t updated_bits, uint8_t has_data);
+/* Layer::removeBlock / removeDistantBlocks / removeAllBlocks (layer.h:167-182). */
+int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]);
+int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance);
+int vbx_clear(vbx_ctx* ctx, int layer);
+/* block.updated().reset(bit) over all blocks of a layer (mesher / ESDF consumers). */
+int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask);
+
+/* ---- measurement ---- */
+typedef struct vbx_counters {
+  uint64_t points;          /* points handed to the last integrate call */
+  uint64_t rays_cast;       /* rays actually cast */
+  uint64_t voxel_updates;   /* updateTsdfVoxel evaluations */
+  uint64_t voxels_touched;  /* distinct voxels updated (U in SURVEY §8(d)) */
+  uint64_t blocks_allocated;/* blocks newly published by the last call */
+  uint64_t iterations;      /* Fast: fixed-point sweeps of the early-termination solver */
+  uint64_t esdf_blocks;     /* ESDF: TSDF blocks propagated */
+  uint64_t esdf_relaxations;/* ESDF: successful wavefront relaxations */
+  uint64_t esdf_sweeps;     /* ESDF: wavefront sweeps */
+} vbx_counters;
+int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
+
+/* HIP-event timing of the last integrate / esdf call on the handle's stream, in ms. */
+typedef struct vbx_timing {
+  float total_ms;
+  float prep_ms;     /* validate/transform/bundle/dedupe */
+  float alloc_ms;    /* block allocation walk */
+  float solve_ms;    /* Fast: early-termination solver */
+  float emit_ms;     /* ray march emitting ordered voxel updates */
+  float sort_ms;     /* ordering of the updates */
+  float fold_ms;     /* per-voxel ordered fold (the TSDF update itself) */
+} vbx_timing;
+int vbx_enable_timing(vbx_ctx* ctx, int enable);
+int vbx_get_timing(vbx_ctx* ctx, vbx_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBX_HIP_H_ */

@@ -1,0 +1,274 @@
+"""ctypes binding of libvbx_hip.so (C-ABI: include/vbx_hip.h).
+
+The shared library is built in-tree by __graft_entry__.build() (hipcc, gfx950).  There is
+no CPU fallback: importing this module without the library, or creating a map without a
+HIP device, raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvbx_hip.so")
+
+VBX_OK = 0
+TSDF_SIMPLE, TSDF_MERGED, TSDF_FAST = 1, 2, 3
+LAYER_TSDF, LAYER_ESDF = 0, 1
+UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
+
+# every symbol include/vbx_hip.h declares
+EXPORTED_SYMBOLS = (
+    "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
+    "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
+    "vbx_esdf_update", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
+    "vbx_block_download", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
+    "vbx_clear", "vbx_clear_updated", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
+
+
+class MapCfg(C.Structure):
+    _fields_ = [("voxel_size", C.c_float), ("voxels_per_side", C.c_uint32),
+                ("max_blocks", C.c_uint32)]
+
+
+class TsdfCfg(C.Structure):
+    """TsdfIntegratorBase::Config (tsdf_integrator.h:56-89)."""
+    _fields_ = [("default_truncation_distance", C.c_float), ("max_weight", C.c_float),
+                ("voxel_carving_enabled", C.c_int32), ("min_ray_length_m", C.c_float),
+                ("max_ray_length_m", C.c_float), ("use_const_weight", C.c_int32),
+                ("allow_clear", C.c_int32), ("use_weight_dropoff", C.c_int32),
+                ("use_sparsity_compensation_factor", C.c_int32),
+                ("sparsity_compensation_factor", C.c_float), ("integrator_threads", C.c_int32),
+                ("integration_order_mode", C.c_int32), ("enable_anti_grazing", C.c_int32),
+                ("start_voxel_subsampling_factor", C.c_float),
+                ("max_consecutive_ray_collisions", C.c_int32),
+                ("clear_checks_every_n_frames", C.c_int32), ("max_integration_time_s", C.c_float)]
+
+
+class EsdfCfg(C.Structure):
+    """EsdfIntegrator::Config (esdf_integrator.h:29-78)."""
+    _fields_ = [("full_euclidean_distance", C.c_int32), ("max_distance_m", C.c_float),
+                ("min_distance_m", C.c_float), ("default_distance_m", C.c_float),
+                ("min_diff_m", C.c_float), ("min_weight", C.c_float), ("num_buckets", C.c_int32),
+                ("multi_queue", C.c_int32), ("add_occupied_crust", C.c_int32),
+                ("clear_sphere_radius", C.c_float), ("occupied_sphere_radius", C.c_float)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in
+                ("points", "rays_cast", "voxel_updates", "voxels_touched", "blocks_allocated",
+                 "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps")]
+
+
+class Timing(C.Structure):
+    _fields_ = [(k, C.c_float) for k in
+                ("total_ms", "prep_ms", "alloc_ms", "solve_ms", "emit_ms", "sort_ms", "fold_ms")]
+
+
+class VbxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libvbx_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VbxError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, u8p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    szp = C.POINTER(C.c_size_t)
+    sig = {
+        "vbx_tsdf_cfg_default": (None, [C.POINTER(TsdfCfg)]),
+        "vbx_esdf_cfg_default": (None, [C.POINTER(EsdfCfg)]),
+        "vbx_create": (vp, [C.POINTER(MapCfg), C.c_int]),
+        "vbx_destroy": (None, [vp]),
+        "vbx_last_error": (C.c_char_p, [vp]),
+        "vbx_set_stream": (C.c_int, [vp, vp]),
+        "vbx_tsdf_integrate": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, f32p, u8p,
+                                         C.c_size_t, C.c_int]),
+        "vbx_tsdf_integrate_device": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, vp, vp,
+                                                C.c_size_t, C.c_int]),
+        "vbx_esdf_update": (C.c_int, [vp, C.POINTER(EsdfCfg), C.c_int, C.c_int]),
+        "vbx_num_blocks": (C.c_int, [vp, C.c_int, szp]),
+        "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
+        "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),
+        "vbx_block_download": (C.c_int, [vp, C.c_int, i32p, vp, u8p, u8p]),
+        "vbx_block_upload": (C.c_int, [vp, C.c_int, i32p, vp, C.c_uint8, C.c_uint8]),
+        "vbx_block_remove": (C.c_int, [vp, C.c_int, i32p]),
+        "vbx_remove_distant_blocks": (C.c_int, [vp, C.c_int, f32p, C.c_double]),
+        "vbx_clear": (C.c_int, [vp, C.c_int]),
+        "vbx_clear_updated": (C.c_int, [vp, C.c_int, C.c_int]),
+        "vbx_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
+        "vbx_enable_timing": (C.c_int, [vp, C.c_int]),
+        "vbx_get_timing": (C.c_int, [vp, C.POINTER(Timing)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def tsdf_cfg(**kw):
+    c = TsdfCfg()
+    lib().vbx_tsdf_cfg_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def esdf_cfg(**kw):
+    c = EsdfCfg()
+    lib().vbx_esdf_cfg_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+TSDF_VOXEL_DTYPE = np.dtype([("distance", "<f4"), ("weight", "<f4"), ("rgba", "u1", (4,))])
+ESDF_VOXEL_DTYPE = np.dtype([("distance", "<f4"), ("observed", "u1"), ("hallucinated", "u1"),
+                             ("in_queue", "u1"), ("fixed", "u1"), ("parent", "<i4", (3,))])
+assert TSDF_VOXEL_DTYPE.itemsize == 12 and ESDF_VOXEL_DTYPE.itemsize == 20
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Map:
+    """One (Layer<TsdfVoxel>, Layer<EsdfVoxel>) pair resident in HBM."""
+
+    def __init__(self, voxel_size, voxels_per_side=16, max_blocks=0, device=0):
+        self.L = lib()
+        self.voxel_size = np.float32(voxel_size)
+        self.vps = int(voxels_per_side)
+        cfg = MapCfg(float(self.voxel_size), self.vps, int(max_blocks))
+        self.h = self.L.vbx_create(C.byref(cfg), int(device))
+        if not self.h:
+            raise VbxError(self.L.vbx_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vbx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != VBX_OK:
+            raise VbxError(f"vbx error {rc}: {self.L.vbx_last_error(self.h).decode()}")
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.vbx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def integrate(self, kind, cfg, pos, quat_wxyz, points_C, rgba, freespace=False):
+        """integratePointCloud with host arrays (tsdf_integrator.h:100-103)."""
+        pos = np.ascontiguousarray(pos, np.float32)
+        q = np.ascontiguousarray(quat_wxyz, np.float32)
+        pts = np.ascontiguousarray(points_C, np.float32)
+        col = np.ascontiguousarray(rgba, np.uint8)
+        if pts.ndim != 2 or pts.shape[1] != 3 or col.shape != (pts.shape[0], 4):
+            raise ValueError("points_C must be (N,3) float32 and rgba (N,4) uint8")  # CHECK_EQ, tsdf_integrator.cc:247
+        self._chk(self.L.vbx_tsdf_integrate(self.h, int(kind), C.byref(cfg), _fp(pos), _fp(q), _fp(pts),
+                                            col.ctypes.data_as(C.POINTER(C.c_uint8)), pts.shape[0],
+                                            int(freespace)))
+
+    def integrate_device(self, kind, cfg, pos, quat_wxyz, d_points_ptr, d_rgba_ptr, n, freespace=False):
+        pos = np.ascontiguousarray(pos, np.float32)
+        q = np.ascontiguousarray(quat_wxyz, np.float32)
+        self._chk(self.L.vbx_tsdf_integrate_device(self.h, int(kind), C.byref(cfg), _fp(pos), _fp(q),
+                                                   C.c_void_p(d_points_ptr), C.c_void_p(d_rgba_ptr),
+                                                   int(n), int(freespace)))
+
+    def esdf_update(self, cfg, batch=False, clear_updated_flag=True):
+        self._chk(self.L.vbx_esdf_update(self.h, C.byref(cfg), int(batch), int(clear_updated_flag)))
+
+    def num_blocks(self, layer=LAYER_TSDF):
+        n = C.c_size_t(0)
+        self._chk(self.L.vbx_num_blocks(self.h, layer, C.byref(n)))
+        return n.value
+
+    def block_indices(self, layer=LAYER_TSDF):
+        n = C.c_size_t(0)
+        self._chk(self.L.vbx_num_blocks(self.h, layer, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        self._chk(self.L.vbx_block_indices(self.h, layer, out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           n.value, C.byref(n)))
+        return out[:n.value]
+
+    def blocks_updated(self, mask, layer=LAYER_TSDF):
+        n = C.c_size_t(0)
+        self._chk(self.L.vbx_blocks_updated(self.h, layer, mask, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        self._chk(self.L.vbx_blocks_updated(self.h, layer, mask, out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            n.value, C.byref(n)))
+        return out[:n.value]
+
+    def block_download(self, idx, layer=LAYER_TSDF):
+        """Returns (structured voxel array in the reference's AoS layout, updated bits, has_data)."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        dt = TSDF_VOXEL_DTYPE if layer == LAYER_TSDF else ESDF_VOXEL_DTYPE
+        out = np.zeros(self.vps ** 3, dt)
+        u = C.c_uint8(0)
+        hd = C.c_uint8(0)
+        self._chk(self.L.vbx_block_download(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            out.ctypes.data_as(C.c_void_p), C.byref(u), C.byref(hd)))
+        return out, u.value, hd.value
+
+    def block_upload(self, idx, voxels, updated_bits=7, has_data=0, layer=LAYER_TSDF):
+        idx = np.ascontiguousarray(idx, np.int32)
+        dt = TSDF_VOXEL_DTYPE if layer == LAYER_TSDF else ESDF_VOXEL_DTYPE
+        v = np.ascontiguousarray(voxels, dt)
+        assert v.shape == (self.vps ** 3,)
+        self._chk(self.L.vbx_block_upload(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          v.ctypes.data_as(C.c_void_p), updated_bits, has_data))
+
+    def block_remove(self, idx, layer=LAYER_TSDF):
+        idx = np.ascontiguousarray(idx, np.int32)
+        self._chk(self.L.vbx_block_remove(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def remove_distant_blocks(self, center, max_distance, layer=LAYER_TSDF):
+        c = np.ascontiguousarray(center, np.float32)
+        self._chk(self.L.vbx_remove_distant_blocks(self.h, layer, _fp(c), float(max_distance)))
+
+    def clear(self, layer=LAYER_TSDF):
+        self._chk(self.L.vbx_clear(self.h, layer))
+
+    def clear_updated(self, mask, layer=LAYER_TSDF):
+        self._chk(self.L.vbx_clear_updated(self.h, layer, mask))
+
+    def counters(self):
+        c = Counters()
+        self._chk(self.L.vbx_get_counters(self.h, C.byref(c)))
+        return {k: int(getattr(c, k)) for k, _ in Counters._fields_}
+
+    def enable_timing(self, on=True):
+        self._chk(self.L.vbx_enable_timing(self.h, int(on)))
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.L.vbx_get_timing(self.h, C.byref(t)))
+        return {k: float(getattr(t, k)) for k, _ in Timing._fields_}
+
+    def tsdf_dict(self):
+        """{(bx,by,bz): (dist, weight, rgba, updated_bits)} for every allocated TSDF block."""
+        out = {}
+        for i in self.block_indices(LAYER_TSDF):
+            v, u, _ = self.block_download(i, LAYER_TSDF)
+            out[tuple(int(x) for x in i)] = (v["distance"].copy(), v["weight"].copy(), v["rgba"].copy(), u)
+        return out

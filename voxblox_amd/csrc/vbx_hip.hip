@@ -1,0 +1,1615 @@
+// libvbx_hip.so — MI355X (gfx950) TSDF integration hot path of voxblox, hand-written HIP.
+//
+// What this file implements (reference = /root/reference/voxblox):
+//   {Simple,Merged,Fast}TsdfIntegrator::integratePointCloud  src/integrator/tsdf_integrator.cc:242-590
+//   RayCaster / ThreadSafeIndex                               src/integrator/integrator_utils.cc
+//   Layer<TsdfVoxel> / Block<TsdfVoxel> storage               include/voxblox/core/{layer,block}.h
+// behind the C-ABI of include/vbx_hip.h.  See DESIGN.md for the data layout and the kernel list.
+//
+// Design in one paragraph.  The map lives in HBM as a struct-of-arrays block pool
+// (dist[], weight[], rgba[] — vps^3 voxels per block, so a block is three contiguous
+// 16 KiB / 16 KiB / 16 KiB runs at vps=16) addressed through an open-addressing hash map
+// BlockIndex -> pool slot.  updateTsdfVoxel clamps after every update, so the per-voxel fold
+// is neither associative nor commutative: the reference's 1-thread result is
+// reproduced by marching every ray once to EMIT (voxel, order) keys, sorting them, and folding
+// each voxel's updates sequentially in the reference's point order — parallel across voxels,
+// ordered within a voxel.  No MFMA anywhere: this is a raycast/scatter path.
+//
+// Built with -ffp-contract=off (see vbx_device_math.hpp for why).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/vbx_hip.h"
+#include "vbx_device_math.hpp"
+
+using namespace vbx;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// small host utilities
+// ---------------------------------------------------------------------------
+thread_local std::string g_create_error;
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ctx->fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return VBX_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+struct DBuf {  // growable device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      if (e != hipSuccess) return e;
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = (want + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
+
+// block flag bits (blk_flags[slot])
+constexpr uint32_t kFlagUpdMask = 0x7;      // Update::kMap|kMesh|kEsdf, core/block.h:15-18
+constexpr uint32_t kFlagPublished = 0x100;  // block is part of the API-visible Layer
+constexpr uint32_t kFlagHasData = 0x200;    // Block::has_data_
+constexpr uint32_t kFlagNewThisCall = 0x400;
+
+// Device-resident scalar state, read back at the per-call sync points.
+struct DevState {
+  uint32_t pool_used;
+  uint32_t free_count;
+  uint32_t new_count;
+  uint32_t error;  // bit0: pool/hash capacity, bit1: lookup of a missing block
+  uint32_t changed;
+  uint32_t sentinel_cleared;
+  uint32_t blocks_published;
+  uint32_t pad;
+  unsigned long long total_keys;
+  unsigned long long voxels_touched;
+  unsigned long long rays_cast;
+  unsigned long long num_kept;
+};
+
+struct MapDev {  // by-value kernel argument
+  uint64_t* hkeys;
+  uint32_t* hvals;
+  uint32_t hmask;
+  float* dist;
+  float* weight;
+  uint32_t* rgba;
+  int32_t* blk_idx;     // 3 per slot
+  uint32_t* blk_flags;  // 1 per slot
+  uint32_t* free_list;
+  uint32_t cap_blocks;
+  uint32_t nvox;
+  int vps;
+  int vps_log2;
+  float voxel_size;
+  float voxel_size_inv;
+  float vps_inv;
+};
+
+struct CastCfg {  // by-value kernel argument: TsdfIntegratorBase::Config + derived constants
+  f3 origin;
+  float trunc;
+  float max_ray_length_m;
+  float min_ray_length_m;
+  float max_weight;
+  float sparsity_factor;
+  int carving;
+  int allow_clear;
+  int use_const_weight;
+  int dropoff;
+  int sparsity;
+  int anti_grazing;
+  int max_consecutive;
+  float start_factor_times_inv;  // start_voxel_subsampling_factor * voxel_size_inv_
+};
+
+struct RayTab {  // SoA ray table indexed by integration order o
+  float* px;
+  float* py;
+  float* pz;      // point_G
+  uint32_t* rgba;
+  float* w;       // point / bundle weight
+  uint8_t* flags; // bit0 cast this ray, bit1 clearing ray
+  uint64_t* bkey; // Merged: packed endpoint voxel key of the bundle (anti-grazing), else null
+  uint32_t R;
+};
+
+__host__ __device__ inline uint64_t pack_block_key(int x, int y, int z) {
+  const uint64_t B = 1ull << 20;
+  return ((uint64_t)(z + (long long)B) << 42) | ((uint64_t)(y + (long long)B) << 21) |
+         (uint64_t)(x + (long long)B);
+}
+__host__ __device__ inline void unpack_block_key(uint64_t k, int* x, int* y, int* z) {
+  const long long B = 1ll << 20;
+  *x = (int)((long long)(k & 0x1FFFFF) - B);
+  *y = (int)((long long)((k >> 21) & 0x1FFFFF) - B);
+  *z = (int)((long long)((k >> 42) & 0x1FFFFF) - B);
+}
+__host__ __device__ inline uint32_t mix_key(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// BlockIndex -> pool slot lookup (Layer::getBlockPtrByIndex, layer.h:72-89).
+__device__ inline uint32_t map_find(const MapDev& m, uint64_t key) {
+  uint32_t h = mix_key(key) & m.hmask;
+  for (uint32_t probes = 0; probes <= m.hmask; ++probes) {
+    const uint64_t k = __hip_atomic_load(&m.hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return __hip_atomic_load(&m.hvals[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyKey) return kInvalidSlot;
+    h = (h + 1) & m.hmask;
+  }
+  return kInvalidSlot;
+}
+
+// Insert-if-absent; the pool slot is assigned afterwards by k_assign_slots (temp_block_map_
+// + updateLayerWithStoredBlocks, tsdf_integrator.cc:107-126, 137-147).
+__device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* new_list,
+                                      DevState* st) {
+  uint32_t h = mix_key(key) & m.hmask;
+  for (uint32_t probes = 0; probes <= m.hmask; ++probes) {
+    uint64_t k = __hip_atomic_load(&m.hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return;
+    if (k == kEmptyKey) {
+      const unsigned long long old =
+          atomicCAS((unsigned long long*)&m.hkeys[h], (unsigned long long)kEmptyKey,
+                    (unsigned long long)key);
+      if (old == kEmptyKey) {
+        const uint32_t i = atomicAdd(&st->new_count, 1u);
+        if (i < m.cap_blocks) new_list[i] = h; else atomicOr(&st->error, 1u);
+        return;
+      }
+      if (old == key) return;
+    }
+    h = (h + 1) & m.hmask;
+  }
+  atomicOr(&st->error, 1u);
+}
+
+// ---------------------------------------------------------------------------
+// kernels: map maintenance
+// ---------------------------------------------------------------------------
+__global__ void k_fill_u64(uint64_t* p, uint64_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_assign_slots(MapDev m, const uint32_t* new_list, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = min(st->new_count, m.cap_blocks);
+  if (i >= n) return;
+  const uint32_t h = new_list[i];
+  const uint32_t fc = st->free_count;
+  uint32_t slot;
+  if (i < fc) {
+    slot = m.free_list[fc - 1 - i];
+  } else {
+    slot = st->pool_used + (i - fc);
+  }
+  if (slot >= m.cap_blocks) {
+    atomicOr(&st->error, 1u);
+    return;  // hvals stays invalid; voxels of this block are skipped and the call fails
+  }
+  int x, y, z;
+  unpack_block_key(m.hkeys[h], &x, &y, &z);
+  m.blk_idx[3 * slot] = x;
+  m.blk_idx[3 * slot + 1] = y;
+  m.blk_idx[3 * slot + 2] = z;
+  m.blk_flags[slot] = 0;
+  __hip_atomic_store(&m.hvals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_commit_alloc(MapDev m, DevState* st) {
+  const uint32_t n = min(st->new_count, m.cap_blocks);
+  const uint32_t fc = st->free_count;
+  if (n <= fc) {
+    st->free_count = fc - n;
+  } else {
+    const uint32_t grow = n - fc;
+    st->free_count = 0;
+    if (st->pool_used + grow > m.cap_blocks) {
+      st->pool_used = m.cap_blocks;
+      st->error |= 1u;
+    } else {
+      st->pool_used += grow;
+    }
+  }
+  st->new_count = 0;
+}
+
+// ---------------------------------------------------------------------------
+// kernels: ray table construction
+// ---------------------------------------------------------------------------
+// isPointValid (tsdf_integrator.h:112-129) + T_G_C * point_C + getVoxelWeight
+// (tsdf_integrator.cc:231-240); one thread per input point, rows written at the point's
+// position in the reference's visiting order (MixedThreadSafeIndex).
+__device__ inline bool point_valid(const CastCfg& c, f3 pc, bool freespace, bool* clearing) {
+  const float r = f3_norm(pc);
+  if (r < c.min_ray_length_m) return false;
+  if (r > c.max_ray_length_m) {
+    if (c.allow_clear || freespace) {
+      *clearing = true;
+      return true;
+    }
+    return false;
+  }
+  *clearing = freespace;
+  return true;
+}
+__device__ inline float voxel_weight(const CastCfg& c, f3 pc) {
+  if (c.use_const_weight) return 1.0f;
+  const float dz = fabsf(pc.z);
+  if (dz > 1e-6f) return 1.0f / (dz * dz);
+  return 0.0f;
+}
+
+__global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __restrict__ rgba,
+                              size_t n, Pose T, CastCfg c, int freespace, RayTab tab,
+                              float* pcx, float* pcy, float* pcz) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t s = mixed_index_inverse(p, n);
+  const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+  bool clearing = false;
+  const bool valid = point_valid(c, pc, freespace != 0, &clearing);
+  const f3 pg = pose_transform(T, pc);
+  tab.px[s] = pg.x;
+  tab.py[s] = pg.y;
+  tab.pz[s] = pg.z;
+  tab.rgba[s] = rgba[p];
+  tab.w[s] = voxel_weight(c, pc);
+  tab.flags[s] = (valid ? 1 : 0) | (clearing ? 2 : 0);
+  if (pcx) {  // Merged keeps point_C for the bundle mean
+    pcx[s] = pc.x;
+    pcy[s] = pc.y;
+    pcz[s] = pc.z;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernels: generic ray march over a ray table
+// ---------------------------------------------------------------------------
+__device__ inline bool ray_init(RayCaster& rc, const RayTab& tab, uint32_t o, const CastCfg& c,
+                                const MapDev& m, bool from_origin, f3* pg_out) {
+  const uint8_t fl = tab.flags[o];
+  if (!(fl & 1)) return false;
+  const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+  rc.init(c.origin, pg, (fl & 2) != 0, c.carving != 0, c.max_ray_length_m, m.voxel_size_inv,
+          c.trunc, from_origin);
+  if (pg_out) *pg_out = pg;
+  return true;
+}
+
+// cnt[o] = number of voxel indices the ray emits (ray_length_in_steps_ + 1), or `limit[o]`.
+__global__ void k_ray_count(RayTab tab, CastCfg c, MapDev m, int from_origin,
+                            const uint32_t* __restrict__ limit, uint32_t* cnt) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o > tab.R) return;
+  if (o == tab.R) {
+    cnt[o] = 0;
+    return;
+  }
+  RayCaster rc;
+  uint32_t n = 0;
+  if (ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) {
+    n = (rc.cur == 0) ? rc.steps + 1 : 0;
+    if (limit) n = min(n, limit[o]);
+  }
+  cnt[o] = n;
+}
+
+// Walks every ray and makes sure each block it crosses has a pool slot
+// (allocateStorageAndGetVoxelPtr's block part, tsdf_integrator.cc:97-126).
+__global__ void k_ray_mark_blocks(RayTab tab, CastCfg c, MapDev m, int from_origin,
+                                  const uint32_t* __restrict__ limit, uint32_t* new_list,
+                                  DevState* st) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= tab.R) return;
+  RayCaster rc;
+  if (!ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) return;
+  const uint32_t lim = limit ? limit[o] : 0xFFFFFFFFu;
+  uint64_t last_key = kEmptyKey;
+  l3 g;
+  uint32_t k = 0;
+  while (k < lim && rc.next(&g)) {
+    ++k;
+    const i3 b = block_index_from_global(g, m.vps_inv);
+    const uint64_t key = pack_block_key(b.x, b.y, b.z);
+    if (key != last_key) {
+      last_key = key;
+      map_insert_key(m, key, new_list, st);
+    }
+  }
+}
+
+// The ray march proper: every visited voxel becomes one 64-bit key
+//   (pool_slot * nvox + linear_index) << 32 | order
+// written at off[o] + k.  Blocks touched are published and get all Update bits
+// (tsdf_integrator.cc:128).  Merged's anti-grazing test (:415-422) is a binary search in
+// the sorted bundle keys.
+__global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
+                           const uint32_t* __restrict__ limit, const uint32_t* __restrict__ off,
+                           uint64_t* keys, const uint64_t* __restrict__ graze_keys,
+                           uint32_t n_graze, DevState* st) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= tab.R) return;
+  RayCaster rc;
+  if (!ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) return;
+  const uint32_t lim = limit ? limit[o] : 0xFFFFFFFFu;
+  atomicAdd(&st->rays_cast, 1ull);
+  if (lim == 0 || rc.cur != 0) return;
+  const bool clearing = (tab.flags[o] & 2) != 0;
+  uint64_t last_key = kEmptyKey;
+  uint32_t slot = kInvalidSlot;
+  uint32_t base = off[o];
+  l3 g;
+  uint32_t k = 0;
+  while (k < lim && rc.next(&g)) {
+    uint64_t out = ~0ull;  // sorts last, skipped by the fold
+    bool skip = false;
+    if (graze_keys) {
+      // voxel_map.find(global_voxel_idx) != end && (clearing || idx != kv.first)
+      const uint64_t vk = ((uint64_t)(g.z + (1ll << 20)) << 42) |
+                          ((uint64_t)(g.y + (1ll << 20)) << 21) | (uint64_t)(g.x + (1ll << 20));
+      if (clearing || vk != tab.bkey[o]) {
+        uint32_t lo = 0, hi = n_graze;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (graze_keys[mid] < vk) lo = mid + 1; else hi = mid;
+        }
+        skip = (lo < n_graze && graze_keys[lo] == vk);
+      }
+    }
+    if (!skip) {
+      const i3 b = block_index_from_global(g, m.vps_inv);
+      const uint64_t key = pack_block_key(b.x, b.y, b.z);
+      if (key != last_key) {
+        last_key = key;
+        slot = map_find(m, key);
+        if (slot == kInvalidSlot) {
+          atomicOr(&st->error, 2u);
+        } else {
+          const uint32_t old = atomicOr(&m.blk_flags[slot], kFlagPublished | kFlagUpdMask);
+          if (!(old & kFlagPublished)) {
+            atomicOr(&m.blk_flags[slot], kFlagNewThisCall);
+            atomicAdd(&st->blocks_published, 1u);
+          }
+        }
+      }
+      if (slot != kInvalidSlot) {
+        const i3 l = local_from_global(g, m.vps);
+        const uint32_t lin = (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
+        const uint32_t gid = slot * m.nvox + lin;
+        out = ((uint64_t)gid << 32) | o;
+      }
+    }
+    keys[base + k] = out;
+    ++k;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernel: ordered per-voxel fold == updateTsdfVoxel (tsdf_integrator.cc:150-209) applied to
+// each voxel's updates in ascending integration order.  One thread per segment head.
+// ---------------------------------------------------------------------------
+__device__ inline void tsdf_update(const CastCfg& c, float voxel_size, f3 pg, l3 g,
+                                   uint32_t color, float weight, float& d, float& W,
+                                   uint32_t& col) {
+  const f3 center = center_point_from_grid_index(g, voxel_size);
+  // computeDistance, tsdf_integrator.cc:216-228
+  const f3 a = f3_sub(center, c.origin);
+  const f3 b = f3_sub(pg, c.origin);
+  const float dist_G = f3_norm(b);
+  const float dist_G_V = f3_dot(a, b) / dist_G;
+  const float sdf = dist_G - dist_G_V;
+
+  float uw = weight;
+  const float eps = voxel_size;
+  if (c.dropoff && sdf < -eps) {
+    uw = weight * (c.trunc + sdf) / (c.trunc - eps);
+    uw = std_max(uw, 0.0f);
+  }
+  if (c.sparsity) {
+    if (fabsf(sdf) < c.trunc) uw *= c.sparsity_factor;
+  }
+  const float nw = W + uw;
+  if (nw < 1e-6f) return;
+  const float nsdf = (sdf * uw + d * W) / nw;
+  if (fabsf(sdf) < c.trunc) col = blend_two_colors(col, W, color, uw);
+  d = (nsdf > 0.0f) ? std_min(c.trunc, nsdf) : std_max(-c.trunc, nsdf);
+  W = std_min(c.max_weight, nw);
+}
+
+__global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
+                       MapDev m, DevState* st) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == ~0ull) return;
+  const uint32_t gid = (uint32_t)(key >> 32);
+  if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid) return;  // not a segment head
+
+  const uint32_t slot = gid / m.nvox;
+  const uint32_t lin = gid - slot * m.nvox;
+  const int lx = lin & (m.vps - 1);
+  const int ly = (lin >> m.vps_log2) & (m.vps - 1);
+  const int lz = lin >> (2 * m.vps_log2);
+  const l3 g{(long long)m.blk_idx[3 * slot] * m.vps + lx,
+             (long long)m.blk_idx[3 * slot + 1] * m.vps + ly,
+             (long long)m.blk_idx[3 * slot + 2] * m.vps + lz};
+
+  float d = m.dist[gid];
+  float W = m.weight[gid];
+  uint32_t col = m.rgba[gid];
+  size_t j = i;
+  uint64_t kj = key;
+  while (true) {
+    const uint32_t o = (uint32_t)(kj & 0xFFFFFFFFu);
+    const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+    tsdf_update(c, m.voxel_size, pg, g, tab.rgba[o], tab.w[o], d, W, col);
+    ++j;
+    if (j >= n) break;
+    kj = keys[j];
+    if ((uint32_t)(kj >> 32) != gid) break;
+  }
+  m.dist[gid] = d;
+  m.weight[gid] = W;
+  m.rgba[gid] = col;
+  atomicAdd(&st->voxels_touched, 1ull);
+}
+
+// ---------------------------------------------------------------------------
+// kernels: Merged integrator bundling (tsdf_integrator.cc:340-407)
+// ---------------------------------------------------------------------------
+// key[s] = clearing << 63 | packed endpoint voxel index; invalid points sort last.
+__global__ void k_merged_keys(RayTab pt, uint32_t n, MapDev m, uint64_t* keys, uint32_t* vals) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint8_t fl = pt.flags[s];
+  uint64_t key = ~0ull;
+  if (fl & 1) {
+    const l3 g = grid_index_from_point({pt.px[s], pt.py[s], pt.pz[s]}, m.voxel_size_inv);
+    key = ((uint64_t)(g.z + (1ll << 20)) << 42) | ((uint64_t)(g.y + (1ll << 20)) << 21) |
+          (uint64_t)(g.x + (1ll << 20));
+    if (fl & 2) key |= 1ull << 63;
+  }
+  keys[s] = key;
+  vals[s] = s;
+}
+
+// head[i] = 1 where a new bundle starts in the sorted (key, s) list.
+__global__ void k_merged_heads(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* head) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    head[i] = 0;
+    return;
+  }
+  const uint64_t k = keys[i];
+  head[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+// One thread per bundle: running weighted mean of point_C, blended colour, summed weight in
+// push_back (= visiting) order; clearing bundles take their first usable point only
+// (tsdf_integrator.cc:387-405); merged_point_G = T_G_C * merged_point_C (:407).
+__global__ void k_merged_bundle(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank,
+                                uint32_t n, RayTab pt, const float* __restrict__ pcx,
+                                const float* __restrict__ pcy, const float* __restrict__ pcz,
+                                Pose T, RayTab out, uint64_t* graze_keys, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const uint64_t key = keys[i];
+  const bool clearing = (key >> 63) != 0;
+  const uint32_t b = rank[i];
+  f3 mp{0.f, 0.f, 0.f};
+  uint32_t mc = 0;
+  float mw = 0.0f;
+  for (uint32_t j = i; j < n && keys[j] == key; ++j) {
+    const uint32_t s = vals[j];
+    const float pw = pt.w[s];
+    if (pw < 1e-6f) continue;
+    const f3 pc{pcx[s], pcy[s], pcz[s]};
+    const float tw = mw + pw;
+    mp = {(mp.x * mw + pc.x * pw) / tw, (mp.y * mw + pc.y * pw) / tw, (mp.z * mw + pc.z * pw) / tw};
+    mc = blend_two_colors(mc, mw, pt.rgba[s], pw);
+    mw += pw;
+    if (clearing) break;
+  }
+  const f3 pg = pose_transform(T, mp);
+  out.px[b] = pg.x;
+  out.py[b] = pg.y;
+  out.pz[b] = pg.z;
+  out.rgba[b] = mc;
+  out.w[b] = mw;
+  out.flags[b] = 1 | (clearing ? 2 : 0);
+  out.bkey[b] = key & ~(1ull << 63);
+  if (!clearing && graze_keys) graze_keys[b] = key;
+  (void)st;
+}
+
+// ---------------------------------------------------------------------------
+// kernels: Fast integrator (tsdf_integrator.cc:488-590)
+// ---------------------------------------------------------------------------
+// start_voxel_approx_set_.replaceHash(cell at start_voxel_subsampling_factor x resolution),
+// tsdf_integrator.cc:514-519.  key = slot << 32 | s so that a stable radix sort groups the
+// probes of one ApproxHashSet slot in visiting order; val = the 32-bit hash.
+__global__ void k_fast_keys(RayTab pt, uint32_t n, CastCfg c, uint64_t* keys, uint32_t* vals) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  uint64_t key = ~0ull;
+  uint32_t h = 0;
+  if (pt.flags[s] & 1) {
+    const l3 g = grid_index_from_point({pt.px[s], pt.py[s], pt.pz[s]}, c.start_factor_times_inv);
+    h = long_index_hash(g);
+    key = ((uint64_t)(h & 0xFFFFFu) << 32) | s;
+  }
+  keys[s] = key;
+  vals[s] = h;
+}
+
+// Exact replay of ApproxHashSet<20,10000>::replaceHash over the sorted probes
+// (approx_hash_array.h:125-134): a probe "replaces" iff the value it finds in its slot —
+// the previous probe's hash, or the slot's content from before this frame — differs from
+// its own hash; every probe leaves its hash behind.  set_vals mirrors pseudo_set_ at
+// offset_ (u32 per slot; the u64 max() sentinel of slot 0 is tracked separately).
+__global__ void k_fast_start_dedupe(const uint64_t* __restrict__ keys,
+                                    const uint32_t* __restrict__ vals, uint32_t n,
+                                    const uint32_t* __restrict__ set_vals, uint32_t offset,
+                                    int sentinel_live, uint8_t* flags_by_s) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == ~0ull) return;
+  const uint32_t slot = (uint32_t)(key >> 32);
+  const uint32_t s = (uint32_t)(key & 0xFFFFFFFFu);
+  const uint32_t h = vals[i];
+  bool replaced;
+  if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == slot) {
+    replaced = (vals[i - 1] != h);
+  } else {
+    const uint32_t ai = slot + offset;
+    if (ai == 0 && sentinel_live) replaced = true;  // slot holds size_t max()
+    else replaced = (set_vals[ai] != h);
+  }
+  if (!replaced) flags_by_s[s] &= ~1;  // `continue` at tsdf_integrator.cc:517-519
+}
+// Second half of the replay: the last probe of every slot leaves its hash in the set
+// (separate launch so that no thread can read a slot after this frame has written it).
+__global__ void k_fast_start_commit(const uint64_t* __restrict__ keys,
+                                    const uint32_t* __restrict__ vals, uint32_t n,
+                                    uint32_t* set_vals, uint32_t offset, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == ~0ull) return;
+  const uint32_t slot = (uint32_t)(key >> 32);
+  const bool last = (i + 1 >= n) || ((uint32_t)(keys[i + 1] >> 32) != slot);
+  if (last) {
+    set_vals[slot + offset] = vals[i];
+    if (slot + offset == 0) st->sentinel_cleared = 1;
+  }
+}
+
+// Compacts the rays that survive the start-voxel test, keeping visiting order.
+__global__ void k_compact_flags(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* keep) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > n) return;
+  keep[s] = (s < n && (flags[s] & 1)) ? 1u : 0u;
+}
+__global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
+                               const uint32_t* __restrict__ pos, uint32_t n, RayTab out,
+                               DevState* st) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  if (s == n - 1) st->num_kept = pos[s] + keep[s];
+  if (!keep[s]) return;
+  const uint32_t r = pos[s];
+  out.px[r] = in.px[s];
+  out.py[r] = in.py[s];
+  out.pz[r] = in.pz[s];
+  out.rgba[r] = in.rgba[s];
+  out.w[r] = in.w[s];
+  out.flags[r] = in.flags[s];
+}
+
+// Early-termination solver.  With an exact observed-set, "voxel already observed when ray r
+// probes it" == "some ray r' < r reaches that voxel", i.e. owner(v) = min{r' reaching v} < r.
+// Which voxels a ray reaches depends on where it terminates, which depends on the owners of
+// the voxels ahead of it — a fixed point, unique because dependencies only run from lower to
+// higher r.  One sweep = every ray re-walks against the owners of the previous sweep and
+// publishes the owners for the next one (atomicMin); repeat until no termination step moves.
+// Owner entries carry a descending sweep tag in their high bits so that the two ping-pong
+// arrays never need clearing.  (tsdf_integrator.cc:531-551)
+__global__ void k_fast_sweep(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ own_rd,
+                             uint32_t* own_wr, uint32_t tag_rd, uint32_t tag_wr, int s_bits,
+                             uint32_t* T, uint32_t* U, int first, DevState* st) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= tab.R) return;
+  RayCaster rc;
+  if (!ray_init(rc, tab, r, c, m, /*from_origin=*/false, nullptr)) return;
+  const uint32_t smask = (1u << s_bits) - 1;
+  uint64_t last_key = kEmptyKey;
+  uint32_t slot = kInvalidSlot;
+  int cons = 0;
+  uint32_t k = 0, t_end = 0, u_end = 0;
+  bool broke = false;
+  l3 g;
+  while (rc.next(&g)) {
+    const i3 b = block_index_from_global(g, m.vps_inv);
+    const uint64_t key = pack_block_key(b.x, b.y, b.z);
+    if (key != last_key) {
+      last_key = key;
+      slot = map_find(m, key);
+    }
+    uint32_t gid = 0;
+    bool present = false;
+    if (slot != kInvalidSlot) {
+      const i3 l = local_from_global(g, m.vps);
+      gid = slot * m.nvox + (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
+      if (!first) {
+        const uint32_t ov = own_rd[gid];
+        present = ((ov >> s_bits) == tag_rd) && ((ov & smask) < r);
+      }
+    } else {
+      atomicOr(&st->error, 2u);
+    }
+    if (present) ++cons; else cons = 0;
+    if (cons > c.max_consecutive) {
+      t_end = k + 1;
+      u_end = k;
+      broke = true;
+      break;
+    }
+    if (slot != kInvalidSlot) atomicMin(&own_wr[gid], (tag_wr << s_bits) | r);
+    ++k;
+  }
+  if (!broke) {
+    t_end = k;
+    u_end = k;
+  }
+  if (first || T[r] != t_end || U[r] != u_end) {
+    T[r] = t_end;
+    U[r] = u_end;
+    if (!first) st->changed = 1;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct vbx_ctx {
+  int device = 0;
+  vbx_map_cfg mcfg{};
+  MapDev map{};
+  uint32_t hcap = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  DevState* d_state = nullptr;
+  DevState h_state{};
+  std::string err;
+
+  // pool / map storage
+  DBuf b_hkeys, b_hvals, b_dist, b_weight, b_rgba, b_blkidx, b_blkflags, b_freelist, b_newlist;
+  // per-call scratch
+  DBuf b_pts, b_cols;                                   // staged host input
+  DBuf t_px, t_py, t_pz, t_rgba, t_w, t_flags, t_bkey;  // ray table A (per point, order s)
+  DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
+  DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
+  DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
+  DBuf b_T, b_U;
+  // Fast integrator persistent state
+  DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
+  uint32_t start_offset = 0;
+  bool start_sentinel_live = true;
+  bool startset_init = false;
+  int64_t reset_counter = 0;  // tsdf_integrator.cc:564
+  DBuf b_own0, b_own1;
+  uint32_t own_tag = 0;  // descending
+  int own_s_bits = 0;
+
+  vbx_counters counters{};
+  bool timing = false;
+  hipEvent_t ev[8] = {};
+  bool ev_hit[8] = {};
+  vbx_timing last_timing{};
+
+  void fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+  }
+};
+
+namespace {
+
+inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+int sync_state(vbx_ctx* ctx) {
+  HIP_TRY(hipMemcpyAsync(&ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VBX_OK;
+}
+
+int check_state_error(vbx_ctx* ctx) {
+  if (ctx->h_state.error & 1u) {
+    ctx->fail("block pool / hash map capacity exceeded (max_blocks=%u)", ctx->map.cap_blocks);
+    return VBX_ERR_CAPACITY;
+  }
+  if (ctx->h_state.error & 2u) {
+    ctx->fail("internal: ray march hit a block without a pool slot");
+    return VBX_ERR_HIP;
+  }
+  return VBX_OK;
+}
+
+RayTab make_tab(vbx_ctx* ctx, bool second, uint32_t R) {
+  RayTab t;
+  if (!second) {
+    t.px = ctx->t_px.as<float>(); t.py = ctx->t_py.as<float>(); t.pz = ctx->t_pz.as<float>();
+    t.rgba = ctx->t_rgba.as<uint32_t>(); t.w = ctx->t_w.as<float>();
+    t.flags = ctx->t_flags.as<uint8_t>(); t.bkey = ctx->t_bkey.as<uint64_t>();
+  } else {
+    t.px = ctx->u_px.as<float>(); t.py = ctx->u_py.as<float>(); t.pz = ctx->u_pz.as<float>();
+    t.rgba = ctx->u_rgba.as<uint32_t>(); t.w = ctx->u_w.as<float>();
+    t.flags = ctx->u_flags.as<uint8_t>(); t.bkey = ctx->u_bkey.as<uint64_t>();
+  }
+  t.R = R;
+  return t;
+}
+
+int ensure_tab(vbx_ctx* ctx, bool second, size_t R, bool with_bkey) {
+  const size_t n = R + 1;
+  if (!second) {
+    HIP_TRY(ctx->t_px.ensure(n * 4)); HIP_TRY(ctx->t_py.ensure(n * 4)); HIP_TRY(ctx->t_pz.ensure(n * 4));
+    HIP_TRY(ctx->t_rgba.ensure(n * 4)); HIP_TRY(ctx->t_w.ensure(n * 4)); HIP_TRY(ctx->t_flags.ensure(n));
+    if (with_bkey) HIP_TRY(ctx->t_bkey.ensure(n * 8));
+  } else {
+    HIP_TRY(ctx->u_px.ensure(n * 4)); HIP_TRY(ctx->u_py.ensure(n * 4)); HIP_TRY(ctx->u_pz.ensure(n * 4));
+    HIP_TRY(ctx->u_rgba.ensure(n * 4)); HIP_TRY(ctx->u_w.ensure(n * 4)); HIP_TRY(ctx->u_flags.ensure(n));
+    if (with_bkey) HIP_TRY(ctx->u_bkey.ensure(n * 8));
+  }
+  return VBX_OK;
+}
+
+// rocPRIM is used only for the two generic primitives of the pipeline (LSD radix sort,
+// exclusive scan); everything domain-specific is a kernel in this file.
+int sort_keys(vbx_ctx* ctx, uint64_t* in, uint64_t* out, size_t n, unsigned begin_bit,
+              unsigned end_bit) {
+  size_t tmp = 0;
+  HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
+  HIP_TRY(ctx->b_tmp.ensure(tmp));
+  HIP_TRY(rocprim::radix_sort_keys(ctx->b_tmp.p, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
+  return VBX_OK;
+}
+int sort_pairs(vbx_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
+               unsigned begin_bit, unsigned end_bit) {
+  size_t tmp = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
+                                    ctx->stream));
+  HIP_TRY(ctx->b_tmp.ensure(tmp));
+  HIP_TRY(rocprim::radix_sort_pairs(ctx->b_tmp.p, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
+                                    ctx->stream));
+  return VBX_OK;
+}
+int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
+  size_t tmp = 0;
+  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
+  HIP_TRY(ctx->b_tmp.ensure(tmp));
+  HIP_TRY(rocprim::exclusive_scan(ctx->b_tmp.p, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(),
+                                  ctx->stream));
+  return VBX_OK;
+}
+
+inline unsigned bits_for(uint64_t v) {
+  unsigned b = 1;
+  while (b < 64 && (v >> b)) ++b;
+  return b;
+}
+
+void tmark(vbx_ctx* ctx, int i) {
+  if (ctx->timing) {
+    (void)hipEventRecord(ctx->ev[i], ctx->stream);
+    ctx->ev_hit[i] = true;
+  }
+}
+
+CastCfg make_cast_cfg(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float pos[3]) {
+  CastCfg c{};
+  c.origin = {pos[0], pos[1], pos[2]};
+  c.trunc = cfg->default_truncation_distance;
+  c.max_ray_length_m = cfg->max_ray_length_m;
+  c.min_ray_length_m = cfg->min_ray_length_m;
+  c.max_weight = cfg->max_weight;
+  c.sparsity_factor = cfg->sparsity_compensation_factor;
+  c.carving = cfg->voxel_carving_enabled != 0;
+  // tsdf_integrator.cc:62-65: clearing rays have no utility if voxel_carving is disabled
+  c.allow_clear = (cfg->allow_clear != 0) && (cfg->voxel_carving_enabled != 0);
+  c.use_const_weight = cfg->use_const_weight != 0;
+  c.dropoff = cfg->use_weight_dropoff != 0;
+  c.sparsity = cfg->use_sparsity_compensation_factor != 0;
+  c.anti_grazing = cfg->enable_anti_grazing != 0;
+  c.max_consecutive = cfg->max_consecutive_ray_collisions;
+  c.start_factor_times_inv = cfg->start_voxel_subsampling_factor * ctx->map.voxel_size_inv;
+  return c;
+}
+
+// Shared tail of all three integrators: allocate blocks along the rays, emit ordered voxel
+// keys, sort, fold.  `limit` (optional) bounds the number of voxels each ray visits.
+int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_origin,
+                   const uint32_t* limit, bool blocks_already_marked, const uint64_t* graze_keys,
+                   uint32_t n_graze) {
+  const uint32_t R = tab.R;
+  if (R == 0) return VBX_OK;
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+
+  HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
+  hipLaunchKernelGGL(k_ray_count, grid_for(R + 1), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0,
+                     limit, ctx->b_cnt.as<uint32_t>());
+  int rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
+  if (rc) return rc;
+  if (!blocks_already_marked) {
+    hipLaunchKernelGGL(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, tab, c, m,
+                       from_origin ? 1 : 0, limit, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+    hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+                       ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+    hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  }
+  tmark(ctx, 2);
+  // total number of keys = off[R]
+  uint32_t total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, ctx->b_off.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  rc = check_state_error(ctx);
+  if (rc) return rc;
+  if (total == 0) return VBX_OK;
+
+  HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
+  HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));
+  hipLaunchKernelGGL(k_ray_emit, grid_for(R), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0, limit,
+                     ctx->b_off.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), graze_keys, n_graze,
+                     ctx->d_state);
+  tmark(ctx, 4);
+  const unsigned end_bit = 32 + bits_for((uint64_t)m.cap_blocks * m.nvox);
+  rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 0,
+                 std::min(64u, end_bit + 1));
+  if (rc) return rc;
+  tmark(ctx, 5);
+  hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     (size_t)total, tab, c, m, ctx->d_state);
+  tmark(ctx, 6);
+  ctx->counters.voxel_updates = total;
+  return VBX_OK;
+}
+
+int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
+                     const uint32_t* d_rgba, size_t n, int freespace) {
+  CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  int rc = ensure_tab(ctx, false, n, false);
+  if (rc) return rc;
+  RayTab tab = make_tab(ctx, false, (uint32_t)n);
+  tab.bkey = nullptr;
+  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
+                     freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  tmark(ctx, 1);
+  return march_and_fold(ctx, tab, c, /*from_origin=*/true, nullptr, false, nullptr, 0);
+}
+
+int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
+                     const uint32_t* d_rgba, size_t n, int freespace) {
+  CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  hipStream_t s = ctx->stream;
+  int rc = ensure_tab(ctx, false, n, false);
+  if (rc) return rc;
+  HIP_TRY(ctx->b_pcx.ensure(n * 4)); HIP_TRY(ctx->b_pcy.ensure(n * 4)); HIP_TRY(ctx->b_pcz.ensure(n * 4));
+  RayTab pt = make_tab(ctx, false, (uint32_t)n);
+  pt.bkey = nullptr;
+  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
+                     pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>());
+  // bundleRays (tsdf_integrator.cc:340-371): group points by endpoint voxel.  A stable sort
+  // of (key, s) keeps each bundle's points in visiting order.
+  HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
+  HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
+  hipLaunchKernelGGL(k_merged_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, ctx->map,
+                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
+  rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(),
+                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 0, 64);
+  if (rc) return rc;
+  HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
+  hipLaunchKernelGGL(k_merged_heads, grid_for(n + 1), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     (uint32_t)n, ctx->b_head.as<uint32_t>());
+  rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
+  if (rc) return rc;
+  uint32_t nb = 0;
+  HIP_TRY(hipMemcpyAsync(&nb, ctx->b_rank.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (nb == 0) return VBX_OK;
+  rc = ensure_tab(ctx, true, nb, true);
+  if (rc) return rc;
+  HIP_TRY(ctx->b_graze.ensure((size_t)nb * 8));
+  HIP_TRY(hipMemsetAsync(ctx->b_graze.p, 0xFF, (size_t)nb * 8, s));
+  RayTab bt = make_tab(ctx, true, nb);
+  hipLaunchKernelGGL(k_merged_bundle, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(),
+                     ctx->b_rank.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(),
+                     ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), T, bt,
+                     ctx->b_graze.as<uint64_t>(), ctx->d_state);
+  tmark(ctx, 1);
+  // Non-clearing bundles sort before clearing ones (bit 63), so the graze key list is the
+  // sorted prefix of non-clearing bundle keys; entries of clearing bundles stay ~0 (sorted last).
+  const uint64_t* graze = c.anti_grazing ? ctx->b_graze.as<uint64_t>() : nullptr;
+  return march_and_fold(ctx, bt, c, /*from_origin=*/true, nullptr, false, graze, nb);
+}
+
+int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
+                   const uint32_t* d_rgba, size_t n, int freespace) {
+  if (cfg->clear_checks_every_n_frames != 1) {
+    ctx->fail("Fast integrator: clear_checks_every_n_frames != 1 is not supported yet");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  constexpr uint32_t kSetSize = (1u << 20) + 10000u;
+  if (!ctx->startset_init) {
+    HIP_TRY(ctx->b_startset.ensure((size_t)kSetSize * 4));
+    HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
+    ctx->startset_init = true;
+    ctx->start_offset = 0;
+    ctx->start_sentinel_live = true;
+  }
+  // tsdf_integrator.cc:564-569 + ApproxHashSet::resetApproxSet (approx_hash_array.h:156-169)
+  if ((++ctx->reset_counter) >= cfg->clear_checks_every_n_frames) {
+    ctx->reset_counter = 0;
+    if (++ctx->start_offset >= 10000u) {
+      HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
+      ctx->start_offset = 0;
+      ctx->start_sentinel_live = true;
+    }
+  }
+
+  int rc = ensure_tab(ctx, false, n, false);
+  if (rc) return rc;
+  RayTab pt = make_tab(ctx, false, (uint32_t)n);
+  pt.bkey = nullptr;
+  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
+                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
+  HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
+  hipLaunchKernelGGL(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,
+                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
+  rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(),
+                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 0, 64);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_fast_start_dedupe, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
+                     ctx->start_offset, ctx->start_sentinel_live ? 1 : 0, pt.flags);
+  hipLaunchKernelGGL(k_fast_start_commit, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
+                     ctx->start_offset, ctx->d_state);
+  HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
+  hipLaunchKernelGGL(k_compact_flags, grid_for(n + 1), dim3(256), 0, s, pt.flags, (uint32_t)n,
+                     ctx->b_head.as<uint32_t>());
+  rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
+  if (rc) return rc;
+  rc = ensure_tab(ctx, true, n, false);
+  if (rc) return rc;
+  RayTab kt = make_tab(ctx, true, 0);
+  kt.bkey = nullptr;
+  hipLaunchKernelGGL(k_compact_rays, grid_for(n), dim3(256), 0, s, pt, ctx->b_head.as<uint32_t>(),
+                     ctx->b_rank.as<uint32_t>(), (uint32_t)n, kt, ctx->d_state);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  if (ctx->h_state.sentinel_cleared) ctx->start_sentinel_live = false;
+  const uint32_t R = (uint32_t)ctx->h_state.num_kept;
+  kt.R = R;
+  tmark(ctx, 1);
+  if (R == 0) return VBX_OK;
+
+  // Candidate blocks along the full (unterminated) paths; a block only becomes part of the
+  // Layer ("published") when a ray actually reaches it in k_ray_emit.
+  hipLaunchKernelGGL(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, kt, c, m, 0,
+                     (const uint32_t*)nullptr, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  tmark(ctx, 2);
+
+  // owner arrays + tags
+  const size_t nvox_total = (size_t)m.cap_blocks * m.nvox;
+  const int s_bits = (int)bits_for(std::max<uint32_t>(R, 2) - 1);
+  const bool fresh = (ctx->b_own0.p == nullptr);
+  HIP_TRY(ctx->b_own0.ensure(nvox_total * 4));
+  HIP_TRY(ctx->b_own1.ensure(nvox_total * 4));
+  const uint32_t max_tag = (1u << (32 - s_bits)) - 2;
+  if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 4) {
+    HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
+    ctx->own_s_bits = s_bits;
+    ctx->own_tag = max_tag;
+  }
+  HIP_TRY(ctx->b_T.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_U.ensure((size_t)(R + 1) * 4));
+  uint32_t iters = 0;
+  uint32_t tag_prev = 0xFFFFFFFFu;
+  for (;;) {
+    if (ctx->own_tag < 2) {  // tag space exhausted mid-call: restart the tag range
+      HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
+      HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
+      ctx->own_tag = max_tag;
+      iters = 0;  // previous sweeps' owners are gone: start over
+      tag_prev = 0xFFFFFFFFu;
+    }
+    const uint32_t tag = --ctx->own_tag;
+    uint32_t* rd = (iters & 1) ? ctx->b_own0.as<uint32_t>() : ctx->b_own1.as<uint32_t>();
+    uint32_t* wr = (iters & 1) ? ctx->b_own1.as<uint32_t>() : ctx->b_own0.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+    hipLaunchKernelGGL(k_fast_sweep, grid_for(R), dim3(256), 0, s, kt, c, m, rd, wr, tag_prev, tag,
+                       s_bits, ctx->b_T.as<uint32_t>(), ctx->b_U.as<uint32_t>(), iters == 0 ? 1 : 0,
+                       ctx->d_state);
+    tag_prev = tag;
+    ++iters;
+    if (iters == 1) continue;
+    rc = sync_state(ctx);
+    if (rc) return rc;
+    rc = check_state_error(ctx);
+    if (rc) return rc;
+    if (!ctx->h_state.changed) break;
+    if (iters > 100000) {
+      ctx->fail("Fast integrator: early-termination solver did not converge");
+      return VBX_ERR_HIP;
+    }
+  }
+  ctx->counters.iterations = iters;
+  tmark(ctx, 3);
+  return march_and_fold(ctx, kt, c, /*from_origin=*/false, ctx->b_U.as<uint32_t>(), true, nullptr, 0);
+}
+
+int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
+                     const float quat[4], const float* d_pts, const uint8_t* d_rgba, size_t n,
+                     int freespace) {
+  if (!cfg || !pos || !quat || (n && (!d_pts || !d_rgba))) {
+    ctx->fail("vbx_tsdf_integrate: null argument");
+    return VBX_ERR_INVALID;
+  }
+  if (n >= (1ull << 31)) {
+    ctx->fail("vbx_tsdf_integrate: too many points");
+    return VBX_ERR_INVALID;
+  }
+  if (cfg->integration_order_mode != 0) {
+    ctx->fail("integration_order_mode 'sorted' is not supported yet");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->counters = vbx_counters{};
+  ctx->counters.points = n;
+  if (n == 0) return VBX_OK;
+  // per-call device counters
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, offsetof(DevState, total_keys) - offsetof(DevState, error), ctx->stream));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->total_keys, 0, sizeof(DevState) - offsetof(DevState, total_keys), ctx->stream));
+  Pose T;
+  T.t = {pos[0], pos[1], pos[2]};
+  T.qw = quat[0]; T.qx = quat[1]; T.qy = quat[2]; T.qz = quat[3];
+  for (int i = 0; i < 8; ++i) ctx->ev_hit[i] = false;
+  tmark(ctx, 0);
+  int rc;
+  const uint32_t* rgba32 = reinterpret_cast<const uint32_t*>(d_rgba);
+  switch (kind) {
+    case VBX_TSDF_SIMPLE: rc = integrate_simple(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
+    case VBX_TSDF_MERGED: rc = integrate_merged(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
+    case VBX_TSDF_FAST: rc = integrate_fast(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
+    default:
+      ctx->fail("unknown TSDF integrator type %d", kind);  // tsdf_integrator.cc:40-43
+      return VBX_ERR_INVALID;
+  }
+  if (rc) return rc;
+  tmark(ctx, 7);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  rc = check_state_error(ctx);
+  if (rc) return rc;
+  ctx->counters.rays_cast = ctx->h_state.rays_cast;
+  ctx->counters.voxels_touched = ctx->h_state.voxels_touched;
+  ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
+  if (ctx->timing) {
+    float t[8] = {0};
+    int last = 0;
+    for (int i = 1; i < 8; ++i) {  // a stage a path skips reads as zero-length
+      if (!ctx->ev_hit[i]) continue;
+      (void)hipEventElapsedTime(&t[i], ctx->ev[last], ctx->ev[i]);
+      last = i;
+    }
+    vbx_timing& o = ctx->last_timing;
+    o.prep_ms = t[1]; o.alloc_ms = t[2]; o.solve_ms = t[3]; o.emit_ms = t[4];
+    o.sort_ms = t[5]; o.fold_ms = t[6];
+    (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
+  }
+  return VBX_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+void vbx_tsdf_cfg_default(vbx_tsdf_cfg* c) {  // tsdf_integrator.h:59-86
+  c->default_truncation_distance = 0.1f;
+  c->max_weight = 10000.0f;
+  c->voxel_carving_enabled = 1;
+  c->min_ray_length_m = 0.1f;
+  c->max_ray_length_m = 5.0f;
+  c->use_const_weight = 0;
+  c->allow_clear = 1;
+  c->use_weight_dropoff = 1;
+  c->use_sparsity_compensation_factor = 0;
+  c->sparsity_compensation_factor = 1.0f;
+  c->integrator_threads = 1;
+  c->integration_order_mode = 0;
+  c->enable_anti_grazing = 0;
+  c->start_voxel_subsampling_factor = 2.0f;
+  c->max_consecutive_ray_collisions = 2;
+  c->clear_checks_every_n_frames = 1;
+  c->max_integration_time_s = 3.402823466e+38f;
+}
+
+void vbx_esdf_cfg_default(vbx_esdf_cfg* c) {  // esdf_integrator.h:37-77
+  c->full_euclidean_distance = 0;
+  c->max_distance_m = 2.0f;
+  c->min_distance_m = 0.2f;
+  c->default_distance_m = 2.0f;
+  c->min_diff_m = 0.001f;
+  c->min_weight = 1e-6f;
+  c->num_buckets = 20;
+  c->multi_queue = 0;
+  c->add_occupied_crust = 0;
+  c->clear_sphere_radius = 1.5f;
+  c->occupied_sphere_radius = 5.0f;
+}
+
+const char* vbx_last_error(vbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+vbx_ctx* vbx_create(const vbx_map_cfg* cfg, int device) {
+  auto bail = [](vbx_ctx* c, const std::string& msg) -> vbx_ctx* {
+    g_create_error = msg;
+    if (c) vbx_destroy(c);
+    return nullptr;
+  };
+  if (!cfg || !(cfg->voxel_size > 0.0f)) return bail(nullptr, "vbx_create: voxel_size must be > 0");
+  const uint32_t vps = cfg->voxels_per_side;
+  if (vps < 4 || vps > 32 || (vps & (vps - 1))) return bail(nullptr, "vbx_create: voxels_per_side must be a power of two in [4,32]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return bail(nullptr, "vbx_create: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return bail(nullptr, "vbx_create: bad device ordinal");
+  if (hipSetDevice(device) != hipSuccess) return bail(nullptr, "vbx_create: hipSetDevice failed");
+
+  vbx_ctx* ctx = new vbx_ctx;
+  ctx->device = device;
+  ctx->mcfg = *cfg;
+  if (ctx->mcfg.max_blocks == 0) ctx->mcfg.max_blocks = 65536;
+  MapDev& m = ctx->map;
+  m.cap_blocks = ctx->mcfg.max_blocks;
+  m.vps = (int)vps;
+  m.vps_log2 = (int)bits_for(vps) - 1;
+  m.nvox = vps * vps * vps;
+  if ((uint64_t)m.cap_blocks * m.nvox >= (1ull << 32)) {
+    return bail(ctx, "vbx_create: max_blocks * voxels_per_side^3 must be < 2^32");
+  }
+  // Derived constants exactly as Layer's constructor / TsdfIntegratorBase::setLayer compute
+  // them (layer.h:34-44, tsdf_integrator.cc:73-79): double division, rounded to float.
+  m.voxel_size = cfg->voxel_size;
+  m.voxel_size_inv = (float)(1.0 / (double)cfg->voxel_size);
+  m.vps_inv = (float)(1.0 / (double)vps);
+  uint32_t hcap = 1;
+  while (hcap < 4u * m.cap_blocks) hcap <<= 1;
+  ctx->hcap = hcap;
+  m.hmask = hcap - 1;
+
+  auto ok = [&](hipError_t e) { return e == hipSuccess; };
+  const size_t nv = (size_t)m.cap_blocks * m.nvox;
+  if (!ok(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)))
+    return bail(ctx, "vbx_create: hipStreamCreate failed");
+  ctx->stream = ctx->own_stream;
+  if (!ok(ctx->b_hkeys.ensure((size_t)hcap * 8)) || !ok(ctx->b_hvals.ensure((size_t)hcap * 4)) ||
+      !ok(ctx->b_dist.ensure(nv * 4)) || !ok(ctx->b_weight.ensure(nv * 4)) ||
+      !ok(ctx->b_rgba.ensure(nv * 4)) || !ok(ctx->b_blkidx.ensure((size_t)m.cap_blocks * 12)) ||
+      !ok(ctx->b_blkflags.ensure((size_t)m.cap_blocks * 4)) ||
+      !ok(ctx->b_freelist.ensure((size_t)m.cap_blocks * 4)) ||
+      !ok(ctx->b_newlist.ensure((size_t)m.cap_blocks * 4)) ||
+      !ok(hipMalloc((void**)&ctx->d_state, sizeof(DevState))))
+    return bail(ctx, "vbx_create: out of device memory for the block pool");
+  m.hkeys = ctx->b_hkeys.as<uint64_t>();
+  m.hvals = ctx->b_hvals.as<uint32_t>();
+  m.dist = ctx->b_dist.as<float>();
+  m.weight = ctx->b_weight.as<float>();
+  m.rgba = ctx->b_rgba.as<uint32_t>();
+  m.blk_idx = ctx->b_blkidx.as<int32_t>();
+  m.blk_flags = ctx->b_blkflags.as<uint32_t>();
+  m.free_list = ctx->b_freelist.as<uint32_t>();
+  hipStream_t s = ctx->stream;
+  bool good = ok(hipMemsetAsync(m.hkeys, 0xFF, (size_t)hcap * 8, s)) &&
+              ok(hipMemsetAsync(m.hvals, 0xFF, (size_t)hcap * 4, s)) &&
+              ok(hipMemsetAsync(m.dist, 0, nv * 4, s)) && ok(hipMemsetAsync(m.weight, 0, nv * 4, s)) &&
+              ok(hipMemsetAsync(m.rgba, 0, nv * 4, s)) &&
+              ok(hipMemsetAsync(m.blk_flags, 0, (size_t)m.cap_blocks * 4, s)) &&
+              ok(hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), s));
+  for (int i = 0; i < 8 && good; ++i) good = ok(hipEventCreate(&ctx->ev[i]));
+  good = good && ok(hipStreamSynchronize(s));
+  if (!good) return bail(ctx, "vbx_create: device initialisation failed");
+  return ctx;
+}
+
+void vbx_destroy(vbx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+  DBuf* bufs[] = {&ctx->b_hkeys, &ctx->b_hvals, &ctx->b_dist, &ctx->b_weight, &ctx->b_rgba,
+                  &ctx->b_blkidx, &ctx->b_blkflags, &ctx->b_freelist, &ctx->b_newlist, &ctx->b_pts,
+                  &ctx->b_cols, &ctx->t_px, &ctx->t_py, &ctx->t_pz, &ctx->t_rgba, &ctx->t_w,
+                  &ctx->t_flags, &ctx->t_bkey, &ctx->u_px, &ctx->u_py, &ctx->u_pz, &ctx->u_rgba,
+                  &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
+                  &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
+                  &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
+                  &ctx->b_U, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1};
+  for (DBuf* b : bufs) b->release();
+  if (ctx->d_state) (void)hipFree(ctx->d_state);
+  for (int i = 0; i < 8; ++i)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int vbx_set_stream(vbx_ctx* ctx, void* hip_stream) {
+  if (!ctx) return VBX_ERR_INVALID;
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return VBX_OK;
+}
+
+int vbx_tsdf_integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
+                              const float quat[4], const float* d_points_C, const uint8_t* d_rgba,
+                              size_t n, int freespace_points) {
+  if (!ctx) return VBX_ERR_INVALID;
+  return integrate_device(ctx, kind, cfg, pos, quat, d_points_C, d_rgba, n, freespace_points);
+}
+
+int vbx_tsdf_integrate(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
+                       const float quat[4], const float* points_C, const uint8_t* rgba, size_t n,
+                       int freespace_points) {
+  if (!ctx) return VBX_ERR_INVALID;
+  if (n && (!points_C || !rgba)) {
+    ctx->fail("vbx_tsdf_integrate: null input");
+    return VBX_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n) {
+    HIP_TRY(ctx->b_pts.ensure(n * 12));
+    HIP_TRY(ctx->b_cols.ensure(n * 4));
+    HIP_TRY(hipMemcpyAsync(ctx->b_pts.p, points_C, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->b_cols.p, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return integrate_device(ctx, kind, cfg, pos, quat, ctx->b_pts.as<float>(),
+                          ctx->b_cols.as<uint8_t>(), n, freespace_points);
+}
+
+int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
+  if (!ctx) return VBX_ERR_INVALID;
+  (void)cfg; (void)batch; (void)clear_updated_flag;
+  ctx->fail("vbx_esdf_update: not implemented yet");
+  return VBX_ERR_UNSUPPORTED;
+}
+
+// ---- block listing / transfer --------------------------------------------------------
+static int list_blocks(vbx_ctx* ctx, int layer, uint32_t need_mask, std::vector<std::pair<uint64_t, uint32_t>>* out) {
+  if (layer != VBX_LAYER_TSDF) {
+    ctx->fail("ESDF layer not implemented yet");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  std::vector<uint32_t> flags(used);
+  std::vector<int32_t> idx((size_t)used * 3);
+  if (used) {
+    HIP_TRY(hipMemcpy(flags.data(), ctx->map.blk_flags, (size_t)used * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(idx.data(), ctx->map.blk_idx, (size_t)used * 12, hipMemcpyDeviceToHost));
+  }
+  out->clear();
+  for (uint32_t sl = 0; sl < used; ++sl) {
+    if (!(flags[sl] & kFlagPublished)) continue;
+    if (need_mask && !(flags[sl] & need_mask)) continue;
+    out->emplace_back(pack_block_key(idx[3 * sl], idx[3 * sl + 1], idx[3 * sl + 2]), sl);
+  }
+  std::sort(out->begin(), out->end());
+  return VBX_OK;
+}
+
+int vbx_num_blocks(vbx_ctx* ctx, int layer, size_t* n) {
+  if (!ctx || !n) return VBX_ERR_INVALID;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  int rc = list_blocks(ctx, layer, 0, &v);
+  if (rc) return rc;
+  *n = v.size();
+  return VBX_OK;
+}
+
+static int emit_list(const std::vector<std::pair<uint64_t, uint32_t>>& v, int32_t* idx, size_t cap, size_t* n) {
+  *n = v.size();
+  for (size_t i = 0; i < v.size() && i < cap; ++i) {
+    int x, y, z;
+    unpack_block_key(v[i].first, &x, &y, &z);
+    idx[3 * i] = x; idx[3 * i + 1] = y; idx[3 * i + 2] = z;
+  }
+  return VBX_OK;
+}
+
+int vbx_block_indices(vbx_ctx* ctx, int layer, int32_t* idx, size_t cap, size_t* n) {
+  if (!ctx || !n || (cap && !idx)) return VBX_ERR_INVALID;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  int rc = list_blocks(ctx, layer, 0, &v);
+  if (rc) return rc;
+  return emit_list(v, idx, cap, n);
+}
+
+int vbx_blocks_updated(vbx_ctx* ctx, int layer, int update_mask, int32_t* idx, size_t cap, size_t* n) {
+  if (!ctx || !n || (cap && !idx)) return VBX_ERR_INVALID;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  int rc = list_blocks(ctx, layer, (uint32_t)update_mask & kFlagUpdMask, &v);
+  if (rc) return rc;
+  return emit_list(v, idx, cap, n);
+}
+
+static int find_slot_host(vbx_ctx* ctx, const int32_t idx[3], uint32_t* slot, uint32_t* hpos) {
+  // host-side probe of the device hash map (small D2H reads; not on the hot path)
+  const uint64_t key = pack_block_key(idx[0], idx[1], idx[2]);
+  uint32_t h = mix_key(key) & ctx->map.hmask;
+  for (uint32_t probes = 0; probes <= ctx->map.hmask; ++probes) {
+    uint64_t k;
+    HIP_TRY(hipMemcpy(&k, ctx->map.hkeys + h, 8, hipMemcpyDeviceToHost));
+    if (k == key) {
+      HIP_TRY(hipMemcpy(slot, ctx->map.hvals + h, 4, hipMemcpyDeviceToHost));
+      if (hpos) *hpos = h;
+      return VBX_OK;
+    }
+    if (k == kEmptyKey) break;
+    h = (h + 1) & ctx->map.hmask;
+  }
+  *slot = kInvalidSlot;
+  return VBX_OK;
+}
+
+int vbx_block_download(vbx_ctx* ctx, int layer, const int32_t idx[3], void* aos, uint8_t* updated_bits,
+                       uint8_t* has_data) {
+  if (!ctx || !idx || !aos) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF) {
+    ctx->fail("ESDF layer not implemented yet");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  uint32_t slot;
+  int rc = find_slot_host(ctx, idx, &slot, nullptr);
+  if (rc) return rc;
+  uint32_t flags = 0;
+  if (slot != kInvalidSlot) HIP_TRY(hipMemcpy(&flags, ctx->map.blk_flags + slot, 4, hipMemcpyDeviceToHost));
+  if (slot == kInvalidSlot || !(flags & kFlagPublished)) {
+    ctx->fail("block (%d,%d,%d) is not allocated", idx[0], idx[1], idx[2]);
+    return VBX_ERR_INVALID;
+  }
+  const uint32_t nv = ctx->map.nvox;
+  std::vector<float> d(nv), w(nv);
+  std::vector<uint32_t> c(nv);
+  HIP_TRY(hipMemcpy(d.data(), ctx->map.dist + (size_t)slot * nv, nv * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(w.data(), ctx->map.weight + (size_t)slot * nv, nv * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(c.data(), ctx->map.rgba + (size_t)slot * nv, nv * 4, hipMemcpyDeviceToHost));
+  uint8_t* o = static_cast<uint8_t*>(aos);
+  for (uint32_t i = 0; i < nv; ++i) {  // TsdfVoxel AoS, voxel.h:12-16
+    std::memcpy(o + 12 * i, &d[i], 4);
+    std::memcpy(o + 12 * i + 4, &w[i], 4);
+    std::memcpy(o + 12 * i + 8, &c[i], 4);
+  }
+  if (updated_bits) *updated_bits = (uint8_t)(flags & kFlagUpdMask);
+  if (has_data) *has_data = (flags & kFlagHasData) ? 1 : 0;
+  return VBX_OK;
+}
+
+int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos, uint8_t updated_bits,
+                     uint8_t has_data) {
+  if (!ctx || !idx || !aos) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF) {
+    ctx->fail("ESDF layer not implemented yet");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  uint32_t slot;
+  int rc = find_slot_host(ctx, idx, &slot, nullptr);
+  if (rc) return rc;
+  MapDev& m = ctx->map;
+  if (slot == kInvalidSlot) {
+    // host-side insert: take a slot from the free list or the bump pointer
+    rc = sync_state(ctx);
+    if (rc) return rc;
+    if (ctx->h_state.free_count > 0) {
+      HIP_TRY(hipMemcpy(&slot, m.free_list + (ctx->h_state.free_count - 1), 4, hipMemcpyDeviceToHost));
+      ctx->h_state.free_count--;
+    } else {
+      if (ctx->h_state.pool_used >= m.cap_blocks) {
+        ctx->fail("block pool full");
+        return VBX_ERR_CAPACITY;
+      }
+      slot = ctx->h_state.pool_used++;
+    }
+    HIP_TRY(hipMemcpy(&ctx->d_state->pool_used, &ctx->h_state.pool_used, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&ctx->d_state->free_count, &ctx->h_state.free_count, 4, hipMemcpyHostToDevice));
+    const uint64_t key = pack_block_key(idx[0], idx[1], idx[2]);
+    uint32_t h = mix_key(key) & m.hmask;
+    for (;;) {
+      uint64_t k;
+      HIP_TRY(hipMemcpy(&k, m.hkeys + h, 8, hipMemcpyDeviceToHost));
+      if (k == kEmptyKey) break;
+      h = (h + 1) & m.hmask;
+    }
+    HIP_TRY(hipMemcpy(m.hkeys + h, &key, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m.hvals + h, &slot, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m.blk_idx + 3 * slot, idx, 12, hipMemcpyHostToDevice));
+  }
+  const uint32_t nv = m.nvox;
+  std::vector<float> d(nv), w(nv);
+  std::vector<uint32_t> c(nv);
+  const uint8_t* in = static_cast<const uint8_t*>(aos);
+  for (uint32_t i = 0; i < nv; ++i) {
+    std::memcpy(&d[i], in + 12 * i, 4);
+    std::memcpy(&w[i], in + 12 * i + 4, 4);
+    std::memcpy(&c[i], in + 12 * i + 8, 4);
+  }
+  HIP_TRY(hipMemcpy(m.dist + (size_t)slot * nv, d.data(), nv * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m.weight + (size_t)slot * nv, w.data(), nv * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m.rgba + (size_t)slot * nv, c.data(), nv * 4, hipMemcpyHostToDevice));
+  const uint32_t flags = kFlagPublished | (updated_bits & kFlagUpdMask) | (has_data ? kFlagHasData : 0);
+  HIP_TRY(hipMemcpy(m.blk_flags + slot, &flags, 4, hipMemcpyHostToDevice));
+  return VBX_OK;
+}
+
+static int remove_slot(vbx_ctx* ctx, uint32_t slot, uint32_t hpos) {
+  // Unpublish and zero the block; the hash entry stays and keeps its slot, so the block is
+  // simply a zeroed "candidate" again (no tombstones, no free-list churn).
+  MapDev& m = ctx->map;
+  (void)hpos;
+  const uint32_t nv = m.nvox;
+  const uint32_t zero = 0;
+  HIP_TRY(hipMemset(m.dist + (size_t)slot * nv, 0, nv * 4));
+  HIP_TRY(hipMemset(m.weight + (size_t)slot * nv, 0, nv * 4));
+  HIP_TRY(hipMemset(m.rgba + (size_t)slot * nv, 0, nv * 4));
+  HIP_TRY(hipMemcpy(m.blk_flags + slot, &zero, 4, hipMemcpyHostToDevice));
+  return VBX_OK;
+}
+
+int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]) {
+  if (!ctx || !idx) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF) {
+    ctx->fail("ESDF layer not implemented yet");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  uint32_t slot, hpos = 0;
+  int rc = find_slot_host(ctx, idx, &slot, &hpos);
+  if (rc) return rc;
+  if (slot == kInvalidSlot) return VBX_OK;  // unordered_map::erase of a missing key is a no-op
+  return remove_slot(ctx, slot, hpos);
+}
+
+int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance) {
+  if (!ctx || !center) return VBX_ERR_INVALID;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  int rc = list_blocks(ctx, layer, 0, &v);
+  if (rc) return rc;
+  // Layer::removeDistantBlocks, layer.h:170-182: (origin - center).squaredNorm() > max^2 with
+  // origin = float(index) * block_size (common.h:195-201), block_size = voxel_size * vps.
+  const float block_size = ctx->map.voxel_size * (float)ctx->map.vps;
+  for (const auto& kv : v) {
+    int x, y, z;
+    unpack_block_key(kv.first, &x, &y, &z);
+    const f3 o{(float)x * block_size, (float)y * block_size, (float)z * block_size};
+    const f3 d = f3_sub(o, f3{center[0], center[1], center[2]});
+    if ((double)f3_sqnorm(d) > max_distance * max_distance) {
+      rc = remove_slot(ctx, kv.second, 0);
+      if (rc) return rc;
+    }
+  }
+  return VBX_OK;
+}
+
+int vbx_clear(vbx_ctx* ctx, int layer) {
+  if (!ctx) return VBX_ERR_INVALID;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  int rc = list_blocks(ctx, layer, 0, &v);
+  if (rc) return rc;
+  for (const auto& kv : v) {
+    rc = remove_slot(ctx, kv.second, 0);
+    if (rc) return rc;
+  }
+  return VBX_OK;
+}
+
+int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask) {
+  if (!ctx) return VBX_ERR_INVALID;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  int rc = list_blocks(ctx, layer, 0, &v);
+  if (rc) return rc;
+  for (const auto& kv : v) {
+    uint32_t f;
+    HIP_TRY(hipMemcpy(&f, ctx->map.blk_flags + kv.second, 4, hipMemcpyDeviceToHost));
+    f &= ~((uint32_t)update_mask & kFlagUpdMask);
+    HIP_TRY(hipMemcpy(ctx->map.blk_flags + kv.second, &f, 4, hipMemcpyHostToDevice));
+  }
+  return VBX_OK;
+}
+
+int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out) {
+  if (!ctx || !out) return VBX_ERR_INVALID;
+  *out = ctx->counters;
+  return VBX_OK;
+}
+int vbx_enable_timing(vbx_ctx* ctx, int enable) {
+  if (!ctx) return VBX_ERR_INVALID;
+  ctx->timing = enable != 0;
+  return VBX_OK;
+}
+int vbx_get_timing(vbx_ctx* ctx, vbx_timing* out) {
+  if (!ctx || !out) return VBX_ERR_INVALID;
+  *out = ctx->last_timing;
+  return VBX_OK;
+}
+
+}  // extern "C"
