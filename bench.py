@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py — Mpoints/s integrated by the HIP TSDF hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): FastTsdfIntegrator, 640x480 synthetic room-scan stream
+(voxblox_amd.scenes.room_frame), 0.05 m voxels / 16^3 blocks, truncation 4 voxels, all other
+Config defaults.  One "step" = one integratePointCloud() call on one 307,200-point frame
+whose points/colours are already resident in HBM (vbx_tsdf_integrate_device).
+
+Contract (see the task statement): W untimed warm-up steps, then exactly K timed steps
+bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints
+ONE JSON line.  For --gpus N every rank integrates its own sensor stream into its own map
+shard (weak scaling, no data-path collective in the timed region yet — see DESIGN.md §multi-GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+VOXEL = 0.05
+TRUNC = 4 * VOXEL
+N_STREAM = 100
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--integrator", default="fast", choices=["fast", "merged", "simple"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames, kind):
+    """Times the oracle (CPU restatement of the reference, reference threading scheme) on a
+    bounded sample of the same stream: threads = host cores, median frame after 3 warm-ups."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    cores = os.cpu_count() or 1
+    best = None
+    for threads in sorted({1, cores}):
+        O.lib().orc_fast_reset_counter_set(0)
+        m = O.OracleMap(VOXEL, 16)
+        it = m.tsdf_integrator(kind, O.tsdf_cfg(default_truncation_distance=TRUNC,
+                                                integrator_threads=threads))
+        ts = []
+        t_begin = time.time()
+        for i, (pose, pts, col) in enumerate(frames):
+            t0 = time.perf_counter()
+            it.integrate(pose[0], pose[1], pts, col)
+            ts.append(time.perf_counter() - t0)
+            if time.time() - t_begin > 15.0 and i >= 5:
+                break
+        used = ts[3:] if len(ts) > 4 else ts
+        med = float(np.median(used))
+        rec = dict(value=round(frames[0][1].shape[0] / med / 1e6, 3), threads=threads,
+                   frames=len(ts), median_ms=round(med * 1e3, 2))
+        if best is None or rec["value"] > best["value"]:
+            best = rec
+        del it, m
+    return {"value": best["value"], "unit": "Mpoints/s", "cores": best["threads"],
+            "kind": "port",
+            "sample": f"{best['frames']} frames of the same 640x480 room stream, {kind} integrator, "
+                      f"median frame {best['median_ms']} ms after 3 warm-up frames, "
+                      f"best of threads in {{1,{cores}}} (host has {cores} cores)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from voxblox_amd import capi, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    kind = {"fast": capi.TSDF_FAST, "merged": capi.TSDF_MERGED, "simple": capi.TSDF_SIMPLE}[args.integrator]
+
+    total = args.warmup + args.steps
+    # Synthetic stream: rank r starts its sweep a quarter turn further (its own sensor).
+    frames = [scenes.room_frame((k + 25 * rank) % N_STREAM, N_STREAM) for k in range(min(total, N_STREAM))]
+    d_frames = []
+    for pose, pts, col in frames:
+        d_frames.append((pose, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev)))
+    n_pts = frames[0][1].shape[0]
+
+    gm = capi.Map(VOXEL, 16, max_blocks=8192, device=local_rank)
+    gm.set_stream(torch.cuda.current_stream().cuda_stream)
+    cfg = capi.tsdf_cfg(default_truncation_distance=TRUNC)
+
+    def step(i):
+        pose, dp, dc = d_frames[i % len(d_frames)]
+        gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_pts)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    gm.enable_timing(True)
+    stage = {}
+    counters = {}
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+        t = gm.timing()
+        c = gm.counters()
+        for k, v in t.items():
+            stage[k] = stage.get(k, 0.0) + v
+        for k, v in c.items():
+            counters[k] = counters.get(k, 0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    K = args.steps
+    value = world * K * n_pts / dt / 1e6
+    out = {
+        "metric": "Mpoints/s integrated (640x480 frame, 0.05 m voxels) + achieved HBM GB/s",
+        "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": K,
+        "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.integrator.capitalize()}TsdfIntegrator, 640x480 synthetic room scan "
+                               "stream (BASELINE configs[1]), 0.05 m voxels / 16^3 blocks, trunc 0.2 m",
+                   "points_per_step": n_pts, "voxel_size": VOXEL, "voxels_per_side": 16,
+                   "parallelism": f"{world} sensor stream(s), one map shard per GPU"},
+    }
+    if rank == 0:
+        # Roofline of the dominant stage (HIP events on the launch stream, averaged over the
+        # K timed frames).  Algorithmic bytes per frame:
+        #   16 B x N_points + 24 B x U (distinct voxels updated), U counted by the fold kernel.
+        U = counters.get("voxels_touched", 0) / K
+        alg_bytes = 16.0 * n_pts + 24.0 * U
+        stages = {k: v / K for k, v in stage.items() if k != "total_ms"}
+        dom = max(stages, key=stages.get) if stages else "total_ms"
+        dom_ms = stages.get(dom, 0.0)
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                           "kernel": dom, "kernel_ms": round(dom_ms, 4),
+                           "algorithmic_bytes_per_launch": int(alg_bytes),
+                           "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                           "device_total_ms": round(stage.get("total_ms", 0.0) / K, 4)}
+        out["counters_per_step"] = {k: round(v / K, 1) for k, v in counters.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            nf = args.cpu_frames or 40
+            out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

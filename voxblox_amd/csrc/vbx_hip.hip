@@ -303,6 +303,13 @@ __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __r
   }
 }
 
+// number of rows with the cast flag set (one atomic per workgroup)
+__global__ void k_count_cast(const uint8_t* __restrict__ flags, uint32_t n, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = __syncthreads_count(i < n && (flags[i] & 1));
+  if (threadIdx.x == 0 && c) atomicAdd(&st->rays_cast, (unsigned long long)c);
+}
+
 // ---------------------------------------------------------------------------
 // kernels: generic ray march over a ray table
 // ---------------------------------------------------------------------------
@@ -373,7 +380,6 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
   RayCaster rc;
   if (!ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) return;
   const uint32_t lim = limit ? limit[o] : 0xFFFFFFFFu;
-  atomicAdd(&st->rays_cast, 1ull);
   if (lim == 0 || rc.cur != 0) return;
   const bool clearing = (tab.flags[o] & 2) != 0;
   uint64_t last_key = kEmptyKey;
@@ -460,11 +466,12 @@ __device__ inline void tsdf_update(const CastCfg& c, float voxel_size, f3 pg, l3
 __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
                        MapDev m, DevState* st) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t key = keys[i];
-  if (key == ~0ull) return;
+  const uint64_t key = (i < n) ? keys[i] : ~0ull;
   const uint32_t gid = (uint32_t)(key >> 32);
-  if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid) return;  // not a segment head
+  const bool head = (key != ~0ull) && !(i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid);
+  const int nheads = __syncthreads_count(head);
+  if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched, (unsigned long long)nheads);
+  if (!head) return;  // only segment heads fold
 
   const uint32_t slot = gid / m.nvox;
   const uint32_t lin = gid - slot * m.nvox;
@@ -492,7 +499,6 @@ __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, 
   m.dist[gid] = d;
   m.weight[gid] = W;
   m.rgba[gid] = col;
-  atomicAdd(&st->voxels_touched, 1ull);
 }
 
 // ---------------------------------------------------------------------------
@@ -650,27 +656,21 @@ __global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
   out.flags[r] = in.flags[s];
 }
 
-// Early-termination solver.  With an exact observed-set, "voxel already observed when ray r
-// probes it" == "some ray r' < r reaches that voxel", i.e. owner(v) = min{r' reaching v} < r.
-// Which voxels a ray reaches depends on where it terminates, which depends on the owners of
-// the voxels ahead of it — a fixed point, unique because dependencies only run from lower to
-// higher r.  One sweep = every ray re-walks against the owners of the previous sweep and
-// publishes the owners for the next one (atomicMin); repeat until no termination step moves.
-// Owner entries carry a descending sweep tag in their high bits so that the two ping-pong
-// arrays never need clearing.  (tsdf_integrator.cc:531-551)
-__global__ void k_fast_sweep(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ own_rd,
-                             uint32_t* own_wr, uint32_t tag_rd, uint32_t tag_wr, int s_bits,
-                             uint32_t* T, uint32_t* U, int first, DevState* st) {
+// Per-ray voxel lists: vox[off[r] + k] = pool_slot * nvox + linear_index of the k-th voxel the
+// ray visits walking from the surface towards the sensor (cast_from_origin = false,
+// tsdf_integrator.cc:521-525).  Built once per frame; the solver and the emit step then work
+// on these lists instead of re-running the DDA and the block hash lookups.
+__global__ void k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
+                                   uint32_t* vox, DevState* st) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= tab.R) return;
   RayCaster rc;
   if (!ray_init(rc, tab, r, c, m, /*from_origin=*/false, nullptr)) return;
-  const uint32_t smask = (1u << s_bits) - 1;
+  if (rc.cur != 0) return;
+  const uint32_t base = off[r];
   uint64_t last_key = kEmptyKey;
   uint32_t slot = kInvalidSlot;
-  int cons = 0;
-  uint32_t k = 0, t_end = 0, u_end = 0;
-  bool broke = false;
+  uint32_t k = 0;
   l3 g;
   while (rc.next(&g)) {
     const i3 b = block_index_from_global(g, m.vps_inv);
@@ -678,37 +678,109 @@ __global__ void k_fast_sweep(RayTab tab, CastCfg c, MapDev m, const uint32_t* __
     if (key != last_key) {
       last_key = key;
       slot = map_find(m, key);
+      if (slot == kInvalidSlot) atomicOr(&st->error, 2u);
     }
-    uint32_t gid = 0;
-    bool present = false;
+    uint32_t gid = 0xFFFFFFFFu;
     if (slot != kInvalidSlot) {
       const i3 l = local_from_global(g, m.vps);
       gid = slot * m.nvox + (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
-      if (!first) {
-        const uint32_t ov = own_rd[gid];
-        present = ((ov >> s_bits) == tag_rd) && ((ov & smask) < r);
-      }
-    } else {
-      atomicOr(&st->error, 2u);
     }
-    if (present) ++cons; else cons = 0;
-    if (cons > c.max_consecutive) {
-      t_end = k + 1;
-      u_end = k;
-      broke = true;
-      break;
-    }
-    if (slot != kInvalidSlot) atomicMin(&own_wr[gid], (tag_wr << s_bits) | r);
+    vox[base + k] = gid;
     ++k;
   }
-  if (!broke) {
-    t_end = k;
-    u_end = k;
+}
+
+// Early-termination solver.  With an exact observed-set, "voxel already observed when ray r
+// probes it" == "some ray r' < r reaches that voxel", i.e. owner(v) = min{r' reaching v} < r.
+// Which voxels a ray reaches depends on where it terminates, which depends on the owners of
+// the voxels ahead of it — a fixed point, unique because dependencies only run from lower to
+// higher r.  One sweep = every ray re-evaluates its termination against the owners of the
+// previous sweep and publishes the owners for the next one (atomicMin); repeat until no
+// termination step moves.  Owner entries carry a descending sweep tag in their high bits so
+// the two ping-pong arrays never need clearing.  (tsdf_integrator.cc:531-551)
+//
+// One wave per ray, 64 probes per step: the lanes fetch 64 consecutive owners of the ray's
+// voxel list at once, the consecutive-collision counter becomes a run-length computed from
+// the ballot mask, and the first lane whose run exceeds max_consecutive_ray_collisions is
+// the termination step.
+__global__ void __launch_bounds__(256)
+k_fast_sweep(const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, uint32_t R,
+             int max_consecutive, const uint32_t* __restrict__ own_rd, uint32_t* own_wr,
+             uint32_t tag_rd, uint32_t tag_wr, int s_bits, uint32_t* T, uint32_t* U, int first,
+             DevState* st) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= R) return;
+  const uint32_t beg = off[r];
+  const uint32_t len = off[r + 1] - beg;
+  const uint32_t smask = (1u << s_bits) - 1;
+  const uint32_t wr_val = (tag_wr << s_bits) | r;
+  int cons_in = 0;
+  uint32_t t_end = len, u_end = len;
+  for (uint32_t base = 0; base < len; base += 64) {
+    const uint32_t k = base + lane;
+    const bool act = k < len;
+    const uint32_t gid = act ? vox[beg + k] : 0xFFFFFFFFu;
+    bool present = false;
+    if (gid != 0xFFFFFFFFu && !first) {
+      const uint32_t ov = own_rd[gid];
+      present = ((ov >> s_bits) == tag_rd) && ((ov & smask) < r);
+    }
+    const unsigned long long P = __ballot(present);
+    // consecutive_ray_collisions after this probe: length of the run of set bits ending here
+    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long zeros = ~P & below;
+    const int run = zeros ? (lane - (63 - __clzll((long long)zeros))) : (lane + 1);
+    const int cons = present ? (run + ((run == lane + 1) ? cons_in : 0)) : 0;
+    const bool brk = act && (cons > max_consecutive);
+    const unsigned long long B = __ballot(brk);
+    const int kb = B ? (__ffsll((long long)B) - 1) : 64;
+    if (act && lane < kb && gid != 0xFFFFFFFFu) atomicMin(&own_wr[gid], wr_val);
+    if (B) {
+      t_end = base + kb + 1;  // the terminating probe still happened ...
+      u_end = base + kb;      // ... but its voxel is not updated
+      break;
+    }
+    cons_in = __shfl(cons, 63);
   }
-  if (first || T[r] != t_end || U[r] != u_end) {
-    T[r] = t_end;
-    U[r] = u_end;
-    if (!first) st->changed = 1;
+  if (lane == 0) {
+    if (first || T[r] != t_end || U[r] != u_end) {
+      T[r] = t_end;
+      U[r] = u_end;
+      if (!first) st->changed = 1;
+    }
+  }
+}
+
+// Emit the ordered update keys of the voxels each ray reaches (k < U[r]) straight from the
+// voxel lists; one thread per key, the ray is found by binary search in the key offsets.
+__global__ void k_fast_emit(const uint32_t* __restrict__ off_full, const uint32_t* __restrict__ vox,
+                            const uint32_t* __restrict__ off_u, uint32_t R, uint32_t total,
+                            MapDev m, uint64_t* keys, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  uint32_t lo = 0, hi = R;  // largest r with off_u[r] <= i
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off_u[mid] <= i) lo = mid; else hi = mid;
+  }
+  const uint32_t r = lo;
+  const uint32_t k = i - off_u[r];
+  const uint32_t gid = vox[off_full[r] + k];
+  if (gid == 0xFFFFFFFFu) {
+    keys[i] = ~0ull;
+    return;
+  }
+  keys[i] = ((uint64_t)gid << 32) | r;
+  // tsdf_integrator.cc:128: block->updated().set() on every visited voxel's block
+  const uint32_t slot = gid / m.nvox;
+  const bool first_of_block = (k == 0) || (vox[off_full[r] + k - 1] / m.nvox != slot);
+  if (first_of_block) {
+    const uint32_t old = atomicOr(&m.blk_flags[slot], kFlagPublished | kFlagUpdMask);
+    if (!(old & kFlagPublished)) {
+      atomicOr(&m.blk_flags[slot], kFlagNewThisCall);
+      atomicAdd(&st->blocks_published, 1u);
+    }
   }
 }
 
@@ -736,7 +808,7 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_U;
+  DBuf b_T, b_U, b_vox;
   // Fast integrator persistent state
   DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
   uint32_t start_offset = 0;
@@ -877,6 +949,22 @@ CastCfg make_cast_cfg(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float pos[3])
   return c;
 }
 
+// Order the emitted (voxel, order) keys and fold them per voxel (keys in b_keys0).
+int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t total) {
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  const unsigned end_bit = 32 + bits_for((uint64_t)m.cap_blocks * m.nvox);
+  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 0,
+                     std::min(64u, end_bit + 1));
+  if (rc) return rc;
+  tmark(ctx, 5);
+  hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     (size_t)total, tab, c, m, ctx->d_state);
+  tmark(ctx, 6);
+  ctx->counters.voxel_updates = total;
+  return VBX_OK;
+}
+
 // Shared tail of all three integrators: allocate blocks along the rays, emit ordered voxel
 // keys, sort, fold.  `limit` (optional) bounds the number of voxels each ray visits.
 int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_origin,
@@ -899,8 +987,8 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
     hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
                        ctx->b_newlist.as<uint32_t>(), ctx->d_state);
     hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    tmark(ctx, 2);
   }
-  tmark(ctx, 2);
   // total number of keys = off[R]
   uint32_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, ctx->b_off.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
@@ -915,17 +1003,9 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
   hipLaunchKernelGGL(k_ray_emit, grid_for(R), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0, limit,
                      ctx->b_off.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), graze_keys, n_graze,
                      ctx->d_state);
+  hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, tab.flags, R, ctx->d_state);
   tmark(ctx, 4);
-  const unsigned end_bit = 32 + bits_for((uint64_t)m.cap_blocks * m.nvox);
-  rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 0,
-                 std::min(64u, end_bit + 1));
-  if (rc) return rc;
-  tmark(ctx, 5);
-  hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                     (size_t)total, tab, c, m, ctx->d_state);
-  tmark(ctx, 6);
-  ctx->counters.voxel_updates = total;
-  return VBX_OK;
+  return sort_and_fold(ctx, tab, c, total);
 }
 
 int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
@@ -1053,12 +1133,27 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   if (R == 0) return VBX_OK;
 
   // Candidate blocks along the full (unterminated) paths; a block only becomes part of the
-  // Layer ("published") when a ray actually reaches it in k_ray_emit.
+  // Layer ("published") when a ray actually reaches it (k_fast_emit).
+  HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
+  hipLaunchKernelGGL(k_ray_count, grid_for(R + 1), dim3(256), 0, s, kt, c, m, 0,
+                     (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>());
+  rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, kt, c, m, 0,
                      (const uint32_t*)nullptr, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
   hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
                      ctx->b_newlist.as<uint32_t>(), ctx->d_state);
   hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  uint32_t total_full = 0;
+  HIP_TRY(hipMemcpyAsync(&total_full, ctx->b_off.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  rc = check_state_error(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx->b_vox.ensure((size_t)std::max<uint32_t>(total_full, 1) * 4));
+  hipLaunchKernelGGL(k_fast_build_lists, grid_for(R), dim3(256), 0, s, kt, c, m,
+                     ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), ctx->d_state);
   tmark(ctx, 2);
 
   // owner arrays + tags
@@ -1068,7 +1163,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_own0.ensure(nvox_total * 4));
   HIP_TRY(ctx->b_own1.ensure(nvox_total * 4));
   const uint32_t max_tag = (1u << (32 - s_bits)) - 2;
-  if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 4) {
+  if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 64) {
     HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
     ctx->own_s_bits = s_bits;
@@ -1076,39 +1171,57 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   }
   HIP_TRY(ctx->b_T.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_U.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_rank.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(hipMemsetAsync(ctx->b_U.as<uint32_t>() + R, 0, 4, s));
   uint32_t iters = 0;
   uint32_t tag_prev = 0xFFFFFFFFu;
+  uint32_t total = 0;
+  const int kBatch = 4;  // sweeps per convergence check (one host sync per batch)
   for (;;) {
-    if (ctx->own_tag < 2) {  // tag space exhausted mid-call: restart the tag range
-      HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
-      HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
-      ctx->own_tag = max_tag;
-      iters = 0;  // previous sweeps' owners are gone: start over
-      tag_prev = 0xFFFFFFFFu;
+    for (int b = 0; b < kBatch; ++b) {
+      if (ctx->own_tag < 2) {  // tag space exhausted mid-call: restart the tag range
+        HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
+        HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
+        ctx->own_tag = max_tag;
+        iters = 0;  // the previous sweeps' owners are gone: start over
+        tag_prev = 0xFFFFFFFFu;
+      }
+      const uint32_t tag = --ctx->own_tag;
+      const uint32_t* rd = (iters & 1) ? ctx->b_own0.as<uint32_t>() : ctx->b_own1.as<uint32_t>();
+      uint32_t* wr = (iters & 1) ? ctx->b_own1.as<uint32_t>() : ctx->b_own0.as<uint32_t>();
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+      hipLaunchKernelGGL(k_fast_sweep, grid_for((size_t)R * 64), dim3(256), 0, s,
+                         ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), R, c.max_consecutive,
+                         rd, wr, tag_prev, tag, s_bits, ctx->b_T.as<uint32_t>(),
+                         ctx->b_U.as<uint32_t>(), iters == 0 ? 1 : 0, ctx->d_state);
+      tag_prev = tag;
+      ++iters;
     }
-    const uint32_t tag = --ctx->own_tag;
-    uint32_t* rd = (iters & 1) ? ctx->b_own0.as<uint32_t>() : ctx->b_own1.as<uint32_t>();
-    uint32_t* wr = (iters & 1) ? ctx->b_own1.as<uint32_t>() : ctx->b_own0.as<uint32_t>();
-    HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
-    hipLaunchKernelGGL(k_fast_sweep, grid_for(R), dim3(256), 0, s, kt, c, m, rd, wr, tag_prev, tag,
-                       s_bits, ctx->b_T.as<uint32_t>(), ctx->b_U.as<uint32_t>(), iters == 0 ? 1 : 0,
-                       ctx->d_state);
-    tag_prev = tag;
-    ++iters;
-    if (iters == 1) continue;
+    // offsets of the keys each ray will emit; valid once the batch's last sweep changed nothing
+    rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(&total, ctx->b_rank.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
     rc = sync_state(ctx);
     if (rc) return rc;
     rc = check_state_error(ctx);
     if (rc) return rc;
     if (!ctx->h_state.changed) break;
-    if (iters > 100000) {
+    if (iters > 1000000) {
       ctx->fail("Fast integrator: early-termination solver did not converge");
       return VBX_ERR_HIP;
     }
   }
   ctx->counters.iterations = iters;
   tmark(ctx, 3);
-  return march_and_fold(ctx, kt, c, /*from_origin=*/false, ctx->b_U.as<uint32_t>(), true, nullptr, 0);
+  hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
+  if (total == 0) return VBX_OK;
+  HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
+  HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));
+  hipLaunchKernelGGL(k_fast_emit, grid_for(total), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
+                     ctx->b_vox.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R, total, m,
+                     ctx->b_keys0.as<uint64_t>(), ctx->d_state);
+  tmark(ctx, 4);
+  return sort_and_fold(ctx, kt, c, total);
 }
 
 int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
@@ -1299,7 +1412,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1};
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   for (int i = 0; i < 8; ++i)
