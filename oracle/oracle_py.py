@@ -99,7 +99,7 @@ def lib():
         "orc_transform_point": (None, [f32p, f32p, f32p, f32p]),
         "orc_cast_ray": (C.c_size_t, [f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_float,
                                       C.c_float, C.c_int, i64p, C.c_size_t]),
-        "orc_approx_set_create": (vp, []),
+        "orc_approx_set_create": (vp, [C.c_int]),
         "orc_approx_set_destroy": (None, [vp]),
         "orc_approx_set_replace_hash": (C.c_int, [vp, C.c_uint64]),
         "orc_approx_set_is_present": (C.c_int, [vp, C.c_uint64]),

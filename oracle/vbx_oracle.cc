@@ -23,8 +23,21 @@ struct orc_tsdf_integrator {
 struct orc_esdf_integrator {
   std::unique_ptr<EsdfIntegrator> impl;
 };
+struct ApproxSetIface {
+  virtual ~ApproxSetIface() = default;
+  virtual bool replace(size_t h) = 0;
+  virtual bool present(size_t h) = 0;
+  virtual void reset() = 0;
+};
+template <size_t B, size_t T>
+struct ApproxSetImpl : ApproxSetIface {
+  ApproxHashSet<B, T> s;
+  bool replace(size_t h) override { return s.replaceHash(h); }
+  bool present(size_t h) override { return s.isHashCurrentlyPresent(h); }
+  void reset() override { s.resetApproxSet(); }
+};
 struct orc_approx_set {
-  ApproxHashSet<20, 10000> s;
+  std::unique_ptr<ApproxSetIface> s;
 };
 struct orc_bucket_queue {
   BucketQueue<size_t> q;
@@ -305,11 +318,16 @@ size_t orc_cast_ray(const float o[3], const float pg[3], int is_clearing, int ca
   return n;
 }
 
-orc_approx_set* orc_approx_set_create(void) { return new orc_approx_set; }
+orc_approx_set* orc_approx_set_create(int small) {
+  auto* r = new orc_approx_set;
+  if (small) r->s.reset(new ApproxSetImpl<16, 10>());   // test_approx_hash_array.cc:63
+  else r->s.reset(new ApproxSetImpl<20, 10000>());       // tsdf_integrator.h:315-328
+  return r;
+}
 void orc_approx_set_destroy(orc_approx_set* s) { delete s; }
-int orc_approx_set_replace_hash(orc_approx_set* s, uint64_t h) { return s->s.replaceHash(h); }
-int orc_approx_set_is_present(orc_approx_set* s, uint64_t h) { return s->s.isHashCurrentlyPresent(h); }
-void orc_approx_set_reset(orc_approx_set* s) { s->s.resetApproxSet(); }
+int orc_approx_set_replace_hash(orc_approx_set* s, uint64_t h) { return s->s->replace(h); }
+int orc_approx_set_is_present(orc_approx_set* s, uint64_t h) { return s->s->present(h); }
+void orc_approx_set_reset(orc_approx_set* s) { s->s->reset(); }
 
 orc_bucket_queue* orc_bucket_queue_create(int nb, double max_val) {
   auto* q = new orc_bucket_queue;

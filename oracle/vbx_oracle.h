@@ -119,8 +119,8 @@ size_t orc_cast_ray(const float origin[3], const float point_G[3], int is_cleari
                     int voxel_carving, float max_ray_length_m, float voxel_size_inv,
                     float truncation, int cast_from_origin, int64_t* out_xyz, size_t cap);
 
-typedef struct orc_approx_set orc_approx_set; /* ApproxHashSet<20,10000> */
-orc_approx_set* orc_approx_set_create(void);
+typedef struct orc_approx_set orc_approx_set; /* small != 0: ApproxHashSet<16,10> (the reference test's size), else <20,10000> */
+orc_approx_set* orc_approx_set_create(int small);
 void orc_approx_set_destroy(orc_approx_set* s);
 int orc_approx_set_replace_hash(orc_approx_set* s, uint64_t hash);
 int orc_approx_set_is_present(orc_approx_set* s, uint64_t hash);

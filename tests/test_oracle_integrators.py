@@ -1,0 +1,189 @@
+"""CPU: behaviour of the oracle's three TSDF integrators and the ESDF integrator, pinned the
+way the reference pins them (test/test_sdf_integrators.cc: statistical envelopes against
+analytic ground truth and against each other) plus the documented quirks."""
+import numpy as np
+import pytest
+
+from parity_utils import layer_stats
+from voxblox_amd import scenes
+
+VOXEL = 0.10
+TRUNC = 4 * VOXEL
+
+
+def _frames(n=6, w=160, h=120, f=80.0):
+    return [scenes.room_frame(k * 4, 100, f=f, width=w, height=h) for k in range(n)]
+
+
+def _integrate(oracle, kind, frames, voxel=VOXEL, **kw):
+    oracle.lib().orc_fast_reset_counter_set(0)
+    m = oracle.OracleMap(voxel, 16)
+    it = m.tsdf_integrator(kind, oracle.tsdf_cfg(default_truncation_distance=4 * voxel,
+                                                 integrator_threads=1, **kw))
+    for pose, pts, col in frames:
+        it.integrate(pose[0], pose[1], pts, col)
+    return m, it
+
+
+def _room_gt(block_idx, voxel, vps, trunc):
+    """Analytic SDF of the box room at the voxel centres of one block, truncated like the
+    reference's generateSdfFromWorld (simulation_world_inl.h:13-70): + inside free space."""
+    r = (np.arange(vps) + 0.5) * voxel
+    z, y, x = np.meshgrid(r, r, r, indexing="ij")
+    c = np.stack([x, y, z], -1).reshape(-1, 3) + np.array(block_idx) * vps * voxel
+    d = np.minimum(c - scenes.ROOM_LO, scenes.ROOM_HI - c).min(1)
+    return np.clip(d, -trunc, trunc)
+
+
+def test_tsdf_envelope_vs_ground_truth_and_each_other(oracle):
+    """test_sdf_integrators.cc:110-181: merged/fast observe within 1 % as many voxels as
+    simple overlapping... and every integrator has rmse < 2*voxel_size, max error < 2*trunc
+    against the analytic SDF on the voxels it observed."""
+    frames = _frames()
+    maps = {k: _integrate(oracle, k, frames)[0] for k in ("simple", "merged", "fast")}
+    dicts = {k: m.tsdf_dict() for k, m in maps.items()}
+    n_obs = {k: m.count_observed() for k, m in maps.items()}
+    # tolerance as the reference defines it: 1 % of all ground-truth voxels inside the world
+    # bounds (num_overlapping + num_non_overlapping of the GT layer, :156-164)
+    total_gt = int(np.prod(np.round((scenes.ROOM_HI - scenes.ROOM_LO) / VOXEL)))
+    assert abs(n_obs["merged"] - n_obs["simple"]) <= 0.01 * total_gt, n_obs
+    # the Fast integrator stops rays early: it may observe fewer voxels, never more
+    assert n_obs["fast"] <= n_obs["simple"]
+    assert n_obs["simple"] - n_obs["fast"] <= 0.10 * total_gt, n_obs
+    for k, d in dicts.items():
+        se = 0.0; n = 0; mx = 0.0
+        for b, (dist, w, _, _) in d.items():
+            obs = w > 1e-6
+            if not obs.any():
+                continue
+            gt = _room_gt(b, VOXEL, 16, TRUNC)
+            # like the reference only voxels near the surface carry a meaningful projective SDF
+            sel = obs & (np.abs(gt) < TRUNC)
+            e = (dist[sel] - gt[sel]).astype(np.float64)
+            se += float((e * e).sum()); n += int(sel.sum())
+            mx = max(mx, float(np.abs(e).max()) if e.size else 0.0)
+        rmse = (se / max(n, 1)) ** 0.5
+        assert n > 1000, k
+        assert rmse < 2 * VOXEL, (k, rmse)
+        assert mx < 2 * TRUNC, (k, mx)
+
+
+def test_simple_is_thread_count_invariant_on_disjoint_voxels(oracle):
+    """1 thread is the deterministic reference; re-running gives identical bits."""
+    frames = _frames(2)
+    a = _integrate(oracle, "simple", frames)[0].tsdf_dict()
+    b = _integrate(oracle, "simple", frames)[0].tsdf_dict()
+    for k in a:
+        assert np.array_equal(a[k][0].view(np.uint32), b[k][0].view(np.uint32))
+        assert np.array_equal(a[k][1].view(np.uint32), b[k][1].view(np.uint32))
+        assert np.array_equal(a[k][2], b[k][2])
+
+
+def test_update_is_order_dependent_q1(oracle):
+    """clamp after every update makes the fold non-commutative.  Two single-point
+    clouds through the same voxel in both orders give different distances."""
+    voxel = 0.05
+    pose = (np.zeros(3, np.float32), np.array([1, 0, 0, 0], np.float32))
+    col = np.array([[1, 2, 3, 255]], np.uint8)
+    # slightly off-axis: a ray component that is exactly 0 triggers the 0/0 quirk
+    far = np.array([[0.013, 0.017, 3.0]], np.float32)  # voxel at z~1.02 is far in front: sdf >> trunc
+    near = (far * np.float32(0.95 / 3.0)).astype(np.float32)  # same voxel lies just behind this surface
+    res = []
+    for order in ((far, near), (near, far)):
+        m = oracle.OracleMap(voxel, 16)
+        it = m.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=0.2,
+                                                         integrator_threads=1, use_const_weight=1,
+                                                         use_weight_dropoff=0))
+        for pts in order:
+            it.integrate(pose[0], pose[1], pts, col)
+        d, w, _, _ = m.tsdf_block((0, 0, 1))
+        lin = 0 + 16 * (0 + 4 * 16)  # voxel (0,0,20) -> block z=1, local z=4
+        res.append((float(d[lin]), float(w[lin])))
+    assert res[0][1] == res[1][1] == 2.0
+    assert abs(res[0][0] - res[1][0]) > 0.05
+
+
+def test_fast_stops_on_third_consecutive_seen_voxel_q7(oracle):
+    """the same ray twice in one cloud -> start-voxel set drops the 2nd point; a
+    nearby second ray through the same voxels stops after 2 already-seen voxels."""
+    voxel = 0.05
+    pose = (np.zeros(3, np.float32), np.array([1, 0, 0, 0], np.float32))
+    pts = np.array([[0.013, 0.017, 2.0], [0.013, 0.017, 2.0], [0.0132, 0.0172, 2.03]], np.float32)
+    col = np.full((3, 4), 255, np.uint8)
+    m, it = _integrate(oracle, "fast", [(pose, pts, col)], voxel=voxel)
+    st = it.stats()
+    assert st["rays_cast"] == 2                   # the duplicate start cell is skipped
+    first = 2.2 / voxel + 1                       # ray 1 walks all the way back to the sensor
+    assert st["voxel_updates"] == pytest.approx(first + 2, abs=2)
+
+
+def test_merged_bundles_by_endpoint_voxel_q8(oracle):
+    """points in the same endpoint voxel form one bundle whose weight is the SUM
+    of the point weights; clearing bundles use only their first point."""
+    voxel = 0.10
+    pose = (np.zeros(3, np.float32), np.array([1, 0, 0, 0], np.float32))
+    pts = np.array([[0.01, 0.01, 2.01], [0.02, 0.02, 2.02], [0.03, 0.01, 2.03],
+                    [0.011, 0.007, 7.0], [0.012, 0.008, 7.01]], np.float32)
+    col = np.full((5, 4), 200, np.uint8)
+    m, it = _integrate(oracle, "merged", [(pose, pts, col)], voxel=voxel, use_const_weight=1)
+    st = it.stats()
+    assert st["bundles"] == 1 and st["clear_bundles"] == 1
+    d, w, _, _ = m.tsdf_block((0, 0, 1))
+    lin = 0 + 16 * (0 + 4 * 16)                   # voxel (0,0,20): the bundle's endpoint voxel
+    assert w[lin] == 4.0                          # 3 (summed bundle weight) + 1 (clearing ray)
+    assert w[0 + 16 * (0 + 14 * 16)] == 1.0       # z = 3.0 m: beyond the bundle, clearing ray only
+    d0, w0, _, _ = m.tsdf_block((0, 0, 0))        #   (first clearing point only, not 2)
+    assert w0[0 + 16 * (0 + 5 * 16)] == 4.0
+
+
+def test_esdf_fixed_band_copies_tsdf(oracle):
+    """test_clear_spheres.cc:192-201 (restated without the sphere part): every TSDF voxel with
+    w > 1e-6 and |d| < min_distance appears in the ESDF with the same distance and sign."""
+    frames = _frames(3)
+    m, _ = _integrate(oracle, "merged", frames)
+    e = m.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, max_distance_m=2.0,
+                                          default_distance_m=2.0))
+    e.update_from_tsdf_layer(True)
+    t, es = m.tsdf_dict(), m.esdf_dict()
+    assert set(t.keys()) == set(es.keys())
+    n = 0
+    for b in t:
+        d, w, _, upd = t[b]
+        ed, fl, _, eupd = es[b]
+        assert not (upd & 4)                      # kEsdf bit cleared (esdf_integrator.cc:113-121)
+        assert eupd == 1                          # set_updated(true) sets only kMap (:147, Q9)
+        band = (w > 1e-6) & (np.abs(d) < TRUNC / 2)
+        assert np.all(fl[band] & 1) and np.all(fl[band] & 8)      # observed + fixed
+        assert np.array_equal(ed[band], d[band])
+        obs = (fl & 1).astype(bool)
+        assert np.array_equal(obs, w >= np.float32(1e-6))
+        n += int(band.sum())
+    assert n > 1000
+    st = e.stats()
+    assert st["blocks"] == len(t) and st["relaxations"] > 0
+
+
+def test_esdf_incremental_matches_batch_envelope(oracle):
+    """test_sdf_integrators.cc:183-284: incremental vs batch ESDF agree within 1e-2 rmse with
+    equal overlap (min_diff_m = 0, multi_queue = true as in the reference test)."""
+    frames = _frames(4)
+    cfg = dict(min_distance_m=TRUNC / 2, min_diff_m=0.0, multi_queue=1)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    mi = oracle.OracleMap(VOXEL, 16)
+    ti = mi.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1))
+    ei = mi.esdf_integrator(oracle.esdf_cfg(**cfg))
+    for pose, pts, col in frames:
+        ti.integrate(pose[0], pose[1], pts, col)
+        ei.update_from_tsdf_layer(True)
+    mb, _ = _integrate(oracle, "merged", frames)
+    eb = mb.esdf_integrator(oracle.esdf_cfg(**cfg))
+    eb.update_from_tsdf_layer_batch()
+    a, b = mi.esdf_dict(), mb.esdf_dict()
+    assert set(a.keys()) == set(b.keys())
+    se = 0.0; n = 0
+    for k in a:
+        oa = (a[k][1] & 1).astype(bool); ob = (b[k][1] & 1).astype(bool)
+        assert np.array_equal(oa, ob)
+        e = (a[k][0][oa] - b[k][0][oa]).astype(np.float64)
+        se += float((e * e).sum()); n += int(oa.sum())
+    assert n > 1000 and (se / n) ** 0.5 < 1e-2
