@@ -115,6 +115,12 @@ struct EsdfConfig {  // esdf_integrator.h:29-78
   bool add_occupied_crust = false;
   float clear_sphere_radius = 1.5f;
   float occupied_sphere_radius = 5.0f;
+  // ---- oracle-only switch (NOT in the reference; default = reference) ----
+  // The sign-mismatch assignment of processOpenSet (esdf_integrator.cc:459-488) depends on
+  // the pop order of opposite-sign neighbours, i.e. on libstdc++'s unordered_map block
+  // order.  With this switch the same candidate is applied whenever it moves the voxel
+  // closer to the surface (monotone, hence order-free) — the form the HIP path implements.
+  bool oracle_orderfree_sign_mismatch = false;
 };
 
 struct EsdfStats {
@@ -363,7 +369,20 @@ class EsdfIntegrator {
           }
         } else {
           const float potential_distance = voxel->distance - signum(voxel->distance) * distance;
-          if (std::abs(potential_distance - nv->distance) > distance) {
+          if (config_.oracle_orderfree_sign_mismatch) {
+            float cand;
+            if (static_cast<float>(signum(potential_distance)) == nv->distance) cand = potential_distance;
+            else cand = signum(nv->distance) * distance;
+            if (std::abs(cand) < std::abs(nv->distance)) {
+              stats.relaxations++;
+              nv->distance = cand;
+              nv->parent = new_parent;
+              if (config_.multi_queue || !nv->in_queue) {
+                open_.push(neighbor_index, nv->distance);
+                nv->in_queue = true;
+              }
+            }
+          } else if (std::abs(potential_distance - nv->distance) > distance) {
             // esdf_integrator.cc:464 compares signum(int) with the float distance.
             if (static_cast<float>(signum(potential_distance)) == nv->distance) {
               stats.relaxations++;

@@ -81,6 +81,7 @@ void orc_esdf_cfg_default(orc_esdf_cfg* c) {
   c->add_occupied_crust = d.add_occupied_crust;
   c->clear_sphere_radius = d.clear_sphere_radius;
   c->occupied_sphere_radius = d.occupied_sphere_radius;
+  c->oracle_orderfree_sign_mismatch = 0;
 }
 
 static TsdfConfig toCfg(const orc_tsdf_cfg* c) {
@@ -159,6 +160,7 @@ static EsdfConfig toEsdfCfg(const orc_esdf_cfg* c) {
   d.add_occupied_crust = c->add_occupied_crust != 0;
   d.clear_sphere_radius = c->clear_sphere_radius;
   d.occupied_sphere_radius = c->occupied_sphere_radius;
+  d.oracle_orderfree_sign_mismatch = c->oracle_orderfree_sign_mismatch != 0;
   return d;
 }
 orc_esdf_integrator* orc_esdf_integrator_create(orc_map* m, const orc_esdf_cfg* cfg) {

@@ -53,6 +53,7 @@ typedef struct orc_esdf_cfg {
   int32_t add_occupied_crust;
   float clear_sphere_radius;
   float occupied_sphere_radius;
+  int32_t oracle_orderfree_sign_mismatch; /* oracle-only switch, see vbx_esdf.hpp */
 } orc_esdf_cfg;
 
 void orc_tsdf_cfg_default(orc_tsdf_cfg* cfg);

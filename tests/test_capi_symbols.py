@@ -56,6 +56,7 @@ def test_oracle_and_capi_defaults_agree(oracle):
     oe, ge = oracle.esdf_cfg(), capi.esdf_cfg()
     for name, _ in capi.EsdfCfg._fields_:
         assert getattr(oe, name) == getattr(ge, name), name
+    assert oe.oracle_orderfree_sign_mismatch == 0  # oracle-only switch defaults to the reference
 
 
 def test_no_gpu_fails_loudly():

@@ -1,0 +1,164 @@
+"""-m gpu: ESDF integrator on the GPU vs the CPU oracle, through the C-ABI.
+
+Bar: allocated blocks, observed and fixed flags identical; fixed-band
+distances bit-exact copies of the TSDF; with min_diff_m = 0 every distance is bit-exact
+against the oracle's updateFromTsdfLayerBatch (the wavefront's fixed point is order-free);
+with the reference's default min_diff_m the reference's own envelope (1e-2 rmse,
+test_sdf_integrators.cc:270) applies.  Parents must be valid (point at a 26-neighbour that
+explains the distance exactly)."""
+import numpy as np
+import pytest
+
+from voxblox_amd import scenes
+
+pytestmark = pytest.mark.gpu
+VOXEL = 0.05
+TRUNC = 4 * VOXEL
+
+
+def _frames(n):
+    return [scenes.room_frame(4 * k, 100, f=80.0, width=160, height=120) for k in range(n)]
+
+
+def _pair(oracle, frames, kind="simple", esdf_each_frame=False, ocfg=None, gcfg=None, batch_gpu=False):
+    from voxblox_amd import capi
+    ocfg = ocfg or {}
+    gcfg = gcfg or {}
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(VOXEL, 16)
+    oi = om.tsdf_integrator(kind, oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1))
+    gm = capi.Map(VOXEL, 16, max_blocks=4096)
+    k = {"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED}[kind]
+    gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
+    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, **gcfg)
+    for pose, pts, col in frames:
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(k, gt, pose[0], pose[1], pts, col)
+        if esdf_each_frame:
+            gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+    if not esdf_each_frame:
+        gm.esdf_update(ge, batch=batch_gpu, clear_updated_flag=True)
+    oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, **ocfg))
+    return om, oe, gm
+
+
+def _gpu_esdf(gm):
+    from voxblox_amd import capi
+    out = {}
+    for i in gm.block_indices(capi.LAYER_ESDF):
+        v, u, _ = gm.block_download(i, capi.LAYER_ESDF)
+        fl = (v["observed"] | (v["hallucinated"] << 1) | (v["in_queue"] << 2) | (v["fixed"] << 3)).astype(np.uint8)
+        out[tuple(int(x) for x in i)] = (v["distance"].copy(), fl, v["parent"].copy(), u)
+    return out
+
+
+def _check_exact(g, r, gm_tsdf=None):
+    assert set(g.keys()) == set(r.keys())
+    n = nfix = 0
+    for k in r:
+        gd, gf, gp, gu = g[k]
+        rd, rf, rp, ru = r[k]
+        assert gu == ru == 1, (gu, ru)                 # set_updated(true) -> kMap only
+        assert np.array_equal(gf & 1, rf & 1), f"observed mask differs in {k}"
+        assert np.array_equal(gf & 8, rf & 8), f"fixed mask differs in {k}"
+        assert not (gf & 4).any() and not (rf & 4).any()   # nothing left in_queue
+        obs = (rf & 1).astype(bool)
+        bad = gd[obs].view(np.uint32) != rd[obs].view(np.uint32)
+        assert not bad.any(), (f"{int(bad.sum())} distances differ in block {k}: "
+                               f"max |d|={np.abs(gd[obs] - rd[obs]).max()}")
+        n += int(obs.sum()); nfix += int(((rf & 8) != 0).sum())
+    return n, nfix
+
+
+def _check_parents(g, voxel, max_d):
+    """parent == 0 for fixed / never-lowered voxels, else a unit LUT offset to a voxel with
+    d_parent +- dist == d exactly."""
+    sq = {1: np.float32(1.0), 2: np.float32(np.sqrt(2.0)), 3: np.float32(np.sqrt(3.0))}
+    checked = 0
+    for k, (d, f, p, _) in g.items():
+        vps = 16
+        dd = d.reshape(vps, vps, vps)  # [z,y,x]
+        pz, py, px = p[:, 2].reshape(vps, vps, vps), p[:, 1].reshape(vps, vps, vps), p[:, 0].reshape(vps, vps, vps)
+        nz = (np.abs(p).sum(1) > 0).reshape(vps, vps, vps)
+        assert np.abs(p).max() <= 1
+        fixed = ((f & 8) != 0).reshape(vps, vps, vps)
+        assert not (nz & fixed).any()
+        zz, yy, xx = np.nonzero(nz)
+        for z, y, x in list(zip(zz, yy, xx))[::97]:
+            qx, qy, qz = x + px[z, y, x], y + py[z, y, x], z + pz[z, y, x]
+            if not (0 <= qx < vps and 0 <= qy < vps and 0 <= qz < vps):
+                continue  # parent in the neighbouring block: covered statistically by interior ones
+            n2 = int(abs(px[z, y, x]) + abs(py[z, y, x]) + abs(pz[z, y, x]))
+            step = np.float32(sq[n2] * np.float32(voxel))
+            dv, dn = dd[qz, qy, qx], dd[z, y, x]
+            assert abs(dv) < max_d
+            if (dv > 0) == (dn > 0):
+                want = np.float32(dv + step) if dn > 0 else np.float32(dv - step)
+            else:   # sign-mismatch rule (esdf_integrator.cc:459-488): one step from the surface
+                want = np.float32(np.sign(dn) * step)
+            assert want == dn
+            checked += 1
+    assert checked > 50
+
+
+def test_esdf_batch_bit_exact(oracle):
+    frames = _frames(3)
+    om, oe, gm = _pair(oracle, frames, ocfg=dict(min_diff_m=0.0, oracle_orderfree_sign_mismatch=1), gcfg=dict(min_diff_m=0.0), batch_gpu=True)
+    oe.update_from_tsdf_layer_batch()
+    g, r = _gpu_esdf(gm), om.esdf_dict()
+    n, nfix = _check_exact(g, r)
+    assert n > 100000 and nfix > 1000
+    _check_parents(g, VOXEL, 2.0)
+    c = gm.counters()
+    assert c["esdf_blocks"] == len(r) and c["esdf_sweeps"] >= 2
+
+
+def test_esdf_incremental_stream_equals_batch_fixed_point(oracle):
+    """updateFromTsdfLayer(true) after every frame on the GPU ends at the same fixed point as
+    the reference's batch update of the final TSDF layer (min_diff_m = 0)."""
+    from voxblox_amd import capi
+    frames = _frames(5)
+    om, oe, gm = _pair(oracle, frames, esdf_each_frame=True, ocfg=dict(min_diff_m=0.0, oracle_orderfree_sign_mismatch=1),
+                       gcfg=dict(min_diff_m=0.0))
+    oe.update_from_tsdf_layer_batch()
+    g, r = _gpu_esdf(gm), om.esdf_dict()
+    _check_exact(g, r)
+    # every TSDF block lost its kEsdf bit, kept kMap|kMesh (esdf_integrator.cc:113-121)
+    assert len(gm.blocks_updated(capi.UPDATE_ESDF)) == 0
+    assert len(gm.blocks_updated(capi.UPDATE_MESH)) == gm.num_blocks()
+
+
+def test_esdf_default_min_diff_envelope_vs_reference_incremental(oracle):
+    """Reference semantics with its default min_diff_m = 1e-3 and its incremental queue order:
+    same observed/fixed voxels, fixed band bit-exact, rmse within the reference's 1e-2."""
+    frames = _frames(4)
+    from voxblox_amd import capi
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(VOXEL, 16)
+    oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1,
+                                                      oracle_merged_sorted_bundles=1))
+    oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2))
+    gm = capi.Map(VOXEL, 16, max_blocks=4096)
+    gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
+    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2)
+    for pose, pts, col in frames:
+        oi.integrate(pose[0], pose[1], pts, col)
+        oe.update_from_tsdf_layer(True)
+        gm.integrate(capi.TSDF_MERGED, gt, pose[0], pose[1], pts, col)
+        gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+    g, r = _gpu_esdf(gm), om.esdf_dict()
+    assert set(g.keys()) == set(r.keys())
+    se = 0.0; n = 0; nband = 0
+    for k in r:
+        gd, gf, _, _ = g[k]
+        rd, rf, _, _ = r[k]
+        assert np.array_equal(gf & 1, rf & 1)
+        obs = (rf & 1).astype(bool)
+        e = (gd[obs] - rd[obs]).astype(np.float64)
+        se += float((e * e).sum()); n += int(obs.sum())
+        band = ((gf & 8) != 0) & ((rf & 8) != 0)
+        # fixed band: both are copies of the same TSDF voxel, up to the min_diff_m gate
+        assert np.abs(gd[band] - rd[band]).max(initial=0.0) <= 1e-3 + 1e-7
+        nband += int(band.sum())
+    assert n > 100000 and nband > 1000
+    assert (se / n) ** 0.5 < 1e-2

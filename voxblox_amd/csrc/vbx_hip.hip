@@ -92,7 +92,9 @@ struct DevState {
   uint32_t changed;
   uint32_t sentinel_cleared;
   uint32_t blocks_published;
-  uint32_t pad;
+  uint32_t esdf_blocks;
+  uint32_t esdf_raise_any;
+  uint32_t esdf_relax_blocks;
   unsigned long long total_keys;
   unsigned long long voxels_touched;
   unsigned long long rays_cast;
@@ -200,6 +202,21 @@ __device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* n
     h = (h + 1) & m.hmask;
   }
   atomicOr(&st->error, 1u);
+}
+
+// Marks a block as part of the Layer and sets all Update bits (tsdf_integrator.cc:128).  The
+// common case — block already published and flagged this frame — is a plain L2 read: only
+// the first toucher pays for the atomic, so hundreds of thousands of rays crossing ~200
+// blocks do not serialise on ~200 addresses.
+__device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* st) {
+  const uint32_t want = kFlagPublished | kFlagUpdMask;
+  const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((cur & want) == want) return;
+  const uint32_t old = atomicOr(&m.blk_flags[slot], want);
+  if (!(old & kFlagPublished)) {
+    atomicOr(&m.blk_flags[slot], kFlagNewThisCall);
+    atomicAdd(&st->blocks_published, 1u);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -412,11 +429,7 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
         if (slot == kInvalidSlot) {
           atomicOr(&st->error, 2u);
         } else {
-          const uint32_t old = atomicOr(&m.blk_flags[slot], kFlagPublished | kFlagUpdMask);
-          if (!(old & kFlagPublished)) {
-            atomicOr(&m.blk_flags[slot], kFlagNewThisCall);
-            atomicAdd(&st->blocks_published, 1u);
-          }
+          publish_block(m, slot, st);
         }
       }
       if (slot != kInvalidSlot) {
@@ -775,11 +788,319 @@ __global__ void k_fast_emit(const uint32_t* __restrict__ off_full, const uint32_
   // tsdf_integrator.cc:128: block->updated().set() on every visited voxel's block
   const uint32_t slot = gid / m.nvox;
   const bool first_of_block = (k == 0) || (vox[off_full[r] + k - 1] / m.nvox != slot);
-  if (first_of_block) {
-    const uint32_t old = atomicOr(&m.blk_flags[slot], kFlagPublished | kFlagUpdMask);
-    if (!(old & kFlagPublished)) {
-      atomicOr(&m.blk_flags[slot], kFlagNewThisCall);
-      atomicAdd(&st->blocks_published, 1u);
+  if (first_of_block) publish_block(m, slot, st);
+}
+
+// ===========================================================================
+// ESDF integrator (esdf_integrator.cc) — see DESIGN.md §ESDF.
+//
+// The reference runs three strictly sequential phases per update: (1) walk every voxel of the
+// updated TSDF blocks and classify it (new / lower / raise / sign flip), (2) a FIFO "raise"
+// wavefront that invalidates the children (by parent pointer) of voxels whose distance grew,
+// (3) a bucket-queue "lower" wavefront that relaxes 26-neighbours until nothing improves.
+// Phase 1 is per-voxel independent and is reproduced rule by rule.  Phases 2 and 3 compute
+// closures / fixed points that do not depend on the visiting order (for min_diff_m == 0 the
+// lower phase is Bellman-Ford on the 26-graph: every voxel ends at the float-minimum over
+// all paths), so they run as LDS-tiled chaotic relaxations: one workgroup stages a block plus
+// its one-voxel halo (18^3 distances + states, 46 KiB) in LDS, relaxes it to a local fixed
+// point, and the host repeats global sweeps until no block changes.
+// ===========================================================================
+constexpr uint32_t kFlagEsdfAlloc = 0x1000;   // block exists in Layer<EsdfVoxel>
+constexpr uint32_t kFlagEsdfUpdShift = 4;     // ESDF block's Update bits live in bits 4..6
+constexpr uint32_t kEsdfObserved = 1, kEsdfHallucinated = 2, kEsdfInQueue = 4, kEsdfFixed = 8;
+
+struct EsdfDev {
+  float* dist;
+  uint32_t* state;    // bits 0-3 flags, 8-15 / 16-23 / 24-31 parent x/y/z (int8)
+  uint8_t* raised;    // 1 = raised during the current update
+  uint32_t* active;   // per slot: 1 = process this sweep, 2 = process next sweep, 4 = touched
+};
+struct EsdfCfgDev {
+  float max_distance, min_distance, default_distance, min_diff, min_weight;
+  int add_occupied_crust;
+  float voxel_size;
+};
+
+__constant__ int c_nb_off[26][3] = {
+    {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+    {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {0, -1, -1}, {0, -1, 1},
+    {0, 1, -1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
+    {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1},
+    {1, 1, -1}, {1, 1, 1}};  // neighbor_tools.cc:24-30, column order is observable
+
+__device__ inline uint32_t pack_parent(int x, int y, int z) {
+  return ((uint32_t)(uint8_t)(int8_t)x << 8) | ((uint32_t)(uint8_t)(int8_t)y << 16) |
+         ((uint32_t)(uint8_t)(int8_t)z << 24);
+}
+__device__ inline void unpack_parent(uint32_t s, int* x, int* y, int* z) {
+  *x = (int)(int8_t)((s >> 8) & 0xFF);
+  *y = (int)(int8_t)((s >> 16) & 0xFF);
+  *z = (int)(int8_t)((s >> 24) & 0xFF);
+}
+
+// Phase 1: EsdfIntegrator::updateFromTsdfBlocks, esdf_integrator.cc:136-287, one thread per
+// voxel of every TSDF block that carries the kEsdf update bit (incremental) or of every
+// allocated TSDF block (batch).  Queue pushes become marks: `raised` for raise_.push, block
+// activity for open_.push (the lower phase re-relaxes whole active blocks).
+// updateVoxelFromNeighbors (:498-530) is a pull from already-converged neighbours; the lower
+// phase's pull relaxation subsumes it (and does not reproduce its unscaled-distance quirk).
+__global__ void k_esdf_classify(MapDev m, EsdfDev e, EsdfCfgDev c, int incremental, DevState* st) {
+  const uint32_t slot = blockIdx.x;
+  const uint32_t flags = m.blk_flags[slot];
+  if (!(flags & kFlagPublished)) return;
+  if (incremental && !(flags & 4u)) return;  // Update::kEsdf
+  const uint32_t lin = blockIdx.y * blockDim.x + threadIdx.x;
+  if (lin >= m.nvox) return;
+  if (lin == 0) {
+    atomicOr(&m.blk_flags[slot], kFlagEsdfAlloc | (1u << kFlagEsdfUpdShift));  // set_updated(true): kMap only
+    e.active[slot] |= 8u;  // processed by this update
+    atomicAdd(&st->esdf_blocks, 1u);
+  }
+  const uint32_t gid = slot * m.nvox + lin;
+  const float td = m.dist[gid];
+  const float tw = m.weight[gid];
+  float ed = e.dist[gid];
+  uint32_t es = e.state[gid];
+  if (tw < c.min_weight) {
+    if (!incremental && c.add_occupied_crust) {
+      ed = -c.default_distance;
+      es = (es | kEsdfObserved | kEsdfHallucinated) & ~kEsdfFixed;
+      e.dist[gid] = ed;
+      e.state[gid] = es;
+    }
+    return;
+  }
+  const bool tsdf_fixed = fabsf(td) < c.min_distance;
+  const float sgn_default = (float)signum(td) * c.default_distance;
+  bool raise = false;
+  if (!(es & kEsdfObserved) || (es & kEsdfHallucinated)) {
+    if (es & kEsdfHallucinated) raise = true;
+    if (tsdf_fixed) {
+      ed = td;
+      es |= kEsdfFixed;
+    } else {
+      ed = sgn_default;
+      es &= ~kEsdfFixed;
+    }
+    es &= 0xFFu;  // parent.setZero()
+  } else {
+    const bool efixed = (es & kEsdfFixed) != 0;
+    if (tsdf_fixed || efixed) {
+      if (!tsdf_fixed) {
+        ed = sgn_default;
+        es &= 0xFFu;
+        es &= ~kEsdfFixed;
+        raise = true;
+      } else if ((ed > 0.0f && td + c.min_diff < ed) || (ed <= 0.0f && td - c.min_diff > ed)) {
+        es |= kEsdfFixed;  // fixed = tsdf_fixed (true here)
+        ed = td;
+        es &= 0xFFu;
+      } else if ((ed > 0.0f && td - c.min_diff > ed) || (ed <= 0.0f && td + c.min_diff < ed)) {
+        es |= kEsdfFixed;
+        ed = td;
+        es &= 0xFFu;
+        raise = true;
+      }
+    } else if (signum(td) != signum(ed)) {
+      if (td < ed) {
+        ed = sgn_default;
+        es &= 0xFFu;
+      } else {
+        ed = sgn_default;
+        es &= 0xFFu;
+        raise = true;
+      }
+    }
+  }
+  es |= kEsdfObserved;
+  es &= ~(kEsdfHallucinated | kEsdfInQueue);
+  e.dist[gid] = ed;
+  e.state[gid] = es;
+  if (raise) {
+    e.raised[gid] = 1;
+    st->esdf_raise_any = 1;
+  }
+}
+
+// active(cur) = every block processed by this update and its 26 neighbours.
+__global__ void k_esdf_seed_active(MapDev m, EsdfDev e, uint32_t n_slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t slot = i / 27, nb = i % 27;
+  if (slot >= n_slots) return;
+  if (!(e.active[slot] & 8u)) return;
+  const int dx = (int)(nb % 3) - 1, dy = (int)((nb / 3) % 3) - 1, dz = (int)(nb / 9) - 1;
+  const uint32_t s2 = map_find(m, pack_block_key(m.blk_idx[3 * slot] + dx, m.blk_idx[3 * slot + 1] + dy,
+                                                 m.blk_idx[3 * slot + 2] + dz));
+  if (s2 != kInvalidSlot && (m.blk_flags[s2] & kFlagEsdfAlloc)) atomicOr(&e.active[s2], 1u | 4u);
+}
+__global__ void k_esdf_rotate_active(EsdfDev e, uint32_t n_slots, int reseed) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint32_t a = e.active[s];
+  uint32_t cur = (a & 2u) ? 1u : 0u;
+  if (reseed) cur = (a & 4u) ? 1u : 0u;  // start of a new phase: everything touched so far
+  e.active[s] = cur | (a & 12u) | (cur ? 4u : 0u);
+}
+
+// Phases 2/3 (+ parent canonicalisation) on one block + halo staged in LDS.
+//   mode 0: processRaiseSet (esdf_integrator.cc:305-369) as a closure: a non-fixed observed
+//           voxel whose parent voxel was raised is reset to sign*default and raised itself.
+//   mode 1: processOpenSet (:371-496) as a pull relaxation over the 26-neighbourhood.
+//   mode 2: parent = first LUT neighbour that explains the converged distance exactly.
+template <int VPS>
+__global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
+                                                   DevState* st) {
+  constexpr int T = VPS + 2;
+  constexpr int NT = T * T * T;
+  constexpr int NV = VPS * VPS * VPS;
+  __shared__ float s_d[NT];
+  __shared__ uint32_t s_s[NT];
+  __shared__ uint8_t s_r[NT];
+  __shared__ uint32_t s_nb[27];
+  __shared__ int s_flag;
+  const uint32_t slot = blockIdx.x;
+  if (!(m.blk_flags[slot] & kFlagEsdfAlloc)) return;
+  if (!(e.active[slot] & 1u)) return;
+  const int tid = threadIdx.x;
+  if (tid < 27) {
+    const int dx = tid % 3 - 1, dy = (tid / 3) % 3 - 1, dz = tid / 9 - 1;
+    uint32_t s2 = map_find(m, pack_block_key(m.blk_idx[3 * slot] + dx, m.blk_idx[3 * slot + 1] + dy,
+                                             m.blk_idx[3 * slot + 2] + dz));
+    if (s2 != kInvalidSlot && !(m.blk_flags[s2] & kFlagEsdfAlloc)) s2 = kInvalidSlot;
+    s_nb[tid] = s2;
+  }
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+  for (int t = tid; t < NT; t += 256) {
+    const int tx = t % T, ty = (t / T) % T, tz = t / (T * T);
+    const int bx = (tx == 0) ? 0 : (tx == T - 1 ? 2 : 1);
+    const int by = (ty == 0) ? 0 : (ty == T - 1 ? 2 : 1);
+    const int bz = (tz == 0) ? 0 : (tz == T - 1 ? 2 : 1);
+    const uint32_t s2 = s_nb[bx + 3 * by + 9 * bz];
+    float d = 0.f;
+    uint32_t s = 0;  // getVoxelPtrByGlobalIndex == nullptr: looks unobserved
+    uint8_t r = 0;
+    if (s2 != kInvalidSlot) {
+      const int lx = (tx - 1) & (VPS - 1), ly = (ty - 1) & (VPS - 1), lz = (tz - 1) & (VPS - 1);
+      const uint32_t g2 = s2 * NV + (uint32_t)(lx + VPS * (ly + lz * VPS));
+      d = e.dist[g2];
+      s = e.state[g2];
+      r = e.raised[g2];
+    }
+    s_d[t] = d;
+    s_s[t] = s;
+    s_r[t] = r;
+  }
+  __syncthreads();
+
+  const float sq2 = (float)1.4142135623730951, sq3 = (float)1.7320508075688772;
+  bool any_change = false;
+  for (int iter = 0; iter < 4 * VPS; ++iter) {
+    bool changed = false;
+    for (int v = tid; v < NV; v += 256) {
+      const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+      const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+      uint32_t s = s_s[t];
+      if (!(s & kEsdfObserved) || (s & kEsdfFixed)) continue;
+      float d = s_d[t];
+      if (mode == 0) {
+        int px, py, pz;
+        unpack_parent(s, &px, &py, &pz);
+        if ((px | py | pz) == 0 || s_r[t]) continue;
+        // quasi-Euclidean parents are unit LUT offsets, so the parent voxel is inside the halo
+        const int tp = t + px + T * (py + T * pz);
+        if (s_r[tp]) {
+          s_d[t] = (float)signum(d) * c.default_distance;
+          s_s[t] = s & 0xFFu;
+          s_r[t] = 1;
+          changed = true;
+        }
+        continue;
+      }
+      if (mode == 1) {
+        bool upd = false;
+        int best = -1;
+#pragma unroll 1
+        for (int i = 0; i < 26; ++i) {
+          const int tv = t + c_nb_off[i][0] + T * (c_nb_off[i][1] + T * c_nb_off[i][2]);
+          const uint32_t sv = s_s[tv];
+          if (!(sv & kEsdfObserved)) continue;
+          const float dv = s_d[tv];
+          if (dv >= c.max_distance || dv <= -c.max_distance) continue;
+          const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
+          if (dv > 0 && d > 0) {
+            if (dv + dist + c.min_diff < d) { d = dv + dist; best = i; upd = true; }
+          } else if (dv <= 0 && d <= 0) {
+            if (dv - dist - c.min_diff > d) { d = dv - dist; best = i; upd = true; }
+          } else {
+            // sign mismatch (esdf_integrator.cc:459-488).  In the reference this assignment is
+            // gated by |potential - d| > dist and its outcome depends on the pop order of the
+            // two neighbours (libstdc++ unordered_map block order).  The order-free form used
+            // here applies the same candidate whenever it moves the voxel closer to the
+            // surface, which is the outcome of the reference when the opposite-sign neighbour
+            // pops first.
+            const float potential = dv - (float)signum(dv) * dist;
+            float cand;
+            if ((float)signum(potential) == d) cand = potential;
+            else cand = (float)signum(d) * dist;
+            if (fabsf(cand) < fabsf(d)) { d = cand; best = i; upd = true; }
+          }
+        }
+        if (upd) {
+          s_d[t] = d;
+          s_s[t] = (s & 0xFFu) | pack_parent(c_nb_off[best][0], c_nb_off[best][1], c_nb_off[best][2]);
+          changed = true;
+        }
+        continue;
+      }
+      // mode 2: canonical parent
+      {
+        int px, py, pz;
+        unpack_parent(s, &px, &py, &pz);
+        if ((px | py | pz) == 0) continue;
+        for (int i = 0; i < 26; ++i) {
+          const int tv = t + c_nb_off[i][0] + T * (c_nb_off[i][1] + T * c_nb_off[i][2]);
+          const uint32_t sv = s_s[tv];
+          if (!(sv & kEsdfObserved)) continue;
+          const float dv = s_d[tv];
+          if (dv >= c.max_distance || dv <= -c.max_distance) continue;
+          const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
+          bool hit;
+          if (dv > 0 && d > 0) hit = (dv + dist == d);
+          else if (dv <= 0 && d <= 0) hit = (dv - dist == d);
+          else {  // the sign-mismatch rule: d == potential or sign(d) * dist
+            const float potential = dv - (float)signum(dv) * dist;
+            const float cand = ((float)signum(potential) == d) ? potential : (float)signum(d) * dist;
+            hit = (cand == d);
+          }
+          if (hit) {
+            const uint32_t ns = (s & 0xFFu) | pack_parent(c_nb_off[i][0], c_nb_off[i][1], c_nb_off[i][2]);
+            if (ns != s) { s_s[t] = ns; changed = true; }
+            break;
+          }
+        }
+      }
+    }
+    any_change |= changed;
+    const int more = __syncthreads_or(changed ? 1 : 0);
+    if (!more || mode == 2) break;
+  }
+  if (any_change) s_flag = 1;
+  __syncthreads();
+  if (!s_flag) return;
+  for (int v = tid; v < NV; v += 256) {
+    const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+    const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+    const uint32_t g = slot * NV + v;
+    e.dist[g] = s_d[t];
+    e.state[g] = s_s[t];
+    e.raised[g] = s_r[t];
+  }
+  if (mode != 2) {
+    if (tid < 27 && s_nb[tid] != kInvalidSlot) atomicOr(&e.active[s_nb[tid]], 2u | 4u);
+    if (tid == 0) {
+      st->changed = 1;
+      atomicAdd(&st->esdf_relax_blocks, 1u);
     }
   }
 }
@@ -816,6 +1137,9 @@ struct vbx_ctx {
   bool startset_init = false;
   int64_t reset_counter = 0;  // tsdf_integrator.cc:564
   DBuf b_own0, b_own1;
+  // ESDF layer (allocated on first use)
+  DBuf b_edist, b_estate, b_eraised, b_eactive;
+  bool esdf_init = false;
   uint32_t own_tag = 0;  // descending
   int own_s_bits = 0;
 
@@ -1287,6 +1611,155 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   return VBX_OK;
 }
 
+
+__global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int drop_layer) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  e.active[s] = 0;
+  if (drop_layer) m.blk_flags[s] &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+}
+__global__ void k_esdf_clear_tsdf_bit(MapDev m, EsdfDev e, uint32_t n_slots) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  if (e.active[s] & 8u) m.blk_flags[s] &= ~4u;  // updated().reset(Update::kEsdf), esdf_integrator.cc:113-121
+}
+
+EsdfDev esdf_dev(vbx_ctx* ctx) {
+  EsdfDev e;
+  e.dist = ctx->b_edist.as<float>();
+  e.state = ctx->b_estate.as<uint32_t>();
+  e.raised = ctx->b_eraised.as<uint8_t>();
+  e.active = ctx->b_eactive.as<uint32_t>();
+  return e;
+}
+
+int esdf_ensure(vbx_ctx* ctx) {
+  if (ctx->esdf_init) return VBX_OK;
+  const MapDev& m = ctx->map;
+  const size_t nv = (size_t)m.cap_blocks * m.nvox;
+  HIP_TRY(ctx->b_edist.ensure(nv * 4));
+  HIP_TRY(ctx->b_estate.ensure(nv * 4));
+  HIP_TRY(ctx->b_eraised.ensure(nv));
+  HIP_TRY(ctx->b_eactive.ensure((size_t)m.cap_blocks * 4));
+  HIP_TRY(hipMemsetAsync(ctx->b_edist.p, 0, nv * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->b_estate.p, 0, nv * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->b_eraised.p, 0, nv, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->b_eactive.p, 0, (size_t)m.cap_blocks * 4, ctx->stream));
+  ctx->esdf_init = true;
+  return VBX_OK;
+}
+
+template <int VPS>
+int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, uint32_t used,
+               uint32_t* sweeps) {
+  hipStream_t s = ctx->stream;
+  for (;;) {
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+    hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(256), 0, s, ctx->map, e, c, mode, ctx->d_state);
+    ++*sweeps;
+    if (mode == 2) return VBX_OK;
+    hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
+    int rc = sync_state(ctx);
+    if (rc) return rc;
+    if (!ctx->h_state.changed) return VBX_OK;
+    if (*sweeps > 100000) {
+      ctx->fail("ESDF: wavefront did not converge");
+      return VBX_ERR_HIP;
+    }
+  }
+}
+
+template <int VPS>
+int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  int rc = esdf_ensure(ctx);
+  if (rc) return rc;
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  ctx->counters = vbx_counters{};
+  if (used == 0) return VBX_OK;
+  EsdfDev e = esdf_dev(ctx);
+  EsdfCfgDev c;
+  c.max_distance = cfg->max_distance_m;
+  c.min_distance = cfg->min_distance_m;
+  c.default_distance = cfg->default_distance_m;
+  c.min_diff = cfg->min_diff_m;
+  c.min_weight = cfg->min_weight;
+  c.add_occupied_crust = cfg->add_occupied_crust != 0;
+  c.voxel_size = m.voxel_size;
+  const size_t nv = (size_t)used * m.nvox;
+  for (int i = 0; i < 8; ++i) ctx->ev_hit[i] = false;
+  tmark(ctx, 0);
+  if (batch) {  // esdf_layer_->removeAllBlocks(), esdf_integrator.cc:95
+    HIP_TRY(hipMemsetAsync(e.dist, 0, nv * 4, s));
+    HIP_TRY(hipMemsetAsync(e.state, 0, nv * 4, s));
+  }
+  HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
+  hipLaunchKernelGGL(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0);
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->esdf_blocks, 0, 12, s));
+  hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
+                     batch ? 0 : 1, ctx->d_state);
+  hipLaunchKernelGGL(k_esdf_seed_active, grid_for((size_t)used * 27), dim3(256), 0, s, m, e, used);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  tmark(ctx, 1);
+  ctx->counters.esdf_blocks = ctx->h_state.esdf_blocks;
+  uint32_t sweeps = 0;
+  // The wavefronts run to their exact fixed points: min_diff_m only gates the TSDF->ESDF copy
+  // of phase 1 (see DESIGN.md §ESDF for why the relaxation itself uses strict improvement).
+  EsdfCfgDev cr = c;
+  cr.min_diff = 0.0f;
+  if (ctx->h_state.esdf_blocks) {
+    if (ctx->h_state.esdf_raise_any) {
+      rc = esdf_phase<VPS>(ctx, e, cr, 0, used, &sweeps);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+    }
+    tmark(ctx, 3);
+    rc = esdf_phase<VPS>(ctx, e, cr, 1, used, &sweeps);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+    rc = esdf_phase<VPS>(ctx, e, cr, 2, used, &sweeps);
+    if (rc) return rc;
+    tmark(ctx, 6);
+  }
+  if (clear_updated_flag && !batch)
+    hipLaunchKernelGGL(k_esdf_clear_tsdf_bit, grid_for(used), dim3(256), 0, s, m, e, used);
+  tmark(ctx, 7);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  ctx->counters.esdf_sweeps = sweeps;
+  ctx->counters.esdf_relaxations = ctx->h_state.esdf_relax_blocks;
+  if (ctx->timing) {
+    vbx_timing& o = ctx->last_timing;
+    o = vbx_timing{};
+    float t = 0;
+    (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
+    (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]);
+    o.prep_ms = t;  // phase 1 (classification)
+    if (ctx->ev_hit[3]) { (void)hipEventElapsedTime(&t, ctx->ev[1], ctx->ev[3]); o.solve_ms = t; }  // raise
+    if (ctx->ev_hit[6]) { (void)hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[6]); o.fold_ms = t; }   // lower
+  }
+  return VBX_OK;
+}
+
+int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (cfg->full_euclidean_distance) {
+    ctx->fail("ESDF: full_euclidean_distance is not supported yet (quasi-Euclidean only)");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  switch (ctx->map.vps) {
+    case 8: return esdf_update_t<8>(ctx, cfg, batch, clear_updated_flag);
+    case 16: return esdf_update_t<16>(ctx, cfg, batch, clear_updated_flag);
+    default:
+      ctx->fail("ESDF: voxels_per_side must be 8 or 16 (LDS tile)");
+      return VBX_ERR_UNSUPPORTED;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1412,7 +1885,8 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1};
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   for (int i = 0; i < 8; ++i)
@@ -1454,17 +1928,15 @@ int vbx_tsdf_integrate(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const fl
 }
 
 int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
-  if (!ctx) return VBX_ERR_INVALID;
-  (void)cfg; (void)batch; (void)clear_updated_flag;
-  ctx->fail("vbx_esdf_update: not implemented yet");
-  return VBX_ERR_UNSUPPORTED;
+  if (!ctx || !cfg) return VBX_ERR_INVALID;
+  return esdf_update(ctx, cfg, batch, clear_updated_flag);
 }
 
 // ---- block listing / transfer --------------------------------------------------------
 static int list_blocks(vbx_ctx* ctx, int layer, uint32_t need_mask, std::vector<std::pair<uint64_t, uint32_t>>* out) {
-  if (layer != VBX_LAYER_TSDF) {
-    ctx->fail("ESDF layer not implemented yet");
-    return VBX_ERR_UNSUPPORTED;
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+    ctx->fail("unknown layer %d", layer);
+    return VBX_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = sync_state(ctx);
@@ -1478,8 +1950,13 @@ static int list_blocks(vbx_ctx* ctx, int layer, uint32_t need_mask, std::vector<
   }
   out->clear();
   for (uint32_t sl = 0; sl < used; ++sl) {
-    if (!(flags[sl] & kFlagPublished)) continue;
-    if (need_mask && !(flags[sl] & need_mask)) continue;
+    if (layer == VBX_LAYER_ESDF) {
+      if (!(flags[sl] & kFlagEsdfAlloc)) continue;
+      if (need_mask && !((flags[sl] >> kFlagEsdfUpdShift) & need_mask)) continue;
+    } else {
+      if (!(flags[sl] & kFlagPublished)) continue;
+      if (need_mask && !(flags[sl] & need_mask)) continue;
+    }
     out->emplace_back(pack_block_key(idx[3 * sl], idx[3 * sl + 1], idx[3 * sl + 2]), sl);
   }
   std::sort(out->begin(), out->end());
@@ -1543,10 +2020,6 @@ static int find_slot_host(vbx_ctx* ctx, const int32_t idx[3], uint32_t* slot, ui
 int vbx_block_download(vbx_ctx* ctx, int layer, const int32_t idx[3], void* aos, uint8_t* updated_bits,
                        uint8_t* has_data) {
   if (!ctx || !idx || !aos) return VBX_ERR_INVALID;
-  if (layer != VBX_LAYER_TSDF) {
-    ctx->fail("ESDF layer not implemented yet");
-    return VBX_ERR_UNSUPPORTED;
-  }
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   uint32_t slot;
@@ -1554,11 +2027,32 @@ int vbx_block_download(vbx_ctx* ctx, int layer, const int32_t idx[3], void* aos,
   if (rc) return rc;
   uint32_t flags = 0;
   if (slot != kInvalidSlot) HIP_TRY(hipMemcpy(&flags, ctx->map.blk_flags + slot, 4, hipMemcpyDeviceToHost));
-  if (slot == kInvalidSlot || !(flags & kFlagPublished)) {
+  const uint32_t need = (layer == VBX_LAYER_ESDF) ? kFlagEsdfAlloc : kFlagPublished;
+  if (slot == kInvalidSlot || !(flags & need) || (layer == VBX_LAYER_ESDF && !ctx->esdf_init)) {
     ctx->fail("block (%d,%d,%d) is not allocated", idx[0], idx[1], idx[2]);
     return VBX_ERR_INVALID;
   }
   const uint32_t nv = ctx->map.nvox;
+  if (layer == VBX_LAYER_ESDF) {
+    std::vector<float> d(nv);
+    std::vector<uint32_t> st(nv);
+    HIP_TRY(hipMemcpy(d.data(), ctx->b_edist.as<float>() + (size_t)slot * nv, nv * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), ctx->b_estate.as<uint32_t>() + (size_t)slot * nv, nv * 4, hipMemcpyDeviceToHost));
+    uint8_t* o = static_cast<uint8_t*>(aos);
+    for (uint32_t i = 0; i < nv; ++i) {  // EsdfVoxel AoS, voxel.h:18-37 (20 bytes)
+      std::memcpy(o + 20 * i, &d[i], 4);
+      o[20 * i + 4] = (st[i] & 1) ? 1 : 0;
+      o[20 * i + 5] = (st[i] & 2) ? 1 : 0;
+      o[20 * i + 6] = (st[i] & 4) ? 1 : 0;
+      o[20 * i + 7] = (st[i] & 8) ? 1 : 0;
+      const int32_t p[3] = {(int32_t)(int8_t)((st[i] >> 8) & 0xFF), (int32_t)(int8_t)((st[i] >> 16) & 0xFF),
+                            (int32_t)(int8_t)((st[i] >> 24) & 0xFF)};
+      std::memcpy(o + 20 * i + 8, p, 12);
+    }
+    if (updated_bits) *updated_bits = (uint8_t)((flags >> kFlagEsdfUpdShift) & kFlagUpdMask);
+    if (has_data) *has_data = 0;
+    return VBX_OK;
+  }
   std::vector<float> d(nv), w(nv);
   std::vector<uint32_t> c(nv);
   HIP_TRY(hipMemcpy(d.data(), ctx->map.dist + (size_t)slot * nv, nv * 4, hipMemcpyDeviceToHost));
@@ -1633,13 +2127,33 @@ int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* 
   return VBX_OK;
 }
 
-static int remove_slot(vbx_ctx* ctx, uint32_t slot, uint32_t hpos) {
+static int remove_slot(vbx_ctx* ctx, int layer, uint32_t slot, uint32_t hpos) {
   // Unpublish and zero the block; the hash entry stays and keeps its slot, so the block is
   // simply a zeroed "candidate" again (no tombstones, no free-list churn).
   MapDev& m = ctx->map;
   (void)hpos;
   const uint32_t nv = m.nvox;
   const uint32_t zero = 0;
+  if (layer == VBX_LAYER_ESDF) {
+    if (!ctx->esdf_init) return VBX_OK;
+    uint32_t f;
+    HIP_TRY(hipMemset(ctx->b_edist.as<float>() + (size_t)slot * nv, 0, nv * 4));
+    HIP_TRY(hipMemset(ctx->b_estate.as<uint32_t>() + (size_t)slot * nv, 0, nv * 4));
+    HIP_TRY(hipMemcpy(&f, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
+    f &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+    HIP_TRY(hipMemcpy(m.blk_flags + slot, &f, 4, hipMemcpyHostToDevice));
+    return VBX_OK;
+  }
+  {  // a removed TSDF block keeps its ESDF flags (the layers are independent, layer.h:167)
+    uint32_t f;
+    HIP_TRY(hipMemcpy(&f, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
+    f &= (kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+    HIP_TRY(hipMemset(m.dist + (size_t)slot * nv, 0, nv * 4));
+    HIP_TRY(hipMemset(m.weight + (size_t)slot * nv, 0, nv * 4));
+    HIP_TRY(hipMemset(m.rgba + (size_t)slot * nv, 0, nv * 4));
+    HIP_TRY(hipMemcpy(m.blk_flags + slot, &f, 4, hipMemcpyHostToDevice));
+    return VBX_OK;
+  }
   HIP_TRY(hipMemset(m.dist + (size_t)slot * nv, 0, nv * 4));
   HIP_TRY(hipMemset(m.weight + (size_t)slot * nv, 0, nv * 4));
   HIP_TRY(hipMemset(m.rgba + (size_t)slot * nv, 0, nv * 4));
@@ -1649,17 +2163,13 @@ static int remove_slot(vbx_ctx* ctx, uint32_t slot, uint32_t hpos) {
 
 int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]) {
   if (!ctx || !idx) return VBX_ERR_INVALID;
-  if (layer != VBX_LAYER_TSDF) {
-    ctx->fail("ESDF layer not implemented yet");
-    return VBX_ERR_UNSUPPORTED;
-  }
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   uint32_t slot, hpos = 0;
   int rc = find_slot_host(ctx, idx, &slot, &hpos);
   if (rc) return rc;
   if (slot == kInvalidSlot) return VBX_OK;  // unordered_map::erase of a missing key is a no-op
-  return remove_slot(ctx, slot, hpos);
+  return remove_slot(ctx, layer, slot, hpos);
 }
 
 int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance) {
@@ -1676,7 +2186,7 @@ int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], do
     const f3 o{(float)x * block_size, (float)y * block_size, (float)z * block_size};
     const f3 d = f3_sub(o, f3{center[0], center[1], center[2]});
     if ((double)f3_sqnorm(d) > max_distance * max_distance) {
-      rc = remove_slot(ctx, kv.second, 0);
+      rc = remove_slot(ctx, layer, kv.second, 0);
       if (rc) return rc;
     }
   }
@@ -1689,7 +2199,7 @@ int vbx_clear(vbx_ctx* ctx, int layer) {
   int rc = list_blocks(ctx, layer, 0, &v);
   if (rc) return rc;
   for (const auto& kv : v) {
-    rc = remove_slot(ctx, kv.second, 0);
+    rc = remove_slot(ctx, layer, kv.second, 0);
     if (rc) return rc;
   }
   return VBX_OK;
@@ -1703,7 +2213,8 @@ int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask) {
   for (const auto& kv : v) {
     uint32_t f;
     HIP_TRY(hipMemcpy(&f, ctx->map.blk_flags + kv.second, 4, hipMemcpyDeviceToHost));
-    f &= ~((uint32_t)update_mask & kFlagUpdMask);
+    if (layer == VBX_LAYER_ESDF) f &= ~(((uint32_t)update_mask & kFlagUpdMask) << kFlagEsdfUpdShift);
+    else f &= ~((uint32_t)update_mask & kFlagUpdMask);
     HIP_TRY(hipMemcpy(ctx->map.blk_flags + kv.second, &f, 4, hipMemcpyHostToDevice));
   }
   return VBX_OK;
