@@ -23,6 +23,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,7 @@ struct DevState {
   uint32_t esdf_blocks;
   uint32_t esdf_raise_any;
   uint32_t esdf_relax_blocks;
+  uint32_t act_count[2];
   unsigned long long total_keys;
   unsigned long long voxels_touched;
   unsigned long long rays_cast;
@@ -716,53 +718,140 @@ __global__ void k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32
 // voxel list at once, the consecutive-collision counter becomes a run-length computed from
 // the ballot mask, and the first lane whose run exceeds max_consecutive_ray_collisions is
 // the termination step.
-__global__ void __launch_bounds__(256)
-k_fast_sweep(const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, uint32_t R,
-             int max_consecutive, const uint32_t* __restrict__ own_rd, uint32_t* own_wr,
-             uint32_t tag_rd, uint32_t tag_wr, int s_bits, uint32_t* T, uint32_t* U, int first,
-             DevState* st) {
+// Two-sided form of that iteration.  Every ray carries a lower bound TL and an upper bound TH
+// on its true number of probes T* (TL = 0, TH = full path length to start with).
+//   certain claims  CL(v) = min{r : v among the first TL_r voxels of r}   (>= true owner)
+//   possible claims CH(v) = min{r : v among the first TH_r voxels of r}   (<= true owner)
+// A sweep recomputes TH from the certain claims only (fewest collisions -> latest stop) and TL
+// from the possible claims (most collisions -> earliest stop).  TL only grows and TH only
+// shrinks, so CL is a persistent atomicMin array, a ray with TL == TH is final for good and
+// drops out of the work list, and only the possible claims of the still-open rays are rebuilt
+// per sweep (tagged ping-pong arrays; the final rays' claims are already in CL).  The loop
+// ends when no ray is open; the fixed point is the reference's sequential result.
+//
+// G lanes per ray: the lanes fetch G consecutive entries of the ray's voxel list at once, the
+// consecutive-collision counter becomes a run-length computed from the ballot mask, and the
+// first lane whose run exceeds max_consecutive_ray_collisions is the termination step.
+// atomicMin that first looks: near the sensor origin tens of thousands of rays share the same
+// few voxels, and same-address atomics serialise (~90 per microsecond on one word).  Claims
+// only ever decrease, so when the word already holds a smaller value the RMW is a no-op and
+// can be skipped after an L2 read.
+__device__ inline void claim_min(uint32_t* p, uint32_t val) {
+  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > val) atomicMin(p, val);
+}
+
+struct SweepArgs {
+  const uint32_t* off;      // voxel list offsets (R+1)
+  const uint32_t* vox;      // voxel lists
+  const uint32_t* list_in;  // open rays of this sweep (null: identity, all R rays)
+  uint32_t* list_out;       // open rays for the next sweep
+  uint32_t n_in;            // upper bound of the input list length (grid size)
+  int which;                // DevState::act_count[which] = input count, [which^1] = output
+  uint32_t* cl;             // certain claims (persistent within the frame)
+  const uint32_t* ch_rd;    // possible claims of open rays, previous sweep
+  uint32_t* ch_wr;          // possible claims of open rays, this sweep
+  uint32_t tag_cl, tag_rd, tag_wr;
+  int s_bits;
+  int max_consecutive;
+  uint32_t* TL; uint32_t* TH; uint32_t* U;
+  int init;                 // 1: first pass (publish full-path possible claims, no reads)
+  int l_only;               // 1: only tighten the lower bounds (TH and the possible claims stay)
+};
+
+template <int G>
+__global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, DevState* st) {
   const int lane = threadIdx.x & 63;
-  const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= R) return;
-  const uint32_t beg = off[r];
-  const uint32_t len = off[r + 1] - beg;
-  const uint32_t smask = (1u << s_bits) - 1;
-  const uint32_t wr_val = (tag_wr << s_bits) | r;
-  int cons_in = 0;
-  uint32_t t_end = len, u_end = len;
-  for (uint32_t base = 0; base < len; base += 64) {
-    const uint32_t k = base + lane;
-    const bool act = k < len;
-    const uint32_t gid = act ? vox[beg + k] : 0xFFFFFFFFu;
-    bool present = false;
-    if (gid != 0xFFFFFFFFu && !first) {
-      const uint32_t ov = own_rd[gid];
-      present = ((ov >> s_bits) == tag_rd) && ((ov & smask) < r);
+  const int grp = lane / G;
+  const int gl = lane % G;
+  constexpr int RPW = 64 / G;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t idx = wave * RPW + grp;
+  const uint32_t n_in = a.list_in ? min(a.n_in, st->act_count[a.which]) : R;
+  const bool ray_ok = idx < n_in;
+  const uint32_t r = ray_ok ? (a.list_in ? a.list_in[idx] : idx) : 0;
+  const uint32_t beg = ray_ok ? a.off[r] : 0;
+  const uint32_t len = ray_ok ? a.off[r + 1] - beg : 0;
+  const uint32_t smask = (1u << a.s_bits) - 1;
+  const uint32_t cl_val = (a.tag_cl << a.s_bits) | r;
+  const uint32_t ch_val = (a.tag_wr << a.s_bits) | r;
+  const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  const unsigned long long below = (gl == 63) ? ~0ull : ((2ull << gl) - 1ull);
+  const uint32_t tl_old = (ray_ok && !a.init) ? a.TL[r] : 0;
+  int consL = 0, consH = 0;  // carries of the two collision counters
+  uint32_t tl = len, th = len;
+  bool brokeL = false, brokeH = false;
+  bool doneL = (len == 0) || a.init, done = (len == 0);
+  if (a.init) tl = 0;
+  if (a.l_only) th = ray_ok ? a.TH[r] : 0;
+  for (uint32_t base = 0; __any(!done); base += G) {
+    const uint32_t k = base + gl;
+    const bool act = !done && k < len;
+    const uint32_t gid = act ? a.vox[beg + k] : 0xFFFFFFFFu;
+    bool pL = false, pH = false;  // collision under certain / possible claims
+    if (gid != 0xFFFFFFFFu && !a.init) {
+      const uint32_t c1 = __hip_atomic_load(&a.cl[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pL = ((c1 >> a.s_bits) == a.tag_cl) && ((c1 & smask) < r);
+      pH = pL;
+      if (!pH) {
+        const uint32_t c2 = a.ch_rd[gid];
+        pH = ((c2 >> a.s_bits) == a.tag_rd) && ((c2 & smask) < r);
+      }
     }
-    const unsigned long long P = __ballot(present);
-    // consecutive_ray_collisions after this probe: length of the run of set bits ending here
-    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const unsigned long long zeros = ~P & below;
-    const int run = zeros ? (lane - (63 - __clzll((long long)zeros))) : (lane + 1);
-    const int cons = present ? (run + ((run == lane + 1) ? cons_in : 0)) : 0;
-    const bool brk = act && (cons > max_consecutive);
-    const unsigned long long B = __ballot(brk);
-    const int kb = B ? (__ffsll((long long)B) - 1) : 64;
-    if (act && lane < kb && gid != 0xFFFFFFFFu) atomicMin(&own_wr[gid], wr_val);
-    if (B) {
-      t_end = base + kb + 1;  // the terminating probe still happened ...
-      u_end = base + kb;      // ... but its voxel is not updated
-      break;
+    // upper bound TH: stop on a run of certain collisions
+    const unsigned long long PL = (__ballot(pL) >> (grp * G)) & gmask;
+    const unsigned long long zl = ~PL & below;
+    const int runL = zl ? (gl - (63 - __clzll((long long)zl))) : (gl + 1);
+    const int cH = pL ? (runL + ((runL == gl + 1) ? consH : 0)) : 0;
+    const unsigned long long BH = (__ballot(act && cH > a.max_consecutive) >> (grp * G)) & gmask;
+    const int kbH = BH ? (__ffsll((long long)BH) - 1) : G;
+    // lower bound TL: stop on a run of possible collisions
+    const unsigned long long PH = (__ballot(pH) >> (grp * G)) & gmask;
+    const unsigned long long zh = ~PH & below;
+    const int runH = zh ? (gl - (63 - __clzll((long long)zh))) : (gl + 1);
+    const int cL = pH ? (runH + ((runH == gl + 1) ? consL : 0)) : 0;
+    const unsigned long long BL = (__ballot(act && !doneL && cL > a.max_consecutive) >> (grp * G)) & gmask;
+    const int kbL = BL ? (__ffsll((long long)BL) - 1) : G;
+    // publish claims: every probe up to and including the terminating one
+    if (act && gid != 0xFFFFFFFFu) {
+      if (!a.l_only && gl <= kbH) claim_min(&a.ch_wr[gid], ch_val);
+      if (!doneL && gl <= kbL && k >= tl_old) claim_min(&a.cl[gid], cl_val);
     }
-    cons_in = __shfl(cons, 63);
+    const int carryH = __shfl(cH, grp * G + (G - 1));
+    const int carryL = __shfl(cL, grp * G + (G - 1));
+    if (!done) {
+      if (!doneL) {
+        if (BL) { tl = base + kbL + 1; brokeL = true; doneL = true; }
+        else { consL = carryL; if (base + G >= len) doneL = true; }
+      }
+      if (a.l_only) {
+        done = doneL;
+      } else {
+        if (BH) { th = base + kbH + 1; brokeH = true; done = true; }
+        else { consH = carryH; if (base + G >= len) done = true; }
+      }
+    }
   }
-  if (lane == 0) {
-    if (first || T[r] != t_end || U[r] != u_end) {
-      T[r] = t_end;
-      U[r] = u_end;
-      if (!first) st->changed = 1;
+  // Open rays go to the next sweep's work list: one global atomic per workgroup.
+  __shared__ uint32_t s_cnt, s_base;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  bool open = false;
+  uint32_t my = 0;
+  if (gl == 0 && ray_ok) {
+    a.TL[r] = tl;
+    if (!a.l_only) a.TH[r] = th;
+    const bool final_ray = !a.init && !a.l_only && (tl == th) && (brokeL == brokeH);
+    if (final_ray) {
+      a.U[r] = brokeH ? th - 1 : th;  // the terminating probe's voxel is not updated
+    } else if (a.list_out) {
+      open = true;
+      my = atomicAdd(&s_cnt, 1u);
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(&st->act_count[a.which ^ 1], s_cnt);
+  __syncthreads();
+  if (open) a.list_out[s_base + my] = r;
 }
 
 // Emit the ordered update keys of the voxels each ray reaches (k < U[r]) straight from the
@@ -1129,7 +1218,7 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_U, b_vox;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1;
   // Fast integrator persistent state
   DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
   uint32_t start_offset = 0;
@@ -1480,61 +1569,96 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                      ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), ctx->d_state);
   tmark(ctx, 2);
 
-  // owner arrays + tags
+  // claim arrays + tags (see k_fast_sweep)
   const size_t nvox_total = (size_t)m.cap_blocks * m.nvox;
   const int s_bits = (int)bits_for(std::max<uint32_t>(R, 2) - 1);
   const bool fresh = (ctx->b_own0.p == nullptr);
   HIP_TRY(ctx->b_own0.ensure(nvox_total * 4));
   HIP_TRY(ctx->b_own1.ensure(nvox_total * 4));
+  HIP_TRY(ctx->b_cl.ensure(nvox_total * 4));
   const uint32_t max_tag = (1u << (32 - s_bits)) - 2;
-  if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 64) {
+  auto reset_tags = [&]() -> int {
     HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_cl.p, 0xFF, nvox_total * 4, s));
     ctx->own_s_bits = s_bits;
     ctx->own_tag = max_tag;
+    return VBX_OK;
+  };
+  if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 1024) {
+    rc = reset_tags();
+    if (rc) return rc;
   }
   HIP_TRY(ctx->b_T.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_TH.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_U.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_rank.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_act0.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_act1.ensure((size_t)(R + 1) * 4));
   HIP_TRY(hipMemsetAsync(ctx->b_U.as<uint32_t>() + R, 0, 4, s));
+  SweepArgs sa{};
+  sa.off = ctx->b_off.as<uint32_t>();
+  sa.vox = ctx->b_vox.as<uint32_t>();
+  sa.cl = ctx->b_cl.as<uint32_t>();
+  sa.tag_cl = --ctx->own_tag;
+  sa.s_bits = s_bits;
+  sa.max_consecutive = c.max_consecutive;
+  sa.TL = ctx->b_T.as<uint32_t>();
+  sa.TH = ctx->b_TH.as<uint32_t>();
+  sa.U = ctx->b_U.as<uint32_t>();
+  // sweep 0: publish the full-path possible claims (TH = path length);
+  // sweep 1: lower bounds only (TH cannot move while there are no certain claims);
+  // sweeps 2..: both bounds, open rays only.
   uint32_t iters = 0;
-  uint32_t tag_prev = 0xFFFFFFFFu;
+  uint32_t n_open = R;  // host-side upper bound of the open list
   uint32_t total = 0;
-  const int kBatch = 4;  // sweeps per convergence check (one host sync per batch)
+  uint32_t tag_rd = 0xFFFFFFFFu;
+  int ch_flip = 0;      // which of the two possible-claim arrays holds the readable sweep
+  bool have_list = false;
   for (;;) {
+    const int kBatch = (iters == 0) ? 3 : 2;  // sweeps per host check
     for (int b = 0; b < kBatch; ++b) {
-      if (ctx->own_tag < 2) {  // tag space exhausted mid-call: restart the tag range
-        HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
-        HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
-        ctx->own_tag = max_tag;
-        iters = 0;  // the previous sweeps' owners are gone: start over
-        tag_prev = 0xFFFFFFFFu;
+      sa.init = (iters == 0) ? 1 : 0;
+      sa.l_only = (iters == 1) ? 1 : 0;
+      const bool writes_ch = !sa.l_only;
+      const int which = (int)(iters & 1);
+      sa.which = which;
+      sa.list_in = have_list ? ((which ? ctx->b_act1 : ctx->b_act0).as<uint32_t>()) : nullptr;
+      sa.list_out = (iters >= 2) ? (which ? ctx->b_act0 : ctx->b_act1).as<uint32_t>() : nullptr;
+      sa.n_in = n_open;
+      sa.ch_rd = (ch_flip ? ctx->b_own1 : ctx->b_own0).as<uint32_t>();
+      sa.ch_wr = (ch_flip ? ctx->b_own0 : ctx->b_own1).as<uint32_t>();
+      sa.tag_rd = tag_rd;
+      sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[which ^ 1], 0, 4, s));
+      if (iters == 0)
+        hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
+      else
+        hipLaunchKernelGGL(k_fast_sweep<16>, grid_for((size_t)n_open * 16), dim3(256), 0, s, sa, R, ctx->d_state);
+      if (writes_ch) {
+        tag_rd = sa.tag_wr;
+        ch_flip ^= 1;
       }
-      const uint32_t tag = --ctx->own_tag;
-      const uint32_t* rd = (iters & 1) ? ctx->b_own0.as<uint32_t>() : ctx->b_own1.as<uint32_t>();
-      uint32_t* wr = (iters & 1) ? ctx->b_own1.as<uint32_t>() : ctx->b_own0.as<uint32_t>();
-      HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
-      hipLaunchKernelGGL(k_fast_sweep, grid_for((size_t)R * 64), dim3(256), 0, s,
-                         ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), R, c.max_consecutive,
-                         rd, wr, tag_prev, tag, s_bits, ctx->b_T.as<uint32_t>(),
-                         ctx->b_U.as<uint32_t>(), iters == 0 ? 1 : 0, ctx->d_state);
-      tag_prev = tag;
+      if (sa.list_out) have_list = true;
       ++iters;
     }
-    // offsets of the keys each ray will emit; valid once the batch's last sweep changed nothing
-    rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(&total, ctx->b_rank.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
     rc = sync_state(ctx);
     if (rc) return rc;
     rc = check_state_error(ctx);
     if (rc) return rc;
-    if (!ctx->h_state.changed) break;
-    if (iters > 1000000) {
+    n_open = ctx->h_state.act_count[iters & 1];
+    if (getenv("VBX_DEBUG")) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
+    if (n_open == 0) break;
+    if (iters > 1000000 || ctx->own_tag < 8) {
       ctx->fail("Fast integrator: early-termination solver did not converge");
       return VBX_ERR_HIP;
     }
   }
+  // offsets of the keys each ray emits
+  rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(&total, ctx->b_rank.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   ctx->counters.iterations = iters;
   tmark(ctx, 3);
   hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
@@ -1885,7 +2009,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
