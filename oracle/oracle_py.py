@@ -51,13 +51,40 @@ class EsdfCfg(C.Structure):
 
 
 _lib = None
+_REF_LIB = os.path.join(_HERE, "_ref", "libvbxref.so")
+_ref = None
+
+
+def ref_available():
+    """True when oracle/_ref/libvbxref.so (the reference's own sources over dependency
+    shims) exists or can be built here (needs /root/reference)."""
+    if os.path.exists(_REF_LIB):
+        return True
+    if not os.path.isdir("/root/reference/voxblox"):
+        return False
+    return subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL) == 0 and os.path.exists(_REF_LIB)
+
+
+def ref_lib():
+    """The same orc_* C API served by the real reference sources (see ref_harness.cc)."""
+    global _ref
+    if _ref is None:
+        if not ref_available():
+            raise RuntimeError("oracle/_ref/libvbxref.so is not available")
+        _ref = _bind(C.CDLL(_REF_LIB))
+    return _ref
 
 
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    L = C.CDLL(build())
+    _lib = _bind(C.CDLL(build()))
+    return _lib
+
+
+def _bind(L):
     vp, f32p, u8p, i32p, i64p, u64p = (C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_uint64))
@@ -117,7 +144,6 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = L
     return L
 
 
@@ -152,8 +178,8 @@ def esdf_cfg(**kw):
 class OracleMap:
     """A TSDF layer + ESDF layer pair (voxblox Layer<TsdfVoxel>/Layer<EsdfVoxel>)."""
 
-    def __init__(self, voxel_size, voxels_per_side=16):
-        self.L = lib()
+    def __init__(self, voxel_size, voxels_per_side=16, L=None):
+        self.L = L or lib()
         self.voxel_size = np.float32(voxel_size)
         self.vps = int(voxels_per_side)
         self.h = self.L.orc_map_create(float(self.voxel_size), self.vps)

@@ -1,0 +1,174 @@
+"""Pins the oracle restatement against the REAL reference sources.
+
+oracle/_ref/libvbxref.so = /root/reference/voxblox's own tsdf_integrator.cc,
+integrator_utils.cc, esdf_integrator.cc, neighbor_tools.cc (+ the headers they include)
+compiled in place over minimal Eigen/glog/minkindr/protobuf stand-ins (oracle/ref_shims,
+recipe oracle/Makefile `ref`).  It exports the same orc_* C API, so the same inputs run
+through both and every layer must come out BIT-identical — distances, weights, colours,
+flags, parents, updated bits and even the unordered_map block iteration order.
+
+Runs wherever the prebuilt .so is present (it travels to the GPU box) or /root/reference
+exists; skipped otherwise.  CPU only.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from voxblox_amd import scenes
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built and no /root/reference")
+
+
+def _frames(n, w=96, h=72, f=48.0):
+    return [scenes.room_frame(5 * k, 100, f=f, width=w, height=h) for k in range(n)]
+
+
+def _both(kind, frames, voxel=0.1, esdf=None, freespace=False, **cfg):
+    out = []
+    for L in (O.lib(), O.ref_lib()):
+        L.orc_fast_reset_counter_set(0)
+        m = O.OracleMap(voxel, 16, L=L)
+        c = O.TsdfCfg()
+        L.orc_tsdf_cfg_default(C.byref(c))
+        c.default_truncation_distance = 4 * voxel
+        c.integrator_threads = 1
+        for k, v in cfg.items():
+            setattr(c, k, v)
+        it = m.tsdf_integrator(kind, c)
+        e = None
+        if esdf is not None:
+            ec = O.EsdfCfg()
+            L.orc_esdf_cfg_default(C.byref(ec))
+            ec.min_distance_m = 2 * voxel
+            for k, v in esdf.get("cfg", {}).items():
+                setattr(ec, k, v)
+            e = m.esdf_integrator(ec)
+        for pose, pts, col in frames:
+            it.integrate(pose[0], pose[1], pts, col, freespace)
+            if e is not None and esdf.get("mode") == "incremental":
+                e.update_from_tsdf_layer(True)
+        if e is not None and esdf.get("mode") == "batch":
+            e.update_from_tsdf_layer_batch()
+        out.append(m)
+    return out
+
+
+def _same_tsdf(a, b):
+    ia, ib = a.block_indices(0), b.block_indices(0)
+    assert np.array_equal(ia, ib), "block iteration order differs (unordered_map order is part of the restatement)"
+    assert len(ia) > 0
+    for i in ia:
+        da, wa, ca, ua = a.tsdf_block(i)
+        db, wb, cb, ub = b.tsdf_block(i)
+        assert ua == ub
+        assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), f"distance bits differ in block {tuple(i)}"
+        assert np.array_equal(wa.view(np.uint32), wb.view(np.uint32)), f"weight bits differ in block {tuple(i)}"
+        assert np.array_equal(ca, cb), f"colours differ in block {tuple(i)}"
+
+
+def _same_esdf(a, b):
+    ia, ib = a.block_indices(1), b.block_indices(1)
+    assert np.array_equal(ia, ib) and len(ia) > 0
+    for i in ia:
+        da, fa, pa, ua = a.esdf_block(i)
+        db, fb, pb, ub = b.esdf_block(i)
+        assert ua == ub
+        assert np.array_equal(fa, fb), f"flags differ in block {tuple(i)}"
+        assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), f"distance bits differ in block {tuple(i)}"
+        assert np.array_equal(pa, pb), f"parents differ in block {tuple(i)}"
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_tsdf_integrators_bit_identical(kind):
+    a, b = _both(kind, _frames(4))
+    _same_tsdf(a, b)
+
+
+@pytest.mark.parametrize("kind,cfg", [
+    ("simple", dict(voxel_carving_enabled=0)),
+    ("simple", dict(use_const_weight=1, use_weight_dropoff=0)),
+    ("simple", dict(use_sparsity_compensation_factor=1, sparsity_compensation_factor=3.0)),
+    ("simple", dict(allow_clear=0, max_ray_length_m=3.0)),
+    ("merged", dict(enable_anti_grazing=1)),
+    ("merged", dict(max_ray_length_m=2.5, min_ray_length_m=1.5)),
+    ("fast", dict(max_consecutive_ray_collisions=0)),
+    ("fast", dict(start_voxel_subsampling_factor=1.0, max_consecutive_ray_collisions=5)),
+    ("fast", dict(integration_order_mode=1)),
+])
+def test_tsdf_config_variants_bit_identical(kind, cfg):
+    a, b = _both(kind, _frames(2), **cfg)
+    _same_tsdf(a, b)
+
+
+def test_fast_small_voxels_many_frames():
+    a, b = _both("fast", _frames(6), voxel=0.05)
+    _same_tsdf(a, b)
+
+
+def test_freespace_points():
+    a, b = _both("merged", _frames(2), freespace=True)
+    _same_tsdf(a, b)
+
+
+def test_esdf_incremental_bit_identical():
+    a, b = _both("merged", _frames(4), esdf=dict(mode="incremental"))
+    _same_tsdf(a, b)
+    _same_esdf(a, b)
+
+
+def test_esdf_batch_and_variants_bit_identical():
+    for cfg in (dict(), dict(min_diff_m=0.0, multi_queue=1), dict(add_occupied_crust=1),
+                dict(full_euclidean_distance=1)):
+        a, b = _both("simple", _frames(2), esdf=dict(mode="batch", cfg=cfg))
+        _same_esdf(a, b)
+
+
+def test_esdf_full_euclidean_incremental():
+    a, b = _both("merged", _frames(3), esdf=dict(mode="incremental", cfg=dict(full_euclidean_distance=1)))
+    _same_esdf(a, b)
+
+
+def test_helpers_bit_identical():
+    rng = np.random.RandomState(3)
+    La, Lb = O.lib(), O.ref_lib()
+    f32p, i64p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    for _ in range(300):
+        p = (rng.uniform(-20, 20, 3)).astype(np.float32)
+        inv = np.float32(rng.choice([20.0, 10.0, 5.0, 1.25, 40.0]))
+        oa, ob = np.zeros(3, np.int64), np.zeros(3, np.int64)
+        La.orc_grid_index_from_point(p.ctypes.data_as(f32p), float(inv), oa.ctypes.data_as(i64p))
+        Lb.orc_grid_index_from_point(p.ctypes.data_as(f32p), float(inv), ob.ctypes.data_as(i64p))
+        assert np.array_equal(oa, ob)
+        ca, cb = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        La.orc_center_point_from_grid_index(oa.ctypes.data_as(i64p), float(1 / inv), ca.ctypes.data_as(f32p))
+        Lb.orc_center_point_from_grid_index(oa.ctypes.data_as(i64p), float(1 / inv), cb.ctypes.data_as(f32p))
+        assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
+        assert La.orc_long_index_hash(oa.ctypes.data_as(i64p)) == Lb.orc_long_index_hash(oa.ctypes.data_as(i64p))
+        q = rng.normal(size=4); q = (q / np.linalg.norm(q)).astype(np.float32)
+        t = rng.uniform(-3, 3, 3).astype(np.float32)
+        ta, tb = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        La.orc_transform_point(t.ctypes.data_as(f32p), q.ctypes.data_as(f32p), p.ctypes.data_as(f32p), ta.ctypes.data_as(f32p))
+        Lb.orc_transform_point(t.ctypes.data_as(f32p), q.ctypes.data_as(f32p), p.ctypes.data_as(f32p), tb.ctypes.data_as(f32p))
+        assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+        o = rng.uniform(-2, 2, 3).astype(np.float32)
+        ba, bb = np.zeros((2048, 3), np.int64), np.zeros((2048, 3), np.int64)
+        for clearing in (0, 1):
+            for from_origin in (0, 1):
+                na = La.orc_cast_ray(o.ctypes.data_as(f32p), ta.ctypes.data_as(f32p), clearing, 1, 5.0, float(inv),
+                                     float(4 / inv), from_origin, ba.ctypes.data_as(i64p), 2048)
+                nb = Lb.orc_cast_ray(o.ctypes.data_as(f32p), ta.ctypes.data_as(f32p), clearing, 1, 5.0, float(inv),
+                                     float(4 / inv), from_origin, bb.ctypes.data_as(i64p), 2048)
+                assert na == nb and np.array_equal(ba[:min(na, 2048)], bb[:min(nb, 2048)])
+        c1, c2 = int(rng.randint(0, 2 ** 32, dtype=np.uint64)), int(rng.randint(0, 2 ** 32, dtype=np.uint64))
+        w1, w2 = float(np.float32(rng.uniform(0, 50))), float(np.float32(rng.uniform(1e-3, 5)))
+        assert La.orc_blend_two_colors(c1, w1, c2, w2) == Lb.orc_blend_two_colors(c1, w1, c2, w2)
+    for n in (1000, 5000, 307200):
+        for s in (0, 1, 299, 300, 999, n // 2, n - 1):
+            assert La.orc_mixed_index(s, n) == Lb.orc_mixed_index(s, n)
+    offa, offb = np.zeros(78, np.int32), np.zeros(78, np.int32)
+    da, db = np.zeros(26, np.float32), np.zeros(26, np.float32)
+    La.orc_neighbor_lut(offa.ctypes.data_as(i32p), da.ctypes.data_as(f32p))
+    Lb.orc_neighbor_lut(offb.ctypes.data_as(i32p), db.ctypes.data_as(f32p))
+    assert np.array_equal(offa, offb) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
