@@ -8,8 +8,9 @@ whose points/colours are already resident in HBM (vbx_tsdf_integrate_device).
 
 Contract (see the task statement): W untimed warm-up steps, then exactly K timed steps
 bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints
-ONE JSON line.  For --gpus N every rank integrates its own sensor stream into its own map
-shard (weak scaling, no data-path collective in the timed region yet — see DESIGN.md §multi-GPU).
+ONE JSON line.  For --gpus N every rank integrates its own sensor's frame (weak scaling) into a per-frame
+delta map; overlapping block updates are merged with an RCCL reduce-scatter into a persistent
+map distributed by block ownership (voxblox_amd/multi_gpu.py).
 """
 import argparse
 import json
@@ -43,21 +44,29 @@ def cpu_baseline(frames, kind):
     """Times the oracle (CPU restatement of the reference, reference threading scheme) on a
     bounded sample of the same stream: threads = host cores, median frame after 3 warm-ups."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes
     import oracle_py as O
     cores = os.cpu_count() or 1
+    # oracle/_ref = the reference's own sources (over dependency shims) when it was built;
+    # otherwise the restatement.
+    use_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libvbxref.so"))
+    L = O.ref_lib() if use_ref else O.lib()
     best = None
-    for threads in sorted({1, cores}):
-        O.lib().orc_fast_reset_counter_set(0)
-        m = O.OracleMap(VOXEL, 16)
-        it = m.tsdf_integrator(kind, O.tsdf_cfg(default_truncation_distance=TRUNC,
-                                                integrator_threads=threads))
+    for threads in sorted({1, min(cores, 8), cores}):
+        L.orc_fast_reset_counter_set(0)
+        m = O.OracleMap(VOXEL, 16, L=L)
+        c = O.TsdfCfg()
+        L.orc_tsdf_cfg_default(ctypes.byref(c))
+        c.default_truncation_distance = TRUNC
+        c.integrator_threads = threads
+        it = m.tsdf_integrator(kind, c)
         ts = []
         t_begin = time.time()
         for i, (pose, pts, col) in enumerate(frames):
             t0 = time.perf_counter()
             it.integrate(pose[0], pose[1], pts, col)
             ts.append(time.perf_counter() - t0)
-            if time.time() - t_begin > 15.0 and i >= 5:
+            if time.time() - t_begin > 8.0 and i >= 5:
                 break
         used = ts[3:] if len(ts) > 4 else ts
         med = float(np.median(used))
@@ -67,10 +76,12 @@ def cpu_baseline(frames, kind):
             best = rec
         del it, m
     return {"value": best["value"], "unit": "Mpoints/s", "cores": best["threads"],
-            "kind": "port",
-            "sample": f"{best['frames']} frames of the same 640x480 room stream, {kind} integrator, "
-                      f"median frame {best['median_ms']} ms after 3 warm-up frames, "
-                      f"best of threads in {{1,{cores}}} (host has {cores} cores)"}
+            "kind": "reference" if use_ref else "port",
+            "sample": f"{best['frames']} frames of the same 640x480 room stream, {kind} integrator "
+                      + ("(reference sources compiled over dependency shims, oracle/_ref), "
+                         if use_ref else "(oracle restatement), ")
+                      + f"median frame {best['median_ms']} ms after 3 warm-up frames, "
+                      f"best of integrator_threads in {{1,{min(cores, 8)},{cores}}} (host has {cores} hw threads)"}
 
 
 def main():
@@ -102,10 +113,22 @@ def main():
     gm = capi.Map(VOXEL, 16, max_blocks=8192, device=local_rank)
     gm.set_stream(torch.cuda.current_stream().cuda_stream)
     cfg = capi.tsdf_cfg(default_truncation_distance=TRUNC)
+    sharded = None
+    if world > 1:
+        # Ray-bundle sharding: gm is this rank's per-frame delta map; the
+        # persistent map is distributed by block ownership and fed by an RCCL reduce-scatter.
+        from voxblox_amd import multi_gpu
+        pm = capi.Map(VOXEL, 16, max_blocks=8192, device=local_rank)
+        pm.set_stream(torch.cuda.current_stream().cuda_stream)
+        sharded = multi_gpu.ShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), multi_gpu.GpuBackend(gm, dev),
+                                           rank, world, dist)
 
     def step(i):
         pose, dp, dc = d_frames[i % len(d_frames)]
-        gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_pts)
+        if sharded is None:
+            gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_pts)
+        else:
+            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n_pts)
 
     def barrier():
         if world > 1:
@@ -144,7 +167,9 @@ def main():
         "config": {"workload": f"{args.integrator.capitalize()}TsdfIntegrator, 640x480 synthetic room scan "
                                "stream (BASELINE configs[1]), 0.05 m voxels / 16^3 blocks, trunc 0.2 m",
                    "points_per_step": n_pts, "voxel_size": VOXEL, "voxels_per_side": 16,
-                   "parallelism": f"{world} sensor stream(s), one map shard per GPU"},
+                   "parallelism": ("1 GPU, whole cloud" if world == 1 else
+                                   f"{world} sensors, one ray shard per GPU, RCCL reduce-scatter block merge, "
+                                   "map distributed by block owner")},
     }
     if rank == 0:
         # Roofline of the dominant stage (HIP events on the launch stream, averaged over the

@@ -147,6 +147,25 @@ int vbx_clear(vbx_ctx* ctx, int layer);
 /* block.updated().reset(bit) over all blocks of a layer (mesher / ESDF consumers). */
 int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask);
 
+/* ---- multi-GPU: ray-bundle sharding with a block merge ----
+ * Each rank integrates its ray shard into a per-frame delta map; the deltas are combined as
+ * weighted sums — which is what Block::mergeBlock / mergeVoxelAIntoVoxelB compute
+ * (core/block_inl.h:112-129, src/utils/voxel_utils.cc:10-22) — by an RCCL reduce-scatter over
+ * the union of touched blocks, and each block's owner folds the reduced delta into its shard
+ * of the persistent map. */
+/* For each listed block writes six float planes of nvox = vps^3 values each,
+ *   [w*d, w, w*r, w*g, w*b, w*a],  layout d_out[(i*6 + plane)*nvox + linear_index],
+ * zeros for blocks this map does not hold.  idx_xyz is a host array, d_out a device pointer. */
+int vbx_blocks_export_sums(vbx_ctx* ctx, const int32_t* idx_xyz, size_t n, float* d_out);
+/* Folds reduced sums (same layout, device pointer) into this map: A = {d = Swd/Sw, w = Sw,
+ * colour = round(Swc/Sw)} merged into the stored voxel B exactly as mergeVoxelAIntoVoxelB does
+ * (d = (dA*wA + dB*wB)/(wA+wB), colour = blendTwoColors(A,wA,B,wB), w = wA+wB; nothing when
+ * wA+wB <= 0).  Blocks are allocated as needed and get all Update bits.  If apply_caps != 0
+ * the result is clamped like updateTsdfVoxel does (|d| <= truncation, w <= max_weight,
+ * tsdf_integrator.cc:205-208), which mergeVoxelAIntoVoxelB itself does not do. */
+int vbx_blocks_merge_sums(vbx_ctx* ctx, const int32_t* idx_xyz, size_t n, const float* d_sums,
+                          int apply_caps, float truncation_distance, float max_weight);
+
 /* ---- measurement ---- */
 typedef struct vbx_counters {
   uint64_t points;          /* points handed to the last integrate call */

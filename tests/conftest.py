@@ -9,6 +9,16 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# torch bundles its own HIP runtime; when both torch and libvbx_hip.so live in one process the
+# runtime must be initialised through torch FIRST (the other order leaves torch without a GPU).
+try:
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except Exception:  # pragma: no cover - torch is optional for the CPU suite
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 

@@ -1,0 +1,148 @@
+"""-m gpu: the HIP side of the multi-GPU block merge (vbx_blocks_export_sums /
+vbx_blocks_merge_sums) on one GPU: two ray shards integrated into delta maps, merged into a
+persistent map through voxblox_amd.multi_gpu with world = 1 per shard, compared with the
+serial oracle merge (mergeVoxelAIntoVoxelB)."""
+import numpy as np
+import pytest
+
+from test_multi_gpu_gloo import merge_A_into_B
+from voxblox_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_export_merge_matches_reference_merge(oracle):
+    import torch
+    from voxblox_amd import capi, multi_gpu
+    voxel = 0.1
+    gcfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    ocfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
+    persistent = multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0")
+    delta = multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0")
+    sm = multi_gpu.ShardedTsdfMap(persistent, delta, 0, 1)
+    ref = {}
+    for k in range(3):
+        pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
+        n = pts.shape[0]
+        for shard in range(2):
+            lo, hi = shard * n // 2, (shard + 1) * n // 2
+            sm.integrate_shard(capi.TSDF_SIMPLE, gcfg, pose[0], pose[1], pts[lo:hi], col[lo:hi])
+            m = oracle.OracleMap(voxel, 16)
+            m.tsdf_integrator("simple", ocfg).integrate(pose[0], pose[1], pts[lo:hi], col[lo:hi])
+            for key, (d, w, c, _) in m.tsdf_dict().items():
+                if not (w > 0).any():
+                    continue
+                dB, wB, cB = ref.get(key, (np.zeros(4096, np.float32), np.zeros(4096, np.float32),
+                                           np.zeros((4096, 4), np.uint8)))
+                sA = np.stack([w * d, w] + [w * c[:, ch].astype(np.float32) for ch in range(4)])
+                ref[key] = merge_A_into_B(sA, dB, wB, cB)
+    torch.cuda.synchronize()
+    got = persistent.m.tsdf_dict()
+    assert set(got) == set(ref)
+    for key in ref:
+        gd, gw, gc, gu = got[key]
+        rd, rw, rc = ref[key]
+        assert gu == 7
+        assert np.array_equal(gw > 0, rw > 0)
+        assert np.allclose(gw, rw, rtol=1e-6, atol=1e-7)
+        assert np.abs(gd - rd).max() <= 1e-6
+        assert np.abs(gc.astype(np.int32) - rc.astype(np.int32)).max() <= 1
+    assert sm.last["union_blocks"] > 0
+
+
+def test_clear_is_complete():
+    from voxblox_amd import capi
+    pose, pts, col = scenes.room_frame(0, 100, f=40.0, width=80, height=60)
+    gm = capi.Map(0.1, 16, max_blocks=1024)
+    cfg = capi.tsdf_cfg(default_truncation_distance=0.4)
+    gm.integrate(capi.TSDF_FAST, cfg, pose[0], pose[1], pts, col)
+    a = gm.tsdf_dict()
+    gm.clear()
+    assert gm.num_blocks() == 0
+    gm.integrate(capi.TSDF_FAST, cfg, pose[0], pose[1], pts, col)
+    b = gm.tsdf_dict()
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1]) and np.array_equal(a[k][2], b[k][2])
+
+
+def _gpu_worker(rank, world, port, out_q):
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import torch
+    torch.cuda.init()
+    import torch.distributed as dist
+    from voxblox_amd import capi, multi_gpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    # two ranks share the single test GPU, so the collective layer is gloo here; the RCCL
+    # branch differs only in reduce_scatter_tensor vs all_reduce + slice
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    voxel = 0.1
+    cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    sm = multi_gpu.ShardedTsdfMap(multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0"),
+                                  multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0"),
+                                  rank, world, dist)
+    for k in range(3):
+        pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
+        n = pts.shape[0]
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        sm.integrate_shard(capi.TSDF_FAST, cfg, pose[0], pose[1], pts[lo:hi], col[lo:hi])
+    torch.cuda.synchronize()
+    out_q.put((rank, sm.p.m.tsdf_dict(), sm.last))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_sharded_fast_on_one_gpu(oracle):
+    """End to end with the real kernels: 2 processes, ray-band shards, merged map distributed
+    by owner == serial oracle shard + mergeVoxelAIntoVoxelB."""
+    import torch.multiprocessing as mp
+    from test_multi_gpu_gloo import _free_port
+    from voxblox_amd import multi_gpu
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    merged = {}
+    for rank, owned, last in results:
+        assert not (set(owned) & set(merged))
+        merged.update(owned)
+        keys = np.array(list(owned.keys()), np.int32).reshape(-1, 3)
+        if keys.shape[0]:
+            assert np.all(multi_gpu.owner_of(keys, 2) == rank)
+    voxel = 0.1
+    ocfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1,
+                           oracle_fast_exact_observed_set=1)
+    ref = {}
+    for k in range(3):
+        pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
+        n = pts.shape[0]
+        for rank in range(2):
+            lo, hi = rank * n // 2, (rank + 1) * n // 2
+            oracle.lib().orc_fast_reset_counter_set(0)
+            m = oracle.OracleMap(voxel, 16)
+            m.tsdf_integrator("fast", ocfg).integrate(pose[0], pose[1], pts[lo:hi], col[lo:hi])
+            for key, (d, w, c, _) in m.tsdf_dict().items():
+                if not (w > 0).any():
+                    continue
+                dB, wB, cB = ref.get(key, (np.zeros(4096, np.float32), np.zeros(4096, np.float32),
+                                           np.zeros((4096, 4), np.uint8)))
+                sA = np.stack([w * d, w] + [w * c[:, ch].astype(np.float32) for ch in range(4)])
+                ref[key] = merge_A_into_B(sA, dB, wB, cB)
+    assert set(merged) == set(ref)
+    for key in ref:
+        gd, gw, gc, _ = merged[key]
+        rd, rw, rc = ref[key]
+        assert np.array_equal(gw > 0, rw > 0)
+        assert np.allclose(gw, rw, rtol=1e-5, atol=1e-6)
+        assert np.abs(gd - rd).max() <= 1e-5
+        assert np.abs(gc.astype(np.int32) - rc.astype(np.int32)).max() <= 1

@@ -1,0 +1,184 @@
+"""CPU, world_size 2, gloo: the N>1 path of voxblox_amd.multi_gpu (key all-gather, owner
+layout, staging, reduce(-scatter), owner fold) with an oracle-backed backend, checked against
+the same shard + merge done serially with the reference's mergeVoxelAIntoVoxelB
+(voxel_utils.cc:10-22).  The HIP kernels behind the same protocol are covered by
+tests/test_gpu_multi_merge.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleBackend:
+    """The backend protocol of multi_gpu.ShardedTsdfMap on top of the CPU oracle (numpy)."""
+
+    def __init__(self, O, voxel, vps=16):
+        import torch
+        self.O, self.voxel, self.vps = O, voxel, vps
+        self.nvox = vps ** 3
+        self.device = torch.device("cpu")
+        self._torch = torch
+        self.m = O.OracleMap(voxel, vps)
+        self.it = None
+
+    def clear(self):
+        self.m.clear(0)
+
+    def integrate(self, kind, cfg, pos, quat, points, colors, n_points=None):
+        self.O.lib().orc_fast_reset_counter_set(0)
+        it = self.m.tsdf_integrator(kind, cfg)
+        it.integrate(pos, quat, points, colors)
+
+    def block_indices(self):
+        return self.m.block_indices(0)
+
+    def zeros(self, shape):
+        return self._torch.zeros(shape, dtype=self._torch.float32)
+
+    def export_sums(self, keys, out_view):
+        o = out_view.numpy()
+        for i, k in enumerate(keys):
+            blk = self.m.tsdf_block(k)
+            if blk is None:
+                continue
+            d, w, c, _ = blk
+            o[i, 0] = w * d
+            o[i, 1] = w
+            for ch in range(4):
+                o[i, 2 + ch] = w * c[:, ch].astype(np.float32)
+
+    def merge_sums(self, keys, sums, apply_caps, trunc, max_weight):
+        s = sums.numpy()
+        for i, k in enumerate(keys):
+            wA = s[i, 1]
+            if not (wA > 0).any():
+                continue
+            blk = self.m.tsdf_block(k)
+            if blk is None:
+                n = self.nvox
+                dB, wB, cB = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros((n, 4), np.uint8)
+            else:
+                dB, wB, cB, _ = blk
+            dB, wB, cB = merge_A_into_B(s[i], dB, wB, cB)
+            self.m.tsdf_block_set(k, dB, wB, cB, 7)
+
+
+def merge_A_into_B(sA, dB, wB, cB):
+    """mergeVoxelAIntoVoxelB with A given as sums (w*d, w, w*rgba)."""
+    wA = sA[1].astype(np.float32)
+    on = wA > 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dA = np.where(on, sA[0] / wA, 0).astype(np.float32)
+        cA = np.stack([np.where(on, np.round(sA[2 + ch] / wA), 0) for ch in range(4)], 1).astype(np.float32)
+        cw = (wA + wB).astype(np.float32)
+        d = np.where(on & (cw > 0), ((dA * wA + dB * wB) / cw).astype(np.float32), dB)
+        f1 = (wA / cw).astype(np.float32)
+        f2 = (wB / cw).astype(np.float32)
+        col = np.where((on & (cw > 0))[:, None],
+                       np.round(cA * f1[:, None] + cB.astype(np.float32) * f2[:, None]), cB).astype(np.uint8)
+    w = np.where(on & (cw > 0), cw, wB).astype(np.float32)
+    return d.astype(np.float32), w, col
+
+
+def _worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import oracle_py as O
+    from voxblox_amd import multi_gpu, scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    voxel = 0.1
+    cfg = O.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
+    sm = multi_gpu.ShardedTsdfMap(OracleBackend(O, voxel), OracleBackend(O, voxel), rank, world, dist)
+    for k in range(3):  # every rank: its own band of the same frame (ray-bundle sharding)
+        pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
+        n = pts.shape[0]
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        sm.integrate_shard("simple", cfg, pose[0], pose[1], pts[lo:hi], col[lo:hi])
+    owned = {tuple(int(v) for v in i): sm.p.m.tsdf_block(i) for i in sm.p.block_indices()}
+    out_q.put((rank, owned, sm.last))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owner_and_layout_are_deterministic():
+    sys.path.insert(0, ROOT)
+    from voxblox_amd import multi_gpu
+    rng = np.random.RandomState(0)
+    a = rng.randint(-20, 20, (50, 3)).astype(np.int32)
+    b = rng.randint(-20, 20, (70, 3)).astype(np.int32)
+    g1, L1 = multi_gpu.build_layout([a, b], 4)
+    g2, L2 = multi_gpu.build_layout([b, a], 4)
+    assert L1 == L2 and all(np.array_equal(x, y) for x, y in zip(g1, g2))
+    uni = np.unique(np.concatenate([a, b]), axis=0)
+    assert sum(g.shape[0] for g in g1) == uni.shape[0]
+    for r, g in enumerate(g1):
+        assert np.all(multi_gpu.owner_of(g, 4) == r) and g.shape[0] <= L1
+
+
+def test_two_rank_shard_and_merge_matches_serial_reference_merge(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    merged = {}
+    for rank, owned, last in results:
+        assert not (set(owned) & set(merged)), "a block is owned by two ranks"
+        merged.update(owned)
+        assert last["union_blocks"] > 0 and last["padded_rows"] % 2 == 0
+
+    # serial restatement: per frame, per rank delta (fresh map), merged in rank order with the
+    # reference's mergeVoxelAIntoVoxelB
+    from voxblox_amd import multi_gpu, scenes
+    voxel = 0.1
+    cfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
+    ref = {}
+    for k in range(3):
+        pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
+        n = pts.shape[0]
+        for rank in range(2):
+            lo, hi = rank * n // 2, (rank + 1) * n // 2
+            m = oracle.OracleMap(voxel, 16)
+            m.tsdf_integrator("simple", cfg).integrate(pose[0], pose[1], pts[lo:hi], col[lo:hi])
+            for key, (d, w, c, _) in m.tsdf_dict().items():
+                if not (w > 0).any():
+                    continue
+                dB, wB, cB = ref.get(key, (np.zeros(4096, np.float32), np.zeros(4096, np.float32),
+                                           np.zeros((4096, 4), np.uint8)))
+                sA = np.stack([w * d, w] + [w * c[:, ch].astype(np.float32) for ch in range(4)])
+                ref[key] = merge_A_into_B(sA, dB, wB, cB)
+    assert set(merged) == set(ref), (len(merged), len(ref))
+    for key in ref:
+        gd, gw, gc, _ = merged[key]
+        rd, rw, rc = ref[key]
+        assert np.array_equal(gw > 0, rw > 0)
+        assert np.allclose(gw, rw, rtol=1e-5, atol=1e-6)
+        assert np.abs(gd - rd).max() <= 1e-5
+        # one rounding after the sum vs a rounding at every pairwise blend: +-1 LSB
+        assert np.abs(gc.astype(np.int32) - rc.astype(np.int32)).max() <= 1
+    # owners partition the union exactly as owner_of says
+    for rank, owned, _ in results:
+        keys = np.array(list(owned.keys()), np.int32).reshape(-1, 3)
+        if keys.shape[0]:
+            assert np.all(multi_gpu.owner_of(keys, 2) == rank)

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
-    "vbx_clear", "vbx_clear_updated", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
+    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
 
 
 class MapCfg(C.Structure):
@@ -77,6 +77,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # If torch is already imported, make it bring up its bundled HIP runtime before ours is
+    # dlopen'ed: the other order leaves torch unable to see the GPU in this process.
+    import sys
+    _t = sys.modules.get("torch")
+    if _t is not None:
+        try:
+            if _t.cuda.is_available():
+                _t.cuda.init()
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise VbxError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
                        "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
@@ -104,6 +114,8 @@ def lib():
         "vbx_remove_distant_blocks": (C.c_int, [vp, C.c_int, f32p, C.c_double]),
         "vbx_clear": (C.c_int, [vp, C.c_int]),
         "vbx_clear_updated": (C.c_int, [vp, C.c_int, C.c_int]),
+        "vbx_blocks_export_sums": (C.c_int, [vp, i32p, C.c_size_t, vp]),
+        "vbx_blocks_merge_sums": (C.c_int, [vp, i32p, C.c_size_t, vp, C.c_int, C.c_float, C.c_float]),
         "vbx_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
         "vbx_enable_timing": (C.c_int, [vp, C.c_int]),
         "vbx_get_timing": (C.c_int, [vp, C.POINTER(Timing)]),
@@ -251,6 +263,18 @@ class Map:
 
     def clear_updated(self, mask, layer=LAYER_TSDF):
         self._chk(self.L.vbx_clear_updated(self.h, layer, mask))
+
+    def export_sums(self, idx_xyz, d_out_ptr):
+        """vbx_blocks_export_sums: six float planes [w*d, w, w*r, w*g, w*b, w*a] per listed block."""
+        idx = np.ascontiguousarray(idx_xyz, np.int32).reshape(-1, 3)
+        self._chk(self.L.vbx_blocks_export_sums(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.shape[0],
+                                                C.c_void_p(d_out_ptr)))
+
+    def merge_sums(self, idx_xyz, d_sums_ptr, apply_caps=False, truncation=0.0, max_weight=0.0):
+        idx = np.ascontiguousarray(idx_xyz, np.int32).reshape(-1, 3)
+        self._chk(self.L.vbx_blocks_merge_sums(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.shape[0],
+                                               C.c_void_p(d_sums_ptr), int(apply_caps), float(truncation),
+                                               float(max_weight)))
 
     def counters(self):
         c = Counters()

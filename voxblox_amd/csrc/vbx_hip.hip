@@ -83,6 +83,8 @@ constexpr uint32_t kFlagUpdMask = 0x7;      // Update::kMap|kMesh|kEsdf, core/bl
 constexpr uint32_t kFlagPublished = 0x100;  // block is part of the API-visible Layer
 constexpr uint32_t kFlagHasData = 0x200;    // Block::has_data_
 constexpr uint32_t kFlagNewThisCall = 0x400;
+constexpr uint32_t kFlagEsdfAlloc = 0x1000;   // block exists in Layer<EsdfVoxel>
+constexpr uint32_t kFlagEsdfUpdShift = 4;     // ESDF block's Update bits live in bits 4..6
 
 // Device-resident scalar state, read back at the per-call sync points.
 struct DevState {
@@ -880,6 +882,89 @@ __global__ void k_fast_emit(const uint32_t* __restrict__ off_full, const uint32_
   if (first_of_block) publish_block(m, slot, st);
 }
 
+
+// ---------------------------------------------------------------------------
+// kernels: multi-GPU block merge (mergeVoxelAIntoVoxelB as weighted sums)
+// ---------------------------------------------------------------------------
+__global__ void k_export_sums(MapDev m, const uint32_t* __restrict__ slots, float* out) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  float* o = out + (size_t)b * 6 * m.nvox;
+  for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+    float wd = 0.f, w = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f;
+    if (slot != kInvalidSlot) {
+      const uint32_t gid = slot * m.nvox + v;
+      w = m.weight[gid];
+      wd = w * m.dist[gid];
+      const uint32_t c = m.rgba[gid];
+      cr = w * (float)(c & 0xFF); cg = w * (float)((c >> 8) & 0xFF);
+      cb = w * (float)((c >> 16) & 0xFF); ca = w * (float)((c >> 24) & 0xFF);
+    }
+    o[v] = wd; o[m.nvox + v] = w; o[2 * m.nvox + v] = cr; o[3 * m.nvox + v] = cg;
+    o[4 * m.nvox + v] = cb; o[5 * m.nvox + v] = ca;
+  }
+}
+
+// lookup (find-only) of a host-provided block list -> slots; unpublished blocks read as absent
+__global__ void k_lookup_slots(MapDev m, const int32_t* __restrict__ idx, uint32_t n, int published_only,
+                               uint32_t* slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s = map_find(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]));
+  if (s != kInvalidSlot && published_only && !(m.blk_flags[s] & kFlagPublished)) s = kInvalidSlot;
+  slots[i] = s;
+}
+__global__ void k_insert_blocks(MapDev m, const int32_t* __restrict__ idx, uint32_t n, uint32_t* new_list,
+                                DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  map_insert_key(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]), new_list, st);
+}
+
+__global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const float* __restrict__ in,
+                             int apply_caps, float trunc, float max_weight, DevState* st) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  if (slot == kInvalidSlot) return;
+  const float* a = in + (size_t)b * 6 * m.nvox;
+  bool any = false;
+  for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+    const float wA = a[m.nvox + v];
+    if (!(wA > 0.0f)) continue;
+    any = true;
+    const uint32_t gid = slot * m.nvox + v;
+    const float dA = a[v] / wA;
+    uint32_t cA = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const float c = roundf(a[(2 + ch) * m.nvox + v] / wA);
+      cA |= ((uint32_t)(int)std_min(std_max(c, 0.0f), 255.0f) & 0xFFu) << (8 * ch);
+    }
+    const float wB = m.weight[gid];
+    const float dB = m.dist[gid];
+    const float cw = wA + wB;  // mergeVoxelAIntoVoxelB, voxel_utils.cc:10-22
+    if (cw > 0.0f) {
+      float d = (dA * wA + dB * wB) / cw;
+      float w = cw;
+      const uint32_t col = blend_two_colors(cA, wA, m.rgba[gid], wB);
+      if (apply_caps) {
+        d = (d > 0.0f) ? std_min(trunc, d) : std_max(-trunc, d);
+        w = std_min(max_weight, w);
+      }
+      m.dist[gid] = d;
+      m.weight[gid] = w;
+      m.rgba[gid] = col;
+    }
+  }
+  if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) publish_block(m, slot, st);
+}
+
+__global__ void k_reset_tsdf_flags(MapDev m, uint32_t n_slots) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  m.blk_flags[s] &= (kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+}
+
 // ===========================================================================
 // ESDF integrator (esdf_integrator.cc) — see DESIGN.md §ESDF.
 //
@@ -894,8 +979,6 @@ __global__ void k_fast_emit(const uint32_t* __restrict__ off_full, const uint32_
 // its one-voxel halo (18^3 distances + states, 46 KiB) in LDS, relaxes it to a local fixed
 // point, and the host repeats global sweeps until no block changes.
 // ===========================================================================
-constexpr uint32_t kFlagEsdfAlloc = 0x1000;   // block exists in Layer<EsdfVoxel>
-constexpr uint32_t kFlagEsdfUpdShift = 4;     // ESDF block's Update bits live in bits 4..6
 constexpr uint32_t kEsdfObserved = 1, kEsdfHallucinated = 2, kEsdfInQueue = 4, kEsdfFixed = 8;
 
 struct EsdfDev {
@@ -2319,6 +2402,21 @@ int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], do
 
 int vbx_clear(vbx_ctx* ctx, int layer) {
   if (!ctx) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (layer == VBX_LAYER_TSDF) {
+    // removeAllBlocks (layer.h:168): zero every slot in use and unpublish it in one go; the
+    // hash entries stay and turn back into invisible candidates.
+    int rc = sync_state(ctx);
+    if (rc) return rc;
+    const uint32_t used = ctx->h_state.pool_used;
+    if (used == 0) return VBX_OK;
+    const size_t nv = (size_t)used * ctx->map.nvox;
+    HIP_TRY(hipMemsetAsync(ctx->map.dist, 0, nv * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->map.weight, 0, nv * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->map.rgba, 0, nv * 4, ctx->stream));
+    hipLaunchKernelGGL(k_reset_tsdf_flags, grid_for(used), dim3(256), 0, ctx->stream, ctx->map, used);
+    return VBX_OK;
+  }
   std::vector<std::pair<uint64_t, uint32_t>> v;
   int rc = list_blocks(ctx, layer, 0, &v);
   if (rc) return rc;
@@ -2342,6 +2440,54 @@ int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask) {
     HIP_TRY(hipMemcpy(ctx->map.blk_flags + kv.second, &f, 4, hipMemcpyHostToDevice));
   }
   return VBX_OK;
+}
+
+
+// ---- multi-GPU block merge ------------------------------------------------------------
+static int upload_idx(vbx_ctx* ctx, const int32_t* idx, size_t n) {
+  HIP_TRY(ctx->b_head.ensure(std::max<size_t>(n, 1) * 12));
+  HIP_TRY(ctx->b_rank.ensure(std::max<size_t>(n, 1) * 4));
+  HIP_TRY(hipMemcpyAsync(ctx->b_head.p, idx, n * 12, hipMemcpyHostToDevice, ctx->stream));
+  return VBX_OK;
+}
+
+int vbx_blocks_export_sums(vbx_ctx* ctx, const int32_t* idx, size_t n, float* d_out) {
+  if (!ctx || (n && (!idx || !d_out))) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return VBX_OK;
+  int rc = upload_idx(ctx, idx, n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, ctx->stream, ctx->map,
+                     ctx->b_head.as<int32_t>(), (uint32_t)n, 1, ctx->b_rank.as<uint32_t>());
+  hipLaunchKernelGGL(k_export_sums, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->map,
+                     ctx->b_rank.as<uint32_t>(), d_out);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // idx is a caller-owned host buffer
+  return VBX_OK;
+}
+
+int vbx_blocks_merge_sums(vbx_ctx* ctx, const int32_t* idx, size_t n, const float* d_sums, int apply_caps,
+                          float truncation_distance, float max_weight) {
+  if (!ctx || (n && (!idx || !d_sums))) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return VBX_OK;
+  int rc = upload_idx(ctx, idx, n);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
+  hipLaunchKernelGGL(k_insert_blocks, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+                     ctx->d_state);
+  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
+                     ctx->b_rank.as<uint32_t>());
+  hipLaunchKernelGGL(k_merge_sums, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), d_sums,
+                     apply_caps, truncation_distance, max_weight, ctx->d_state);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  return check_state_error(ctx);
 }
 
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out) {
