@@ -98,7 +98,7 @@ struct DevState {
   uint32_t esdf_blocks;
   uint32_t esdf_raise_any;
   uint32_t esdf_relax_blocks;
-  uint32_t act_count[2];
+  uint32_t act_count[3];
   unsigned long long total_keys;
   unsigned long long voxels_touched;
   unsigned long long rays_cast;
@@ -677,33 +677,48 @@ __global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
 // ray visits walking from the surface towards the sensor (cast_from_origin = false,
 // tsdf_integrator.cc:521-525).  Built once per frame; the solver and the emit step then work
 // on these lists instead of re-running the DDA and the block hash lookups.
-__global__ void k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
-                                   uint32_t* vox, DevState* st) {
+__global__ void __launch_bounds__(256)
+k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
+                   uint32_t* vox, DevState* st) {
+  // One ray per lane; every lane stages 16 list entries in LDS, then the wave writes them out
+  // ray by ray as 64-byte runs (4 rays per store instruction) instead of 64 scattered dwords.
+  __shared__ uint32_t s_buf[4][64][17];  // [wave][lane][entry], padded against bank conflicts
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= tab.R) return;
   RayCaster rc;
-  if (!ray_init(rc, tab, r, c, m, /*from_origin=*/false, nullptr)) return;
-  if (rc.cur != 0) return;
-  const uint32_t base = off[r];
+  bool live = (r < tab.R) && ray_init(rc, tab, r, c, m, /*from_origin=*/false, nullptr) && rc.cur == 0;
+  const uint32_t base = (r < tab.R) ? off[r] : 0;
+  const uint32_t len = live ? rc.steps + 1 : 0;
   uint64_t last_key = kEmptyKey;
   uint32_t slot = kInvalidSlot;
-  uint32_t k = 0;
-  l3 g;
-  while (rc.next(&g)) {
-    const i3 b = block_index_from_global(g, m.vps_inv);
-    const uint64_t key = pack_block_key(b.x, b.y, b.z);
-    if (key != last_key) {
-      last_key = key;
-      slot = map_find(m, key);
-      if (slot == kInvalidSlot) atomicOr(&st->error, 2u);
+  for (uint32_t k0 = 0; __any(k0 < len); k0 += 16) {
+    for (int j = 0; j < 16; ++j) {
+      uint32_t gid = 0xFFFFFFFFu;
+      l3 g;
+      if (k0 + j < len && rc.next(&g)) {
+        const i3 b = block_index_from_global(g, m.vps_inv);
+        const uint64_t key = pack_block_key(b.x, b.y, b.z);
+        if (key != last_key) {
+          last_key = key;
+          slot = map_find(m, key);
+          if (slot == kInvalidSlot) atomicOr(&st->error, 2u);
+        }
+        if (slot != kInvalidSlot) {
+          const i3 l = local_from_global(g, m.vps);
+          gid = slot * m.nvox + (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
+        }
+      }
+      s_buf[wv][lane][j] = gid;
     }
-    uint32_t gid = 0xFFFFFFFFu;
-    if (slot != kInvalidSlot) {
-      const i3 l = local_from_global(g, m.vps);
-      gid = slot * m.nvox + (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
+    // wave-synchronous flush (same wave wrote and reads; LDS ops of one wave are ordered)
+    const int sub = lane >> 4, e = lane & 15;
+    for (int q = 0; q < 16; ++q) {
+      const int src = q * 4 + sub;  // lane whose ray is being written
+      const uint32_t sbase = __shfl(base, src);
+      const uint32_t slen = __shfl(len, src);
+      if (k0 + e < slen) vox[sbase + k0 + e] = s_buf[wv][src][e];
     }
-    vox[base + k] = gid;
-    ++k;
   }
 }
 
@@ -748,7 +763,7 @@ struct SweepArgs {
   const uint32_t* list_in;  // open rays of this sweep (null: identity, all R rays)
   uint32_t* list_out;       // open rays for the next sweep
   uint32_t n_in;            // upper bound of the input list length (grid size)
-  int which;                // DevState::act_count[which] = input count, [which^1] = output
+  int cnt_in, cnt_out;      // DevState::act_count[] indices of the input / output list lengths
   uint32_t* cl;             // certain claims (persistent within the frame)
   const uint32_t* ch_rd;    // possible claims of open rays, previous sweep
   uint32_t* ch_wr;          // possible claims of open rays, this sweep
@@ -760,17 +775,10 @@ struct SweepArgs {
   int l_only;               // 1: only tighten the lower bounds (TH and the possible claims stay)
 };
 
-template <int G>
-__global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, DevState* st) {
-  const int lane = threadIdx.x & 63;
-  const int grp = lane / G;
-  const int gl = lane % G;
-  constexpr int RPW = 64 / G;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t idx = wave * RPW + grp;
-  const uint32_t n_in = a.list_in ? min(a.n_in, st->act_count[a.which]) : R;
-  const bool ray_ok = idx < n_in;
-  const uint32_t r = ray_ok ? (a.list_in ? a.list_in[idx] : idx) : 0;
+// One sweep step for the ray handled by this lane group.  All 64 lanes of the wave must call
+// it together.  Returns (on the group's lane 0) whether the ray is still open.
+template <int G, bool kCoherentReads>
+__device__ inline bool sweep_ray(const SweepArgs& a, bool ray_ok, uint32_t r, int grp, int gl) {
   const uint32_t beg = ray_ok ? a.off[r] : 0;
   const uint32_t len = ray_ok ? a.off[r + 1] - beg : 0;
   const uint32_t smask = (1u << a.s_bits) - 1;
@@ -795,7 +803,9 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
       pL = ((c1 >> a.s_bits) == a.tag_cl) && ((c1 & smask) < r);
       pH = pL;
       if (!pH) {
-        const uint32_t c2 = a.ch_rd[gid];
+        const uint32_t c2 = kCoherentReads
+                                ? __hip_atomic_load(&a.ch_rd[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : a.ch_rd[gid];
         pH = ((c2 >> a.s_bits) == a.tag_rd) && ((c2 & smask) < r);
       }
     }
@@ -833,27 +843,47 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
       }
     }
   }
-  // Open rays go to the next sweep's work list: one global atomic per workgroup.
-  __shared__ uint32_t s_cnt, s_base;
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
   bool open = false;
-  uint32_t my = 0;
   if (gl == 0 && ray_ok) {
     a.TL[r] = tl;
     if (!a.l_only) a.TH[r] = th;
     const bool final_ray = !a.init && !a.l_only && (tl == th) && (brokeL == brokeH);
-    if (final_ray) {
-      a.U[r] = brokeH ? th - 1 : th;  // the terminating probe's voxel is not updated
-    } else if (a.list_out) {
-      open = true;
-      my = atomicAdd(&s_cnt, 1u);
-    }
+    if (final_ray) a.U[r] = brokeH ? th - 1 : th;  // the terminating probe's voxel is not updated
+    else open = true;
   }
+  return open;
+}
+
+// Appends the workgroup's open rays to the next sweep's work list: one global atomic per
+// workgroup.  Every thread of the workgroup must call it.
+__device__ inline void append_open(bool open, uint32_t r, uint32_t* list_out, uint32_t* counter) {
+  __shared__ uint32_t s_cnt, s_base;
+  if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(&st->act_count[a.which ^ 1], s_cnt);
+  uint32_t my = 0;
+  if (open) my = atomicAdd(&s_cnt, 1u);
   __syncthreads();
-  if (open) a.list_out[s_base + my] = r;
+  if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(counter, s_cnt);
+  __syncthreads();
+  if (open) list_out[s_base + my] = r;
+  __syncthreads();
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, DevState* st) {
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / G;
+  const int gl = lane % G;
+  constexpr int RPW = 64 / G;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t idx = wave * RPW + grp;
+  const uint32_t n_in = a.list_in ? min(a.n_in, st->act_count[a.cnt_in]) : R;
+  const bool ray_ok = idx < n_in;
+  const uint32_t r = ray_ok ? (a.list_in ? a.list_in[idx] : idx) : 0;
+  // the counter after the output one is the NEXT launch's output: zero it here
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->act_count[(a.cnt_out + 1) % 3] = 0;
+  const bool open = sweep_ray<G, false>(a, ray_ok, r, grp, gl);
+  if (a.list_out) append_open(open, r, a.list_out, &st->act_count[a.cnt_out]);
 }
 
 // Emit the ordered update keys of the voxels each ray reaches (k < U[r]) straight from the
@@ -1654,7 +1684,9 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
 
   // claim arrays + tags (see k_fast_sweep)
   const size_t nvox_total = (size_t)m.cap_blocks * m.nvox;
-  const int s_bits = (int)bits_for(std::max<uint32_t>(R, 2) - 1);
+  // ray-index bits: sized by the cloud (an upper bound of R) so the tag layout — and with it
+  // the claim arrays' contents — stays valid from frame to frame
+  const int s_bits = std::max((int)bits_for(std::max<size_t>(n, 2) - 1), ctx->own_s_bits);
   const bool fresh = (ctx->b_own0.p == nullptr);
   HIP_TRY(ctx->b_own0.ensure(nvox_total * 4));
   HIP_TRY(ctx->b_own1.ensure(nvox_total * 4));
@@ -1679,70 +1711,90 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_act0.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_act1.ensure((size_t)(R + 1) * 4));
   HIP_TRY(hipMemsetAsync(ctx->b_U.as<uint32_t>() + R, 0, 4, s));
-  SweepArgs sa{};
-  sa.off = ctx->b_off.as<uint32_t>();
-  sa.vox = ctx->b_vox.as<uint32_t>();
-  sa.cl = ctx->b_cl.as<uint32_t>();
-  sa.tag_cl = --ctx->own_tag;
-  sa.s_bits = s_bits;
-  sa.max_consecutive = c.max_consecutive;
-  sa.TL = ctx->b_T.as<uint32_t>();
-  sa.TH = ctx->b_TH.as<uint32_t>();
-  sa.U = ctx->b_U.as<uint32_t>();
-  // sweep 0: publish the full-path possible claims (TH = path length);
-  // sweep 1: lower bounds only (TH cannot move while there are no certain claims);
-  // sweeps 2..: both bounds, open rays only.
-  uint32_t iters = 0;
-  uint32_t n_open = R;  // host-side upper bound of the open list
-  uint32_t total = 0;
-  uint32_t tag_rd = 0xFFFFFFFFu;
-  int ch_flip = 0;      // which of the two possible-claim arrays holds the readable sweep
-  bool have_list = false;
-  for (;;) {
-    const int kBatch = (iters == 0) ? 3 : 2;  // sweeps per host check
-    for (int b = 0; b < kBatch; ++b) {
-      sa.init = (iters == 0) ? 1 : 0;
-      sa.l_only = (iters == 1) ? 1 : 0;
-      const bool writes_ch = !sa.l_only;
-      const int which = (int)(iters & 1);
-      sa.which = which;
-      sa.list_in = have_list ? ((which ? ctx->b_act1 : ctx->b_act0).as<uint32_t>()) : nullptr;
-      sa.list_out = (iters >= 2) ? (which ? ctx->b_act0 : ctx->b_act1).as<uint32_t>() : nullptr;
-      sa.n_in = n_open;
-      sa.ch_rd = (ch_flip ? ctx->b_own1 : ctx->b_own0).as<uint32_t>();
-      sa.ch_wr = (ch_flip ? ctx->b_own0 : ctx->b_own1).as<uint32_t>();
-      sa.tag_rd = tag_rd;
-      sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
-      HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[which ^ 1], 0, 4, s));
-      if (iters == 0)
-        hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
-      else
-        hipLaunchKernelGGL(k_fast_sweep<16>, grid_for((size_t)n_open * 16), dim3(256), 0, s, sa, R, ctx->d_state);
-      if (writes_ch) {
-        tag_rd = sa.tag_wr;
-        ch_flip ^= 1;
+  uint32_t iters_total = 0;
+  auto run_solver = [&]() -> int {
+    SweepArgs sa{};
+    sa.off = ctx->b_off.as<uint32_t>();
+    sa.vox = ctx->b_vox.as<uint32_t>();
+    sa.cl = ctx->b_cl.as<uint32_t>();
+    sa.tag_cl = --ctx->own_tag;
+    sa.s_bits = s_bits;
+    sa.max_consecutive = c.max_consecutive;
+    sa.TL = ctx->b_T.as<uint32_t>();
+    sa.TH = ctx->b_TH.as<uint32_t>();
+    sa.U = ctx->b_U.as<uint32_t>();
+    // sweep 0: publish the full-path possible claims (TH = path length);
+    // sweep 1: lower bounds only (TH cannot move while there are no certain claims);
+    // sweeps 2..: both bounds, open rays only.  (A persistent tail kernel with grid barriers
+    // instead of launches was measured slower: 1.07 vs 0.98 ms — barrier + L2 write-back per
+    // sweep cost more than a launch.)
+    uint32_t iters = 0;
+    uint32_t n_open = R;  // host-side upper bound of the open list
+    uint32_t tag_rd = 0xFFFFFFFFu;
+    int ch_flip = 0;      // which of the two possible-claim arrays holds the readable sweep
+    int list_sel = 0;     // which work list the next sweep reads
+    int cnt_cur = 0;      // act_count index of that list's length
+    bool have_list = false;
+    uint32_t* lists[2] = {ctx->b_act0.as<uint32_t>(), ctx->b_act1.as<uint32_t>()};
+    uint32_t* chs[2] = {ctx->b_own0.as<uint32_t>(), ctx->b_own1.as<uint32_t>()};
+    for (;;) {
+      {
+        const int kBatch = (iters == 0) ? 3 : 4;  // sweeps per host check (an idle sweep is ~8 us, a check ~30 us)
+        for (int b = 0; b < kBatch; ++b) {
+          sa.init = (iters == 0) ? 1 : 0;
+          sa.l_only = (iters == 1) ? 1 : 0;
+          const bool writes_ch = !sa.l_only;
+          const bool writes_list = iters >= 2;
+          sa.cnt_in = cnt_cur;
+          sa.cnt_out = (cnt_cur + 1) % 3;
+          sa.list_in = have_list ? lists[list_sel] : nullptr;
+          sa.list_out = writes_list ? lists[have_list ? (list_sel ^ 1) : 0] : nullptr;
+          sa.n_in = n_open;
+          sa.ch_rd = chs[ch_flip];
+          sa.ch_wr = chs[ch_flip ^ 1];
+          sa.tag_rd = tag_rd;
+          sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
+          if (writes_list && !have_list) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[sa.cnt_out], 0, 4, s));
+          if (iters == 0)
+            hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
+          else
+            hipLaunchKernelGGL(k_fast_sweep<16>, grid_for((size_t)n_open * 16), dim3(256), 0, s, sa, R, ctx->d_state);
+          if (writes_ch) {
+            tag_rd = sa.tag_wr;
+            ch_flip ^= 1;
+          }
+          if (writes_list) {
+            list_sel = have_list ? (list_sel ^ 1) : 0;
+            have_list = true;
+            cnt_cur = sa.cnt_out;
+          }
+          ++iters;
+        }
+        rc = sync_state(ctx);
+        if (rc) return rc;
+        rc = check_state_error(ctx);
+        if (rc) return rc;
+        n_open = ctx->h_state.act_count[cnt_cur];
       }
-      if (sa.list_out) have_list = true;
-      ++iters;
+      if (getenv("VBX_DEBUG")) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
+      if (n_open == 0) break;
+      if (iters > 1000000 || ctx->own_tag < 128) {
+        ctx->fail("Fast integrator: early-termination solver did not converge");
+        return VBX_ERR_HIP;
+      }
     }
-    rc = sync_state(ctx);
-    if (rc) return rc;
-    rc = check_state_error(ctx);
-    if (rc) return rc;
-    n_open = ctx->h_state.act_count[iters & 1];
-    if (getenv("VBX_DEBUG")) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
-    if (n_open == 0) break;
-    if (iters > 1000000 || ctx->own_tag < 8) {
-      ctx->fail("Fast integrator: early-termination solver did not converge");
-      return VBX_ERR_HIP;
-    }
-  }
+    iters_total = iters;
+    return VBX_OK;
+  };
+  rc = run_solver();
+  if (rc) return rc;
+  uint32_t total = 0;
   // offsets of the keys each ray emits
   rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(&total, ctx->b_rank.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  ctx->counters.iterations = iters;
+  ctx->counters.iterations = iters_total;
   tmark(ctx, 3);
   hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
   if (total == 0) return VBX_OK;
