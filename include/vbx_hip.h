@@ -147,6 +147,22 @@ int vbx_clear(vbx_ctx* ctx, int layer);
 /* block.updated().reset(bit) over all blocks of a layer (mesher / ESDF consumers). */
 int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask);
 
+/* ---- Layer serialization ----
+ * Block<V>::serializeToIntegers / deserializeFromIntegers (src/core/block.cc:66-90, 112-137,
+ * 160-183, 204-234): the uint32 word stream that both the .voxblox file format
+ * (BlockProto.voxel_data, layer_inl.h:139-158) and voxblox_msgs/Block.data
+ * (conversions_inl.h:34-38) carry.  TSDF: 3 words per voxel {bits(distance), bits(weight),
+ * r<<24|g<<16|b<<8|a}; ESDF: 2 words {bits(distance), parent<<8|flags} including the reference
+ * writer's sign-extension of negative parent components (block.cc:37-39).  Packed/unpacked on
+ * the GPU straight from/to the SoA pool; n blocks per call, words_per_block = vps^3 * (3|2).
+ * words: host buffer of n * words_per_block uint32.  Serializing an unallocated block is
+ * VBX_ERR_INVALID.  Deserializing allocates, publishes and sets all Update bits
+ * (Layer::addBlockFromProto, layer_inl.h:199-230); has_data[i] may be NULL (= 0). */
+int vbx_blocks_serialize(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t n, uint32_t* words,
+                         uint8_t* has_data);
+int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t n, const uint32_t* words,
+                           const uint8_t* has_data);
+
 /* ---- multi-GPU: ray-bundle sharding with a block merge ----
  * Each rank integrates its ray shard into a per-frame delta map; the deltas are combined as
  * weighted sums — which is what Block::mergeBlock / mergeVoxelAIntoVoxelB compute

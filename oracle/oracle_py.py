@@ -108,6 +108,9 @@ def _bind(L):
         "orc_tsdf_block_get": (C.c_int, [vp, i32p, f32p, f32p, u8p, u8p]),
         "orc_esdf_block_get": (C.c_int, [vp, i32p, f32p, u8p, i32p, u8p]),
         "orc_tsdf_block_set": (C.c_int, [vp, i32p, f32p, f32p, u8p, C.c_uint8]),
+        "orc_block_serialize": (C.c_size_t, [vp, C.c_int, i32p, C.POINTER(C.c_uint32), C.c_size_t]),
+        "orc_block_deserialize": (C.c_int, [vp, C.c_int, i32p, C.POINTER(C.c_uint32), C.c_size_t]),
+        "orc_esdf_block_set": (C.c_int, [vp, i32p, f32p, u8p, i32p, C.c_uint8]),
         "orc_remove_distant_blocks": (None, [vp, C.c_int, f32p, C.c_double]),
         "orc_clear": (None, [vp, C.c_int]),
         "orc_tsdf_count_observed": (C.c_uint64, [vp]),
@@ -238,6 +241,25 @@ class OracleMap:
         d = f32(d); w = f32(w); c = np.ascontiguousarray(c, np.uint8)
         self.L.orc_tsdf_block_set(self.h, _p(idx, C.c_int32), _p(d, C.c_float), _p(w, C.c_float),
                                   _p(c, C.c_uint8), updated_bits)
+
+    def esdf_block_set(self, idx, d, flags, parent, updated_bits=1):
+        idx = np.ascontiguousarray(idx, np.int32)
+        d = f32(d); fl = np.ascontiguousarray(flags, np.uint8); p = np.ascontiguousarray(parent, np.int32)
+        self.L.orc_esdf_block_set(self.h, _p(idx, C.c_int32), _p(d, C.c_float), _p(fl, C.c_uint8),
+                                  _p(p, C.c_int32), updated_bits)
+
+    def block_serialize(self, idx, layer=0):
+        """Block::serializeToIntegers -> uint32 words (None if the block is absent)."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        n = self.vps ** 3 * (3 if layer == 0 else 2)
+        out = np.zeros(n, np.uint32)
+        got = self.L.orc_block_serialize(self.h, layer, _p(idx, C.c_int32), _p(out, C.c_uint32), n)
+        return out if got == n else None
+
+    def block_deserialize(self, idx, words, layer=0):
+        idx = np.ascontiguousarray(idx, np.int32)
+        w = np.ascontiguousarray(words, np.uint32)
+        return bool(self.L.orc_block_deserialize(self.h, layer, _p(idx, C.c_int32), _p(w, C.c_uint32), w.shape[0]))
 
     def tsdf_dict(self):
         """{(bx,by,bz): (dist, weight, rgba, updated)} for every allocated TSDF block."""

@@ -216,6 +216,50 @@ uint64_t orc_tsdf_count_observed(orc_map* m) {
   return n;
 }
 
+size_t orc_block_serialize(orc_map* m, int layer, const int32_t idx[3], uint32_t* words, size_t cap) {
+  std::vector<uint32_t> data;
+  const BlockIndex bi(idx[0], idx[1], idx[2]);
+  if (layer == 0) {
+    Block<TsdfVoxel>::Ptr b = m->tsdf.getBlockPtrByIndex(bi);
+    if (!b) return 0;
+    b->serializeToIntegers(&data);
+  } else {
+    Block<EsdfVoxel>::Ptr b = m->esdf.getBlockPtrByIndex(bi);
+    if (!b) return 0;
+    b->serializeToIntegers(&data);
+  }
+  for (size_t i = 0; i < data.size() && i < cap; ++i) words[i] = data[i];
+  return data.size();
+}
+int orc_block_deserialize(orc_map* m, int layer, const int32_t idx[3], const uint32_t* words, size_t n) {
+  const std::vector<uint32_t> data(words, words + n);
+  const BlockIndex bi(idx[0], idx[1], idx[2]);
+  if (layer == 0) {
+    Block<TsdfVoxel>::Ptr b = m->tsdf.allocateBlockPtrByIndex(bi);
+    if (data.size() != b->num_voxels() * 3) return 0;
+    b->deserializeFromIntegers(data);
+    b->updated().set();
+  } else {
+    Block<EsdfVoxel>::Ptr b = m->esdf.allocateBlockPtrByIndex(bi);
+    if (data.size() != b->num_voxels() * 2) return 0;
+    b->deserializeFromIntegers(data);
+    b->updated().set();
+  }
+  return 1;
+}
+int orc_esdf_block_set(orc_map* m, const int32_t idx[3], const float* dist, const uint8_t* flags,
+                       const int32_t* parent, uint8_t updated_bits) {
+  Block<EsdfVoxel>::Ptr b = m->esdf.allocateBlockPtrByIndex(BlockIndex(idx[0], idx[1], idx[2]));
+  for (size_t i = 0; i < b->num_voxels(); ++i) {
+    EsdfVoxel& v = b->getVoxelByLinearIndex(i);
+    v.distance = dist[i];
+    v.observed = flags[i] & 1; v.hallucinated = flags[i] & 2; v.in_queue = flags[i] & 4; v.fixed = flags[i] & 8;
+    v.parent = Eigen::Vector3i(parent[3 * i], parent[3 * i + 1], parent[3 * i + 2]);
+  }
+  b->updated() = std::bitset<Update::kCount>(updated_bits);
+  return 1;
+}
+
 void orc_grid_index_from_point(const float p[3], float inv, int64_t out[3]) {
   const GlobalIndex r = getGridIndexFromPoint<GlobalIndex>(Point(p[0], p[1], p[2]), inv);
   out[0] = r.x(); out[1] = r.y(); out[2] = r.z();

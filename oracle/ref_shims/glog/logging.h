@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 #include <cstdlib>
+#include <cstring>  // real glog pulls this in; block.cc relies on it for memcpy
 #include <iostream>
 #include <sstream>
 

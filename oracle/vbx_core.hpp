@@ -17,6 +17,7 @@
 // /root/reference/voxblox).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -260,6 +261,86 @@ struct Block {
   float voxel_size_inv, block_size, block_size_inv;
   uint8_t updated;  // bitset<3>
 };
+
+// ---------------------------------------------------------------------------
+// Block <-> uint32 words, src/core/block.cc.  TSDF: 3 words per voxel
+// {bits(distance), bits(weight), r<<24|g<<16|b<<8|a} (:160-183, :66-90).  ESDF: 2 words
+// {bits(distance), parent<<8 | flags} (:204-234, :112-137) where serializeDirection (:8-40)
+// shifts each int8 AFTER promotion to int and before the uint32 cast, so a negative component
+// sign-extends over all higher bytes — reproduced for byte compatibility.
+// ---------------------------------------------------------------------------
+inline void serializeBlock(const Block<TsdfVoxel>& b, std::vector<uint32_t>* data) {
+  data->clear();
+  data->reserve(b.num_voxels * 3);
+  for (size_t i = 0; i < b.num_voxels; ++i) {
+    const TsdfVoxel& v = b.voxels[i];
+    uint32_t w1, w2;
+    std::memcpy(&w1, &v.distance, 4);
+    std::memcpy(&w2, &v.weight, 4);
+    data->push_back(w1);
+    data->push_back(w2);
+    data->push_back(static_cast<uint32_t>(v.color.a) | (static_cast<uint32_t>(v.color.b) << 8) |
+                    (static_cast<uint32_t>(v.color.g) << 16) | (static_cast<uint32_t>(v.color.r) << 24));
+  }
+}
+inline bool deserializeBlock(const std::vector<uint32_t>& data, Block<TsdfVoxel>* b) {
+  if (data.size() != b->num_voxels * 3) return false;  // CHECK_EQ, block.cc:70
+  for (size_t i = 0, d = 0; i < b->num_voxels; ++i, d += 3) {
+    TsdfVoxel& v = b->voxels[i];
+    std::memcpy(&v.distance, &data[d], 4);
+    std::memcpy(&v.weight, &data[d + 1], 4);
+    const uint32_t c = data[d + 2];
+    v.color.r = static_cast<uint8_t>(c >> 24);
+    v.color.g = static_cast<uint8_t>((c & 0x00FF0000) >> 16);
+    v.color.b = static_cast<uint8_t>((c & 0x0000FF00) >> 8);
+    v.color.a = static_cast<uint8_t>(c & 0x000000FF);
+  }
+  return true;
+}
+inline uint32_t serializeDirection(const Idx3& p) {
+  const int8_t px = static_cast<int8_t>(std::min<int>(INT8_MAX, std::max<int>(p.x, INT8_MIN)));
+  const int8_t py = static_cast<int8_t>(std::min<int>(INT8_MAX, std::max<int>(p.y, INT8_MIN)));
+  const int8_t pz = static_cast<int8_t>(std::min<int>(INT8_MAX, std::max<int>(p.z, INT8_MIN)));
+  uint32_t data = 0;
+  // static_cast<int8_t>(x) << 24 is an int shift of the promoted (sign-extended) value
+  data |= static_cast<uint32_t>(static_cast<int64_t>(px) << 24);
+  data |= static_cast<uint32_t>(static_cast<int64_t>(py) << 16);
+  data |= static_cast<uint32_t>(static_cast<int64_t>(pz) << 8);
+  return data;
+}
+inline void serializeBlock(const Block<EsdfVoxel>& b, std::vector<uint32_t>* data) {
+  data->clear();
+  data->reserve(b.num_voxels * 2);
+  for (size_t i = 0; i < b.num_voxels; ++i) {
+    const EsdfVoxel& v = b.voxels[i];
+    uint32_t w1;
+    std::memcpy(&w1, &v.distance, 4);
+    data->push_back(w1);
+    uint32_t w2 = serializeDirection(v.parent);
+    uint8_t flags = 0;
+    flags |= v.observed ? 1 : 0;
+    flags |= v.hallucinated ? 2 : 0;
+    flags |= v.in_queue ? 4 : 0;
+    flags |= v.fixed ? 8 : 0;
+    w2 |= static_cast<uint32_t>(flags) & 0xFF;
+    data->push_back(w2);
+  }
+}
+inline bool deserializeBlock(const std::vector<uint32_t>& data, Block<EsdfVoxel>* b) {
+  if (data.size() != b->num_voxels * 2) return false;
+  for (size_t i = 0, d = 0; i < b->num_voxels; ++i, d += 2) {
+    EsdfVoxel& v = b->voxels[i];
+    std::memcpy(&v.distance, &data[d], 4);
+    const uint32_t w = data[d + 1];
+    v.observed = (w & 1) != 0;
+    v.hallucinated = (w & 2) != 0;
+    v.in_queue = (w & 4) != 0;
+    v.fixed = (w & 8) != 0;
+    v.parent = {static_cast<int8_t>((w >> 24) & 0xFF), static_cast<int8_t>((w >> 16) & 0xFF),
+                static_cast<int8_t>((w >> 8) & 0xFF)};
+  }
+  return true;
+}
 
 // ---------------------------------------------------------------------------
 // Layer<V>, core/layer.h:24-296.  std::unordered_map with the reference's hash

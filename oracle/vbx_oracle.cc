@@ -249,6 +249,46 @@ uint64_t orc_tsdf_count_observed(orc_map* m) {
   return n;
 }
 
+size_t orc_block_serialize(orc_map* m, int layer, const int32_t idx[3], uint32_t* words, size_t cap) {
+  std::vector<uint32_t> data;
+  if (layer == 0) {
+    auto b = m->tsdf.getBlockPtrByIndex({idx[0], idx[1], idx[2]});
+    if (!b) return 0;
+    serializeBlock(*b, &data);
+  } else {
+    auto b = m->esdf.getBlockPtrByIndex({idx[0], idx[1], idx[2]});
+    if (!b) return 0;
+    serializeBlock(*b, &data);
+  }
+  for (size_t i = 0; i < data.size() && i < cap; ++i) words[i] = data[i];
+  return data.size();
+}
+int orc_block_deserialize(orc_map* m, int layer, const int32_t idx[3], const uint32_t* words, size_t n) {
+  const std::vector<uint32_t> data(words, words + n);
+  if (layer == 0) {
+    auto b = m->tsdf.allocateBlockPtrByIndex({idx[0], idx[1], idx[2]});
+    if (!deserializeBlock(data, b.get())) return 0;
+    b->updated = 0x7;
+  } else {
+    auto b = m->esdf.allocateBlockPtrByIndex({idx[0], idx[1], idx[2]});
+    if (!deserializeBlock(data, b.get())) return 0;
+    b->updated = 0x7;
+  }
+  return 1;
+}
+int orc_esdf_block_set(orc_map* m, const int32_t idx[3], const float* dist, const uint8_t* flags,
+                       const int32_t* parent, uint8_t updated_bits) {
+  auto b = m->esdf.allocateBlockPtrByIndex({idx[0], idx[1], idx[2]});
+  for (size_t i = 0; i < b->num_voxels; ++i) {
+    EsdfVoxel& v = b->voxels[i];
+    v.distance = dist[i];
+    v.observed = flags[i] & 1; v.hallucinated = flags[i] & 2; v.in_queue = flags[i] & 4; v.fixed = flags[i] & 8;
+    v.parent = {parent[3 * i], parent[3 * i + 1], parent[3 * i + 2]};
+  }
+  b->updated = updated_bits;
+  return 1;
+}
+
 // ---- known-answer helpers ----
 void orc_grid_index_from_point(const float p[3], float inv, int64_t out[3]) {
   const LIdx3 r = gridIndexFromPointL({p[0], p[1], p[2]}, inv);

@@ -100,6 +100,16 @@ void orc_clear(orc_map* m, int layer);
 /* counts voxels with weight > 1e-6 (evaluation_utils.cc:75-78 "observed") */
 uint64_t orc_tsdf_count_observed(orc_map* m);
 
+/* Block::serializeToIntegers / deserializeFromIntegers (src/core/block.cc).  serialize returns
+ * the number of words (3 or 2 per voxel) or 0 if the block is absent; deserialize allocates the
+ * block if needed, sets all updated bits like Layer::addBlockFromProto (layer_inl.h:227), and
+ * returns 0 on a size mismatch. */
+size_t orc_block_serialize(orc_map* m, int layer, const int32_t idx[3], uint32_t* words, size_t cap);
+int orc_block_deserialize(orc_map* m, int layer, const int32_t idx[3], const uint32_t* words, size_t n);
+/* write an ESDF block from SoA arrays (tests of the serialisation corner cases) */
+int orc_esdf_block_set(orc_map* m, const int32_t idx[3], const float* dist, const uint8_t* flags,
+                       const int32_t* parent_xyz, uint8_t updated_bits);
+
 /* ---- known-answer helpers (restate test_tsdf_map / test_approx_hash_array / test_bucket_queue) ---- */
 void orc_grid_index_from_point(const float p[3], float grid_size_inv, int64_t out[3]);
 void orc_center_point_from_grid_index(const int64_t idx[3], float grid_size, float out[3]);

@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../../voxblox_amd/host/vbx_integrators.hpp"
+#include "../../voxblox_amd/host/vbx_io.hpp"
 
 using namespace vbx_host;
 
@@ -79,6 +80,34 @@ int main() {
               still_flagged.size());
   if (eblocks.size() != tsdf.getNumberOfAllocatedBlocks() || eobs == 0 || efixed == 0 || !still_flagged.empty())
     return 6;
+  // save_map / load_map path: TSDF + ESDF sections in one file, reloaded into a fresh map
+  const char* path = "/tmp/vbx_shim_demo.voxblox";
+  if (!io::SaveLayer(tsdf, path, true) || !io::SaveLayer(esdf, path, false)) return 7;
+  auto map2 = std::make_shared<DeviceMap>(voxel, 16, 2048, 0);
+  Layer<TsdfVoxel> tsdf2(map2);
+  Layer<EsdfVoxel> esdf2(map2);
+  if (!io::LoadBlocksFromFile(path, false, &tsdf2) || !io::LoadBlocksFromFile(path, true, &esdf2)) return 8;
+  BlockIndexList b1, b2;
+  tsdf.getAllAllocatedBlocks(&b1);
+  tsdf2.getAllAllocatedBlocks(&b2);
+  if (b1.size() != b2.size() || esdf2.getNumberOfAllocatedBlocks() != eblocks.size()) return 9;
+  size_t diff = 0;
+  for (size_t i = 0; i < b1.size(); ++i) {
+    auto x = tsdf.getBlockPtrByIndex(b1[i]);
+    auto y = tsdf2.getBlockPtrByIndex(b1[i]);
+    if (!x || !y) return 10;
+    diff += std::memcmp(&x->getVoxelByLinearIndex(0), &y->getVoxelByLinearIndex(0), x->num_voxels() * sizeof(TsdfVoxel)) != 0;
+    auto ex = esdf.getBlockPtrByIndex(b1[i]);
+    auto ey = esdf2.getBlockPtrByIndex(b1[i]);
+    if (!ex || !ey) return 11;
+    for (size_t v = 0; v < ex->num_voxels(); ++v) {
+      const EsdfVoxel& p = ex->getVoxelByLinearIndex(v);
+      const EsdfVoxel& q = ey->getVoxelByLinearIndex(v);
+      diff += std::memcmp(&p.distance, &q.distance, 4) != 0 || p.observed != q.observed || p.fixed != q.fixed;
+    }
+  }
+  std::printf("io round trip blocks=%zu differing=%zu\n", b1.size(), diff);
+  if (diff) return 12;
   std::printf("shim OK\n");
   return 0;
 }

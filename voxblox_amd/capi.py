@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
-    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
+    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
 
 
 class MapCfg(C.Structure):
@@ -114,6 +114,8 @@ def lib():
         "vbx_remove_distant_blocks": (C.c_int, [vp, C.c_int, f32p, C.c_double]),
         "vbx_clear": (C.c_int, [vp, C.c_int]),
         "vbx_clear_updated": (C.c_int, [vp, C.c_int, C.c_int]),
+        "vbx_blocks_serialize": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, C.POINTER(C.c_uint32), u8p]),
+        "vbx_blocks_deserialize": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, C.POINTER(C.c_uint32), u8p]),
         "vbx_blocks_export_sums": (C.c_int, [vp, i32p, C.c_size_t, vp]),
         "vbx_blocks_merge_sums": (C.c_int, [vp, i32p, C.c_size_t, vp, C.c_int, C.c_float, C.c_float]),
         "vbx_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
@@ -263,6 +265,26 @@ class Map:
 
     def clear_updated(self, mask, layer=LAYER_TSDF):
         self._chk(self.L.vbx_clear_updated(self.h, layer, mask))
+
+    def blocks_serialize(self, idx_xyz, layer=LAYER_TSDF):
+        """Block::serializeToIntegers for n blocks -> (words [n, vps^3*(3|2)] uint32, has_data [n])."""
+        idx = np.ascontiguousarray(idx_xyz, np.int32).reshape(-1, 3)
+        wpb = self.vps ** 3 * (3 if layer == LAYER_TSDF else 2)
+        words = np.zeros((idx.shape[0], wpb), np.uint32)
+        hd = np.zeros(max(idx.shape[0], 1), np.uint8)
+        self._chk(self.L.vbx_blocks_serialize(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.shape[0],
+                                              words.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              hd.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return words, hd[:idx.shape[0]]
+
+    def blocks_deserialize(self, idx_xyz, words, has_data=None, layer=LAYER_TSDF):
+        idx = np.ascontiguousarray(idx_xyz, np.int32).reshape(-1, 3)
+        wpb = self.vps ** 3 * (3 if layer == LAYER_TSDF else 2)
+        w = np.ascontiguousarray(words, np.uint32).reshape(idx.shape[0], wpb)
+        hd = None if has_data is None else np.ascontiguousarray(has_data, np.uint8)
+        self._chk(self.L.vbx_blocks_deserialize(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.shape[0],
+                                                w.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                None if hd is None else hd.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     def export_sums(self, idx_xyz, d_out_ptr):
         """vbx_blocks_export_sums: six float planes [w*d, w, w*r, w*g, w*b, w*a] per listed block."""

@@ -223,6 +223,12 @@ __device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* s
   }
 }
 
+__device__ inline void unpack_parent_bits(uint32_t s, int* x, int* y, int* z) {
+  *x = (int)(int8_t)((s >> 8) & 0xFF);
+  *y = (int)(int8_t)((s >> 16) & 0xFF);
+  *z = (int)(int8_t)((s >> 24) & 0xFF);
+}
+
 // ---------------------------------------------------------------------------
 // kernels: map maintenance
 // ---------------------------------------------------------------------------
@@ -912,6 +918,83 @@ __global__ void k_fast_emit(const uint32_t* __restrict__ off_full, const uint32_
   if (first_of_block) publish_block(m, slot, st);
 }
 
+
+
+// ---------------------------------------------------------------------------
+// kernels: Block<V>::serializeToIntegers / deserializeFromIntegers (src/core/block.cc)
+// ---------------------------------------------------------------------------
+__device__ inline uint32_t esdf_state_to_word(uint32_t st) {
+  int px, py, pz;
+  unpack_parent_bits(st, &px, &py, &pz);
+  // serializeDirection (block.cc:8-40): int8 promoted to int, shifted, then cast to uint32 —
+  // a negative component sign-extends over the higher bytes.
+  uint32_t w = 0;
+  w |= (uint32_t)((long long)(int8_t)px << 24);
+  w |= (uint32_t)((long long)(int8_t)py << 16);
+  w |= (uint32_t)((long long)(int8_t)pz << 8);
+  w |= st & 0xFu;
+  return w;
+}
+__global__ void k_serialize_tsdf(MapDev m, const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  uint32_t* o = out + (size_t)blockIdx.x * m.nvox * 3;
+  for (uint32_t i = threadIdx.x; i < m.nvox * 3; i += blockDim.x) {  // coalesced word stream
+    const uint32_t v = i / 3, f = i - 3 * v;
+    const uint32_t gid = slot * m.nvox + v;
+    uint32_t w;
+    if (f == 0) w = __float_as_uint(m.dist[gid]);
+    else if (f == 1) w = __float_as_uint(m.weight[gid]);
+    else {
+      const uint32_t c = m.rgba[gid];  // r | g<<8 | b<<16 | a<<24  ->  r<<24 | g<<16 | b<<8 | a
+      w = ((c & 0xFF) << 24) | (((c >> 8) & 0xFF) << 16) | (((c >> 16) & 0xFF) << 8) | ((c >> 24) & 0xFF);
+    }
+    o[i] = w;
+  }
+}
+__global__ void k_deserialize_tsdf(MapDev m, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ in) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* w = in + (size_t)blockIdx.x * m.nvox * 3;
+  for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+    const uint32_t gid = slot * m.nvox + v;
+    m.dist[gid] = __uint_as_float(w[3 * v]);
+    m.weight[gid] = __uint_as_float(w[3 * v + 1]);
+    const uint32_t c = w[3 * v + 2];
+    m.rgba[gid] = ((c >> 24) & 0xFF) | (((c >> 16) & 0xFF) << 8) | (((c >> 8) & 0xFF) << 16) | ((c & 0xFF) << 24);
+  }
+}
+__global__ void k_serialize_esdf(uint32_t nvox, const float* __restrict__ edist, const uint32_t* __restrict__ estate,
+                                 const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  uint32_t* o = out + (size_t)blockIdx.x * nvox * 2;
+  for (uint32_t i = threadIdx.x; i < nvox * 2; i += blockDim.x) {
+    const uint32_t v = i >> 1;
+    const uint32_t gid = slot * nvox + v;
+    o[i] = (i & 1) ? esdf_state_to_word(estate[gid]) : __float_as_uint(edist[gid]);
+  }
+}
+__global__ void k_deserialize_esdf(uint32_t nvox, float* edist, uint32_t* estate,
+                                   const uint32_t* __restrict__ slots, const uint32_t* __restrict__ in) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* w = in + (size_t)blockIdx.x * nvox * 2;
+  for (uint32_t v = threadIdx.x; v < nvox; v += blockDim.x) {
+    const uint32_t gid = slot * nvox + v;
+    edist[gid] = __uint_as_float(w[2 * v]);
+    const uint32_t b = w[2 * v + 1];  // deserializeDirection (block.cc:42-64) + flag bits
+    estate[gid] = (b & 0xFu) | (((b >> 24) & 0xFF) << 8) | (((b >> 16) & 0xFF) << 16) | (((b >> 8) & 0xFF) << 24);
+  }
+}
+__global__ void k_set_block_flags(MapDev m, const uint32_t* __restrict__ slots, uint32_t n, uint32_t or_bits,
+                                  const uint8_t* __restrict__ has_data, uint32_t has_data_bit) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || slots[i] == kInvalidSlot) return;
+  uint32_t f = or_bits;
+  if (has_data && has_data[i]) f |= has_data_bit;
+  atomicOr(&m.blk_flags[slots[i]], f);
+}
 
 // ---------------------------------------------------------------------------
 // kernels: multi-GPU block merge (mergeVoxelAIntoVoxelB as weighted sums)
@@ -2537,6 +2620,96 @@ int vbx_blocks_merge_sums(vbx_ctx* ctx, const int32_t* idx, size_t n, const floa
                      ctx->b_rank.as<uint32_t>());
   hipLaunchKernelGGL(k_merge_sums, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), d_sums,
                      apply_caps, truncation_distance, max_weight, ctx->d_state);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  return check_state_error(ctx);
+}
+
+
+// ---- Layer serialization -----------------------------------------------------------------
+int vbx_blocks_serialize(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, uint32_t* words, uint8_t* has_data) {
+  if (!ctx || (n && (!idx || !words))) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return VBX_OK;
+  if (layer == VBX_LAYER_ESDF && !ctx->esdf_init) {
+    ctx->fail("ESDF layer is empty");
+    return VBX_ERR_INVALID;
+  }
+  int rc = upload_idx(ctx, idx, n);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  const size_t wpb = (size_t)m.nvox * (layer == VBX_LAYER_TSDF ? 3 : 2);
+  HIP_TRY(ctx->b_keys0.ensure(n * wpb * 4));
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+                     layer == VBX_LAYER_TSDF ? 1 : 0, ctx->b_rank.as<uint32_t>());
+  if (layer == VBX_LAYER_TSDF)
+    hipLaunchKernelGGL(k_serialize_tsdf, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
+                       ctx->b_keys0.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(k_serialize_esdf, dim3((unsigned)n), dim3(256), 0, s, m.nvox, ctx->b_edist.as<float>(),
+                       ctx->b_estate.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), ctx->b_keys0.as<uint32_t>());
+  std::vector<uint32_t> slots(n), flags(n);
+  HIP_TRY(hipMemcpyAsync(slots.data(), ctx->b_rank.p, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(words, ctx->b_keys0.p, n * wpb * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t f = 0;
+    if (slots[i] != kInvalidSlot) HIP_TRY(hipMemcpy(&f, m.blk_flags + slots[i], 4, hipMemcpyDeviceToHost));
+    const bool ok = slots[i] != kInvalidSlot && (layer == VBX_LAYER_TSDF || (f & kFlagEsdfAlloc));
+    if (!ok) {
+      ctx->fail("block (%d,%d,%d) is not allocated", idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]);
+      return VBX_ERR_INVALID;
+    }
+    if (has_data) has_data[i] = (layer == VBX_LAYER_TSDF && (f & kFlagHasData)) ? 1 : 0;
+  }
+  return VBX_OK;
+}
+
+int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, const uint32_t* words,
+                           const uint8_t* has_data) {
+  if (!ctx || (n && (!idx || !words))) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return VBX_OK;
+  int rc = upload_idx(ctx, idx, n);
+  if (rc) return rc;
+  if (layer == VBX_LAYER_ESDF) {
+    rc = esdf_ensure(ctx);
+    if (rc) return rc;
+  }
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  const size_t wpb = (size_t)m.nvox * (layer == VBX_LAYER_TSDF ? 3 : 2);
+  HIP_TRY(ctx->b_keys0.ensure(n * wpb * 4));
+  HIP_TRY(hipMemcpyAsync(ctx->b_keys0.p, words, n * wpb * 4, hipMemcpyHostToDevice, s));
+  uint8_t* d_hd = nullptr;
+  if (has_data) {
+    HIP_TRY(ctx->b_graze.ensure(n));
+    HIP_TRY(hipMemcpyAsync(ctx->b_graze.p, has_data, n, hipMemcpyHostToDevice, s));
+    d_hd = ctx->b_graze.as<uint8_t>();
+  }
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
+  hipLaunchKernelGGL(k_insert_blocks, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+                     ctx->d_state);
+  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
+                     ctx->b_rank.as<uint32_t>());
+  if (layer == VBX_LAYER_TSDF) {
+    hipLaunchKernelGGL(k_deserialize_tsdf, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
+                       ctx->b_keys0.as<uint32_t>());
+    hipLaunchKernelGGL(k_set_block_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n,
+                       kFlagPublished | kFlagUpdMask, d_hd, kFlagHasData);
+  } else {
+    hipLaunchKernelGGL(k_deserialize_esdf, dim3((unsigned)n), dim3(256), 0, s, m.nvox, ctx->b_edist.as<float>(),
+                       ctx->b_estate.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), ctx->b_keys0.as<uint32_t>());
+    hipLaunchKernelGGL(k_set_block_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n,
+                       kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift), (const uint8_t*)nullptr, 0u);
+  }
   rc = sync_state(ctx);
   if (rc) return rc;
   return check_state_error(ctx);
