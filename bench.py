@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--integrator", default="fast", choices=["fast", "merged", "simple"])
+    ap.add_argument("--esdf", action="store_true",
+                    help="BASELINE configs[3]: EsdfIntegrator::updateFromTsdfLayer(true) after every frame")
+    ap.add_argument("--scene", default="room", choices=["room", "cow"],
+                    help="room = configs[1]/[3] stream; cow = configs[2] Cow-and-Lady-style orbit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -104,11 +108,15 @@ def main():
 
     total = args.warmup + args.steps
     # Synthetic stream: rank r starts its sweep a quarter turn further (its own sensor).
-    frames = [scenes.room_frame((k + 25 * rank) % N_STREAM, N_STREAM) for k in range(min(total, N_STREAM))]
+    if args.scene == "cow":
+        frames = [scenes.cow_and_lady_like_frame((k + 50 * rank) % 200) for k in range(min(total, 200))]
+    else:
+        frames = [scenes.room_frame((k + 25 * rank) % N_STREAM, N_STREAM) for k in range(min(total, N_STREAM))]
     d_frames = []
     for pose, pts, col in frames:
         d_frames.append((pose, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev)))
     n_pts = frames[0][1].shape[0]
+    n_pts_all = [f[1].shape[0] for f in frames]
 
     gm = capi.Map(VOXEL, 16, max_blocks=8192, device=local_rank)
     gm.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -123,12 +131,28 @@ def main():
         sharded = multi_gpu.ShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), multi_gpu.GpuBackend(gm, dev),
                                            rank, world, dist)
 
+    ecfg = capi.esdf_cfg(min_distance_m=TRUNC / 2)  # ros_params.h:136-137
+    esdf_ms = [0.0]
+
     def step(i):
         pose, dp, dc = d_frames[i % len(d_frames)]
+        n_i = n_pts_all[i % len(d_frames)]
         if sharded is None:
-            gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_pts)
+            gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_i)
+            if args.esdf:
+                tt = gm.timing() if timing_on[0] else None
+                cc = gm.counters()
+                gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+                if timing_on[0]:
+                    esdf_ms[0] += gm.timing()["total_ms"]
+                    esdf_cnt.update({k: esdf_cnt.get(k, 0) + v for k, v in gm.counters().items() if k.startswith("esdf")})
+                    last_tsdf[0] = (tt, cc)
         else:
-            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n_pts)
+            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n_i)
+
+    timing_on = [False]
+    esdf_cnt = {}
+    last_tsdf = [None]
 
     def barrier():
         if world > 1:
@@ -138,14 +162,14 @@ def main():
     for i in range(args.warmup):
         step(i)
     gm.enable_timing(True)
+    timing_on[0] = True
     stage = {}
     counters = {}
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
-        t = gm.timing()
-        c = gm.counters()
+        t, c = last_tsdf[0] if (args.esdf and last_tsdf[0]) else (gm.timing(), gm.counters())
         for k, v in t.items():
             stage[k] = stage.get(k, 0.0) + v
         for k, v in c.items():
@@ -158,7 +182,8 @@ def main():
         dt = float(tt.item())
 
     K = args.steps
-    value = world * K * n_pts / dt / 1e6
+    pts_timed = sum(n_pts_all[i % len(d_frames)] for i in range(args.warmup, total))
+    value = world * pts_timed / dt / 1e6
     out = {
         "metric": "Mpoints/s integrated (640x480 frame, 0.05 m voxels) + achieved HBM GB/s",
         "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": K,
@@ -188,6 +213,11 @@ def main():
                            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                            "device_total_ms": round(stage.get("total_ms", 0.0) / K, 4)}
         out["counters_per_step"] = {k: round(v / K, 1) for k, v in counters.items()}
+        if args.esdf:
+            out["esdf"] = {"ms_per_update": round(esdf_ms[0] / K, 4),
+                           "counters_per_update": {k: round(v / K, 1) for k, v in esdf_cnt.items()}}
+        out["config"]["scene"] = args.scene
+        out["config"]["esdf_after_each_frame"] = bool(args.esdf)
         if world == 1 and not args.no_cpu_baseline:
             nf = args.cpu_frames or 40
             out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator)

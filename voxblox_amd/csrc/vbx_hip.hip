@@ -99,6 +99,7 @@ struct DevState {
   uint32_t esdf_raise_any;
   uint32_t esdf_relax_blocks;
   uint32_t act_count[3];
+  uint32_t fold_long_count;
   unsigned long long total_keys;
   unsigned long long voxels_touched;
   unsigned long long rays_cast;
@@ -486,8 +487,53 @@ __device__ inline void tsdf_update(const CastCfg& c, float voxel_size, f3 pg, l3
   W = std_min(c.max_weight, nw);
 }
 
+// Everything of updateTsdfVoxel that does not depend on the voxel's state (tsdf_integrator.cc:
+// 157-183): the projective sdf and the (drop-off / sparsity adjusted) weight of one update.
+__device__ inline void tsdf_update_inputs(const CastCfg& c, float voxel_size, f3 pg, l3 g, float weight,
+                                          float* sdf_out, float* uw_out) {
+  const f3 center = center_point_from_grid_index(g, voxel_size);
+  const f3 a = f3_sub(center, c.origin);
+  const f3 b = f3_sub(pg, c.origin);
+  const float dist_G = f3_norm(b);
+  const float dist_G_V = f3_dot(a, b) / dist_G;
+  const float sdf = dist_G - dist_G_V;
+  float uw = weight;
+  const float eps = voxel_size;
+  if (c.dropoff && sdf < -eps) {
+    uw = weight * (c.trunc + sdf) / (c.trunc - eps);
+    uw = std_max(uw, 0.0f);
+  }
+  if (c.sparsity) {
+    if (fabsf(sdf) < c.trunc) uw *= c.sparsity_factor;
+  }
+  *sdf_out = sdf;
+  *uw_out = uw;
+}
+// The state-dependent rest (tsdf_integrator.cc:188-208).
+__device__ inline void tsdf_update_state(const CastCfg& c, float sdf, float uw, uint32_t color, float& d,
+                                         float& W, uint32_t& col) {
+  const float nw = W + uw;
+  if (nw < 1e-6f) return;
+  const float nsdf = (sdf * uw + d * W) / nw;
+  if (fabsf(sdf) < c.trunc) col = blend_two_colors(col, W, color, uw);
+  d = (nsdf > 0.0f) ? std_min(c.trunc, nsdf) : std_max(-c.trunc, nsdf);
+  W = std_min(c.max_weight, nw);
+}
+
+constexpr uint32_t kFoldShort = 48;  // longer runs go to the wave-cooperative kernel
+
+__device__ inline l3 voxel_of_gid(const MapDev& m, uint32_t gid) {
+  const uint32_t slot = gid / m.nvox;
+  const uint32_t lin = gid - slot * m.nvox;
+  const int lx = lin & (m.vps - 1);
+  const int ly = (lin >> m.vps_log2) & (m.vps - 1);
+  const int lz = lin >> (2 * m.vps_log2);
+  return {(long long)m.blk_idx[3 * slot] * m.vps + lx, (long long)m.blk_idx[3 * slot + 1] * m.vps + ly,
+          (long long)m.blk_idx[3 * slot + 2] * m.vps + lz};
+}
+
 __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
-                       MapDev m, DevState* st) {
+                       MapDev m, uint32_t* long_list, DevState* st) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = (i < n) ? keys[i] : ~0ull;
   const uint32_t gid = (uint32_t)(key >> 32);
@@ -496,24 +542,23 @@ __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, 
   if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched, (unsigned long long)nheads);
   if (!head) return;  // only segment heads fold
 
-  const uint32_t slot = gid / m.nvox;
-  const uint32_t lin = gid - slot * m.nvox;
-  const int lx = lin & (m.vps - 1);
-  const int ly = (lin >> m.vps_log2) & (m.vps - 1);
-  const int lz = lin >> (2 * m.vps_log2);
-  const l3 g{(long long)m.blk_idx[3 * slot] * m.vps + lx,
-             (long long)m.blk_idx[3 * slot + 1] * m.vps + ly,
-             (long long)m.blk_idx[3 * slot + 2] * m.vps + lz};
-
+  const l3 g = voxel_of_gid(m, gid);
   float d = m.dist[gid];
   float W = m.weight[gid];
   uint32_t col = m.rgba[gid];
   size_t j = i;
   uint64_t kj = key;
+  uint32_t count = 0;
   while (true) {
+    if (count == kFoldShort) {  // a long run: hand it to k_fold_long untouched
+      const uint32_t o = atomicAdd(&st->fold_long_count, 1u);
+      long_list[o] = (uint32_t)i;
+      return;
+    }
     const uint32_t o = (uint32_t)(kj & 0xFFFFFFFFu);
     const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
     tsdf_update(c, m.voxel_size, pg, g, tab.rgba[o], tab.w[o], d, W, col);
+    ++count;
     ++j;
     if (j >= n) break;
     kj = keys[j];
@@ -522,6 +567,98 @@ __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, 
   m.dist[gid] = d;
   m.weight[gid] = W;
   m.rgba[gid] = col;
+}
+
+// Long runs (the voxels around the sensor origin collect one update per ray): one wave per run,
+// 64 updates per step.  The state-independent part of the 64 updates (sdf, weight) is computed
+// in parallel; the ordered fold over them is then done by the cheapest exact method:
+//   1. every update is a no-op on the current state (saturated free-space voxel)  -> skip;
+//   2. the distance provably stays where it is (clamped at +-trunc) and no colour changes:
+//      only the weight chain W <- min(max_weight, W + w) is evaluated in order, then all 64
+//      distance updates are verified in parallel against their own W;
+//   3. otherwise the 64 updates are applied in order (operands broadcast lane by lane).
+// All three produce exactly the sequential result of updateTsdfVoxel.
+__global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ keys, size_t n, RayTab tab,
+                                                   CastCfg c, MapDev m, const uint32_t* __restrict__ long_list,
+                                                   DevState* st) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_long = st->fold_long_count;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; seg < n_long; seg += n_waves) {
+    const size_t i0 = long_list[seg];
+    const uint32_t gid = (uint32_t)(keys[i0] >> 32);
+    const l3 g = voxel_of_gid(m, gid);
+    float d = m.dist[gid];
+    float W = m.weight[gid];
+    uint32_t col = m.rgba[gid];
+    for (size_t base = i0;; base += 64) {
+      const size_t i = base + lane;
+      const uint64_t key = (i < n) ? keys[i] : ~0ull;
+      const bool mine = (key != ~0ull) && ((uint32_t)(key >> 32) == gid);
+      const unsigned long long V = __ballot(mine);
+      // keys of one voxel are contiguous: the valid lanes are a prefix
+      const int cnt = (V == ~0ull) ? 64 : (__ffsll((long long)~V) - 1);
+      if (cnt == 0) break;
+      float sdf = 0.f, uw = 0.f;
+      uint32_t color = 0;
+      if (lane < cnt) {
+        const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
+        const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+        tsdf_update_inputs(c, m.voxel_size, pg, g, tab.w[o], &sdf, &uw);
+        color = tab.rgba[o];
+      }
+      const bool inband = fabsf(sdf) < c.trunc;
+      // 1. identity test against the current state
+      bool same = true;
+      if (lane < cnt) {
+        float d1 = d, W1 = W;
+        uint32_t c1 = col;
+        tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
+        same = (__float_as_uint(d1) == __float_as_uint(d)) && (__float_as_uint(W1) == __float_as_uint(W)) && (c1 == col);
+      }
+      if (__all(same)) {
+        if (cnt < 64) break;
+        continue;
+      }
+      // 2. weight chain + parallel verification that d does not move
+      bool done = false;
+      if (!__any(lane < cnt && inband)) {
+        float Wrun = W, Wmine = W;
+        for (int j = 0; j < cnt; ++j) {
+          const float uwj = __shfl(uw, j);
+          if (lane == j) Wmine = Wrun;
+          const float nw = Wrun + uwj;
+          if (!(nw < 1e-6f)) Wrun = std_min(c.max_weight, nw);
+        }
+        bool ok = true;
+        if (lane < cnt) {
+          float d1 = d, W1 = Wmine;
+          uint32_t c1 = col;
+          tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
+          ok = (__float_as_uint(d1) == __float_as_uint(d));
+        }
+        if (__all(ok)) {
+          W = Wrun;
+          done = true;
+        }
+      }
+      // 3. generic ordered application
+      if (!done) {
+        for (int j = 0; j < cnt; ++j) {
+          const float sj = __shfl(sdf, j);
+          const float wj = __shfl(uw, j);
+          const uint32_t cj = (uint32_t)__shfl((int)color, j);
+          tsdf_update_state(c, sj, wj, cj, d, W, col);
+        }
+      }
+      if (cnt < 64) break;
+    }
+    if (lane == 0) {
+      m.dist[gid] = d;
+      m.weight[gid] = W;
+      m.rgba[gid] = col;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1414,7 +1551,7 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long;
   // Fast integrator persistent state
   DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
   uint32_t start_offset = 0;
@@ -1567,8 +1704,17 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
                      std::min(64u, end_bit + 1));
   if (rc) return rc;
   tmark(ctx, 5);
+  // long runs are collected by k_fold and folded wave-cooperatively afterwards (their number is
+  // bounded by total / kFoldShort)
+  HIP_TRY(ctx->b_long.ensure(((size_t)total / kFoldShort + 2) * 4));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->fold_long_count, 0, 4, s));
   hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                     (size_t)total, tab, c, m, ctx->d_state);
+                     (size_t)total, tab, c, m, ctx->b_long.as<uint32_t>(), ctx->d_state);
+  {
+    const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);
+    hipLaunchKernelGGL(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                       (size_t)total, tab, c, m, ctx->b_long.as<uint32_t>(), ctx->d_state);
+  }
   tmark(ctx, 6);
   ctx->counters.voxel_updates = total;
   return VBX_OK;
@@ -2227,7 +2373,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
