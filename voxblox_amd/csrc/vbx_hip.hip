@@ -1243,6 +1243,12 @@ struct EsdfCfgDev {
   float voxel_size;
 };
 
+constexpr int kNbOff[26][3] = {
+    {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+    {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {0, -1, -1}, {0, -1, 1},
+    {0, 1, -1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
+    {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1},
+    {1, 1, -1}, {1, 1, 1}};  // same table, compile-time (unrolled loops)
 __constant__ int c_nb_off[26][3] = {
     {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
     {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {0, -1, -1}, {0, -1, 1},
@@ -1377,7 +1383,9 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
   constexpr int NV = VPS * VPS * VPS;
   __shared__ float s_d[NT];
   __shared__ uint32_t s_s[NT];
-  __shared__ uint8_t s_r[NT];
+  __shared__ uint8_t s_r[NT];     // raise marks (mode 0) / need flags (mode 1): never both
+  __shared__ uint16_t s_q[NV];    // mode 1: dense work queue
+  __shared__ int s_qn;
   __shared__ uint32_t s_nb[27];
   __shared__ int s_flag;
   const uint32_t slot = blockIdx.x;
@@ -1393,6 +1401,7 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
   }
   if (tid == 0) s_flag = 0;
   __syncthreads();
+#pragma unroll 4
   for (int t = tid; t < NT; t += 256) {
     const int tx = t % T, ty = (t / T) % T, tz = t / (T * T);
     const int bx = (tx == 0) ? 0 : (tx == T - 1 ? 2 : 1);
@@ -1417,6 +1426,86 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
 
   const float sq2 = (float)1.4142135623730951, sq3 = (float)1.7320508075688772;
   bool any_change = false;
+
+  // processOpenSet for one voxel (pull form): returns true if the voxel was lowered.
+  auto relax = [&](int t) -> bool {
+    const uint32_t s = s_s[t];
+    if (!(s & kEsdfObserved) || (s & kEsdfFixed)) return false;
+    float d = s_d[t];
+    bool upd = false;
+    int best = -1;
+    // fully unrolled: the 52 LDS reads of one voxel issue back to back
+#pragma unroll
+    for (int i = 0; i < 26; ++i) {
+      const int tv = t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2]);
+      const uint32_t sv = s_s[tv];
+      if (!(sv & kEsdfObserved)) continue;
+      const float dv = s_d[tv];
+      if (dv >= c.max_distance || dv <= -c.max_distance) continue;
+      const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
+      if (dv > 0 && d > 0) {
+        if (dv + dist + c.min_diff < d) { d = dv + dist; best = i; upd = true; }
+      } else if (dv <= 0 && d <= 0) {
+        if (dv - dist - c.min_diff > d) { d = dv - dist; best = i; upd = true; }
+      } else {
+        // sign mismatch (esdf_integrator.cc:459-488).  In the reference this assignment is
+        // gated by |potential - d| > dist and its outcome depends on the pop order of the two
+        // neighbours (libstdc++ unordered_map block order).  The order-free form used here
+        // applies the same candidate whenever it moves the voxel closer to the surface, which
+        // is the outcome of the reference when the opposite-sign neighbour pops first.
+        const float potential = dv - (float)signum(dv) * dist;
+        float cand;
+        if ((float)signum(potential) == d) cand = potential;
+        else cand = (float)signum(d) * dist;
+        if (fabsf(cand) < fabsf(d)) { d = cand; best = i; upd = true; }
+      }
+    }
+    if (upd) {
+      s_d[t] = d;
+      s_s[t] = (s & 0xFFu) | pack_parent(c_nb_off[best][0], c_nb_off[best][1], c_nb_off[best][2]);
+    }
+    return upd;
+  };
+
+  if (mode == 1) {
+    // Worklist relaxation: s_need marks voxels whose neighbourhood changed; every iteration
+    // compacts the marked voxels into a dense queue (so all lanes evaluate real work), relaxes
+    // them, and marks the 26 neighbours of every voxel that moved.  Total evaluations are
+    // proportional to the number of changes, not to iterations x block size.  (A push-based
+    // queue with an atomic visited bitset was measured slower: 3.1 vs 2.2 ms per update.)
+    uint8_t* s_need = s_r;  // the raise marks are not used while lowering
+    for (int t = tid; t < NT; t += 256) s_need[t] = 0;
+    __syncthreads();
+    for (int v = tid; v < NV; v += 256) {
+      const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+      s_need[(lx + 1) + T * ((ly + 1) + T * (lz + 1))] = 1;  // first pass: everything
+    }
+    for (int iter = 0; iter < 64 * VPS; ++iter) {
+      if (tid == 0) s_qn = 0;
+      __syncthreads();
+      for (int v = tid; v < NV; v += 256) {
+        const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+        const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+        if (s_need[t]) {
+          s_need[t] = 0;
+          const uint32_t sv = s_s[t];
+          if ((sv & kEsdfObserved) && !(sv & kEsdfFixed)) s_q[atomicAdd(&s_qn, 1)] = (uint16_t)t;
+        }
+      }
+      __syncthreads();
+      const int qn = s_qn;
+      if (qn == 0) break;
+      for (int q = tid; q < qn; q += 256) {
+        const int t = s_q[q];
+        if (relax(t)) {
+          any_change = true;
+#pragma unroll
+          for (int i = 0; i < 26; ++i) s_need[t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2])] = 1;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   for (int iter = 0; iter < 4 * VPS; ++iter) {
     bool changed = false;
     for (int v = tid; v < NV; v += 256) {
@@ -1435,42 +1524,6 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
           s_d[t] = (float)signum(d) * c.default_distance;
           s_s[t] = s & 0xFFu;
           s_r[t] = 1;
-          changed = true;
-        }
-        continue;
-      }
-      if (mode == 1) {
-        bool upd = false;
-        int best = -1;
-#pragma unroll 1
-        for (int i = 0; i < 26; ++i) {
-          const int tv = t + c_nb_off[i][0] + T * (c_nb_off[i][1] + T * c_nb_off[i][2]);
-          const uint32_t sv = s_s[tv];
-          if (!(sv & kEsdfObserved)) continue;
-          const float dv = s_d[tv];
-          if (dv >= c.max_distance || dv <= -c.max_distance) continue;
-          const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
-          if (dv > 0 && d > 0) {
-            if (dv + dist + c.min_diff < d) { d = dv + dist; best = i; upd = true; }
-          } else if (dv <= 0 && d <= 0) {
-            if (dv - dist - c.min_diff > d) { d = dv - dist; best = i; upd = true; }
-          } else {
-            // sign mismatch (esdf_integrator.cc:459-488).  In the reference this assignment is
-            // gated by |potential - d| > dist and its outcome depends on the pop order of the
-            // two neighbours (libstdc++ unordered_map block order).  The order-free form used
-            // here applies the same candidate whenever it moves the voxel closer to the
-            // surface, which is the outcome of the reference when the opposite-sign neighbour
-            // pops first.
-            const float potential = dv - (float)signum(dv) * dist;
-            float cand;
-            if ((float)signum(potential) == d) cand = potential;
-            else cand = (float)signum(d) * dist;
-            if (fabsf(cand) < fabsf(d)) { d = cand; best = i; upd = true; }
-          }
-        }
-        if (upd) {
-          s_d[t] = d;
-          s_s[t] = (s & 0xFFu) | pack_parent(c_nb_off[best][0], c_nb_off[best][1], c_nb_off[best][2]);
           changed = true;
         }
         continue;
@@ -1507,6 +1560,7 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
     const int more = __syncthreads_or(changed ? 1 : 0);
     if (!more || mode == 2) break;
   }
+  }
   if (any_change) s_flag = 1;
   __syncthreads();
   if (!s_flag) return;
@@ -1516,7 +1570,7 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
     const uint32_t g = slot * NV + v;
     e.dist[g] = s_d[t];
     e.state[g] = s_s[t];
-    e.raised[g] = s_r[t];
+    if (mode == 0) e.raised[g] = s_r[t];
   }
   if (mode != 2) {
     if (tid < 27 && s_nb[tid] != kInvalidSlot) atomicOr(&e.active[s_nb[tid]], 2u | 4u);
