@@ -115,6 +115,13 @@ int vbx_tsdf_integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg,
  * batch == 0, EsdfIntegrator::updateFromTsdfLayerBatch() (:94-102) when batch != 0. */
 int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag);
 
+/* EsdfIntegrator::addNewRobotPosition(position) (esdf_integrator.cc:25-92; caller
+ * esdf_server.cc:219-226): unknown or hallucinated voxels within cfg->clear_sphere_radius become
+ * free, remaining unknown voxels within cfg->occupied_sphere_radius occupied (both
+ * "hallucinated"); ESDF blocks are allocated as needed.  The wavefront work it queues is done by
+ * the next vbx_esdf_update(batch == 0); a batch update discards it with the layer. */
+int vbx_esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const float position[3]);
+
 /* ---- host <-> HBM coherence for the callers that read/modify the Layer directly
  *      (mesher, publishers, removeDistantBlocks, load_map) ---- */
 #define VBX_LAYER_TSDF 0

@@ -102,6 +102,7 @@ def _bind(L):
         "orc_esdf_integrator_destroy": (None, [vp]),
         "orc_esdf_update_from_tsdf_layer": (None, [vp, C.c_int]),
         "orc_esdf_update_from_tsdf_layer_batch": (None, [vp]),
+        "orc_esdf_add_new_robot_position": (None, [vp, f32p]),
         "orc_esdf_stats": (None, [vp, u64p, C.c_int]),
         "orc_num_blocks": (C.c_size_t, [vp, C.c_int]),
         "orc_block_indices": (C.c_size_t, [vp, C.c_int, i32p, C.c_size_t]),
@@ -307,6 +308,10 @@ class OracleEsdfIntegrator:
 
     def update_from_tsdf_layer_batch(self):
         self.L.orc_esdf_update_from_tsdf_layer_batch(self.h)
+
+    def add_new_robot_position(self, position):
+        p = np.ascontiguousarray(position, np.float32)
+        self.L.orc_esdf_add_new_robot_position(self.h, _p(p, C.c_float))
 
     def stats(self, reset=False):
         out = np.zeros(7, np.uint64)

@@ -152,6 +152,9 @@ orc_esdf_integrator* orc_esdf_integrator_create(orc_map* m, const orc_esdf_cfg* 
 void orc_esdf_integrator_destroy(orc_esdf_integrator* it) { delete it; }
 void orc_esdf_update_from_tsdf_layer(orc_esdf_integrator* it, int clear) { it->impl->updateFromTsdfLayer(clear != 0); }
 void orc_esdf_update_from_tsdf_layer_batch(orc_esdf_integrator* it) { it->impl->updateFromTsdfLayerBatch(); }
+void orc_esdf_add_new_robot_position(orc_esdf_integrator* it, const float p[3]) {
+  it->impl->addNewRobotPosition(Point(p[0], p[1], p[2]));
+}
 void orc_esdf_stats(orc_esdf_integrator*, uint64_t out[7], int) { for (int i = 0; i < 7; ++i) out[i] = 0; }
 
 size_t orc_num_blocks(orc_map* m, int layer) {

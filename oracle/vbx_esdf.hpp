@@ -4,8 +4,8 @@
 //   include/voxblox/utils/bucket_queue.h
 //   include/voxblox/utils/neighbor_tools.h, src/utils/neighbor_tools.cc
 //   include/voxblox/integrator/esdf_integrator.h, src/integrator/esdf_integrator.cc
-// addNewRobotPosition (esdf_integrator.cc:25-92) is not restated yet
-// (clear_sphere_for_planning=false by default).
+//   include/voxblox/utils/planning_utils_inl.h:14-61 (sphere voxel lists for
+//   addNewRobotPosition, esdf_integrator.cc:25-92)
 #pragma once
 
 #include <deque>
@@ -151,6 +151,86 @@ class EsdfIntegrator {
     tsdf_blocks.insert(tsdf_blocks.end(), updated_blocks_.begin(), updated_blocks_.end());
     updated_blocks_.clear();
     updateFromTsdfBlocks(tsdf_blocks, false);
+  }
+
+  // planning_utils_inl.h:14-48.  The loop variables are floats stepped by 1.0f.
+  // HierarchicalIndexMap (common.h:97-99) is an unordered_map keyed with AnyIndexHash; its
+  // iteration order decides the ESDF layer's block insertion order and the queue push order,
+  // so the same container with the same hash and insertion sequence is used here.
+  using SphereList = std::unordered_map<Idx3, std::vector<Idx3>, AnyIndexHasher>;
+  void getSphereAroundPoint(const Vec3f& center, float radius, SphereList* out) const {
+    const float voxel_size = voxel_size_;
+    const float voxel_size_inv = static_cast<float>(1.0 / voxel_size_);
+    const int voxels_per_side = static_cast<int>(voxels_per_side_);
+    const LIdx3 center_index = gridIndexFromPointL(center, voxel_size_inv);
+    const float radius_in_voxels = radius / voxel_size;
+    for (float x = -radius_in_voxels; x <= radius_in_voxels; x++) {
+      for (float y = -radius_in_voxels; y <= radius_in_voxels; y++) {
+        for (float z = -radius_in_voxels; z <= radius_in_voxels; z++) {
+          const Vec3f point_voxel_space{x, y, z};
+          if (norm(point_voxel_space) <= radius_in_voxels) {
+            const LIdx3 g{static_cast<int64_t>(std::floor(x)) + center_index.x,
+                          static_cast<int64_t>(std::floor(y)) + center_index.y,
+                          static_cast<int64_t>(std::floor(z)) + center_index.z};
+            // common.h:245-255
+            const float vps_inv = static_cast<float>(1.0 / voxels_per_side);
+            const Idx3 block_index = blockIndexFromGlobalVoxelIndex(g, vps_inv);
+            const Idx3 voxel_index = localFromGlobalVoxelIndex(g, voxels_per_side);
+            (*out)[block_index].push_back(voxel_index);
+          }
+        }
+      }
+    }
+  }
+
+  // esdf_integrator.cc:25-92
+  void addNewRobotPosition(const Vec3f& position) {
+    // inner sphere: unknown or hallucinated -> free
+    SphereList inner;
+    getSphereAroundPoint(position, config_.clear_sphere_radius, &inner);
+    for (const auto& kv : inner) esdf_layer_->allocateBlockPtrByIndex(kv.first);  // planning_utils_inl.h:57-60
+    for (const auto& kv : inner) {
+      const Idx3& b = kv.first;
+      auto block_ptr = esdf_layer_->getBlockPtrByIndex(b);
+      for (const Idx3& voxel_index : kv.second) {
+        if (!block_ptr->isValidVoxelIndex(voxel_index)) continue;
+        EsdfVoxel& esdf_voxel = block_ptr->voxels[block_ptr->linearIndex(voxel_index)];
+        if (!esdf_voxel.observed || esdf_voxel.hallucinated) {
+          if (esdf_voxel.hallucinated) {
+            raise_.push(globalVoxelIndexFromBlockAndVoxelIndex(b, voxel_index,
+                                                               static_cast<int>(voxels_per_side_)));
+          }
+          esdf_voxel.distance = config_.default_distance_m;
+          esdf_voxel.observed = true;
+          esdf_voxel.hallucinated = true;
+          esdf_voxel.parent = {0, 0, 0};
+          updated_blocks_.insert(b);
+        }
+      }
+    }
+    // outer sphere: remaining unknown -> occupied
+    SphereList outer;
+    getSphereAroundPoint(position, config_.occupied_sphere_radius, &outer);
+    for (const auto& kv : outer) esdf_layer_->allocateBlockPtrByIndex(kv.first);
+    for (const auto& kv : outer) {
+      const Idx3& b = kv.first;
+      auto block_ptr = esdf_layer_->getBlockPtrByIndex(b);
+      for (const Idx3& voxel_index : kv.second) {
+        if (!block_ptr->isValidVoxelIndex(voxel_index)) continue;
+        EsdfVoxel& esdf_voxel = block_ptr->voxels[block_ptr->linearIndex(voxel_index)];
+        if (!esdf_voxel.observed) {
+          esdf_voxel.distance = -config_.default_distance_m;
+          esdf_voxel.observed = true;
+          esdf_voxel.hallucinated = true;
+          esdf_voxel.parent = {0, 0, 0};
+          updated_blocks_.insert(b);
+        } else if (!esdf_voxel.in_queue) {
+          open_.push(globalVoxelIndexFromBlockAndVoxelIndex(b, voxel_index,
+                                                            static_cast<int>(voxels_per_side_)),
+                     esdf_voxel.distance);
+        }
+      }
+    }
   }
 
   // esdf_integrator.cc:104-122

@@ -175,6 +175,9 @@ void orc_esdf_update_from_tsdf_layer(orc_esdf_integrator* it, int clear_updated_
 void orc_esdf_update_from_tsdf_layer_batch(orc_esdf_integrator* it) {
   it->impl->updateFromTsdfLayerBatch();
 }
+void orc_esdf_add_new_robot_position(orc_esdf_integrator* it, const float p[3]) {
+  it->impl->addNewRobotPosition(Vec3f{p[0], p[1], p[2]});
+}
 void orc_esdf_stats(orc_esdf_integrator* it, uint64_t out[7], int reset) {
   const EsdfStats& s = it->impl->stats;
   out[0] = s.num_lower; out[1] = s.num_raise; out[2] = s.num_new; out[3] = s.raised;

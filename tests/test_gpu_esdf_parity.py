@@ -162,3 +162,94 @@ def test_esdf_default_min_diff_envelope_vs_reference_incremental(oracle):
         nband += int(band.sum())
     assert n > 100000 and nband > 1000
     assert (se / n) ** 0.5 < 1e-2
+
+
+def _check_robot(g, r, exact):
+    assert set(g.keys()) == set(r.keys())
+    n = nh = 0
+    se = 0.0
+    for k in r:
+        gd, gf, gp, gu = g[k]
+        rd, rf, rp, ru = r[k]
+        assert gu == ru, (k, gu, ru)                    # sphere-only blocks never get set_updated()
+        assert np.array_equal(gf & 1, rf & 1), f"observed mask differs in {k}"
+        assert np.array_equal(gf & 2, rf & 2), f"hallucinated mask differs in {k}"
+        if exact:
+            assert np.array_equal(gf & 8, rf & 8), f"fixed mask differs in {k}"
+        else:  # the min_diff_m gate of the fixed-band copy sees slightly different old distances
+            assert int(((gf ^ rf) & 8).astype(bool).sum()) <= 8, f"fixed mask differs in {k}"
+        assert not (gf & 4).any() and not (rf & 4).any()
+        obs = (rf & 1).astype(bool)
+        if exact:
+            bad = gd[obs].view(np.uint32) != rd[obs].view(np.uint32)
+            assert not bad.any(), (f"{int(bad.sum())} distances differ in block {k}: "
+                                   f"max |d|={np.abs(gd[obs] - rd[obs]).max()}")
+        e = (gd[obs] - rd[obs]).astype(np.float64)
+        se += float((e * e).sum())
+        n += int(obs.sum()); nh += int(((rf & 2) != 0).sum())
+    return n, nh, (se / max(n, 1)) ** 0.5
+
+
+def test_esdf_add_new_robot_position_bit_exact(oracle):
+    """addNewRobotPosition (esdf_integrator.cc:25-92) between incremental updates of a fixed TSDF
+    layer: sphere voxel lists, hallucinated free/occupied voxels, ESDF-only blocks, the raise of
+    re-cleared voxels and the re-lowering all match the oracle bit for bit (min_diff_m = 0).
+    The occupied sphere covers every observed voxel, so the reference's wavefront (sources = the
+    voxels it pushed) reaches the same fixed point as the GPU's unrestricted relaxation; with
+    observed voxels outside the sphere the reference stops short at the sphere boundary
+     and only the envelope of the next test applies."""
+    from voxblox_amd import capi
+    frames = _frames(3)
+    sph = dict(clear_sphere_radius=0.6, occupied_sphere_radius=3.8)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(VOXEL, 16)
+    oi = om.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1,
+                                                      max_ray_length_m=3.2))
+    oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0,
+                                            oracle_orderfree_sign_mismatch=1, **sph))
+    gm = capi.Map(VOXEL, 16, max_blocks=4096)
+    gt = capi.tsdf_cfg(default_truncation_distance=TRUNC, max_ray_length_m=3.2)
+    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0, **sph)
+    for pose, pts, col in frames:
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
+    oe.update_from_tsdf_layer_batch()
+    gm.esdf_update(ge, batch=True, clear_updated_flag=False)
+    n_tsdf = gm.num_blocks()
+    p0 = frames[0][0][0]
+    # the repeated position finds its inner sphere hallucinated -> raise; the third is shifted
+    for p in (p0, p0, p0 + np.array([0.1, -0.05, 0.05], np.float32)):
+        oe.add_new_robot_position(p)
+        oe.update_from_tsdf_layer(False)
+        gm.esdf_add_new_robot_position(ge, p)
+        gm.esdf_update(ge, batch=False, clear_updated_flag=False)
+        n, nh, _ = _check_robot(_gpu_esdf(gm), om.esdf_dict(), exact=True)
+    assert nh > 100000 and gm.num_blocks(capi.LAYER_ESDF) > n_tsdf
+    assert gm.num_blocks() == n_tsdf          # the spheres allocate ESDF blocks only
+    _check_parents(_gpu_esdf(gm), VOXEL, 2.0)
+
+
+def test_esdf_robot_position_stream_envelope_vs_reference(oracle):
+    """EsdfServer's loop with clear_sphere_for_planning (esdf_server.cc:219-230): integrate,
+    addNewRobotPosition(T_G_C position), updateFromTsdfLayer(true) — against the reference's own
+    queue order and min_diff_m: masks identical, distances within the reference's 1e-2 rmse."""
+    from voxblox_amd import capi
+    frames = _frames(4)
+    sph = dict(clear_sphere_radius=0.6, occupied_sphere_radius=1.5)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(VOXEL, 16)
+    oi = om.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1))
+    oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, **sph))
+    gm = capi.Map(VOXEL, 16, max_blocks=4096)
+    gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
+    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, **sph)
+    for pose, pts, col in frames:
+        oi.integrate(pose[0], pose[1], pts, col)
+        oe.add_new_robot_position(pose[0])
+        oe.update_from_tsdf_layer(True)
+        gm.integrate(capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
+        gm.esdf_add_new_robot_position(ge, pose[0])
+        gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+    n, nh, rmse = _check_robot(_gpu_esdf(gm), om.esdf_dict(), exact=False)
+    assert n > 100000 and nh > 1000
+    assert rmse < 1e-2, rmse

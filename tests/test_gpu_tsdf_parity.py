@@ -110,3 +110,39 @@ def test_fast_vs_reference_approx_set_envelope(oracle):
     total = st["both"] + st["a_only"] + st["b_only"]
     assert (st["a_only"] + st["b_only"]) <= 0.01 * total, st
     assert st["rmse"] < 2 * 0.05, st
+
+
+def _unique_norm_frame(k):
+    """Frame whose points have pairwise distinct squared norms: "sorted" order is then unique
+    (the reference's std::sort leaves ties unspecified, integrator_utils.cc:24-37)."""
+    pose, pts, col = _small_room(k)
+    sq = pts[:, 0] * pts[:, 0] + (pts[:, 1] * pts[:, 1] + pts[:, 2] * pts[:, 2])  # Eigen's order
+    _, first = np.unique(sq.astype(np.float32), return_index=True)
+    keep = np.sort(first)
+    return pose, np.ascontiguousarray(pts[keep]), np.ascontiguousarray(col[keep])
+
+
+@pytest.mark.parametrize("kind,extra", [("simple", {}), ("merged", {"oracle_merged_sorted_bundles": 1}),
+                                        ("fast", {"oracle_fast_exact_observed_set": 1})])
+def test_sorted_integration_order(oracle, kind, extra):
+    """integration_order_mode = "sorted" (SortedThreadSafeIndex): nearest points first."""
+    frames = [_unique_norm_frame(k) for k in (1, 6)]
+    om, oi, gm = _run(oracle, kind, 0.05, frames, integration_order_mode=1, **extra)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    # and the order matters: mixed order gives a different layer for the order-sensitive fold
+    if kind == "simple":
+        _, _, gm2 = _run(oracle, kind, 0.05, frames)
+        a, b = gm.tsdf_dict(), gm2.tsdf_dict()
+        assert any(not np.array_equal(a[k][0], b[k][0]) for k in a)
+
+
+@pytest.mark.parametrize("n_frames", [2, 3])
+def test_fast_clear_checks_every_n_frames(oracle, n_frames):
+    """clear_checks_every_n_frames > 1: both voxel sets survive n frames (tsdf_integrator.cc:564-569)."""
+    frames = [_small_room(k) for k in (0, 1, 2, 3, 4)]
+    om, oi, gm = _run(oracle, "fast", 0.05, frames, oracle_fast_exact_observed_set=1,
+                      clear_checks_every_n_frames=n_frames)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    # fewer voxels are re-observed than with a per-frame reset
+    _, _, gm1 = _run(oracle, "fast", 0.05, frames, oracle_fast_exact_observed_set=1)
+    assert gm.tsdf_dict().keys() <= gm1.tsdf_dict().keys()

@@ -47,6 +47,8 @@ def _both(kind, frames, voxel=0.1, esdf=None, freespace=False, **cfg):
             e = m.esdf_integrator(ec)
         for pose, pts, col in frames:
             it.integrate(pose[0], pose[1], pts, col, freespace)
+            if e is not None and esdf.get("robot"):
+                e.add_new_robot_position(pose[0])  # esdf_server.cc:224
             if e is not None and esdf.get("mode") == "incremental":
                 e.update_from_tsdf_layer(True)
         if e is not None and esdf.get("mode") == "batch":
@@ -128,6 +130,19 @@ def test_esdf_batch_and_variants_bit_identical():
 def test_esdf_full_euclidean_incremental():
     a, b = _both("merged", _frames(3), esdf=dict(mode="incremental", cfg=dict(full_euclidean_distance=1)))
     _same_esdf(a, b)
+
+
+def test_esdf_add_new_robot_position_bit_identical():
+    """addNewRobotPosition (clear sphere + occupied sphere) before every incremental update, as
+    EsdfServer does with clear_sphere_for_planning (esdf_server.cc:219-226)."""
+    for cfg in (dict(clear_sphere_radius=0.6, occupied_sphere_radius=1.6),
+                dict(clear_sphere_radius=0.75, occupied_sphere_radius=1.25, min_diff_m=0.0)):
+        a, b = _both("merged", _frames(4), esdf=dict(mode="incremental", robot=True, cfg=cfg))
+        _same_esdf(a, b)
+        n_tsdf, n_esdf = len(a.block_indices(0)), len(a.block_indices(1))
+        assert n_esdf > n_tsdf  # the spheres allocate ESDF blocks the TSDF layer does not have
+        d, f, p, u = a.esdf_block(a.block_indices(1)[0])
+        assert f.any()
 
 
 def test_helpers_bit_identical():

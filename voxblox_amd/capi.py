@@ -21,7 +21,7 @@ UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
 EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
-    "vbx_esdf_update", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
+    "vbx_esdf_update", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
 
@@ -105,6 +105,7 @@ def lib():
         "vbx_tsdf_integrate_device": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, vp, vp,
                                                 C.c_size_t, C.c_int]),
         "vbx_esdf_update": (C.c_int, [vp, C.POINTER(EsdfCfg), C.c_int, C.c_int]),
+        "vbx_esdf_add_new_robot_position": (C.c_int, [vp, C.POINTER(EsdfCfg), f32p]),
         "vbx_num_blocks": (C.c_int, [vp, C.c_int, szp]),
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),
@@ -211,6 +212,11 @@ class Map:
 
     def esdf_update(self, cfg, batch=False, clear_updated_flag=True):
         self._chk(self.L.vbx_esdf_update(self.h, C.byref(cfg), int(batch), int(clear_updated_flag)))
+
+    def esdf_add_new_robot_position(self, cfg, position):
+        """EsdfIntegrator::addNewRobotPosition (esdf_integrator.cc:25-92)."""
+        p = np.ascontiguousarray(position, np.float32)
+        self._chk(self.L.vbx_esdf_add_new_robot_position(self.h, C.byref(cfg), p.ctypes.data_as(C.POINTER(C.c_float))))
 
     def num_blocks(self, layer=LAYER_TSDF):
         n = C.c_size_t(0)

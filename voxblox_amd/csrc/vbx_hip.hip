@@ -85,6 +85,8 @@ constexpr uint32_t kFlagHasData = 0x200;    // Block::has_data_
 constexpr uint32_t kFlagNewThisCall = 0x400;
 constexpr uint32_t kFlagEsdfAlloc = 0x1000;   // block exists in Layer<EsdfVoxel>
 constexpr uint32_t kFlagEsdfUpdShift = 4;     // ESDF block's Update bits live in bits 4..6
+constexpr uint32_t kFlagEsdfPendClassify = 0x2000;  // EsdfIntegrator::updated_blocks_ member (esdf_integrator.cc:54,80)
+constexpr uint32_t kFlagEsdfPendOpen = 0x4000;      // holds voxels pushed to open_ by addNewRobotPosition (:84)
 
 // Device-resident scalar state, read back at the per-call sync points.
 struct DevState {
@@ -308,12 +310,28 @@ __device__ inline float voxel_weight(const CastCfg& c, f3 pc) {
   return 0.0f;
 }
 
-__global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __restrict__ rgba,
-                              size_t n, Pose T, CastCfg c, int freespace, RayTab tab,
-                              float* pcx, float* pcy, float* pcz) {
+// SortedThreadSafeIndex (integrator_utils.cc:24-37): visiting order = ascending squared norm.
+// key = float bits of point_C.squaredNorm() (non-negative, so they order like the floats) with
+// the point index below it: a stable order where the reference's std::sort leaves ties
+// unspecified.
+__global__ void k_sorted_keys(const float* __restrict__ pts, size_t n, uint64_t* keys) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const size_t s = mixed_index_inverse(p, n);
+  const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+  keys[p] = ((uint64_t)__float_as_uint(f3_sqnorm(pc)) << 32) | (uint64_t)p;
+}
+__global__ void k_sorted_inverse(const uint64_t* __restrict__ keys, size_t n, uint32_t* s_of_p) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  s_of_p[(uint32_t)(keys[s] & 0xFFFFFFFFu)] = (uint32_t)s;
+}
+
+__global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __restrict__ rgba,
+                              size_t n, Pose T, CastCfg c, int freespace, RayTab tab,
+                              float* pcx, float* pcy, float* pcz, const uint32_t* __restrict__ s_of_p) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t s = s_of_p ? (size_t)s_of_p[p] : mixed_index_inverse(p, n);
   const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
   bool clearing = false;
   const bool valid = point_valid(c, pc, freespace != 0, &clearing);
@@ -914,6 +932,8 @@ struct SweepArgs {
   int s_bits;
   int max_consecutive;
   uint32_t* TL; uint32_t* TH; uint32_t* U;
+  const uint32_t* obs;      // voxels observed in earlier frames since the last reset (or null)
+  uint32_t obs_epoch;
   int init;                 // 1: first pass (publish full-path possible claims, no reads)
   int l_only;               // 1: only tighten the lower bounds (TH and the possible claims stay)
 };
@@ -944,6 +964,7 @@ __device__ inline bool sweep_ray(const SweepArgs& a, bool ray_ok, uint32_t r, in
     if (gid != 0xFFFFFFFFu && !a.init) {
       const uint32_t c1 = __hip_atomic_load(&a.cl[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pL = ((c1 >> a.s_bits) == a.tag_cl) && ((c1 & smask) < r);
+      if (!pL && a.obs) pL = (a.obs[gid] == a.obs_epoch);  // seen in an earlier frame of this epoch
       pH = pL;
       if (!pH) {
         const uint32_t c2 = kCoherentReads
@@ -1027,6 +1048,21 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
   if (blockIdx.x == 0 && threadIdx.x == 0) st->act_count[(a.cnt_out + 1) % 3] = 0;
   const bool open = sweep_ray<G, false>(a, ray_ok, r, grp, gl);
   if (a.list_out) append_open(open, r, a.list_out, &st->act_count[a.cnt_out]);
+}
+
+// clear_checks_every_n_frames > 1: the observed-voxel set outlives the frame, so every voxel a
+// ray probed (k < T[r], the terminating probe included — it was inserted too,
+// tsdf_integrator.cc:470-478) is stamped with the current epoch.  16 lanes per ray.
+__global__ void k_fast_mark_observed(const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox,
+                                     const uint32_t* __restrict__ T, uint32_t R, uint32_t* obs, uint32_t epoch) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = t >> 4;
+  if (r >= R) return;
+  const uint32_t beg = off[r], len = T[r];
+  for (uint32_t k = t & 15u; k < len; k += 16) {
+    const uint32_t gid = vox[beg + k];
+    if (gid != 0xFFFFFFFFu && obs[gid] != epoch) obs[gid] = epoch;
+  }
 }
 
 // Emit the ordered update keys of the voxels each ray reaches (k < U[r]) straight from the
@@ -1209,6 +1245,13 @@ __global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const
   if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) publish_block(m, slot, st);
 }
 
+// Block::updated().reset(bits) on every block of one layer
+__global__ void k_clear_update_bits(MapDev m, uint32_t n_slots, uint32_t need, uint32_t bits) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint32_t f = m.blk_flags[s];
+  if ((f & need) && (f & bits)) m.blk_flags[s] = f & ~bits;
+}
 __global__ void k_reset_tsdf_flags(MapDev m, uint32_t n_slots) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
@@ -1276,12 +1319,13 @@ __global__ void k_esdf_classify(MapDev m, EsdfDev e, EsdfCfgDev c, int increment
   const uint32_t slot = blockIdx.x;
   const uint32_t flags = m.blk_flags[slot];
   if (!(flags & kFlagPublished)) return;
-  if (incremental && !(flags & 4u)) return;  // Update::kEsdf
+  // Update::kEsdf, or a member of updated_blocks_ (esdf_integrator.cc:107-108)
+  if (incremental && !(flags & 4u) && !(e.active[slot] & 16u)) return;
   const uint32_t lin = blockIdx.y * blockDim.x + threadIdx.x;
   if (lin >= m.nvox) return;
   if (lin == 0) {
     atomicOr(&m.blk_flags[slot], kFlagEsdfAlloc | (1u << kFlagEsdfUpdShift));  // set_updated(true): kMap only
-    e.active[slot] |= 8u;  // processed by this update
+    atomicOr(&e.active[slot], 8u);  // processed by this update
     atomicAdd(&st->esdf_blocks, 1u);
   }
   const uint32_t gid = slot * m.nvox + lin;
@@ -1348,6 +1392,70 @@ __global__ void k_esdf_classify(MapDev m, EsdfDev e, EsdfCfgDev c, int increment
     e.raised[gid] = 1;
     st->esdf_raise_any = 1;
   }
+}
+
+// ---------------------------------------------------------------------------
+// EsdfIntegrator::addNewRobotPosition, esdf_integrator.cc:25-92, over the sphere voxel lists of
+// utils::getSphereAroundPoint (planning_utils_inl.h:14-48).  `xs` holds the reference's float
+// loop variable (x = -r; x <= r; x++) computed on the host with the same increments; one thread
+// per (i,j,k) of the n^3 cube around the centre voxel.
+// ---------------------------------------------------------------------------
+struct SphereDev {
+  const float* xs;
+  int n;
+  float r;      // radius in voxels
+  l3 center;    // getGridIndexFromPoint<GlobalIndex>(center, voxel_size_inv)
+};
+__device__ inline bool sphere_voxel(const SphereDev& sp, const MapDev& m, size_t t, uint64_t* key, uint32_t* lin) {
+  const size_t n = (size_t)sp.n;
+  if (t >= n * n * n) return false;
+  const int k = (int)(t % n), j = (int)((t / n) % n), i = (int)(t / (n * n));
+  const f3 pv{sp.xs[i], sp.xs[j], sp.xs[k]};
+  if (!(f3_norm(pv) <= sp.r)) return false;
+  const l3 g{(int64_t)floorf(pv.x) + sp.center.x, (int64_t)floorf(pv.y) + sp.center.y,
+             (int64_t)floorf(pv.z) + sp.center.z};
+  const i3 b = block_index_from_global(g, m.vps_inv);  // common.h:245-255
+  const i3 v = local_from_global(g, (int)m.vps);
+  *key = pack_block_key(b.x, b.y, b.z);
+  *lin = (uint32_t)v.x + m.vps * ((uint32_t)v.y + (uint32_t)v.z * m.vps);
+  return true;
+}
+// getAndAllocateSphereAroundPoint (planning_utils_inl.h:50-61): every block holding a sphere voxel
+__global__ void k_sphere_mark_blocks(MapDev m, SphereDev sp, uint32_t* new_list, DevState* st) {
+  uint64_t key;
+  uint32_t lin;
+  if (!sphere_voxel(sp, m, (size_t)blockIdx.x * blockDim.x + threadIdx.x, &key, &lin)) return;
+  map_insert_key(m, key, new_list, st);
+}
+// mode 0: inner sphere (unknown or hallucinated -> free); mode 1: outer sphere (unknown ->
+// occupied, known -> open_).  Queue pushes become marks that the next update consumes.
+__global__ void k_sphere_apply(MapDev m, EsdfDev e, SphereDev sp, float default_distance, int mode) {
+  uint64_t key;
+  uint32_t lin;
+  if (!sphere_voxel(sp, m, (size_t)blockIdx.x * blockDim.x + threadIdx.x, &key, &lin)) return;
+  const uint32_t slot = map_find(m, key);
+  if (slot == kInvalidSlot) return;  // pool exhausted: reported through DevState::error
+  const uint32_t gid = slot * m.nvox + lin;
+  uint32_t want = kFlagEsdfAlloc;
+  const uint32_t es = e.state[gid];
+  if (mode == 0) {
+    if (!(es & kEsdfObserved) || (es & kEsdfHallucinated)) {
+      if (es & kEsdfHallucinated) e.raised[gid] = 1;  // raise_.push
+      e.dist[gid] = default_distance;
+      e.state[gid] = (es & 0xFFu) | kEsdfObserved | kEsdfHallucinated;  // parent.setZero()
+      want |= kFlagEsdfPendClassify;
+    }
+  } else {
+    if (!(es & kEsdfObserved)) {
+      e.dist[gid] = -default_distance;
+      e.state[gid] = (es & 0xFFu) | kEsdfObserved | kEsdfHallucinated;
+      want |= kFlagEsdfPendClassify;
+    } else {
+      want |= kFlagEsdfPendOpen;  // open_.push(global_index, distance) — in_queue stays clear (:81-85)
+    }
+  }
+  const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((cur & want) != want) atomicOr(&m.blk_flags[slot], want);
 }
 
 // active(cur) = every block processed by this update and its 26 neighbours.
@@ -1605,7 +1713,8 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1;
+  uint32_t obs_epoch = 1;
   // Fast integrator persistent state
   DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
   uint32_t start_offset = 0;
@@ -1616,6 +1725,7 @@ struct vbx_ctx {
   // ESDF layer (allocated on first use)
   DBuf b_edist, b_estate, b_eraised, b_eactive;
   bool esdf_init = false;
+  bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
   uint32_t own_tag = 0;  // descending
   int own_s_bits = 0;
 
@@ -1749,6 +1859,24 @@ CastCfg make_cast_cfg(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float pos[3])
   return c;
 }
 
+
+// Visiting order of the points: nullptr = MixedThreadSafeIndex (closed form on the device), else
+// a device array s_of_p for "sorted" (integration_order_mode, tsdf_integrator.h:72-74).
+int visiting_order(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float* d_pts, size_t n, const uint32_t** order) {
+  *order = nullptr;
+  if (cfg->integration_order_mode == 0) return VBX_OK;
+  HIP_TRY(ctx->b_keys0.ensure(n * 8));
+  HIP_TRY(ctx->b_keys1.ensure(n * 8));
+  HIP_TRY(ctx->b_order.ensure(n * 4));
+  hipLaunchKernelGGL(k_sorted_keys, grid_for(n), dim3(256), 0, ctx->stream, d_pts, n, ctx->b_keys0.as<uint64_t>());
+  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), n, 0, 64);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sorted_inverse, grid_for(n), dim3(256), 0, ctx->stream, ctx->b_keys1.as<uint64_t>(), n,
+                     ctx->b_order.as<uint32_t>());
+  *order = ctx->b_order.as<uint32_t>();
+  return VBX_OK;
+}
+
 // Order the emitted (voxel, order) keys and fold them per voxel (keys in b_keys0).
 int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t total) {
   MapDev& m = ctx->map;
@@ -1820,12 +1948,17 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
 int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
                      const uint32_t* d_rgba, size_t n, int freespace) {
   CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  const uint32_t* order = nullptr;
+  {
+    int orc_ = visiting_order(ctx, cfg, d_pts, n, &order);
+    if (orc_) return orc_;
+  }
   int rc = ensure_tab(ctx, false, n, false);
   if (rc) return rc;
   RayTab tab = make_tab(ctx, false, (uint32_t)n);
   tab.bkey = nullptr;
   hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
-                     freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, order);
   tmark(ctx, 1);
   return march_and_fold(ctx, tab, c, /*from_origin=*/true, nullptr, false, nullptr, 0);
 }
@@ -1833,6 +1966,11 @@ int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
 int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
                      const uint32_t* d_rgba, size_t n, int freespace) {
   CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  const uint32_t* order = nullptr;
+  {
+    int orc_ = visiting_order(ctx, cfg, d_pts, n, &order);
+    if (orc_) return orc_;
+  }
   hipStream_t s = ctx->stream;
   int rc = ensure_tab(ctx, false, n, false);
   if (rc) return rc;
@@ -1840,7 +1978,7 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
   hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
-                     pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>());
+                     pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), order);
   // bundleRays (tsdf_integrator.cc:340-371): group points by endpoint voxel.  A stable sort
   // of (key, s) keeps each bundle's points in visiting order.
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
@@ -1878,11 +2016,12 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
 
 int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
                    const uint32_t* d_rgba, size_t n, int freespace) {
-  if (cfg->clear_checks_every_n_frames != 1) {
-    ctx->fail("Fast integrator: clear_checks_every_n_frames != 1 is not supported yet");
-    return VBX_ERR_UNSUPPORTED;
-  }
   CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  const uint32_t* order = nullptr;
+  {
+    int orc_ = visiting_order(ctx, cfg, d_pts, n, &order);
+    if (orc_) return orc_;
+  }
   hipStream_t s = ctx->stream;
   MapDev& m = ctx->map;
   constexpr uint32_t kSetSize = (1u << 20) + 10000u;
@@ -1896,6 +2035,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   // tsdf_integrator.cc:564-569 + ApproxHashSet::resetApproxSet (approx_hash_array.h:156-169)
   if ((++ctx->reset_counter) >= cfg->clear_checks_every_n_frames) {
     ctx->reset_counter = 0;
+    ++ctx->obs_epoch;  // voxel_observed set cleared (exact-set form of resetApproxSet)
     if (++ctx->start_offset >= 10000u) {
       HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
       ctx->start_offset = 0;
@@ -1908,7 +2048,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
   hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
-                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order);
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
   hipLaunchKernelGGL(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,
@@ -1987,6 +2127,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     rc = reset_tags();
     if (rc) return rc;
   }
+  const bool keep_observed = cfg->clear_checks_every_n_frames > 1;
+  if (keep_observed && ctx->b_obs.cap < nvox_total * 4) {
+    HIP_TRY(ctx->b_obs.ensure(nvox_total * 4));
+    HIP_TRY(hipMemsetAsync(ctx->b_obs.p, 0, nvox_total * 4, s));
+  }
   HIP_TRY(ctx->b_T.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_TH.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_U.ensure((size_t)(R + 1) * 4));
@@ -2006,6 +2151,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     sa.TL = ctx->b_T.as<uint32_t>();
     sa.TH = ctx->b_TH.as<uint32_t>();
     sa.U = ctx->b_U.as<uint32_t>();
+    sa.obs = keep_observed ? ctx->b_obs.as<uint32_t>() : nullptr;
+    sa.obs_epoch = ctx->obs_epoch;
     // sweep 0: publish the full-path possible claims (TH = path length);
     // sweep 1: lower bounds only (TH cannot move while there are no certain claims);
     // sweeps 2..: both bounds, open rays only.  (A persistent tail kernel with grid barriers
@@ -2071,6 +2218,10 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   };
   rc = run_solver();
   if (rc) return rc;
+  if (keep_observed)
+    hipLaunchKernelGGL(k_fast_mark_observed, grid_for((size_t)R * 16), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
+                       ctx->b_vox.as<uint32_t>(), ctx->b_T.as<uint32_t>(), R, ctx->b_obs.as<uint32_t>(),
+                       ctx->obs_epoch);
   uint32_t total = 0;
   // offsets of the keys each ray emits
   rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
@@ -2101,9 +2252,9 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
     ctx->fail("vbx_tsdf_integrate: too many points");
     return VBX_ERR_INVALID;
   }
-  if (cfg->integration_order_mode != 0) {
-    ctx->fail("integration_order_mode 'sorted' is not supported yet");
-    return VBX_ERR_UNSUPPORTED;
+  if (cfg->integration_order_mode != 0 && cfg->integration_order_mode != 1) {
+    ctx->fail("Unknown integration order mode");  // integrator_utils.cc:12
+    return VBX_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
   ctx->counters = vbx_counters{};
@@ -2157,8 +2308,14 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
 __global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int drop_layer) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
-  e.active[s] = 0;
-  if (drop_layer) m.blk_flags[s] &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+  // blocks addNewRobotPosition left work in: 8 = take part in this update (their voxels sit in
+  // open_/raise_), 16 = also re-run the TSDF classification on them
+  const uint32_t f = m.blk_flags[s];
+  const uint32_t pend = f & (kFlagEsdfPendClassify | kFlagEsdfPendOpen);
+  e.active[s] = (pend && !drop_layer) ? (8u | ((pend & kFlagEsdfPendClassify) ? 16u : 0u)) : 0u;
+  uint32_t nf = f & ~(kFlagEsdfPendClassify | kFlagEsdfPendOpen);
+  if (drop_layer) nf &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+  if (nf != f) m.blk_flags[s] = nf;
 }
 __global__ void k_esdf_clear_tsdf_bit(MapDev m, EsdfDev e, uint32_t n_slots) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2238,7 +2395,11 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
     HIP_TRY(hipMemsetAsync(e.dist, 0, nv * 4, s));
     HIP_TRY(hipMemsetAsync(e.state, 0, nv * 4, s));
   }
-  HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
+  // `raised` is clear between updates except for the marks addNewRobotPosition left (a batch
+  // update drops those with the layer)
+  if (batch) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
+  const bool robot_pending = ctx->esdf_robot_pending && !batch;
+  ctx->esdf_robot_pending = false;
   hipLaunchKernelGGL(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0);
   HIP_TRY(hipMemsetAsync(&ctx->d_state->esdf_blocks, 0, 12, s));
   hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
@@ -2253,8 +2414,8 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   // of phase 1 (see DESIGN.md §ESDF for why the relaxation itself uses strict improvement).
   EsdfCfgDev cr = c;
   cr.min_diff = 0.0f;
-  if (ctx->h_state.esdf_blocks) {
-    if (ctx->h_state.esdf_raise_any) {
+  if (ctx->h_state.esdf_blocks || robot_pending) {
+    if (ctx->h_state.esdf_raise_any || robot_pending) {
       rc = esdf_phase<VPS>(ctx, e, cr, 0, used, &sweeps);
       if (rc) return rc;
       hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
@@ -2266,6 +2427,7 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
     rc = esdf_phase<VPS>(ctx, e, cr, 2, used, &sweeps);
     if (rc) return rc;
     tmark(ctx, 6);
+    if (ctx->h_state.esdf_raise_any || robot_pending) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
   }
   if (clear_updated_flag && !batch)
     hipLaunchKernelGGL(k_esdf_clear_tsdf_bit, grid_for(used), dim3(256), 0, s, m, e, used);
@@ -2285,6 +2447,51 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
     if (ctx->ev_hit[6]) { (void)hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[6]); o.fold_ms = t; }   // lower
   }
   return VBX_OK;
+}
+
+// EsdfIntegrator::addNewRobotPosition (esdf_integrator.cc:25-92).
+int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const float position[3]) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  int rc = esdf_ensure(ctx);
+  if (rc) return rc;
+  EsdfDev e = esdf_dev(ctx);
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
+  const float radii[2] = {cfg->clear_sphere_radius, cfg->occupied_sphere_radius};
+  for (int pass = 0; pass < 2; ++pass) {
+    SphereDev sp;
+    // planning_utils_inl.h:18-26: the float loop variable, stepped exactly like the reference's
+    sp.r = radii[pass] / m.voxel_size;
+    std::vector<float> xs;
+    for (float x = -sp.r; x <= sp.r; x++) {
+      xs.push_back(x);
+      if (xs.size() > 2048) {
+        ctx->fail("addNewRobotPosition: sphere radius of more than 1024 voxels");
+        return VBX_ERR_INVALID;
+      }
+    }
+    if (xs.empty()) continue;  // negative / NaN radius: empty list
+    sp.n = (int)xs.size();
+    sp.center = grid_index_from_point(f3{position[0], position[1], position[2]}, m.voxel_size_inv);
+    DBuf& bx = pass ? ctx->b_sphere1 : ctx->b_sphere0;
+    HIP_TRY(bx.ensure(xs.size() * 4));
+    HIP_TRY(hipMemcpyAsync(bx.p, xs.data(), xs.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // xs is a stack-lifetime staging buffer
+    sp.xs = bx.as<float>();
+    const size_t cube = (size_t)sp.n * sp.n * sp.n;
+    hipLaunchKernelGGL(k_sphere_mark_blocks, grid_for(cube), dim3(256), 0, s, m, sp, ctx->b_newlist.as<uint32_t>(),
+                       ctx->d_state);
+    hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+                       ctx->d_state);
+    hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    hipLaunchKernelGGL(k_sphere_apply, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, pass);
+  }
+  ctx->esdf_robot_pending = true;
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  return check_state_error(ctx);
 }
 
 int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
@@ -2427,7 +2634,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
@@ -2472,6 +2679,11 @@ int vbx_tsdf_integrate(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const fl
 int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
   if (!ctx || !cfg) return VBX_ERR_INVALID;
   return esdf_update(ctx, cfg, batch, clear_updated_flag);
+}
+
+int vbx_esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const float position[3]) {
+  if (!ctx || !cfg || !position) return VBX_ERR_INVALID;
+  return esdf_add_new_robot_position(ctx, cfg, position);
 }
 
 // ---- block listing / transfer --------------------------------------------------------
@@ -2764,16 +2976,19 @@ int vbx_clear(vbx_ctx* ctx, int layer) {
 
 int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask) {
   if (!ctx) return VBX_ERR_INVALID;
-  std::vector<std::pair<uint64_t, uint32_t>> v;
-  int rc = list_blocks(ctx, layer, 0, &v);
-  if (rc) return rc;
-  for (const auto& kv : v) {
-    uint32_t f;
-    HIP_TRY(hipMemcpy(&f, ctx->map.blk_flags + kv.second, 4, hipMemcpyDeviceToHost));
-    if (layer == VBX_LAYER_ESDF) f &= ~(((uint32_t)update_mask & kFlagUpdMask) << kFlagEsdfUpdShift);
-    else f &= ~((uint32_t)update_mask & kFlagUpdMask);
-    HIP_TRY(hipMemcpy(ctx->map.blk_flags + kv.second, &f, 4, hipMemcpyHostToDevice));
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+    ctx->fail("unknown layer %d", layer);
+    return VBX_ERR_INVALID;
   }
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  if (used == 0) return VBX_OK;
+  const uint32_t bits = (layer == VBX_LAYER_ESDF) ? (((uint32_t)update_mask & kFlagUpdMask) << kFlagEsdfUpdShift)
+                                                  : ((uint32_t)update_mask & kFlagUpdMask);
+  hipLaunchKernelGGL(k_clear_update_bits, grid_for(used), dim3(256), 0, ctx->stream, ctx->map, used,
+                     layer == VBX_LAYER_ESDF ? kFlagEsdfAlloc : kFlagPublished, bits);
   return VBX_OK;
 }
 

@@ -350,6 +350,12 @@ class EsdfIntegrator {  // esdf_integrator.h:24-179
   }
   void updateFromTsdfLayer(bool clear_updated_flag) { run(false, clear_updated_flag); }  // esdf_integrator.cc:104-122
   void updateFromTsdfLayerBatch() { run(true, false); }                                   // esdf_integrator.cc:94-102
+  void addNewRobotPosition(const Point& position) {                                       // esdf_integrator.cc:25-92
+    const vbx_esdf_cfg c = toC();
+    const float p[3] = {position.x, position.y, position.z};
+    const DeviceMap& m = *tsdf_layer_->map();
+    m.check(vbx_esdf_add_new_robot_position(m.ctx(), &c, p), "vbx_esdf_add_new_robot_position");
+  }
   float getEsdfMaxDistance() const { return config_.max_distance_m; }
   void setEsdfMaxDistance(float max_distance) {  // esdf_integrator.h:139-144
     config_.max_distance_m = max_distance;
@@ -359,7 +365,7 @@ class EsdfIntegrator {  // esdf_integrator.h:24-179
   void setFullEuclidean(bool full_euclidean) { config_.full_euclidean_distance = full_euclidean; }
 
  private:
-  void run(bool batch, bool clear_updated_flag) {
+  vbx_esdf_cfg toC() const {
     vbx_esdf_cfg c;
     vbx_esdf_cfg_default(&c);
     c.full_euclidean_distance = config_.full_euclidean_distance;
@@ -373,6 +379,10 @@ class EsdfIntegrator {  // esdf_integrator.h:24-179
     c.add_occupied_crust = config_.add_occupied_crust;
     c.clear_sphere_radius = config_.clear_sphere_radius;
     c.occupied_sphere_radius = config_.occupied_sphere_radius;
+    return c;
+  }
+  void run(bool batch, bool clear_updated_flag) {
+    const vbx_esdf_cfg c = toC();
     const DeviceMap& m = *tsdf_layer_->map();
     m.check(vbx_esdf_update(m.ctx(), &c, batch ? 1 : 0, clear_updated_flag ? 1 : 0), "vbx_esdf_update");
   }

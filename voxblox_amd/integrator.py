@@ -97,3 +97,6 @@ class EsdfIntegrator:
 
     def updateFromTsdfLayerBatch(self):
         self.map_.esdf_update(self.config_, batch=True, clear_updated_flag=False)
+
+    def addNewRobotPosition(self, position):
+        self.map_.esdf_add_new_robot_position(self.config_, position)
