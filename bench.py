@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--scene", default="room", choices=["room", "cow"],
                     help="room = configs[1]/[3] stream; cow = configs[2] Cow-and-Lady-style orbit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mirror-frames", type=int, default=8,
+                    help="extra untimed-for-`value` frames that also mirror the touched blocks to the host "
+                         "(vbx_blocks_updated + vbx_blocks_download + vbx_clear_updated); 0 = skip")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     return ap.parse_args()
 
@@ -181,6 +184,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # Host-mirror cost, outside the timed region: what a caller that keeps a
+    # host Layer coherent pays per frame on top of the integration.
+    mirror = None
+    if sharded is None and args.mirror_frames > 0 and rank == 0:
+        timing_on[0] = False
+        staging = gm.pinned_voxels(2048)   # page-locked, reused every frame (vbx_host_alloc)
+        gm.clear_updated(capi.UPDATE_MAP)
+        torch.cuda.synchronize()
+        nb = 0
+        nbytes = 0
+        t_int = 0.0
+        t_mir = 0.0
+        for j in range(args.mirror_frames):
+            ta = time.perf_counter()
+            step(total + j)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            upd = gm.blocks_updated(capi.UPDATE_MAP)
+            vox, bits, hd = gm.blocks_download(upd, out=staging)
+            gm.clear_updated(capi.UPDATE_MAP)
+            tc = time.perf_counter()
+            t_int += tb - ta
+            t_mir += tc - tb
+            nb += len(upd)
+            nbytes += vox.nbytes
+        M = args.mirror_frames
+        mirror = {"frames": M, "blocks_per_frame": round(nb / M, 1), "MB_per_frame": round(nbytes / M / 1e6, 3),
+                  "integrate_ms": round(t_int / M * 1e3, 4), "mirror_ms": round(t_mir / M * 1e3, 4),
+                  "note": "mirror = list updated blocks + AoS pack kernel + one D2H copy into page-locked staging + clear kMap bits"}
+
     K = args.steps
     pts_timed = sum(n_pts_all[i % len(d_frames)] for i in range(args.warmup, total))
     value = world * pts_timed / dt / 1e6
@@ -216,6 +249,8 @@ def main():
         if args.esdf:
             out["esdf"] = {"ms_per_update": round(esdf_ms[0] / K, 4),
                            "counters_per_update": {k: round(v / K, 1) for k, v in esdf_cnt.items()}}
+        if mirror:
+            out["host_mirror"] = mirror
         out["config"]["scene"] = args.scene
         out["config"]["esdf_after_each_frame"] = bool(args.esdf)
         if world == 1 and not args.no_cpu_baseline:

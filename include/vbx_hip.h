@@ -144,6 +144,15 @@ int vbx_blocks_updated(vbx_ctx* ctx, int layer, int update_mask, int32_t* idx_xy
  * VBX_ERR_INVALID if the block is not allocated. */
 int vbx_block_download(vbx_ctx* ctx, int layer, const int32_t idx[3], void* aos_voxels,
                        uint8_t* updated_bits, uint8_t* has_data);
+/* The same for n blocks in one pack kernel + one device-to-host copy: aos_voxels receives n
+ * consecutive voxel arrays, updated_bits / has_data (optional) n bytes each.  This is the call the
+ * per-frame host mirror uses (the blocks Layer::getAllUpdatedBlocks(kMap) returns). */
+int vbx_blocks_download(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t n, void* aos_voxels,
+                        uint8_t* updated_bits, uint8_t* has_data);
+/* Page-locked host memory for the mirror's staging buffer: device-to-host copies into it run at
+ * link speed, copies into pageable memory are several times slower.  Any host pointer works. */
+void* vbx_host_alloc(size_t bytes);
+void vbx_host_free(void* p);
 /* Layer::allocateBlockPtrByIndex + overwrite (load_map / tsdfMapCallback path). */
 int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos_voxels,
                      uint8_t updated_bits, uint8_t has_data);

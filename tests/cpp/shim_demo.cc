@@ -108,6 +108,29 @@ int main() {
   }
   std::printf("io round trip blocks=%zu differing=%zu\n", b1.size(), diff);
   if (diff) return 12;
+  // bulk mirror == per-block mirror, both layers
+  std::vector<std::shared_ptr<Block<TsdfVoxel>>> bulk_t;
+  std::vector<std::shared_ptr<Block<EsdfVoxel>>> bulk_e;
+  tsdf.getBlocksByIndex(b1, &bulk_t);
+  esdf.getBlocksByIndex(b1, &bulk_e);
+  if (bulk_t.size() != b1.size() || bulk_e.size() != b1.size()) return 13;
+  for (size_t i = 0; i < b1.size(); ++i) {
+    auto x = tsdf.getBlockPtrByIndex(b1[i]);
+    auto ex = esdf.getBlockPtrByIndex(b1[i]);
+    if (std::memcmp(&x->getVoxelByLinearIndex(0), &bulk_t[i]->getVoxelByLinearIndex(0), x->num_voxels() * sizeof(TsdfVoxel)) ||
+        x->updated_bits != bulk_t[i]->updated_bits || x->has_data_flag != bulk_t[i]->has_data_flag)
+      return 14;
+    if (std::memcmp(&ex->getVoxelByLinearIndex(0), &bulk_e[i]->getVoxelByLinearIndex(0), ex->num_voxels() * sizeof(EsdfVoxel)) ||
+        ex->updated_bits != bulk_e[i]->updated_bits)
+      return 15;
+  }
+  // addNewRobotPosition: clear + occupied spheres allocate ESDF-only blocks
+  const size_t before = esdf.getNumberOfAllocatedBlocks();
+  esdf_integrator.addNewRobotPosition(Point{0.f, 0.f, 0.f});
+  esdf_integrator.updateFromTsdfLayer(true);
+  std::printf("robot sphere: esdf blocks %zu -> %zu (tsdf %zu)\n", before, esdf.getNumberOfAllocatedBlocks(),
+              tsdf.getNumberOfAllocatedBlocks());
+  if (esdf.getNumberOfAllocatedBlocks() <= before || tsdf.getNumberOfAllocatedBlocks() != b1.size()) return 16;
   std::printf("shim OK\n");
   return 0;
 }

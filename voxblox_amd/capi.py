@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
-    "vbx_block_download", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
+    "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
 
 
@@ -110,6 +110,9 @@ def lib():
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_block_download": (C.c_int, [vp, C.c_int, i32p, vp, u8p, u8p]),
+        "vbx_blocks_download": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, vp, u8p, u8p]),
+        "vbx_host_alloc": (vp, [C.c_size_t]),
+        "vbx_host_free": (None, [vp]),
         "vbx_block_upload": (C.c_int, [vp, C.c_int, i32p, vp, C.c_uint8, C.c_uint8]),
         "vbx_block_remove": (C.c_int, [vp, C.c_int, i32p]),
         "vbx_remove_distant_blocks": (C.c_int, [vp, C.c_int, f32p, C.c_double]),
@@ -169,12 +172,16 @@ class Map:
         self.voxel_size = np.float32(voxel_size)
         self.vps = int(voxels_per_side)
         cfg = MapCfg(float(self.voxel_size), self.vps, int(max_blocks))
+        self._pinned = []
         self.h = self.L.vbx_create(C.byref(cfg), int(device))
         if not self.h:
             raise VbxError(self.L.vbx_last_error(None).decode())
 
     def close(self):
         if getattr(self, "h", None):
+            for p in self._pinned:
+                self.L.vbx_host_free(p)
+            self._pinned = []
             self.L.vbx_destroy(self.h)
             self.h = None
 
@@ -250,6 +257,35 @@ class Map:
                                             out.ctypes.data_as(C.c_void_p), C.byref(u), C.byref(hd)))
         return out, u.value, hd.value
 
+    def pinned_voxels(self, max_blocks, layer=LAYER_TSDF):
+        """Page-locked staging array [max_blocks, vps^3] for blocks_download(out=...); lives as
+        long as the Map."""
+        dt = TSDF_VOXEL_DTYPE if layer == LAYER_TSDF else ESDF_VOXEL_DTYPE
+        nbytes = int(max_blocks) * self.vps ** 3 * dt.itemsize
+        p = self.L.vbx_host_alloc(nbytes)
+        if not p:
+            raise MemoryError("vbx_host_alloc failed")
+        self._pinned.append(p)
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dt).reshape(int(max_blocks), self.vps ** 3)
+
+    def blocks_download(self, indices, layer=LAYER_TSDF, out=None):
+        """Bulk mirror: (voxels[n, vps^3] in the reference's AoS layout, updated bits[n], has_data[n])."""
+        idx = np.ascontiguousarray(indices, np.int32).reshape(-1, 3)
+        n = idx.shape[0]
+        dt = TSDF_VOXEL_DTYPE if layer == LAYER_TSDF else ESDF_VOXEL_DTYPE
+        if out is not None:
+            assert out.dtype == dt and out.flags.c_contiguous and out.shape[0] >= n
+            out = out[:n]
+        else:
+            out = np.empty((n, self.vps ** 3), dt)
+        u = np.zeros(n, np.uint8)
+        hd = np.zeros(n, np.uint8)
+        self._chk(self.L.vbx_blocks_download(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)), n,
+                                             out.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                             hd.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out, u, hd
+
     def block_upload(self, idx, voxels, updated_bits=7, has_data=0, layer=LAYER_TSDF):
         idx = np.ascontiguousarray(idx, np.int32)
         dt = TSDF_VOXEL_DTYPE if layer == LAYER_TSDF else ESDF_VOXEL_DTYPE
@@ -319,8 +355,7 @@ class Map:
 
     def tsdf_dict(self):
         """{(bx,by,bz): (dist, weight, rgba, updated_bits)} for every allocated TSDF block."""
-        out = {}
-        for i in self.block_indices(LAYER_TSDF):
-            v, u, _ = self.block_download(i, LAYER_TSDF)
-            out[tuple(int(x) for x in i)] = (v["distance"].copy(), v["weight"].copy(), v["rgba"].copy(), u)
-        return out
+        idx = self.block_indices(LAYER_TSDF)
+        v, u, _ = self.blocks_download(idx, LAYER_TSDF)
+        return {tuple(int(x) for x in i): (v[k]["distance"].copy(), v[k]["weight"].copy(), v[k]["rgba"].copy(), int(u[k]))
+                for k, i in enumerate(idx)}

@@ -1207,6 +1207,59 @@ __global__ void k_insert_blocks(MapDev m, const int32_t* __restrict__ idx, uint3
   map_insert_key(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]), new_list, st);
 }
 
+// Bulk mirror of blocks into the reference's AoS voxel layouts (voxel.h:12-37), one workgroup
+// per requested block, coalesced word writes.  flags_out[b] = block flags, ~0u if the block is
+// not part of the layer.
+__global__ void k_lookup_slots_flags(MapDev m, const int32_t* __restrict__ idx, uint32_t n, uint32_t need,
+                                     uint32_t* slots, uint32_t* flags_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s = map_find(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]));
+  uint32_t f = ~0u;
+  if (s != kInvalidSlot) {
+    f = m.blk_flags[s];
+    if (!(f & need)) { s = kInvalidSlot; f = ~0u; }
+  }
+  slots[i] = s;
+  flags_out[i] = f;
+}
+__global__ void k_pack_tsdf_aos(MapDev m, const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* d = reinterpret_cast<const uint32_t*>(m.dist) + (size_t)slot * m.nvox;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(m.weight) + (size_t)slot * m.nvox;
+  const uint32_t* c = m.rgba + (size_t)slot * m.nvox;
+  uint32_t* o = out + (size_t)b * m.nvox * 3;
+  for (uint32_t i = threadIdx.x; i < m.nvox * 3; i += blockDim.x) {
+    const uint32_t v = i / 3, k = i % 3;
+    o[i] = (k == 0) ? d[v] : (k == 1 ? w[v] : c[v]);  // {float distance; float weight; Color color}
+  }
+}
+__global__ void k_pack_esdf_aos(uint32_t nvox, const float* __restrict__ edist, const uint32_t* __restrict__ estate,
+                                const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* d = reinterpret_cast<const uint32_t*>(edist) + (size_t)slot * nvox;
+  const uint32_t* st = estate + (size_t)slot * nvox;
+  uint32_t* o = out + (size_t)b * nvox * 5;
+  for (uint32_t i = threadIdx.x; i < nvox * 5; i += blockDim.x) {
+    const uint32_t v = i / 5, k = i % 5;
+    uint32_t wv;
+    if (k == 0) {
+      wv = d[v];
+    } else {
+      const uint32_t x = st[v];
+      if (k == 1)  // bool observed, hallucinated, in_queue, fixed: one byte each
+        wv = (x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21);
+      else         // Eigen::Vector3i parent
+        wv = (uint32_t)(int32_t)(int8_t)((x >> (8 * (k - 1))) & 0xFFu);
+    }
+    o[i] = wv;
+  }
+}
+
 __global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const float* __restrict__ in,
                              int apply_caps, float trunc, float max_weight, DevState* st) {
   const uint32_t b = blockIdx.x;
@@ -2823,6 +2876,66 @@ int vbx_block_download(vbx_ctx* ctx, int layer, const int32_t idx[3], void* aos,
   return VBX_OK;
 }
 
+void* vbx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void vbx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+static int upload_idx(vbx_ctx* ctx, const int32_t* idx, size_t n);
+
+int vbx_blocks_download(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, void* aos, uint8_t* updated_bits,
+                        uint8_t* has_data) {
+  if (!ctx || (n && (!idx || !aos))) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+    ctx->fail("unknown layer %d", layer);
+    return VBX_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return VBX_OK;
+  if (layer == VBX_LAYER_ESDF && !ctx->esdf_init) {
+    ctx->fail("ESDF layer is empty");
+    return VBX_ERR_INVALID;
+  }
+  int rc = upload_idx(ctx, idx, n);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  const size_t wpb = (size_t)m.nvox * (layer == VBX_LAYER_TSDF ? 3 : 5);
+  HIP_TRY(ctx->b_keys0.ensure(n * wpb * 4));
+  HIP_TRY(ctx->b_vals0.ensure(n * 4));
+  hipLaunchKernelGGL(k_lookup_slots_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+                     layer == VBX_LAYER_TSDF ? kFlagPublished : kFlagEsdfAlloc, ctx->b_rank.as<uint32_t>(),
+                     ctx->b_vals0.as<uint32_t>());
+  if (layer == VBX_LAYER_TSDF)
+    hipLaunchKernelGGL(k_pack_tsdf_aos, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
+                       ctx->b_keys0.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(k_pack_esdf_aos, dim3((unsigned)n), dim3(256), 0, s, m.nvox, ctx->b_edist.as<float>(),
+                       ctx->b_estate.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), ctx->b_keys0.as<uint32_t>());
+  std::vector<uint32_t> flags(n);
+  HIP_TRY(hipMemcpyAsync(flags.data(), ctx->b_vals0.p, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(aos, ctx->b_keys0.p, n * wpb * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (size_t i = 0; i < n; ++i) {
+    if (flags[i] == ~0u) {
+      ctx->fail("block (%d,%d,%d) is not allocated", idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]);
+      return VBX_ERR_INVALID;
+    }
+    if (layer == VBX_LAYER_TSDF) {
+      if (updated_bits) updated_bits[i] = (uint8_t)(flags[i] & kFlagUpdMask);
+      if (has_data) has_data[i] = (flags[i] & kFlagHasData) ? 1 : 0;
+    } else {
+      if (updated_bits) updated_bits[i] = (uint8_t)((flags[i] >> kFlagEsdfUpdShift) & kFlagUpdMask);
+      if (has_data) has_data[i] = 0;
+    }
+  }
+  return VBX_OK;
+}
+
 int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos, uint8_t updated_bits,
                      uint8_t has_data) {
   if (!ctx || !idx || !aos) return VBX_ERR_INVALID;
@@ -3057,27 +3170,26 @@ int vbx_blocks_serialize(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, 
   MapDev& m = ctx->map;
   const size_t wpb = (size_t)m.nvox * (layer == VBX_LAYER_TSDF ? 3 : 2);
   HIP_TRY(ctx->b_keys0.ensure(n * wpb * 4));
-  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
-                     layer == VBX_LAYER_TSDF ? 1 : 0, ctx->b_rank.as<uint32_t>());
+  HIP_TRY(ctx->b_vals0.ensure(n * 4));
+  hipLaunchKernelGGL(k_lookup_slots_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+                     layer == VBX_LAYER_TSDF ? kFlagPublished : kFlagEsdfAlloc, ctx->b_rank.as<uint32_t>(),
+                     ctx->b_vals0.as<uint32_t>());
   if (layer == VBX_LAYER_TSDF)
     hipLaunchKernelGGL(k_serialize_tsdf, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
                        ctx->b_keys0.as<uint32_t>());
   else
     hipLaunchKernelGGL(k_serialize_esdf, dim3((unsigned)n), dim3(256), 0, s, m.nvox, ctx->b_edist.as<float>(),
                        ctx->b_estate.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), ctx->b_keys0.as<uint32_t>());
-  std::vector<uint32_t> slots(n), flags(n);
-  HIP_TRY(hipMemcpyAsync(slots.data(), ctx->b_rank.p, n * 4, hipMemcpyDeviceToHost, s));
+  std::vector<uint32_t> flags(n);
+  HIP_TRY(hipMemcpyAsync(flags.data(), ctx->b_vals0.p, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(words, ctx->b_keys0.p, n * wpb * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (size_t i = 0; i < n; ++i) {
-    uint32_t f = 0;
-    if (slots[i] != kInvalidSlot) HIP_TRY(hipMemcpy(&f, m.blk_flags + slots[i], 4, hipMemcpyDeviceToHost));
-    const bool ok = slots[i] != kInvalidSlot && (layer == VBX_LAYER_TSDF || (f & kFlagEsdfAlloc));
-    if (!ok) {
+    if (flags[i] == ~0u) {
       ctx->fail("block (%d,%d,%d) is not allocated", idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]);
       return VBX_ERR_INVALID;
     }
-    if (has_data) has_data[i] = (layer == VBX_LAYER_TSDF && (f & kFlagHasData)) ? 1 : 0;
+    if (has_data) has_data[i] = (layer == VBX_LAYER_TSDF && (flags[i] & kFlagHasData)) ? 1 : 0;
   }
   return VBX_OK;
 }

@@ -189,6 +189,27 @@ class Layer {
     map_->check(rc, "vbx_block_download");
     return b;
   }
+  // Bulk form of the loop `for (idx : list) getBlockPtrByIndex(idx)` — one device pack + one copy
+  // (vbx_blocks_download); what a per-frame host mirror of getAllUpdatedBlocks(kMap) should use.
+  void getBlocksByIndex(const BlockIndexList& list, std::vector<std::shared_ptr<BlockType>>* out) const {
+    VBX_CHECK(out != nullptr, "out");
+    const size_t n = list.size();
+    out->clear();
+    if (n == 0) return;
+    const size_t nv = voxels_per_side() * voxels_per_side() * voxels_per_side();
+    std::vector<VoxelType> voxels(n * nv);
+    std::vector<uint8_t> bits(n), hd(n);
+    map_->check(vbx_blocks_download(map_->ctx(), kId, &list[0].x, n, voxels.data(), bits.data(), hd.data()),
+                "vbx_blocks_download");
+    out->reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+      auto b = std::make_shared<BlockType>(voxels_per_side(), voxel_size());
+      std::copy(voxels.begin() + i * nv, voxels.begin() + (i + 1) * nv, b->data());
+      b->updated_bits = bits[i];
+      b->has_data_flag = hd[i];
+      out->push_back(std::move(b));
+    }
+  }
   bool hasBlock(const BlockIndex& index) const { return getBlockPtrByIndex(index) != nullptr; }  // layer.h:207
   void insertBlock(const BlockIndex& index, const BlockType& block) {  // load_map path, layer.h:147-157
     map_->check(vbx_block_upload(map_->ctx(), kId, &index.x, &block.getVoxelByLinearIndex(0), block.updated_bits,
