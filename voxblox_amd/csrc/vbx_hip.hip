@@ -956,7 +956,13 @@ __device__ inline bool sweep_ray(const SweepArgs& a, bool ray_ok, uint32_t r, in
   bool doneL = (len == 0) || a.init, done = (len == 0);
   if (a.init) tl = 0;
   if (a.l_only) th = ray_ok ? a.TH[r] : 0;
-  for (uint32_t base = 0; __any(!done); base += G) {
+  // No bound can move below the old lower bound: under the (shrinking) possible claims the ray
+  // did not stop before probe kT = tl_old - 1, so neither does it under the certain ones, and a
+  // collision run that ends at kT or later starts at kT - max_consecutive at the earliest.
+  // The scan therefore restarts there with clear counters; the claims of the skipped prefix
+  // are already in CL.
+  const uint32_t k0 = (tl_old > (uint32_t)a.max_consecutive + 1u) ? tl_old - 1u - (uint32_t)a.max_consecutive : 0u;
+  for (uint32_t base = k0; __any(!done); base += G) {
     const uint32_t k = base + gl;
     const bool act = !done && k < len;
     const uint32_t gid = act ? a.vox[beg + k] : 0xFFFFFFFFu;
@@ -1852,22 +1858,28 @@ int ensure_tab(vbx_ctx* ctx, bool second, size_t R, bool with_bkey) {
 
 // rocPRIM is used only for the two generic primitives of the pipeline (LSD radix sort,
 // exclusive scan); everything domain-specific is a kernel in this file.
+// Frame-sized inputs (3e5..1e6 keys) sit below rocPRIM's default merge-sort limit, where it runs
+// ~20 launch-bound merge passes over the full 64-bit key; the callers here only need a STABLE
+// sort on a 20..26-bit field (the inputs are already in visiting order), which is 3-4 onesweep
+// passes.  MergeSortLimit = 0 selects the LSD onesweep path for every size.
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                           rocprim::default_config, 0>;
 int sort_keys(vbx_ctx* ctx, uint64_t* in, uint64_t* out, size_t n, unsigned begin_bit,
               unsigned end_bit) {
   size_t tmp = 0;
-  HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
+  HIP_TRY(rocprim::radix_sort_keys<SortCfg>(nullptr, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
   HIP_TRY(ctx->b_tmp.ensure(tmp));
-  HIP_TRY(rocprim::radix_sort_keys(ctx->b_tmp.p, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
+  HIP_TRY(rocprim::radix_sort_keys<SortCfg>(ctx->b_tmp.p, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
   return VBX_OK;
 }
 int sort_pairs(vbx_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
                unsigned begin_bit, unsigned end_bit) {
   size_t tmp = 0;
-  HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
-                                    ctx->stream));
+  HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
+                                             ctx->stream));
   HIP_TRY(ctx->b_tmp.ensure(tmp));
-  HIP_TRY(rocprim::radix_sort_pairs(ctx->b_tmp.p, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
-                                    ctx->stream));
+  HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(ctx->b_tmp.p, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
+                                             ctx->stream));
   return VBX_OK;
 }
 int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
@@ -1935,7 +1947,9 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   MapDev& m = ctx->map;
   hipStream_t s = ctx->stream;
   const unsigned end_bit = 32 + bits_for((uint64_t)m.cap_blocks * m.nvox);
-  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 0,
+  // keys are emitted ray by ray in visiting order, so a stable sort on the voxel field alone
+  // leaves every voxel's updates in visiting order (invalid keys, all ones, go last)
+  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 32,
                      std::min(64u, end_bit + 1));
   if (rc) return rc;
   tmark(ctx, 5);
@@ -2106,8 +2120,10 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
   hipLaunchKernelGGL(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,
                      ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
+  // keys[s] = slot << 32 | s is written in visiting order: a stable sort on the 20 slot bits
+  // (+ bit 52, set only in the all-ones key of dropped points) orders by (slot, s)
   rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(),
-                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 0, 64);
+                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 32, 53);
   if (rc) return rc;
   hipLaunchKernelGGL(k_fast_start_dedupe, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
