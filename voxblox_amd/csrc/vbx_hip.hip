@@ -102,6 +102,8 @@ struct DevState {
   uint32_t esdf_relax_blocks;
   uint32_t act_count[3];
   uint32_t fold_long_count;
+  uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)
+  uint32_t pad_;
   unsigned long long total_keys;
   unsigned long long voxels_touched;
   unsigned long long rays_cast;
@@ -239,6 +241,26 @@ __global__ void k_fill_u64(uint64_t* p, uint64_t v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) p[i] = v;
+}
+
+// Per-call counters: one launch instead of several unaligned memsets (each of which the
+// runtime splits into head/body/tail fill kernels).
+__global__ void k_reset_call_state(DevState* st) {
+  st->new_count = 0;
+  st->error = 0;
+  st->changed = 0;
+  st->sentinel_cleared = 0;
+  st->blocks_published = 0;
+  st->esdf_blocks = 0;
+  st->esdf_raise_any = 0;
+  st->esdf_relax_blocks = 0;
+  st->act_count[0] = st->act_count[1] = st->act_count[2] = 0;
+  st->fold_long_count = 0;
+  st->fast_idle_sweep = 0;
+  st->total_keys = 0;
+  st->voxels_touched = 0;
+  st->rays_cast = 0;
+  st->num_kept = 0;
 }
 
 __global__ void k_assign_slots(MapDev m, const uint32_t* new_list, DevState* st) {
@@ -934,6 +956,7 @@ struct SweepArgs {
   uint32_t* TL; uint32_t* TH; uint32_t* U;
   const uint32_t* obs;      // voxels observed in earlier frames since the last reset (or null)
   uint32_t obs_epoch;
+  uint32_t sweep_idx;       // 0, 1, 2, ... within the frame
   int init;                 // 1: first pass (publish full-path possible claims, no reads)
   int l_only;               // 1: only tighten the lower bounds (TH and the possible claims stay)
 };
@@ -1051,7 +1074,11 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
   const bool ray_ok = idx < n_in;
   const uint32_t r = ray_ok ? (a.list_in ? a.list_in[idx] : idx) : 0;
   // the counter after the output one is the NEXT launch's output: zero it here
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->act_count[(a.cnt_out + 1) % 3] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->act_count[(a.cnt_out + 1) % 3] = 0;
+    if (a.init) a.U[R] = 0;  // terminator of the exclusive scan over U
+    if (a.list_in && n_in == 0) atomicMax(&st->fast_idle_sweep, 0xFFFFFFFFu - a.sweep_idx);
+  }
   const bool open = sweep_ray<G, false>(a, ray_ok, r, grp, gl);
   if (a.list_out) append_open(open, r, a.list_out, &st->act_count[a.cnt_out]);
 }
@@ -1774,6 +1801,7 @@ struct vbx_ctx {
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
   DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1;
   uint32_t obs_epoch = 1;
+  uint32_t fast_last_iters = 0;  // sweeps the previous Fast frame needed
   // Fast integrator persistent state
   DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
   uint32_t start_offset = 0;
@@ -2207,7 +2235,6 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_rank.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_act0.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_act1.ensure((size_t)(R + 1) * 4));
-  HIP_TRY(hipMemsetAsync(ctx->b_U.as<uint32_t>() + R, 0, 4, s));
   uint32_t iters_total = 0;
   auto run_solver = [&]() -> int {
     SweepArgs sa{};
@@ -2238,9 +2265,14 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     uint32_t* chs[2] = {ctx->b_own0.as<uint32_t>(), ctx->b_own1.as<uint32_t>()};
     for (;;) {
       {
-        const int kBatch = (iters == 0) ? 3 : 4;  // sweeps per host check (an idle sweep is ~8 us, a check ~30 us)
+        // sweeps per host check (an idle sweep is ~5 us, a check ~30 us): the first three give
+        // the open-ray count that sizes the later grids; then one batch up to where the previous
+        // frame converged (consecutive frames behave alike), then fours
+        int kBatch = (iters == 0) ? 3 : 4;
+        if (iters == 3 && ctx->fast_last_iters > 7) kBatch = (int)ctx->fast_last_iters - 3 + 1;
         for (int b = 0; b < kBatch; ++b) {
           sa.init = (iters == 0) ? 1 : 0;
+          sa.sweep_idx = iters;
           sa.l_only = (iters == 1) ? 1 : 0;
           const bool writes_ch = !sa.l_only;
           const bool writes_list = iters >= 2;
@@ -2282,7 +2314,10 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         return VBX_ERR_HIP;
       }
     }
+    // sweeps that did work (the launches after convergence are idle)
+    if (ctx->h_state.fast_idle_sweep) iters = std::min(iters, 0xFFFFFFFFu - ctx->h_state.fast_idle_sweep);
     iters_total = iters;
+    ctx->fast_last_iters = std::min<uint32_t>(iters, 64);
     return VBX_OK;
   };
   rc = run_solver();
@@ -2330,9 +2365,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters.points = n;
   if (n == 0) return VBX_OK;
   // per-call device counters
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, ctx->stream));
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, offsetof(DevState, total_keys) - offsetof(DevState, error), ctx->stream));
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->total_keys, 0, sizeof(DevState) - offsetof(DevState, total_keys), ctx->stream));
+  hipLaunchKernelGGL(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
   Pose T;
   T.t = {pos[0], pos[1], pos[2]};
   T.qw = quat[0]; T.qx = quat[1]; T.qy = quat[2]; T.qz = quat[3];
