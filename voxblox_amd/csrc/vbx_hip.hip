@@ -102,8 +102,8 @@ struct DevState {
   uint32_t esdf_relax_blocks;
   uint32_t act_count[3];
   uint32_t fold_long_count;
+  uint32_t redo_count;       // rays whose voxel list must be rebuilt after slot assignment
   uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)
-  uint32_t pad_;
   unsigned long long total_keys;
   unsigned long long voxels_touched;
   unsigned long long rays_cast;
@@ -257,6 +257,7 @@ __global__ void k_reset_call_state(DevState* st) {
   st->act_count[0] = st->act_count[1] = st->act_count[2] = 0;
   st->fold_long_count = 0;
   st->fast_idle_sweep = 0;
+  st->redo_count = 0;
   st->total_keys = 0;
   st->voxels_touched = 0;
   st->rays_cast = 0;
@@ -862,46 +863,73 @@ __global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
 // on these lists instead of re-running the DDA and the block hash lookups.
 __global__ void __launch_bounds__(256)
 k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
-                   uint32_t* vox, DevState* st) {
+                   uint32_t* vox, uint32_t vox_cap, uint32_t* new_list, const uint32_t* __restrict__ redo_in,
+                   uint32_t* redo_out, DevState* st) {
+  // First pass (redo_in == nullptr): blocks met for the first time are inserted into the map
+  // here (the block part of allocateStorageAndGetVoxelPtr, tsdf_integrator.cc:97-126); they
+  // only get their pool slot after this kernel, so a ray that crossed one is queued in
+  // redo_out and rebuilt by the second pass (redo_in = that queue).  In steady state a frame
+  // adds a handful of blocks, so the second pass touches a few hundred rays.
   // One ray per lane; every lane stages 16 list entries in LDS, then the wave writes them out
   // ray by ray as 64-byte runs (4 rays per store instruction) instead of 64 scattered dwords.
   __shared__ uint32_t s_buf[4][64][17];  // [wave][lane][entry], padded against bank conflicts
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  RayCaster rc;
-  bool live = (r < tab.R) && ray_init(rc, tab, r, c, m, /*from_origin=*/false, nullptr) && rc.cur == 0;
-  const uint32_t base = (r < tab.R) ? off[r] : 0;
-  const uint32_t len = live ? rc.steps + 1 : 0;
-  uint64_t last_key = kEmptyKey;
-  uint32_t slot = kInvalidSlot;
-  for (uint32_t k0 = 0; __any(k0 < len); k0 += 16) {
-    for (int j = 0; j < 16; ++j) {
-      uint32_t gid = 0xFFFFFFFFu;
-      l3 g;
-      if (k0 + j < len && rc.next(&g)) {
-        const i3 b = block_index_from_global(g, m.vps_inv);
-        const uint64_t key = pack_block_key(b.x, b.y, b.z);
-        if (key != last_key) {
-          last_key = key;
-          slot = map_find(m, key);
-          if (slot == kInvalidSlot) atomicOr(&st->error, 2u);
+  const uint32_t limit = redo_in ? min(st->redo_count, tab.R) : tab.R;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  // grid-stride over the work items; the trip count is uniform within a wave (the flush below
+  // is wave-cooperative)
+  for (uint32_t wbase = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; wbase < limit; wbase += stride) {
+    const uint32_t tix = wbase + lane;
+    const bool in_range = tix < limit;
+    const uint32_t r = in_range ? (redo_in ? redo_in[tix] : tix) : 0;
+    RayCaster rc;
+    bool live = in_range && ray_init(rc, tab, r, c, m, /*from_origin=*/false, nullptr) && rc.cur == 0;
+    const uint32_t base = in_range ? off[r] : 0;
+    uint32_t len = live ? rc.steps + 1 : 0;
+    if (live && base + len > vox_cap) {  // cannot happen while the host's per-ray bound holds
+      atomicOr(&st->error, 4u);
+      len = 0;
+    }
+    uint64_t last_key = kEmptyKey;
+    uint32_t slot = kInvalidSlot;
+    bool redo = false;
+    for (uint32_t k0 = 0; __any(k0 < len); k0 += 16) {
+      for (int j = 0; j < 16; ++j) {
+        uint32_t gid = 0xFFFFFFFFu;
+        l3 g;
+        if (k0 + j < len && rc.next(&g)) {
+          const i3 b = block_index_from_global(g, m.vps_inv);
+          const uint64_t key = pack_block_key(b.x, b.y, b.z);
+          if (key != last_key) {
+            last_key = key;
+            slot = map_find(m, key);
+            if (slot == kInvalidSlot) {
+              if (redo_in) {
+                atomicOr(&st->error, 2u);
+              } else {
+                map_insert_key(m, key, new_list, st);
+                redo = true;
+              }
+            }
+          }
+          if (slot != kInvalidSlot) {
+            const i3 l = local_from_global(g, m.vps);
+            gid = slot * m.nvox + (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
+          }
         }
-        if (slot != kInvalidSlot) {
-          const i3 l = local_from_global(g, m.vps);
-          gid = slot * m.nvox + (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
-        }
+        s_buf[wv][lane][j] = gid;
       }
-      s_buf[wv][lane][j] = gid;
+      // wave-synchronous flush (same wave wrote and reads; LDS ops of one wave are ordered)
+      const int sub = lane >> 4, e = lane & 15;
+      for (int q = 0; q < 16; ++q) {
+        const int src = q * 4 + sub;  // lane whose ray is being written
+        const uint32_t sbase = __shfl(base, src);
+        const uint32_t slen = __shfl(len, src);
+        if (k0 + e < slen) vox[sbase + k0 + e] = s_buf[wv][src][e];
+      }
     }
-    // wave-synchronous flush (same wave wrote and reads; LDS ops of one wave are ordered)
-    const int sub = lane >> 4, e = lane & 15;
-    for (int q = 0; q < 16; ++q) {
-      const int src = q * 4 + sub;  // lane whose ray is being written
-      const uint32_t sbase = __shfl(base, src);
-      const uint32_t slen = __shfl(len, src);
-      if (k0 + e < slen) vox[sbase + k0 + e] = s_buf[wv][src][e];
-    }
+    if (redo) redo_out[atomicAdd(&st->redo_count, 1u)] = r;
   }
 }
 
@@ -1799,9 +1827,10 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo;
   uint32_t obs_epoch = 1;
   uint32_t fast_last_iters = 0;  // sweeps the previous Fast frame needed
+  uint32_t fast_redo_grid = 0;   // rays the second list-building pass is launched for
   // Fast integrator persistent state
   DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
   uint32_t start_offset = 0;
@@ -1850,6 +1879,10 @@ int check_state_error(vbx_ctx* ctx) {
   }
   if (ctx->h_state.error & 2u) {
     ctx->fail("internal: ray march hit a block without a pool slot");
+    return VBX_ERR_HIP;
+  }
+  if (ctx->h_state.error & 4u) {
+    ctx->fail("internal: voxel list capacity bound violated");
     return VBX_ERR_HIP;
   }
   return VBX_OK;
@@ -2186,20 +2219,26 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                      (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>());
   rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, kt, c, m, 0,
-                     (const uint32_t*)nullptr, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+  // Every ray emits at most sqrt(3) * (max_ray_length + truncation) / voxel_size + 4 voxels
+  // (L1 <= sqrt(3) L2 of the walked segment), so the list buffer is sized without waiting for
+  // the exact total; 288 GB of HBM make the slack irrelevant and the buffer is reused.
+  const double seg = (double)c.max_ray_length_m + (double)c.trunc;
+  const size_t per_ray = (size_t)(1.7320508075688772 * seg * (double)m.voxel_size_inv) + 6;
+  const size_t vox_cap = std::min<size_t>((size_t)R * per_ray + 64, 0xFFFFFFF0u);
+  HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
+  HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
+  hipLaunchKernelGGL(k_fast_build_lists, grid_for(R), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
+                     ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
+                     (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
   hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
                      ctx->b_newlist.as<uint32_t>(), ctx->d_state);
   hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-  uint32_t total_full = 0;
-  HIP_TRY(hipMemcpyAsync(&total_full, ctx->b_off.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
-  rc = sync_state(ctx);
-  if (rc) return rc;
-  rc = check_state_error(ctx);
-  if (rc) return rc;
-  HIP_TRY(ctx->b_vox.ensure((size_t)std::max<uint32_t>(total_full, 1) * 4));
-  hipLaunchKernelGGL(k_fast_build_lists, grid_for(R), dim3(256), 0, s, kt, c, m,
-                     ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), ctx->d_state);
+  // second pass over the queued rays (grid sized for the first-frame worst case; idle
+  // workgroups leave at once); capacity / lookup errors surface at the solver's first check
+  if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
+  hipLaunchKernelGGL(k_fast_build_lists, grid_for(std::max<uint32_t>(ctx->fast_redo_grid, 4096)), dim3(256), 0, s, kt, c, m,
+                     ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap,
+                     ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
   tmark(ctx, 2);
 
   // claim arrays + tags (see k_fast_sweep)
@@ -2306,6 +2345,9 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         rc = check_state_error(ctx);
         if (rc) return rc;
         n_open = ctx->h_state.act_count[cnt_cur];
+        // size the next frame's second list-building pass (it is a grid-stride loop, so this is
+        // only a performance hint)
+        ctx->fast_redo_grid = std::max<uint32_t>(1, 2 * ctx->h_state.redo_count);
       }
       if (getenv("VBX_DEBUG")) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
       if (n_open == 0) break;
@@ -2736,7 +2778,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
