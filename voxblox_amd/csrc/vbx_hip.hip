@@ -130,6 +130,7 @@ struct MapDev {  // by-value kernel argument
 };
 
 struct CastCfg {  // by-value kernel argument: TsdfIntegratorBase::Config + derived constants
+  int exp;  // TEMP experiment switch
   f3 origin;
   float trunc;
   float max_ray_length_m;
@@ -861,6 +862,8 @@ __global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
 // ray visits walking from the surface towards the sensor (cast_from_origin = false,
 // tsdf_integrator.cc:521-525).  Built once per frame; the solver and the emit step then work
 // on these lists instead of re-running the DDA and the block hash lookups.
+constexpr int kListRPW = 64;  // rays per wave in k_fast_build_lists
+template <int RPW>
 __global__ void __launch_bounds__(256)
 k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
                    uint32_t* vox, uint32_t vox_cap, uint32_t* new_list, const uint32_t* __restrict__ redo_in,
@@ -870,18 +873,22 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
   // only get their pool slot after this kernel, so a ray that crossed one is queued in
   // redo_out and rebuilt by the second pass (redo_in = that queue).  In steady state a frame
   // adds a handful of blocks, so the second pass touches a few hundred rays.
-  // One ray per lane; every lane stages 16 list entries in LDS, then the wave writes them out
-  // ray by ray as 64-byte runs (4 rays per store instruction) instead of 64 scattered dwords.
-  __shared__ uint32_t s_buf[4][64][17];  // [wave][lane][entry], padded against bank conflicts
+  // RPW rays per wave, one per lane in the low lanes: the walk is a serial dependency chain per
+  // ray, so with all 64 lanes busy the 70k rays of a frame are ~1 wave per SIMD and nothing
+  // hides the latencies; fewer rays per wave means more resident waves.  Every ray lane stages
+  // 16 list entries in LDS, then ALL 64 lanes write them out ray by ray as 64-byte runs (4 rays
+  // per store instruction) instead of scattered dwords.
+  __shared__ uint32_t s_buf[4][RPW][17];  // [wave][ray][entry], padded against bank conflicts
+  __shared__ uint64_t s_keys[4][RPW][17]; // keys, then pool slots, of the blocks a ray enters within a chunk
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const uint32_t limit = redo_in ? min(st->redo_count, tab.R) : tab.R;
-  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t stride = gridDim.x * (blockDim.x / 64) * RPW;
   // grid-stride over the work items; the trip count is uniform within a wave (the flush below
   // is wave-cooperative)
-  for (uint32_t wbase = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; wbase < limit; wbase += stride) {
+  for (uint32_t wbase = (blockIdx.x * (blockDim.x / 64) + wv) * RPW; wbase < limit; wbase += stride) {
     const uint32_t tix = wbase + lane;
-    const bool in_range = tix < limit;
+    const bool in_range = lane < RPW && tix < limit;
     const uint32_t r = in_range ? (redo_in ? redo_in[tix] : tix) : 0;
     RayCaster rc;
     bool live = in_range && ray_init(rc, tab, r, c, m, /*from_origin=*/false, nullptr) && rc.cur == 0;
@@ -891,42 +898,63 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
       atomicOr(&st->error, 4u);
       len = 0;
     }
-    uint64_t last_key = kEmptyKey;
+    BlockWalk bw{};
+    if (live) bw.start(rc, m.vps, m.vps_inv);
     uint32_t slot = kInvalidSlot;
     bool redo = false;
-    for (uint32_t k0 = 0; __any(k0 < len); k0 += 16) {
-      for (int j = 0; j < 16; ++j) {
-        uint32_t gid = 0xFFFFFFFFu;
-        l3 g;
-        if (k0 + j < len && rc.next(&g)) {
-          const i3 b = block_index_from_global(g, m.vps_inv);
-          const uint64_t key = pack_block_key(b.x, b.y, b.z);
-          if (key != last_key) {
-            last_key = key;
-            slot = map_find(m, key);
-            if (slot == kInvalidSlot) {
-              if (redo_in) {
-                atomicOr(&st->error, 2u);
-              } else {
-                map_insert_key(m, key, new_list, st);
-                redo = true;
-              }
-            }
-          }
-          if (slot != kInvalidSlot) {
-            const i3 l = local_from_global(g, m.vps);
-            gid = slot * m.nvox + (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
-          }
+    auto lookup = [&](uint64_t key) -> uint32_t {
+      const uint32_t sl = map_find(m, key);
+      if (sl == kInvalidSlot) {
+        if (redo_in) {
+          atomicOr(&st->error, 2u);
+        } else {
+          map_insert_key(m, key, new_list, st);
+          redo = true;
         }
-        s_buf[wv][lane][j] = gid;
+      }
+      return sl;
+    };
+    for (uint32_t k0 = 0; __any(k0 < len); k0 += 16) {
+      // (a) 16 DDA steps, no memory traffic: linear voxel index + "enters a new block" mark
+      // per entry, the new blocks' keys on the side.  A hash lookup inside this loop would
+      // stall the whole wave at almost every step (some lane always crosses a block face).
+      uint64_t* tkeys = s_keys[wv][lane < RPW ? lane : 0];  // at most one block change per step
+      int nt = 0;
+      for (int j = 0; j < 16; ++j) {
+        uint32_t e = 0xFFFFFFFFu;
+        if (k0 + j < len) {
+          e = bw.lin;
+          if (bw.entered) {
+            tkeys[nt] = pack_block_key(bw.bx, bw.by, bw.bz);
+            e |= 0x80000000u | ((uint32_t)nt << 24);
+            ++nt;
+          }
+          bw.step(m.vps, m.vps_log2);
+        }
+        if (lane < RPW) s_buf[wv][lane][j] = e;
+      }
+      // (b) the lookups, rank by rank: all lanes issue their t-th lookup together
+      for (int t = 0; __any(t < nt); ++t)
+        if (t < nt) tkeys[t] = (c.exp & 1) ? 0ull : (uint64_t)lookup(tkeys[t]);
+      // (c) entries -> global voxel ids
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t e = (lane < RPW) ? s_buf[wv][lane][j] : 0xFFFFFFFFu;
+        uint32_t gid = 0xFFFFFFFFu;
+        if (e != 0xFFFFFFFFu) {
+          if (e & 0x80000000u) {
+            slot = (uint32_t)tkeys[(e >> 24) & 0x7Fu];
+          }
+          if (slot != kInvalidSlot) gid = slot * m.nvox + (e & 0xFFFFFFu);
+        }
+        if (lane < RPW) s_buf[wv][lane][j] = gid;
       }
       // wave-synchronous flush (same wave wrote and reads; LDS ops of one wave are ordered)
       const int sub = lane >> 4, e = lane & 15;
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < RPW / 4; ++q) {
         const int src = q * 4 + sub;  // lane whose ray is being written
         const uint32_t sbase = __shfl(base, src);
         const uint32_t slen = __shfl(len, src);
-        if (k0 + e < slen) vox[sbase + k0 + e] = s_buf[wv][src][e];
+        if (k0 + e < slen && !(c.exp & 2)) vox[sbase + k0 + e] = s_buf[wv][src][e];
       }
     }
     if (redo) redo_out[atomicAdd(&st->redo_count, 1u)] = r;
@@ -1970,6 +1998,7 @@ CastCfg make_cast_cfg(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float pos[3])
   c.origin = {pos[0], pos[1], pos[2]};
   c.trunc = cfg->default_truncation_distance;
   c.max_ray_length_m = cfg->max_ray_length_m;
+  c.exp = getenv("VBX_EXP") ? atoi(getenv("VBX_EXP")) : 0;
   c.min_ray_length_m = cfg->min_ray_length_m;
   c.max_weight = cfg->max_weight;
   c.sparsity_factor = cfg->sparsity_compensation_factor;
@@ -2227,7 +2256,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   const size_t vox_cap = std::min<size_t>((size_t)R * per_ray + 64, 0xFFFFFFF0u);
   HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
   HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
-  hipLaunchKernelGGL(k_fast_build_lists, grid_for(R), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
+  hipLaunchKernelGGL(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
                      ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
                      (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
   hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
@@ -2236,7 +2265,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   // second pass over the queued rays (grid sized for the first-frame worst case; idle
   // workgroups leave at once); capacity / lookup errors surface at the solver's first check
   if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
-  hipLaunchKernelGGL(k_fast_build_lists, grid_for(std::max<uint32_t>(ctx->fast_redo_grid, 4096)), dim3(256), 0, s, kt, c, m,
+  hipLaunchKernelGGL(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
                      ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap,
                      ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
   tmark(ctx, 2);
