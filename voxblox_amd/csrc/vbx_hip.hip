@@ -1041,22 +1041,25 @@ __device__ inline bool sweep_ray(const SweepArgs& a, bool ray_ok, uint32_t r, in
   // The scan therefore restarts there with clear counters; the claims of the skipped prefix
   // are already in CL.
   const uint32_t k0 = (tl_old > (uint32_t)a.max_consecutive + 1u) ? tl_old - 1u - (uint32_t)a.max_consecutive : 0u;
+  // The list entries of the next step are fetched while the current step's claim reads are in
+  // flight, and both claim words are read unconditionally: one memory latency per step instead
+  // of three dependent ones (vox -> cl -> ch).
+  uint32_t gid_pf = (k0 + gl < len) ? a.vox[beg + k0 + gl] : 0xFFFFFFFFu;
   for (uint32_t base = k0; __any(!done); base += G) {
     const uint32_t k = base + gl;
     const bool act = !done && k < len;
-    const uint32_t gid = act ? a.vox[beg + k] : 0xFFFFFFFFu;
+    const uint32_t gid = act ? gid_pf : 0xFFFFFFFFu;
+    gid_pf = (!done && k + G < len) ? a.vox[beg + k + G] : 0xFFFFFFFFu;
     bool pL = false, pH = false;  // collision under certain / possible claims
     if (gid != 0xFFFFFFFFu && !a.init) {
       const uint32_t c1 = __hip_atomic_load(&a.cl[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t c2 = kCoherentReads
+                              ? __hip_atomic_load(&a.ch_rd[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : a.ch_rd[gid];
+      const uint32_t c3 = a.obs ? a.obs[gid] : 0u;
       pL = ((c1 >> a.s_bits) == a.tag_cl) && ((c1 & smask) < r);
-      if (!pL && a.obs) pL = (a.obs[gid] == a.obs_epoch);  // seen in an earlier frame of this epoch
-      pH = pL;
-      if (!pH) {
-        const uint32_t c2 = kCoherentReads
-                                ? __hip_atomic_load(&a.ch_rd[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                : a.ch_rd[gid];
-        pH = ((c2 >> a.s_bits) == a.tag_rd) && ((c2 & smask) < r);
-      }
+      if (a.obs) pL = pL || (c3 == a.obs_epoch);  // seen in an earlier frame of this epoch
+      pH = pL || (((c2 >> a.s_bits) == a.tag_rd) && ((c2 & smask) < r));
     }
     // upper bound TH: stop on a run of certain collisions
     const unsigned long long PL = (__ballot(pL) >> (grp * G)) & gmask;
@@ -2355,6 +2358,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
           if (writes_list && !have_list) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[sa.cnt_out], 0, 4, s));
           if (iters == 0)
+            hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
+          else if (n_open <= 8192)  // few open rays: a whole wave per ray (64 list entries per step)
             hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
           else
             hipLaunchKernelGGL(k_fast_sweep<16>, grid_for((size_t)n_open * 16), dim3(256), 0, s, sa, R, ctx->d_state);
