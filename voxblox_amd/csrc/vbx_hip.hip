@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -108,6 +109,16 @@ struct DevState {
   unsigned long long voxels_touched;
   unsigned long long rays_cast;
   unsigned long long num_kept;
+};
+
+// Host-visible copy of DevState in page-locked, device-mapped host memory.  A read-back is a
+// tiny kernel that writes this struct and then its sequence number; the host spins on the
+// number.  hipMemcpyAsync + hipStreamSynchronize costs ~35 us per read-back (copy engine launch
+// + interrupt-driven wait), and a Fast frame needs five of them.
+struct StateMirror {
+  DevState st;
+  uint32_t extra;
+  uint32_t seq;
 };
 
 struct MapDev {  // by-value kernel argument
@@ -246,6 +257,16 @@ __global__ void k_fill_u64(uint64_t* p, uint64_t v, size_t n) {
 
 // Per-call counters: one launch instead of several unaligned memsets (each of which the
 // runtime splits into head/body/tail fill kernels).
+__global__ void k_publish_state(const DevState* st, StateMirror* out, const uint32_t* extra, uint32_t seq) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(st);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&out->st);
+  for (uint32_t i = threadIdx.x; i < sizeof(DevState) / 4; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x == 0 && extra) out->extra = *extra;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void k_reset_call_state(DevState* st) {
   st->new_count = 0;
   st->error = 0;
@@ -1848,6 +1869,9 @@ struct vbx_ctx {
   hipStream_t stream = nullptr;
   DevState* d_state = nullptr;
   DevState h_state{};
+  StateMirror* h_mirror = nullptr;  // page-locked, mapped (may stay null: plain copies are used then)
+  StateMirror* d_mirror = nullptr;
+  uint32_t sync_seq = 0;
   std::string err;
 
   // pool / map storage
@@ -1896,10 +1920,34 @@ namespace {
 
 inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
-int sync_state(vbx_ctx* ctx) {
-  HIP_TRY(hipMemcpyAsync(&ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost,
-                         ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+// Reads DevState (and optionally one more device word) back to the host; on return everything
+// queued on the stream before the call has completed.
+int sync_state(vbx_ctx* ctx, const uint32_t* d_extra = nullptr, uint32_t* extra_out = nullptr) {
+  if (!ctx->h_mirror) {
+    HIP_TRY(hipMemcpyAsync(&ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+    if (d_extra) HIP_TRY(hipMemcpyAsync(extra_out, d_extra, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VBX_OK;
+  }
+  const uint32_t seq = ++ctx->sync_seq;
+  hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, ctx->d_mirror, d_extra, seq);
+  HIP_TRY(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (__atomic_load_n(&ctx->h_mirror->seq, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFFu) == 0 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      // long-running or failed work: block, and let the runtime report an error if there is one
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (__atomic_load_n(&ctx->h_mirror->seq, __ATOMIC_ACQUIRE) != seq) {
+        ctx->fail("device state read-back did not arrive");
+        return VBX_ERR_HIP;
+      }
+      break;
+    }
+  }
+  std::memcpy(&ctx->h_state, &ctx->h_mirror->st, sizeof(DevState));
+  if (d_extra) *extra_out = ctx->h_mirror->extra;
   return VBX_OK;
 }
 
@@ -2154,8 +2202,8 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
   if (rc) return rc;
   uint32_t nb = 0;
-  HIP_TRY(hipMemcpyAsync(&nb, ctx->b_rank.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  rc = sync_state(ctx, ctx->b_rank.as<uint32_t>() + n, &nb);
+  if (rc) return rc;
   if (nb == 0) return VBX_OK;
   rc = ensure_tab(ctx, true, nb, true);
   if (rc) return rc;
@@ -2406,8 +2454,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   // offsets of the keys each ray emits
   rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(&total, ctx->b_rank.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  rc = sync_state(ctx, ctx->b_rank.as<uint32_t>() + R, &total);
+  if (rc) return rc;
   ctx->counters.iterations = iters_total;
   tmark(ctx, 3);
   hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
@@ -2780,6 +2828,21 @@ vbx_ctx* vbx_create(const vbx_map_cfg* cfg, int device) {
       !ok(ctx->b_newlist.ensure((size_t)m.cap_blocks * 4)) ||
       !ok(hipMalloc((void**)&ctx->d_state, sizeof(DevState))))
     return bail(ctx, "vbx_create: out of device memory for the block pool");
+  {  // host-visible state mirror (optional: VBX_NO_MIRROR=1 or a failed allocation fall back to copies)
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (!getenv("VBX_NO_MIRROR") &&
+        hipHostMalloc(&hp, sizeof(StateMirror), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+        std::memset(hp, 0, sizeof(StateMirror));
+        ctx->h_mirror = static_cast<StateMirror*>(hp);
+        ctx->d_mirror = static_cast<StateMirror*>(dp);
+      } else {
+        (void)hipHostFree(hp);
+      }
+    }
+    (void)hipGetLastError();
+  }
   m.hkeys = ctx->b_hkeys.as<uint64_t>();
   m.hvals = ctx->b_hvals.as<uint32_t>();
   m.dist = ctx->b_dist.as<float>();
@@ -2816,6 +2879,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
+  if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
   for (int i = 0; i < 8; ++i)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
