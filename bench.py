@@ -230,21 +230,42 @@ def main():
                                    "map distributed by block owner")},
     }
     if rank == 0:
-        # Roofline of the dominant stage (HIP events on the launch stream, averaged over the
-        # K timed frames).  Algorithmic bytes per frame:
-        #   16 B x N_points + 24 B x U (distinct voxels updated), U counted by the fold kernel.
+        # Roofline of the dominant kernel.  For the Fast integrator that is k_fast_sweep, launched
+        # ~20 times per frame by the early-termination solver; its "launch" here is one frame's
+        # whole sweep sequence, timed with HIP events on the launch stream inside the library
+        # (vbx_get_timing solve_ms) and averaged over the K timed frames.  The per-launch average
+        # (kernel_ms / launches_per_step) is the number to compare with rocprofv3's avg duration
+        # (profiles/r01b_kernel_stats.md).  Algorithmic bytes per frame:
+        #   16 B x N_points + 24 B x U (distinct voxels updated), U counted on the device.
         U = counters.get("voxels_touched", 0) / K
         alg_bytes = 16.0 * n_pts + 24.0 * U
         stages = {k: v / K for k, v in stage.items() if k != "total_ms"}
         dom = max(stages, key=stages.get) if stages else "total_ms"
         dom_ms = stages.get(dom, 0.0)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        kernel_of_stage = {"solve_ms": "k_fast_sweep", "fold_ms": "k_fold", "emit_ms": "k_ray_emit",
+                           "prep_ms": "k_prep_points+sort", "alloc_ms": "k_fast_build_lists", "sort_ms": "rocprim onesweep"}
+        kname = kernel_of_stage.get(dom, dom)
+        launches = (counters.get("iterations", 0) / K) if dom == "solve_ms" else 1.0
+        # HBM bytes of that kernel per frame from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+        # runs, profiles/r01b_pmc_hbm_traffic.json); null when no summary for this kernel exists.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm_traffic.json")))["per_frame_bytes"]
+            if args.integrator == "fast" and args.scene == "room" and kname in pmc:
+                traffic = int(pmc[kname]["fetch_bytes"] + pmc[kname]["write_bytes"])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
-                           "kernel": dom, "kernel_ms": round(dom_ms, 4),
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                           "kernel": kname, "launch": "all launches of one frame (stage %s)" % dom,
+                           "kernel_ms": round(dom_ms, 4), "launches_per_step": round(launches, 1),
+                           "avg_launch_us": round(dom_ms * 1e3 / max(launches, 1.0), 2),
                            "algorithmic_bytes_per_launch": int(alg_bytes),
                            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-                           "device_total_ms": round(stage.get("total_ms", 0.0) / K, 4)}
+                           "device_total_ms": round(stage.get("total_ms", 0.0) / K, 4),
+                           "note": "latency/atomic bound irregular path, far below the HBM roofline (SURVEY 8(d)); "
+                                   "traffic = PMC FETCH_SIZE+WRITE_SIZE of this kernel per frame"}
         out["counters_per_step"] = {k: round(v / K, 1) for k, v in counters.items()}
         if args.esdf:
             out["esdf"] = {"ms_per_update": round(esdf_ms[0] / K, 4),

@@ -2515,6 +2515,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters.voxels_touched = ctx->h_state.voxels_touched;
   ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
   if (ctx->timing) {
+    (void)hipEventSynchronize(ctx->ev[7]);  // the state read-back spins on mapped memory; the runtime may not have retired the events yet
     float t[8] = {0};
     int last = 0;
     for (int i = 1; i < 8; ++i) {  // a stage a path skips reads as zero-length
@@ -2663,6 +2664,7 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   ctx->counters.esdf_sweeps = sweeps;
   ctx->counters.esdf_relaxations = ctx->h_state.esdf_relax_blocks;
   if (ctx->timing) {
+    (void)hipEventSynchronize(ctx->ev[7]);
     vbx_timing& o = ctx->last_timing;
     o = vbx_timing{};
     float t = 0;
