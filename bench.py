@@ -39,6 +39,10 @@ def parse():
                     help="BASELINE configs[3]: EsdfIntegrator::updateFromTsdfLayer(true) after every frame")
     ap.add_argument("--scene", default="room", choices=["room", "cow"],
                     help="room = configs[1]/[3] stream; cow = configs[2] Cow-and-Lady-style orbit")
+    ap.add_argument("--voxel", type=float, default=VOXEL,
+                    help="voxel size (default = configs[1]'s 0.05 m; 0.02 = configs[4]'s resolution); "
+                         "truncation stays 4 voxels")
+    ap.add_argument("--max-blocks", type=int, default=0, help="block pool capacity (0 = sized from --voxel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mirror-frames", type=int, default=8,
                     help="extra untimed-for-`value` frames that also mirror the touched blocks to the host "
@@ -47,7 +51,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(frames, kind):
+def cpu_baseline(frames, kind, voxel=VOXEL):
     """Times the oracle (CPU restatement of the reference, reference threading scheme) on a
     bounded sample of the same stream: threads = host cores, median frame after 3 warm-ups."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -61,10 +65,10 @@ def cpu_baseline(frames, kind):
     best = None
     for threads in sorted({1, min(cores, 8), cores}):
         L.orc_fast_reset_counter_set(0)
-        m = O.OracleMap(VOXEL, 16, L=L)
+        m = O.OracleMap(voxel, 16, L=L)
         c = O.TsdfCfg()
         L.orc_tsdf_cfg_default(ctypes.byref(c))
-        c.default_truncation_distance = TRUNC
+        c.default_truncation_distance = 4 * voxel
         c.integrator_threads = threads
         it = m.tsdf_integrator(kind, c)
         ts = []
@@ -121,20 +125,23 @@ def main():
     n_pts = frames[0][1].shape[0]
     n_pts_all = [f[1].shape[0] for f in frames]
 
-    gm = capi.Map(VOXEL, 16, max_blocks=8192, device=local_rank)
+    voxel = float(args.voxel)
+    trunc = 4 * voxel
+    max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3))
+    gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
     gm.set_stream(torch.cuda.current_stream().cuda_stream)
-    cfg = capi.tsdf_cfg(default_truncation_distance=TRUNC)
+    cfg = capi.tsdf_cfg(default_truncation_distance=trunc)
     sharded = None
     if world > 1:
         # Ray-bundle sharding: gm is this rank's per-frame delta map; the
         # persistent map is distributed by block ownership and fed by an RCCL reduce-scatter.
         from voxblox_amd import multi_gpu
-        pm = capi.Map(VOXEL, 16, max_blocks=8192, device=local_rank)
+        pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
         pm.set_stream(torch.cuda.current_stream().cuda_stream)
         sharded = multi_gpu.ShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), multi_gpu.GpuBackend(gm, dev),
                                            rank, world, dist)
 
-    ecfg = capi.esdf_cfg(min_distance_m=TRUNC / 2)  # ros_params.h:136-137
+    ecfg = capi.esdf_cfg(min_distance_m=trunc / 2)  # ros_params.h:136-137
     esdf_ms = [0.0]
 
     def step(i):
@@ -218,13 +225,13 @@ def main():
     pts_timed = sum(n_pts_all[i % len(d_frames)] for i in range(args.warmup, total))
     value = world * pts_timed / dt / 1e6
     out = {
-        "metric": "Mpoints/s integrated (640x480 frame, 0.05 m voxels) + achieved HBM GB/s",
+        "metric": "Mpoints/s integrated (640x480 frame, %g m voxels) + achieved HBM GB/s" % voxel,
         "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": K,
         "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.integrator.capitalize()}TsdfIntegrator, 640x480 synthetic room scan "
-                               "stream (BASELINE configs[1]), 0.05 m voxels / 16^3 blocks, trunc 0.2 m",
-                   "points_per_step": n_pts, "voxel_size": VOXEL, "voxels_per_side": 16,
+                               "stream (BASELINE configs[1]), %g m voxels / 16^3 blocks, trunc %g m" % (voxel, trunc),
+                   "points_per_step": n_pts, "voxel_size": voxel, "voxels_per_side": 16,
                    "parallelism": ("1 GPU, whole cloud" if world == 1 else
                                    f"{world} sensors, one ray shard per GPU, RCCL reduce-scatter block merge, "
                                    "map distributed by block owner")},
@@ -276,7 +283,7 @@ def main():
         out["config"]["esdf_after_each_frame"] = bool(args.esdf)
         if world == 1 and not args.no_cpu_baseline:
             nf = args.cpu_frames or 40
-            out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator)
+            out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator, voxel)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -146,3 +146,14 @@ def test_fast_clear_checks_every_n_frames(oracle, n_frames):
     # fewer voxels are re-observed than with a per-frame reset
     _, _, gm1 = _run(oracle, "fast", 0.05, frames, oracle_fast_exact_observed_set=1)
     assert gm.tsdf_dict().keys() <= gm1.tsdf_dict().keys()
+
+
+def test_fast_and_simple_fine_voxels_0p02(oracle):
+    """BASELINE configs[4] resolution (0.02 m, truncation 0.08): per-ray lists of several hundred
+    voxels, ~10x the blocks; bit-exact like the 0.05 m cases."""
+    frames = [_small_room(k) for k in (0, 9)]
+    om, oi, gm = _run(oracle, "fast", 0.02, frames, max_blocks=32768, oracle_fast_exact_observed_set=1)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    assert gm.num_blocks() > 2000
+    om, oi, gm = _run(oracle, "simple", 0.02, frames[:1], max_blocks=32768)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
