@@ -104,7 +104,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_sharded = bool(os.environ.get("VBX_FORCE_SHARDED")) and "RANK" in os.environ
+    if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -132,7 +133,7 @@ def main():
     gm.set_stream(torch.cuda.current_stream().cuda_stream)
     cfg = capi.tsdf_cfg(default_truncation_distance=trunc)
     sharded = None
-    if world > 1:
+    if world > 1 or force_sharded:
         # Ray-bundle sharding: gm is this rank's per-frame delta map; the
         # persistent map is distributed by block ownership and fed by an RCCL reduce-scatter.
         from voxblox_amd import multi_gpu
@@ -285,7 +286,7 @@ def main():
             nf = args.cpu_frames or 40
             out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator, voxel)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 

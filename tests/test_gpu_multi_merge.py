@@ -146,3 +146,24 @@ def test_two_process_sharded_fast_on_one_gpu(oracle):
         assert np.allclose(gw, rw, rtol=1e-5, atol=1e-6)
         assert np.abs(gd - rd).max() <= 1e-5
         assert np.abs(gc.astype(np.int32) - rc.astype(np.int32)).max() <= 1
+
+
+def test_bench_sharded_path_over_rccl_single_rank():
+    """bench.py's N>1 code path (delta map, key all-gather, RCCL reduce_scatter_tensor, owner
+    merge) launched exactly like the driver launches it, with one rank: the RCCL calls run for
+    real, and the throughput line must come out well-formed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from test_multi_gpu_gloo import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBX_FORCE_SHARDED="1", VBX_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--mirror-frames", "0"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["steps"] == 4

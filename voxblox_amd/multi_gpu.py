@@ -66,11 +66,14 @@ class ShardedTsdfMap:
         self.dist = dist
         self.apply_caps, self.trunc, self.max_weight = apply_caps, truncation, max_weight
         self.last = {}
+        # run the collectives even with one rank (exercises the RCCL calls on a 1-GPU box)
+        import os
+        self.force_collectives = bool(os.environ.get("VBX_FORCE_COLLECTIVES")) and dist is not None
 
     # -- collectives ------------------------------------------------------------------------
     def _gather_keys(self, keys):
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return [keys]
         # RCCL moves device tensors; gloo (CPU tests) gathers host tensors
         dev = self.d.device if self.dist.get_backend() == "nccl" else torch.device("cpu")
@@ -89,7 +92,7 @@ class ShardedTsdfMap:
     def _reduce_scatter(self, sums, L):
         """sums: [world*L, 6, nvox] -> this rank's [L, 6, nvox] chunk of the elementwise sum."""
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return sums
         if self.dist.get_backend() == "nccl":
             out = torch.empty((L,) + tuple(sums.shape[1:]), dtype=sums.dtype, device=sums.device)
