@@ -61,3 +61,23 @@ def layer_stats(a, b, obs_eps=1e-6):
             max_err = max(max_err, float(np.abs(e).max()))
     rmse = (se / n_both) ** 0.5 if n_both else 0.0
     return dict(rmse=rmse, max_err=max_err, both=n_both, a_only=n_a_only, b_only=n_b_only)
+
+
+def clear_sphere_assertions(tsdf, esdf, min_distance_m):
+    """The assertions of test_clear_spheres.cc:175-203 over {block: (d, w, rgba, upd)} /
+    {block: (d, flags, parent, upd)} dicts.  Returns (#band voxels, #hallucinated voxels)."""
+    import numpy as np
+    n_band = n_hall = 0
+    for b, (td, tw, _, _) in tsdf.items():
+        assert b in esdf, f"ESDF lacks TSDF block {b}"                    # ASSERT_TRUE(esdf_layer.hasBlock)
+        ed, ef, _, _ = esdf[b]
+        obs = (ef & 1).astype(bool)
+        hall = (ef & 2).astype(bool)
+        unobserved_tsdf = tw < 1e-6
+        assert np.all(hall[unobserved_tsdf & obs]), "observed ESDF voxel without TSDF data must be hallucinated"
+        band = (tw > 1e-6) & (np.abs(td) <= np.float32(min_distance_m))
+        assert np.all(obs[band]) and not np.any(hall[band])
+        assert np.array_equal(np.sign(td[band]), np.sign(ed[band]))
+        assert np.abs(td[band] - ed[band]).max(initial=0.0) <= 1e-3
+        n_band += int(band.sum()); n_hall += int(hall.sum())
+    return n_band, n_hall

@@ -253,3 +253,35 @@ def test_esdf_robot_position_stream_envelope_vs_reference(oracle):
     n, nh, rmse = _check_robot(_gpu_esdf(gm), om.esdf_dict(), exact=False)
     assert n > 100000 and nh > 1000
     assert rmse < 1e-2, rmse
+
+
+@pytest.mark.parametrize("voxel", [0.1, 0.2])
+def test_clear_spheres_reference_test_on_gpu(oracle, voxel):
+    """The reference's own ClearSphereTest.EsdfIntegrators (test_clear_spheres.cc:107-203) through
+    the HIP path, plus block/mask agreement with the oracle run on the same inputs."""
+    from parity_utils import clear_sphere_assertions
+    from voxblox_amd import capi
+    sph = dict(max_distance_m=4.0, default_distance_m=4.0, min_distance_m=2 * voxel, min_diff_m=0.0,
+               clear_sphere_radius=1.0, occupied_sphere_radius=4.0)
+    gm = capi.Map(voxel, 16, max_blocks=4096)
+    gt = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    ge = capi.esdf_cfg(**sph)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1,
+                                                      oracle_merged_sorted_bundles=1))
+    oe = om.esdf_integrator(oracle.esdf_cfg(oracle_orderfree_sign_mismatch=1, **sph))
+    for k in (0, 20):
+        pose, pts, col = scenes.room_frame(k, 100, f=80.0, width=160, height=120)
+        gm.esdf_add_new_robot_position(ge, pose[0])
+        gm.integrate(capi.TSDF_MERGED, gt, pose[0], pose[1], pts, col)
+        gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+        oe.add_new_robot_position(pose[0])
+        oi.integrate(pose[0], pose[1], pts, col)
+        oe.update_from_tsdf_layer(True)
+    g = _gpu_esdf(gm)
+    n_band, n_hall = clear_sphere_assertions(gm.tsdf_dict(), g, 2 * voxel)
+    assert n_band > 500 and n_hall > 1000
+    r = om.esdf_dict()
+    n, nh, rmse = _check_robot(g, r, exact=False)
+    assert rmse < 1e-2, rmse

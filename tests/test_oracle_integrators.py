@@ -187,3 +187,35 @@ def test_esdf_incremental_matches_batch_envelope(oracle):
         e = (a[k][0][oa] - b[k][0][oa]).astype(np.float64)
         se += float((e * e).sum()); n += int(oa.sum())
     assert n > 1000 and (se / n) ** 0.5 < 1e-2
+
+
+@pytest.mark.parametrize("voxel", [0.1, 0.2])
+def test_clear_spheres_restated(oracle, voxel):
+    """test_clear_spheres.cc:107-203 (ClearSphereTest.EsdfIntegrators, voxel sizes 0.1 / 0.2):
+    addNewRobotPosition -> integrate (Merged, 1 thread) -> updateFromTsdfLayer(true), twice from
+    two poses; then every voxel inside the fixed band must be observed, not hallucinated and
+    carry the TSDF distance within 1e-3, and every ESDF voxel observed without TSDF data must
+    be hallucinated.  ESDF config as in the reference test (max = default = 4 m, min_diff 0,
+    clear sphere 1 m, occupied sphere 4 m).  Run on the restatement and, when built, on the
+    reference's own sources."""
+    import ctypes as C
+    from parity_utils import clear_sphere_assertions
+    libs = [oracle.lib()] + ([oracle.ref_lib()] if oracle.ref_available() else [])
+    for L in libs:
+        L.orc_fast_reset_counter_set(0)
+        m = oracle.OracleMap(voxel, 16, L=L)
+        tc = oracle.TsdfCfg(); L.orc_tsdf_cfg_default(C.byref(tc))
+        tc.default_truncation_distance = 4 * voxel
+        tc.integrator_threads = 1
+        it = m.tsdf_integrator("merged", tc)
+        ec = oracle.EsdfCfg(); L.orc_esdf_cfg_default(C.byref(ec))
+        ec.max_distance_m = 4.0; ec.default_distance_m = 4.0; ec.min_distance_m = 2 * voxel
+        ec.min_diff_m = 0.0; ec.clear_sphere_radius = 1.0; ec.occupied_sphere_radius = 4.0
+        e = m.esdf_integrator(ec)
+        for k in (0, 20):                                   # two poses 72 degrees apart, like poses_[0], poses_[2]
+            pose, pts, col = scenes.room_frame(k, 100, f=80.0, width=160, height=120)
+            e.add_new_robot_position(pose[0])
+            it.integrate(pose[0], pose[1], pts, col)
+            e.update_from_tsdf_layer(True)
+        n_band, n_hall = clear_sphere_assertions(m.tsdf_dict(), m.esdf_dict(), 2 * voxel)
+        assert n_band > 500 and n_hall > 1000
