@@ -43,3 +43,43 @@ def test_blocks_download_equals_per_block():
     with pytest.raises(Exception):
         gm.blocks_download(np.array([[1000, 1000, 1000]], np.int32))
     assert gm.blocks_download(np.zeros((0, 3), np.int32))[0].shape[0] == 0
+
+
+def test_remove_distant_blocks_matches_reference(oracle):
+    """Layer::removeDistantBlocks (layer.h:170-182; caller tsdf_server.cc:315) on both layers:
+    same surviving blocks as the oracle, survivors untouched, and integration goes on afterwards."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    gm = capi.Map(voxel, 16, max_blocks=2048)
+    om = oracle.OracleMap(voxel, 16)
+    gcfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    oi = om.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    frames = [scenes.room_frame(k, 100, f=40.0, width=80, height=60) for k in (0, 30, 60)]
+    for pose, pts, col in frames[:2]:
+        gm.integrate(capi.TSDF_SIMPLE, gcfg, pose[0], pose[1], pts, col)
+        oi.integrate(pose[0], pose[1], pts, col)
+    ecfg = capi.esdf_cfg(min_distance_m=2 * voxel)
+    gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+    oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=2 * voxel))
+    oe.update_from_tsdf_layer(True)
+    before = gm.tsdf_dict()
+    center = np.array([0.5, -0.2, -1.0], np.float32)
+    gm.remove_distant_blocks(center, 2.5, capi.LAYER_TSDF)
+    om.remove_distant_blocks(center, 2.5, 0)
+    gm.remove_distant_blocks(center, 3.0, capi.LAYER_ESDF)
+    om.remove_distant_blocks(center, 3.0, 1)
+    got, ref = gm.tsdf_dict(), om.tsdf_dict()
+    assert set(got) == set(ref) and 0 < len(got) < len(before)
+    for k in got:
+        assert np.array_equal(got[k][0], before[k][0]) and np.array_equal(got[k][1], before[k][1])
+    ge = {tuple(int(x) for x in i) for i in gm.block_indices(capi.LAYER_ESDF)}
+    assert ge == set(om.esdf_dict().keys()) and len(ge) > len(got)     # the layers are independent
+    # removed blocks come back as fresh blocks when observed again
+    pose, pts, col = frames[2]
+    gm.integrate(capi.TSDF_SIMPLE, gcfg, pose[0], pose[1], pts, col)
+    oi.integrate(pose[0], pose[1], pts, col)
+    got, ref = gm.tsdf_dict(), om.tsdf_dict()
+    assert set(got) == set(ref)
+    for k in ref:
+        assert np.array_equal(got[k][0].view(np.uint32), ref[k][0].view(np.uint32))
+        assert np.array_equal(got[k][1].view(np.uint32), ref[k][1].view(np.uint32))

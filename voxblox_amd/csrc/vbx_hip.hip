@@ -1411,6 +1411,36 @@ __global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const
   if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) publish_block(m, slot, st);
 }
 
+// Layer::removeDistantBlocks (layer.h:170-182) for every block of one layer in one launch: a
+// workgroup per pool slot; (origin - center).squaredNorm() > max^2 with origin = float(index) *
+// block_size (common.h:195-201).  A removed block is zeroed and leaves the layer; its hash
+// entry and pool slot stay (an invisible candidate again).
+__global__ void k_remove_distant(MapDev m, float* edist, uint32_t* estate, int layer, f3 center, double max_sq,
+                                 float block_size) {
+  const uint32_t slot = blockIdx.x;
+  const uint32_t f = m.blk_flags[slot];
+  const uint32_t need = (layer == VBX_LAYER_ESDF) ? kFlagEsdfAlloc : kFlagPublished;
+  if (!(f & need)) return;
+  const f3 o{(float)m.blk_idx[3 * slot] * block_size, (float)m.blk_idx[3 * slot + 1] * block_size,
+             (float)m.blk_idx[3 * slot + 2] * block_size};
+  if (!((double)f3_sqnorm(f3_sub(o, center)) > max_sq)) return;
+  const size_t base = (size_t)slot * m.nvox;
+  if (layer == VBX_LAYER_ESDF) {
+    if (edist)
+      for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) { edist[base + v] = 0.f; estate[base + v] = 0u; }
+  } else {
+    for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+      m.dist[base + v] = 0.f; m.weight[base + v] = 0.f; m.rgba[base + v] = 0u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // the two layers are independent (layer.h:167): keep the other layer's membership and bits
+    const uint32_t esdf_bits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen;
+    m.blk_flags[slot] = (layer == VBX_LAYER_ESDF) ? (f & ~esdf_bits) : (f & esdf_bits);
+  }
+}
+
 // Block::updated().reset(bits) on every block of one layer
 __global__ void k_clear_update_bits(MapDev m, uint32_t n_slots, uint32_t need, uint32_t bits) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3232,22 +3262,20 @@ int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]) {
 
 int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance) {
   if (!ctx || !center) return VBX_ERR_INVALID;
-  std::vector<std::pair<uint64_t, uint32_t>> v;
-  int rc = list_blocks(ctx, layer, 0, &v);
-  if (rc) return rc;
-  // Layer::removeDistantBlocks, layer.h:170-182: (origin - center).squaredNorm() > max^2 with
-  // origin = float(index) * block_size (common.h:195-201), block_size = voxel_size * vps.
-  const float block_size = ctx->map.voxel_size * (float)ctx->map.vps;
-  for (const auto& kv : v) {
-    int x, y, z;
-    unpack_block_key(kv.first, &x, &y, &z);
-    const f3 o{(float)x * block_size, (float)y * block_size, (float)z * block_size};
-    const f3 d = f3_sub(o, f3{center[0], center[1], center[2]});
-    if ((double)f3_sqnorm(d) > max_distance * max_distance) {
-      rc = remove_slot(ctx, layer, kv.second, 0);
-      if (rc) return rc;
-    }
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+    ctx->fail("unknown layer %d", layer);
+    return VBX_ERR_INVALID;
   }
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  if (used == 0) return VBX_OK;
+  const float block_size = ctx->map.voxel_size * (float)ctx->map.vps;
+  hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map,
+                     ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,
+                     ctx->esdf_init ? ctx->b_estate.as<uint32_t>() : (uint32_t*)nullptr, layer,
+                     f3{center[0], center[1], center[2]}, max_distance * max_distance, block_size);
   return VBX_OK;
 }
 
