@@ -83,3 +83,34 @@ def test_remove_distant_blocks_matches_reference(oracle):
     for k in ref:
         assert np.array_equal(got[k][0].view(np.uint32), ref[k][0].view(np.uint32))
         assert np.array_equal(got[k][1].view(np.uint32), ref[k][1].view(np.uint32))
+
+
+def test_block_upload_round_trip_both_layers():
+    """loadMap / tsdfMapCallback path (tsdf_server.cc:566-578, 639-653): blocks written into a
+    fresh map through vbx_block_upload read back identically, for both layers, and uploading one
+    layer leaves the other layer's block alone."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    src = capi.Map(voxel, 16, max_blocks=1024)
+    cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    pose, pts, col = scenes.room_frame(3, 100, f=40.0, width=80, height=60)
+    src.integrate(capi.TSDF_MERGED, cfg, pose[0], pose[1], pts, col)
+    src.esdf_update(capi.esdf_cfg(min_distance_m=2 * voxel), batch=True, clear_updated_flag=False)
+    dst = capi.Map(voxel, 16, max_blocks=1024)
+    idx = src.block_indices(capi.LAYER_ESDF)
+    ev, eu, _ = src.blocks_download(idx, capi.LAYER_ESDF)
+    tv, tu, thd = src.blocks_download(idx, capi.LAYER_TSDF)
+    for k, i in enumerate(idx):                      # ESDF first: TSDF upload must not disturb it
+        dst.block_upload(i, ev[k], int(eu[k]), 0, capi.LAYER_ESDF)
+    assert dst.num_blocks(capi.LAYER_TSDF) == 0 and dst.num_blocks(capi.LAYER_ESDF) == len(idx)
+    for k, i in enumerate(idx):
+        dst.block_upload(i, tv[k], int(tu[k]), int(thd[k]), capi.LAYER_TSDF)
+    ev2, eu2, _ = dst.blocks_download(idx, capi.LAYER_ESDF)
+    tv2, tu2, thd2 = dst.blocks_download(idx, capi.LAYER_TSDF)
+    assert ev2.tobytes() == ev.tobytes() and np.array_equal(eu2, eu)
+    assert tv2.tobytes() == tv.tobytes() and np.array_equal(tu2, tu) and np.array_equal(thd2, thd)
+    # overwrite of an existing block
+    z = np.zeros(4096, capi.ESDF_VOXEL_DTYPE)
+    dst.block_upload(idx[0], z, 0, 0, capi.LAYER_ESDF)
+    assert dst.block_download(idx[0], capi.LAYER_ESDF)[0].tobytes() == z.tobytes()
+    assert dst.block_download(idx[0], capi.LAYER_TSDF)[0].tobytes() == tv[0].tobytes()

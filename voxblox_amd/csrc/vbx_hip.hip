@@ -3160,16 +3160,23 @@ int vbx_blocks_download(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, v
 int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos, uint8_t updated_bits,
                      uint8_t has_data) {
   if (!ctx || !idx || !aos) return VBX_ERR_INVALID;
-  if (layer != VBX_LAYER_TSDF) {
-    ctx->fail("ESDF layer not implemented yet");
-    return VBX_ERR_UNSUPPORTED;
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+    ctx->fail("unknown layer %d", layer);
+    return VBX_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
+  int rc = VBX_OK;
+  if (layer == VBX_LAYER_ESDF) {
+    rc = esdf_ensure(ctx);
+    if (rc) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   uint32_t slot;
-  int rc = find_slot_host(ctx, idx, &slot, nullptr);
+  rc = find_slot_host(ctx, idx, &slot, nullptr);
   if (rc) return rc;
   MapDev& m = ctx->map;
+  uint32_t old_flags = 0;
+  if (slot != kInvalidSlot) HIP_TRY(hipMemcpy(&old_flags, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
   if (slot == kInvalidSlot) {
     // host-side insert: take a slot from the free list or the bump pointer
     rc = sync_state(ctx);
@@ -3199,6 +3206,26 @@ int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* 
     HIP_TRY(hipMemcpy(m.blk_idx + 3 * slot, idx, 12, hipMemcpyHostToDevice));
   }
   const uint32_t nv = m.nvox;
+  const uint32_t esdf_bits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen;
+  if (layer == VBX_LAYER_ESDF) {  // EsdfVoxel AoS (voxel.h:18-37) -> distance + packed state
+    std::vector<float> d(nv);
+    std::vector<uint32_t> st(nv);
+    const uint8_t* in = static_cast<const uint8_t*>(aos);
+    for (uint32_t i = 0; i < nv; ++i) {
+      std::memcpy(&d[i], in + 20 * i, 4);
+      int32_t par[3];
+      std::memcpy(par, in + 20 * i + 8, 12);
+      st[i] = (in[20 * i + 4] ? 1u : 0u) | (in[20 * i + 5] ? 2u : 0u) | (in[20 * i + 6] ? 4u : 0u) |
+              (in[20 * i + 7] ? 8u : 0u) | ((uint32_t)(uint8_t)(int8_t)par[0] << 8) |
+              ((uint32_t)(uint8_t)(int8_t)par[1] << 16) | ((uint32_t)(uint8_t)(int8_t)par[2] << 24);
+    }
+    HIP_TRY(hipMemcpy(ctx->b_edist.as<float>() + (size_t)slot * nv, d.data(), nv * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->b_estate.as<uint32_t>() + (size_t)slot * nv, st.data(), nv * 4, hipMemcpyHostToDevice));
+    const uint32_t flags = (old_flags & ~esdf_bits) | kFlagEsdfAlloc |
+                           (((uint32_t)updated_bits & kFlagUpdMask) << kFlagEsdfUpdShift);
+    HIP_TRY(hipMemcpy(m.blk_flags + slot, &flags, 4, hipMemcpyHostToDevice));
+    return VBX_OK;
+  }
   std::vector<float> d(nv), w(nv);
   std::vector<uint32_t> c(nv);
   const uint8_t* in = static_cast<const uint8_t*>(aos);
@@ -3210,7 +3237,8 @@ int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* 
   HIP_TRY(hipMemcpy(m.dist + (size_t)slot * nv, d.data(), nv * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m.weight + (size_t)slot * nv, w.data(), nv * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m.rgba + (size_t)slot * nv, c.data(), nv * 4, hipMemcpyHostToDevice));
-  const uint32_t flags = kFlagPublished | (updated_bits & kFlagUpdMask) | (has_data ? kFlagHasData : 0);
+  // the ESDF layer's membership of the same slot is untouched (the layers are independent)
+  const uint32_t flags = (old_flags & esdf_bits) | kFlagPublished | (updated_bits & kFlagUpdMask) | (has_data ? kFlagHasData : 0);
   HIP_TRY(hipMemcpy(m.blk_flags + slot, &flags, 4, hipMemcpyHostToDevice));
   return VBX_OK;
 }
