@@ -1679,8 +1679,9 @@ __global__ void k_esdf_rotate_active(EsdfDev e, uint32_t n_slots, int reseed) {
 //           voxel whose parent voxel was raised is reset to sign*default and raised itself.
 //   mode 1: processOpenSet (:371-496) as a pull relaxation over the 26-neighbourhood.
 //   mode 2: parent = first LUT neighbour that explains the converged distance exactly.
+constexpr int kEsdfThreads = 1024;  // one workgroup relaxes one block; big frontiers need the lanes
 template <int VPS>
-__global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
+__global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
                                                    DevState* st) {
   constexpr int T = VPS + 2;
   constexpr int NT = T * T * T;
@@ -1706,7 +1707,7 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
   if (tid == 0) s_flag = 0;
   __syncthreads();
 #pragma unroll 4
-  for (int t = tid; t < NT; t += 256) {
+  for (int t = tid; t < NT; t += kEsdfThreads) {
     const int tx = t % T, ty = (t / T) % T, tz = t / (T * T);
     const int bx = (tx == 0) ? 0 : (tx == T - 1 ? 2 : 1);
     const int by = (ty == 0) ? 0 : (ty == T - 1 ? 2 : 1);
@@ -1778,16 +1779,16 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
     // proportional to the number of changes, not to iterations x block size.  (A push-based
     // queue with an atomic visited bitset was measured slower: 3.1 vs 2.2 ms per update.)
     uint8_t* s_need = s_r;  // the raise marks are not used while lowering
-    for (int t = tid; t < NT; t += 256) s_need[t] = 0;
+    for (int t = tid; t < NT; t += kEsdfThreads) s_need[t] = 0;
     __syncthreads();
-    for (int v = tid; v < NV; v += 256) {
+    for (int v = tid; v < NV; v += kEsdfThreads) {
       const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
       s_need[(lx + 1) + T * ((ly + 1) + T * (lz + 1))] = 1;  // first pass: everything
     }
     for (int iter = 0; iter < 64 * VPS; ++iter) {
       if (tid == 0) s_qn = 0;
       __syncthreads();
-      for (int v = tid; v < NV; v += 256) {
+      for (int v = tid; v < NV; v += kEsdfThreads) {
         const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
         const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
         if (s_need[t]) {
@@ -1799,7 +1800,7 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
       __syncthreads();
       const int qn = s_qn;
       if (qn == 0) break;
-      for (int q = tid; q < qn; q += 256) {
+      for (int q = tid; q < qn; q += kEsdfThreads) {
         const int t = s_q[q];
         if (relax(t)) {
           any_change = true;
@@ -1812,7 +1813,7 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
   } else {
   for (int iter = 0; iter < 4 * VPS; ++iter) {
     bool changed = false;
-    for (int v = tid; v < NV; v += 256) {
+    for (int v = tid; v < NV; v += kEsdfThreads) {
       const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
       const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
       uint32_t s = s_s[t];
@@ -1868,7 +1869,7 @@ __global__ void __launch_bounds__(256) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgD
   if (any_change) s_flag = 1;
   __syncthreads();
   if (!s_flag) return;
-  for (int v = tid; v < NV; v += 256) {
+  for (int v = tid; v < NV; v += kEsdfThreads) {
     const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
     const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
     const uint32_t g = slot * NV + v;
@@ -2611,7 +2612,7 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
   hipStream_t s = ctx->stream;
   for (;;) {
     HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
-    hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(256), 0, s, ctx->map, e, c, mode, ctx->d_state);
+    hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, ctx->d_state);
     ++*sweeps;
     if (mode == 2) return VBX_OK;
     hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
