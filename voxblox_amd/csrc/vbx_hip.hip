@@ -442,18 +442,13 @@ __global__ void k_ray_mark_blocks(RayTab tab, CastCfg c, MapDev m, int from_orig
   if (o >= tab.R) return;
   RayCaster rc;
   if (!ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) return;
-  const uint32_t lim = limit ? limit[o] : 0xFFFFFFFFu;
-  uint64_t last_key = kEmptyKey;
-  l3 g;
-  uint32_t k = 0;
-  while (k < lim && rc.next(&g)) {
-    ++k;
-    const i3 b = block_index_from_global(g, m.vps_inv);
-    const uint64_t key = pack_block_key(b.x, b.y, b.z);
-    if (key != last_key) {
-      last_key = key;
-      map_insert_key(m, key, new_list, st);
-    }
+  if (rc.cur != 0) return;
+  const uint32_t n = min(limit ? limit[o] : 0xFFFFFFFFu, rc.steps + 1);
+  BlockWalk bw;
+  bw.start(rc, m.vps, m.vps_inv);
+  for (uint32_t k = 0; k < n; ++k) {
+    if (bw.entered) map_insert_key(m, pack_block_key(bw.bx, bw.by, bw.bz), new_list, st);
+    bw.step(m.vps, m.vps_log2);
   }
 }
 
@@ -461,7 +456,7 @@ __global__ void k_ray_mark_blocks(RayTab tab, CastCfg c, MapDev m, int from_orig
 //   (pool_slot * nvox + linear_index) << 32 | order
 // written at off[o] + k.  Blocks touched are published and get all Update bits
 // (tsdf_integrator.cc:128).  Merged's anti-grazing test (:415-422) is a binary search in
-// the sorted bundle keys.
+// the sorted bundle keys.  The walk is BlockWalk (branch-free steps, no int64 index math).
 __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
                            const uint32_t* __restrict__ limit, const uint32_t* __restrict__ off,
                            uint64_t* keys, const uint64_t* __restrict__ graze_keys,
@@ -470,21 +465,26 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
   if (o >= tab.R) return;
   RayCaster rc;
   if (!ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) return;
-  const uint32_t lim = limit ? limit[o] : 0xFFFFFFFFu;
-  if (lim == 0 || rc.cur != 0) return;
+  if (rc.cur != 0) return;
+  const uint32_t n = min(limit ? limit[o] : 0xFFFFFFFFu, rc.steps + 1);
   const bool clearing = (tab.flags[o] & 2) != 0;
-  uint64_t last_key = kEmptyKey;
+  BlockWalk bw;
+  bw.start(rc, m.vps, m.vps_inv);
+  bool need_lookup = false;
   uint32_t slot = kInvalidSlot;
-  uint32_t base = off[o];
-  l3 g;
-  uint32_t k = 0;
-  while (k < lim && rc.next(&g)) {
+  const uint32_t base = off[o];
+  const uint32_t lmask = (uint32_t)m.vps - 1u;
+  for (uint32_t k = 0; k < n; ++k) {
     uint64_t out = ~0ull;  // sorts last, skipped by the fold
+    need_lookup = need_lookup || bw.entered;
     bool skip = false;
     if (graze_keys) {
       // voxel_map.find(global_voxel_idx) != end && (clearing || idx != kv.first)
-      const uint64_t vk = ((uint64_t)(g.z + (1ll << 20)) << 42) |
-                          ((uint64_t)(g.y + (1ll << 20)) << 21) | (uint64_t)(g.x + (1ll << 20));
+      const long long gx = (long long)bw.bx * m.vps + (long long)(bw.lin & lmask);
+      const long long gy = (long long)bw.by * m.vps + (long long)((bw.lin >> m.vps_log2) & lmask);
+      const long long gz = (long long)bw.bz * m.vps + (long long)((bw.lin >> (2 * m.vps_log2)) & lmask);
+      const uint64_t vk = ((uint64_t)(gz + (1ll << 20)) << 42) | ((uint64_t)(gy + (1ll << 20)) << 21) |
+                          (uint64_t)(gx + (1ll << 20));
       if (clearing || vk != tab.bkey[o]) {
         uint32_t lo = 0, hi = n_graze;
         while (lo < hi) {
@@ -495,26 +495,19 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
       }
     }
     if (!skip) {
-      const i3 b = block_index_from_global(g, m.vps_inv);
-      const uint64_t key = pack_block_key(b.x, b.y, b.z);
-      if (key != last_key) {
-        last_key = key;
-        slot = map_find(m, key);
+      if (need_lookup) {
+        need_lookup = false;
+        slot = map_find(m, pack_block_key(bw.bx, bw.by, bw.bz));
         if (slot == kInvalidSlot) {
           atomicOr(&st->error, 2u);
         } else {
           publish_block(m, slot, st);
         }
       }
-      if (slot != kInvalidSlot) {
-        const i3 l = local_from_global(g, m.vps);
-        const uint32_t lin = (uint32_t)(l.x + m.vps * (l.y + l.z * m.vps));
-        const uint32_t gid = slot * m.nvox + lin;
-        out = ((uint64_t)gid << 32) | o;
-      }
+      if (slot != kInvalidSlot) out = ((uint64_t)(slot * m.nvox + bw.lin) << 32) | o;
     }
     keys[base + k] = out;
-    ++k;
+    bw.step(m.vps, m.vps_log2);
   }
 }
 
