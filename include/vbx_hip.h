@@ -115,6 +115,14 @@ int vbx_tsdf_integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg,
  * batch == 0, EsdfIntegrator::updateFromTsdfLayerBatch() (:94-102) when batch != 0. */
 int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag);
 
+/* EsdfIntegrator::updateFromTsdfBlocks(tsdf_blocks, incremental) (esdf_integrator.cc:124-302): the
+ * same update restricted to the listed TSDF blocks (blocks not in the TSDF layer are skipped); no
+ * Update bit is cleared and the blocks addNewRobotPosition queued stay queued for classification. */
+int vbx_esdf_update_blocks(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const int32_t* idx_xyz, size_t n,
+                           int incremental);
+/* EsdfIntegrator::clear() (esdf_integrator.h:138-142): forget the work addNewRobotPosition queued. */
+int vbx_esdf_integrator_clear(vbx_ctx* ctx);
+
 /* EsdfIntegrator::addNewRobotPosition(position) (esdf_integrator.cc:25-92; caller
  * esdf_server.cc:219-226): unknown or hallucinated voxels within cfg->clear_sphere_radius become
  * free, remaining unknown voxels within cfg->occupied_sphere_radius occupied (both

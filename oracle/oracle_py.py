@@ -103,6 +103,8 @@ def _bind(L):
         "orc_esdf_update_from_tsdf_layer": (None, [vp, C.c_int]),
         "orc_esdf_update_from_tsdf_layer_batch": (None, [vp]),
         "orc_esdf_add_new_robot_position": (None, [vp, f32p]),
+        "orc_esdf_update_from_tsdf_blocks": (None, [vp, i32p, C.c_size_t, C.c_int]),
+        "orc_esdf_integrator_clear": (None, [vp]),
         "orc_esdf_stats": (None, [vp, u64p, C.c_int]),
         "orc_num_blocks": (C.c_size_t, [vp, C.c_int]),
         "orc_block_indices": (C.c_size_t, [vp, C.c_int, i32p, C.c_size_t]),
@@ -308,6 +310,13 @@ class OracleEsdfIntegrator:
 
     def update_from_tsdf_layer_batch(self):
         self.L.orc_esdf_update_from_tsdf_layer_batch(self.h)
+
+    def update_from_tsdf_blocks(self, indices, incremental=False):
+        idx = np.ascontiguousarray(indices, np.int32).reshape(-1, 3)
+        self.L.orc_esdf_update_from_tsdf_blocks(self.h, _p(idx, C.c_int32), idx.shape[0], int(incremental))
+
+    def clear(self):
+        self.L.orc_esdf_integrator_clear(self.h)
 
     def add_new_robot_position(self, position):
         p = np.ascontiguousarray(position, np.float32)

@@ -175,6 +175,12 @@ void orc_esdf_update_from_tsdf_layer(orc_esdf_integrator* it, int clear_updated_
 void orc_esdf_update_from_tsdf_layer_batch(orc_esdf_integrator* it) {
   it->impl->updateFromTsdfLayerBatch();
 }
+void orc_esdf_update_from_tsdf_blocks(orc_esdf_integrator* it, const int32_t* idx, size_t n, int incremental) {
+  std::vector<Idx3> blocks(n);
+  for (size_t i = 0; i < n; ++i) blocks[i] = Idx3{idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]};
+  it->impl->updateFromTsdfBlocks(blocks, incremental != 0);
+}
+void orc_esdf_integrator_clear(orc_esdf_integrator* it) { it->impl->clear(); }
 void orc_esdf_add_new_robot_position(orc_esdf_integrator* it, const float p[3]) {
   it->impl->addNewRobotPosition(Vec3f{p[0], p[1], p[2]});
 }

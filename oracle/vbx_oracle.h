@@ -81,6 +81,9 @@ orc_esdf_integrator* orc_esdf_integrator_create(orc_map* m, const orc_esdf_cfg* 
 void orc_esdf_integrator_destroy(orc_esdf_integrator* it);
 void orc_esdf_update_from_tsdf_layer(orc_esdf_integrator* it, int clear_updated_flag);
 void orc_esdf_update_from_tsdf_layer_batch(orc_esdf_integrator* it);
+/* EsdfIntegrator::updateFromTsdfBlocks(list, incremental) (:124-302) and clear() (esdf_integrator.h:138-142) */
+void orc_esdf_update_from_tsdf_blocks(orc_esdf_integrator* it, const int32_t* idx_xyz, size_t n, int incremental);
+void orc_esdf_integrator_clear(orc_esdf_integrator* it);
 /* EsdfIntegrator::addNewRobotPosition, esdf_integrator.cc:25-92 */
 void orc_esdf_add_new_robot_position(orc_esdf_integrator* it, const float position[3]);
 /* out: lower, raise, new, raised, open_pops, relaxations, blocks */

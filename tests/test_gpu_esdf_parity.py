@@ -285,3 +285,70 @@ def test_clear_spheres_reference_test_on_gpu(oracle, voxel):
     r = om.esdf_dict()
     n, nh, rmse = _check_robot(g, r, exact=False)
     assert rmse < 1e-2, rmse
+
+
+def test_esdf_update_from_tsdf_blocks_subsets(oracle):
+    """EsdfIntegrator::updateFromTsdfBlocks(list, incremental=false) on two disjoint halves of the
+    TSDF blocks (min_diff_m = 0).  First call (fresh ESDF layer, every source is queued): bit-exact
+    against the oracle.  Second call: the reference only expands voxels it queued, so new voxels
+    bordering the first half's converged voxels stay under-relaxed there, while
+    the pull relaxation here reaches the unrestricted fixed point = the reference's own batch
+    result: same masks, |d_gpu| <= |d_ref| everywhere, and bit-exact against the oracle batch."""
+    from voxblox_amd import capi
+    frames = _frames(3)
+    om, oe, gm = _pair(oracle, frames, ocfg=dict(min_diff_m=0.0, oracle_orderfree_sign_mismatch=1),
+                       gcfg=dict(min_diff_m=0.0), batch_gpu=True)
+    gm.clear(capi.LAYER_ESDF)
+    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0)
+    blocks = gm.block_indices()
+    gm.esdf_update_blocks(ge, blocks[::2], incremental=False)
+    oe.update_from_tsdf_blocks(blocks[::2], False)
+    _check_exact(_gpu_esdf(gm), om.esdf_dict())
+    gm.esdf_update_blocks(ge, blocks[1::2], incremental=False)
+    oe.update_from_tsdf_blocks(blocks[1::2], False)
+    g, r = _gpu_esdf(gm), om.esdf_dict()
+    assert set(g) == set(r) and len(g) == len(blocks)
+    for k in r:
+        gd, gf, _, gu = g[k]
+        rd, rf, _, ru = r[k]
+        assert gu == ru == 1
+        assert np.array_equal(gf & 9, rf & 9)                  # observed + fixed masks
+        obs = (rf & 1).astype(bool)
+        assert np.all(np.abs(gd[obs]) <= np.abs(rd[obs]) + 1e-6)
+        assert np.array_equal(np.sign(gd[obs]), np.sign(rd[obs]))
+    assert len(gm.blocks_updated(capi.UPDATE_ESDF)) == len(blocks)     # nothing cleared the kEsdf bits
+    # an unknown block in the list is skipped like a missing TSDF block (esdf_integrator.cc:139-141)
+    gm.esdf_update_blocks(ge, np.array([[999, 999, 999]], np.int32))
+    om2, oe2, _ = _pair(oracle, frames[:0], ocfg=dict(min_diff_m=0.0, oracle_orderfree_sign_mismatch=1))
+    oi2 = om2.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1))
+    for pose, pts, col in frames:
+        oi2.integrate(pose[0], pose[1], pts, col)
+    oe2.update_from_tsdf_layer_batch()
+    _check_exact(_gpu_esdf(gm), om2.esdf_dict())
+
+
+def test_esdf_integrator_clear_forgets_robot_spheres(oracle):
+    """EsdfIntegrator::clear() (esdf_integrator.h:138-142, caller esdf_server.cc:249-252) drops the
+    queues addNewRobotPosition filled: the next update must not run their wavefront."""
+    from voxblox_amd import capi
+    frames = _frames(2)
+    sph = dict(clear_sphere_radius=0.6, occupied_sphere_radius=1.2)
+    om, oe, gm = _pair(oracle, frames, ocfg=dict(min_diff_m=0.0, oracle_orderfree_sign_mismatch=1, **sph),
+                       gcfg=dict(min_diff_m=0.0, **sph), batch_gpu=True)
+    oe.update_from_tsdf_layer_batch()
+    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0, **sph)
+    p = frames[0][0][0]
+    gm.esdf_add_new_robot_position(ge, p)
+    gm.esdf_integrator_clear()
+    before = _gpu_esdf(gm)
+    gm.esdf_update_blocks(ge, np.zeros((0, 3), np.int32))     # runs the (now empty) queues only
+    after = _gpu_esdf(gm)
+    assert set(before) == set(after)
+    for k in before:
+        assert np.array_equal(before[k][0].view(np.uint32), after[k][0].view(np.uint32))
+        assert np.array_equal(before[k][1], after[k][1])
+    oe.add_new_robot_position(p)
+    oe.clear()
+    oe.update_from_tsdf_blocks(np.zeros((0, 3), np.int32), False)
+    n, nh, _ = _check_robot(after, om.esdf_dict(), exact=True)
+    assert nh > 1000

@@ -145,6 +145,31 @@ def test_esdf_add_new_robot_position_bit_identical():
         assert f.any()
 
 
+def test_esdf_update_from_tsdf_blocks_and_clear_bit_identical():
+    """updateFromTsdfBlocks(list, incremental) on block subsets, then addNewRobotPosition +
+    clear() (the queued work must be forgotten) + a regular incremental update."""
+    out = []
+    for L in (O.lib(), O.ref_lib()):
+        L.orc_fast_reset_counter_set(0)
+        m = O.OracleMap(0.1, 16, L=L)
+        c = O.TsdfCfg(); L.orc_tsdf_cfg_default(C.byref(c))
+        c.default_truncation_distance = 0.4; c.integrator_threads = 1
+        it = m.tsdf_integrator("merged", c)
+        for pose, pts, col in _frames(3):
+            it.integrate(pose[0], pose[1], pts, col)
+        ec = O.EsdfCfg(); L.orc_esdf_cfg_default(C.byref(ec))
+        ec.min_distance_m = 0.2; ec.clear_sphere_radius = 0.6; ec.occupied_sphere_radius = 1.4
+        e = m.esdf_integrator(ec)
+        blocks = m.block_indices(0)
+        e.update_from_tsdf_blocks(blocks[::2], False)
+        e.update_from_tsdf_blocks(blocks[1::2], True)
+        e.add_new_robot_position(np.array([0.3, -0.2, -0.5], np.float32))
+        e.clear()
+        e.update_from_tsdf_layer(True)
+        out.append(m)
+    _same_esdf(*out)
+
+
 def test_helpers_bit_identical():
     rng = np.random.RandomState(3)
     La, Lb = O.lib(), O.ref_lib()

@@ -21,7 +21,7 @@ UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
 EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
-    "vbx_esdf_update", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
+    "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
 
@@ -106,6 +106,8 @@ def lib():
                                                 C.c_size_t, C.c_int]),
         "vbx_esdf_update": (C.c_int, [vp, C.POINTER(EsdfCfg), C.c_int, C.c_int]),
         "vbx_esdf_add_new_robot_position": (C.c_int, [vp, C.POINTER(EsdfCfg), f32p]),
+        "vbx_esdf_update_blocks": (C.c_int, [vp, C.POINTER(EsdfCfg), i32p, C.c_size_t, C.c_int]),
+        "vbx_esdf_integrator_clear": (C.c_int, [vp]),
         "vbx_num_blocks": (C.c_int, [vp, C.c_int, szp]),
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),
@@ -219,6 +221,15 @@ class Map:
 
     def esdf_update(self, cfg, batch=False, clear_updated_flag=True):
         self._chk(self.L.vbx_esdf_update(self.h, C.byref(cfg), int(batch), int(clear_updated_flag)))
+
+    def esdf_update_blocks(self, cfg, indices, incremental=False):
+        """EsdfIntegrator::updateFromTsdfBlocks (esdf_integrator.cc:124-302)."""
+        idx = np.ascontiguousarray(indices, np.int32).reshape(-1, 3)
+        self._chk(self.L.vbx_esdf_update_blocks(self.h, C.byref(cfg), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                idx.shape[0], int(incremental)))
+
+    def esdf_integrator_clear(self):
+        self._chk(self.L.vbx_esdf_integrator_clear(self.h))
 
     def esdf_add_new_robot_position(self, cfg, position):
         """EsdfIntegrator::addNewRobotPosition (esdf_integrator.cc:25-92)."""

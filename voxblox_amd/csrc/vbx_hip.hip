@@ -1504,12 +1504,15 @@ __device__ inline void unpack_parent(uint32_t s, int* x, int* y, int* z) {
 // activity for open_.push (the lower phase re-relaxes whole active blocks).
 // updateVoxelFromNeighbors (:498-530) is a pull from already-converged neighbours; the lower
 // phase's pull relaxation subsumes it (and does not reproduce its unscaled-distance quirk).
-__global__ void k_esdf_classify(MapDev m, EsdfDev e, EsdfCfgDev c, int incremental, DevState* st) {
+// select: 0 = every TSDF block (batch), 1 = blocks with Update::kEsdf or in updated_blocks_
+// (updateFromTsdfLayer), 2 = only the blocks the caller listed (updateFromTsdfBlocks).
+__global__ void k_esdf_classify(MapDev m, EsdfDev e, EsdfCfgDev c, int incremental, int select, DevState* st) {
   const uint32_t slot = blockIdx.x;
   const uint32_t flags = m.blk_flags[slot];
   if (!(flags & kFlagPublished)) return;
   // Update::kEsdf, or a member of updated_blocks_ (esdf_integrator.cc:107-108)
-  if (incremental && !(flags & 4u) && !(e.active[slot] & 16u)) return;
+  if (select == 1 && !(flags & 4u) && !(e.active[slot] & 16u)) return;
+  if (select == 2 && !(e.active[slot] & 32u)) return;
   const uint32_t lin = blockIdx.y * blockDim.x + threadIdx.x;
   if (lin >= m.nvox) return;
   if (lin == 0) {
@@ -1645,6 +1648,14 @@ __global__ void k_sphere_apply(MapDev m, EsdfDev e, SphereDev sp, float default_
   }
   const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if ((cur & want) != want) atomicOr(&m.blk_flags[slot], want);
+}
+
+// updateFromTsdfBlocks(list): mark the listed blocks for classification
+__global__ void k_esdf_mark_listed(MapDev m, EsdfDev e, const int32_t* __restrict__ idx, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = map_find(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]));
+  if (s != kInvalidSlot) atomicOr(&e.active[s], 32u);
 }
 
 // active(cur) = every block processed by this update and its 26 neighbours.
@@ -2556,7 +2567,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
 }
 
 
-__global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int drop_layer) {
+__global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int drop_layer, int keep_classify_pending) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
   // blocks addNewRobotPosition left work in: 8 = take part in this update (their voxels sit in
@@ -2564,7 +2575,8 @@ __global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int dr
   const uint32_t f = m.blk_flags[s];
   const uint32_t pend = f & (kFlagEsdfPendClassify | kFlagEsdfPendOpen);
   e.active[s] = (pend && !drop_layer) ? (8u | ((pend & kFlagEsdfPendClassify) ? 16u : 0u)) : 0u;
-  uint32_t nf = f & ~(kFlagEsdfPendClassify | kFlagEsdfPendOpen);
+  // updateFromTsdfBlocks does not consume updated_blocks_: the classification stays pending
+  uint32_t nf = f & ~((keep_classify_pending ? 0u : kFlagEsdfPendClassify) | kFlagEsdfPendOpen);
   if (drop_layer) nf &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
   if (nf != f) m.blk_flags[s] = nf;
 }
@@ -2620,7 +2632,8 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
 }
 
 template <int VPS>
-int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
+int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag,
+                  const int32_t* list = nullptr, size_t n_list = 0, int list_incremental = 0) {
   MapDev& m = ctx->map;
   hipStream_t s = ctx->stream;
   int rc = esdf_ensure(ctx);
@@ -2651,10 +2664,20 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   if (batch) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
   const bool robot_pending = ctx->esdf_robot_pending && !batch;
   ctx->esdf_robot_pending = false;
-  hipLaunchKernelGGL(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0);
+  hipLaunchKernelGGL(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0);
   HIP_TRY(hipMemsetAsync(&ctx->d_state->esdf_blocks, 0, 12, s));
-  hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
-                     batch ? 0 : 1, ctx->d_state);
+  if (list) {
+    HIP_TRY(ctx->b_head.ensure(std::max<size_t>(n_list, 1) * 12));
+    HIP_TRY(hipMemcpyAsync(ctx->b_head.p, list, n_list * 12, hipMemcpyHostToDevice, s));
+    if (n_list)
+      hipLaunchKernelGGL(k_esdf_mark_listed, grid_for(n_list), dim3(256), 0, s, m, e, ctx->b_head.as<int32_t>(),
+                         (uint32_t)n_list);
+    hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
+                       list_incremental ? 1 : 0, 2, ctx->d_state);
+  } else {
+    hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
+                       batch ? 0 : 1, batch ? 0 : 1, ctx->d_state);
+  }
   hipLaunchKernelGGL(k_esdf_seed_active, grid_for((size_t)used * 27), dim3(256), 0, s, m, e, used);
   rc = sync_state(ctx);
   if (rc) return rc;
@@ -2746,15 +2769,16 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
   return check_state_error(ctx);
 }
 
-int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
+int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag,
+                const int32_t* list = nullptr, size_t n_list = 0, int list_incremental = 0) {
   HIP_TRY(hipSetDevice(ctx->device));
   if (cfg->full_euclidean_distance) {
     ctx->fail("ESDF: full_euclidean_distance is not supported yet (quasi-Euclidean only)");
     return VBX_ERR_UNSUPPORTED;
   }
   switch (ctx->map.vps) {
-    case 8: return esdf_update_t<8>(ctx, cfg, batch, clear_updated_flag);
-    case 16: return esdf_update_t<16>(ctx, cfg, batch, clear_updated_flag);
+    case 8: return esdf_update_t<8>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
+    case 16: return esdf_update_t<16>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
     default:
       ctx->fail("ESDF: voxels_per_side must be 8 or 16 (LDS tile)");
       return VBX_ERR_UNSUPPORTED;
@@ -2947,6 +2971,27 @@ int vbx_tsdf_integrate(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const fl
 int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
   if (!ctx || !cfg) return VBX_ERR_INVALID;
   return esdf_update(ctx, cfg, batch, clear_updated_flag);
+}
+
+int vbx_esdf_update_blocks(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const int32_t* idx_xyz, size_t n, int incremental) {
+  if (!ctx || !cfg || (n && !idx_xyz)) return VBX_ERR_INVALID;
+  static const int32_t kNone[3] = {0, 0, 0};
+  return esdf_update(ctx, cfg, 0, 0, n ? idx_xyz : kNone, n, incremental);
+}
+
+int vbx_esdf_integrator_clear(vbx_ctx* ctx) {
+  if (!ctx) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->esdf_robot_pending = false;
+  if (!ctx->esdf_init) return VBX_OK;
+  int rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  if (used == 0) return VBX_OK;
+  HIP_TRY(hipMemsetAsync(ctx->b_eraised.p, 0, (size_t)used * ctx->map.nvox, ctx->stream));
+  hipLaunchKernelGGL(k_clear_update_bits, grid_for(used), dim3(256), 0, ctx->stream, ctx->map, used, ~0u,
+                     kFlagEsdfPendClassify | kFlagEsdfPendOpen);
+  return VBX_OK;
 }
 
 int vbx_esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const float position[3]) {

@@ -371,6 +371,17 @@ class EsdfIntegrator {  // esdf_integrator.h:24-179
   }
   void updateFromTsdfLayer(bool clear_updated_flag) { run(false, clear_updated_flag); }  // esdf_integrator.cc:104-122
   void updateFromTsdfLayerBatch() { run(true, false); }                                   // esdf_integrator.cc:94-102
+  void updateFromTsdfBlocks(const BlockIndexList& tsdf_blocks, bool incremental = false) {  // esdf_integrator.cc:124-302
+    const vbx_esdf_cfg c = toC();
+    const DeviceMap& m = *tsdf_layer_->map();
+    m.check(vbx_esdf_update_blocks(m.ctx(), &c, tsdf_blocks.empty() ? nullptr : &tsdf_blocks[0].x, tsdf_blocks.size(),
+                                   incremental ? 1 : 0),
+            "vbx_esdf_update_blocks");
+  }
+  void clear() {  // esdf_integrator.h:138-142
+    const DeviceMap& m = *tsdf_layer_->map();
+    m.check(vbx_esdf_integrator_clear(m.ctx()), "vbx_esdf_integrator_clear");
+  }
   void addNewRobotPosition(const Point& position) {                                       // esdf_integrator.cc:25-92
     const vbx_esdf_cfg c = toC();
     const float p[3] = {position.x, position.y, position.z};

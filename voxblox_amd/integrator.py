@@ -98,5 +98,11 @@ class EsdfIntegrator:
     def updateFromTsdfLayerBatch(self):
         self.map_.esdf_update(self.config_, batch=True, clear_updated_flag=False)
 
+    def updateFromTsdfBlocks(self, tsdf_blocks, incremental=False):
+        self.map_.esdf_update_blocks(self.config_, tsdf_blocks, incremental)
+
+    def clear(self):
+        self.map_.esdf_integrator_clear()
+
     def addNewRobotPosition(self, position):
         self.map_.esdf_add_new_robot_position(self.config_, position)
