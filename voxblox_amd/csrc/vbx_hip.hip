@@ -2122,7 +2122,9 @@ int visiting_order(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float* d_pts, si
 int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t total) {
   MapDev& m = ctx->map;
   hipStream_t s = ctx->stream;
-  const unsigned end_bit = 32 + bits_for((uint64_t)m.cap_blocks * m.nvox);
+  // gids are below pool_used * nvox; h_state holds the value from after this call's slot
+  // assignment (every path reads DevState back between k_commit_alloc and here)
+  const unsigned end_bit = 32 + bits_for((uint64_t)std::max<uint32_t>(ctx->h_state.pool_used, 1) * m.nvox);
   // keys are emitted ray by ray in visiting order, so a stable sort on the voxel field alone
   // leaves every voxel's updates in visiting order (invalid keys, all ones, go last)
   int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 32,
@@ -2171,8 +2173,7 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
   }
   // total number of keys = off[R]
   uint32_t total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, ctx->b_off.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
-  rc = sync_state(ctx);
+  rc = sync_state(ctx, ctx->b_off.as<uint32_t>() + R, &total);
   if (rc) return rc;
   rc = check_state_error(ctx);
   if (rc) return rc;
