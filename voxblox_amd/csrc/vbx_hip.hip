@@ -598,23 +598,23 @@ __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, 
   if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched, (unsigned long long)nheads);
   if (!head) return;  // only segment heads fold
 
+  // a long run (the keys of a voxel are contiguous, so one look ahead tells): hand it to
+  // k_fold_long untouched
+  if (i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid) {
+    const uint32_t o = atomicAdd(&st->fold_long_count, 1u);
+    long_list[o] = (uint32_t)i;
+    return;
+  }
   const l3 g = voxel_of_gid(m, gid);
   float d = m.dist[gid];
   float W = m.weight[gid];
   uint32_t col = m.rgba[gid];
   size_t j = i;
   uint64_t kj = key;
-  uint32_t count = 0;
   while (true) {
-    if (count == kFoldShort) {  // a long run: hand it to k_fold_long untouched
-      const uint32_t o = atomicAdd(&st->fold_long_count, 1u);
-      long_list[o] = (uint32_t)i;
-      return;
-    }
     const uint32_t o = (uint32_t)(kj & 0xFFFFFFFFu);
     const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
     tsdf_update(c, m.voxel_size, pg, g, tab.rgba[o], tab.w[o], d, W, col);
-    ++count;
     ++j;
     if (j >= n) break;
     kj = keys[j];
@@ -647,67 +647,102 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
     float d = m.dist[gid];
     float W = m.weight[gid];
     uint32_t col = m.rgba[gid];
-    for (size_t base = i0;; base += 64) {
-      const size_t i = base + lane;
-      const uint64_t key = (i < n) ? keys[i] : ~0ull;
-      const bool mine = (key != ~0ull) && ((uint32_t)(key >> 32) == gid);
-      const unsigned long long V = __ballot(mine);
-      // keys of one voxel are contiguous: the valid lanes are a prefix
-      const int cnt = (V == ~0ull) ? 64 : (__ffsll((long long)~V) - 1);
-      if (cnt == 0) break;
-      float sdf = 0.f, uw = 0.f;
-      uint32_t color = 0;
-      if (lane < cnt) {
-        const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
-        const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
-        tsdf_update_inputs(c, m.voxel_size, pg, g, tab.w[o], &sdf, &uw);
-        color = tab.rgba[o];
-      }
-      const bool inband = fabsf(sdf) < c.trunc;
-      // 1. identity test against the current state
-      bool same = true;
-      if (lane < cnt) {
-        float d1 = d, W1 = W;
-        uint32_t c1 = col;
-        tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
-        same = (__float_as_uint(d1) == __float_as_uint(d)) && (__float_as_uint(W1) == __float_as_uint(W)) && (c1 == col);
-      }
-      if (__all(same)) {
-        if (cnt < 64) break;
-        continue;
-      }
-      // 2. weight chain + parallel verification that d does not move
-      bool done = false;
-      if (!__any(lane < cnt && inband)) {
-        float Wrun = W, Wmine = W;
-        for (int j = 0; j < cnt; ++j) {
-          const float uwj = __shfl(uw, j);
-          if (lane == j) Wmine = Wrun;
-          const float nw = Wrun + uwj;
-          if (!(nw < 1e-6f)) Wrun = std_min(c.max_weight, nw);
+    // kU chunks of 64 updates are fetched together (the gathers of px/py/pz/w/rgba by ray index
+    // cost ~2 us of latency per chunk when issued one chunk at a time, and a run of 300k updates
+    // on the sensor's own voxel is 4800 chunks), then folded chunk by chunk in order.
+    constexpr int kU = 4;
+    bool more = true;
+    for (size_t base = i0; more; base += 64 * kU) {
+      float sdf_u[kU], uw_u[kU];
+      uint32_t color_u[kU];
+      int cnt_u[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const size_t i = base + 64 * u + lane;
+        const uint64_t key = (i < n) ? keys[i] : ~0ull;
+        const bool mine = (key != ~0ull) && ((uint32_t)(key >> 32) == gid);
+        const unsigned long long V = __ballot(mine);
+        // keys of one voxel are contiguous: the valid lanes are a prefix
+        cnt_u[u] = (V == ~0ull) ? 64 : (__ffsll((long long)~V) - 1);
+        sdf_u[u] = 0.f; uw_u[u] = 0.f; color_u[u] = 0;
+        if (lane < cnt_u[u]) {
+          const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
+          const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+          tsdf_update_inputs(c, m.voxel_size, pg, g, tab.w[o], &sdf_u[u], &uw_u[u]);
+          color_u[u] = tab.rgba[o];
         }
-        bool ok = true;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int cnt = cnt_u[u];
+        if (cnt == 0) { more = false; break; }
+        const float sdf = sdf_u[u], uw = uw_u[u];
+        const uint32_t color = color_u[u];
+        const bool inband = fabsf(sdf) < c.trunc;
+        // 1. identity test against the current state
+        bool same = true;
         if (lane < cnt) {
-          float d1 = d, W1 = Wmine;
+          float d1 = d, W1 = W;
           uint32_t c1 = col;
           tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
-          ok = (__float_as_uint(d1) == __float_as_uint(d));
+          same = (__float_as_uint(d1) == __float_as_uint(d)) && (__float_as_uint(W1) == __float_as_uint(W)) && (c1 == col);
         }
-        if (__all(ok)) {
-          W = Wrun;
-          done = true;
+        if (!__all(same)) {
+          // 2. weight chain + parallel verification that d does not move
+          bool done = false;
+          if (!__any(lane < cnt && inband)) {
+            // the chain itself: operands come out of the lanes with v_readlane (constant lane
+            // index, fully unrolled) — a ds_bpermute per element made this loop the whole cost
+            // of the fold (~2.7 us per 64 updates)
+            float Wrun = W, Wmine = W;
+            if (cnt == 64 && W >= 1e-6f && __all(uw >= 0.0f)) {
+              // full chunk, weights only grow: the `new_weight < kFloatEpsilon` exit of
+              // updateTsdfVoxel (tsdf_integrator.cc:183-186) cannot trigger, so the chain is two
+              // dependent VALU ops per update with no branches
+#pragma unroll
+              for (int j = 0; j < 64; ++j) {
+                const float uwj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+                Wmine = (lane == j) ? Wrun : Wmine;
+                Wrun = std_min(c.max_weight, Wrun + uwj);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 64; ++j) {
+                if (j < cnt) {
+                  const float uwj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+                  if (lane == j) Wmine = Wrun;
+                  const float nw = Wrun + uwj;
+                  if (!(nw < 1e-6f)) Wrun = std_min(c.max_weight, nw);
+                }
+              }
+            }
+            bool ok = true;
+            if (lane < cnt) {
+              float d1 = d, W1 = Wmine;
+              uint32_t c1 = col;
+              tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
+              ok = (__float_as_uint(d1) == __float_as_uint(d));
+            }
+            if (__all(ok)) {
+              W = Wrun;
+              done = true;
+            }
+          }
+          // 3. generic ordered application
+          if (!done) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+              if (j < cnt) {
+                const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), j));
+                const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)color, j);
+                tsdf_update_state(c, sj, wj, cj, d, W, col);
+              }
+            }
+          }
         }
+        if (cnt < 64) { more = false; break; }
       }
-      // 3. generic ordered application
-      if (!done) {
-        for (int j = 0; j < cnt; ++j) {
-          const float sj = __shfl(sdf, j);
-          const float wj = __shfl(uw, j);
-          const uint32_t cj = (uint32_t)__shfl((int)color, j);
-          tsdf_update_state(c, sj, wj, cj, d, W, col);
-        }
-      }
-      if (cnt < 64) break;
     }
     if (lane == 0) {
       m.dist[gid] = d;
