@@ -130,17 +130,19 @@ def main():
     trunc = 4 * voxel
     max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3))
     gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-    gm.set_stream(torch.cuda.current_stream().cuda_stream)
     cfg = capi.tsdf_cfg(default_truncation_distance=trunc)
     sharded = None
-    if world > 1 or force_sharded:
+    if not (world > 1 or force_sharded):
+        gm.set_stream(torch.cuda.current_stream().cuda_stream)
+    else:  # every map keeps its own non-blocking stream so that integration and exchange overlap
         # Ray-bundle sharding: gm is this rank's per-frame delta map; the
         # persistent map is distributed by block ownership and fed by an RCCL reduce-scatter.
         from voxblox_amd import multi_gpu
         pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-        pm.set_stream(torch.cuda.current_stream().cuda_stream)
-        sharded = multi_gpu.ShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), multi_gpu.GpuBackend(gm, dev),
-                                           rank, world, dist)
+        gm2 = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)   # second delta map (double buffer)
+        sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev),
+                                                    [multi_gpu.GpuBackend(gm, dev), multi_gpu.GpuBackend(gm2, dev)],
+                                                    rank, world, dist, device=dev)
 
     ecfg = capi.esdf_cfg(min_distance_m=trunc / 2)  # ros_params.h:136-137
     esdf_ms = [0.0]
@@ -166,6 +168,8 @@ def main():
     last_tsdf = [None]
 
     def barrier():
+        if sharded is not None:
+            sharded.flush()          # the exchange worker must be idle before a collective of ours
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -174,17 +178,24 @@ def main():
         step(i)
     gm.enable_timing(True)
     timing_on[0] = True
+    if sharded is not None:
+        sharded.flush()
+        for k in sharded.stats:
+            sharded.stats[k] = 0
     stage = {}
     counters = {}
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
+        if sharded is not None and i < total - 1:
+            continue   # per-stage figures from the last frame only: no extra calls between frames
         t, c = last_tsdf[0] if (args.esdf and last_tsdf[0]) else (gm.timing(), gm.counters())
+        rep = args.steps if sharded is not None else 1
         for k, v in t.items():
-            stage[k] = stage.get(k, 0.0) + v
+            stage[k] = stage.get(k, 0.0) + v * rep
         for k, v in c.items():
-            counters[k] = counters.get(k, 0) + v
+            counters[k] = counters.get(k, 0) + v * rep
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -234,8 +245,8 @@ def main():
                                "stream (BASELINE configs[1]), %g m voxels / 16^3 blocks, trunc %g m" % (voxel, trunc),
                    "points_per_step": n_pts, "voxel_size": voxel, "voxels_per_side": 16,
                    "parallelism": ("1 GPU, whole cloud" if world == 1 else
-                                   f"{world} sensors, one ray shard per GPU, RCCL reduce-scatter block merge, "
-                                   "map distributed by block owner")},
+                                   f"{world} sensors, one ray shard per GPU, RCCL reduce-scatter block merge "
+                                   "pipelined behind the next frame's integration, map distributed by block owner")},
     }
     if rank == 0:
         # Roofline of the dominant kernel.  For the Fast integrator that is k_fast_sweep, launched
@@ -286,6 +297,12 @@ def main():
             nf = args.cpu_frames or 40
             out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator, voxel)
         print(json.dumps(out), flush=True)
+    if sharded is not None:
+        sharded.close()
+        if rank == 0 and os.environ.get("VBX_PIPE_DEBUG"):
+            f = max(sharded.stats["frames"], 1)
+            print({k: (round(v / f * 1e3, 3) if k != "frames" else v) for k, v in sharded.stats.items()},
+                  file=sys.stderr)
     if world > 1 or force_sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -167,3 +167,30 @@ def test_bench_sharded_path_over_rccl_single_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["steps"] == 4
+
+
+def test_pipelined_exchange_equals_sequential():
+    """PipelinedShardedTsdfMap (double-buffered delta maps, exchange on a worker thread/stream)
+    must produce exactly the persistent map the sequential ShardedTsdfMap produces."""
+    import torch
+    from voxblox_amd import capi, multi_gpu
+    voxel = 0.1
+    cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    frames = [scenes.room_frame(5 * k, 100, f=40.0, width=80, height=60) for k in range(7)]
+    seq = multi_gpu.ShardedTsdfMap(multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0"),
+                                   multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0"), 0, 1)
+    pipe = multi_gpu.PipelinedShardedTsdfMap(
+        multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0"),
+        [multi_gpu.GpuBackend(capi.Map(voxel, 16, max_blocks=2048), "cuda:0") for _ in range(2)], 0, 1,
+        device=torch.device("cuda", 0))
+    for pose, pts, col in frames:
+        seq.integrate_shard(capi.TSDF_FAST, cfg, pose[0], pose[1], pts, col)
+        pipe.integrate_shard(capi.TSDF_FAST, cfg, pose[0], pose[1], pts, col)
+    pipe.close()
+    torch.cuda.synchronize()
+    a, b = seq.p.m.tsdf_dict(), pipe.p.m.tsdf_dict()
+    assert set(a) == set(b) and len(a) > 20
+    for k in a:
+        assert np.array_equal(a[k][0].view(np.uint32), b[k][0].view(np.uint32))
+        assert np.array_equal(a[k][1].view(np.uint32), b[k][1].view(np.uint32))
+        assert np.array_equal(a[k][2], b[k][2])

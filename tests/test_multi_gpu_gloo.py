@@ -92,7 +92,7 @@ def merge_A_into_B(sA, dB, wB, cB):
     return d.astype(np.float32), w, col
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, pipelined=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.distributed as dist
@@ -103,12 +103,18 @@ def _worker(rank, world, port, out_q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     voxel = 0.1
     cfg = O.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
-    sm = multi_gpu.ShardedTsdfMap(OracleBackend(O, voxel), OracleBackend(O, voxel), rank, world, dist)
+    if pipelined:  # double-buffered deltas, exchange on a worker thread (all collectives issued there)
+        sm = multi_gpu.PipelinedShardedTsdfMap(OracleBackend(O, voxel), [OracleBackend(O, voxel), OracleBackend(O, voxel)],
+                                               rank, world, dist)
+    else:
+        sm = multi_gpu.ShardedTsdfMap(OracleBackend(O, voxel), OracleBackend(O, voxel), rank, world, dist)
     for k in range(3):  # every rank: its own band of the same frame (ray-bundle sharding)
         pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
         n = pts.shape[0]
         lo, hi = rank * n // world, (rank + 1) * n // world
         sm.integrate_shard("simple", cfg, pose[0], pose[1], pts[lo:hi], col[lo:hi])
+    if pipelined:
+        sm.close()
     owned = {tuple(int(v) for v in i): sm.p.m.tsdf_block(i) for i in sm.p.block_indices()}
     out_q.put((rank, owned, sm.last))
     dist.barrier()
@@ -130,12 +136,13 @@ def test_owner_and_layout_are_deterministic():
         assert np.all(multi_gpu.owner_of(g, 4) == r) and g.shape[0] <= L1
 
 
-def test_two_rank_shard_and_merge_matches_serial_reference_merge(oracle):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_two_rank_shard_and_merge_matches_serial_reference_merge(oracle, pipelined):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, pipelined)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]

@@ -3385,28 +3385,24 @@ int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], do
 int vbx_clear(vbx_ctx* ctx, int layer) {
   if (!ctx) return VBX_ERR_INVALID;
   HIP_TRY(hipSetDevice(ctx->device));
-  if (layer == VBX_LAYER_TSDF) {
-    // removeAllBlocks (layer.h:168): zero every slot in use and unpublish it in one go; the
-    // hash entries stay and turn back into invisible candidates.
+  {
+    // removeAllBlocks (layer.h:168): every block of the layer is zeroed and leaves it in one
+    // launch (a workgroup per pool slot, slots outside the layer exit at once); the hash entries
+    // stay and turn back into invisible candidates.
     int rc = sync_state(ctx);
     if (rc) return rc;
     const uint32_t used = ctx->h_state.pool_used;
     if (used == 0) return VBX_OK;
-    const size_t nv = (size_t)used * ctx->map.nvox;
-    HIP_TRY(hipMemsetAsync(ctx->map.dist, 0, nv * 4, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->map.weight, 0, nv * 4, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->map.rgba, 0, nv * 4, ctx->stream));
-    hipLaunchKernelGGL(k_reset_tsdf_flags, grid_for(used), dim3(256), 0, ctx->stream, ctx->map, used);
+    if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+      ctx->fail("unknown layer %d", layer);
+      return VBX_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map,
+                       ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,
+                       ctx->esdf_init ? ctx->b_estate.as<uint32_t>() : (uint32_t*)nullptr, layer, f3{0.f, 0.f, 0.f},
+                       -1.0, 0.0f);  // squared distance > -1: every block
     return VBX_OK;
   }
-  std::vector<std::pair<uint64_t, uint32_t>> v;
-  int rc = list_blocks(ctx, layer, 0, &v);
-  if (rc) return rc;
-  for (const auto& kv : v) {
-    rc = remove_slot(ctx, layer, kv.second, 0);
-    if (rc) return rc;
-  }
-  return VBX_OK;
 }
 
 int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask) {

@@ -22,6 +22,8 @@ shard + merge done with the CPU oracle (tests/test_multi_gpu_gloo.py).
 
 The collective layer is torch.distributed ("nccl" is RCCL on ROCm; "gloo" for the CPU tests).
 """
+import time
+
 import numpy as np
 
 _SENTINEL = np.iinfo(np.int32).max
@@ -123,6 +125,97 @@ class ShardedTsdfMap:
             self.p.merge_sums(g, mine[:g.shape[0]], self.apply_caps, self.trunc, self.max_weight)
         self.last = dict(union_blocks=int(sum(x.shape[0] for x in groups)), owned_blocks=int(g.shape[0]),
                          padded_rows=int(self.world * L), payload_bytes=int(self.world * L * 6 * nvox * 4))
+
+
+class PipelinedShardedTsdfMap:
+    """The same frame step with the exchange pipelined behind the next frame's integration.
+
+    Two delta maps alternate: while a worker thread runs frame k's exchange (key all-gather,
+    export, RCCL reduce-scatter, owner merge) on its own HIP stream, the caller already
+    integrates frame k+1 into the other delta map.  The integration is latency-bound (the GPU is
+    mostly idle between its kernels), so the two overlap well; per-frame time tends to
+    max(integrate, exchange) instead of their sum.  Every collective is issued by the worker
+    thread, in frame order, so all ranks issue them in the same order; call flush() before any
+    collective of your own (barriers) and before reading the persistent map."""
+
+    def __init__(self, persistent, deltas, rank, world, dist=None, apply_caps=False, truncation=0.0,
+                 max_weight=0.0, device=None):
+        import queue
+        import sys
+        import threading
+        assert len(deltas) == 2
+        # the caller's thread comes back from a ~1 ms native call and must not wait long for the
+        # GIL while the worker is between its own native calls (default switch interval: 5 ms)
+        sys.setswitchinterval(5e-5)
+        self.sm = [ShardedTsdfMap(persistent, d, rank, world, dist, apply_caps, truncation, max_weight)
+                   for d in deltas]
+        self.p = persistent
+        self.device = device
+        self._q = queue.Queue()
+        self._idle = [threading.Event(), threading.Event()]
+        for e in self._idle:
+            e.set()
+        self._err = None
+        self._n = 0
+        self.last = {}
+        self.stats = {"frames": 0, "wait_s": 0.0, "integrate_s": 0.0, "exchange_s": 0.0}
+        self._thread = threading.Thread(target=self._worker, name="vbx-exchange", daemon=True)
+        self._thread.start()
+
+    def _worker(self):
+        stream_ctx = None
+        if self.device is not None:
+            import torch
+            torch.cuda.set_device(self.device)
+            stream_ctx = torch.cuda.stream(torch.cuda.Stream(self.device))
+            stream_ctx.__enter__()
+        try:
+            while True:
+                i = self._q.get()
+                if i is None:
+                    return
+                try:
+                    t0 = time.perf_counter()
+                    self.sm[i].exchange_and_merge()
+                    self.stats["exchange_s"] += time.perf_counter() - t0
+                    self.last = self.sm[i].last
+                except BaseException as e:  # surfaced by the next call on the caller's thread
+                    self._err = e
+                self._idle[i].set()
+        finally:
+            if stream_ctx is not None:
+                stream_ctx.__exit__(None, None, None)
+
+    def _check(self):
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+
+    def integrate_shard(self, kind, cfg, pos, quat, points, colors, n_points=None):
+        i = self._n & 1
+        self._n += 1
+        t0 = time.perf_counter()
+        self._idle[i].wait()          # this delta map's previous exchange is done
+        t1 = time.perf_counter()
+        self._check()
+        self._idle[i].clear()
+        d = self.sm[i].d
+        d.clear()
+        d.integrate(kind, cfg, pos, quat, points, colors, n_points)
+        self._q.put(i)
+        self.stats["wait_s"] += t1 - t0
+        self.stats["integrate_s"] += time.perf_counter() - t1
+        self.stats["frames"] += 1
+
+    def flush(self):
+        for e in self._idle:
+            e.wait()
+        self._check()
+
+    def close(self):
+        self.flush()
+        self._q.put(None)
+        self._thread.join(30)
 
 
 class GpuBackend:
