@@ -1,0 +1,96 @@
+"""Scenario definitions shared by the generator (make_golden.py, runs the REAL reference sources
+compiled as oracle/_ref) and by the tests that replay them on the oracle restatement and on the
+HIP path.  Every scenario is a deterministic function of voxblox_amd.scenes; results are reduced
+to SHA-256 digests of the raw voxel bytes in sorted block order plus a few counts."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+from voxblox_amd import scenes
+
+
+def frames(n, w=96, h=72, f=48.0, step=5):
+    return [scenes.room_frame(step * k, 100, f=f, width=w, height=h) for k in range(n)]
+
+
+# name -> dict(kind, voxel, n_frames, tsdf cfg overrides, esdf: None | dict(mode, cfg, robot))
+SCENARIOS = {
+    "simple_default": dict(kind="simple", voxel=0.1, n=4, cfg={}),
+    "simple_const_weight_no_carving": dict(kind="simple", voxel=0.1, n=2,
+                                           cfg=dict(use_const_weight=1, use_weight_dropoff=0, voxel_carving_enabled=0)),
+    "simple_sorted_order": dict(kind="simple", voxel=0.1, n=2, cfg=dict(integration_order_mode=1)),
+    "merged_default": dict(kind="merged", voxel=0.1, n=4, cfg={}),
+    "merged_anti_grazing": dict(kind="merged", voxel=0.1, n=2, cfg=dict(enable_anti_grazing=1)),
+    "fast_default": dict(kind="fast", voxel=0.1, n=4, cfg={}),
+    "fast_0p05_six_frames": dict(kind="fast", voxel=0.05, n=6, cfg={}),
+    "fast_every_3_frames": dict(kind="fast", voxel=0.1, n=5, cfg=dict(clear_checks_every_n_frames=3)),
+    "esdf_incremental": dict(kind="merged", voxel=0.1, n=4, cfg={}, esdf=dict(mode="incremental", cfg={})),
+    "esdf_batch_min_diff0": dict(kind="simple", voxel=0.1, n=2, cfg={}, esdf=dict(mode="batch", cfg=dict(min_diff_m=0.0))),
+    "esdf_batch_full_euclidean": dict(kind="simple", voxel=0.1, n=2, cfg={},
+                                      esdf=dict(mode="batch", cfg=dict(full_euclidean_distance=1))),
+    "esdf_robot_spheres": dict(kind="merged", voxel=0.1, n=4, cfg={},
+                               esdf=dict(mode="incremental", robot=True,
+                                         cfg=dict(clear_sphere_radius=0.6, occupied_sphere_radius=1.6))),
+}
+
+
+def run_on_oracle_api(O, L, sc):
+    """Runs a scenario through an orc_* library (restatement or reference build); returns the map."""
+    L.orc_fast_reset_counter_set(0)
+    m = O.OracleMap(sc["voxel"], 16, L=L)
+    c = O.TsdfCfg()
+    L.orc_tsdf_cfg_default(C.byref(c))
+    c.default_truncation_distance = 4 * sc["voxel"]
+    c.integrator_threads = 1
+    for k, v in sc["cfg"].items():
+        setattr(c, k, v)
+    it = m.tsdf_integrator(sc["kind"], c)
+    e = None
+    es = sc.get("esdf")
+    if es is not None:
+        ec = O.EsdfCfg()
+        L.orc_esdf_cfg_default(C.byref(ec))
+        ec.min_distance_m = 2 * sc["voxel"]
+        for k, v in es.get("cfg", {}).items():
+            setattr(ec, k, v)
+        e = m.esdf_integrator(ec)
+    for pose, pts, col in frames(sc["n"]):
+        it.integrate(pose[0], pose[1], pts, col)
+        if e is not None and es.get("robot"):
+            e.add_new_robot_position(pose[0])
+        if e is not None and es["mode"] == "incremental":
+            e.update_from_tsdf_layer(True)
+    if e is not None and es["mode"] == "batch":
+        e.update_from_tsdf_layer_batch()
+    return m
+
+
+def digest_tsdf(d):
+    """d: {(bx,by,bz): (dist f32[4096], weight f32[4096], rgba, updated)} -> summary dict."""
+    h = hashlib.sha256()
+    n_obs = 0
+    for k in sorted(d):
+        dist, w, rgba, upd = d[k]
+        h.update(np.asarray(k, np.int32).tobytes())
+        h.update(np.ascontiguousarray(dist, np.float32).tobytes())
+        h.update(np.ascontiguousarray(w, np.float32).tobytes())
+        h.update(np.ascontiguousarray(rgba).view(np.uint8).tobytes())
+        h.update(bytes([int(upd) & 0xFF]))
+        n_obs += int((np.asarray(w) > 1e-6).sum())
+    return {"blocks": len(d), "observed": n_obs, "sha256": h.hexdigest()}
+
+
+def digest_esdf(d, with_parents=True):
+    h = hashlib.sha256()
+    n_obs = 0
+    for k in sorted(d):
+        dist, fl, par, upd = d[k]
+        h.update(np.asarray(k, np.int32).tobytes())
+        h.update(np.ascontiguousarray(dist, np.float32).tobytes())
+        h.update(np.ascontiguousarray(fl, np.uint8).tobytes())
+        if with_parents:
+            h.update(np.ascontiguousarray(par, np.int32).tobytes())
+        h.update(bytes([int(upd) & 0xFF]))
+        n_obs += int((np.asarray(fl) & 1).sum())
+    return {"blocks": len(d), "observed": n_obs, "sha256": h.hexdigest()}
