@@ -43,6 +43,9 @@ def parse():
                     help="voxel size (default = configs[1]'s 0.05 m; 0.02 = configs[4]'s resolution); "
                          "truncation stays 4 voxels")
     ap.add_argument("--max-blocks", type=int, default=0, help="block pool capacity (0 = sized from --voxel)")
+    ap.add_argument("--merged-order", type=int, default=0, choices=[0, 1],
+                    help="Merged only: 0 = the reference's unordered_map bundle order (bit-exact, host replay), "
+                         "1 = ascending voxel key (no host step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mirror-frames", type=int, default=8,
                     help="extra untimed-for-`value` frames that also mirror the touched blocks to the host "
@@ -130,7 +133,7 @@ def main():
     trunc = 4 * voxel
     max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3))
     gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-    cfg = capi.tsdf_cfg(default_truncation_distance=trunc)
+    cfg = capi.tsdf_cfg(default_truncation_distance=trunc, merged_bundle_order=args.merged_order)
     sharded = None
     if not (world > 1 or force_sharded):
         gm.set_stream(torch.cuda.current_stream().cuda_stream)

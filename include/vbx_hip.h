@@ -60,6 +60,13 @@ typedef struct vbx_tsdf_cfg {
   int32_t max_consecutive_ray_collisions;
   int32_t clear_checks_every_n_frames;
   float max_integration_time_s; /* accepted; the GPU path never truncates a frame */
+  /* Not in the reference Config.  MergedTsdfIntegrator visits its ray bundles in the iteration
+   * order of a std::unordered_map (tsdf_integrator.cc:440-456), which the clamped fold makes
+   * observable.  0 (default): that order, reproduced by replaying the container's insertions on
+   * the host with this library's libstdc++ (bit-exact, ~1 ms per frame at 640x480);
+   * 1: ascending voxel key (no host step; same voxels, distances differ in the order-sensitive
+   * ~1 % of them). */
+  int32_t merged_bundle_order;
 } vbx_tsdf_cfg;
 
 /* EsdfIntegrator::Config, esdf_integrator.h:29-78. */

@@ -135,8 +135,7 @@ def test_esdf_default_min_diff_envelope_vs_reference_incremental(oracle):
     from voxblox_amd import capi
     oracle.lib().orc_fast_reset_counter_set(0)
     om = oracle.OracleMap(VOXEL, 16)
-    oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1,
-                                                      oracle_merged_sorted_bundles=1))
+    oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1))
     oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2))
     gm = capi.Map(VOXEL, 16, max_blocks=4096)
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
@@ -268,8 +267,7 @@ def test_clear_spheres_reference_test_on_gpu(oracle, voxel):
     ge = capi.esdf_cfg(**sph)
     oracle.lib().orc_fast_reset_counter_set(0)
     om = oracle.OracleMap(voxel, 16)
-    oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1,
-                                                      oracle_merged_sorted_bundles=1))
+    oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
     oe = om.esdf_integrator(oracle.esdf_cfg(oracle_orderfree_sign_mismatch=1, **sph))
     for k in (0, 20):
         pose, pts, col = scenes.room_frame(k, 100, f=80.0, width=160, height=120)

@@ -15,8 +15,10 @@ pytestmark = pytest.mark.gpu
 
 def _cfgs(oracle, trunc, **kw):
     from voxblox_amd import capi
-    okw = dict(kw)
+    okw = {k: v for k, v in kw.items() if k != "merged_bundle_order"}   # a HIP-only field
     gkw = {k: v for k, v in kw.items() if not k.startswith("oracle_")}
+    if kw.get("oracle_merged_sorted_bundles"):
+        gkw["merged_bundle_order"] = 1      # ascending voxel key on both sides
     return (oracle.tsdf_cfg(default_truncation_distance=trunc, integrator_threads=1, **okw),
             capi.tsdf_cfg(default_truncation_distance=trunc, **gkw))
 
@@ -78,13 +80,24 @@ def test_merged_anti_grazing(oracle):
     compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
 
 
-def test_merged_vs_reference_bundle_order(oracle):
-    """The reference visits bundles in libstdc++ unordered_map order (implementation-defined);
-    the HIP path uses ascending voxel-key order.  Same voxels must be observed; distances may
-    differ only where the clamped fold is order-sensitive — bounded by the reference's own
-    envelope (test_sdf_integrators.cc:162-178)."""
+@pytest.mark.parametrize("extra", [{}, {"enable_anti_grazing": 1}, {"integration_order_mode": 1}])
+def test_merged_reference_bundle_order_bit_exact(oracle, extra):
+    """Default merged_bundle_order = 0: the bundles are visited in the iteration order of the
+    reference's std::unordered_map (replayed on the host with the same container and hash), so
+    the HIP result equals the UNSWITCHED 1-thread reference bit for bit."""
+    frames = [_small_room(k) for k in (0, 5, 10)] if not extra.get("integration_order_mode") \
+        else [_unique_norm_frame(k) for k in (0, 5)]
+    om, oi, gm = _run(oracle, "merged", 0.05, frames, **extra)   # oracle with the reference's own order
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    assert gm.counters()["rays_cast"] == oi.stats()["bundles"] + oi.stats()["clear_bundles"]
+
+
+def test_merged_sorted_bundle_order_vs_reference_envelope(oracle):
+    """merged_bundle_order = 1 (ascending voxel key, no host step) against the reference's order:
+    same voxels observed; distances differ only where the clamped fold is order-sensitive —
+    bounded by the reference's own envelope (test_sdf_integrators.cc:162-178)."""
     frames = [_small_room(k) for k in (0, 5)]
-    om, oi, gm = _run(oracle, "merged", 0.05, frames)  # oracle in reference order
+    om, oi, gm = _run(oracle, "merged", 0.05, frames, merged_bundle_order=1)  # oracle in reference order
     g, r = gm.tsdf_dict(), om.tsdf_dict()
     assert set(g.keys()) == set(r.keys())
     st = layer_stats(g, r)

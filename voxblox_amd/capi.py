@@ -42,7 +42,8 @@ class TsdfCfg(C.Structure):
                 ("integration_order_mode", C.c_int32), ("enable_anti_grazing", C.c_int32),
                 ("start_voxel_subsampling_factor", C.c_float),
                 ("max_consecutive_ray_collisions", C.c_int32),
-                ("clear_checks_every_n_frames", C.c_int32), ("max_integration_time_s", C.c_float)]
+                ("clear_checks_every_n_frames", C.c_int32), ("max_integration_time_s", C.c_float),
+                ("merged_bundle_order", C.c_int32)]
 
 
 class EsdfCfg(C.Structure):

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -790,12 +791,14 @@ __global__ void k_merged_bundle(const uint64_t* __restrict__ keys, const uint32_
                                 const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank,
                                 uint32_t n, RayTab pt, const float* __restrict__ pcx,
                                 const float* __restrict__ pcy, const float* __restrict__ pcz,
-                                Pose T, RayTab out, uint64_t* graze_keys, DevState* st) {
+                                Pose T, RayTab out, uint64_t* graze_keys, const uint32_t* __restrict__ perm,
+                                DevState* st) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !head[i]) return;
   const uint64_t key = keys[i];
   const bool clearing = (key >> 63) != 0;
-  const uint32_t b = rank[i];
+  const uint32_t br = rank[i];                    // rank in ascending key order
+  const uint32_t b = perm ? perm[br] : br;        // row = position in the visiting order of the bundles
   f3 mp{0.f, 0.f, 0.f};
   uint32_t mc = 0;
   float mw = 0.0f;
@@ -818,8 +821,19 @@ __global__ void k_merged_bundle(const uint64_t* __restrict__ keys, const uint32_
   out.w[b] = mw;
   out.flags[b] = 1 | (clearing ? 2 : 0);
   out.bkey[b] = key & ~(1ull << 63);
-  if (!clearing && graze_keys) graze_keys[b] = key;
+  if (!clearing && graze_keys) graze_keys[br] = key;  // stays sorted: binary-searched by the march
   (void)st;
+}
+
+// Per bundle (ascending key rank): its key and the visiting position of its first point — the
+// order in which bundleRays inserts the keys into its unordered_map.
+__global__ void k_merged_collect(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                 const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank, uint32_t n,
+                                 uint64_t* bkeys, uint32_t* first_s) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  bkeys[rank[i]] = keys[i];
+  first_s[rank[i]] = vals[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -1952,7 +1966,7 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_bkeys, b_bfirst, b_bperm;
   uint32_t obs_epoch = 1;
   uint32_t fast_last_iters = 0;  // sweeps the previous Fast frame needed
   uint32_t fast_redo_grid = 0;   // rays the second list-building pass is launched for
@@ -2242,6 +2256,55 @@ int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   return march_and_fold(ctx, tab, c, /*from_origin=*/true, nullptr, false, nullptr, 0);
 }
 
+// MergedTsdfIntegrator::integrateVoxels walks voxel_map / clear_map — std::unordered_map keyed by
+// GlobalIndex with LongIndexHash (block_hash.h:54-64) — from begin() to end()
+// (tsdf_integrator.cc:440-456).  That order is a property of libstdc++'s hashtable (bucket
+// count growth, node splicing) given the hash values and the insertion sequence, so it is
+// obtained the way the reference obtains it: the bundle keys are inserted into the same container,
+// in bundleRays' insertion order (first point of each bundle, visiting order), on the host.
+// perm[rank in ascending key order] = row in visiting order; non-clearing bundles first (:324-333).
+struct HostL3Hash {
+  size_t operator()(const l3& k) const { return (size_t)long_index_hash(k); }
+};
+struct HostL3Eq {
+  bool operator()(const l3& a, const l3& b) const { return a.x == b.x && a.y == b.y && a.z == b.z; }
+};
+int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t** perm_out) {
+  hipStream_t s = ctx->stream;
+  HIP_TRY(ctx->b_bkeys.ensure((size_t)nb * 8));
+  HIP_TRY(ctx->b_bfirst.ensure((size_t)nb * 4));
+  HIP_TRY(ctx->b_bperm.ensure((size_t)nb * 4));
+  hipLaunchKernelGGL(k_merged_collect, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(),
+                     (uint32_t)n, ctx->b_bkeys.as<uint64_t>(), ctx->b_bfirst.as<uint32_t>());
+  std::vector<uint64_t> keys(nb);
+  std::vector<uint32_t> first(nb), perm(nb), idx(nb);
+  HIP_TRY(hipMemcpyAsync(keys.data(), ctx->b_bkeys.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(first.data(), ctx->b_bfirst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  // the keys are sorted with the clearing bit on top: [0, n1) normal bundles, [n1, nb) clearing
+  uint32_t n1 = 0;
+  while (n1 < nb && !(keys[n1] >> 63)) ++n1;
+  uint32_t row = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t lo = pass ? n1 : 0, hi = pass ? nb : n1;
+    for (uint32_t b = lo; b < hi; ++b) idx[b] = b;
+    std::sort(idx.begin() + lo, idx.begin() + hi, [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
+    std::unordered_map<l3, uint32_t, HostL3Hash, HostL3Eq> map;
+    for (uint32_t q = lo; q < hi; ++q) {
+      const uint64_t k = keys[idx[q]] & ~(1ull << 63);
+      const l3 g{(long long)(k & 0x1FFFFFu) - (1ll << 20), (long long)((k >> 21) & 0x1FFFFFu) - (1ll << 20),
+                 (long long)((k >> 42) & 0x1FFFFFu) - (1ll << 20)};
+      map.emplace(g, idx[q]);
+    }
+    for (const auto& kv : map) perm[kv.second] = row++;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->b_bperm.p, perm.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // perm is a local
+  *perm_out = ctx->b_bperm.as<uint32_t>();
+  return VBX_OK;
+}
+
 int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
                      const uint32_t* d_rgba, size_t n, int freespace) {
   CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
@@ -2281,11 +2344,16 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   HIP_TRY(ctx->b_graze.ensure((size_t)nb * 8));
   HIP_TRY(hipMemsetAsync(ctx->b_graze.p, 0xFF, (size_t)nb * 8, s));
   RayTab bt = make_tab(ctx, true, nb);
+  const uint32_t* perm = nullptr;
+  if (cfg->merged_bundle_order == 0) {
+    rc = merged_reference_order(ctx, n, nb, &perm);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_merged_bundle, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(),
                      ctx->b_rank.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(),
                      ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), T, bt,
-                     ctx->b_graze.as<uint64_t>(), ctx->d_state);
+                     ctx->b_graze.as<uint64_t>(), perm, ctx->d_state);
   tmark(ctx, 1);
   // Non-clearing bundles sort before clearing ones (bit 63), so the graze key list is the
   // sorted prefix of non-clearing bundle keys; entries of clearing bundles stay ~0 (sorted last).
@@ -2846,6 +2914,7 @@ void vbx_tsdf_cfg_default(vbx_tsdf_cfg* c) {  // tsdf_integrator.h:59-86
   c->max_consecutive_ray_collisions = 2;
   c->clear_checks_every_n_frames = 1;
   c->max_integration_time_s = 3.402823466e+38f;
+  c->merged_bundle_order = 0;
 }
 
 void vbx_esdf_cfg_default(vbx_esdf_cfg* c) {  // esdf_integrator.h:37-77
@@ -2961,7 +3030,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);

@@ -254,6 +254,8 @@ class TsdfIntegratorBase {  // tsdf_integrator.h:51-198
     int max_consecutive_ray_collisions = 2;
     int clear_checks_every_n_frames = 1;
     float max_integration_time_s = std::numeric_limits<float>::max();
+    // not in the reference: 0 = the reference's unordered_map bundle order (bit-exact), 1 = ascending voxel key (faster)
+    int merged_bundle_order = 0;
   };
 
   TsdfIntegratorBase(const Config& config, Layer<TsdfVoxel>* layer) : config_(config) {
@@ -297,6 +299,7 @@ class TsdfIntegratorBase {  // tsdf_integrator.h:51-198
     c.max_consecutive_ray_collisions = config_.max_consecutive_ray_collisions;
     c.clear_checks_every_n_frames = config_.clear_checks_every_n_frames;
     c.max_integration_time_s = config_.max_integration_time_s;
+    c.merged_bundle_order = config_.merged_bundle_order;
     const DeviceMap& m = *layer_->map();
     m.check(vbx_tsdf_integrate(m.ctx(), kind, &c, &T_G_C.getPosition().x, T_G_C.getRotationWxyz().data(),
                                points_C.empty() ? nullptr : &points_C[0].x,
