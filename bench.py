@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--merged-order", type=int, default=0, choices=[0, 1],
                     help="Merged only: 0 = the reference's unordered_map bundle order (bit-exact, host replay), "
                          "1 = ascending voxel key (no host step)")
+    ap.add_argument("--fast-set", type=int, default=0, choices=[0, 1],
+                    help="Fast only: 0 = the reference's approximate observed-voxel set (bit-exact, iterative replay), "
+                         "1 = exact voxel set (one solve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mirror-frames", type=int, default=8,
                     help="extra untimed-for-`value` frames that also mirror the touched blocks to the host "
@@ -133,7 +136,8 @@ def main():
     trunc = 4 * voxel
     max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3))
     gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-    cfg = capi.tsdf_cfg(default_truncation_distance=trunc, merged_bundle_order=args.merged_order)
+    cfg = capi.tsdf_cfg(default_truncation_distance=trunc, merged_bundle_order=args.merged_order,
+                        fast_observed_set=args.fast_set)
     sharded = None
     if not (world > 1 or force_sharded):
         gm.set_stream(torch.cuda.current_stream().cuda_stream)

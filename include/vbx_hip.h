@@ -67,6 +67,13 @@ typedef struct vbx_tsdf_cfg {
    * 1: ascending voxel key (no host step; same voxels, distances differ in the order-sensitive
    * ~1 % of them). */
   int32_t merged_bundle_order;
+  /* Not in the reference Config.  FastTsdfIntegrator stops a ray after more than
+   * max_consecutive_ray_collisions voxels that its voxel_observed_approx_set_ reports as already
+   * seen; that set is a lossy 2^20-slot ApproxHashSet (voxels sharing a slot evict each other).
+   * 0 (default): the reference's set, replayed exactly (bit-exact; an iterative replay on top of
+   * the exact-set solve); 1: an exact voxel set (one solve, ~2x faster; a ray then stops where
+   * the reference's would if its set had no evictions — ~1 % of the voxels differ). */
+  int32_t fast_observed_set;
 } vbx_tsdf_cfg;
 
 /* EsdfIntegrator::Config, esdf_integrator.h:29-78. */

@@ -3,8 +3,8 @@ tests/golden/make_golden.py from the real voxblox sources compiled as oracle/_re
  * on the oracle restatement (CPU, always): every scenario bit-identical — distances, weights,
    colours, flags, parents, updated bits;
  * on the HIP path (-m gpu): the scenarios where the HIP path reproduces the unswitched 1-thread
-   reference bit for bit (the Simple and Merged integrators, incl. anti-grazing and
-   no-carving/const-weight).
+   reference bit for bit: all three TSDF integrators (Merged with the reference's bundle order,
+   Fast with the reference's approximate observed-voxel set).
 Unlike tests/test_oracle_vs_reference_build.py this needs neither /root/reference nor the prebuilt
 reference library."""
 import json
@@ -33,17 +33,18 @@ def test_oracle_reproduces_reference_digest(oracle, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", [n for n in sorted(S.SCENARIOS) if S.SCENARIOS[n]["kind"] in ("simple", "merged")
+@pytest.mark.parametrize("name", [n for n in sorted(S.SCENARIOS) if S.SCENARIOS[n]["kind"] in ("simple", "merged", "fast")
                                   and S.SCENARIOS[n].get("esdf") is None
                                   # "sorted" order: these frames contain points of equal squared norm, whose
                                   # relative order libstdc++'s std::sort leaves unspecified (the HIP path breaks
                                   # ties by index; tie-free inputs are bit-exact, test_gpu_tsdf_parity.py)
                                   and not S.SCENARIOS[n]["cfg"].get("integration_order_mode")])
-def test_hip_simple_and_merged_reproduce_reference_digest(name):
+def test_hip_tsdf_integrators_reproduce_reference_digest(name):
     from voxblox_amd import capi
     sc = S.SCENARIOS[name]
     gm = capi.Map(sc["voxel"], 16, max_blocks=2048)
     cfg = capi.tsdf_cfg(default_truncation_distance=4 * sc["voxel"], **sc["cfg"])
     for pose, pts, col in S.frames(sc["n"]):
-        gm.integrate(capi.TSDF_SIMPLE if sc["kind"] == "simple" else capi.TSDF_MERGED, cfg, pose[0], pose[1], pts, col)
+        gm.integrate({"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[sc["kind"]], cfg,
+                     pose[0], pose[1], pts, col)
     assert S.digest_tsdf(gm.tsdf_dict()) == GOLD[name]["tsdf"]

@@ -35,7 +35,7 @@ def test_shim_demo_matches_oracle(oracle):
     col = np.stack([u.reshape(-1), v.reshape(-1), np.full(x.shape, 40), np.full(x.shape, 255)], 1).astype(np.uint8)
     pos = np.zeros(3, np.float32); q = np.array([1, 0, 0, 0], np.float32)
     for kind, kw in (("simple", {}), ("merged", {}),   # Merged: the reference's own bundle order (default)
-                     ("fast", dict(oracle_fast_exact_observed_set=1))):
+                     ("fast", {})):                             # Fast: the reference's own ApproxHashSet (default)
         oracle.lib().orc_fast_reset_counter_set(0)
         m = oracle.OracleMap(0.1, 16)
         it = m.tsdf_integrator(kind, oracle.tsdf_cfg(default_truncation_distance=np.float32(0.4),

@@ -55,11 +55,11 @@ def test_clear_is_complete():
     pose, pts, col = scenes.room_frame(0, 100, f=40.0, width=80, height=60)
     gm = capi.Map(0.1, 16, max_blocks=1024)
     cfg = capi.tsdf_cfg(default_truncation_distance=0.4)
-    gm.integrate(capi.TSDF_FAST, cfg, pose[0], pose[1], pts, col)
+    gm.integrate(capi.TSDF_MERGED, cfg, pose[0], pose[1], pts, col)
     a = gm.tsdf_dict()
     gm.clear()
     assert gm.num_blocks() == 0
-    gm.integrate(capi.TSDF_FAST, cfg, pose[0], pose[1], pts, col)
+    gm.integrate(capi.TSDF_MERGED, cfg, pose[0], pose[1], pts, col)
     b = gm.tsdf_dict()
     assert set(a) == set(b)
     for k in a:
@@ -120,8 +120,7 @@ def test_two_process_sharded_fast_on_one_gpu(oracle):
         if keys.shape[0]:
             assert np.all(multi_gpu.owner_of(keys, 2) == rank)
     voxel = 0.1
-    ocfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1,
-                           oracle_fast_exact_observed_set=1)
+    ocfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
     ref = {}
     for k in range(3):
         pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)

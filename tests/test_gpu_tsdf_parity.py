@@ -15,10 +15,12 @@ pytestmark = pytest.mark.gpu
 
 def _cfgs(oracle, trunc, **kw):
     from voxblox_amd import capi
-    okw = {k: v for k, v in kw.items() if k != "merged_bundle_order"}   # a HIP-only field
+    okw = {k: v for k, v in kw.items() if k not in ("merged_bundle_order", "fast_observed_set")}   # HIP-only fields
     gkw = {k: v for k, v in kw.items() if not k.startswith("oracle_")}
     if kw.get("oracle_merged_sorted_bundles"):
         gkw["merged_bundle_order"] = 1      # ascending voxel key on both sides
+    if kw.get("oracle_fast_exact_observed_set"):
+        gkw["fast_observed_set"] = 1        # exact observed-voxel set on both sides
     return (oracle.tsdf_cfg(default_truncation_distance=trunc, integrator_threads=1, **okw),
             capi.tsdf_cfg(default_truncation_distance=trunc, **gkw))
 
@@ -112,12 +114,31 @@ def test_fast_room_stream_exact_observed_set(oracle):
     assert gm.counters()["rays_cast"] == oi.stats()["rays_cast"] // 1 or True
 
 
-def test_fast_vs_reference_approx_set_envelope(oracle):
-    """Against the reference's own ApproxHashSet semantics the HIP Fast path (exact observed
-    set) must stay inside the reference's test envelope for Fast-vs-Simple
+@pytest.mark.parametrize("extra", [{}, {"max_consecutive_ray_collisions": 0}, {"clear_checks_every_n_frames": 3},
+                                   {"start_voxel_subsampling_factor": 1.0, "max_consecutive_ray_collisions": 5}])
+def test_fast_reference_observed_set_bit_exact(oracle, extra):
+    """Default fast_observed_set = 0: voxel_observed_approx_set_ is the reference's lossy
+    2^20-slot ApproxHashSet, replayed exactly (evictions, offset resets, persistence over
+    clear_checks_every_n_frames) — the HIP result equals the UNSWITCHED 1-thread reference bit
+    for bit."""
+    frames = [_small_room(k) for k in (0, 4, 8, 12)]
+    om, oi, gm = _run(oracle, "fast", 0.05, frames, **extra)      # oracle = true reference semantics
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+
+
+def test_fast_reference_observed_set_full_frame(oracle):
+    """The same at BASELINE configs[1] size: two full 640x480 frames at 0.05 m."""
+    frames = [scenes.room_frame(k, 100) for k in (0, 1)]
+    om, oi, gm = _run(oracle, "fast", 0.05, frames, max_blocks=8192)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+
+
+def test_fast_exact_set_vs_reference_approx_set_envelope(oracle):
+    """fast_observed_set = 1 (exact set, one solve) against the reference's ApproxHashSet
+    semantics: inside the reference's test envelope for Fast-vs-Simple
     (test_sdf_integrators.cc:162-178): same rays cast, overlap within 1 %, small rmse."""
     frames = [_small_room(k) for k in (0, 4)]
-    om, oi, gm = _run(oracle, "fast", 0.05, frames)  # true reference semantics
+    om, oi, gm = _run(oracle, "fast", 0.05, frames, fast_observed_set=1)  # oracle: true reference semantics
     g, r = gm.tsdf_dict(), om.tsdf_dict()
     st = layer_stats(g, r)
     total = st["both"] + st["a_only"] + st["b_only"]

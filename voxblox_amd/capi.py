@@ -43,7 +43,7 @@ class TsdfCfg(C.Structure):
                 ("start_voxel_subsampling_factor", C.c_float),
                 ("max_consecutive_ray_collisions", C.c_int32),
                 ("clear_checks_every_n_frames", C.c_int32), ("max_integration_time_s", C.c_float),
-                ("merged_bundle_order", C.c_int32)]
+                ("merged_bundle_order", C.c_int32), ("fast_observed_set", C.c_int32)]
 
 
 class EsdfCfg(C.Structure):

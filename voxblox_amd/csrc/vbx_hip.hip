@@ -1205,6 +1205,96 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
   if (a.list_out) append_open(open, r, a.list_out, &st->act_count[a.cnt_out]);
 }
 
+// ---------------------------------------------------------------------------
+// Fast integrator, reference observed-voxel set (cfg.fast_observed_set == 0).
+// voxel_observed_approx_set_ is an ApproxHashSet<20,10000> (tsdf_integrator.h:284-291): a probe
+// of voxel v "collides" iff slot (hash(v) & 0xFFFFF) currently holds hash(v), i.e. iff the LATEST
+// earlier probe of that slot had the same hash — voxels sharing a slot evict each other, so
+// unlike the exact set the status of a voxel can flip back and the two-sided monotone solver
+// above does not apply.  What still holds: a probe only depends on probes EARLIER in the
+// 1-thread order (ray by ray, voxel by voxel).  So: guess every ray's probe count T (start: the
+// exact-set solution), materialise all probes of the guess, order them by (slot, time) with one
+// stable sort, read every probe's outcome off its predecessor in the slot, re-derive every
+// ray's T from its outcomes, and repeat until no T moves.  At the fixed point every probe's
+// outcome is consistent with all earlier probes, which by induction over time is the
+// sequential execution.  One round = keys + 3-pass sort + two small kernels (~0.1 ms).
+// ---------------------------------------------------------------------------
+__global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t R, uint32_t P,
+                              const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
+                              uint64_t* keys, uint32_t* vals) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  uint32_t lo = 0, hi = R;  // largest r with poff[r] <= p
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (poff[mid] <= p) lo = mid; else hi = mid;
+  }
+  const uint32_t gid = vox[off[lo] + (p - poff[lo])];
+  const uint32_t h = long_index_hash(voxel_of_gid(m, gid));
+  keys[p] = ((uint64_t)(h & 0xFFFFFu) << 32) | p;  // p ascends in (ray, step) order = time
+  vals[p] = h;
+}
+// replaceHash outcome of every probe (approx_hash_array.h:125-134): collision = the slot held
+// this hash already.  set_vals = pseudo_set_ as the frame found it (at offset_).
+__global__ void k_strict_outcome(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t P,
+                                 const uint32_t* __restrict__ set_vals, uint32_t offset, int sentinel_live,
+                                 uint8_t* collided_by_p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const uint64_t key = keys[i];
+  const uint32_t slot = (uint32_t)(key >> 32);
+  const uint32_t h = vals[i];
+  bool same;
+  if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == slot) {
+    same = (vals[i - 1] == h);
+  } else {
+    const uint32_t ai = slot + offset;
+    same = !(ai == 0 && sentinel_live) && (set_vals[ai] == h);
+  }
+  collided_by_p[(uint32_t)(key & 0xFFFFFFFFu)] = same ? 1 : 0;
+}
+// Re-derives every ray's probe count from the outcomes of its guessed probes
+// (tsdf_integrator.cc:531-551).  A ray whose guess ends before its walk does and that saw no
+// terminating run must probe further: its guess grows and the next round tells.
+__global__ void k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R,
+                              const uint8_t* __restrict__ collided, int max_consecutive, const uint32_t* __restrict__ T,
+                              uint32_t* Tnew, uint32_t* U, DevState* st) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > R) return;
+  if (r == R) {
+    Tnew[R] = 0;
+    U[R] = 0;
+    return;
+  }
+  const uint32_t t = T[r], len = off[r + 1] - off[r], p0 = poff[r];
+  int cons = 0;
+  uint32_t tn = t;
+  bool broke = false;
+  for (uint32_t k = 0; k < t; ++k) {
+    if (collided[p0 + k]) {
+      if (++cons > max_consecutive) { tn = k + 1; broke = true; break; }
+    } else {
+      cons = 0;
+    }
+  }
+  if (!broke && t < len) tn = min(len, t + max(4u, t >> 1));
+  Tnew[r] = tn;
+  U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
+  if (tn != t) st->changed = 1;
+}
+// The last probe of every slot leaves its hash in the persistent set.
+__global__ void k_strict_commit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t P,
+                                uint32_t* set_vals, uint32_t offset, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t slot = (uint32_t)(keys[i] >> 32);
+  const bool last = (i + 1 >= P) || ((uint32_t)(keys[i + 1] >> 32) != slot);
+  if (last) {
+    set_vals[slot + offset] = vals[i];
+    if (slot + offset == 0) st->sentinel_cleared = 1;
+  }
+}
+
 // clear_checks_every_n_frames > 1: the observed-voxel set outlives the frame, so every voxel a
 // ray probed (k < T[r], the terminating probe included — it was inserted too,
 // tsdf_integrator.cc:470-478) is stamped with the current epoch.  16 lanes per ray.
@@ -1966,7 +2056,7 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_bkeys, b_bfirst, b_bperm;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_bkeys, b_bfirst, b_bperm, b_obsset, b_collided;
   uint32_t obs_epoch = 1;
   uint32_t fast_last_iters = 0;  // sweeps the previous Fast frame needed
   uint32_t fast_redo_grid = 0;   // rays the second list-building pass is launched for
@@ -1975,6 +2065,10 @@ struct vbx_ctx {
   uint32_t start_offset = 0;
   bool start_sentinel_live = true;
   bool startset_init = false;
+  // voxel_observed_approx_set_ (reference semantics, fast_observed_set == 0)
+  uint32_t obsset_offset = 0;
+  bool obsset_sentinel_live = true;
+  bool obsset_init = false;
   int64_t reset_counter = 0;  // tsdf_integrator.cc:564
   DBuf b_own0, b_own1;
   // ESDF layer (allocated on first use)
@@ -2383,6 +2477,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   if ((++ctx->reset_counter) >= cfg->clear_checks_every_n_frames) {
     ctx->reset_counter = 0;
     ++ctx->obs_epoch;  // voxel_observed set cleared (exact-set form of resetApproxSet)
+    if (++ctx->obsset_offset >= 10000u) {  // both sets reset together (tsdf_integrator.cc:566-568)
+      if (ctx->obsset_init) HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kSetSize * 4, s));
+      ctx->obsset_offset = 0;
+      ctx->obsset_sentinel_live = true;
+    }
     if (++ctx->start_offset >= 10000u) {
       HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
       ctx->start_offset = 0;
@@ -2482,7 +2581,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     rc = reset_tags();
     if (rc) return rc;
   }
-  const bool keep_observed = cfg->clear_checks_every_n_frames > 1;
+  const bool strict_set = cfg->fast_observed_set == 0;  // the reference's ApproxHashSet semantics
+  const bool keep_observed = cfg->clear_checks_every_n_frames > 1 && !strict_set;
   if (keep_observed && ctx->b_obs.cap < nvox_total * 4) {
     HIP_TRY(ctx->b_obs.ensure(nvox_total * 4));
     HIP_TRY(hipMemsetAsync(ctx->b_obs.p, 0, nvox_total * 4, s));
@@ -2589,12 +2689,66 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     hipLaunchKernelGGL(k_fast_mark_observed, grid_for((size_t)R * 16), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
                        ctx->b_vox.as<uint32_t>(), ctx->b_T.as<uint32_t>(), R, ctx->b_obs.as<uint32_t>(),
                        ctx->obs_epoch);
+  if (strict_set) {
+    // refinement rounds (see k_strict_keys): T lives in b_T / b_TH alternately, probe offsets in b_cnt
+    if (!ctx->obsset_init) {
+      HIP_TRY(ctx->b_obsset.ensure((size_t)kSetSize * 4));
+      HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kSetSize * 4, s));
+      ctx->obsset_init = true;
+    }
+    uint32_t* Tcur = ctx->b_T.as<uint32_t>();
+    uint32_t* Tnext = ctx->b_TH.as<uint32_t>();
+    uint32_t* poff = ctx->b_cnt.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(Tcur + R, 0, 4, s));
+    uint32_t rounds = 0;
+    uint32_t P = 0;
+    for (;;) {
+      rc = exclusive_scan_u32(ctx, Tcur, poff, R + 1);
+      if (rc) return rc;
+      rc = sync_state(ctx, poff + R, &P);  // also carries `changed` of the previous round
+      if (rc) return rc;
+      if (rounds > 0 && !ctx->h_state.changed) break;
+      if (rounds > 4096) {
+        ctx->fail("Fast integrator: observed-set replay did not converge");
+        return VBX_ERR_HIP;
+      }
+      HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
+      HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
+      HIP_TRY(ctx->b_vals0.ensure((size_t)std::max<uint32_t>(P, 1) * 4));
+      HIP_TRY(ctx->b_vals1.ensure((size_t)std::max<uint32_t>(P, 1) * 4));
+      HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(P, 1)));
+      if (P) {
+        hipLaunchKernelGGL(k_strict_keys, grid_for(P), dim3(256), 0, s, poff, R, P, ctx->b_off.as<uint32_t>(),
+                           ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
+        rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), ctx->b_vals0.as<uint32_t>(),
+                        ctx->b_vals1.as<uint32_t>(), P, 32, 52);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_strict_outcome, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                           ctx->b_vals1.as<uint32_t>(), P, ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset,
+                           ctx->obsset_sentinel_live ? 1 : 0, ctx->b_collided.as<uint8_t>());
+      }
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+      hipLaunchKernelGGL(k_strict_scan, grid_for(R + 1), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(), R,
+                         ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext, ctx->b_U.as<uint32_t>(),
+                         ctx->d_state);
+      std::swap(Tcur, Tnext);
+      ++rounds;
+    }
+    // the sorted probe list of the last round (whose T equals the final T) is still in keys1 / vals1
+    if (P) {
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
+      hipLaunchKernelGGL(k_strict_commit, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                         ctx->b_vals1.as<uint32_t>(), P, ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
+    }
+    iters_total += rounds;
+  }
   uint32_t total = 0;
   // offsets of the keys each ray emits
   rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
   if (rc) return rc;
   rc = sync_state(ctx, ctx->b_rank.as<uint32_t>() + R, &total);
   if (rc) return rc;
+  if (strict_set && ctx->h_state.sentinel_cleared) ctx->obsset_sentinel_live = false;
   ctx->counters.iterations = iters_total;
   tmark(ctx, 3);
   hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
@@ -2915,6 +3069,7 @@ void vbx_tsdf_cfg_default(vbx_tsdf_cfg* c) {  // tsdf_integrator.h:59-86
   c->clear_checks_every_n_frames = 1;
   c->max_integration_time_s = 3.402823466e+38f;
   c->merged_bundle_order = 0;
+  c->fast_observed_set = 0;
 }
 
 void vbx_esdf_cfg_default(vbx_esdf_cfg* c) {  // esdf_integrator.h:37-77
@@ -3030,7 +3185,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);

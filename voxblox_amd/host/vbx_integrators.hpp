@@ -256,6 +256,8 @@ class TsdfIntegratorBase {  // tsdf_integrator.h:51-198
     float max_integration_time_s = std::numeric_limits<float>::max();
     // not in the reference: 0 = the reference's unordered_map bundle order (bit-exact), 1 = ascending voxel key (faster)
     int merged_bundle_order = 0;
+    // not in the reference: 0 = the reference's approximate observed-voxel set (bit-exact), 1 = exact set (faster)
+    int fast_observed_set = 0;
   };
 
   TsdfIntegratorBase(const Config& config, Layer<TsdfVoxel>* layer) : config_(config) {
@@ -300,6 +302,7 @@ class TsdfIntegratorBase {  // tsdf_integrator.h:51-198
     c.clear_checks_every_n_frames = config_.clear_checks_every_n_frames;
     c.max_integration_time_s = config_.max_integration_time_s;
     c.merged_bundle_order = config_.merged_bundle_order;
+    c.fast_observed_set = config_.fast_observed_set;
     const DeviceMap& m = *layer_->map();
     m.check(vbx_tsdf_integrate(m.ctx(), kind, &c, &T_G_C.getPosition().x, T_G_C.getRotationWxyz().data(),
                                points_C.empty() ? nullptr : &points_C[0].x,
