@@ -50,9 +50,10 @@ def test_oracle_and_capi_defaults_agree(oracle):
     from voxblox_amd import capi
     o, g = oracle.tsdf_cfg(), capi.tsdf_cfg()
     for name, _ in capi.TsdfCfg._fields_:
-        if name == "integrator_threads":
-            continue
+        if name in ("integrator_threads", "merged_bundle_order", "fast_observed_set"):
+            continue   # the last two are HIP-only fields; 0 = the reference's semantics
         assert getattr(o, name) == getattr(g, name), name
+    assert g.merged_bundle_order == 0 and g.fast_observed_set == 0
     oe, ge = oracle.esdf_cfg(), capi.esdf_cfg()
     for name, _ in capi.EsdfCfg._fields_:
         assert getattr(oe, name) == getattr(ge, name), name
