@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <memory_resource>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -2065,6 +2066,7 @@ struct vbx_ctx {
   uint32_t start_offset = 0;
   bool start_sentinel_live = true;
   bool startset_init = false;
+  std::vector<int32_t> h_by_s;  // scratch of merged_reference_order
   // voxel_observed_approx_set_ (reference semantics, fast_observed_set == 0)
   uint32_t obsset_offset = 0;
   bool obsset_sentinel_live = true;
@@ -2379,12 +2381,23 @@ int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t**
   // the keys are sorted with the clearing bit on top: [0, n1) normal bundles, [n1, nb) clearing
   uint32_t n1 = 0;
   while (n1 < nb && !(keys[n1] >> 63)) ++n1;
+  // insertion order = ascending visiting position of each bundle's first point; positions are
+  // unique and < n, so a direct-address pass orders them without a comparison sort
+  std::vector<int32_t>& by_s = ctx->h_by_s;
+  by_s.assign(n, -1);
+  for (uint32_t b = 0; b < nb; ++b) by_s[first[b]] = (int32_t)b;
+  uint32_t q1 = 0, q2 = n1;
+  for (size_t sidx = 0; sidx < n; ++sidx) {
+    const int32_t b = by_s[sidx];
+    if (b < 0) continue;
+    if ((uint32_t)b < n1) idx[q1++] = (uint32_t)b; else idx[q2++] = (uint32_t)b;
+  }
   uint32_t row = 0;
   for (int pass = 0; pass < 2; ++pass) {
     const uint32_t lo = pass ? n1 : 0, hi = pass ? nb : n1;
-    for (uint32_t b = lo; b < hi; ++b) idx[b] = b;
-    std::sort(idx.begin() + lo, idx.begin() + hi, [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
-    std::unordered_map<l3, uint32_t, HostL3Hash, HostL3Eq> map;
+    // node storage from a monotonic arena: the allocator has no influence on the iteration order
+    std::pmr::monotonic_buffer_resource arena((size_t)(hi - lo) * 64 + 4096);
+    std::pmr::unordered_map<l3, uint32_t, HostL3Hash, HostL3Eq> map(&arena);
     for (uint32_t q = lo; q < hi; ++q) {
       const uint64_t k = keys[idx[q]] & ~(1ull << 63);
       const l3 g{(long long)(k & 0x1FFFFFu) - (1ll << 20), (long long)((k >> 21) & 0x1FFFFFu) - (1ll << 20),
