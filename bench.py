@@ -240,6 +240,32 @@ def main():
                   "integrate_ms": round(t_int / M * 1e3, 4), "mirror_ms": round(t_mir / M * 1e3, 4),
                   "note": "mirror = list updated blocks + AoS pack kernel + one D2H copy into page-locked staging + clear kMap bits"}
 
+    # The non-default fast modes (results differ from the reference on ~1 % of the voxels, see
+    # include/vbx_hip.h), measured beside the bit-exact default for reference.
+    variants = None
+    if sharded is None and rank == 0 and not args.esdf and args.integrator in ("fast", "merged") \
+            and args.fast_set == 0 and args.merged_order == 0:
+        vkw = {"fast": dict(fast_observed_set=1), "merged": dict(merged_bundle_order=1)}[args.integrator]
+        vcfg = capi.tsdf_cfg(default_truncation_distance=trunc, **vkw)
+        vm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+        vm.set_stream(torch.cuda.current_stream().cuda_stream)
+        vsteps = max(10, min(args.steps, 40))
+        for i in range(args.warmup + vsteps):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                tv0 = time.perf_counter()
+            pose, dp, dc = d_frames[i % len(d_frames)]
+            vm.integrate_device(kind, vcfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_pts_all[i % len(d_frames)])
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - tv0
+        vpts = sum(n_pts_all[i % len(d_frames)] for i in range(args.warmup, args.warmup + vsteps))
+        name = list(vkw.items())[0]
+        variants = {"%s=%d" % name: {"value": round(vpts / tv / 1e6, 3), "unit": "Mpoints/s",
+                                     "ms_per_step": round(tv / vsteps * 1e3, 4), "steps": vsteps,
+                                     "note": "not bit-exact against the reference (exact observed-voxel set / "
+                                             "sorted bundle order); the default mode above is"}}
+        vm.close()
+
     K = args.steps
     pts_timed = sum(n_pts_all[i % len(d_frames)] for i in range(args.warmup, total))
     value = world * pts_timed / dt / 1e6
@@ -251,6 +277,8 @@ def main():
         "config": {"workload": f"{args.integrator.capitalize()}TsdfIntegrator, 640x480 synthetic room scan "
                                "stream (BASELINE configs[1]), %g m voxels / 16^3 blocks, trunc %g m" % (voxel, trunc),
                    "points_per_step": n_pts, "voxel_size": voxel, "voxels_per_side": 16,
+                   "semantics": "bit-exact vs the 1-thread reference" if (args.merged_order == 0 and args.fast_set == 0)
+                                else "fast mode (merged_bundle_order=%d, fast_observed_set=%d)" % (args.merged_order, args.fast_set),
                    "parallelism": ("1 GPU, whole cloud" if world == 1 else
                                    f"{world} sensors, one ray shard per GPU, RCCL reduce-scatter block merge "
                                    "pipelined behind the next frame's integration, map distributed by block owner")},
@@ -298,6 +326,8 @@ def main():
                            "counters_per_update": {k: round(v / K, 1) for k, v in esdf_cnt.items()}}
         if mirror:
             out["host_mirror"] = mirror
+        if variants:
+            out["variants"] = variants
         out["config"]["scene"] = args.scene
         out["config"]["esdf_after_each_frame"] = bool(args.esdf)
         if world == 1 and not args.no_cpu_baseline:
