@@ -1278,10 +1278,14 @@ __global__ void k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t*
       cons = 0;
     }
   }
-  if (!broke && t < len) tn = min(len, t + max(4u, t >> 1));
+  if (!broke && t < len) tn = min(len, max(4u * t, t + 16u));  // surplus probes vanish again next round
   Tnew[r] = tn;
   U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
-  if (tn != t) st->changed = 1;
+  if (tn != t) {
+    st->changed = 1;
+    atomicAdd(&st->act_count[0], 1u);                       // rays whose probe count moved this round
+    if (!broke) atomicAdd(&st->act_count[1], 1u);           // of which: guesses that had to grow
+  }
 }
 // The last probe of every slot leaves its hash in the persistent set.
 __global__ void k_strict_commit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t P,
@@ -2720,6 +2724,9 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       if (rc) return rc;
       rc = sync_state(ctx, poff + R, &P);  // also carries `changed` of the previous round
       if (rc) return rc;
+      if (getenv("VBX_DEBUG") && rounds > 0)
+        fprintf(stderr, "[vbx] strict round %u: %u probes, %u rays moved (%u grew)\n", rounds, P, ctx->h_state.act_count[0],
+                ctx->h_state.act_count[1]);
       if (rounds > 0 && !ctx->h_state.changed) break;
       if (rounds > 4096) {
         ctx->fail("Fast integrator: observed-set replay did not converge");
@@ -2741,6 +2748,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                            ctx->obsset_sentinel_live ? 1 : 0, ctx->b_collided.as<uint8_t>());
       }
       HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
       hipLaunchKernelGGL(k_strict_scan, grid_for(R + 1), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(), R,
                          ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext, ctx->b_U.as<uint32_t>(),
                          ctx->d_state);
