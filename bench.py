@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--fast-set", type=int, default=0, choices=[0, 1],
                     help="Fast only: 0 = the reference's approximate observed-voxel set (bit-exact, iterative replay), "
                          "1 = exact voxel set (one solve)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the fast-mode variant measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mirror-frames", type=int, default=8,
                     help="extra untimed-for-`value` frames that also mirror the touched blocks to the host "
@@ -243,7 +244,7 @@ def main():
     # The non-default fast modes (results differ from the reference on ~1 % of the voxels, see
     # include/vbx_hip.h), measured beside the bit-exact default for reference.
     variants = None
-    if sharded is None and rank == 0 and not args.esdf and args.integrator in ("fast", "merged") \
+    if sharded is None and rank == 0 and not args.esdf and not args.no_variants and args.integrator in ("fast", "merged") \
             and args.fast_set == 0 and args.merged_order == 0:
         vkw = {"fast": dict(fast_observed_set=1), "merged": dict(merged_bundle_order=1)}[args.integrator]
         vcfg = capi.tsdf_cfg(default_truncation_distance=trunc, **vkw)
@@ -289,7 +290,7 @@ def main():
         # whole sweep sequence, timed with HIP events on the launch stream inside the library
         # (vbx_get_timing solve_ms) and averaged over the K timed frames.  The per-launch average
         # (kernel_ms / launches_per_step) is the number to compare with rocprofv3's avg duration
-        # (profiles/r01b_kernel_stats.md).  Algorithmic bytes per frame:
+        # (profiles/r01c_kernel_stats.md).  Algorithmic bytes per frame:
         #   16 B x N_points + 24 B x U (distinct voxels updated), U counted on the device.
         U = counters.get("voxels_touched", 0) / K
         alg_bytes = 16.0 * n_pts + 24.0 * U
@@ -297,22 +298,26 @@ def main():
         dom = max(stages, key=stages.get) if stages else "total_ms"
         dom_ms = stages.get(dom, 0.0)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        kernel_of_stage = {"solve_ms": "k_fast_sweep", "fold_ms": "k_fold", "emit_ms": "k_ray_emit",
+        kernel_of_stage = {"solve_ms": "k_fast_sweep", "replay_ms": "rocprim::onesweep_iteration", "fold_ms": "k_fold", "emit_ms": "k_ray_emit",
                            "prep_ms": "k_prep_points+sort", "alloc_ms": "k_fast_build_lists", "sort_ms": "rocprim onesweep"}
         kname = kernel_of_stage.get(dom, dom)
-        launches = (counters.get("iterations", 0) / K) if dom == "solve_ms" else 1.0
+        launches = {"solve_ms": counters.get("iterations", 0) / K,
+                    "replay_ms": 3.0 * counters.get("replay_rounds", 0) / K}.get(dom, 1.0)   # 3 onesweep passes per round
+        launches = max(launches, 1.0)
         # HBM bytes of that kernel per frame from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-        # runs, profiles/r01b_pmc_hbm_traffic.json); null when no summary for this kernel exists.
+        # runs, profiles/r01c_pmc_hbm_traffic.json); null when no summary for this kernel exists.
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm_traffic.json")))["per_frame_bytes"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.json")))["per_frame_bytes"]
             if args.integrator == "fast" and args.scene == "room" and kname in pmc:
                 traffic = int(pmc[kname]["fetch_bytes"] + pmc[kname]["write_bytes"])
         except (OSError, KeyError, ValueError):
             traffic = None
+        kdesc = {"k_fast_sweep": "k_fast_sweep (early-termination solver)",
+                 "rocprim::onesweep_iteration": "rocprim onesweep passes of the observed-set replay rounds"}.get(kname, kname)
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                           "kernel": kname, "launch": "all launches of one frame (stage %s)" % dom,
+                           "kernel": kdesc, "launch": "all launches of one frame (stage %s)" % dom,
                            "kernel_ms": round(dom_ms, 4), "launches_per_step": round(launches, 1),
                            "avg_launch_us": round(dom_ms * 1e3 / max(launches, 1.0), 2),
                            "algorithmic_bytes_per_launch": int(alg_bytes),

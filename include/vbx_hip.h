@@ -231,6 +231,7 @@ typedef struct vbx_counters {
   uint64_t esdf_blocks;     /* ESDF: TSDF blocks propagated */
   uint64_t esdf_relaxations;/* ESDF: successful wavefront relaxations */
   uint64_t esdf_sweeps;     /* ESDF: wavefront sweeps */
+  uint64_t replay_rounds;   /* Fast, fast_observed_set = 0: rounds of the observed-set replay */
 } vbx_counters;
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
 
@@ -243,6 +244,7 @@ typedef struct vbx_timing {
   float emit_ms;     /* ray march emitting ordered voxel updates */
   float sort_ms;     /* ordering of the updates */
   float fold_ms;     /* per-voxel ordered fold (the TSDF update itself) */
+  float replay_ms;   /* Fast, fast_observed_set = 0: replay rounds of the reference's observed-voxel set */
 } vbx_timing;
 int vbx_enable_timing(vbx_ctx* ctx, int enable);
 int vbx_get_timing(vbx_ctx* ctx, vbx_timing* out);

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=$PWD
 rm -rf /tmp/prof
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-cpu-baseline --mirror-frames 0 "$@" > /tmp/b.log 2>&1
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-cpu-baseline --mirror-frames 0 --no-variants "$@" > /tmp/b.log 2>&1
 grep -v "^W2026\|^E2026" /tmp/b.log | tail -1 | cut -c1-200
 python - <<'PY'
 import csv, glob, re, collections

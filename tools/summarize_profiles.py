@@ -25,7 +25,7 @@ for r in csv.DictReader(open(f'{src}/kernel_stats.csv')):
 tot = sum(v[1] for v in agg.values())
 lines = [f"# rocprofv3 --kernel-trace --stats — {tag}", "",
          "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 3 "
-         "--no-cpu-baseline --mirror-frames 0`",
+         "--no-cpu-baseline --mirror-frames 0 --no-variants`",
          f"({frames_stats} frames of BASELINE configs[1]: Fast integrator, 640x480 room stream, 0.05 m). Aggregated by kernel "
          f"(template instances merged); raw CSV: profiles/{tag}_kernel_stats.csv", "",
          "| kernel | calls | calls/frame | total us | avg us | us/frame | % |", "|---|---|---|---|---|---|---|"]
@@ -46,7 +46,7 @@ for name, col in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         if name == 'fetch':
             d['launches'] += 1
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 5 "
-                  "--warmup 1 --no-cpu-baseline --mirror-frames 0 (two separate passes)",
+                  "--warmup 1 --no-cpu-baseline --mirror-frames 0 --no-variants (two separate passes)",
        "frames": frames_pmc,
        "units": "rocprofv3 reports KB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE halves wide coalesced (16 B/lane) "
                 "streams; these kernels read 4-8 B/lane, left uncorrected; Infinity-Cache hits are counted",

@@ -58,12 +58,12 @@ class EsdfCfg(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("points", "rays_cast", "voxel_updates", "voxels_touched", "blocks_allocated",
-                 "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps")]
+                 "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps", "replay_rounds")]
 
 
 class Timing(C.Structure):
     _fields_ = [(k, C.c_float) for k in
-                ("total_ms", "prep_ms", "alloc_ms", "solve_ms", "emit_ms", "sort_ms", "fold_ms")]
+                ("total_ms", "prep_ms", "alloc_ms", "solve_ms", "emit_ms", "sort_ms", "fold_ms", "replay_ms")]
 
 
 class VbxError(RuntimeError):

@@ -1257,34 +1257,61 @@ __global__ void k_strict_outcome(const uint64_t* __restrict__ keys, const uint32
 // Re-derives every ray's probe count from the outcomes of its guessed probes
 // (tsdf_integrator.cc:531-551).  A ray whose guess ends before its walk does and that saw no
 // terminating run must probe further: its guess grows and the next round tells.
-__global__ void k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R,
-                              const uint8_t* __restrict__ collided, int max_consecutive, const uint32_t* __restrict__ T,
-                              uint32_t* Tnew, uint32_t* U, DevState* st) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > R) return;
-  if (r == R) {
+__global__ void __launch_bounds__(256)
+k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R,
+              const uint8_t* __restrict__ collided, int max_consecutive, const uint32_t* __restrict__ T,
+              uint32_t* Tnew, uint32_t* U, int debug_counts, DevState* st) {
+  // 16 lanes per ray: 16 outcomes per step, the consecutive-collision counter is the run length
+  // of the ballot mask (as in sweep_ray)
+  constexpr int G = 16;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / G, gl = lane % G;
+  const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (r == R && gl == 0) {
     Tnew[R] = 0;
     U[R] = 0;
-    return;
   }
-  const uint32_t t = T[r], len = off[r + 1] - off[r], p0 = poff[r];
-  int cons = 0;
+  const bool ray_ok = r < R;
+  const uint32_t t = ray_ok ? T[r] : 0;
+  const uint32_t len = ray_ok ? off[r + 1] - off[r] : 0;
+  const uint32_t p0 = ray_ok ? poff[r] : 0;
+  const unsigned long long gmask = (1ull << G) - 1ull;
+  const unsigned long long below = (2ull << gl) - 1ull;
+  int carry = 0;
   uint32_t tn = t;
-  bool broke = false;
-  for (uint32_t k = 0; k < t; ++k) {
-    if (collided[p0 + k]) {
-      if (++cons > max_consecutive) { tn = k + 1; broke = true; break; }
-    } else {
-      cons = 0;
+  bool broke = false, done = (t == 0);
+  for (uint32_t base = 0; __any(!done); base += G) {
+    const uint32_t k = base + gl;
+    const bool act = !done && k < t;
+    const bool c = act && collided[p0 + k] != 0;
+    const unsigned long long C = (__ballot(c) >> (grp * G)) & gmask;
+    const unsigned long long z = ~C & below;
+    const int run = z ? (gl - (63 - __clzll((long long)z))) : (gl + 1);
+    const int cons = c ? (run + ((run == gl + 1) ? carry : 0)) : 0;
+    const unsigned long long B = (__ballot(act && cons > max_consecutive) >> (grp * G)) & gmask;
+    const int next_carry = __shfl(cons, grp * G + (G - 1));
+    if (!done) {
+      if (B) {
+        tn = base + (uint32_t)(__ffsll((long long)B) - 1) + 1;
+        broke = true;
+        done = true;
+      } else {
+        carry = next_carry;
+        if (base + G >= t) done = true;
+      }
     }
   }
-  if (!broke && t < len) tn = min(len, max(4u * t, t + 16u));  // surplus probes vanish again next round
-  Tnew[r] = tn;
-  U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
-  if (tn != t) {
-    st->changed = 1;
-    atomicAdd(&st->act_count[0], 1u);                       // rays whose probe count moved this round
-    if (!broke) atomicAdd(&st->act_count[1], 1u);           // of which: guesses that had to grow
+  if (gl == 0 && ray_ok) {
+    if (!broke && t < len) tn = min(len, max(4u * t, t + 16u));  // surplus probes vanish again next round
+    Tnew[r] = tn;
+    U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
+    if (tn != t) {
+      st->changed = 1;
+      if (debug_counts) {  // same-address atomics serialise (~90/us): only on request (VBX_DEBUG)
+        atomicAdd(&st->act_count[0], 1u);              // rays whose probe count moved this round
+        if (!broke) atomicAdd(&st->act_count[1], 1u);  // of which: guesses that had to grow
+      }
+    }
   }
 }
 // The last probe of every slot leaves its hash in the persistent set.
@@ -2086,8 +2113,8 @@ struct vbx_ctx {
 
   vbx_counters counters{};
   bool timing = false;
-  hipEvent_t ev[8] = {};
-  bool ev_hit[8] = {};
+  hipEvent_t ev[9] = {};  // 0..7 stage boundaries in order, 8 = end of the exact-set solve inside stage 3
+  bool ev_hit[9] = {};
   vbx_timing last_timing{};
 
   void fail(const char* fmt, ...) {
@@ -2707,6 +2734,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                        ctx->b_vox.as<uint32_t>(), ctx->b_T.as<uint32_t>(), R, ctx->b_obs.as<uint32_t>(),
                        ctx->obs_epoch);
   if (strict_set) {
+    tmark(ctx, 8);
     // refinement rounds (see k_strict_keys): T lives in b_T / b_TH alternately, probe offsets in b_cnt
     if (!ctx->obsset_init) {
       HIP_TRY(ctx->b_obsset.ensure((size_t)kSetSize * 4));
@@ -2749,9 +2777,9 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       }
       HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
       HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
-      hipLaunchKernelGGL(k_strict_scan, grid_for(R + 1), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(), R,
+      hipLaunchKernelGGL(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(), R,
                          ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext, ctx->b_U.as<uint32_t>(),
-                         ctx->d_state);
+                         getenv("VBX_DEBUG") ? 1 : 0, ctx->d_state);
       std::swap(Tcur, Tnext);
       ++rounds;
     }
@@ -2761,7 +2789,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       hipLaunchKernelGGL(k_strict_commit, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                          ctx->b_vals1.as<uint32_t>(), P, ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
     }
-    iters_total += rounds;
+    ctx->counters.replay_rounds = rounds;
   }
   uint32_t total = 0;
   // offsets of the keys each ray emits
@@ -2807,7 +2835,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   Pose T;
   T.t = {pos[0], pos[1], pos[2]};
   T.qw = quat[0]; T.qx = quat[1]; T.qy = quat[2]; T.qz = quat[3];
-  for (int i = 0; i < 8; ++i) ctx->ev_hit[i] = false;
+  for (int i = 0; i < 9; ++i) ctx->ev_hit[i] = false;
   tmark(ctx, 0);
   int rc;
   const uint32_t* rgba32 = reinterpret_cast<const uint32_t*>(d_rgba);
@@ -2840,6 +2868,11 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
     vbx_timing& o = ctx->last_timing;
     o.prep_ms = t[1]; o.alloc_ms = t[2]; o.solve_ms = t[3]; o.emit_ms = t[4];
     o.sort_ms = t[5]; o.fold_ms = t[6];
+    o.replay_ms = 0.0f;
+    if (ctx->ev_hit[8] && ctx->ev_hit[3]) {  // stage 3 = exact-set solve + reference-set replay rounds
+      (void)hipEventElapsedTime(&o.replay_ms, ctx->ev[8], ctx->ev[3]);
+      o.solve_ms = t[3] - o.replay_ms;
+    }
     (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
   }
   return VBX_OK;
@@ -2932,7 +2965,7 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   c.add_occupied_crust = cfg->add_occupied_crust != 0;
   c.voxel_size = m.voxel_size;
   const size_t nv = (size_t)used * m.nvox;
-  for (int i = 0; i < 8; ++i) ctx->ev_hit[i] = false;
+  for (int i = 0; i < 9; ++i) ctx->ev_hit[i] = false;
   tmark(ctx, 0);
   if (batch) {  // esdf_layer_->removeAllBlocks(), esdf_integrator.cc:95
     HIP_TRY(hipMemsetAsync(e.dist, 0, nv * 4, s));
@@ -3189,7 +3222,7 @@ vbx_ctx* vbx_create(const vbx_map_cfg* cfg, int device) {
               ok(hipMemsetAsync(m.rgba, 0, nv * 4, s)) &&
               ok(hipMemsetAsync(m.blk_flags, 0, (size_t)m.cap_blocks * 4, s)) &&
               ok(hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), s));
-  for (int i = 0; i < 8 && good; ++i) good = ok(hipEventCreate(&ctx->ev[i]));
+  for (int i = 0; i < 9 && good; ++i) good = ok(hipEventCreate(&ctx->ev[i]));
   good = good && ok(hipStreamSynchronize(s));
   if (!good) return bail(ctx, "vbx_create: device initialisation failed");
   return ctx;
@@ -3211,7 +3244,7 @@ void vbx_destroy(vbx_ctx* ctx) {
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 9; ++i)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
