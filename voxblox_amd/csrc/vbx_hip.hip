@@ -1220,9 +1220,13 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
 // outcome is consistent with all earlier probes, which by induction over time is the
 // sequential execution.  One round = keys + 3-pass sort + two small kernels (~0.1 ms).
 // ---------------------------------------------------------------------------
+// key = slot(20) << 44 | hash bits 20..31 << 32 | probe index: the hash travels inside the key,
+// so the sort moves 8 bytes per probe and no value array.  (Sorting only the upper 16 slot bits
+// and walking back inside the 16-slot group was slower: groups next to the sensor hold
+// thousands of probes of one hot slot.)
 __global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t R, uint32_t P,
                               const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
-                              uint64_t* keys, uint32_t* vals) {
+                              uint64_t* keys) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   uint32_t lo = 0, hi = R;  // largest r with poff[r] <= p
@@ -1232,22 +1236,25 @@ __global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t R, uin
   }
   const uint32_t gid = vox[off[lo] + (p - poff[lo])];
   const uint32_t h = long_index_hash(voxel_of_gid(m, gid));
-  keys[p] = ((uint64_t)(h & 0xFFFFFu) << 32) | p;  // p ascends in (ray, step) order = time
-  vals[p] = h;
+  keys[p] = ((uint64_t)(h & 0xFFFFFu) << 44) | ((uint64_t)(h >> 20) << 32) | p;  // p ascends in (ray, step) order = time
+}
+__device__ inline uint32_t strict_key_slot(uint64_t key) { return (uint32_t)(key >> 44); }
+__device__ inline uint32_t strict_key_hash(uint64_t key) {
+  return (uint32_t)(key >> 44) | ((uint32_t)((key >> 32) & 0xFFFu) << 20);
 }
 // replaceHash outcome of every probe (approx_hash_array.h:125-134): collision = the slot held
 // this hash already.  set_vals = pseudo_set_ as the frame found it (at offset_).
-__global__ void k_strict_outcome(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t P,
+__global__ void k_strict_outcome(const uint64_t* __restrict__ keys, uint32_t P,
                                  const uint32_t* __restrict__ set_vals, uint32_t offset, int sentinel_live,
                                  uint8_t* collided_by_p) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const uint64_t key = keys[i];
-  const uint32_t slot = (uint32_t)(key >> 32);
-  const uint32_t h = vals[i];
+  const uint32_t slot = strict_key_slot(key);
+  const uint32_t h = strict_key_hash(key);
   bool same;
-  if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == slot) {
-    same = (vals[i - 1] == h);
+  if (i > 0 && strict_key_slot(keys[i - 1]) == slot) {
+    same = (strict_key_hash(keys[i - 1]) == h);
   } else {
     const uint32_t ai = slot + offset;
     same = !(ai == 0 && sentinel_live) && (set_vals[ai] == h);
@@ -1315,16 +1322,15 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
   }
 }
 // The last probe of every slot leaves its hash in the persistent set.
-__global__ void k_strict_commit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t P,
-                                uint32_t* set_vals, uint32_t offset, DevState* st) {
+__global__ void k_strict_commit(const uint64_t* __restrict__ keys, uint32_t P, uint32_t* set_vals, uint32_t offset,
+                                DevState* st) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
-  const uint32_t slot = (uint32_t)(keys[i] >> 32);
-  const bool last = (i + 1 >= P) || ((uint32_t)(keys[i + 1] >> 32) != slot);
-  if (last) {
-    set_vals[slot + offset] = vals[i];
-    if (slot + offset == 0) st->sentinel_cleared = 1;
-  }
+  const uint64_t key = keys[i];
+  const uint32_t slot = strict_key_slot(key);
+  if (i + 1 < P && strict_key_slot(keys[i + 1]) == slot) return;  // a later probe of the same slot
+  set_vals[slot + offset] = strict_key_hash(key);
+  if (slot + offset == 0) st->sentinel_cleared = 1;
 }
 
 // clear_checks_every_n_frames > 1: the observed-voxel set outlives the frame, so every voxel a
@@ -2762,18 +2768,15 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       }
       HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
       HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
-      HIP_TRY(ctx->b_vals0.ensure((size_t)std::max<uint32_t>(P, 1) * 4));
-      HIP_TRY(ctx->b_vals1.ensure((size_t)std::max<uint32_t>(P, 1) * 4));
       HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(P, 1)));
       if (P) {
         hipLaunchKernelGGL(k_strict_keys, grid_for(P), dim3(256), 0, s, poff, R, P, ctx->b_off.as<uint32_t>(),
-                           ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
-        rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), ctx->b_vals0.as<uint32_t>(),
-                        ctx->b_vals1.as<uint32_t>(), P, 32, 52);
+                           ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>());
+        rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), P, 44, 64);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_strict_outcome, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                           ctx->b_vals1.as<uint32_t>(), P, ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset,
-                           ctx->obsset_sentinel_live ? 1 : 0, ctx->b_collided.as<uint8_t>());
+        hipLaunchKernelGGL(k_strict_outcome, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
+                           ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
+                           ctx->b_collided.as<uint8_t>());
       }
       HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
       HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
@@ -2783,11 +2786,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       std::swap(Tcur, Tnext);
       ++rounds;
     }
-    // the sorted probe list of the last round (whose T equals the final T) is still in keys1 / vals1
+    // the sorted probe list of the last round (whose T equals the final T) is still in keys1
     if (P) {
       HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
-      hipLaunchKernelGGL(k_strict_commit, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                         ctx->b_vals1.as<uint32_t>(), P, ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
+      hipLaunchKernelGGL(k_strict_commit, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
+                         ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
     }
     ctx->counters.replay_rounds = rounds;
   }
