@@ -191,3 +191,42 @@ def test_fast_and_simple_fine_voxels_0p02(oracle):
     assert gm.num_blocks() > 2000
     om, oi, gm = _run(oracle, "simple", 0.02, frames[:1], max_blocks=32768)
     compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_edge_case_clouds(oracle, kind):
+    """Degenerate inputs the reference handles silently: an empty cloud, a cloud whose points are all
+    rejected by isPointValid (tsdf_integrator.h:112-129), a single point, only-clearing rays (beyond
+    max_ray_length_m), freespace points, duplicates of one point, and a frame after them that must
+    integrate as if nothing had happened."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    ocfg, gcfg = _cfgs(oracle, 4 * voxel)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator(kind, ocfg)
+    gm = capi.Map(voxel, 16, max_blocks=2048)
+    k = {"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[kind]
+    pos = np.array([0.1, 0.2, 0.3], np.float32)
+    q = np.array([1, 0, 0, 0], np.float32)
+    white = lambda n: np.full((n, 4), 255, np.uint8)
+    clouds = [
+        (np.zeros((0, 3), np.float32), False),                                    # empty
+        (np.full((5, 3), 0.01, np.float32), False),                               # all closer than min_ray_length_m
+        (np.array([[0.3, 0.1, 2.0]], np.float32), False),                         # one point
+        (np.array([[0.5, 0.2, 7.0], [-1.0, 0.4, 9.0]], np.float32), False),       # clearing rays only
+        (np.array([[0.2, -0.3, 1.5], [0.4, 0.3, 2.5]], np.float32), True),        # freespace_points = true
+        (np.tile(np.array([[0.7, 0.1, 1.8]], np.float32), (300, 1)), False),      # 300 copies of one point
+    ]
+    for pts, freespace in clouds:
+        col = white(pts.shape[0])
+        oi.integrate(pos, q, pts, col, freespace)
+        gm.integrate(k, gcfg, pos, q, pts, col, freespace)
+        g, r = gm.tsdf_dict(), om.tsdf_dict()
+        assert set(g) == set(r)
+        if r:
+            compare_tsdf(g, r, exact=True)
+    pose, pts, col = _small_room(3)
+    oi.integrate(pose[0], pose[1], pts, col)
+    gm.integrate(k, gcfg, pose[0], pose[1], pts, col)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
