@@ -1,0 +1,216 @@
+// vbx_common.hpp — device-visible structs (block pool, hash map, ray tables, state) and the hash map's device functions
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// small host utilities
+// ---------------------------------------------------------------------------
+thread_local std::string g_create_error;
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ctx->fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return VBX_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+struct DBuf {  // growable device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      if (e != hipSuccess) return e;
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = (want + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
+
+// block flag bits (blk_flags[slot])
+constexpr uint32_t kFlagUpdMask = 0x7;      // Update::kMap|kMesh|kEsdf, core/block.h:15-18
+constexpr uint32_t kFlagPublished = 0x100;  // block is part of the API-visible Layer
+constexpr uint32_t kFlagHasData = 0x200;    // Block::has_data_
+constexpr uint32_t kFlagNewThisCall = 0x400;
+constexpr uint32_t kFlagEsdfAlloc = 0x1000;   // block exists in Layer<EsdfVoxel>
+constexpr uint32_t kFlagEsdfUpdShift = 4;     // ESDF block's Update bits live in bits 4..6
+constexpr uint32_t kFlagEsdfPendClassify = 0x2000;  // EsdfIntegrator::updated_blocks_ member (esdf_integrator.cc:54,80)
+constexpr uint32_t kFlagEsdfPendOpen = 0x4000;      // holds voxels pushed to open_ by addNewRobotPosition (:84)
+
+// Device-resident scalar state, read back at the per-call sync points.
+struct DevState {
+  uint32_t pool_used;
+  uint32_t free_count;
+  uint32_t new_count;
+  uint32_t error;  // bit0: pool/hash capacity, bit1: lookup of a missing block
+  uint32_t changed;
+  uint32_t sentinel_cleared;
+  uint32_t blocks_published;
+  uint32_t esdf_blocks;
+  uint32_t esdf_raise_any;
+  uint32_t esdf_relax_blocks;
+  uint32_t act_count[3];
+  uint32_t fold_long_count;
+  uint32_t redo_count;       // rays whose voxel list must be rebuilt after slot assignment
+  uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)
+  unsigned long long total_keys;
+  unsigned long long voxels_touched;
+  unsigned long long rays_cast;
+  unsigned long long num_kept;
+};
+
+// Host-visible copy of DevState in page-locked, device-mapped host memory.  A read-back is a
+// tiny kernel that writes this struct and then its sequence number; the host spins on the
+// number.  hipMemcpyAsync + hipStreamSynchronize costs ~35 us per read-back (copy engine launch
+// + interrupt-driven wait), and a Fast frame needs five of them.
+struct StateMirror {
+  DevState st;
+  uint32_t extra;
+  uint32_t seq;
+};
+
+struct MapDev {  // by-value kernel argument
+  uint64_t* hkeys;
+  uint32_t* hvals;
+  uint32_t hmask;
+  float* dist;
+  float* weight;
+  uint32_t* rgba;
+  int32_t* blk_idx;     // 3 per slot
+  uint32_t* blk_flags;  // 1 per slot
+  uint32_t* free_list;
+  uint32_t cap_blocks;
+  uint32_t nvox;
+  int vps;
+  int vps_log2;
+  float voxel_size;
+  float voxel_size_inv;
+  float vps_inv;
+};
+
+struct CastCfg {  // by-value kernel argument: TsdfIntegratorBase::Config + derived constants
+  int exp;  // TEMP experiment switch
+  f3 origin;
+  float trunc;
+  float max_ray_length_m;
+  float min_ray_length_m;
+  float max_weight;
+  float sparsity_factor;
+  int carving;
+  int allow_clear;
+  int use_const_weight;
+  int dropoff;
+  int sparsity;
+  int anti_grazing;
+  int max_consecutive;
+  float start_factor_times_inv;  // start_voxel_subsampling_factor * voxel_size_inv_
+};
+
+struct RayTab {  // SoA ray table indexed by integration order o
+  float* px;
+  float* py;
+  float* pz;      // point_G
+  uint32_t* rgba;
+  float* w;       // point / bundle weight
+  uint8_t* flags; // bit0 cast this ray, bit1 clearing ray
+  uint64_t* bkey; // Merged: packed endpoint voxel key of the bundle (anti-grazing), else null
+  uint32_t R;
+};
+
+__host__ __device__ inline uint64_t pack_block_key(int x, int y, int z) {
+  const uint64_t B = 1ull << 20;
+  return ((uint64_t)(z + (long long)B) << 42) | ((uint64_t)(y + (long long)B) << 21) |
+         (uint64_t)(x + (long long)B);
+}
+__host__ __device__ inline void unpack_block_key(uint64_t k, int* x, int* y, int* z) {
+  const long long B = 1ll << 20;
+  *x = (int)((long long)(k & 0x1FFFFF) - B);
+  *y = (int)((long long)((k >> 21) & 0x1FFFFF) - B);
+  *z = (int)((long long)((k >> 42) & 0x1FFFFF) - B);
+}
+__host__ __device__ inline uint32_t mix_key(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// BlockIndex -> pool slot lookup (Layer::getBlockPtrByIndex, layer.h:72-89).
+__device__ inline uint32_t map_find(const MapDev& m, uint64_t key) {
+  uint32_t h = mix_key(key) & m.hmask;
+  for (uint32_t probes = 0; probes <= m.hmask; ++probes) {
+    const uint64_t k = __hip_atomic_load(&m.hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return __hip_atomic_load(&m.hvals[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyKey) return kInvalidSlot;
+    h = (h + 1) & m.hmask;
+  }
+  return kInvalidSlot;
+}
+
+// Insert-if-absent; the pool slot is assigned afterwards by k_assign_slots (temp_block_map_
+// + updateLayerWithStoredBlocks, tsdf_integrator.cc:107-126, 137-147).
+__device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* new_list,
+                                      DevState* st) {
+  uint32_t h = mix_key(key) & m.hmask;
+  for (uint32_t probes = 0; probes <= m.hmask; ++probes) {
+    uint64_t k = __hip_atomic_load(&m.hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return;
+    if (k == kEmptyKey) {
+      const unsigned long long old =
+          atomicCAS((unsigned long long*)&m.hkeys[h], (unsigned long long)kEmptyKey,
+                    (unsigned long long)key);
+      if (old == kEmptyKey) {
+        const uint32_t i = atomicAdd(&st->new_count, 1u);
+        if (i < m.cap_blocks) new_list[i] = h; else atomicOr(&st->error, 1u);
+        return;
+      }
+      if (old == key) return;
+    }
+    h = (h + 1) & m.hmask;
+  }
+  atomicOr(&st->error, 1u);
+}
+
+// Marks a block as part of the Layer and sets all Update bits (tsdf_integrator.cc:128).  The
+// common case — block already published and flagged this frame — is a plain L2 read: only
+// the first toucher pays for the atomic, so hundreds of thousands of rays crossing ~200
+// blocks do not serialise on ~200 addresses.
+__device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* st) {
+  const uint32_t want = kFlagPublished | kFlagUpdMask;
+  const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((cur & want) == want) return;
+  const uint32_t old = atomicOr(&m.blk_flags[slot], want);
+  if (!(old & kFlagPublished)) {
+    atomicOr(&m.blk_flags[slot], kFlagNewThisCall);
+    atomicAdd(&st->blocks_published, 1u);
+  }
+}
+
+__device__ inline void unpack_parent_bits(uint32_t s, int* x, int* y, int* z) {
+  *x = (int)(int8_t)((s >> 8) & 0xFF);
+  *y = (int)(int8_t)((s >> 16) & 0xFF);
+  *z = (int)(int8_t)((s >> 24) & 0xFF);
+}
+
+}  // namespace
+

@@ -1,0 +1,67 @@
+// vbx_ctx.hpp — the per-map context behind the opaque vbx_ctx handle
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct vbx_ctx {
+  int device = 0;
+  vbx_map_cfg mcfg{};
+  MapDev map{};
+  uint32_t hcap = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  DevState* d_state = nullptr;
+  DevState h_state{};
+  StateMirror* h_mirror = nullptr;  // page-locked, mapped (may stay null: plain copies are used then)
+  StateMirror* d_mirror = nullptr;
+  uint32_t sync_seq = 0;
+  std::string err;
+
+  // pool / map storage
+  DBuf b_hkeys, b_hvals, b_dist, b_weight, b_rgba, b_blkidx, b_blkflags, b_freelist, b_newlist;
+  // per-call scratch
+  DBuf b_pts, b_cols;                                   // staged host input
+  DBuf t_px, t_py, t_pz, t_rgba, t_w, t_flags, t_bkey;  // ray table A (per point, order s)
+  DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
+  DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
+  DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_bkeys, b_bfirst, b_bperm, b_obsset, b_collided;
+  uint32_t obs_epoch = 1;
+  uint32_t fast_last_iters = 0;  // sweeps the previous Fast frame needed
+  uint32_t fast_redo_grid = 0;   // rays the second list-building pass is launched for
+  // Fast integrator persistent state
+  DBuf b_startset;       // ApproxHashSet<20,10000> storage (u32 per slot)
+  uint32_t start_offset = 0;
+  bool start_sentinel_live = true;
+  bool startset_init = false;
+  std::vector<int32_t> h_by_s;  // scratch of merged_reference_order
+  // voxel_observed_approx_set_ (reference semantics, fast_observed_set == 0)
+  uint32_t obsset_offset = 0;
+  bool obsset_sentinel_live = true;
+  bool obsset_init = false;
+  int64_t reset_counter = 0;  // tsdf_integrator.cc:564
+  DBuf b_own0, b_own1;
+  // ESDF layer (allocated on first use)
+  DBuf b_edist, b_estate, b_eraised, b_eactive;
+  bool esdf_init = false;
+  bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
+  uint32_t own_tag = 0;  // descending
+  int own_s_bits = 0;
+
+  vbx_counters counters{};
+  bool timing = false;
+  hipEvent_t ev[9] = {};  // 0..7 stage boundaries in order, 8 = end of the exact-set solve inside stage 3
+  bool ev_hit[9] = {};
+  vbx_timing last_timing{};
+
+  void fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+  }
+};
+

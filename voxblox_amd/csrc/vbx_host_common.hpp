@@ -1,0 +1,155 @@
+// vbx_host_common.hpp — host helpers: state read-back, ray tables, rocPRIM sort/scan wrappers, stage timing
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+namespace {
+
+inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// Reads DevState (and optionally one more device word) back to the host; on return everything
+// queued on the stream before the call has completed.
+int sync_state(vbx_ctx* ctx, const uint32_t* d_extra = nullptr, uint32_t* extra_out = nullptr) {
+  if (!ctx->h_mirror) {
+    HIP_TRY(hipMemcpyAsync(&ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+    if (d_extra) HIP_TRY(hipMemcpyAsync(extra_out, d_extra, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VBX_OK;
+  }
+  const uint32_t seq = ++ctx->sync_seq;
+  hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, ctx->d_mirror, d_extra, seq);
+  HIP_TRY(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (__atomic_load_n(&ctx->h_mirror->seq, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFFu) == 0 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      // long-running or failed work: block, and let the runtime report an error if there is one
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (__atomic_load_n(&ctx->h_mirror->seq, __ATOMIC_ACQUIRE) != seq) {
+        ctx->fail("device state read-back did not arrive");
+        return VBX_ERR_HIP;
+      }
+      break;
+    }
+  }
+  std::memcpy(&ctx->h_state, &ctx->h_mirror->st, sizeof(DevState));
+  if (d_extra) *extra_out = ctx->h_mirror->extra;
+  return VBX_OK;
+}
+
+int check_state_error(vbx_ctx* ctx) {
+  if (ctx->h_state.error & 1u) {
+    ctx->fail("block pool / hash map capacity exceeded (max_blocks=%u)", ctx->map.cap_blocks);
+    return VBX_ERR_CAPACITY;
+  }
+  if (ctx->h_state.error & 2u) {
+    ctx->fail("internal: ray march hit a block without a pool slot");
+    return VBX_ERR_HIP;
+  }
+  if (ctx->h_state.error & 4u) {
+    ctx->fail("internal: voxel list capacity bound violated");
+    return VBX_ERR_HIP;
+  }
+  return VBX_OK;
+}
+
+RayTab make_tab(vbx_ctx* ctx, bool second, uint32_t R) {
+  RayTab t;
+  if (!second) {
+    t.px = ctx->t_px.as<float>(); t.py = ctx->t_py.as<float>(); t.pz = ctx->t_pz.as<float>();
+    t.rgba = ctx->t_rgba.as<uint32_t>(); t.w = ctx->t_w.as<float>();
+    t.flags = ctx->t_flags.as<uint8_t>(); t.bkey = ctx->t_bkey.as<uint64_t>();
+  } else {
+    t.px = ctx->u_px.as<float>(); t.py = ctx->u_py.as<float>(); t.pz = ctx->u_pz.as<float>();
+    t.rgba = ctx->u_rgba.as<uint32_t>(); t.w = ctx->u_w.as<float>();
+    t.flags = ctx->u_flags.as<uint8_t>(); t.bkey = ctx->u_bkey.as<uint64_t>();
+  }
+  t.R = R;
+  return t;
+}
+
+int ensure_tab(vbx_ctx* ctx, bool second, size_t R, bool with_bkey) {
+  const size_t n = R + 1;
+  if (!second) {
+    HIP_TRY(ctx->t_px.ensure(n * 4)); HIP_TRY(ctx->t_py.ensure(n * 4)); HIP_TRY(ctx->t_pz.ensure(n * 4));
+    HIP_TRY(ctx->t_rgba.ensure(n * 4)); HIP_TRY(ctx->t_w.ensure(n * 4)); HIP_TRY(ctx->t_flags.ensure(n));
+    if (with_bkey) HIP_TRY(ctx->t_bkey.ensure(n * 8));
+  } else {
+    HIP_TRY(ctx->u_px.ensure(n * 4)); HIP_TRY(ctx->u_py.ensure(n * 4)); HIP_TRY(ctx->u_pz.ensure(n * 4));
+    HIP_TRY(ctx->u_rgba.ensure(n * 4)); HIP_TRY(ctx->u_w.ensure(n * 4)); HIP_TRY(ctx->u_flags.ensure(n));
+    if (with_bkey) HIP_TRY(ctx->u_bkey.ensure(n * 8));
+  }
+  return VBX_OK;
+}
+
+// rocPRIM is used only for the two generic primitives of the pipeline (LSD radix sort,
+// exclusive scan); everything domain-specific is a kernel in this file.
+// Frame-sized inputs (3e5..1e6 keys) sit below rocPRIM's default merge-sort limit, where it runs
+// ~20 launch-bound merge passes over the full 64-bit key; the callers here only need a STABLE
+// sort on a 20..26-bit field (the inputs are already in visiting order), which is 3-4 onesweep
+// passes.  MergeSortLimit = 0 selects the LSD onesweep path for every size.
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                           rocprim::default_config, 0>;
+int sort_keys(vbx_ctx* ctx, uint64_t* in, uint64_t* out, size_t n, unsigned begin_bit,
+              unsigned end_bit) {
+  size_t tmp = 0;
+  HIP_TRY(rocprim::radix_sort_keys<SortCfg>(nullptr, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
+  HIP_TRY(ctx->b_tmp.ensure(tmp));
+  HIP_TRY(rocprim::radix_sort_keys<SortCfg>(ctx->b_tmp.p, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
+  return VBX_OK;
+}
+int sort_pairs(vbx_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
+               unsigned begin_bit, unsigned end_bit) {
+  size_t tmp = 0;
+  HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
+                                             ctx->stream));
+  HIP_TRY(ctx->b_tmp.ensure(tmp));
+  HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(ctx->b_tmp.p, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
+                                             ctx->stream));
+  return VBX_OK;
+}
+int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
+  size_t tmp = 0;
+  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
+  HIP_TRY(ctx->b_tmp.ensure(tmp));
+  HIP_TRY(rocprim::exclusive_scan(ctx->b_tmp.p, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(),
+                                  ctx->stream));
+  return VBX_OK;
+}
+
+inline unsigned bits_for(uint64_t v) {
+  unsigned b = 1;
+  while (b < 64 && (v >> b)) ++b;
+  return b;
+}
+
+void tmark(vbx_ctx* ctx, int i) {
+  if (ctx->timing) {
+    (void)hipEventRecord(ctx->ev[i], ctx->stream);
+    ctx->ev_hit[i] = true;
+  }
+}
+
+CastCfg make_cast_cfg(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float pos[3]) {
+  CastCfg c{};
+  c.origin = {pos[0], pos[1], pos[2]};
+  c.trunc = cfg->default_truncation_distance;
+  c.max_ray_length_m = cfg->max_ray_length_m;
+  c.exp = getenv("VBX_EXP") ? atoi(getenv("VBX_EXP")) : 0;
+  c.min_ray_length_m = cfg->min_ray_length_m;
+  c.max_weight = cfg->max_weight;
+  c.sparsity_factor = cfg->sparsity_compensation_factor;
+  c.carving = cfg->voxel_carving_enabled != 0;
+  // tsdf_integrator.cc:62-65: clearing rays have no utility if voxel_carving is disabled
+  c.allow_clear = (cfg->allow_clear != 0) && (cfg->voxel_carving_enabled != 0);
+  c.use_const_weight = cfg->use_const_weight != 0;
+  c.dropoff = cfg->use_weight_dropoff != 0;
+  c.sparsity = cfg->use_sparsity_compensation_factor != 0;
+  c.anti_grazing = cfg->enable_anti_grazing != 0;
+  c.max_consecutive = cfg->max_consecutive_ray_collisions;
+  c.start_factor_times_inv = cfg->start_voxel_subsampling_factor * ctx->map.voxel_size_inv;
+  return c;
+}
+
+
+}  // namespace
+

@@ -1,0 +1,224 @@
+// vbx_host_esdf.hpp — host orchestration of the ESDF update and addNewRobotPosition
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+namespace {
+__global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int drop_layer, int keep_classify_pending) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  // blocks addNewRobotPosition left work in: 8 = take part in this update (their voxels sit in
+  // open_/raise_), 16 = also re-run the TSDF classification on them
+  const uint32_t f = m.blk_flags[s];
+  const uint32_t pend = f & (kFlagEsdfPendClassify | kFlagEsdfPendOpen);
+  e.active[s] = (pend && !drop_layer) ? (8u | ((pend & kFlagEsdfPendClassify) ? 16u : 0u)) : 0u;
+  // updateFromTsdfBlocks does not consume updated_blocks_: the classification stays pending
+  uint32_t nf = f & ~((keep_classify_pending ? 0u : kFlagEsdfPendClassify) | kFlagEsdfPendOpen);
+  if (drop_layer) nf &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+  if (nf != f) m.blk_flags[s] = nf;
+}
+__global__ void k_esdf_clear_tsdf_bit(MapDev m, EsdfDev e, uint32_t n_slots) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  if (e.active[s] & 8u) m.blk_flags[s] &= ~4u;  // updated().reset(Update::kEsdf), esdf_integrator.cc:113-121
+}
+
+EsdfDev esdf_dev(vbx_ctx* ctx) {
+  EsdfDev e;
+  e.dist = ctx->b_edist.as<float>();
+  e.state = ctx->b_estate.as<uint32_t>();
+  e.raised = ctx->b_eraised.as<uint8_t>();
+  e.active = ctx->b_eactive.as<uint32_t>();
+  return e;
+}
+
+int esdf_ensure(vbx_ctx* ctx) {
+  if (ctx->esdf_init) return VBX_OK;
+  const MapDev& m = ctx->map;
+  const size_t nv = (size_t)m.cap_blocks * m.nvox;
+  HIP_TRY(ctx->b_edist.ensure(nv * 4));
+  HIP_TRY(ctx->b_estate.ensure(nv * 4));
+  HIP_TRY(ctx->b_eraised.ensure(nv));
+  HIP_TRY(ctx->b_eactive.ensure((size_t)m.cap_blocks * 4));
+  HIP_TRY(hipMemsetAsync(ctx->b_edist.p, 0, nv * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->b_estate.p, 0, nv * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->b_eraised.p, 0, nv, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->b_eactive.p, 0, (size_t)m.cap_blocks * 4, ctx->stream));
+  ctx->esdf_init = true;
+  return VBX_OK;
+}
+
+template <int VPS>
+int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, uint32_t used,
+               uint32_t* sweeps) {
+  hipStream_t s = ctx->stream;
+  for (;;) {
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+    hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, ctx->d_state);
+    ++*sweeps;
+    if (mode == 2) return VBX_OK;
+    hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
+    int rc = sync_state(ctx);
+    if (rc) return rc;
+    if (!ctx->h_state.changed) return VBX_OK;
+    if (*sweeps > 100000) {
+      ctx->fail("ESDF: wavefront did not converge");
+      return VBX_ERR_HIP;
+    }
+  }
+}
+
+template <int VPS>
+int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag,
+                  const int32_t* list = nullptr, size_t n_list = 0, int list_incremental = 0) {
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  int rc = esdf_ensure(ctx);
+  if (rc) return rc;
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  ctx->counters = vbx_counters{};
+  if (used == 0) return VBX_OK;
+  EsdfDev e = esdf_dev(ctx);
+  EsdfCfgDev c;
+  c.max_distance = cfg->max_distance_m;
+  c.min_distance = cfg->min_distance_m;
+  c.default_distance = cfg->default_distance_m;
+  c.min_diff = cfg->min_diff_m;
+  c.min_weight = cfg->min_weight;
+  c.add_occupied_crust = cfg->add_occupied_crust != 0;
+  c.voxel_size = m.voxel_size;
+  const size_t nv = (size_t)used * m.nvox;
+  for (int i = 0; i < 9; ++i) ctx->ev_hit[i] = false;
+  tmark(ctx, 0);
+  if (batch) {  // esdf_layer_->removeAllBlocks(), esdf_integrator.cc:95
+    HIP_TRY(hipMemsetAsync(e.dist, 0, nv * 4, s));
+    HIP_TRY(hipMemsetAsync(e.state, 0, nv * 4, s));
+  }
+  // `raised` is clear between updates except for the marks addNewRobotPosition left (a batch
+  // update drops those with the layer)
+  if (batch) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
+  const bool robot_pending = ctx->esdf_robot_pending && !batch;
+  ctx->esdf_robot_pending = false;
+  hipLaunchKernelGGL(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0);
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->esdf_blocks, 0, 12, s));
+  if (list) {
+    HIP_TRY(ctx->b_head.ensure(std::max<size_t>(n_list, 1) * 12));
+    HIP_TRY(hipMemcpyAsync(ctx->b_head.p, list, n_list * 12, hipMemcpyHostToDevice, s));
+    if (n_list)
+      hipLaunchKernelGGL(k_esdf_mark_listed, grid_for(n_list), dim3(256), 0, s, m, e, ctx->b_head.as<int32_t>(),
+                         (uint32_t)n_list);
+    hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
+                       list_incremental ? 1 : 0, 2, ctx->d_state);
+  } else {
+    hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
+                       batch ? 0 : 1, batch ? 0 : 1, ctx->d_state);
+  }
+  hipLaunchKernelGGL(k_esdf_seed_active, grid_for((size_t)used * 27), dim3(256), 0, s, m, e, used);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  tmark(ctx, 1);
+  ctx->counters.esdf_blocks = ctx->h_state.esdf_blocks;
+  uint32_t sweeps = 0;
+  // The wavefronts run to their exact fixed points: min_diff_m only gates the TSDF->ESDF copy
+  // of phase 1 (see DESIGN.md §ESDF for why the relaxation itself uses strict improvement).
+  EsdfCfgDev cr = c;
+  cr.min_diff = 0.0f;
+  if (ctx->h_state.esdf_blocks || robot_pending) {
+    if (ctx->h_state.esdf_raise_any || robot_pending) {
+      rc = esdf_phase<VPS>(ctx, e, cr, 0, used, &sweeps);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+    }
+    tmark(ctx, 3);
+    rc = esdf_phase<VPS>(ctx, e, cr, 1, used, &sweeps);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+    rc = esdf_phase<VPS>(ctx, e, cr, 2, used, &sweeps);
+    if (rc) return rc;
+    tmark(ctx, 6);
+    if (ctx->h_state.esdf_raise_any || robot_pending) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
+  }
+  if (clear_updated_flag && !batch)
+    hipLaunchKernelGGL(k_esdf_clear_tsdf_bit, grid_for(used), dim3(256), 0, s, m, e, used);
+  tmark(ctx, 7);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  ctx->counters.esdf_sweeps = sweeps;
+  ctx->counters.esdf_relaxations = ctx->h_state.esdf_relax_blocks;
+  if (ctx->timing) {
+    (void)hipEventSynchronize(ctx->ev[7]);
+    vbx_timing& o = ctx->last_timing;
+    o = vbx_timing{};
+    float t = 0;
+    (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
+    (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]);
+    o.prep_ms = t;  // phase 1 (classification)
+    if (ctx->ev_hit[3]) { (void)hipEventElapsedTime(&t, ctx->ev[1], ctx->ev[3]); o.solve_ms = t; }  // raise
+    if (ctx->ev_hit[6]) { (void)hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[6]); o.fold_ms = t; }   // lower
+  }
+  return VBX_OK;
+}
+
+// EsdfIntegrator::addNewRobotPosition (esdf_integrator.cc:25-92).
+int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const float position[3]) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  int rc = esdf_ensure(ctx);
+  if (rc) return rc;
+  EsdfDev e = esdf_dev(ctx);
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
+  const float radii[2] = {cfg->clear_sphere_radius, cfg->occupied_sphere_radius};
+  for (int pass = 0; pass < 2; ++pass) {
+    SphereDev sp;
+    // planning_utils_inl.h:18-26: the float loop variable, stepped exactly like the reference's
+    sp.r = radii[pass] / m.voxel_size;
+    std::vector<float> xs;
+    for (float x = -sp.r; x <= sp.r; x++) {
+      xs.push_back(x);
+      if (xs.size() > 2048) {
+        ctx->fail("addNewRobotPosition: sphere radius of more than 1024 voxels");
+        return VBX_ERR_INVALID;
+      }
+    }
+    if (xs.empty()) continue;  // negative / NaN radius: empty list
+    sp.n = (int)xs.size();
+    sp.center = grid_index_from_point(f3{position[0], position[1], position[2]}, m.voxel_size_inv);
+    DBuf& bx = pass ? ctx->b_sphere1 : ctx->b_sphere0;
+    HIP_TRY(bx.ensure(xs.size() * 4));
+    HIP_TRY(hipMemcpyAsync(bx.p, xs.data(), xs.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // xs is a stack-lifetime staging buffer
+    sp.xs = bx.as<float>();
+    const size_t cube = (size_t)sp.n * sp.n * sp.n;
+    hipLaunchKernelGGL(k_sphere_mark_blocks, grid_for(cube), dim3(256), 0, s, m, sp, ctx->b_newlist.as<uint32_t>(),
+                       ctx->d_state);
+    hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+                       ctx->d_state);
+    hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    hipLaunchKernelGGL(k_sphere_apply, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, pass);
+  }
+  ctx->esdf_robot_pending = true;
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  return check_state_error(ctx);
+}
+
+int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag,
+                const int32_t* list = nullptr, size_t n_list = 0, int list_incremental = 0) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (cfg->full_euclidean_distance) {
+    ctx->fail("ESDF: full_euclidean_distance is not supported yet (quasi-Euclidean only)");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  switch (ctx->map.vps) {
+    case 8: return esdf_update_t<8>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
+    case 16: return esdf_update_t<16>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
+    default:
+      ctx->fail("ESDF: voxels_per_side must be 8 or 16 (LDS tile)");
+      return VBX_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+

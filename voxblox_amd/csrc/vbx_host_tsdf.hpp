@@ -1,0 +1,605 @@
+// vbx_host_tsdf.hpp — host orchestration of the three TSDF integrators (kernel launch sequences, host decisions)
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+namespace {
+// Visiting order of the points: nullptr = MixedThreadSafeIndex (closed form on the device), else
+// a device array s_of_p for "sorted" (integration_order_mode, tsdf_integrator.h:72-74).
+int visiting_order(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float* d_pts, size_t n, const uint32_t** order) {
+  *order = nullptr;
+  if (cfg->integration_order_mode == 0) return VBX_OK;
+  HIP_TRY(ctx->b_keys0.ensure(n * 8));
+  HIP_TRY(ctx->b_keys1.ensure(n * 8));
+  HIP_TRY(ctx->b_order.ensure(n * 4));
+  hipLaunchKernelGGL(k_sorted_keys, grid_for(n), dim3(256), 0, ctx->stream, d_pts, n, ctx->b_keys0.as<uint64_t>());
+  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), n, 0, 64);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sorted_inverse, grid_for(n), dim3(256), 0, ctx->stream, ctx->b_keys1.as<uint64_t>(), n,
+                     ctx->b_order.as<uint32_t>());
+  *order = ctx->b_order.as<uint32_t>();
+  return VBX_OK;
+}
+
+// Order the emitted (voxel, order) keys and fold them per voxel (keys in b_keys0).
+int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t total) {
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  // gids are below pool_used * nvox; h_state holds the value from after this call's slot
+  // assignment (every path reads DevState back between k_commit_alloc and here)
+  const unsigned end_bit = 32 + bits_for((uint64_t)std::max<uint32_t>(ctx->h_state.pool_used, 1) * m.nvox);
+  // keys are emitted ray by ray in visiting order, so a stable sort on the voxel field alone
+  // leaves every voxel's updates in visiting order (invalid keys, all ones, go last)
+  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 32,
+                     std::min(64u, end_bit + 1));
+  if (rc) return rc;
+  tmark(ctx, 5);
+  // long runs are collected by k_fold and folded wave-cooperatively afterwards (their number is
+  // bounded by total / kFoldShort)
+  HIP_TRY(ctx->b_long.ensure(((size_t)total / kFoldShort + 2) * 4));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->fold_long_count, 0, 4, s));
+  hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     (size_t)total, tab, c, m, ctx->b_long.as<uint32_t>(), ctx->d_state);
+  {
+    const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);
+    hipLaunchKernelGGL(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                       (size_t)total, tab, c, m, ctx->b_long.as<uint32_t>(), ctx->d_state);
+  }
+  tmark(ctx, 6);
+  ctx->counters.voxel_updates = total;
+  return VBX_OK;
+}
+
+// Shared tail of all three integrators: allocate blocks along the rays, emit ordered voxel
+// keys, sort, fold.  `limit` (optional) bounds the number of voxels each ray visits.
+int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_origin,
+                   const uint32_t* limit, bool blocks_already_marked, const uint64_t* graze_keys,
+                   uint32_t n_graze) {
+  const uint32_t R = tab.R;
+  if (R == 0) return VBX_OK;
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+
+  HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
+  hipLaunchKernelGGL(k_ray_count, grid_for(R + 1), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0,
+                     limit, ctx->b_cnt.as<uint32_t>());
+  int rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
+  if (rc) return rc;
+  if (!blocks_already_marked) {
+    hipLaunchKernelGGL(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, tab, c, m,
+                       from_origin ? 1 : 0, limit, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+    hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+                       ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+    hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    tmark(ctx, 2);
+  }
+  // total number of keys = off[R]
+  uint32_t total = 0;
+  rc = sync_state(ctx, ctx->b_off.as<uint32_t>() + R, &total);
+  if (rc) return rc;
+  rc = check_state_error(ctx);
+  if (rc) return rc;
+  if (total == 0) return VBX_OK;
+
+  HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
+  HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));
+  hipLaunchKernelGGL(k_ray_emit, grid_for(R), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0, limit,
+                     ctx->b_off.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), graze_keys, n_graze,
+                     ctx->d_state);
+  hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, tab.flags, R, ctx->d_state);
+  tmark(ctx, 4);
+  return sort_and_fold(ctx, tab, c, total);
+}
+
+int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
+                     const uint32_t* d_rgba, size_t n, int freespace) {
+  CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  const uint32_t* order = nullptr;
+  {
+    int orc_ = visiting_order(ctx, cfg, d_pts, n, &order);
+    if (orc_) return orc_;
+  }
+  int rc = ensure_tab(ctx, false, n, false);
+  if (rc) return rc;
+  RayTab tab = make_tab(ctx, false, (uint32_t)n);
+  tab.bkey = nullptr;
+  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
+                     freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, order);
+  tmark(ctx, 1);
+  return march_and_fold(ctx, tab, c, /*from_origin=*/true, nullptr, false, nullptr, 0);
+}
+
+// MergedTsdfIntegrator::integrateVoxels walks voxel_map / clear_map — std::unordered_map keyed by
+// GlobalIndex with LongIndexHash (block_hash.h:54-64) — from begin() to end()
+// (tsdf_integrator.cc:440-456).  That order is a property of libstdc++'s hashtable (bucket
+// count growth, node splicing) given the hash values and the insertion sequence, so it is
+// obtained the way the reference obtains it: the bundle keys are inserted into the same container,
+// in bundleRays' insertion order (first point of each bundle, visiting order), on the host.
+// perm[rank in ascending key order] = row in visiting order; non-clearing bundles first (:324-333).
+struct HostL3Hash {
+  size_t operator()(const l3& k) const { return (size_t)long_index_hash(k); }
+};
+struct HostL3Eq {
+  bool operator()(const l3& a, const l3& b) const { return a.x == b.x && a.y == b.y && a.z == b.z; }
+};
+int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t** perm_out) {
+  hipStream_t s = ctx->stream;
+  HIP_TRY(ctx->b_bkeys.ensure((size_t)nb * 8));
+  HIP_TRY(ctx->b_bfirst.ensure((size_t)nb * 4));
+  HIP_TRY(ctx->b_bperm.ensure((size_t)nb * 4));
+  hipLaunchKernelGGL(k_merged_collect, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(),
+                     (uint32_t)n, ctx->b_bkeys.as<uint64_t>(), ctx->b_bfirst.as<uint32_t>());
+  std::vector<uint64_t> keys(nb);
+  std::vector<uint32_t> first(nb), perm(nb), idx(nb);
+  HIP_TRY(hipMemcpyAsync(keys.data(), ctx->b_bkeys.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(first.data(), ctx->b_bfirst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  // the keys are sorted with the clearing bit on top: [0, n1) normal bundles, [n1, nb) clearing
+  uint32_t n1 = 0;
+  while (n1 < nb && !(keys[n1] >> 63)) ++n1;
+  // insertion order = ascending visiting position of each bundle's first point; positions are
+  // unique and < n, so a direct-address pass orders them without a comparison sort
+  std::vector<int32_t>& by_s = ctx->h_by_s;
+  by_s.assign(n, -1);
+  for (uint32_t b = 0; b < nb; ++b) by_s[first[b]] = (int32_t)b;
+  uint32_t q1 = 0, q2 = n1;
+  for (size_t sidx = 0; sidx < n; ++sidx) {
+    const int32_t b = by_s[sidx];
+    if (b < 0) continue;
+    if ((uint32_t)b < n1) idx[q1++] = (uint32_t)b; else idx[q2++] = (uint32_t)b;
+  }
+  uint32_t row = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t lo = pass ? n1 : 0, hi = pass ? nb : n1;
+    // node storage from a monotonic arena: the allocator has no influence on the iteration order
+    std::pmr::monotonic_buffer_resource arena((size_t)(hi - lo) * 64 + 4096);
+    std::pmr::unordered_map<l3, uint32_t, HostL3Hash, HostL3Eq> map(&arena);
+    for (uint32_t q = lo; q < hi; ++q) {
+      const uint64_t k = keys[idx[q]] & ~(1ull << 63);
+      const l3 g{(long long)(k & 0x1FFFFFu) - (1ll << 20), (long long)((k >> 21) & 0x1FFFFFu) - (1ll << 20),
+                 (long long)((k >> 42) & 0x1FFFFFu) - (1ll << 20)};
+      map.emplace(g, idx[q]);
+    }
+    for (const auto& kv : map) perm[kv.second] = row++;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->b_bperm.p, perm.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // perm is a local
+  *perm_out = ctx->b_bperm.as<uint32_t>();
+  return VBX_OK;
+}
+
+int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
+                     const uint32_t* d_rgba, size_t n, int freespace) {
+  CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  const uint32_t* order = nullptr;
+  {
+    int orc_ = visiting_order(ctx, cfg, d_pts, n, &order);
+    if (orc_) return orc_;
+  }
+  hipStream_t s = ctx->stream;
+  int rc = ensure_tab(ctx, false, n, false);
+  if (rc) return rc;
+  HIP_TRY(ctx->b_pcx.ensure(n * 4)); HIP_TRY(ctx->b_pcy.ensure(n * 4)); HIP_TRY(ctx->b_pcz.ensure(n * 4));
+  RayTab pt = make_tab(ctx, false, (uint32_t)n);
+  pt.bkey = nullptr;
+  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
+                     pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), order);
+  // bundleRays (tsdf_integrator.cc:340-371): group points by endpoint voxel.  A stable sort
+  // of (key, s) keeps each bundle's points in visiting order.
+  HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
+  HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
+  hipLaunchKernelGGL(k_merged_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, ctx->map,
+                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
+  rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(),
+                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 0, 64);
+  if (rc) return rc;
+  HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
+  hipLaunchKernelGGL(k_merged_heads, grid_for(n + 1), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     (uint32_t)n, ctx->b_head.as<uint32_t>());
+  rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
+  if (rc) return rc;
+  uint32_t nb = 0;
+  rc = sync_state(ctx, ctx->b_rank.as<uint32_t>() + n, &nb);
+  if (rc) return rc;
+  if (nb == 0) return VBX_OK;
+  rc = ensure_tab(ctx, true, nb, true);
+  if (rc) return rc;
+  HIP_TRY(ctx->b_graze.ensure((size_t)nb * 8));
+  HIP_TRY(hipMemsetAsync(ctx->b_graze.p, 0xFF, (size_t)nb * 8, s));
+  RayTab bt = make_tab(ctx, true, nb);
+  const uint32_t* perm = nullptr;
+  if (cfg->merged_bundle_order == 0) {
+    rc = merged_reference_order(ctx, n, nb, &perm);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_merged_bundle, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(),
+                     ctx->b_rank.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(),
+                     ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), T, bt,
+                     ctx->b_graze.as<uint64_t>(), perm, ctx->d_state);
+  tmark(ctx, 1);
+  // Non-clearing bundles sort before clearing ones (bit 63), so the graze key list is the
+  // sorted prefix of non-clearing bundle keys; entries of clearing bundles stay ~0 (sorted last).
+  const uint64_t* graze = c.anti_grazing ? ctx->b_graze.as<uint64_t>() : nullptr;
+  return march_and_fold(ctx, bt, c, /*from_origin=*/true, nullptr, false, graze, nb);
+}
+
+int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
+                   const uint32_t* d_rgba, size_t n, int freespace) {
+  CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  const uint32_t* order = nullptr;
+  {
+    int orc_ = visiting_order(ctx, cfg, d_pts, n, &order);
+    if (orc_) return orc_;
+  }
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  constexpr uint32_t kSetSize = (1u << 20) + 10000u;
+  if (!ctx->startset_init) {
+    HIP_TRY(ctx->b_startset.ensure((size_t)kSetSize * 4));
+    HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
+    ctx->startset_init = true;
+    ctx->start_offset = 0;
+    ctx->start_sentinel_live = true;
+  }
+  // tsdf_integrator.cc:564-569 + ApproxHashSet::resetApproxSet (approx_hash_array.h:156-169)
+  if ((++ctx->reset_counter) >= cfg->clear_checks_every_n_frames) {
+    ctx->reset_counter = 0;
+    ++ctx->obs_epoch;  // voxel_observed set cleared (exact-set form of resetApproxSet)
+    if (++ctx->obsset_offset >= 10000u) {  // both sets reset together (tsdf_integrator.cc:566-568)
+      if (ctx->obsset_init) HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kSetSize * 4, s));
+      ctx->obsset_offset = 0;
+      ctx->obsset_sentinel_live = true;
+    }
+    if (++ctx->start_offset >= 10000u) {
+      HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
+      ctx->start_offset = 0;
+      ctx->start_sentinel_live = true;
+    }
+  }
+
+  int rc = ensure_tab(ctx, false, n, false);
+  if (rc) return rc;
+  RayTab pt = make_tab(ctx, false, (uint32_t)n);
+  pt.bkey = nullptr;
+  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
+                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order);
+  HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
+  HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
+  hipLaunchKernelGGL(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,
+                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
+  // keys[s] = slot << 32 | s is written in visiting order: a stable sort on the 20 slot bits
+  // (+ bit 52, set only in the all-ones key of dropped points) orders by (slot, s)
+  rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(),
+                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 32, 53);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_fast_start_dedupe, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
+                     ctx->start_offset, ctx->start_sentinel_live ? 1 : 0, pt.flags);
+  hipLaunchKernelGGL(k_fast_start_commit, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
+                     ctx->start_offset, ctx->d_state);
+  HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
+  hipLaunchKernelGGL(k_compact_flags, grid_for(n + 1), dim3(256), 0, s, pt.flags, (uint32_t)n,
+                     ctx->b_head.as<uint32_t>());
+  rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
+  if (rc) return rc;
+  rc = ensure_tab(ctx, true, n, false);
+  if (rc) return rc;
+  RayTab kt = make_tab(ctx, true, 0);
+  kt.bkey = nullptr;
+  hipLaunchKernelGGL(k_compact_rays, grid_for(n), dim3(256), 0, s, pt, ctx->b_head.as<uint32_t>(),
+                     ctx->b_rank.as<uint32_t>(), (uint32_t)n, kt, ctx->d_state);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  if (ctx->h_state.sentinel_cleared) ctx->start_sentinel_live = false;
+  const uint32_t R = (uint32_t)ctx->h_state.num_kept;
+  kt.R = R;
+  tmark(ctx, 1);
+  if (R == 0) return VBX_OK;
+
+  // Candidate blocks along the full (unterminated) paths; a block only becomes part of the
+  // Layer ("published") when a ray actually reaches it (k_fast_emit).
+  HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
+  hipLaunchKernelGGL(k_ray_count, grid_for(R + 1), dim3(256), 0, s, kt, c, m, 0,
+                     (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>());
+  rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
+  if (rc) return rc;
+  // Every ray emits at most sqrt(3) * (max_ray_length + truncation) / voxel_size + 4 voxels
+  // (L1 <= sqrt(3) L2 of the walked segment), so the list buffer is sized without waiting for
+  // the exact total; 288 GB of HBM make the slack irrelevant and the buffer is reused.
+  const double seg = (double)c.max_ray_length_m + (double)c.trunc;
+  const size_t per_ray = (size_t)(1.7320508075688772 * seg * (double)m.voxel_size_inv) + 6;
+  const size_t vox_cap = std::min<size_t>((size_t)R * per_ray + 64, 0xFFFFFFF0u);
+  HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
+  HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
+  hipLaunchKernelGGL(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
+                     ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
+                     (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  // second pass over the queued rays (grid sized for the first-frame worst case; idle
+  // workgroups leave at once); capacity / lookup errors surface at the solver's first check
+  if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
+  hipLaunchKernelGGL(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
+                     ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap,
+                     ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
+  tmark(ctx, 2);
+
+  // claim arrays + tags (see k_fast_sweep)
+  const size_t nvox_total = (size_t)m.cap_blocks * m.nvox;
+  // ray-index bits: sized by the cloud (an upper bound of R) so the tag layout — and with it
+  // the claim arrays' contents — stays valid from frame to frame
+  const int s_bits = std::max((int)bits_for(std::max<size_t>(n, 2) - 1), ctx->own_s_bits);
+  const bool fresh = (ctx->b_own0.p == nullptr);
+  HIP_TRY(ctx->b_own0.ensure(nvox_total * 4));
+  HIP_TRY(ctx->b_own1.ensure(nvox_total * 4));
+  HIP_TRY(ctx->b_cl.ensure(nvox_total * 4));
+  const uint32_t max_tag = (1u << (32 - s_bits)) - 2;
+  auto reset_tags = [&]() -> int {
+    HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_cl.p, 0xFF, nvox_total * 4, s));
+    ctx->own_s_bits = s_bits;
+    ctx->own_tag = max_tag;
+    return VBX_OK;
+  };
+  if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 1024) {
+    rc = reset_tags();
+    if (rc) return rc;
+  }
+  const bool strict_set = cfg->fast_observed_set == 0;  // the reference's ApproxHashSet semantics
+  const bool keep_observed = cfg->clear_checks_every_n_frames > 1 && !strict_set;
+  if (keep_observed && ctx->b_obs.cap < nvox_total * 4) {
+    HIP_TRY(ctx->b_obs.ensure(nvox_total * 4));
+    HIP_TRY(hipMemsetAsync(ctx->b_obs.p, 0, nvox_total * 4, s));
+  }
+  HIP_TRY(ctx->b_T.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_TH.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_U.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_rank.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_act0.ensure((size_t)(R + 1) * 4));
+  HIP_TRY(ctx->b_act1.ensure((size_t)(R + 1) * 4));
+  uint32_t iters_total = 0;
+  auto run_solver = [&]() -> int {
+    SweepArgs sa{};
+    sa.off = ctx->b_off.as<uint32_t>();
+    sa.vox = ctx->b_vox.as<uint32_t>();
+    sa.cl = ctx->b_cl.as<uint32_t>();
+    sa.tag_cl = --ctx->own_tag;
+    sa.s_bits = s_bits;
+    sa.max_consecutive = c.max_consecutive;
+    sa.TL = ctx->b_T.as<uint32_t>();
+    sa.TH = ctx->b_TH.as<uint32_t>();
+    sa.U = ctx->b_U.as<uint32_t>();
+    sa.obs = keep_observed ? ctx->b_obs.as<uint32_t>() : nullptr;
+    sa.obs_epoch = ctx->obs_epoch;
+    // sweep 0: publish the full-path possible claims (TH = path length);
+    // sweep 1: lower bounds only (TH cannot move while there are no certain claims);
+    // sweeps 2..: both bounds, open rays only.  (A persistent tail kernel with grid barriers
+    // instead of launches was measured slower: 1.07 vs 0.98 ms — barrier + L2 write-back per
+    // sweep cost more than a launch.)
+    uint32_t iters = 0;
+    uint32_t n_open = R;  // host-side upper bound of the open list
+    uint32_t tag_rd = 0xFFFFFFFFu;
+    int ch_flip = 0;      // which of the two possible-claim arrays holds the readable sweep
+    int list_sel = 0;     // which work list the next sweep reads
+    int cnt_cur = 0;      // act_count index of that list's length
+    bool have_list = false;
+    uint32_t* lists[2] = {ctx->b_act0.as<uint32_t>(), ctx->b_act1.as<uint32_t>()};
+    uint32_t* chs[2] = {ctx->b_own0.as<uint32_t>(), ctx->b_own1.as<uint32_t>()};
+    for (;;) {
+      {
+        // sweeps per host check (an idle sweep is ~5 us, a check ~30 us): the first three give
+        // the open-ray count that sizes the later grids; then one batch up to where the previous
+        // frame converged (consecutive frames behave alike), then fours
+        int kBatch = (iters == 0) ? 3 : 4;
+        if (iters == 3 && ctx->fast_last_iters > 7) kBatch = (int)ctx->fast_last_iters - 3 + 1;
+        for (int b = 0; b < kBatch; ++b) {
+          sa.init = (iters == 0) ? 1 : 0;
+          sa.sweep_idx = iters;
+          sa.l_only = (iters == 1) ? 1 : 0;
+          const bool writes_ch = !sa.l_only;
+          const bool writes_list = iters >= 2;
+          sa.cnt_in = cnt_cur;
+          sa.cnt_out = (cnt_cur + 1) % 3;
+          sa.list_in = have_list ? lists[list_sel] : nullptr;
+          sa.list_out = writes_list ? lists[have_list ? (list_sel ^ 1) : 0] : nullptr;
+          sa.n_in = n_open;
+          sa.ch_rd = chs[ch_flip];
+          sa.ch_wr = chs[ch_flip ^ 1];
+          sa.tag_rd = tag_rd;
+          sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
+          if (writes_list && !have_list) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[sa.cnt_out], 0, 4, s));
+          if (iters == 0)
+            hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
+          else if (n_open <= 8192)  // few open rays: a whole wave per ray (64 list entries per step)
+            hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
+          else
+            hipLaunchKernelGGL(k_fast_sweep<16>, grid_for((size_t)n_open * 16), dim3(256), 0, s, sa, R, ctx->d_state);
+          if (writes_ch) {
+            tag_rd = sa.tag_wr;
+            ch_flip ^= 1;
+          }
+          if (writes_list) {
+            list_sel = have_list ? (list_sel ^ 1) : 0;
+            have_list = true;
+            cnt_cur = sa.cnt_out;
+          }
+          ++iters;
+        }
+        rc = sync_state(ctx);
+        if (rc) return rc;
+        rc = check_state_error(ctx);
+        if (rc) return rc;
+        n_open = ctx->h_state.act_count[cnt_cur];
+        // size the next frame's second list-building pass (it is a grid-stride loop, so this is
+        // only a performance hint)
+        ctx->fast_redo_grid = std::max<uint32_t>(1, 2 * ctx->h_state.redo_count);
+      }
+      if (getenv("VBX_DEBUG")) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
+      if (n_open == 0) break;
+      if (iters > 1000000 || ctx->own_tag < 128) {
+        ctx->fail("Fast integrator: early-termination solver did not converge");
+        return VBX_ERR_HIP;
+      }
+    }
+    // sweeps that did work (the launches after convergence are idle)
+    if (ctx->h_state.fast_idle_sweep) iters = std::min(iters, 0xFFFFFFFFu - ctx->h_state.fast_idle_sweep);
+    iters_total = iters;
+    ctx->fast_last_iters = std::min<uint32_t>(iters, 64);
+    return VBX_OK;
+  };
+  rc = run_solver();
+  if (rc) return rc;
+  if (keep_observed)
+    hipLaunchKernelGGL(k_fast_mark_observed, grid_for((size_t)R * 16), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
+                       ctx->b_vox.as<uint32_t>(), ctx->b_T.as<uint32_t>(), R, ctx->b_obs.as<uint32_t>(),
+                       ctx->obs_epoch);
+  if (strict_set) {
+    tmark(ctx, 8);
+    // refinement rounds (see k_strict_keys): T lives in b_T / b_TH alternately, probe offsets in b_cnt
+    if (!ctx->obsset_init) {
+      HIP_TRY(ctx->b_obsset.ensure((size_t)kSetSize * 4));
+      HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kSetSize * 4, s));
+      ctx->obsset_init = true;
+    }
+    uint32_t* Tcur = ctx->b_T.as<uint32_t>();
+    uint32_t* Tnext = ctx->b_TH.as<uint32_t>();
+    uint32_t* poff = ctx->b_cnt.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(Tcur + R, 0, 4, s));
+    uint32_t rounds = 0;
+    uint32_t P = 0;
+    for (;;) {
+      rc = exclusive_scan_u32(ctx, Tcur, poff, R + 1);
+      if (rc) return rc;
+      rc = sync_state(ctx, poff + R, &P);  // also carries `changed` of the previous round
+      if (rc) return rc;
+      if (getenv("VBX_DEBUG") && rounds > 0)
+        fprintf(stderr, "[vbx] strict round %u: %u probes, %u rays moved (%u grew)\n", rounds, P, ctx->h_state.act_count[0],
+                ctx->h_state.act_count[1]);
+      if (rounds > 0 && !ctx->h_state.changed) break;
+      if (rounds > 4096) {
+        ctx->fail("Fast integrator: observed-set replay did not converge");
+        return VBX_ERR_HIP;
+      }
+      HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
+      HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
+      HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(P, 1)));
+      if (P) {
+        hipLaunchKernelGGL(k_strict_keys, grid_for(P), dim3(256), 0, s, poff, R, P, ctx->b_off.as<uint32_t>(),
+                           ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>());
+        rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), P, 44, 64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_strict_outcome, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
+                           ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
+                           ctx->b_collided.as<uint8_t>());
+      }
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
+      hipLaunchKernelGGL(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(), R,
+                         ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext, ctx->b_U.as<uint32_t>(),
+                         getenv("VBX_DEBUG") ? 1 : 0, ctx->d_state);
+      std::swap(Tcur, Tnext);
+      ++rounds;
+    }
+    // the sorted probe list of the last round (whose T equals the final T) is still in keys1
+    if (P) {
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
+      hipLaunchKernelGGL(k_strict_commit, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
+                         ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
+    }
+    ctx->counters.replay_rounds = rounds;
+  }
+  uint32_t total = 0;
+  // offsets of the keys each ray emits
+  rc = exclusive_scan_u32(ctx, ctx->b_U.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R + 1);
+  if (rc) return rc;
+  rc = sync_state(ctx, ctx->b_rank.as<uint32_t>() + R, &total);
+  if (rc) return rc;
+  if (strict_set && ctx->h_state.sentinel_cleared) ctx->obsset_sentinel_live = false;
+  ctx->counters.iterations = iters_total;
+  tmark(ctx, 3);
+  hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
+  if (total == 0) return VBX_OK;
+  HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
+  HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));
+  hipLaunchKernelGGL(k_fast_emit, grid_for(total), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
+                     ctx->b_vox.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R, total, m,
+                     ctx->b_keys0.as<uint64_t>(), ctx->d_state);
+  tmark(ctx, 4);
+  return sort_and_fold(ctx, kt, c, total);
+}
+
+int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
+                     const float quat[4], const float* d_pts, const uint8_t* d_rgba, size_t n,
+                     int freespace) {
+  if (!cfg || !pos || !quat || (n && (!d_pts || !d_rgba))) {
+    ctx->fail("vbx_tsdf_integrate: null argument");
+    return VBX_ERR_INVALID;
+  }
+  if (n >= (1ull << 31)) {
+    ctx->fail("vbx_tsdf_integrate: too many points");
+    return VBX_ERR_INVALID;
+  }
+  if (cfg->integration_order_mode != 0 && cfg->integration_order_mode != 1) {
+    ctx->fail("Unknown integration order mode");  // integrator_utils.cc:12
+    return VBX_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->counters = vbx_counters{};
+  ctx->counters.points = n;
+  if (n == 0) return VBX_OK;
+  // per-call device counters
+  hipLaunchKernelGGL(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
+  Pose T;
+  T.t = {pos[0], pos[1], pos[2]};
+  T.qw = quat[0]; T.qx = quat[1]; T.qy = quat[2]; T.qz = quat[3];
+  for (int i = 0; i < 9; ++i) ctx->ev_hit[i] = false;
+  tmark(ctx, 0);
+  int rc;
+  const uint32_t* rgba32 = reinterpret_cast<const uint32_t*>(d_rgba);
+  switch (kind) {
+    case VBX_TSDF_SIMPLE: rc = integrate_simple(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
+    case VBX_TSDF_MERGED: rc = integrate_merged(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
+    case VBX_TSDF_FAST: rc = integrate_fast(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
+    default:
+      ctx->fail("unknown TSDF integrator type %d", kind);  // tsdf_integrator.cc:40-43
+      return VBX_ERR_INVALID;
+  }
+  if (rc) return rc;
+  tmark(ctx, 7);
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  rc = check_state_error(ctx);
+  if (rc) return rc;
+  ctx->counters.rays_cast = ctx->h_state.rays_cast;
+  ctx->counters.voxels_touched = ctx->h_state.voxels_touched;
+  ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
+  if (ctx->timing) {
+    (void)hipEventSynchronize(ctx->ev[7]);  // the state read-back spins on mapped memory; the runtime may not have retired the events yet
+    float t[8] = {0};
+    int last = 0;
+    for (int i = 1; i < 8; ++i) {  // a stage a path skips reads as zero-length
+      if (!ctx->ev_hit[i]) continue;
+      (void)hipEventElapsedTime(&t[i], ctx->ev[last], ctx->ev[i]);
+      last = i;
+    }
+    vbx_timing& o = ctx->last_timing;
+    o.prep_ms = t[1]; o.alloc_ms = t[2]; o.solve_ms = t[3]; o.emit_ms = t[4];
+    o.sort_ms = t[5]; o.fold_ms = t[6];
+    o.replay_ms = 0.0f;
+    if (ctx->ev_hit[8] && ctx->ev_hit[3]) {  // stage 3 = exact-set solve + reference-set replay rounds
+      (void)hipEventElapsedTime(&o.replay_ms, ctx->ev[8], ctx->ev[3]);
+      o.solve_ms = t[3] - o.replay_ms;
+    }
+    (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
+  }
+  return VBX_OK;
+}
+
+
+}  // namespace
+

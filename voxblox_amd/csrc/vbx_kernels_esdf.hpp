@@ -1,0 +1,449 @@
+// vbx_kernels_esdf.hpp — EsdfIntegrator kernels: classification, robot spheres, LDS-tiled raise / lower / parent passes
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+namespace {
+// ===========================================================================
+// ESDF integrator (esdf_integrator.cc) — see DESIGN.md §ESDF.
+//
+// The reference runs three strictly sequential phases per update: (1) walk every voxel of the
+// updated TSDF blocks and classify it (new / lower / raise / sign flip), (2) a FIFO "raise"
+// wavefront that invalidates the children (by parent pointer) of voxels whose distance grew,
+// (3) a bucket-queue "lower" wavefront that relaxes 26-neighbours until nothing improves.
+// Phase 1 is per-voxel independent and is reproduced rule by rule.  Phases 2 and 3 compute
+// closures / fixed points that do not depend on the visiting order (for min_diff_m == 0 the
+// lower phase is Bellman-Ford on the 26-graph: every voxel ends at the float-minimum over
+// all paths), so they run as LDS-tiled chaotic relaxations: one workgroup stages a block plus
+// its one-voxel halo (18^3 distances + states, 46 KiB) in LDS, relaxes it to a local fixed
+// point, and the host repeats global sweeps until no block changes.
+// ===========================================================================
+constexpr uint32_t kEsdfObserved = 1, kEsdfHallucinated = 2, kEsdfInQueue = 4, kEsdfFixed = 8;
+
+struct EsdfDev {
+  float* dist;
+  uint32_t* state;    // bits 0-3 flags, 8-15 / 16-23 / 24-31 parent x/y/z (int8)
+  uint8_t* raised;    // 1 = raised during the current update
+  uint32_t* active;   // per slot: 1 = process this sweep, 2 = process next sweep, 4 = touched
+};
+struct EsdfCfgDev {
+  float max_distance, min_distance, default_distance, min_diff, min_weight;
+  int add_occupied_crust;
+  float voxel_size;
+};
+
+constexpr int kNbOff[26][3] = {
+    {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+    {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {0, -1, -1}, {0, -1, 1},
+    {0, 1, -1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
+    {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1},
+    {1, 1, -1}, {1, 1, 1}};  // same table, compile-time (unrolled loops)
+__constant__ int c_nb_off[26][3] = {
+    {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+    {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {0, -1, -1}, {0, -1, 1},
+    {0, 1, -1}, {0, 1, 1}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1},
+    {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1},
+    {1, 1, -1}, {1, 1, 1}};  // neighbor_tools.cc:24-30, column order is observable
+
+__device__ inline uint32_t pack_parent(int x, int y, int z) {
+  return ((uint32_t)(uint8_t)(int8_t)x << 8) | ((uint32_t)(uint8_t)(int8_t)y << 16) |
+         ((uint32_t)(uint8_t)(int8_t)z << 24);
+}
+__device__ inline void unpack_parent(uint32_t s, int* x, int* y, int* z) {
+  *x = (int)(int8_t)((s >> 8) & 0xFF);
+  *y = (int)(int8_t)((s >> 16) & 0xFF);
+  *z = (int)(int8_t)((s >> 24) & 0xFF);
+}
+
+// Phase 1: EsdfIntegrator::updateFromTsdfBlocks, esdf_integrator.cc:136-287, one thread per
+// voxel of every TSDF block that carries the kEsdf update bit (incremental) or of every
+// allocated TSDF block (batch).  Queue pushes become marks: `raised` for raise_.push, block
+// activity for open_.push (the lower phase re-relaxes whole active blocks).
+// updateVoxelFromNeighbors (:498-530) is a pull from already-converged neighbours; the lower
+// phase's pull relaxation subsumes it (and does not reproduce its unscaled-distance quirk).
+// select: 0 = every TSDF block (batch), 1 = blocks with Update::kEsdf or in updated_blocks_
+// (updateFromTsdfLayer), 2 = only the blocks the caller listed (updateFromTsdfBlocks).
+__global__ void k_esdf_classify(MapDev m, EsdfDev e, EsdfCfgDev c, int incremental, int select, DevState* st) {
+  const uint32_t slot = blockIdx.x;
+  const uint32_t flags = m.blk_flags[slot];
+  if (!(flags & kFlagPublished)) return;
+  // Update::kEsdf, or a member of updated_blocks_ (esdf_integrator.cc:107-108)
+  if (select == 1 && !(flags & 4u) && !(e.active[slot] & 16u)) return;
+  if (select == 2 && !(e.active[slot] & 32u)) return;
+  const uint32_t lin = blockIdx.y * blockDim.x + threadIdx.x;
+  if (lin >= m.nvox) return;
+  if (lin == 0) {
+    atomicOr(&m.blk_flags[slot], kFlagEsdfAlloc | (1u << kFlagEsdfUpdShift));  // set_updated(true): kMap only
+    atomicOr(&e.active[slot], 8u);  // processed by this update
+    atomicAdd(&st->esdf_blocks, 1u);
+  }
+  const uint32_t gid = slot * m.nvox + lin;
+  const float td = m.dist[gid];
+  const float tw = m.weight[gid];
+  float ed = e.dist[gid];
+  uint32_t es = e.state[gid];
+  if (tw < c.min_weight) {
+    if (!incremental && c.add_occupied_crust) {
+      ed = -c.default_distance;
+      es = (es | kEsdfObserved | kEsdfHallucinated) & ~kEsdfFixed;
+      e.dist[gid] = ed;
+      e.state[gid] = es;
+    }
+    return;
+  }
+  const bool tsdf_fixed = fabsf(td) < c.min_distance;
+  const float sgn_default = (float)signum(td) * c.default_distance;
+  bool raise = false;
+  if (!(es & kEsdfObserved) || (es & kEsdfHallucinated)) {
+    if (es & kEsdfHallucinated) raise = true;
+    if (tsdf_fixed) {
+      ed = td;
+      es |= kEsdfFixed;
+    } else {
+      ed = sgn_default;
+      es &= ~kEsdfFixed;
+    }
+    es &= 0xFFu;  // parent.setZero()
+  } else {
+    const bool efixed = (es & kEsdfFixed) != 0;
+    if (tsdf_fixed || efixed) {
+      if (!tsdf_fixed) {
+        ed = sgn_default;
+        es &= 0xFFu;
+        es &= ~kEsdfFixed;
+        raise = true;
+      } else if ((ed > 0.0f && td + c.min_diff < ed) || (ed <= 0.0f && td - c.min_diff > ed)) {
+        es |= kEsdfFixed;  // fixed = tsdf_fixed (true here)
+        ed = td;
+        es &= 0xFFu;
+      } else if ((ed > 0.0f && td - c.min_diff > ed) || (ed <= 0.0f && td + c.min_diff < ed)) {
+        es |= kEsdfFixed;
+        ed = td;
+        es &= 0xFFu;
+        raise = true;
+      }
+    } else if (signum(td) != signum(ed)) {
+      if (td < ed) {
+        ed = sgn_default;
+        es &= 0xFFu;
+      } else {
+        ed = sgn_default;
+        es &= 0xFFu;
+        raise = true;
+      }
+    }
+  }
+  es |= kEsdfObserved;
+  es &= ~(kEsdfHallucinated | kEsdfInQueue);
+  e.dist[gid] = ed;
+  e.state[gid] = es;
+  if (raise) {
+    e.raised[gid] = 1;
+    st->esdf_raise_any = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// EsdfIntegrator::addNewRobotPosition, esdf_integrator.cc:25-92, over the sphere voxel lists of
+// utils::getSphereAroundPoint (planning_utils_inl.h:14-48).  `xs` holds the reference's float
+// loop variable (x = -r; x <= r; x++) computed on the host with the same increments; one thread
+// per (i,j,k) of the n^3 cube around the centre voxel.
+// ---------------------------------------------------------------------------
+struct SphereDev {
+  const float* xs;
+  int n;
+  float r;      // radius in voxels
+  l3 center;    // getGridIndexFromPoint<GlobalIndex>(center, voxel_size_inv)
+};
+__device__ inline bool sphere_voxel(const SphereDev& sp, const MapDev& m, size_t t, uint64_t* key, uint32_t* lin) {
+  const size_t n = (size_t)sp.n;
+  if (t >= n * n * n) return false;
+  const int k = (int)(t % n), j = (int)((t / n) % n), i = (int)(t / (n * n));
+  const f3 pv{sp.xs[i], sp.xs[j], sp.xs[k]};
+  if (!(f3_norm(pv) <= sp.r)) return false;
+  const l3 g{(int64_t)floorf(pv.x) + sp.center.x, (int64_t)floorf(pv.y) + sp.center.y,
+             (int64_t)floorf(pv.z) + sp.center.z};
+  const i3 b = block_index_from_global(g, m.vps_inv);  // common.h:245-255
+  const i3 v = local_from_global(g, (int)m.vps);
+  *key = pack_block_key(b.x, b.y, b.z);
+  *lin = (uint32_t)v.x + m.vps * ((uint32_t)v.y + (uint32_t)v.z * m.vps);
+  return true;
+}
+// getAndAllocateSphereAroundPoint (planning_utils_inl.h:50-61): every block holding a sphere voxel
+__global__ void k_sphere_mark_blocks(MapDev m, SphereDev sp, uint32_t* new_list, DevState* st) {
+  uint64_t key;
+  uint32_t lin;
+  if (!sphere_voxel(sp, m, (size_t)blockIdx.x * blockDim.x + threadIdx.x, &key, &lin)) return;
+  map_insert_key(m, key, new_list, st);
+}
+// mode 0: inner sphere (unknown or hallucinated -> free); mode 1: outer sphere (unknown ->
+// occupied, known -> open_).  Queue pushes become marks that the next update consumes.
+__global__ void k_sphere_apply(MapDev m, EsdfDev e, SphereDev sp, float default_distance, int mode) {
+  uint64_t key;
+  uint32_t lin;
+  if (!sphere_voxel(sp, m, (size_t)blockIdx.x * blockDim.x + threadIdx.x, &key, &lin)) return;
+  const uint32_t slot = map_find(m, key);
+  if (slot == kInvalidSlot) return;  // pool exhausted: reported through DevState::error
+  const uint32_t gid = slot * m.nvox + lin;
+  uint32_t want = kFlagEsdfAlloc;
+  const uint32_t es = e.state[gid];
+  if (mode == 0) {
+    if (!(es & kEsdfObserved) || (es & kEsdfHallucinated)) {
+      if (es & kEsdfHallucinated) e.raised[gid] = 1;  // raise_.push
+      e.dist[gid] = default_distance;
+      e.state[gid] = (es & 0xFFu) | kEsdfObserved | kEsdfHallucinated;  // parent.setZero()
+      want |= kFlagEsdfPendClassify;
+    }
+  } else {
+    if (!(es & kEsdfObserved)) {
+      e.dist[gid] = -default_distance;
+      e.state[gid] = (es & 0xFFu) | kEsdfObserved | kEsdfHallucinated;
+      want |= kFlagEsdfPendClassify;
+    } else {
+      want |= kFlagEsdfPendOpen;  // open_.push(global_index, distance) — in_queue stays clear (:81-85)
+    }
+  }
+  const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((cur & want) != want) atomicOr(&m.blk_flags[slot], want);
+}
+
+// updateFromTsdfBlocks(list): mark the listed blocks for classification
+__global__ void k_esdf_mark_listed(MapDev m, EsdfDev e, const int32_t* __restrict__ idx, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = map_find(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]));
+  if (s != kInvalidSlot) atomicOr(&e.active[s], 32u);
+}
+
+// active(cur) = every block processed by this update and its 26 neighbours.
+__global__ void k_esdf_seed_active(MapDev m, EsdfDev e, uint32_t n_slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t slot = i / 27, nb = i % 27;
+  if (slot >= n_slots) return;
+  if (!(e.active[slot] & 8u)) return;
+  const int dx = (int)(nb % 3) - 1, dy = (int)((nb / 3) % 3) - 1, dz = (int)(nb / 9) - 1;
+  const uint32_t s2 = map_find(m, pack_block_key(m.blk_idx[3 * slot] + dx, m.blk_idx[3 * slot + 1] + dy,
+                                                 m.blk_idx[3 * slot + 2] + dz));
+  if (s2 != kInvalidSlot && (m.blk_flags[s2] & kFlagEsdfAlloc)) atomicOr(&e.active[s2], 1u | 4u);
+}
+__global__ void k_esdf_rotate_active(EsdfDev e, uint32_t n_slots, int reseed) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint32_t a = e.active[s];
+  uint32_t cur = (a & 2u) ? 1u : 0u;
+  if (reseed) cur = (a & 4u) ? 1u : 0u;  // start of a new phase: everything touched so far
+  e.active[s] = cur | (a & 12u) | (cur ? 4u : 0u);
+}
+
+// Phases 2/3 (+ parent canonicalisation) on one block + halo staged in LDS.
+//   mode 0: processRaiseSet (esdf_integrator.cc:305-369) as a closure: a non-fixed observed
+//           voxel whose parent voxel was raised is reset to sign*default and raised itself.
+//   mode 1: processOpenSet (:371-496) as a pull relaxation over the 26-neighbourhood.
+//   mode 2: parent = first LUT neighbour that explains the converged distance exactly.
+constexpr int kEsdfThreads = 1024;  // one workgroup relaxes one block; big frontiers need the lanes
+template <int VPS>
+__global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
+                                                   DevState* st) {
+  constexpr int T = VPS + 2;
+  constexpr int NT = T * T * T;
+  constexpr int NV = VPS * VPS * VPS;
+  __shared__ float s_d[NT];
+  __shared__ uint32_t s_s[NT];
+  __shared__ uint8_t s_r[NT];     // raise marks (mode 0) / need flags (mode 1): never both
+  __shared__ uint16_t s_q[NV];    // mode 1: dense work queue
+  __shared__ int s_qn;
+  __shared__ uint32_t s_nb[27];
+  __shared__ int s_flag;
+  const uint32_t slot = blockIdx.x;
+  if (!(m.blk_flags[slot] & kFlagEsdfAlloc)) return;
+  if (!(e.active[slot] & 1u)) return;
+  const int tid = threadIdx.x;
+  if (tid < 27) {
+    const int dx = tid % 3 - 1, dy = (tid / 3) % 3 - 1, dz = tid / 9 - 1;
+    uint32_t s2 = map_find(m, pack_block_key(m.blk_idx[3 * slot] + dx, m.blk_idx[3 * slot + 1] + dy,
+                                             m.blk_idx[3 * slot + 2] + dz));
+    if (s2 != kInvalidSlot && !(m.blk_flags[s2] & kFlagEsdfAlloc)) s2 = kInvalidSlot;
+    s_nb[tid] = s2;
+  }
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+#pragma unroll 4
+  for (int t = tid; t < NT; t += kEsdfThreads) {
+    const int tx = t % T, ty = (t / T) % T, tz = t / (T * T);
+    const int bx = (tx == 0) ? 0 : (tx == T - 1 ? 2 : 1);
+    const int by = (ty == 0) ? 0 : (ty == T - 1 ? 2 : 1);
+    const int bz = (tz == 0) ? 0 : (tz == T - 1 ? 2 : 1);
+    const uint32_t s2 = s_nb[bx + 3 * by + 9 * bz];
+    float d = 0.f;
+    uint32_t s = 0;  // getVoxelPtrByGlobalIndex == nullptr: looks unobserved
+    uint8_t r = 0;
+    if (s2 != kInvalidSlot) {
+      const int lx = (tx - 1) & (VPS - 1), ly = (ty - 1) & (VPS - 1), lz = (tz - 1) & (VPS - 1);
+      const uint32_t g2 = s2 * NV + (uint32_t)(lx + VPS * (ly + lz * VPS));
+      d = e.dist[g2];
+      s = e.state[g2];
+      r = e.raised[g2];
+    }
+    s_d[t] = d;
+    s_s[t] = s;
+    s_r[t] = r;
+  }
+  __syncthreads();
+
+  const float sq2 = (float)1.4142135623730951, sq3 = (float)1.7320508075688772;
+  bool any_change = false;
+
+  // processOpenSet for one voxel (pull form): returns true if the voxel was lowered.
+  auto relax = [&](int t) -> bool {
+    const uint32_t s = s_s[t];
+    if (!(s & kEsdfObserved) || (s & kEsdfFixed)) return false;
+    float d = s_d[t];
+    bool upd = false;
+    int best = -1;
+    // fully unrolled: the 52 LDS reads of one voxel issue back to back
+#pragma unroll
+    for (int i = 0; i < 26; ++i) {
+      const int tv = t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2]);
+      const uint32_t sv = s_s[tv];
+      if (!(sv & kEsdfObserved)) continue;
+      const float dv = s_d[tv];
+      if (dv >= c.max_distance || dv <= -c.max_distance) continue;
+      const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
+      if (dv > 0 && d > 0) {
+        if (dv + dist + c.min_diff < d) { d = dv + dist; best = i; upd = true; }
+      } else if (dv <= 0 && d <= 0) {
+        if (dv - dist - c.min_diff > d) { d = dv - dist; best = i; upd = true; }
+      } else {
+        // sign mismatch (esdf_integrator.cc:459-488).  In the reference this assignment is
+        // gated by |potential - d| > dist and its outcome depends on the pop order of the two
+        // neighbours (libstdc++ unordered_map block order).  The order-free form used here
+        // applies the same candidate whenever it moves the voxel closer to the surface, which
+        // is the outcome of the reference when the opposite-sign neighbour pops first.
+        const float potential = dv - (float)signum(dv) * dist;
+        float cand;
+        if ((float)signum(potential) == d) cand = potential;
+        else cand = (float)signum(d) * dist;
+        if (fabsf(cand) < fabsf(d)) { d = cand; best = i; upd = true; }
+      }
+    }
+    if (upd) {
+      s_d[t] = d;
+      s_s[t] = (s & 0xFFu) | pack_parent(c_nb_off[best][0], c_nb_off[best][1], c_nb_off[best][2]);
+    }
+    return upd;
+  };
+
+  if (mode == 1) {
+    // Worklist relaxation: s_need marks voxels whose neighbourhood changed; every iteration
+    // compacts the marked voxels into a dense queue (so all lanes evaluate real work), relaxes
+    // them, and marks the 26 neighbours of every voxel that moved.  Total evaluations are
+    // proportional to the number of changes, not to iterations x block size.  (A push-based
+    // queue with an atomic visited bitset was measured slower: 3.1 vs 2.2 ms per update.)
+    uint8_t* s_need = s_r;  // the raise marks are not used while lowering
+    for (int t = tid; t < NT; t += kEsdfThreads) s_need[t] = 0;
+    __syncthreads();
+    for (int v = tid; v < NV; v += kEsdfThreads) {
+      const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+      s_need[(lx + 1) + T * ((ly + 1) + T * (lz + 1))] = 1;  // first pass: everything
+    }
+    for (int iter = 0; iter < 64 * VPS; ++iter) {
+      if (tid == 0) s_qn = 0;
+      __syncthreads();
+      for (int v = tid; v < NV; v += kEsdfThreads) {
+        const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+        const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+        if (s_need[t]) {
+          s_need[t] = 0;
+          const uint32_t sv = s_s[t];
+          if ((sv & kEsdfObserved) && !(sv & kEsdfFixed)) s_q[atomicAdd(&s_qn, 1)] = (uint16_t)t;
+        }
+      }
+      __syncthreads();
+      const int qn = s_qn;
+      if (qn == 0) break;
+      for (int q = tid; q < qn; q += kEsdfThreads) {
+        const int t = s_q[q];
+        if (relax(t)) {
+          any_change = true;
+#pragma unroll
+          for (int i = 0; i < 26; ++i) s_need[t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2])] = 1;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+  for (int iter = 0; iter < 4 * VPS; ++iter) {
+    bool changed = false;
+    for (int v = tid; v < NV; v += kEsdfThreads) {
+      const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+      const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+      uint32_t s = s_s[t];
+      if (!(s & kEsdfObserved) || (s & kEsdfFixed)) continue;
+      float d = s_d[t];
+      if (mode == 0) {
+        int px, py, pz;
+        unpack_parent(s, &px, &py, &pz);
+        if ((px | py | pz) == 0 || s_r[t]) continue;
+        // quasi-Euclidean parents are unit LUT offsets, so the parent voxel is inside the halo
+        const int tp = t + px + T * (py + T * pz);
+        if (s_r[tp]) {
+          s_d[t] = (float)signum(d) * c.default_distance;
+          s_s[t] = s & 0xFFu;
+          s_r[t] = 1;
+          changed = true;
+        }
+        continue;
+      }
+      // mode 2: canonical parent
+      {
+        int px, py, pz;
+        unpack_parent(s, &px, &py, &pz);
+        if ((px | py | pz) == 0) continue;
+        for (int i = 0; i < 26; ++i) {
+          const int tv = t + c_nb_off[i][0] + T * (c_nb_off[i][1] + T * c_nb_off[i][2]);
+          const uint32_t sv = s_s[tv];
+          if (!(sv & kEsdfObserved)) continue;
+          const float dv = s_d[tv];
+          if (dv >= c.max_distance || dv <= -c.max_distance) continue;
+          const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
+          bool hit;
+          if (dv > 0 && d > 0) hit = (dv + dist == d);
+          else if (dv <= 0 && d <= 0) hit = (dv - dist == d);
+          else {  // the sign-mismatch rule: d == potential or sign(d) * dist
+            const float potential = dv - (float)signum(dv) * dist;
+            const float cand = ((float)signum(potential) == d) ? potential : (float)signum(d) * dist;
+            hit = (cand == d);
+          }
+          if (hit) {
+            const uint32_t ns = (s & 0xFFu) | pack_parent(c_nb_off[i][0], c_nb_off[i][1], c_nb_off[i][2]);
+            if (ns != s) { s_s[t] = ns; changed = true; }
+            break;
+          }
+        }
+      }
+    }
+    any_change |= changed;
+    const int more = __syncthreads_or(changed ? 1 : 0);
+    if (!more || mode == 2) break;
+  }
+  }
+  if (any_change) s_flag = 1;
+  __syncthreads();
+  if (!s_flag) return;
+  for (int v = tid; v < NV; v += kEsdfThreads) {
+    const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+    const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+    const uint32_t g = slot * NV + v;
+    e.dist[g] = s_d[t];
+    e.state[g] = s_s[t];
+    if (mode == 0) e.raised[g] = s_r[t];
+  }
+  if (mode != 2) {
+    if (tid < 27 && s_nb[tid] != kInvalidSlot) atomicOr(&e.active[s_nb[tid]], 2u | 4u);
+    if (tid == 0) {
+      st->changed = 1;
+      atomicAdd(&st->esdf_relax_blocks, 1u);
+    }
+  }
+}
+
+}  // namespace
+

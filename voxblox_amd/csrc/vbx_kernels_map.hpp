@@ -1,0 +1,337 @@
+// vbx_kernels_map.hpp — map maintenance, layer (de)serialization, host-mirror packing and multi-GPU merge kernels
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+namespace {
+// ---------------------------------------------------------------------------
+// kernels: map maintenance
+// ---------------------------------------------------------------------------
+__global__ void k_fill_u64(uint64_t* p, uint64_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+// Per-call counters: one launch instead of several unaligned memsets (each of which the
+// runtime splits into head/body/tail fill kernels).
+__global__ void k_publish_state(const DevState* st, StateMirror* out, const uint32_t* extra, uint32_t seq) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(st);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&out->st);
+  for (uint32_t i = threadIdx.x; i < sizeof(DevState) / 4; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x == 0 && extra) out->extra = *extra;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_reset_call_state(DevState* st) {
+  st->new_count = 0;
+  st->error = 0;
+  st->changed = 0;
+  st->sentinel_cleared = 0;
+  st->blocks_published = 0;
+  st->esdf_blocks = 0;
+  st->esdf_raise_any = 0;
+  st->esdf_relax_blocks = 0;
+  st->act_count[0] = st->act_count[1] = st->act_count[2] = 0;
+  st->fold_long_count = 0;
+  st->fast_idle_sweep = 0;
+  st->redo_count = 0;
+  st->total_keys = 0;
+  st->voxels_touched = 0;
+  st->rays_cast = 0;
+  st->num_kept = 0;
+}
+
+__global__ void k_assign_slots(MapDev m, const uint32_t* new_list, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = min(st->new_count, m.cap_blocks);
+  if (i >= n) return;
+  const uint32_t h = new_list[i];
+  const uint32_t fc = st->free_count;
+  uint32_t slot;
+  if (i < fc) {
+    slot = m.free_list[fc - 1 - i];
+  } else {
+    slot = st->pool_used + (i - fc);
+  }
+  if (slot >= m.cap_blocks) {
+    atomicOr(&st->error, 1u);
+    return;  // hvals stays invalid; voxels of this block are skipped and the call fails
+  }
+  int x, y, z;
+  unpack_block_key(m.hkeys[h], &x, &y, &z);
+  m.blk_idx[3 * slot] = x;
+  m.blk_idx[3 * slot + 1] = y;
+  m.blk_idx[3 * slot + 2] = z;
+  m.blk_flags[slot] = 0;
+  __hip_atomic_store(&m.hvals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_commit_alloc(MapDev m, DevState* st) {
+  const uint32_t n = min(st->new_count, m.cap_blocks);
+  const uint32_t fc = st->free_count;
+  if (n <= fc) {
+    st->free_count = fc - n;
+  } else {
+    const uint32_t grow = n - fc;
+    st->free_count = 0;
+    if (st->pool_used + grow > m.cap_blocks) {
+      st->pool_used = m.cap_blocks;
+      st->error |= 1u;
+    } else {
+      st->pool_used += grow;
+    }
+  }
+  st->new_count = 0;
+}
+
+// ---------------------------------------------------------------------------
+// kernels: Block<V>::serializeToIntegers / deserializeFromIntegers (src/core/block.cc)
+// ---------------------------------------------------------------------------
+__device__ inline uint32_t esdf_state_to_word(uint32_t st) {
+  int px, py, pz;
+  unpack_parent_bits(st, &px, &py, &pz);
+  // serializeDirection (block.cc:8-40): int8 promoted to int, shifted, then cast to uint32 —
+  // a negative component sign-extends over the higher bytes.
+  uint32_t w = 0;
+  w |= (uint32_t)((long long)(int8_t)px << 24);
+  w |= (uint32_t)((long long)(int8_t)py << 16);
+  w |= (uint32_t)((long long)(int8_t)pz << 8);
+  w |= st & 0xFu;
+  return w;
+}
+__global__ void k_serialize_tsdf(MapDev m, const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  uint32_t* o = out + (size_t)blockIdx.x * m.nvox * 3;
+  for (uint32_t i = threadIdx.x; i < m.nvox * 3; i += blockDim.x) {  // coalesced word stream
+    const uint32_t v = i / 3, f = i - 3 * v;
+    const uint32_t gid = slot * m.nvox + v;
+    uint32_t w;
+    if (f == 0) w = __float_as_uint(m.dist[gid]);
+    else if (f == 1) w = __float_as_uint(m.weight[gid]);
+    else {
+      const uint32_t c = m.rgba[gid];  // r | g<<8 | b<<16 | a<<24  ->  r<<24 | g<<16 | b<<8 | a
+      w = ((c & 0xFF) << 24) | (((c >> 8) & 0xFF) << 16) | (((c >> 16) & 0xFF) << 8) | ((c >> 24) & 0xFF);
+    }
+    o[i] = w;
+  }
+}
+__global__ void k_deserialize_tsdf(MapDev m, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ in) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* w = in + (size_t)blockIdx.x * m.nvox * 3;
+  for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+    const uint32_t gid = slot * m.nvox + v;
+    m.dist[gid] = __uint_as_float(w[3 * v]);
+    m.weight[gid] = __uint_as_float(w[3 * v + 1]);
+    const uint32_t c = w[3 * v + 2];
+    m.rgba[gid] = ((c >> 24) & 0xFF) | (((c >> 16) & 0xFF) << 8) | (((c >> 8) & 0xFF) << 16) | ((c & 0xFF) << 24);
+  }
+}
+__global__ void k_serialize_esdf(uint32_t nvox, const float* __restrict__ edist, const uint32_t* __restrict__ estate,
+                                 const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  uint32_t* o = out + (size_t)blockIdx.x * nvox * 2;
+  for (uint32_t i = threadIdx.x; i < nvox * 2; i += blockDim.x) {
+    const uint32_t v = i >> 1;
+    const uint32_t gid = slot * nvox + v;
+    o[i] = (i & 1) ? esdf_state_to_word(estate[gid]) : __float_as_uint(edist[gid]);
+  }
+}
+__global__ void k_deserialize_esdf(uint32_t nvox, float* edist, uint32_t* estate,
+                                   const uint32_t* __restrict__ slots, const uint32_t* __restrict__ in) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* w = in + (size_t)blockIdx.x * nvox * 2;
+  for (uint32_t v = threadIdx.x; v < nvox; v += blockDim.x) {
+    const uint32_t gid = slot * nvox + v;
+    edist[gid] = __uint_as_float(w[2 * v]);
+    const uint32_t b = w[2 * v + 1];  // deserializeDirection (block.cc:42-64) + flag bits
+    estate[gid] = (b & 0xFu) | (((b >> 24) & 0xFF) << 8) | (((b >> 16) & 0xFF) << 16) | (((b >> 8) & 0xFF) << 24);
+  }
+}
+__global__ void k_set_block_flags(MapDev m, const uint32_t* __restrict__ slots, uint32_t n, uint32_t or_bits,
+                                  const uint8_t* __restrict__ has_data, uint32_t has_data_bit) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || slots[i] == kInvalidSlot) return;
+  uint32_t f = or_bits;
+  if (has_data && has_data[i]) f |= has_data_bit;
+  atomicOr(&m.blk_flags[slots[i]], f);
+}
+
+// ---------------------------------------------------------------------------
+// kernels: multi-GPU block merge (mergeVoxelAIntoVoxelB as weighted sums)
+// ---------------------------------------------------------------------------
+__global__ void k_export_sums(MapDev m, const uint32_t* __restrict__ slots, float* out) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  float* o = out + (size_t)b * 6 * m.nvox;
+  for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+    float wd = 0.f, w = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f;
+    if (slot != kInvalidSlot) {
+      const uint32_t gid = slot * m.nvox + v;
+      w = m.weight[gid];
+      wd = w * m.dist[gid];
+      const uint32_t c = m.rgba[gid];
+      cr = w * (float)(c & 0xFF); cg = w * (float)((c >> 8) & 0xFF);
+      cb = w * (float)((c >> 16) & 0xFF); ca = w * (float)((c >> 24) & 0xFF);
+    }
+    o[v] = wd; o[m.nvox + v] = w; o[2 * m.nvox + v] = cr; o[3 * m.nvox + v] = cg;
+    o[4 * m.nvox + v] = cb; o[5 * m.nvox + v] = ca;
+  }
+}
+
+// lookup (find-only) of a host-provided block list -> slots; unpublished blocks read as absent
+__global__ void k_lookup_slots(MapDev m, const int32_t* __restrict__ idx, uint32_t n, int published_only,
+                               uint32_t* slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s = map_find(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]));
+  if (s != kInvalidSlot && published_only && !(m.blk_flags[s] & kFlagPublished)) s = kInvalidSlot;
+  slots[i] = s;
+}
+__global__ void k_insert_blocks(MapDev m, const int32_t* __restrict__ idx, uint32_t n, uint32_t* new_list,
+                                DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  map_insert_key(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]), new_list, st);
+}
+
+// Bulk mirror of blocks into the reference's AoS voxel layouts (voxel.h:12-37), one workgroup
+// per requested block, coalesced word writes.  flags_out[b] = block flags, ~0u if the block is
+// not part of the layer.
+__global__ void k_lookup_slots_flags(MapDev m, const int32_t* __restrict__ idx, uint32_t n, uint32_t need,
+                                     uint32_t* slots, uint32_t* flags_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s = map_find(m, pack_block_key(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]));
+  uint32_t f = ~0u;
+  if (s != kInvalidSlot) {
+    f = m.blk_flags[s];
+    if (!(f & need)) { s = kInvalidSlot; f = ~0u; }
+  }
+  slots[i] = s;
+  flags_out[i] = f;
+}
+__global__ void k_pack_tsdf_aos(MapDev m, const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* d = reinterpret_cast<const uint32_t*>(m.dist) + (size_t)slot * m.nvox;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(m.weight) + (size_t)slot * m.nvox;
+  const uint32_t* c = m.rgba + (size_t)slot * m.nvox;
+  uint32_t* o = out + (size_t)b * m.nvox * 3;
+  for (uint32_t i = threadIdx.x; i < m.nvox * 3; i += blockDim.x) {
+    const uint32_t v = i / 3, k = i % 3;
+    o[i] = (k == 0) ? d[v] : (k == 1 ? w[v] : c[v]);  // {float distance; float weight; Color color}
+  }
+}
+__global__ void k_pack_esdf_aos(uint32_t nvox, const float* __restrict__ edist, const uint32_t* __restrict__ estate,
+                                const uint32_t* __restrict__ slots, uint32_t* out) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* d = reinterpret_cast<const uint32_t*>(edist) + (size_t)slot * nvox;
+  const uint32_t* st = estate + (size_t)slot * nvox;
+  uint32_t* o = out + (size_t)b * nvox * 5;
+  for (uint32_t i = threadIdx.x; i < nvox * 5; i += blockDim.x) {
+    const uint32_t v = i / 5, k = i % 5;
+    uint32_t wv;
+    if (k == 0) {
+      wv = d[v];
+    } else {
+      const uint32_t x = st[v];
+      if (k == 1)  // bool observed, hallucinated, in_queue, fixed: one byte each
+        wv = (x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21);
+      else         // Eigen::Vector3i parent
+        wv = (uint32_t)(int32_t)(int8_t)((x >> (8 * (k - 1))) & 0xFFu);
+    }
+    o[i] = wv;
+  }
+}
+
+__global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const float* __restrict__ in,
+                             int apply_caps, float trunc, float max_weight, DevState* st) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t slot = slots[b];
+  if (slot == kInvalidSlot) return;
+  const float* a = in + (size_t)b * 6 * m.nvox;
+  bool any = false;
+  for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+    const float wA = a[m.nvox + v];
+    if (!(wA > 0.0f)) continue;
+    any = true;
+    const uint32_t gid = slot * m.nvox + v;
+    const float dA = a[v] / wA;
+    uint32_t cA = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const float c = roundf(a[(2 + ch) * m.nvox + v] / wA);
+      cA |= ((uint32_t)(int)std_min(std_max(c, 0.0f), 255.0f) & 0xFFu) << (8 * ch);
+    }
+    const float wB = m.weight[gid];
+    const float dB = m.dist[gid];
+    const float cw = wA + wB;  // mergeVoxelAIntoVoxelB, voxel_utils.cc:10-22
+    if (cw > 0.0f) {
+      float d = (dA * wA + dB * wB) / cw;
+      float w = cw;
+      const uint32_t col = blend_two_colors(cA, wA, m.rgba[gid], wB);
+      if (apply_caps) {
+        d = (d > 0.0f) ? std_min(trunc, d) : std_max(-trunc, d);
+        w = std_min(max_weight, w);
+      }
+      m.dist[gid] = d;
+      m.weight[gid] = w;
+      m.rgba[gid] = col;
+    }
+  }
+  if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) publish_block(m, slot, st);
+}
+
+// Layer::removeDistantBlocks (layer.h:170-182) for every block of one layer in one launch: a
+// workgroup per pool slot; (origin - center).squaredNorm() > max^2 with origin = float(index) *
+// block_size (common.h:195-201).  A removed block is zeroed and leaves the layer; its hash
+// entry and pool slot stay (an invisible candidate again).
+__global__ void k_remove_distant(MapDev m, float* edist, uint32_t* estate, int layer, f3 center, double max_sq,
+                                 float block_size) {
+  const uint32_t slot = blockIdx.x;
+  const uint32_t f = m.blk_flags[slot];
+  const uint32_t need = (layer == VBX_LAYER_ESDF) ? kFlagEsdfAlloc : kFlagPublished;
+  if (!(f & need)) return;
+  const f3 o{(float)m.blk_idx[3 * slot] * block_size, (float)m.blk_idx[3 * slot + 1] * block_size,
+             (float)m.blk_idx[3 * slot + 2] * block_size};
+  if (!((double)f3_sqnorm(f3_sub(o, center)) > max_sq)) return;
+  const size_t base = (size_t)slot * m.nvox;
+  if (layer == VBX_LAYER_ESDF) {
+    if (edist)
+      for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) { edist[base + v] = 0.f; estate[base + v] = 0u; }
+  } else {
+    for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+      m.dist[base + v] = 0.f; m.weight[base + v] = 0.f; m.rgba[base + v] = 0u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // the two layers are independent (layer.h:167): keep the other layer's membership and bits
+    const uint32_t esdf_bits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen;
+    m.blk_flags[slot] = (layer == VBX_LAYER_ESDF) ? (f & ~esdf_bits) : (f & esdf_bits);
+  }
+}
+
+// Block::updated().reset(bits) on every block of one layer
+__global__ void k_clear_update_bits(MapDev m, uint32_t n_slots, uint32_t need, uint32_t bits) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint32_t f = m.blk_flags[s];
+  if ((f & need) && (f & bits)) m.blk_flags[s] = f & ~bits;
+}
+__global__ void k_reset_tsdf_flags(MapDev m, uint32_t n_slots) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  m.blk_flags[s] &= (kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+}
+
+}  // namespace
+

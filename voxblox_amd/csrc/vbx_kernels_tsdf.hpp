@@ -1,0 +1,512 @@
+// vbx_kernels_tsdf.hpp — ray tables, the generic ray march, the ordered per-voxel fold and Merged's bundling
+// Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
+
+namespace {
+// ---------------------------------------------------------------------------
+// kernels: ray table construction
+// ---------------------------------------------------------------------------
+// isPointValid (tsdf_integrator.h:112-129) + T_G_C * point_C + getVoxelWeight
+// (tsdf_integrator.cc:231-240); one thread per input point, rows written at the point's
+// position in the reference's visiting order (MixedThreadSafeIndex).
+__device__ inline bool point_valid(const CastCfg& c, f3 pc, bool freespace, bool* clearing) {
+  const float r = f3_norm(pc);
+  if (r < c.min_ray_length_m) return false;
+  if (r > c.max_ray_length_m) {
+    if (c.allow_clear || freespace) {
+      *clearing = true;
+      return true;
+    }
+    return false;
+  }
+  *clearing = freespace;
+  return true;
+}
+__device__ inline float voxel_weight(const CastCfg& c, f3 pc) {
+  if (c.use_const_weight) return 1.0f;
+  const float dz = fabsf(pc.z);
+  if (dz > 1e-6f) return 1.0f / (dz * dz);
+  return 0.0f;
+}
+
+// SortedThreadSafeIndex (integrator_utils.cc:24-37): visiting order = ascending squared norm.
+// key = float bits of point_C.squaredNorm() (non-negative, so they order like the floats) with
+// the point index below it: a stable order where the reference's std::sort leaves ties
+// unspecified.
+__global__ void k_sorted_keys(const float* __restrict__ pts, size_t n, uint64_t* keys) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+  keys[p] = ((uint64_t)__float_as_uint(f3_sqnorm(pc)) << 32) | (uint64_t)p;
+}
+__global__ void k_sorted_inverse(const uint64_t* __restrict__ keys, size_t n, uint32_t* s_of_p) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  s_of_p[(uint32_t)(keys[s] & 0xFFFFFFFFu)] = (uint32_t)s;
+}
+
+__global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __restrict__ rgba,
+                              size_t n, Pose T, CastCfg c, int freespace, RayTab tab,
+                              float* pcx, float* pcy, float* pcz, const uint32_t* __restrict__ s_of_p) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t s = s_of_p ? (size_t)s_of_p[p] : mixed_index_inverse(p, n);
+  const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+  bool clearing = false;
+  const bool valid = point_valid(c, pc, freespace != 0, &clearing);
+  const f3 pg = pose_transform(T, pc);
+  tab.px[s] = pg.x;
+  tab.py[s] = pg.y;
+  tab.pz[s] = pg.z;
+  tab.rgba[s] = rgba[p];
+  tab.w[s] = voxel_weight(c, pc);
+  tab.flags[s] = (valid ? 1 : 0) | (clearing ? 2 : 0);
+  if (pcx) {  // Merged keeps point_C for the bundle mean
+    pcx[s] = pc.x;
+    pcy[s] = pc.y;
+    pcz[s] = pc.z;
+  }
+}
+
+// number of rows with the cast flag set (one atomic per workgroup)
+__global__ void k_count_cast(const uint8_t* __restrict__ flags, uint32_t n, DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = __syncthreads_count(i < n && (flags[i] & 1));
+  if (threadIdx.x == 0 && c) atomicAdd(&st->rays_cast, (unsigned long long)c);
+}
+
+// ---------------------------------------------------------------------------
+// kernels: generic ray march over a ray table
+// ---------------------------------------------------------------------------
+__device__ inline bool ray_init(RayCaster& rc, const RayTab& tab, uint32_t o, const CastCfg& c,
+                                const MapDev& m, bool from_origin, f3* pg_out) {
+  const uint8_t fl = tab.flags[o];
+  if (!(fl & 1)) return false;
+  const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+  rc.init(c.origin, pg, (fl & 2) != 0, c.carving != 0, c.max_ray_length_m, m.voxel_size_inv,
+          c.trunc, from_origin);
+  if (pg_out) *pg_out = pg;
+  return true;
+}
+
+// cnt[o] = number of voxel indices the ray emits (ray_length_in_steps_ + 1), or `limit[o]`.
+__global__ void k_ray_count(RayTab tab, CastCfg c, MapDev m, int from_origin,
+                            const uint32_t* __restrict__ limit, uint32_t* cnt) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o > tab.R) return;
+  if (o == tab.R) {
+    cnt[o] = 0;
+    return;
+  }
+  RayCaster rc;
+  uint32_t n = 0;
+  if (ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) {
+    n = (rc.cur == 0) ? rc.steps + 1 : 0;
+    if (limit) n = min(n, limit[o]);
+  }
+  cnt[o] = n;
+}
+
+// Walks every ray and makes sure each block it crosses has a pool slot
+// (allocateStorageAndGetVoxelPtr's block part, tsdf_integrator.cc:97-126).
+__global__ void k_ray_mark_blocks(RayTab tab, CastCfg c, MapDev m, int from_origin,
+                                  const uint32_t* __restrict__ limit, uint32_t* new_list,
+                                  DevState* st) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= tab.R) return;
+  RayCaster rc;
+  if (!ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) return;
+  if (rc.cur != 0) return;
+  const uint32_t n = min(limit ? limit[o] : 0xFFFFFFFFu, rc.steps + 1);
+  BlockWalk bw;
+  bw.start(rc, m.vps, m.vps_inv);
+  for (uint32_t k = 0; k < n; ++k) {
+    if (bw.entered) map_insert_key(m, pack_block_key(bw.bx, bw.by, bw.bz), new_list, st);
+    bw.step(m.vps, m.vps_log2);
+  }
+}
+
+// The ray march proper: every visited voxel becomes one 64-bit key
+//   (pool_slot * nvox + linear_index) << 32 | order
+// written at off[o] + k.  Blocks touched are published and get all Update bits
+// (tsdf_integrator.cc:128).  Merged's anti-grazing test (:415-422) is a binary search in
+// the sorted bundle keys.  The walk is BlockWalk (branch-free steps, no int64 index math).
+__global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
+                           const uint32_t* __restrict__ limit, const uint32_t* __restrict__ off,
+                           uint64_t* keys, const uint64_t* __restrict__ graze_keys,
+                           uint32_t n_graze, DevState* st) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= tab.R) return;
+  RayCaster rc;
+  if (!ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) return;
+  if (rc.cur != 0) return;
+  const uint32_t n = min(limit ? limit[o] : 0xFFFFFFFFu, rc.steps + 1);
+  const bool clearing = (tab.flags[o] & 2) != 0;
+  BlockWalk bw;
+  bw.start(rc, m.vps, m.vps_inv);
+  bool need_lookup = false;
+  uint32_t slot = kInvalidSlot;
+  const uint32_t base = off[o];
+  const uint32_t lmask = (uint32_t)m.vps - 1u;
+  for (uint32_t k = 0; k < n; ++k) {
+    uint64_t out = ~0ull;  // sorts last, skipped by the fold
+    need_lookup = need_lookup || bw.entered;
+    bool skip = false;
+    if (graze_keys) {
+      // voxel_map.find(global_voxel_idx) != end && (clearing || idx != kv.first)
+      const long long gx = (long long)bw.bx * m.vps + (long long)(bw.lin & lmask);
+      const long long gy = (long long)bw.by * m.vps + (long long)((bw.lin >> m.vps_log2) & lmask);
+      const long long gz = (long long)bw.bz * m.vps + (long long)((bw.lin >> (2 * m.vps_log2)) & lmask);
+      const uint64_t vk = ((uint64_t)(gz + (1ll << 20)) << 42) | ((uint64_t)(gy + (1ll << 20)) << 21) |
+                          (uint64_t)(gx + (1ll << 20));
+      if (clearing || vk != tab.bkey[o]) {
+        uint32_t lo = 0, hi = n_graze;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (graze_keys[mid] < vk) lo = mid + 1; else hi = mid;
+        }
+        skip = (lo < n_graze && graze_keys[lo] == vk);
+      }
+    }
+    if (!skip) {
+      if (need_lookup) {
+        need_lookup = false;
+        slot = map_find(m, pack_block_key(bw.bx, bw.by, bw.bz));
+        if (slot == kInvalidSlot) {
+          atomicOr(&st->error, 2u);
+        } else {
+          publish_block(m, slot, st);
+        }
+      }
+      if (slot != kInvalidSlot) out = ((uint64_t)(slot * m.nvox + bw.lin) << 32) | o;
+    }
+    keys[base + k] = out;
+    bw.step(m.vps, m.vps_log2);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernel: ordered per-voxel fold == updateTsdfVoxel (tsdf_integrator.cc:150-209) applied to
+// each voxel's updates in ascending integration order.  One thread per segment head.
+// ---------------------------------------------------------------------------
+__device__ inline void tsdf_update(const CastCfg& c, float voxel_size, f3 pg, l3 g,
+                                   uint32_t color, float weight, float& d, float& W,
+                                   uint32_t& col) {
+  const f3 center = center_point_from_grid_index(g, voxel_size);
+  // computeDistance, tsdf_integrator.cc:216-228
+  const f3 a = f3_sub(center, c.origin);
+  const f3 b = f3_sub(pg, c.origin);
+  const float dist_G = f3_norm(b);
+  const float dist_G_V = f3_dot(a, b) / dist_G;
+  const float sdf = dist_G - dist_G_V;
+
+  float uw = weight;
+  const float eps = voxel_size;
+  if (c.dropoff && sdf < -eps) {
+    uw = weight * (c.trunc + sdf) / (c.trunc - eps);
+    uw = std_max(uw, 0.0f);
+  }
+  if (c.sparsity) {
+    if (fabsf(sdf) < c.trunc) uw *= c.sparsity_factor;
+  }
+  const float nw = W + uw;
+  if (nw < 1e-6f) return;
+  const float nsdf = (sdf * uw + d * W) / nw;
+  if (fabsf(sdf) < c.trunc) col = blend_two_colors(col, W, color, uw);
+  d = (nsdf > 0.0f) ? std_min(c.trunc, nsdf) : std_max(-c.trunc, nsdf);
+  W = std_min(c.max_weight, nw);
+}
+
+// Everything of updateTsdfVoxel that does not depend on the voxel's state (tsdf_integrator.cc:
+// 157-183): the projective sdf and the (drop-off / sparsity adjusted) weight of one update.
+__device__ inline void tsdf_update_inputs(const CastCfg& c, float voxel_size, f3 pg, l3 g, float weight,
+                                          float* sdf_out, float* uw_out) {
+  const f3 center = center_point_from_grid_index(g, voxel_size);
+  const f3 a = f3_sub(center, c.origin);
+  const f3 b = f3_sub(pg, c.origin);
+  const float dist_G = f3_norm(b);
+  const float dist_G_V = f3_dot(a, b) / dist_G;
+  const float sdf = dist_G - dist_G_V;
+  float uw = weight;
+  const float eps = voxel_size;
+  if (c.dropoff && sdf < -eps) {
+    uw = weight * (c.trunc + sdf) / (c.trunc - eps);
+    uw = std_max(uw, 0.0f);
+  }
+  if (c.sparsity) {
+    if (fabsf(sdf) < c.trunc) uw *= c.sparsity_factor;
+  }
+  *sdf_out = sdf;
+  *uw_out = uw;
+}
+// The state-dependent rest (tsdf_integrator.cc:188-208).
+__device__ inline void tsdf_update_state(const CastCfg& c, float sdf, float uw, uint32_t color, float& d,
+                                         float& W, uint32_t& col) {
+  const float nw = W + uw;
+  if (nw < 1e-6f) return;
+  const float nsdf = (sdf * uw + d * W) / nw;
+  if (fabsf(sdf) < c.trunc) col = blend_two_colors(col, W, color, uw);
+  d = (nsdf > 0.0f) ? std_min(c.trunc, nsdf) : std_max(-c.trunc, nsdf);
+  W = std_min(c.max_weight, nw);
+}
+
+constexpr uint32_t kFoldShort = 48;  // longer runs go to the wave-cooperative kernel
+
+__device__ inline l3 voxel_of_gid(const MapDev& m, uint32_t gid) {
+  const uint32_t slot = gid / m.nvox;
+  const uint32_t lin = gid - slot * m.nvox;
+  const int lx = lin & (m.vps - 1);
+  const int ly = (lin >> m.vps_log2) & (m.vps - 1);
+  const int lz = lin >> (2 * m.vps_log2);
+  return {(long long)m.blk_idx[3 * slot] * m.vps + lx, (long long)m.blk_idx[3 * slot + 1] * m.vps + ly,
+          (long long)m.blk_idx[3 * slot + 2] * m.vps + lz};
+}
+
+__global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
+                       MapDev m, uint32_t* long_list, DevState* st) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t key = (i < n) ? keys[i] : ~0ull;
+  const uint32_t gid = (uint32_t)(key >> 32);
+  const bool head = (key != ~0ull) && !(i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid);
+  const int nheads = __syncthreads_count(head);
+  if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched, (unsigned long long)nheads);
+  if (!head) return;  // only segment heads fold
+
+  // a long run (the keys of a voxel are contiguous, so one look ahead tells): hand it to
+  // k_fold_long untouched
+  if (i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid) {
+    const uint32_t o = atomicAdd(&st->fold_long_count, 1u);
+    long_list[o] = (uint32_t)i;
+    return;
+  }
+  const l3 g = voxel_of_gid(m, gid);
+  float d = m.dist[gid];
+  float W = m.weight[gid];
+  uint32_t col = m.rgba[gid];
+  size_t j = i;
+  uint64_t kj = key;
+  while (true) {
+    const uint32_t o = (uint32_t)(kj & 0xFFFFFFFFu);
+    const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+    tsdf_update(c, m.voxel_size, pg, g, tab.rgba[o], tab.w[o], d, W, col);
+    ++j;
+    if (j >= n) break;
+    kj = keys[j];
+    if ((uint32_t)(kj >> 32) != gid) break;
+  }
+  m.dist[gid] = d;
+  m.weight[gid] = W;
+  m.rgba[gid] = col;
+}
+
+// Long runs (the voxels around the sensor origin collect one update per ray): one wave per run,
+// 64 updates per step.  The state-independent part of the 64 updates (sdf, weight) is computed
+// in parallel; the ordered fold over them is then done by the cheapest exact method:
+//   1. every update is a no-op on the current state (saturated free-space voxel)  -> skip;
+//   2. the distance provably stays where it is (clamped at +-trunc) and no colour changes:
+//      only the weight chain W <- min(max_weight, W + w) is evaluated in order, then all 64
+//      distance updates are verified in parallel against their own W;
+//   3. otherwise the 64 updates are applied in order (operands broadcast lane by lane).
+// All three produce exactly the sequential result of updateTsdfVoxel.
+__global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ keys, size_t n, RayTab tab,
+                                                   CastCfg c, MapDev m, const uint32_t* __restrict__ long_list,
+                                                   DevState* st) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_long = st->fold_long_count;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; seg < n_long; seg += n_waves) {
+    const size_t i0 = long_list[seg];
+    const uint32_t gid = (uint32_t)(keys[i0] >> 32);
+    const l3 g = voxel_of_gid(m, gid);
+    float d = m.dist[gid];
+    float W = m.weight[gid];
+    uint32_t col = m.rgba[gid];
+    // kU chunks of 64 updates are fetched together (the gathers of px/py/pz/w/rgba by ray index
+    // cost ~2 us of latency per chunk when issued one chunk at a time, and a run of 300k updates
+    // on the sensor's own voxel is 4800 chunks), then folded chunk by chunk in order.
+    constexpr int kU = 4;
+    bool more = true;
+    for (size_t base = i0; more; base += 64 * kU) {
+      float sdf_u[kU], uw_u[kU];
+      uint32_t color_u[kU];
+      int cnt_u[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const size_t i = base + 64 * u + lane;
+        const uint64_t key = (i < n) ? keys[i] : ~0ull;
+        const bool mine = (key != ~0ull) && ((uint32_t)(key >> 32) == gid);
+        const unsigned long long V = __ballot(mine);
+        // keys of one voxel are contiguous: the valid lanes are a prefix
+        cnt_u[u] = (V == ~0ull) ? 64 : (__ffsll((long long)~V) - 1);
+        sdf_u[u] = 0.f; uw_u[u] = 0.f; color_u[u] = 0;
+        if (lane < cnt_u[u]) {
+          const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
+          const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+          tsdf_update_inputs(c, m.voxel_size, pg, g, tab.w[o], &sdf_u[u], &uw_u[u]);
+          color_u[u] = tab.rgba[o];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int cnt = cnt_u[u];
+        if (cnt == 0) { more = false; break; }
+        const float sdf = sdf_u[u], uw = uw_u[u];
+        const uint32_t color = color_u[u];
+        const bool inband = fabsf(sdf) < c.trunc;
+        // 1. identity test against the current state
+        bool same = true;
+        if (lane < cnt) {
+          float d1 = d, W1 = W;
+          uint32_t c1 = col;
+          tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
+          same = (__float_as_uint(d1) == __float_as_uint(d)) && (__float_as_uint(W1) == __float_as_uint(W)) && (c1 == col);
+        }
+        if (!__all(same)) {
+          // 2. weight chain + parallel verification that d does not move
+          bool done = false;
+          if (!__any(lane < cnt && inband)) {
+            // the chain itself: operands come out of the lanes with v_readlane (constant lane
+            // index, fully unrolled) — a ds_bpermute per element made this loop the whole cost
+            // of the fold (~2.7 us per 64 updates)
+            float Wrun = W, Wmine = W;
+            if (cnt == 64 && W >= 1e-6f && __all(uw >= 0.0f)) {
+              // full chunk, weights only grow: the `new_weight < kFloatEpsilon` exit of
+              // updateTsdfVoxel (tsdf_integrator.cc:183-186) cannot trigger, so the chain is two
+              // dependent VALU ops per update with no branches
+#pragma unroll
+              for (int j = 0; j < 64; ++j) {
+                const float uwj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+                Wmine = (lane == j) ? Wrun : Wmine;
+                Wrun = std_min(c.max_weight, Wrun + uwj);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 64; ++j) {
+                if (j < cnt) {
+                  const float uwj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+                  if (lane == j) Wmine = Wrun;
+                  const float nw = Wrun + uwj;
+                  if (!(nw < 1e-6f)) Wrun = std_min(c.max_weight, nw);
+                }
+              }
+            }
+            bool ok = true;
+            if (lane < cnt) {
+              float d1 = d, W1 = Wmine;
+              uint32_t c1 = col;
+              tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
+              ok = (__float_as_uint(d1) == __float_as_uint(d));
+            }
+            if (__all(ok)) {
+              W = Wrun;
+              done = true;
+            }
+          }
+          // 3. generic ordered application
+          if (!done) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+              if (j < cnt) {
+                const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), j));
+                const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)color, j);
+                tsdf_update_state(c, sj, wj, cj, d, W, col);
+              }
+            }
+          }
+        }
+        if (cnt < 64) { more = false; break; }
+      }
+    }
+    if (lane == 0) {
+      m.dist[gid] = d;
+      m.weight[gid] = W;
+      m.rgba[gid] = col;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernels: Merged integrator bundling (tsdf_integrator.cc:340-407)
+// ---------------------------------------------------------------------------
+// key[s] = clearing << 63 | packed endpoint voxel index; invalid points sort last.
+__global__ void k_merged_keys(RayTab pt, uint32_t n, MapDev m, uint64_t* keys, uint32_t* vals) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint8_t fl = pt.flags[s];
+  uint64_t key = ~0ull;
+  if (fl & 1) {
+    const l3 g = grid_index_from_point({pt.px[s], pt.py[s], pt.pz[s]}, m.voxel_size_inv);
+    key = ((uint64_t)(g.z + (1ll << 20)) << 42) | ((uint64_t)(g.y + (1ll << 20)) << 21) |
+          (uint64_t)(g.x + (1ll << 20));
+    if (fl & 2) key |= 1ull << 63;
+  }
+  keys[s] = key;
+  vals[s] = s;
+}
+
+// head[i] = 1 where a new bundle starts in the sorted (key, s) list.
+__global__ void k_merged_heads(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* head) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    head[i] = 0;
+    return;
+  }
+  const uint64_t k = keys[i];
+  head[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+// One thread per bundle: running weighted mean of point_C, blended colour, summed weight in
+// push_back (= visiting) order; clearing bundles take their first usable point only
+// (tsdf_integrator.cc:387-405); merged_point_G = T_G_C * merged_point_C (:407).
+__global__ void k_merged_bundle(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank,
+                                uint32_t n, RayTab pt, const float* __restrict__ pcx,
+                                const float* __restrict__ pcy, const float* __restrict__ pcz,
+                                Pose T, RayTab out, uint64_t* graze_keys, const uint32_t* __restrict__ perm,
+                                DevState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const uint64_t key = keys[i];
+  const bool clearing = (key >> 63) != 0;
+  const uint32_t br = rank[i];                    // rank in ascending key order
+  const uint32_t b = perm ? perm[br] : br;        // row = position in the visiting order of the bundles
+  f3 mp{0.f, 0.f, 0.f};
+  uint32_t mc = 0;
+  float mw = 0.0f;
+  for (uint32_t j = i; j < n && keys[j] == key; ++j) {
+    const uint32_t s = vals[j];
+    const float pw = pt.w[s];
+    if (pw < 1e-6f) continue;
+    const f3 pc{pcx[s], pcy[s], pcz[s]};
+    const float tw = mw + pw;
+    mp = {(mp.x * mw + pc.x * pw) / tw, (mp.y * mw + pc.y * pw) / tw, (mp.z * mw + pc.z * pw) / tw};
+    mc = blend_two_colors(mc, mw, pt.rgba[s], pw);
+    mw += pw;
+    if (clearing) break;
+  }
+  const f3 pg = pose_transform(T, mp);
+  out.px[b] = pg.x;
+  out.py[b] = pg.y;
+  out.pz[b] = pg.z;
+  out.rgba[b] = mc;
+  out.w[b] = mw;
+  out.flags[b] = 1 | (clearing ? 2 : 0);
+  out.bkey[b] = key & ~(1ull << 63);
+  if (!clearing && graze_keys) graze_keys[br] = key;  // stays sorted: binary-searched by the march
+  (void)st;
+}
+
+// Per bundle (ascending key rank): its key and the visiting position of its first point — the
+// order in which bundleRays inserts the keys into its unordered_map.
+__global__ void k_merged_collect(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                 const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank, uint32_t n,
+                                 uint64_t* bkeys, uint32_t* first_s) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  bkeys[rank[i]] = keys[i];
+  first_s[rank[i]] = vals[i];
+}
+
+}  // namespace
+
