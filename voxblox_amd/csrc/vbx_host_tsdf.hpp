@@ -478,8 +478,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       rc = sync_state(ctx, poff + R, &P);  // also carries `changed` of the previous round
       if (rc) return rc;
       if (getenv("VBX_DEBUG") && rounds > 0)
-        fprintf(stderr, "[vbx] strict round %u: %u probes, %u rays moved (%u grew)\n", rounds, P, ctx->h_state.act_count[0],
-                ctx->h_state.act_count[1]);
+        fprintf(stderr, "[vbx] strict round %u: %u probes, %u rays moved (%u grew), lowest moved ray %u of %u\n", rounds, P,
+                ctx->h_state.act_count[0], ctx->h_state.act_count[1], ctx->h_state.act_count[2], R);
       if (rounds > 0 && !ctx->h_state.changed) break;
       if (rounds > 4096) {
         ctx->fail("Fast integrator: observed-set replay did not converge");
@@ -488,17 +488,20 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
       HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
       HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(P, 1)));
+      if (!P) HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
       if (P) {
         hipLaunchKernelGGL(k_strict_keys, grid_for(P), dim3(256), 0, s, poff, R, P, ctx->b_off.as<uint32_t>(),
-                           ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>());
+                           ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
         rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), P, 44, 64);
         if (rc) return rc;
         hipLaunchKernelGGL(k_strict_outcome, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
                            ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
                            ctx->b_collided.as<uint8_t>());
       }
-      HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
-      HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
+      if (getenv("VBX_DEBUG")) {
+        HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
+        HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[2], 0xFF, 4, s));
+      }
       hipLaunchKernelGGL(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(), R,
                          ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext, ctx->b_U.as<uint32_t>(),
                          getenv("VBX_DEBUG") ? 1 : 0, ctx->d_state);

@@ -391,8 +391,9 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
 // thousands of probes of one hot slot.)
 __global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t R, uint32_t P,
                               const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
-                              uint64_t* keys) {
+                              uint64_t* keys, DevState* st) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) st->changed = 0;  // this round's "some probe count moved" flag (set by k_strict_scan)
   if (p >= P) return;
   uint32_t lo = 0, hi = R;  // largest r with poff[r] <= p
   while (hi - lo > 1) {
@@ -482,6 +483,7 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
       if (debug_counts) {  // same-address atomics serialise (~90/us): only on request (VBX_DEBUG)
         atomicAdd(&st->act_count[0], 1u);              // rays whose probe count moved this round
         if (!broke) atomicAdd(&st->act_count[1], 1u);  // of which: guesses that had to grow
+        atomicMin(&st->act_count[2], r);               // lowest ray index that moved
       }
     }
   }
