@@ -107,7 +107,6 @@ struct MapDev {  // by-value kernel argument
 };
 
 struct CastCfg {  // by-value kernel argument: TsdfIntegratorBase::Config + derived constants
-  int exp;  // TEMP experiment switch
   f3 origin;
   float trunc;
   float max_ray_length_m;

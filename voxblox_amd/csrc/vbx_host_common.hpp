@@ -134,7 +134,6 @@ CastCfg make_cast_cfg(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float pos[3])
   c.origin = {pos[0], pos[1], pos[2]};
   c.trunc = cfg->default_truncation_distance;
   c.max_ray_length_m = cfg->max_ray_length_m;
-  c.exp = getenv("VBX_EXP") ? atoi(getenv("VBX_EXP")) : 0;
   c.min_ray_length_m = cfg->min_ray_length_m;
   c.max_weight = cfg->max_weight;
   c.sparsity_factor = cfg->sparsity_compensation_factor;

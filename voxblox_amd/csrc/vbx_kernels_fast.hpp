@@ -164,7 +164,7 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
       }
       // (b) the lookups, rank by rank: all lanes issue their t-th lookup together
       for (int t = 0; __any(t < nt); ++t)
-        if (t < nt) tkeys[t] = (c.exp & 1) ? 0ull : (uint64_t)lookup(tkeys[t]);
+        if (t < nt) tkeys[t] = (uint64_t)lookup(tkeys[t]);
       // (c) entries -> global voxel ids
       for (int j = 0; j < 16; ++j) {
         const uint32_t e = (lane < RPW) ? s_buf[wv][lane][j] : 0xFFFFFFFFu;
@@ -183,7 +183,7 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
         const int src = q * 4 + sub;  // lane whose ray is being written
         const uint32_t sbase = __shfl(base, src);
         const uint32_t slen = __shfl(len, src);
-        if (k0 + e < slen && !(c.exp & 2)) vox[sbase + k0 + e] = s_buf[wv][src][e];
+        if (k0 + e < slen) vox[sbase + k0 + e] = s_buf[wv][src][e];
       }
     }
     if (redo) redo_out[atomicAdd(&st->redo_count, 1u)] = r;
