@@ -235,6 +235,11 @@ typedef struct vbx_counters {
 } vbx_counters;
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
 
+/* Self-test hook (no reference counterpart): checks the library's stable radix sort — the primitive
+ * under the start-voxel replay, the observed-set replay and the ordered fold — against
+ * std::stable_sort on n pseudo-random keys, bit field [begin_bit, end_bit). */
+int vbx_selftest_sort(vbx_ctx* ctx, uint32_t n, uint32_t begin_bit, uint32_t end_bit, uint32_t seed, int with_vals);
+
 /* HIP-event timing of the last integrate / esdf call on the handle's stream, in ms. */
 typedef struct vbx_timing {
   float total_ms;

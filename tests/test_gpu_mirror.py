@@ -114,3 +114,18 @@ def test_block_upload_round_trip_both_layers():
     dst.block_upload(idx[0], z, 0, 0, capi.LAYER_ESDF)
     assert dst.block_download(idx[0], capi.LAYER_ESDF)[0].tobytes() == z.tobytes()
     assert dst.block_download(idx[0], capi.LAYER_TSDF)[0].tobytes() == tv[0].tobytes()
+
+
+def test_stable_radix_sort_selftest():
+    """The hand-written stable LSD radix sort (csrc/vbx_sort.hpp) against std::stable_sort: sizes
+    around the tile boundaries, every field width class (1..12 bits per pass, 1-6 passes), keys
+    only and key/value pairs, random keys and keys with long runs of equal fields."""
+    from voxblox_amd import capi
+    gm = capi.Map(0.1, 16, max_blocks=64)
+    cases = [(0, 32, 52), (1, 32, 52), (63, 0, 64), (64, 44, 64), (2047, 32, 53), (2048, 32, 56), (2049, 32, 57),
+             (100_000, 44, 64), (307_200, 32, 53), (1_000_003, 44, 64), (400_000, 32, 56), (50_000, 0, 64),
+             (70_000, 7, 8), (70_000, 13, 26), (70_000, 20, 20)]
+    for n, b, e in cases:
+        for seed in (2, 3):
+            gm.selftest_sort(n, b, e, seed, with_vals=True)
+            gm.selftest_sort(n, b, e, seed + 10, with_vals=False)

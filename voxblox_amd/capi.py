@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
-    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_enable_timing", "vbx_get_timing")
+    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_enable_timing", "vbx_get_timing")
 
 
 class MapCfg(C.Structure):
@@ -109,6 +109,7 @@ def lib():
         "vbx_esdf_add_new_robot_position": (C.c_int, [vp, C.POINTER(EsdfCfg), f32p]),
         "vbx_esdf_update_blocks": (C.c_int, [vp, C.POINTER(EsdfCfg), i32p, C.c_size_t, C.c_int]),
         "vbx_esdf_integrator_clear": (C.c_int, [vp]),
+        "vbx_selftest_sort": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
         "vbx_num_blocks": (C.c_int, [vp, C.c_int, szp]),
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),
@@ -351,6 +352,9 @@ class Map:
         self._chk(self.L.vbx_blocks_merge_sums(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.shape[0],
                                                C.c_void_p(d_sums_ptr), int(apply_caps), float(truncation),
                                                float(max_weight)))
+
+    def selftest_sort(self, n, begin_bit, end_bit, seed=0, with_vals=True):
+        self._chk(self.L.vbx_selftest_sort(self.h, int(n), int(begin_bit), int(end_bit), int(seed), int(with_vals)))
 
     def counters(self):
         c = Counters()

@@ -47,6 +47,7 @@ using namespace vbx;
 #include "vbx_kernels_fast.hpp"
 #include "vbx_kernels_esdf.hpp"
 #include "vbx_ctx.hpp"
+#include "vbx_sort.hpp"
 #include "vbx_host_common.hpp"
 #include "vbx_host_tsdf.hpp"
 #include "vbx_host_esdf.hpp"
@@ -191,7 +192,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_hist0, &ctx->b_hist1, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive};
   for (DBuf* b : bufs) b->release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
@@ -788,6 +789,50 @@ int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n
   rc = sync_state(ctx);
   if (rc) return rc;
   return check_state_error(ctx);
+}
+
+// Self-test hook of the hand-written stable radix sort (vbx_sort.hpp): n pseudo-random keys,
+// sorted on bits [begin_bit, end_bit) on the device, compared with std::stable_sort on the host.
+int vbx_selftest_sort(vbx_ctx* ctx, uint32_t n, uint32_t begin_bit, uint32_t end_bit, uint32_t seed, int with_vals) {
+  if (!ctx || begin_bit > end_bit || end_bit > 64) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<uint64_t> keys(n), ref(n), got(n);
+  std::vector<uint32_t> vals(n), gotv(n), idx(n);
+  uint64_t x = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed << 17) ^ n;
+  const bool narrow = (seed & 1u) != 0;  // odd seeds: few distinct field values -> long equal runs
+  for (uint32_t i = 0; i < n; ++i) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    keys[i] = narrow ? (x & ~(0xFFFFFFF0ull << (begin_bit < 60 ? begin_bit : 60))) : x;
+    vals[i] = i;
+    idx[i] = i;
+  }
+  const unsigned bits = end_bit - begin_bit;
+  const uint64_t fmask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+  auto field = [&](uint64_t k) { return bits ? ((k >> begin_bit) & fmask) : 0ull; };
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return field(keys[a]) < field(keys[b]); });
+  HIP_TRY(ctx->b_keys0.ensure(std::max<size_t>(n, 1) * 8));
+  HIP_TRY(ctx->b_vals0.ensure(std::max<size_t>(n, 1) * 4));
+  HIP_TRY(ctx->b_keys1.ensure(std::max<size_t>(n, 1) * 8));
+  HIP_TRY(ctx->b_vals1.ensure(std::max<size_t>(n, 1) * 4));
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(ctx->b_keys0.p, keys.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->b_vals0.p, vals.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int rc = stable_sort01(ctx, n, begin_bit, end_bit, with_vals != 0);
+  if (rc) return rc;
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(got.data(), ctx->b_keys1.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (with_vals) HIP_TRY(hipMemcpyAsync(gotv.data(), ctx->b_vals1.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (uint32_t i = 0; i < n; ++i) {
+    if (got[i] != keys[idx[i]] || (with_vals && gotv[i] != idx[i])) {
+      ctx->fail("stable sort self-test: position %u holds key %llx (value %u), expected key %llx (value %u)", i,
+                (unsigned long long)got[i], with_vals ? gotv[i] : 0u, (unsigned long long)keys[idx[i]], idx[i]);
+      return VBX_ERR_HIP;
+    }
+  }
+  return VBX_OK;
 }
 
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out) {

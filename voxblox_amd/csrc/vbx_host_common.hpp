@@ -116,6 +116,90 @@ int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
   return VBX_OK;
 }
 
+// Stable sort of ctx->b_keys0 (and b_vals0 when with_vals) on key bits [begin_bit, end_bit); the
+// result is left in b_keys1 / b_vals1 (the DBuf handles are swapped when an even number of
+// passes ends in the input buffers, so callers must fetch the pointers after the call).
+// See vbx_sort.hpp.
+template <int CAP>
+int rsort_pass(vbx_ctx* ctx, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n,
+               int shift, uint32_t nwg, bool with_vals) {
+  hipStream_t s = ctx->stream;
+  uint32_t* hist = ctx->b_hist0.as<uint32_t>();
+  uint32_t* gofs = ctx->b_hist1.as<uint32_t>();
+  hipLaunchKernelGGL(k_rsort_count<CAP>, dim3(nwg), dim3(kSortThreads), 0, s, kin, n, shift, hist, nwg);
+  int rc = exclusive_scan_u32(ctx, hist, gofs, (size_t)(1u << CAP) * nwg);
+  if (rc) return rc;
+  if (with_vals)
+    hipLaunchKernelGGL((k_rsort_scatter<CAP, true>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n, shift,
+                       gofs, nwg);
+  else
+    hipLaunchKernelGGL((k_rsort_scatter<CAP, false>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n,
+                       shift, gofs, nwg);
+  return VBX_OK;
+}
+int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit, bool with_vals) {
+  if (n64 == 0 || end_bit <= begin_bit) {
+    // nothing to order: the "sorted" data is the input
+    std::swap(ctx->b_keys0, ctx->b_keys1);
+    if (with_vals) std::swap(ctx->b_vals0, ctx->b_vals1);
+    return VBX_OK;
+  }
+  if (n64 > (4u << 20)) {
+    // tens of millions of keys (the Simple integrator): bandwidth matters there, not launch
+    // count, and rocPRIM's onesweep with 8-bit digits at full occupancy is the faster sort
+    HIP_TRY(ctx->b_keys1.ensure(n64 * 8));
+    if (with_vals) {
+      HIP_TRY(ctx->b_vals1.ensure(n64 * 4));
+      return sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), ctx->b_vals0.as<uint32_t>(),
+                        ctx->b_vals1.as<uint32_t>(), n64, begin_bit, end_bit);
+    }
+    return sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), n64, begin_bit, end_bit);
+  }
+  const uint32_t n = (uint32_t)n64;
+  const unsigned bits = end_bit - begin_bit;
+  const unsigned passes = (bits + kSortMaxBits - 1) / kSortMaxBits;
+  const unsigned per = (bits + passes - 1) / passes;  // digit width, <= 12
+  const uint32_t nwg = (n + kSortTile - 1) / kSortTile;
+  // the kernels are instantiated for every digit width 1..12, so a pass never looks at bits
+  // outside [begin_bit, end_bit)
+  HIP_TRY(ctx->b_hist0.ensure(((size_t)1 << kSortMaxBits) * nwg * 4));
+  HIP_TRY(ctx->b_hist1.ensure(((size_t)1 << kSortMaxBits) * nwg * 4));
+  HIP_TRY(ctx->b_keys1.ensure((size_t)n * 8));
+  if (with_vals) HIP_TRY(ctx->b_vals1.ensure((size_t)n * 4));
+  bool in0 = true;  // where the current input lives
+  unsigned shift = begin_bit;
+  while (shift < end_bit) {
+    const unsigned w = std::min(per, end_bit - shift);
+    const uint64_t* kin = (in0 ? ctx->b_keys0 : ctx->b_keys1).as<uint64_t>();
+    uint64_t* kout = (in0 ? ctx->b_keys1 : ctx->b_keys0).as<uint64_t>();
+    const uint32_t* vin = with_vals ? (in0 ? ctx->b_vals0 : ctx->b_vals1).as<uint32_t>() : nullptr;
+    uint32_t* vout = with_vals ? (in0 ? ctx->b_vals1 : ctx->b_vals0).as<uint32_t>() : nullptr;
+    int rc;
+    switch (w) {
+      case 1: rc = rsort_pass<1>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 2: rc = rsort_pass<2>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 3: rc = rsort_pass<3>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 4: rc = rsort_pass<4>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 5: rc = rsort_pass<5>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 6: rc = rsort_pass<6>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 7: rc = rsort_pass<7>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 8: rc = rsort_pass<8>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 9: rc = rsort_pass<9>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 10: rc = rsort_pass<10>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 11: rc = rsort_pass<11>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      default: rc = rsort_pass<12>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+    }
+    if (rc) return rc;
+    in0 = !in0;
+    shift += w;
+  }
+  if (in0) {  // an even number of passes: the result is in the "0" buffers
+    std::swap(ctx->b_keys0, ctx->b_keys1);
+    if (with_vals) std::swap(ctx->b_vals0, ctx->b_vals1);
+  }
+  return VBX_OK;
+}
+
 inline unsigned bits_for(uint64_t v) {
   unsigned b = 1;
   while (b < 64 && (v >> b)) ++b;

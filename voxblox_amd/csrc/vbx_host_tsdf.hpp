@@ -11,7 +11,7 @@ int visiting_order(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float* d_pts, si
   HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_order.ensure(n * 4));
   hipLaunchKernelGGL(k_sorted_keys, grid_for(n), dim3(256), 0, ctx->stream, d_pts, n, ctx->b_keys0.as<uint64_t>());
-  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), n, 0, 64);
+  int rc = stable_sort01(ctx, n, 0, 64, false);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sorted_inverse, grid_for(n), dim3(256), 0, ctx->stream, ctx->b_keys1.as<uint64_t>(), n,
                      ctx->b_order.as<uint32_t>());
@@ -28,8 +28,7 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   const unsigned end_bit = 32 + bits_for((uint64_t)std::max<uint32_t>(ctx->h_state.pool_used, 1) * m.nvox);
   // keys are emitted ray by ray in visiting order, so a stable sort on the voxel field alone
   // leaves every voxel's updates in visiting order (invalid keys, all ones, go last)
-  int rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), total, 32,
-                     std::min(64u, end_bit + 1));
+  int rc = stable_sort01(ctx, total, 32, std::min(64u, end_bit + 1), false);
   if (rc) return rc;
   tmark(ctx, 5);
   // long runs are collected by k_fold and folded wave-cooperatively afterwards (their number is
@@ -190,8 +189,7 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
   hipLaunchKernelGGL(k_merged_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, ctx->map,
                      ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
-  rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(),
-                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 0, 64);
+  rc = stable_sort01(ctx, n, 0, 64, true);
   if (rc) return rc;
   HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
   hipLaunchKernelGGL(k_merged_heads, grid_for(n + 1), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
@@ -270,8 +268,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                      ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
   // keys[s] = slot << 32 | s is written in visiting order: a stable sort on the 20 slot bits
   // (+ bit 52, set only in the all-ones key of dropped points) orders by (slot, s)
-  rc = sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(),
-                  ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n, 32, 53);
+  rc = stable_sort01(ctx, n, 32, 53, true);
   if (rc) return rc;
   hipLaunchKernelGGL(k_fast_start_dedupe, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
@@ -492,7 +489,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       if (P) {
         hipLaunchKernelGGL(k_strict_keys, grid_for(P), dim3(256), 0, s, poff, R, P, ctx->b_off.as<uint32_t>(),
                            ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
-        rc = sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), P, 44, 64);
+        rc = stable_sort01(ctx, P, 44, 64, false);
         if (rc) return rc;
         hipLaunchKernelGGL(k_strict_outcome, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
                            ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
