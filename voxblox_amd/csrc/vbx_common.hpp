@@ -83,7 +83,7 @@ struct DevState {
 // + interrupt-driven wait), and a Fast frame needs five of them.
 struct StateMirror {
   DevState st;
-  uint32_t extra;
+  uint32_t extra[3];
   uint32_t seq;
 };
 

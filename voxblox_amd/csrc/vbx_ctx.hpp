@@ -26,7 +26,7 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
-  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_bkeys, b_bfirst, b_bperm, b_obsset, b_collided, b_hist0, b_hist1;
+  DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_bkeys, b_bfirst, b_bperm, b_obsset, b_collided, b_hist0, b_hist1, b_moved;
   uint32_t obs_epoch = 1;
   uint32_t fast_last_iters = 0;  // sweeps the previous Fast frame needed
   uint32_t fast_redo_grid = 0;   // rays the second list-building pass is launched for
@@ -36,6 +36,8 @@ struct vbx_ctx {
   bool start_sentinel_live = true;
   bool startset_init = false;
   std::vector<int32_t> h_by_s;  // scratch of merged_reference_order
+  std::vector<uint32_t> h_poff;  // scratch of the blocked observed-set replay
+  uint32_t h_poff_total = 0;     // probes of the current replay guess
   // voxel_observed_approx_set_ (reference semantics, fast_observed_set == 0)
   uint32_t obsset_offset = 0;
   bool obsset_sentinel_live = true;

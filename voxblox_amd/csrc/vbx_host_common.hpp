@@ -7,15 +7,17 @@ inline dim3 grid_for(size_t n, int block = 256) { return dim3((unsigned)((n + bl
 
 // Reads DevState (and optionally one more device word) back to the host; on return everything
 // queued on the stream before the call has completed.
-int sync_state(vbx_ctx* ctx, const uint32_t* d_extra = nullptr, uint32_t* extra_out = nullptr) {
+int sync_state3(vbx_ctx* ctx, const uint32_t* const d_extra[3], uint32_t extra_out[3]) {
   if (!ctx->h_mirror) {
     HIP_TRY(hipMemcpyAsync(&ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
-    if (d_extra) HIP_TRY(hipMemcpyAsync(extra_out, d_extra, 4, hipMemcpyDeviceToHost, ctx->stream));
+    for (int i = 0; i < 3; ++i)
+      if (d_extra[i]) HIP_TRY(hipMemcpyAsync(&extra_out[i], d_extra[i], 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VBX_OK;
   }
   const uint32_t seq = ++ctx->sync_seq;
-  hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, ctx->d_mirror, d_extra, seq);
+  hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, ctx->d_mirror, d_extra[0],
+                     d_extra[1], d_extra[2], seq);
   HIP_TRY(hipGetLastError());
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t spins = 0;
@@ -32,8 +34,16 @@ int sync_state(vbx_ctx* ctx, const uint32_t* d_extra = nullptr, uint32_t* extra_
     }
   }
   std::memcpy(&ctx->h_state, &ctx->h_mirror->st, sizeof(DevState));
-  if (d_extra) *extra_out = ctx->h_mirror->extra;
+  for (int i = 0; i < 3; ++i)
+    if (d_extra[i]) extra_out[i] = ctx->h_mirror->extra[i];
   return VBX_OK;
+}
+int sync_state(vbx_ctx* ctx, const uint32_t* d_extra = nullptr, uint32_t* extra_out = nullptr) {
+  const uint32_t* const ptrs[3] = {d_extra, nullptr, nullptr};
+  uint32_t out[3] = {0, 0, 0};
+  const int rc = sync_state3(ctx, ptrs, out);
+  if (!rc && d_extra) *extra_out = out[0];
+  return rc;
 }
 
 int check_state_error(vbx_ctx* ctx) {

@@ -466,50 +466,126 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     uint32_t* Tcur = ctx->b_T.as<uint32_t>();
     uint32_t* Tnext = ctx->b_TH.as<uint32_t>();
     uint32_t* poff = ctx->b_cnt.as<uint32_t>();
+    HIP_TRY(ctx->b_moved.ensure((size_t)R + 1));
     HIP_TRY(hipMemsetAsync(Tcur + R, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
     uint32_t rounds = 0;
-    uint32_t P = 0;
-    for (;;) {
-      rc = exclusive_scan_u32(ctx, Tcur, poff, R + 1);
+    const bool dbg = getenv("VBX_DEBUG") != nullptr;
+    // Replay of the rays [a, b) against the set content left by everything before them (the
+    // persistent array: what the frame found, plus the commits of the rays below a).  Runs
+    // rounds until no probe count in the range moves (then commits the range's probes) or
+    // max_rounds is used up.
+    auto replay = [&](uint32_t a, uint32_t b, uint32_t max_rounds, bool* converged) -> int {
+      *converged = false;
+      uint32_t Pb = 0, pa = 0;
+      for (uint32_t it = 0;; ++it) {
+        rc = exclusive_scan_u32(ctx, Tcur, poff, R + 1);
+        if (rc) return rc;
+        const uint32_t* const ptrs[3] = {poff + R, poff + a, poff + b};
+        uint32_t vals[3] = {0, 0, 0};
+        rc = sync_state3(ctx, ptrs, vals);  // also carries `changed` of the previous round
+        if (rc) return rc;
+        if (ctx->h_state.sentinel_cleared) ctx->obsset_sentinel_live = false;
+        const uint32_t Ptot = vals[0];
+        ctx->h_poff_total = Ptot;
+        if (dbg && it > 0)
+          fprintf(stderr, "[vbx] replay rays [%u,%u) round %u: %u probes, %u rays moved (%u grew)\n", a, b, it, Pb,
+                  ctx->h_state.act_count[0], ctx->h_state.act_count[1]);
+        if (it > 0 && !ctx->h_state.changed) {
+          *converged = true;
+          break;
+        }
+        if (it >= max_rounds) break;
+        pa = vals[1];
+        Pb = vals[2] - vals[1];
+        HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(Pb, 1) * 8));
+        HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(Pb, 1) * 8));
+        HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(Ptot, 1)));
+        if (!Pb) HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+        if (Pb) {
+          hipLaunchKernelGGL(k_strict_keys, grid_for(Pb), dim3(256), 0, s, poff, a, b, pa, Pb, ctx->b_off.as<uint32_t>(),
+                             ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
+          rc = stable_sort01(ctx, Pb, 44, 64, false);
+          if (rc) return rc;
+          hipLaunchKernelGGL(k_strict_outcome, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
+                             ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
+                             ctx->b_collided.as<uint8_t>());
+        }
+        if (dbg) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
+        hipLaunchKernelGGL(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
+                           R, a, b, ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext,
+                           ctx->b_U.as<uint32_t>(), ctx->b_moved.as<uint8_t>(), dbg ? 1 : 0, ctx->d_state);
+        std::swap(Tcur, Tnext);
+        ++rounds;
+      }
+      // converged: the sorted probe list of the last round (whose T equals the final T) is still
+      // in keys1 — its last probe per slot is the set's content after ray b - 1
+      if (*converged && Pb)
+        hipLaunchKernelGGL(k_strict_commit, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
+                           ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
+      return VBX_OK;
+    };
+    // Phase 1: the whole frame at once.  Steady-state frames converge in 1-5 rounds; a round
+    // costs ~45 us + 0.07 us per 1000 probes.
+    bool converged = false;
+    rc = replay(0, R, 8, &converged);
+    if (rc) return rc;
+    // Blocks pay off only when whole-frame rounds are expensive (millions of probes, i.e. fine
+    // voxels): 16-32 blocks cost at least two cheap rounds each.
+    const bool use_blocks = ctx->h_poff_total > 1500000u;
+    if (!converged && !use_blocks) {
+      rc = replay(0, R, 100000, &converged);
       if (rc) return rc;
-      rc = sync_state(ctx, poff + R, &P);  // also carries `changed` of the previous round
-      if (rc) return rc;
-      if (getenv("VBX_DEBUG") && rounds > 0)
-        fprintf(stderr, "[vbx] strict round %u: %u probes, %u rays moved (%u grew), lowest moved ray %u of %u\n", rounds, P,
-                ctx->h_state.act_count[0], ctx->h_state.act_count[1], ctx->h_state.act_count[2], R);
-      if (rounds > 0 && !ctx->h_state.changed) break;
-      if (rounds > 4096) {
+      if (!converged) {
         ctx->fail("Fast integrator: observed-set replay did not converge");
         return VBX_ERR_HIP;
       }
-      HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
-      HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(P, 1) * 8));
-      HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(P, 1)));
-      if (!P) HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
-      if (P) {
-        hipLaunchKernelGGL(k_strict_keys, grid_for(P), dim3(256), 0, s, poff, R, P, ctx->b_off.as<uint32_t>(),
-                           ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
-        rc = stable_sort01(ctx, P, 44, 64, false);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_strict_outcome, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
-                           ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
-                           ctx->b_collided.as<uint8_t>());
-      }
-      if (getenv("VBX_DEBUG")) {
-        HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
-        HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[2], 0xFF, 4, s));
-      }
-      hipLaunchKernelGGL(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(), R,
-                         ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext, ctx->b_U.as<uint32_t>(),
-                         getenv("VBX_DEBUG") ? 1 : 0, ctx->d_state);
-      std::swap(Tcur, Tnext);
-      ++rounds;
     }
-    // the sorted probe list of the last round (whose T equals the final T) is still in keys1
-    if (P) {
-      HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
-      hipLaunchKernelGGL(k_strict_commit, grid_for(P), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), P,
-                         ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
+    if (!converged) {
+      // Phase 2: long dependency chains (a fresh map, or more probed voxels than set slots: every
+      // round then only fixes the next link).  Rays below the lowest one that still moved are
+      // final: their probes are committed to the set, and the rest is replayed in blocks of
+      // consecutive rays — a block only interacts with itself and with the set content left by
+      // the rays before it, so its rounds are cheap (a 1/16 of the probes) and short chains
+      // inside a block converge in a few of them.
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[2], 0xFF, 4, s));
+      hipLaunchKernelGGL(k_strict_first_moved, grid_for(R), dim3(256), 0, s, ctx->b_moved.as<uint8_t>(), R,
+                         &ctx->d_state->act_count[2]);
+      rc = exclusive_scan_u32(ctx, Tcur, poff, R + 1);
+      if (rc) return rc;
+      rc = sync_state(ctx);
+      if (rc) return rc;
+      const uint32_t r_lo = std::min(ctx->h_state.act_count[2], R);
+      std::vector<uint32_t>& hp = ctx->h_poff;
+      hp.resize((size_t)R + 1);
+      HIP_TRY(hipMemcpyAsync(hp.data(), poff, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (r_lo > 0) {
+        rc = replay(0, r_lo, 8, &converged);  // final already: one round to list the probes, one to confirm
+        if (rc) return rc;
+        if (!converged) {
+          ctx->fail("Fast integrator: observed-set replay: settled prefix moved again");
+          return VBX_ERR_HIP;
+        }
+      }
+      constexpr uint32_t kBlocks = 16;
+      const uint64_t p_lo = hp[r_lo], p_hi = hp[R];
+      uint32_t a = r_lo;
+      for (uint32_t j = 1; j <= kBlocks && a < R; ++j) {
+        uint32_t b = R;
+        if (j < kBlocks) {  // block ends where the j-th share of the remaining probes ends
+          const uint64_t target = p_lo + (p_hi - p_lo) * j / kBlocks;
+          b = (uint32_t)(std::lower_bound(hp.begin() + a + 1, hp.begin() + R, (uint32_t)target) - hp.begin());
+          b = std::max(b, a + 1);
+        }
+        rc = replay(a, b, 100000, &converged);
+        if (rc) return rc;
+        if (!converged) {
+          ctx->fail("Fast integrator: observed-set replay did not converge");
+          return VBX_ERR_HIP;
+        }
+        a = b;
+      }
     }
     ctx->counters.replay_rounds = rounds;
   }

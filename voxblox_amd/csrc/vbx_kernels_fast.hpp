@@ -389,20 +389,21 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
 // so the sort moves 8 bytes per probe and no value array.  (Sorting only the upper 16 slot bits
 // and walking back inside the 16-slot group was slower: groups next to the sensor hold
 // thousands of probes of one hot slot.)
-__global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t R, uint32_t P,
-                              const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
+__global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t r_begin, uint32_t r_end, uint32_t p_begin,
+                              uint32_t P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
                               uint64_t* keys, DevState* st) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p == 0) st->changed = 0;  // this round's "some probe count moved" flag (set by k_strict_scan)
-  if (p >= P) return;
-  uint32_t lo = 0, hi = R;  // largest r with poff[r] <= p
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // probes p_begin .. p_begin + P of rays [r_begin, r_end)
+  if (q == 0) st->changed = 0;  // this round's "some probe count moved" flag (set by k_strict_scan)
+  if (q >= P) return;
+  const uint32_t p = p_begin + q;
+  uint32_t lo = r_begin, hi = r_end;  // largest r with poff[r] <= p
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
     if (poff[mid] <= p) lo = mid; else hi = mid;
   }
   const uint32_t gid = vox[off[lo] + (p - poff[lo])];
   const uint32_t h = long_index_hash(voxel_of_gid(m, gid));
-  keys[p] = ((uint64_t)(h & 0xFFFFFu) << 44) | ((uint64_t)(h >> 20) << 32) | p;  // p ascends in (ray, step) order = time
+  keys[q] = ((uint64_t)(h & 0xFFFFFu) << 44) | ((uint64_t)(h >> 20) << 32) | p;  // p ascends in (ray, step) order = time
 }
 __device__ inline uint32_t strict_key_slot(uint64_t key) { return (uint32_t)(key >> 44); }
 __device__ inline uint32_t strict_key_hash(uint64_t key) {
@@ -431,9 +432,11 @@ __global__ void k_strict_outcome(const uint64_t* __restrict__ keys, uint32_t P,
 // (tsdf_integrator.cc:531-551).  A ray whose guess ends before its walk does and that saw no
 // terminating run must probe further: its guess grows and the next round tells.
 __global__ void __launch_bounds__(256)
-k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R,
-              const uint8_t* __restrict__ collided, int max_consecutive, const uint32_t* __restrict__ T,
-              uint32_t* Tnew, uint32_t* U, int debug_counts, DevState* st) {
+k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R, uint32_t r_begin,
+              uint32_t r_end, const uint8_t* __restrict__ collided, int max_consecutive,
+              const uint32_t* __restrict__ T, uint32_t* Tnew, uint32_t* U, uint8_t* moved, int debug_counts,
+              DevState* st) {
+  // rays outside [r_begin, r_end) keep their probe count (they are final, or not in play yet)
   // 16 lanes per ray: 16 outcomes per step, the consecutive-collision counter is the run length
   // of the ballot mask (as in sweep_ray)
   constexpr int G = 16;
@@ -444,7 +447,12 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
     Tnew[R] = 0;
     U[R] = 0;
   }
-  const bool ray_ok = r < R;
+  const bool in_range = r >= r_begin && r < r_end;
+  if (r < R && !in_range && gl == 0) {
+    Tnew[r] = T[r];
+    moved[r] = 0;
+  }
+  const bool ray_ok = r < R && in_range;
   const uint32_t t = ray_ok ? T[r] : 0;
   const uint32_t len = ray_ok ? off[r + 1] - off[r] : 0;
   const uint32_t p0 = ray_ok ? poff[r] : 0;
@@ -478,6 +486,7 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
     if (!broke && t < len) tn = min(len, max(4u * t, t + 16u));  // surplus probes vanish again next round
     Tnew[r] = tn;
     U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
+    moved[r] = (tn != t) ? 1 : 0;
     if (tn != t) {
       st->changed = 1;
       if (debug_counts) {  // same-address atomics serialise (~90/us): only on request (VBX_DEBUG)
@@ -488,6 +497,14 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
     }
   }
 }
+// Lowest ray index whose probe count moved in the last round: every ray below it is final.
+__global__ void k_strict_first_moved(const uint8_t* __restrict__ moved, uint32_t R, uint32_t* out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool hit = r < R && moved[r];
+  const unsigned long long b = __ballot(hit);
+  if (b && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)b) - 1)) atomicMin(out, r);
+}
+
 // The last probe of every slot leaves its hash in the persistent set.
 __global__ void k_strict_commit(const uint64_t* __restrict__ keys, uint32_t P, uint32_t* set_vals, uint32_t offset,
                                 DevState* st) {

@@ -13,11 +13,14 @@ __global__ void k_fill_u64(uint64_t* p, uint64_t v, size_t n) {
 
 // Per-call counters: one launch instead of several unaligned memsets (each of which the
 // runtime splits into head/body/tail fill kernels).
-__global__ void k_publish_state(const DevState* st, StateMirror* out, const uint32_t* extra, uint32_t seq) {
+__global__ void k_publish_state(const DevState* st, StateMirror* out, const uint32_t* extra0, const uint32_t* extra1,
+                                const uint32_t* extra2, uint32_t seq) {
   const uint32_t* src = reinterpret_cast<const uint32_t*>(st);
   uint32_t* dst = reinterpret_cast<uint32_t*>(&out->st);
   for (uint32_t i = threadIdx.x; i < sizeof(DevState) / 4; i += blockDim.x) dst[i] = src[i];
-  if (threadIdx.x == 0 && extra) out->extra = *extra;
+  if (threadIdx.x == 0 && extra0) out->extra[0] = *extra0;
+  if (threadIdx.x == 1 && extra1) out->extra[1] = *extra1;
+  if (threadIdx.x == 2 && extra2) out->extra[2] = *extra2;
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
