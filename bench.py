@@ -298,11 +298,11 @@ def main():
         dom = max(stages, key=stages.get) if stages else "total_ms"
         dom_ms = stages.get(dom, 0.0)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        kernel_of_stage = {"solve_ms": "k_fast_sweep", "replay_ms": "rocprim::onesweep_iteration", "fold_ms": "k_fold", "emit_ms": "k_ray_emit",
+        kernel_of_stage = {"solve_ms": "k_fast_sweep", "replay_ms": "k_rsort_scatter", "fold_ms": "k_fold", "emit_ms": "k_ray_emit",
                            "prep_ms": "k_prep_points+sort", "alloc_ms": "k_fast_build_lists", "sort_ms": "rocprim onesweep"}
         kname = kernel_of_stage.get(dom, dom)
         launches = {"solve_ms": counters.get("iterations", 0) / K,
-                    "replay_ms": 3.0 * counters.get("replay_rounds", 0) / K}.get(dom, 1.0)   # 3 onesweep passes per round
+                    "replay_ms": 2.0 * counters.get("replay_rounds", 0) / K}.get(dom, 1.0)   # 2 sort passes per round
         launches = max(launches, 1.0)
         # HBM bytes of that kernel per frame from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
         # runs, profiles/r01c_pmc_hbm_traffic.json); null when no summary for this kernel exists.
@@ -314,7 +314,7 @@ def main():
         except (OSError, KeyError, ValueError):
             traffic = None
         kdesc = {"k_fast_sweep": "k_fast_sweep (early-termination solver)",
-                 "rocprim::onesweep_iteration": "rocprim onesweep passes of the observed-set replay rounds"}.get(kname, kname)
+                 "k_rsort_scatter": "k_rsort_scatter (stable radix sort passes of the observed-set replay rounds)"}.get(kname, kname)
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                            "kernel": kdesc, "launch": "all launches of one frame (stage %s)" % dom,
