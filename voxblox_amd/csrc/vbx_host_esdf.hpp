@@ -50,16 +50,32 @@ template <int VPS>
 int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, uint32_t used,
                uint32_t* sweeps) {
   hipStream_t s = ctx->stream;
-  for (;;) {
-    HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
-    hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, ctx->d_state);
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+  if (mode == 2) {
+    hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, 1u, ctx->d_state);
     ++*sweeps;
-    if (mode == 2) return VBX_OK;
-    hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
+    return VBX_OK;
+  }
+  // Global sweeps until none changes a block.  The active-block flags live on the device, so
+  // several sweeps are queued per host check (an idle sweep is ~10 us: every workgroup leaves at
+  // once; a check costs a read-back); the kernels record the last sweep that changed anything.
+  uint32_t sweep_no = 0;
+  for (;;) {
+    constexpr int kPerCheck = 3;
+    for (int i = 0; i < kPerCheck; ++i) {
+      ++sweep_no;
+      hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, sweep_no,
+                         ctx->d_state);
+      hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
+    }
     int rc = sync_state(ctx);
     if (rc) return rc;
-    if (!ctx->h_state.changed) return VBX_OK;
-    if (*sweeps > 100000) {
+    if (ctx->h_state.changed < sweep_no) {  // the last queued sweep was idle: fixed point
+      *sweeps += std::max<uint32_t>(ctx->h_state.changed + 1, sweep_no - kPerCheck + 1) - (sweep_no - kPerCheck);
+      return VBX_OK;
+    }
+    *sweeps += kPerCheck;
+    if (sweep_no > 100000) {
       ctx->fail("ESDF: wavefront did not converge");
       return VBX_ERR_HIP;
     }

@@ -241,7 +241,7 @@ __global__ void k_esdf_rotate_active(EsdfDev e, uint32_t n_slots, int reseed) {
 constexpr int kEsdfThreads = 1024;  // one workgroup relaxes one block; big frontiers need the lanes
 template <int VPS>
 __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
-                                                   DevState* st) {
+                                                   uint32_t sweep_no, DevState* st) {
   constexpr int T = VPS + 2;
   constexpr int NT = T * T * T;
   constexpr int NV = VPS * VPS * VPS;
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
   if (mode != 2) {
     if (tid < 27 && s_nb[tid] != kInvalidSlot) atomicOr(&e.active[s_nb[tid]], 2u | 4u);
     if (tid == 0) {
-      st->changed = 1;
+      atomicMax(&st->changed, sweep_no);  // the last sweep (1-based, per phase) in which a block changed
       atomicAdd(&st->esdf_relax_blocks, 1u);
     }
   }
