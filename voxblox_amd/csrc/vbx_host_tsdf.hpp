@@ -503,7 +503,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(Ptot, 1)));
         if (!Pb) HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
         if (Pb) {
-          hipLaunchKernelGGL(k_strict_keys, grid_for(Pb), dim3(256), 0, s, poff, a, b, pa, Pb, ctx->b_off.as<uint32_t>(),
+          hipLaunchKernelGGL(k_strict_keys, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, a, b, pa, Pb, ctx->b_off.as<uint32_t>(),
                              ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
           rc = stable_sort01(ctx, Pb, 44, 64, false);
           if (rc) return rc;

@@ -392,18 +392,18 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
 __global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t r_begin, uint32_t r_end, uint32_t p_begin,
                               uint32_t P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
                               uint64_t* keys, DevState* st) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // probes p_begin .. p_begin + P of rays [r_begin, r_end)
-  if (q == 0) st->changed = 0;  // this round's "some probe count moved" flag (set by k_strict_scan)
-  if (q >= P) return;
-  const uint32_t p = p_begin + q;
-  uint32_t lo = r_begin, hi = r_end;  // largest r with poff[r] <= p
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (poff[mid] <= p) lo = mid; else hi = mid;
+  // 16 lanes per ray of [r_begin, r_end): the ray's probes are written as one run
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) st->changed = 0;  // this round's "some probe count moved" flag (set by k_strict_scan)
+  const uint32_t r = r_begin + (t >> 4);
+  if (r >= r_end) return;
+  const uint32_t p0 = poff[r], n = poff[r + 1] - p0, beg = off[r];
+  for (uint32_t k = t & 15u; k < n; k += 16) {
+    const uint32_t h = long_index_hash(voxel_of_gid(m, vox[beg + k]));
+    const uint32_t p = p0 + k;  // ascends in (ray, step) order = time
+    keys[p - p_begin] = ((uint64_t)(h & 0xFFFFFu) << 44) | ((uint64_t)(h >> 20) << 32) | p;
   }
-  const uint32_t gid = vox[off[lo] + (p - poff[lo])];
-  const uint32_t h = long_index_hash(voxel_of_gid(m, gid));
-  keys[q] = ((uint64_t)(h & 0xFFFFFu) << 44) | ((uint64_t)(h >> 20) << 32) | p;  // p ascends in (ray, step) order = time
+  (void)P;
 }
 __device__ inline uint32_t strict_key_slot(uint64_t key) { return (uint32_t)(key >> 44); }
 __device__ inline uint32_t strict_key_hash(uint64_t key) {
