@@ -126,6 +126,30 @@ def test_fast_reference_observed_set_bit_exact(oracle, extra):
     compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
 
 
+def test_fast_approx_set_offset_wrap(oracle):
+    """resetApproxSet's full reset (approx_hash_array.h:156-169): 9997 empty clouds with
+    clear_checks_every_n_frames = 1 move both ApproxHashSets to offset 9997 (an empty cloud still
+    counts as a frame, tsdf_integrator.cc:564-569); the real frames then run at offsets 9998,
+    9999, 0 (sets zeroed, sentinel back in slot 0) and 1."""
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8))
+    real = [_small_room(k) for k in (0, 4, 8, 12)]
+    frames = [(real[0][0], empty[0], empty[1])] * 9997 + real
+    om, oi, gm = _run(oracle, "fast", 0.05, frames, clear_checks_every_n_frames=1)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+
+
+def test_fast_empty_clouds_count_as_frames(oracle):
+    """clear_checks_every_n_frames = 3 with empty clouds interleaved: the reset counter advances
+    on every integratePointCloud call, so the sets are cleared at the same real frames as in the
+    reference."""
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8))
+    real = [_small_room(k) for k in (0, 4, 8, 12)]
+    e = (real[0][0], empty[0], empty[1])
+    frames = [real[0], e, real[1], e, e, real[2], real[3]]
+    om, oi, gm = _run(oracle, "fast", 0.05, frames, clear_checks_every_n_frames=3)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+
+
 def test_fast_reference_observed_set_full_frame(oracle):
     """The same at BASELINE configs[1] size: two full 640x480 frames at 0.05 m."""
     frames = [scenes.room_frame(k, 100) for k in (0, 1)]

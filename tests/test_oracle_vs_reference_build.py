@@ -109,6 +109,17 @@ def test_fast_small_voxels_many_frames():
     _same_tsdf(a, b)
 
 
+def test_fast_approx_set_offset_wrap():
+    """ApproxHashSet<20, 10000>::resetApproxSet (approx_hash_array.h:156-169): 9997 empty clouds with
+    clear_checks_every_n_frames = 1 walk both sets to offset 9997; the four real frames then run
+    at offsets 9998, 9999, 0 (full reset, size_t-max sentinel back in slot 0) and 1."""
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8))
+    frames = _frames(4)
+    pad = [(frames[0][0], empty[0], empty[1])] * 9997
+    a, b = _both("fast", pad + frames, voxel=0.05, clear_checks_every_n_frames=1)
+    _same_tsdf(a, b)
+
+
 def test_freespace_points():
     a, b = _both("merged", _frames(2), freespace=True)
     _same_tsdf(a, b)

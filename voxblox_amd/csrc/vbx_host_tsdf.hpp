@@ -222,6 +222,29 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   return march_and_fold(ctx, bt, c, /*from_origin=*/true, nullptr, false, graze, nb);
 }
 
+constexpr uint32_t kFastSetSize = (1u << 20) + 10000u;  // ApproxHashSet<20, 10000>
+
+// Per-frame bookkeeping of FastTsdfIntegrator::integratePointCloud (tsdf_integrator.cc:564-569):
+// every clear_checks_every_n_frames-th call -- empty clouds included -- both ApproxHashSets move
+// on by one offset, and are zeroed when the offset wraps at 10000 (approx_hash_array.h:156-169).
+int fast_frame_tick(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg) {
+  if ((++ctx->reset_counter) < cfg->clear_checks_every_n_frames) return VBX_OK;
+  hipStream_t s = ctx->stream;
+  ctx->reset_counter = 0;
+  ++ctx->obs_epoch;  // voxel_observed set cleared (exact-set form of resetApproxSet)
+  if (++ctx->obsset_offset >= 10000u) {
+    if (ctx->obsset_init) HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kFastSetSize * 4, s));
+    ctx->obsset_offset = 0;
+    ctx->obsset_sentinel_live = true;
+  }
+  if (++ctx->start_offset >= 10000u) {
+    if (ctx->startset_init) HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kFastSetSize * 4, s));
+    ctx->start_offset = 0;
+    ctx->start_sentinel_live = true;
+  }
+  return VBX_OK;
+}
+
 int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
                    const uint32_t* d_rgba, size_t n, int freespace) {
   CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
@@ -232,31 +255,16 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   }
   hipStream_t s = ctx->stream;
   MapDev& m = ctx->map;
-  constexpr uint32_t kSetSize = (1u << 20) + 10000u;
+  constexpr uint32_t kSetSize = kFastSetSize;
+  int rc = fast_frame_tick(ctx, cfg);
+  if (rc) return rc;
   if (!ctx->startset_init) {
     HIP_TRY(ctx->b_startset.ensure((size_t)kSetSize * 4));
     HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
-    ctx->startset_init = true;
-    ctx->start_offset = 0;
-    ctx->start_sentinel_live = true;
-  }
-  // tsdf_integrator.cc:564-569 + ApproxHashSet::resetApproxSet (approx_hash_array.h:156-169)
-  if ((++ctx->reset_counter) >= cfg->clear_checks_every_n_frames) {
-    ctx->reset_counter = 0;
-    ++ctx->obs_epoch;  // voxel_observed set cleared (exact-set form of resetApproxSet)
-    if (++ctx->obsset_offset >= 10000u) {  // both sets reset together (tsdf_integrator.cc:566-568)
-      if (ctx->obsset_init) HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kSetSize * 4, s));
-      ctx->obsset_offset = 0;
-      ctx->obsset_sentinel_live = true;
-    }
-    if (++ctx->start_offset >= 10000u) {
-      HIP_TRY(hipMemsetAsync(ctx->b_startset.p, 0, (size_t)kSetSize * 4, s));
-      ctx->start_offset = 0;
-      ctx->start_sentinel_live = true;
-    }
+    ctx->startset_init = true;  // the offset keeps counting while the set is unallocated
   }
 
-  int rc = ensure_tab(ctx, false, n, false);
+  rc = ensure_tab(ctx, false, n, false);
   if (rc) return rc;
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
@@ -624,10 +632,14 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
     ctx->fail("Unknown integration order mode");  // integrator_utils.cc:12
     return VBX_ERR_INVALID;
   }
+  if (kind != VBX_TSDF_SIMPLE && kind != VBX_TSDF_MERGED && kind != VBX_TSDF_FAST) {
+    ctx->fail("unknown TSDF integrator type %d", kind);  // tsdf_integrator.cc:40-43
+    return VBX_ERR_INVALID;
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   ctx->counters = vbx_counters{};
   ctx->counters.points = n;
-  if (n == 0) return VBX_OK;
+  if (n == 0) return kind == VBX_TSDF_FAST ? fast_frame_tick(ctx, cfg) : VBX_OK;
   // per-call device counters
   hipLaunchKernelGGL(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
   Pose T;
@@ -640,10 +652,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   switch (kind) {
     case VBX_TSDF_SIMPLE: rc = integrate_simple(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
     case VBX_TSDF_MERGED: rc = integrate_merged(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
-    case VBX_TSDF_FAST: rc = integrate_fast(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
-    default:
-      ctx->fail("unknown TSDF integrator type %d", kind);  // tsdf_integrator.cc:40-43
-      return VBX_ERR_INVALID;
+    default: rc = integrate_fast(ctx, cfg, T, d_pts, rgba32, n, freespace); break;
   }
   if (rc) return rc;
   tmark(ctx, 7);
