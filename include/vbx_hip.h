@@ -91,6 +91,13 @@ typedef struct vbx_esdf_cfg {
   float occupied_sphere_radius;
 } vbx_esdf_cfg;
 
+/* MeshIntegratorConfig, mesh/mesh_integrator.h:47-66 (integrator_threads has no meaning here). */
+typedef struct vbx_mesh_cfg {
+  int32_t use_color;
+  float min_weight;
+} vbx_mesh_cfg;
+
+void vbx_mesh_cfg_default(vbx_mesh_cfg* cfg);
 void vbx_tsdf_cfg_default(vbx_tsdf_cfg* cfg);
 void vbx_esdf_cfg_default(vbx_esdf_cfg* cfg);
 
@@ -136,6 +143,27 @@ int vbx_esdf_update_blocks(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const int32_t*
                            int incremental);
 /* EsdfIntegrator::clear() (esdf_integrator.h:138-142): forget the work addNewRobotPosition queued. */
 int vbx_esdf_integrator_clear(vbx_ctx* ctx);
+
+/* MeshIntegrator<TsdfVoxel>::generateMesh(only_mesh_updated_blocks, clear_updated_flag)
+ * (mesh/mesh_integrator.h:142-195; per block updateMeshForBlock :250-270 = extractBlockMesh
+ * :197-248 + MarchingCubes::meshCube marching_cubes.h:70-111 + updateMeshColor :372-392).  Meshes
+ * the TSDF blocks carrying Update::kMesh (or every block) on the device and keeps the result of
+ * THIS call device-resident until the next one: per meshed block a run of vertices (three per
+ * triangle, in the reference's emission order), per-vertex normals and, with cfg->use_color,
+ * per-vertex colours.  Mesh::indices is 0..n-1 per block (marching_cubes.h:94-96) and is not
+ * stored.  A block without triangles is still listed (the reference clears its Mesh and sets
+ * Mesh::updated).  The persistent MeshLayer (mesh_layer.h) stays with the caller. */
+int vbx_mesh_generate(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_mesh_updated_blocks,
+                      int clear_updated_flag, size_t* n_blocks, size_t* n_vertices);
+/* The blocks meshed by the last vbx_mesh_generate: idx_xyz[3*i..] and vertex_offset[i]..[i+1]
+ * (cap + 1 entries) into the vertex arrays.  *n is always set; VBX_ERR_CAPACITY if cap is short. */
+int vbx_mesh_blocks(vbx_ctx* ctx, int32_t* idx_xyz, uint64_t* vertex_offset, size_t cap, size_t* n);
+/* Copies the vertex arrays of the last vbx_mesh_generate to the host (any pointer may be NULL;
+ * rgba = Color r,g,b,a per vertex). */
+int vbx_mesh_download(vbx_ctx* ctx, float* vertices, float* normals, uint8_t* rgba, size_t cap_vertices);
+/* The same arrays where they lie in device memory (valid until the next vbx_mesh_generate). */
+int vbx_mesh_device_ptrs(vbx_ctx* ctx, const float** d_vertices, const float** d_normals,
+                         const uint8_t** d_rgba);
 
 /* EsdfIntegrator::addNewRobotPosition(position) (esdf_integrator.cc:25-92; caller
  * esdf_server.cc:219-226): unknown or hallucinated voxels within cfg->clear_sphere_radius become

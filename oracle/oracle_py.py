@@ -106,6 +106,14 @@ def _bind(L):
         "orc_esdf_update_from_tsdf_blocks": (None, [vp, i32p, C.c_size_t, C.c_int]),
         "orc_esdf_integrator_clear": (None, [vp]),
         "orc_esdf_stats": (None, [vp, u64p, C.c_int]),
+        "orc_mesh_layer_create": (vp, [vp]),
+        "orc_mesh_layer_destroy": (None, [vp]),
+        "orc_mesh_generate": (None, [vp, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]),
+        "orc_mesh_num_blocks": (C.c_size_t, [vp]),
+        "orc_mesh_block_indices": (C.c_size_t, [vp, i32p, C.c_size_t]),
+        "orc_mesh_block_sizes": (C.c_int, [vp, i32p, u64p]),
+        "orc_mesh_block_get": (C.c_int, [vp, i32p, f32p, f32p, u8p, u64p]),
+        "orc_mesh_clear_updated": (None, [vp]),
         "orc_num_blocks": (C.c_size_t, [vp, C.c_int]),
         "orc_block_indices": (C.c_size_t, [vp, C.c_int, i32p, C.c_size_t]),
         "orc_tsdf_block_get": (C.c_int, [vp, i32p, f32p, f32p, u8p, u8p]),
@@ -212,6 +220,9 @@ class OracleMap:
         self._integrators.append(("e", h))
         return OracleEsdfIntegrator(self, h)
 
+    def mesh_layer(self):
+        return OracleMeshLayer(self)
+
     def num_blocks(self, layer=0):
         return self.L.orc_num_blocks(self.h, layer)
 
@@ -299,6 +310,50 @@ class OracleTsdfIntegrator:
         self.L.orc_tsdf_stats(self.h, _p(out, C.c_uint64), int(reset))
         return dict(voxel_updates=int(out[0]), rays_cast=int(out[1]), bundles=int(out[2]),
                     clear_bundles=int(out[3]))
+
+
+class OracleMeshLayer:
+    """MeshLayer + MeshIntegrator<TsdfVoxel> over the map's TSDF layer (mesh_integrator.h)."""
+
+    def __init__(self, m):
+        self.m, self.L = m, m.L
+        self.h = self.L.orc_mesh_layer_create(m.h)
+
+    def __del__(self):
+        try:
+            self.L.orc_mesh_layer_destroy(self.h)
+        except Exception:
+            pass
+
+    def generate(self, only_mesh_updated_blocks=True, clear_updated_flag=True, use_color=True,
+                 min_weight=1e-4, threads=1):
+        self.L.orc_mesh_generate(self.h, int(use_color), float(min_weight), int(threads),
+                                 int(only_mesh_updated_blocks), int(clear_updated_flag))
+
+    def block_indices(self):
+        n = self.L.orc_mesh_num_blocks(self.h)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        self.L.orc_mesh_block_indices(self.h, _p(out, C.c_int32), n)
+        return out[:n]
+
+    def block(self, idx):
+        """dict(vertices [n,3] f32, normals [n,3] f32, colors [m,4] u8, indices [n] u64, updated)."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        sz = np.zeros(5, np.uint64)
+        if not self.L.orc_mesh_block_sizes(self.h, _p(idx, C.c_int32), _p(sz, C.c_uint64)):
+            return None
+        nv, nn, nc, ni = (int(x) for x in sz[:4])
+        v = np.zeros((max(nv, 1), 3), np.float32); n = np.zeros((max(nn, 1), 3), np.float32)
+        c = np.zeros((max(nc, 1), 4), np.uint8); i = np.zeros(max(ni, 1), np.uint64)
+        self.L.orc_mesh_block_get(self.h, _p(idx, C.c_int32), _p(v, C.c_float), _p(n, C.c_float),
+                                  _p(c, C.c_uint8), _p(i, C.c_uint64))
+        return dict(vertices=v[:nv], normals=n[:nn], colors=c[:nc], indices=i[:ni], updated=bool(sz[4]))
+
+    def as_dict(self):
+        return {tuple(int(x) for x in b): self.block(b) for b in self.block_indices()}
+
+    def clear_updated(self):
+        self.L.orc_mesh_clear_updated(self.h)
 
 
 class OracleEsdfIntegrator:

@@ -15,6 +15,7 @@
 #include "voxblox/core/layer.h"
 #include "voxblox/integrator/esdf_integrator.h"
 #include "voxblox/integrator/tsdf_integrator.h"
+#include "voxblox/mesh/mesh_integrator.h"
 #include "voxblox/utils/approx_hash_array.h"
 #include "voxblox/utils/bucket_queue.h"
 #include "voxblox/utils/neighbor_tools.h"
@@ -30,6 +31,11 @@ struct orc_map {
 };
 struct orc_tsdf_integrator { TsdfIntegratorBase::Ptr impl; };
 struct orc_esdf_integrator { std::unique_ptr<EsdfIntegrator> impl; };
+struct orc_mesh_layer {
+  orc_mesh_layer(orc_map* m) : map(m), mesh(m->tsdf.block_size()) {}
+  orc_map* map;
+  MeshLayer mesh;
+};
 struct ApproxSetIface {
   virtual ~ApproxSetIface() = default;
   virtual bool replace(size_t h) = 0;
@@ -162,6 +168,59 @@ void orc_esdf_add_new_robot_position(orc_esdf_integrator* it, const float p[3]) 
   it->impl->addNewRobotPosition(Point(p[0], p[1], p[2]));
 }
 void orc_esdf_stats(orc_esdf_integrator*, uint64_t out[7], int) { for (int i = 0; i < 7; ++i) out[i] = 0; }
+
+static Mesh::Ptr find_mesh(orc_mesh_layer* ml, const BlockIndex& bi) {
+  BlockIndexList l;
+  ml->mesh.getAllAllocatedMeshes(&l);
+  for (const BlockIndex& b : l) if (b == bi) return ml->mesh.getMeshPtrByIndex(bi);
+  return Mesh::Ptr();
+}
+orc_mesh_layer* orc_mesh_layer_create(orc_map* m) { return new orc_mesh_layer(m); }
+void orc_mesh_layer_destroy(orc_mesh_layer* ml) { delete ml; }
+void orc_mesh_generate(orc_mesh_layer* ml, int use_color, float min_weight, int threads, int only_updated,
+                       int clear_flag) {
+  MeshIntegratorConfig c;
+  c.use_color = use_color != 0;
+  c.min_weight = min_weight;
+  c.integrator_threads = threads > 0 ? threads : 1;
+  MeshIntegrator<TsdfVoxel> integrator(c, &ml->map->tsdf, &ml->mesh);
+  integrator.generateMesh(only_updated != 0, clear_flag != 0);
+}
+size_t orc_mesh_num_blocks(orc_mesh_layer* ml) { return ml->mesh.getNumberOfAllocatedMeshes(); }
+size_t orc_mesh_block_indices(orc_mesh_layer* ml, int32_t* out, size_t cap) {
+  BlockIndexList l;
+  ml->mesh.getAllAllocatedMeshes(&l);
+  for (size_t i = 0; i < l.size() && i < cap; ++i) { out[3 * i] = l[i].x(); out[3 * i + 1] = l[i].y(); out[3 * i + 2] = l[i].z(); }
+  return l.size();
+}
+int orc_mesh_block_sizes(orc_mesh_layer* ml, const int32_t idx[3], uint64_t out[5]) {
+  const BlockIndex bi(idx[0], idx[1], idx[2]);
+  Mesh::Ptr m = find_mesh(ml, bi);
+  if (!m) return 0;
+  out[0] = m->vertices.size(); out[1] = m->normals.size(); out[2] = m->colors.size();
+  out[3] = m->indices.size(); out[4] = m->updated;
+  return 1;
+}
+int orc_mesh_block_get(orc_mesh_layer* ml, const int32_t idx[3], float* vertices, float* normals, uint8_t* rgba,
+                       uint64_t* indices) {
+  const BlockIndex bi(idx[0], idx[1], idx[2]);
+  Mesh::Ptr m = find_mesh(ml, bi);
+  if (!m) return 0;
+  for (size_t i = 0; i < m->vertices.size(); ++i)
+    for (int k = 0; k < 3; ++k) if (vertices) vertices[3 * i + k] = m->vertices[i][k];
+  for (size_t i = 0; i < m->normals.size(); ++i)
+    for (int k = 0; k < 3; ++k) if (normals) normals[3 * i + k] = m->normals[i][k];
+  for (size_t i = 0; i < m->colors.size(); ++i) if (rgba) {
+    rgba[4 * i] = m->colors[i].r; rgba[4 * i + 1] = m->colors[i].g; rgba[4 * i + 2] = m->colors[i].b; rgba[4 * i + 3] = m->colors[i].a;
+  }
+  if (indices) for (size_t i = 0; i < m->indices.size(); ++i) indices[i] = m->indices[i];
+  return 1;
+}
+void orc_mesh_clear_updated(orc_mesh_layer* ml) {
+  BlockIndexList l;
+  ml->mesh.getAllAllocatedMeshes(&l);
+  for (const BlockIndex& b : l) ml->mesh.getMeshPtrByIndex(b)->updated = false;
+}
 
 size_t orc_num_blocks(orc_map* m, int layer) {
   return layer == 0 ? m->tsdf.getNumberOfAllocatedBlocks() : m->esdf.getNumberOfAllocatedBlocks();

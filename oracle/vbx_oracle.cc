@@ -7,6 +7,7 @@
 
 #include "vbx_core.hpp"
 #include "vbx_esdf.hpp"
+#include "vbx_mesh.hpp"
 #include "vbx_tsdf.hpp"
 
 using namespace orc;
@@ -22,6 +23,11 @@ struct orc_tsdf_integrator {
 };
 struct orc_esdf_integrator {
   std::unique_ptr<EsdfIntegrator> impl;
+};
+struct orc_mesh_layer {
+  orc_mesh_layer(orc_map* m) : map(m), mesh(m->tsdf.block_size) {}
+  orc_map* map;
+  MeshLayer mesh;
 };
 struct ApproxSetIface {
   virtual ~ApproxSetIface() = default;
@@ -146,6 +152,45 @@ void orc_tsdf_stats(orc_tsdf_integrator* it, uint64_t out[4], int reset) {
   if (reset) it->impl->stats.reset();
 }
 void orc_fast_reset_counter_set(int64_t v) { fastResetCounter() = v; }
+
+orc_mesh_layer* orc_mesh_layer_create(orc_map* m) { return new orc_mesh_layer(m); }
+void orc_mesh_layer_destroy(orc_mesh_layer* ml) { delete ml; }
+void orc_mesh_generate(orc_mesh_layer* ml, int use_color, float min_weight, int threads, int only_updated,
+                       int clear_flag) {
+  MeshIntegratorConfig c;
+  c.use_color = use_color != 0;
+  c.min_weight = min_weight;
+  c.integrator_threads = threads > 0 ? threads : 1;
+  MeshIntegrator(c, &ml->map->tsdf, &ml->mesh).generateMesh(only_updated != 0, clear_flag != 0);
+}
+size_t orc_mesh_num_blocks(orc_mesh_layer* ml) { return ml->mesh.mesh_map.size(); }
+size_t orc_mesh_block_indices(orc_mesh_layer* ml, int32_t* out, size_t cap) {
+  size_t i = 0;
+  for (const auto& kv : ml->mesh.mesh_map) {
+    if (i < cap) { out[3 * i] = kv.first.x; out[3 * i + 1] = kv.first.y; out[3 * i + 2] = kv.first.z; }
+    ++i;
+  }
+  return i;
+}
+int orc_mesh_block_sizes(orc_mesh_layer* ml, const int32_t idx[3], uint64_t out[5]) {
+  auto m = ml->mesh.getMeshPtrByIndex({idx[0], idx[1], idx[2]});
+  if (!m) return 0;
+  out[0] = m->vertices.size(); out[1] = m->normals.size(); out[2] = m->colors.size();
+  out[3] = m->indices.size(); out[4] = m->updated;
+  return 1;
+}
+int orc_mesh_block_get(orc_mesh_layer* ml, const int32_t idx[3], float* vertices, float* normals, uint8_t* rgba,
+                       uint64_t* indices) {
+  auto m = ml->mesh.getMeshPtrByIndex({idx[0], idx[1], idx[2]});
+  if (!m) return 0;
+  static_assert(sizeof(Vec3f) == 12 && sizeof(Color) == 4, "layout");
+  if (vertices && !m->vertices.empty()) std::memcpy(vertices, m->vertices.data(), m->vertices.size() * 12);
+  if (normals && !m->normals.empty()) std::memcpy(normals, m->normals.data(), m->normals.size() * 12);
+  if (rgba && !m->colors.empty()) std::memcpy(rgba, m->colors.data(), m->colors.size() * 4);
+  if (indices) for (size_t i = 0; i < m->indices.size(); ++i) indices[i] = m->indices[i];
+  return 1;
+}
+void orc_mesh_clear_updated(orc_mesh_layer* ml) { for (auto& kv : ml->mesh.mesh_map) kv.second->updated = false; }
 
 static EsdfConfig toEsdfCfg(const orc_esdf_cfg* c) {
   EsdfConfig d;

@@ -115,6 +115,21 @@ int orc_block_deserialize(orc_map* m, int layer, const int32_t idx[3], const uin
 int orc_esdf_block_set(orc_map* m, const int32_t idx[3], const float* dist, const uint8_t* flags,
                        const int32_t* parent_xyz, uint8_t updated_bits);
 
+/* ---- MeshIntegrator<TsdfVoxel> over the map's TSDF layer (mesh_integrator.h) ---- */
+typedef struct orc_mesh_layer orc_mesh_layer; /* MeshLayer(block_size) + the layer it meshes */
+orc_mesh_layer* orc_mesh_layer_create(orc_map* m);
+void orc_mesh_layer_destroy(orc_mesh_layer* ml);
+/* MeshIntegrator(cfg{use_color, min_weight, integrator_threads}, &tsdf, &mesh).generateMesh(...) */
+void orc_mesh_generate(orc_mesh_layer* ml, int use_color, float min_weight, int threads,
+                       int only_mesh_updated_blocks, int clear_updated_flag);
+size_t orc_mesh_num_blocks(orc_mesh_layer* ml);
+size_t orc_mesh_block_indices(orc_mesh_layer* ml, int32_t* idx_xyz, size_t cap);
+/* out = {#vertices, #normals, #colors, #indices, updated}; returns 0 if the mesh is absent */
+int orc_mesh_block_sizes(orc_mesh_layer* ml, const int32_t idx[3], uint64_t out[5]);
+int orc_mesh_block_get(orc_mesh_layer* ml, const int32_t idx[3], float* vertices, float* normals,
+                       uint8_t* rgba, uint64_t* indices);
+void orc_mesh_clear_updated(orc_mesh_layer* ml); /* mesh->updated = false everywhere (the publisher's job) */
+
 /* ---- known-answer helpers (restate test_tsdf_map / test_approx_hash_array / test_bucket_queue) ---- */
 void orc_grid_index_from_point(const float p[3], float grid_size_inv, int64_t out[3]);
 void orc_center_point_from_grid_index(const int64_t idx[3], float grid_size, float out[3]);

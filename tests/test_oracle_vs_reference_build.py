@@ -223,3 +223,50 @@ def test_helpers_bit_identical():
     La.orc_neighbor_lut(offa.ctypes.data_as(i32p), da.ctypes.data_as(f32p))
     Lb.orc_neighbor_lut(offb.ctypes.data_as(i32p), db.ctypes.data_as(f32p))
     assert np.array_equal(offa, offb) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+
+
+def _same_mesh(a, b):
+    assert set(a.keys()) == set(b.keys())
+    nverts = 0
+    for k in a:
+        x, y = a[k], b[k]
+        assert x["updated"] == y["updated"], k
+        for f in ("vertices", "normals", "colors", "indices"):
+            assert x[f].shape == y[f].shape, (k, f, x[f].shape, y[f].shape)
+            assert np.array_equal(x[f].view(np.uint8), y[f].view(np.uint8)), (k, f)
+        nverts += x["vertices"].shape[0]
+    return nverts
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(use_color=False), dict(min_weight=0.05)])
+def test_mesh_integrator_bit_identical(cfg):
+    """MeshIntegrator<TsdfVoxel>::generateMesh (mesh_integrator.h:142-392): incremental meshing of
+    the kMesh-flagged blocks after every frame, then a full re-mesh; vertices, normals, colours,
+    indices, `updated` and the cleared kMesh bits identical to the reference build."""
+    out = []
+    for L in (O.lib(), O.ref_lib()):
+        L.orc_fast_reset_counter_set(0)
+        m = O.OracleMap(0.1, 16, L=L)
+        c = O.TsdfCfg()
+        L.orc_tsdf_cfg_default(C.byref(c))
+        c.default_truncation_distance = 0.4
+        c.integrator_threads = 1
+        it = m.tsdf_integrator("merged", c)
+        ml = m.mesh_layer()
+        snaps = []
+        for k, (pose, pts, col) in enumerate(_frames(3)):
+            it.integrate(pose[0], pose[1], pts, col)
+            ml.generate(True, True, **cfg)
+            snaps.append(ml.as_dict())
+            if k == 1:
+                ml.clear_updated()
+        flags = {tuple(b): m.tsdf_block(b)[3] for b in m.block_indices()}
+        ml.generate(False, False, **cfg)
+        snaps.append(ml.as_dict())
+        out.append((snaps, flags))
+    (sa, fa), (sb, fb) = out
+    assert fa == fb and all((v & 2) == 0 for v in fa.values())
+    total = 0
+    for x, y in zip(sa, sb):
+        total += _same_mesh(x, y)
+    assert total > 3000

@@ -23,7 +23,8 @@ EXPORTED_SYMBOLS = (
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
-    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_enable_timing", "vbx_get_timing")
+    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_enable_timing", "vbx_get_timing",
+    "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
 
 
 class MapCfg(C.Structure):
@@ -44,6 +45,11 @@ class TsdfCfg(C.Structure):
                 ("max_consecutive_ray_collisions", C.c_int32),
                 ("clear_checks_every_n_frames", C.c_int32), ("max_integration_time_s", C.c_float),
                 ("merged_bundle_order", C.c_int32), ("fast_observed_set", C.c_int32)]
+
+
+class MeshCfg(C.Structure):
+    """MeshIntegratorConfig (mesh_integrator.h:47-66)."""
+    _fields_ = [("use_color", C.c_int32), ("min_weight", C.c_float)]
 
 
 class EsdfCfg(C.Structure):
@@ -109,6 +115,11 @@ def lib():
         "vbx_esdf_add_new_robot_position": (C.c_int, [vp, C.POINTER(EsdfCfg), f32p]),
         "vbx_esdf_update_blocks": (C.c_int, [vp, C.POINTER(EsdfCfg), i32p, C.c_size_t, C.c_int]),
         "vbx_esdf_integrator_clear": (C.c_int, [vp]),
+        "vbx_mesh_cfg_default": (None, [C.POINTER(MeshCfg)]),
+        "vbx_mesh_generate": (C.c_int, [vp, C.POINTER(MeshCfg), C.c_int, C.c_int, szp, szp]),
+        "vbx_mesh_blocks": (C.c_int, [vp, i32p, C.POINTER(C.c_uint64), C.c_size_t, szp]),
+        "vbx_mesh_download": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u8p, C.c_size_t]),
+        "vbx_mesh_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "vbx_selftest_sort": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
         "vbx_num_blocks": (C.c_int, [vp, C.c_int, szp]),
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
@@ -141,6 +152,16 @@ def lib():
 def tsdf_cfg(**kw):
     c = TsdfCfg()
     lib().vbx_tsdf_cfg_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def mesh_cfg(**kw):
+    c = MeshCfg()
+    lib().vbx_mesh_cfg_default(C.byref(c))
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)
@@ -229,6 +250,31 @@ class Map:
         idx = np.ascontiguousarray(indices, np.int32).reshape(-1, 3)
         self._chk(self.L.vbx_esdf_update_blocks(self.h, C.byref(cfg), idx.ctypes.data_as(C.POINTER(C.c_int32)),
                                                 idx.shape[0], int(incremental)))
+
+    def mesh_generate(self, cfg=None, only_mesh_updated_blocks=True, clear_updated_flag=True, download=True):
+        """MeshIntegrator<TsdfVoxel>::generateMesh (mesh_integrator.h:142-195).  Returns
+        (block indices [n,3], vertex offsets [n+1], vertices [V,3], normals [V,3], colors [V,4] or None);
+        with download=False only (indices, offsets)."""
+        cfg = cfg or mesh_cfg()
+        nb, nv = C.c_size_t(0), C.c_size_t(0)
+        self._chk(self.L.vbx_mesh_generate(self.h, C.byref(cfg), int(only_mesh_updated_blocks),
+                                           int(clear_updated_flag), C.byref(nb), C.byref(nv)))
+        idx = np.zeros((max(nb.value, 1), 3), np.int32)
+        off = np.zeros(nb.value + 1, np.uint64)
+        n = C.c_size_t(0)
+        self._chk(self.L.vbx_mesh_blocks(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         off.ctypes.data_as(C.POINTER(C.c_uint64)), nb.value, C.byref(n)))
+        idx = idx[:nb.value]
+        if not download:
+            return idx, off
+        v = np.zeros((max(nv.value, 1), 3), np.float32)
+        nn = np.zeros((max(nv.value, 1), 3), np.float32)
+        col = np.zeros((max(nv.value, 1), 4), np.uint8) if cfg.use_color else None
+        self._chk(self.L.vbx_mesh_download(self.h, v.ctypes.data_as(C.POINTER(C.c_float)),
+                                           nn.ctypes.data_as(C.POINTER(C.c_float)),
+                                           col.ctypes.data_as(C.POINTER(C.c_uint8)) if col is not None else None,
+                                           nv.value))
+        return idx, off, v[:nv.value], nn[:nv.value], (col[:nv.value] if col is not None else None)
 
     def esdf_integrator_clear(self):
         self._chk(self.L.vbx_esdf_integrator_clear(self.h))

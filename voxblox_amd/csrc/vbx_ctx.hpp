@@ -48,6 +48,11 @@ struct vbx_ctx {
   DBuf b_edist, b_estate, b_eraised, b_eactive;
   bool esdf_init = false;
   bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
+  // mesher output of the last vbx_mesh_generate call (vbx_host_mesh.hpp)
+  DBuf b_mesh_list, b_mesh_cnt, b_mesh_off, b_mesh_tab, b_mesh_verts, b_mesh_normals, b_mesh_colors;
+  std::vector<int32_t> mesh_idx;        // block index per meshed block
+  std::vector<uint32_t> mesh_off{0u};   // triangle offsets, one more than blocks
+  bool mesh_has_colors = false;
   uint32_t own_tag = 0;  // descending
   int own_s_bits = 0;
 

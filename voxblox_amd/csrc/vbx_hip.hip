@@ -46,11 +46,13 @@ using namespace vbx;
 #include "vbx_kernels_tsdf.hpp"
 #include "vbx_kernels_fast.hpp"
 #include "vbx_kernels_esdf.hpp"
+#include "vbx_kernels_mesh.hpp"
 #include "vbx_ctx.hpp"
 #include "vbx_sort.hpp"
 #include "vbx_host_common.hpp"
 #include "vbx_host_tsdf.hpp"
 #include "vbx_host_esdf.hpp"
+#include "vbx_host_mesh.hpp"
 
 // ---------------------------------------------------------------------------
 // C-ABI
@@ -832,6 +834,61 @@ int vbx_selftest_sort(vbx_ctx* ctx, uint32_t n, uint32_t begin_bit, uint32_t end
       return VBX_ERR_HIP;
     }
   }
+  return VBX_OK;
+}
+
+void vbx_mesh_cfg_default(vbx_mesh_cfg* cfg) {
+  if (!cfg) return;
+  cfg->use_color = 1;        // mesh_integrator.h:50
+  cfg->min_weight = 1e-4f;   // mesh_integrator.h:51
+}
+
+int vbx_mesh_generate(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_mesh_updated_blocks, int clear_updated_flag,
+                      size_t* n_blocks, size_t* n_vertices) {
+  if (!ctx || !cfg) return VBX_ERR_INVALID;
+  int rc = mesh_generate(ctx, cfg, only_mesh_updated_blocks, clear_updated_flag);
+  if (rc) return rc;
+  if (n_blocks) *n_blocks = ctx->mesh_off.size() - 1;
+  if (n_vertices) *n_vertices = (size_t)ctx->mesh_off.back() * 3;
+  return VBX_OK;
+}
+
+int vbx_mesh_blocks(vbx_ctx* ctx, int32_t* idx_xyz, uint64_t* vertex_offset, size_t cap, size_t* n) {
+  if (!ctx || !n) return VBX_ERR_INVALID;
+  const size_t nb = ctx->mesh_off.size() - 1;
+  *n = nb;
+  if (cap < nb) return idx_xyz || vertex_offset ? VBX_ERR_CAPACITY : VBX_OK;
+  if (idx_xyz && nb) std::memcpy(idx_xyz, ctx->mesh_idx.data(), nb * 12);
+  if (vertex_offset)
+    for (size_t i = 0; i <= nb; ++i) vertex_offset[i] = (uint64_t)ctx->mesh_off[i] * 3;
+  return VBX_OK;
+}
+
+int vbx_mesh_download(vbx_ctx* ctx, float* vertices, float* normals, uint8_t* rgba, size_t cap_vertices) {
+  if (!ctx) return VBX_ERR_INVALID;
+  const size_t nv = (size_t)ctx->mesh_off.back() * 3;
+  if (cap_vertices < nv) {
+    ctx->fail("vbx_mesh_download: room for %zu vertices, the mesh has %zu", cap_vertices, nv);
+    return VBX_ERR_CAPACITY;
+  }
+  if (rgba && !ctx->mesh_has_colors) {
+    ctx->fail("vbx_mesh_download: the last vbx_mesh_generate ran with use_color = 0");
+    return VBX_ERR_INVALID;
+  }
+  if (nv == 0) return VBX_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (vertices) HIP_TRY(hipMemcpyAsync(vertices, ctx->b_mesh_verts.p, nv * 12, hipMemcpyDeviceToHost, ctx->stream));
+  if (normals) HIP_TRY(hipMemcpyAsync(normals, ctx->b_mesh_normals.p, nv * 12, hipMemcpyDeviceToHost, ctx->stream));
+  if (rgba) HIP_TRY(hipMemcpyAsync(rgba, ctx->b_mesh_colors.p, nv * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VBX_OK;
+}
+
+int vbx_mesh_device_ptrs(vbx_ctx* ctx, const float** d_vertices, const float** d_normals, const uint8_t** d_rgba) {
+  if (!ctx) return VBX_ERR_INVALID;
+  if (d_vertices) *d_vertices = ctx->b_mesh_verts.as<float>();
+  if (d_normals) *d_normals = ctx->b_mesh_normals.as<float>();
+  if (d_rgba) *d_rgba = ctx->mesh_has_colors ? ctx->b_mesh_colors.as<uint8_t>() : nullptr;
   return VBX_OK;
 }
 
