@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--integrator", default="fast", choices=["fast", "merged", "simple"])
     ap.add_argument("--esdf", action="store_true",
                     help="BASELINE configs[3]: EsdfIntegrator::updateFromTsdfLayer(true) after every frame")
+    ap.add_argument("--mesh", action="store_true",
+                    help="MeshIntegrator::generateMesh(only_mesh_updated_blocks=true, clear_updated_flag=true) "
+                         "after every frame (SURVEY 8(f) #4), reported beside the integration")
     ap.add_argument("--scene", default="room", choices=["room", "cow"],
                     help="room = configs[1]/[3] stream; cow = configs[2] Cow-and-Lady-style orbit")
     ap.add_argument("--voxel", type=float, default=VOXEL,
@@ -100,6 +103,38 @@ def cpu_baseline(frames, kind, voxel=VOXEL):
                          if use_ref else "(oracle restatement), ")
                       + f"median frame {best['median_ms']} ms after 3 warm-up frames, "
                       f"best of integrator_threads in {{1,{min(cores, 8)},{cores}}} (host has {cores} hw threads)"}
+
+
+def cpu_mesh_baseline(frames, kind, voxel):
+    """The reference's MeshIntegrator (oracle/_ref when built, else the restatement) after every
+    frame of a short sample of the same stream: generateMesh(true, true), 1 thread and all cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes
+    import oracle_py as O
+    cores = os.cpu_count() or 1
+    use_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libvbxref.so"))
+    L = O.ref_lib() if use_ref else O.lib()
+    res = {}
+    for threads in (sorted({1, cores}) if use_ref else [1]):   # the restatement meshes on one thread
+        L.orc_fast_reset_counter_set(0)
+        m = O.OracleMap(voxel, 16, L=L)
+        c = O.TsdfCfg()
+        L.orc_tsdf_cfg_default(ctypes.byref(c))
+        c.default_truncation_distance = 4 * voxel
+        c.integrator_threads = cores
+        it = m.tsdf_integrator(kind, c)
+        ml = m.mesh_layer()
+        ts = []
+        for pose, pts, col in frames:
+            it.integrate(pose[0], pose[1], pts, col)
+            t0 = time.perf_counter()
+            ml.generate(True, True, threads=threads)
+            ts.append(time.perf_counter() - t0)
+        res[threads] = float(np.median(ts[2:]))
+        del ml, it, m
+    best = min(res, key=res.get)
+    return {"ms_per_update": round(res[best] * 1e3, 3), "cores": best, "kind": "reference" if use_ref else "port",
+            "sample": f"{len(frames)} frames, median after 2 warm-ups, best of integrator_threads in {sorted(res)}"}
 
 
 def main():
@@ -168,9 +203,23 @@ def main():
                     esdf_ms[0] += gm.timing()["total_ms"]
                     esdf_cnt.update({k: esdf_cnt.get(k, 0) + v for k, v in gm.counters().items() if k.startswith("esdf")})
                     last_tsdf[0] = (tt, cc)
+            if args.mesh:
+                tt = gm.timing() if (timing_on[0] and not args.esdf) else None
+                cc = gm.counters() if not args.esdf else None
+                tm0 = time.perf_counter()
+                midx, moff = gm.mesh_generate(mcfg, True, True, download=False)
+                if timing_on[0]:
+                    mesh_acc["s"] += time.perf_counter() - tm0
+                    mesh_acc["blocks"] += len(midx)
+                    mesh_acc["vertices"] += int(moff[-1])
+                    mesh_acc["calls"] += 1
+                    if not args.esdf:
+                        last_tsdf[0] = (tt, cc)
         else:
             sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n_i)
 
+    mcfg = capi.mesh_cfg()
+    mesh_acc = {"s": 0.0, "blocks": 0, "vertices": 0, "calls": 0}
     timing_on = [False]
     esdf_cnt = {}
     last_tsdf = [None]
@@ -198,7 +247,7 @@ def main():
         step(i)
         if sharded is not None and i < total - 1:
             continue   # per-stage figures from the last frame only: no extra calls between frames
-        t, c = last_tsdf[0] if (args.esdf and last_tsdf[0]) else (gm.timing(), gm.counters())
+        t, c = last_tsdf[0] if ((args.esdf or args.mesh) and last_tsdf[0]) else (gm.timing(), gm.counters())
         rep = args.steps if sharded is not None else 1
         for k, v in t.items():
             stage[k] = stage.get(k, 0.0) + v * rep
@@ -329,12 +378,22 @@ def main():
         if args.esdf:
             out["esdf"] = {"ms_per_update": round(esdf_ms[0] / K, 4),
                            "counters_per_update": {k: round(v / K, 1) for k, v in esdf_cnt.items()}}
+        if args.mesh and mesh_acc["calls"]:
+            n = mesh_acc["calls"]
+            out["mesh"] = {"ms_per_update": round(mesh_acc["s"] / n * 1e3, 4),
+                           "blocks_per_update": round(mesh_acc["blocks"] / n, 1),
+                           "vertices_per_update": round(mesh_acc["vertices"] / n, 1),
+                           "note": "host wall clock of vbx_mesh_generate (select + count + scan + emit + block table), "
+                                   "vertices left device-resident"}
+            if world == 1 and not args.no_cpu_baseline:
+                out["mesh"]["cpu_reference"] = cpu_mesh_baseline(frames[:12], args.integrator, voxel)
         if mirror:
             out["host_mirror"] = mirror
         if variants:
             out["variants"] = variants
         out["config"]["scene"] = args.scene
         out["config"]["esdf_after_each_frame"] = bool(args.esdf)
+        out["config"]["mesh_after_each_frame"] = bool(args.mesh)
         if world == 1 and not args.no_cpu_baseline:
             nf = args.cpu_frames or 40
             out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator, voxel)

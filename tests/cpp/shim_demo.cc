@@ -8,6 +8,7 @@
 
 #include "../../voxblox_amd/host/vbx_integrators.hpp"
 #include "../../voxblox_amd/host/vbx_io.hpp"
+#include "../../voxblox_amd/host/vbx_mesh.hpp"
 
 using namespace vbx_host;
 
@@ -58,6 +59,39 @@ int main() {
     std::printf("%s blocks=%zu observed=%zu sum_w=%.6f sum_d=%.6f\n", name.c_str(), blocks.size(), observed, sum_w,
                 sum_d);
     if (blocks.empty() || observed == 0) return 4;
+  }
+
+  // MeshIntegrator the way tsdf_server.cc:104-106 / :446-449 drives it: incremental, clearing kMesh
+  {
+    MeshLayer mesh_layer(tsdf.block_size());
+    MeshIntegratorConfig mesh_config;
+    MeshIntegrator<TsdfVoxel> mesh_integrator(mesh_config, &tsdf, &mesh_layer);
+    BlockIndexList flagged;
+    tsdf.getAllUpdatedBlocks(Update::kMesh, &flagged);
+    mesh_integrator.generateMesh(true, true);
+    BlockIndexList meshes, updated_meshes, still_flagged_mesh;
+    mesh_layer.getAllAllocatedMeshes(&meshes);
+    mesh_layer.getAllUpdatedMeshes(&updated_meshes);
+    tsdf.getAllUpdatedBlocks(Update::kMesh, &still_flagged_mesh);
+    size_t n_vert = 0;
+    double sum_z = 0;
+    for (const BlockIndex& b : meshes) {
+      const Mesh& mesh = mesh_layer.getMeshByIndex(b);
+      if (mesh.vertices.size() != mesh.normals.size() || mesh.vertices.size() != mesh.colors.size() ||
+          mesh.vertices.size() != mesh.indices.size() || mesh.vertices.size() % 3)
+        return 20;
+      n_vert += mesh.vertices.size();
+      for (const Point& v : mesh.vertices) sum_z += v.z;
+    }
+    std::printf("mesh blocks=%zu vertices=%zu mean_z=%.6f\n", meshes.size(), n_vert, n_vert ? sum_z / n_vert : 0.0);
+    // the wall is at z = 3: every vertex of the zero crossing lies within a voxel of it
+    if (meshes.size() != flagged.size() || updated_meshes.size() != meshes.size() || !still_flagged_mesh.empty() ||
+        n_vert == 0 || std::fabs(sum_z / n_vert - 3.0) > voxel)
+      return 21;
+    mesh_integrator.generateMesh(true, true);  // nothing flagged any more: the layer is unchanged
+    BlockIndexList again;
+    mesh_layer.getAllAllocatedMeshes(&again);
+    if (again.size() != meshes.size()) return 22;
   }
 
   EsdfIntegrator::Config esdf_config;

@@ -26,6 +26,8 @@ def test_shim_demo_matches_oracle(oracle):
         if m:
             got[m.group(1)] = (int(m.group(2)), int(m.group(3)), float(m.group(4)), float(m.group(5)))
     assert set(got) == {"simple", "merged", "fast"}
+    mesh_line = re.search(r"mesh blocks=(\d+) vertices=(\d+) mean_z=([-\d.]+)", out.stdout)
+    assert mesh_line, out.stdout
     # same cloud as tests/cpp/shim_demo.cc
     u, v = np.meshgrid(np.arange(64), np.arange(48))
     x = (u.reshape(-1) + 0.5 - 32) / 32.0
@@ -48,3 +50,12 @@ def test_shim_demo_matches_oracle(oracle):
         blocks, gobs, gsw, gsd = got[kind]
         assert blocks == len(d) and gobs == obs, (kind, got[kind], len(d), obs)
         assert abs(gsw - sw) <= 1e-5 * max(1.0, abs(sw)) and abs(gsd - sd) <= 1e-5 * max(1.0, abs(sd)), kind
+
+    # the mesh the shim's MeshIntegrator stored for the Fast layer == the oracle's MeshIntegrator
+    ml = m.mesh_layer()
+    ml.generate(True, True)
+    meshes = ml.as_dict()
+    n_vert = sum(v["vertices"].shape[0] for v in meshes.values())
+    mean_z = sum(float(v["vertices"][:, 2].astype(np.float64).sum()) for v in meshes.values()) / n_vert
+    assert int(mesh_line.group(1)) == len(meshes) and int(mesh_line.group(2)) == n_vert
+    assert abs(float(mesh_line.group(3)) - mean_z) < 1e-5

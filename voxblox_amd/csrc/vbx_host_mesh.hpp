@@ -35,7 +35,7 @@ int mesh_generate_t(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_updated, int
   d.block_size_inv = (float)(1.0 / (double)d.block_size);     // layer.h:41
   // pass 1 over every pool slot's worth of workgroups: the number of selected blocks is still on
   // the device, surplus workgroups leave at once
-  hipLaunchKernelGGL((k_mesh_block<VPS, false>), dim3(used), dim3(kMeshThreads), 0, s, m, d);
+  hipLaunchKernelGGL((k_mesh_block<VPS, false>), dim3(used), dim3(MeshThreads<VPS>::value), 0, s, m, d);
   rc = exclusive_scan_u32(ctx, ctx->b_mesh_cnt.as<uint32_t>(), ctx->b_mesh_off.as<uint32_t>(), n1);
   if (rc) return rc;
   const uint32_t* const ex[3] = {rank + used, ctx->b_mesh_off.as<uint32_t>() + used, nullptr};
@@ -50,7 +50,7 @@ int mesh_generate_t(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_updated, int
   d.verts = ctx->b_mesh_verts.as<float>();
   d.normals = ctx->b_mesh_normals.as<float>();
   d.colors = cfg->use_color ? ctx->b_mesh_colors.as<uint32_t>() : nullptr;
-  if (n_tri) hipLaunchKernelGGL((k_mesh_block<VPS, true>), dim3(n_list), dim3(kMeshThreads), 0, s, m, d);
+  if (n_tri) hipLaunchKernelGGL((k_mesh_block<VPS, true>), dim3(n_list), dim3(MeshThreads<VPS>::value), 0, s, m, d);
   int32_t* tab_idx = ctx->b_mesh_tab.as<int32_t>();
   uint32_t* tab_off = reinterpret_cast<uint32_t*>(tab_idx + 3 * n1);
   hipLaunchKernelGGL(k_mesh_finish, grid_for((size_t)n_list + 1), dim3(256), 0, s, m, d, clear_flag, tab_idx, tab_off);

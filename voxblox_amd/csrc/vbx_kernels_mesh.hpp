@@ -3,7 +3,7 @@
 //
 // One workgroup per selected TSDF block.  The block's distances and the one-voxel shell it
 // shares with its seven +x/+y/+z neighbours are staged in LDS as a (VPS+1)^3 tile (NaN = corner
-// not usable: weight <= min_weight or block absent), every thread owns VPS^3/256 consecutive
+// not usable: weight <= min_weight or block absent), every thread owns a few consecutive
 // cubes *in the reference's emission order* (interior x-outer/z-inner, then the max-X, max-Y
 // and max-Z planes, mesh_integrator.h:197-248), and a workgroup scan turns the per-cube triangle
 // counts into output positions, so a block's vertex list is the reference's, element by element.
@@ -14,7 +14,9 @@
 
 namespace {
 
-constexpr int kMeshThreads = 256;
+// threads per workgroup: an incremental update meshes ~100 blocks on 256 CUs, so the time is one
+// workgroup's latency; 1024 threads (4 cubes each at VPS = 16) cut it 3x against 256
+template <int VPS> struct MeshThreads { static constexpr int value = VPS >= 16 ? 1024 : 256; };
 
 struct MeshDev {  // by-value kernel argument
   const uint32_t* list;   // selected pool slots
@@ -91,13 +93,14 @@ __device__ inline void mesh_rank_to_voxel(int r, int* x, int* y, int* z) {
 }
 
 template <int VPS, bool EMIT>
-__global__ void __launch_bounds__(kMeshThreads) k_mesh_block(MapDev m, MeshDev d) {
+__global__ void __launch_bounds__(MeshThreads<VPS>::value) k_mesh_block(MapDev m, MeshDev d) {
+  constexpr int kMeshThreads = MeshThreads<VPS>::value;
   constexpr int T = VPS + 1, NT = T * T * T, NV = VPS * VPS * VPS;
   constexpr int RPT = NV / kMeshThreads;  // cubes per thread, consecutive in emission order
   static_assert(NV % kMeshThreads == 0, "block size");
   __shared__ float sdf[NT];
   __shared__ uint32_t nslot[8];
-  __shared__ uint32_t wsum[kMeshThreads];
+  __shared__ uint32_t wsum[64];
   if (blockIdx.x >= *d.n_list) return;
   const uint32_t slot = d.list[blockIdx.x];
   const int tid = threadIdx.x;
@@ -142,20 +145,32 @@ __global__ void __launch_bounds__(kMeshThreads) k_mesh_block(MapDev m, MeshDev d
     cfg[k] = (uint8_t)c;
     mine += (uint32_t)(vbx_mc::kMcTriTable[c] >> 60);
   }
-  // exclusive scan of the per-thread totals
-  wsum[tid] = mine;
-  __syncthreads();
-  for (int o = 1; o < kMeshThreads; o <<= 1) {
-    const uint32_t add = tid >= o ? wsum[tid - o] : 0;
-    __syncthreads();
-    wsum[tid] += add;
-    __syncthreads();
+  // exclusive scan of the per-thread totals: shuffles inside each wave, the wave totals through LDS
+  constexpr int NW = kMeshThreads / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (tid < 64) {
+    uint32_t w = tid < NW ? wsum[tid] : 0;
+#pragma unroll
+    for (int o = 1; o < NW; o <<= 1) {
+      const uint32_t up = __shfl_up(w, o, 64);
+      if (tid >= o) w += up;
+    }
+    if (tid < NW) wsum[tid] = w;
+  }
+  __syncthreads();
   if (!EMIT) {
-    if (tid == kMeshThreads - 1) d.tri_count[blockIdx.x] = wsum[tid];
+    if (tid == 0) d.tri_count[blockIdx.x] = wsum[NW - 1];
     return;
   }
-  uint32_t tri = d.tri_off[blockIdx.x] + wsum[tid] - mine;
+  uint32_t tri = d.tri_off[blockIdx.x] + (wave ? wsum[wave - 1] : 0u) + incl - mine;
 
   const f3 origin = {(float)bx * d.block_size, (float)by * d.block_size, (float)bz * d.block_size};  // layer.h:136-139
 #pragma unroll 1
