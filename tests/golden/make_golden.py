@@ -33,6 +33,8 @@ def main():
         if sc.get("esdf") is not None:
             rec["esdf"] = S.digest_esdf(m.esdf_dict())
             rec["esdf_no_parents"] = S.digest_esdf(m.esdf_dict(), with_parents=False)
+        if sc.get("mesh") is not None:
+            rec["mesh"] = S.digest_mesh(m.mesh.as_dict())
         out["scenarios"][name] = rec
         print(name, rec)
     with open(os.path.join(HERE, "reference_digests.json"), "w") as f:

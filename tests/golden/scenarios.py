@@ -32,6 +32,12 @@ SCENARIOS = {
     "esdf_robot_spheres": dict(kind="merged", voxel=0.1, n=4, cfg={},
                                esdf=dict(mode="incremental", robot=True,
                                          cfg=dict(clear_sphere_radius=0.6, occupied_sphere_radius=1.6))),
+    # mesh: None | dict(incremental: generateMesh(true, true) after every frame, else one full
+    # generateMesh(false, false) at the end; use_color; min_weight)
+    "mesh_merged_incremental": dict(kind="merged", voxel=0.1, n=4, cfg={}, mesh=dict(incremental=True)),
+    "mesh_fast_0p05_incremental": dict(kind="fast", voxel=0.05, n=3, cfg={}, mesh=dict(incremental=True)),
+    "mesh_simple_full_no_color": dict(kind="simple", voxel=0.1, n=2, cfg={},
+                                      mesh=dict(incremental=False, use_color=False, min_weight=0.02)),
 }
 
 
@@ -55,15 +61,41 @@ def run_on_oracle_api(O, L, sc):
         for k, v in es.get("cfg", {}).items():
             setattr(ec, k, v)
         e = m.esdf_integrator(ec)
+    ms = sc.get("mesh")
+    ml = m.mesh_layer() if ms is not None else None
+    mkw = dict(use_color=ms.get("use_color", True), min_weight=ms.get("min_weight", 1e-4)) if ms is not None else {}
+    m.mesh = ml
     for pose, pts, col in frames(sc["n"]):
         it.integrate(pose[0], pose[1], pts, col)
+        if ml is not None and ms["incremental"]:
+            ml.generate(True, True, **mkw)
         if e is not None and es.get("robot"):
             e.add_new_robot_position(pose[0])
         if e is not None and es["mode"] == "incremental":
             e.update_from_tsdf_layer(True)
     if e is not None and es["mode"] == "batch":
         e.update_from_tsdf_layer_batch()
+    if ml is not None and not ms["incremental"]:
+        ml.generate(False, False, **mkw)
     return m
+
+
+def digest_mesh(d):
+    """d: {(bx,by,bz): dict(vertices f32[n,3], normals f32[n,3], colors u8[m,4] | None)} (Mesh::indices is
+    0..n-1 by construction and checked separately)."""
+    h = hashlib.sha256()
+    n_vert = 0
+    for k in sorted(d):
+        x = d[k]
+        col = x.get("colors")
+        h.update(np.asarray(k, np.int32).tobytes())
+        h.update(np.asarray([x["vertices"].shape[0], 0 if col is None else col.shape[0]], np.int64).tobytes())
+        h.update(np.ascontiguousarray(x["vertices"], np.float32).tobytes())
+        h.update(np.ascontiguousarray(x["normals"], np.float32).tobytes())
+        if col is not None and col.shape[0]:
+            h.update(np.ascontiguousarray(col, np.uint8).tobytes())
+        n_vert += int(x["vertices"].shape[0])
+    return {"blocks": len(d), "vertices": n_vert, "sha256": h.hexdigest()}
 
 
 def digest_tsdf(d):

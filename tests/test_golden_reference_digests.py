@@ -4,7 +4,8 @@ tests/golden/make_golden.py from the real voxblox sources compiled as oracle/_re
    colours, flags, parents, updated bits;
  * on the HIP path (-m gpu): the scenarios where the HIP path reproduces the unswitched 1-thread
    reference bit for bit: all three TSDF integrators (Merged with the reference's bundle order,
-   Fast with the reference's approximate observed-voxel set).
+   Fast with the reference's approximate observed-voxel set), and the mesher's vertex / normal /
+   colour arrays per block.
 Unlike tests/test_oracle_vs_reference_build.py this needs neither /root/reference nor the prebuilt
 reference library."""
 import json
@@ -30,6 +31,11 @@ def test_oracle_reproduces_reference_digest(oracle, name):
     assert S.digest_tsdf(m.tsdf_dict()) == GOLD[name]["tsdf"]
     if "esdf" in GOLD[name]:
         assert S.digest_esdf(m.esdf_dict()) == GOLD[name]["esdf"]
+    if "mesh" in GOLD[name]:
+        meshes = m.mesh.as_dict()
+        assert S.digest_mesh(meshes) == GOLD[name]["mesh"]
+        import numpy as np
+        assert all(np.array_equal(v["indices"], np.arange(v["vertices"].shape[0], dtype=np.uint64)) for v in meshes.values())
 
 
 @pytest.mark.gpu
@@ -44,7 +50,25 @@ def test_hip_tsdf_integrators_reproduce_reference_digest(name):
     sc = S.SCENARIOS[name]
     gm = capi.Map(sc["voxel"], 16, max_blocks=2048)
     cfg = capi.tsdf_cfg(default_truncation_distance=4 * sc["voxel"], **sc["cfg"])
+    ms = sc.get("mesh") or {}
+    mcfg = capi.mesh_cfg(use_color=int(ms.get("use_color", True)), min_weight=ms.get("min_weight", 1e-4))
+    meshes = {}
     for pose, pts, col in S.frames(sc["n"]):
         gm.integrate({"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[sc["kind"]], cfg,
                      pose[0], pose[1], pts, col)
+        if sc.get("mesh") is not None and sc["mesh"]["incremental"]:
+            _store_mesh(meshes, gm.mesh_generate(mcfg, True, True))
+    if sc.get("mesh") is not None:
+        if not sc["mesh"]["incremental"]:
+            flagged = S.digest_tsdf(gm.tsdf_dict())
+            _store_mesh(meshes, gm.mesh_generate(mcfg, False, False))
+            assert S.digest_tsdf(gm.tsdf_dict()) == flagged          # clear_updated_flag = false: layer untouched
+        assert S.digest_mesh(meshes) == GOLD[name]["mesh"]
     assert S.digest_tsdf(gm.tsdf_dict()) == GOLD[name]["tsdf"]
+
+
+def _store_mesh(store, result):
+    idx, off, v, n, c = result
+    for i, b in enumerate(idx):
+        a, e = int(off[i]), int(off[i + 1])
+        store[tuple(int(x) for x in b)] = dict(vertices=v[a:e], normals=n[a:e], colors=None if c is None else c[a:e])
