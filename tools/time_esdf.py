@@ -6,7 +6,7 @@ from voxblox_amd import capi, scenes
 dev = torch.device("cuda", 0)
 gm = capi.Map(0.05, 16, max_blocks=8192)
 cfg = capi.tsdf_cfg(default_truncation_distance=0.2)
-ecfg = capi.esdf_cfg(min_distance_m=0.1)
+ecfg = capi.esdf_cfg(min_distance_m=0.1, full_euclidean_distance=int('--full' in sys.argv))
 frames = [scenes.room_frame(k, 100) for k in range(30)]
 d = [(p, torch.from_numpy(a).to(dev), torch.from_numpy(c).to(dev)) for p, a, c in frames]
 for timing in (False, True):

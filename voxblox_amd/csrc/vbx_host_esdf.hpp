@@ -46,13 +46,35 @@ int esdf_ensure(vbx_ctx* ctx) {
   return VBX_OK;
 }
 
-template <int VPS>
+template <int VPS, bool FULL>
 int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, uint32_t used,
                uint32_t* sweeps) {
   hipStream_t s = ctx->stream;
   HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
+  if (FULL && mode == 1) {
+    // one block colour per launch (see k_esdf_tile); a round of all eight colours without a
+    // change is the fixed point
+    uint32_t sub = 0;
+    for (;;) {
+      for (int i = 0; i < 8; ++i) {
+        ++sub;
+        hipLaunchKernelGGL((k_esdf_tile<VPS, true>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, 1, sub,
+                           ctx->d_state);
+        hipLaunchKernelGGL(k_esdf_rotate_active_colour, grid_for(used), dim3(256), 0, s, ctx->map, e, used,
+                           (int)(sub & 7u));
+      }
+      int rc = sync_state(ctx);
+      if (rc) return rc;
+      *sweeps += 1;
+      if (ctx->h_state.changed + 8 <= sub) return VBX_OK;
+      if (sub > 800000) {
+        ctx->fail("ESDF: wavefront did not converge");
+        return VBX_ERR_HIP;
+      }
+    }
+  }
   if (mode == 2) {
-    hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, 1u, ctx->d_state);
+    hipLaunchKernelGGL((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, 1u, ctx->d_state);
     ++*sweeps;
     return VBX_OK;
   }
@@ -64,7 +86,7 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
     constexpr int kPerCheck = 3;
     for (int i = 0; i < kPerCheck; ++i) {
       ++sweep_no;
-      hipLaunchKernelGGL(k_esdf_tile<VPS>, dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, sweep_no,
+      hipLaunchKernelGGL((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, sweep_no,
                          ctx->d_state);
       hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
     }
@@ -82,7 +104,7 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
   }
 }
 
-template <int VPS>
+template <int VPS, bool FULL>
 int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag,
                   const int32_t* list = nullptr, size_t n_list = 0, int list_incremental = 0) {
   MapDev& m = ctx->map;
@@ -141,16 +163,18 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   cr.min_diff = 0.0f;
   if (ctx->h_state.esdf_blocks || robot_pending) {
     if (ctx->h_state.esdf_raise_any || robot_pending) {
-      rc = esdf_phase<VPS>(ctx, e, cr, 0, used, &sweeps);
+      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 0, used, &sweeps);
       if (rc) return rc;
       hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
     }
     tmark(ctx, 3);
-    rc = esdf_phase<VPS>(ctx, e, cr, 1, used, &sweeps);
+    rc = esdf_phase<VPS, FULL>(ctx, e, cr, 1, used, &sweeps);
     if (rc) return rc;
     hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
-    rc = esdf_phase<VPS>(ctx, e, cr, 2, used, &sweeps);
-    if (rc) return rc;
+    if (!FULL) {  // full-Euclidean parents are part of the state, not a by-product to canonicalise
+      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 2, used, &sweeps);
+      if (rc) return rc;
+    }
     tmark(ctx, 6);
     if (ctx->h_state.esdf_raise_any || robot_pending) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
   }
@@ -223,13 +247,20 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
 int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag,
                 const int32_t* list = nullptr, size_t n_list = 0, int list_incremental = 0) {
   HIP_TRY(hipSetDevice(ctx->device));
-  if (cfg->full_euclidean_distance) {
-    ctx->fail("ESDF: full_euclidean_distance is not supported yet (quasi-Euclidean only)");
+  const bool full = cfg->full_euclidean_distance != 0;
+  if (full && !(cfg->max_distance_m / ctx->map.voxel_size < 120.0f)) {
+    // parent vectors are kept as int8 per component (the range Block::serializeToIntegers keeps,
+    // block.cc:27-32); a wavefront stops at max_distance_m, so that bounds the components
+    ctx->fail("ESDF: full_euclidean_distance needs max_distance_m / voxel_size < 120 (int8 parent vectors)");
     return VBX_ERR_UNSUPPORTED;
   }
   switch (ctx->map.vps) {
-    case 8: return esdf_update_t<8>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
-    case 16: return esdf_update_t<16>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
+    case 8:
+      return full ? esdf_update_t<8, true>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental)
+                  : esdf_update_t<8, false>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
+    case 16:
+      return full ? esdf_update_t<16, true>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental)
+                  : esdf_update_t<16, false>(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
     default:
       ctx->fail("ESDF: voxels_per_side must be 8 or 16 (LDS tile)");
       return VBX_ERR_UNSUPPORTED;

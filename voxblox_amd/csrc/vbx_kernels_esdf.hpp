@@ -224,6 +224,20 @@ __global__ void k_esdf_seed_active(MapDev m, EsdfDev e, uint32_t n_slots) {
                                                  m.blk_idx[3 * slot + 2] + dz));
   if (s2 != kInvalidSlot && (m.blk_flags[s2] & kFlagEsdfAlloc)) atomicOr(&e.active[s2], 1u | 4u);
 }
+// block colour = parity of the block index per axis: blocks of one colour are never 26-adjacent
+__device__ inline int esdf_block_colour(const MapDev& m, uint32_t slot) {
+  return (m.blk_idx[3 * slot] & 1) | ((m.blk_idx[3 * slot + 1] & 1) << 1) | ((m.blk_idx[3 * slot + 2] & 1) << 2);
+}
+// the same after one colour's launch of the full-Euclidean lower phase: blocks of the other
+// colours have not run yet and stay scheduled
+__global__ void k_esdf_rotate_active_colour(MapDev m, EsdfDev e, uint32_t n_slots, int colour) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint32_t a = e.active[s];
+  uint32_t cur = (a & 2u) ? 1u : 0u;
+  if ((m.blk_flags[s] & kFlagEsdfAlloc) && esdf_block_colour(m, s) != colour) cur |= (a & 1u);
+  e.active[s] = cur | (a & 12u) | (cur ? 4u : 0u);
+}
 __global__ void k_esdf_rotate_active(EsdfDev e, uint32_t n_slots, int reseed) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
@@ -239,7 +253,14 @@ __global__ void k_esdf_rotate_active(EsdfDev e, uint32_t n_slots, int reseed) {
 //   mode 1: processOpenSet (:371-496) as a pull relaxation over the 26-neighbourhood.
 //   mode 2: parent = first LUT neighbour that explains the converged distance exactly.
 constexpr int kEsdfThreads = 1024;  // one workgroup relaxes one block; big frontiers need the lanes
-template <int VPS>
+// FULL = Config::full_euclidean_distance: parents are accumulated vectors to the source voxel and a
+// step costs voxel_size * (|parent - direction| - |parent|) (esdf_integrator.cc:419-428).  The
+// result of that propagation depends on the path (the reference's on its queue order), so this
+// variant is made race-free and deterministic instead of chaotic: the lower phase runs one block
+// colour (parity of the block index, 8 colours) per launch, so no two adjacent blocks are relaxed
+// concurrently, and inside the tile every iteration evaluates all queued voxels against the
+// previous iteration's state before any of them is written (Jacobi).
+template <int VPS, bool FULL>
 __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
                                                    uint32_t sweep_no, DevState* st) {
   constexpr int T = VPS + 2;
@@ -255,6 +276,7 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
   const uint32_t slot = blockIdx.x;
   if (!(m.blk_flags[slot] & kFlagEsdfAlloc)) return;
   if (!(e.active[slot] & 1u)) return;
+  if (FULL && mode == 1 && esdf_block_colour(m, slot) != (int)(sweep_no & 7u)) return;
   const int tid = threadIdx.x;
   if (tid < 27) {
     const int dx = tid % 3 - 1, dy = (tid / 3) % 3 - 1, dz = tid / 9 - 1;
@@ -291,13 +313,14 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
   const float sq2 = (float)1.4142135623730951, sq3 = (float)1.7320508075688772;
   bool any_change = false;
 
-  // processOpenSet for one voxel (pull form): returns true if the voxel was lowered.
-  auto relax = [&](int t) -> bool {
+  // processOpenSet for one voxel (pull form): the best value its neighbours offer; true if it
+  // lowers the voxel.
+  auto relax_eval = [&](int t, float* d_out, uint32_t* s_out) -> bool {
     const uint32_t s = s_s[t];
     if (!(s & kEsdfObserved) || (s & kEsdfFixed)) return false;
     float d = s_d[t];
     bool upd = false;
-    int best = -1;
+    uint32_t best_parent = 0;
     // fully unrolled: the 52 LDS reads of one voxel issue back to back
 #pragma unroll
     for (int i = 0; i < 26; ++i) {
@@ -306,11 +329,23 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
       if (!(sv & kEsdfObserved)) continue;
       const float dv = s_d[tv];
       if (dv >= c.max_distance || dv <= -c.max_distance) continue;
-      const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
+      float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
+      uint32_t parent = pack_parent(kNbOff[i][0], kNbOff[i][1], kNbOff[i][2]);  // -direction: toward the pusher
+      if (FULL) {
+        // new_parent = voxel->parent - direction; the step costs the growth of the parent vector
+        int px, py, pz;
+        unpack_parent(sv, &px, &py, &pz);
+        const int nx = px + kNbOff[i][0], ny = py + kNbOff[i][1], nz = pz + kNbOff[i][2];
+        const float nn = sqrtf((float)nx * (float)nx + ((float)ny * (float)ny + (float)nz * (float)nz));
+        const float pn = sqrtf((float)px * (float)px + ((float)py * (float)py + (float)pz * (float)pz));
+        dist = c.voxel_size * (nn - pn);
+        if (dist < 0.0f) continue;
+        parent = pack_parent(nx, ny, nz);
+      }
       if (dv > 0 && d > 0) {
-        if (dv + dist + c.min_diff < d) { d = dv + dist; best = i; upd = true; }
+        if (dv + dist + c.min_diff < d) { d = dv + dist; best_parent = parent; upd = true; }
       } else if (dv <= 0 && d <= 0) {
-        if (dv - dist - c.min_diff > d) { d = dv - dist; best = i; upd = true; }
+        if (dv - dist - c.min_diff > d) { d = dv - dist; best_parent = parent; upd = true; }
       } else {
         // sign mismatch (esdf_integrator.cc:459-488).  In the reference this assignment is
         // gated by |potential - d| > dist and its outcome depends on the pop order of the two
@@ -321,12 +356,20 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
         float cand;
         if ((float)signum(potential) == d) cand = potential;
         else cand = (float)signum(d) * dist;
-        if (fabsf(cand) < fabsf(d)) { d = cand; best = i; upd = true; }
+        if (fabsf(cand) < fabsf(d)) { d = cand; best_parent = parent; upd = true; }
       }
     }
+    *d_out = d;
+    *s_out = (s & 0xFFu) | best_parent;
+    return upd;
+  };
+  auto relax = [&](int t) -> bool {
+    float d;
+    uint32_t s;
+    const bool upd = relax_eval(t, &d, &s);
     if (upd) {
       s_d[t] = d;
-      s_s[t] = (s & 0xFFu) | pack_parent(c_nb_off[best][0], c_nb_off[best][1], c_nb_off[best][2]);
+      s_s[t] = s;
     }
     return upd;
   };
@@ -359,12 +402,37 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
       __syncthreads();
       const int qn = s_qn;
       if (qn == 0) break;
-      for (int q = tid; q < qn; q += kEsdfThreads) {
-        const int t = s_q[q];
-        if (relax(t)) {
+      if (FULL) {
+        // Jacobi: NV / kEsdfThreads queue entries per thread at most, evaluated against the state
+        // of the previous iteration, written after the barrier
+        constexpr int PER = (NV + kEsdfThreads - 1) / kEsdfThreads;
+        float nd[PER];
+        uint32_t ns[PER];
+        bool up[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          const int q = tid + k * kEsdfThreads;
+          up[k] = q < qn && relax_eval(s_q[q], &nd[k], &ns[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          if (!up[k]) continue;
+          const int t = s_q[tid + k * kEsdfThreads];
+          s_d[t] = nd[k];
+          s_s[t] = ns[k];
           any_change = true;
 #pragma unroll
           for (int i = 0; i < 26; ++i) s_need[t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2])] = 1;
+        }
+      } else {
+        for (int q = tid; q < qn; q += kEsdfThreads) {
+          const int t = s_q[q];
+          if (relax(t)) {
+            any_change = true;
+#pragma unroll
+            for (int i = 0; i < 26; ++i) s_need[t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2])] = 1;
+          }
         }
       }
       __syncthreads();
@@ -382,6 +450,15 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
         int px, py, pz;
         unpack_parent(s, &px, &py, &pz);
         if ((px | py | pz) == 0 || s_r[t]) continue;
+        if (FULL) {
+          // esdf_integrator.cc:340-348: the parent *direction*, parent.normalized() rounded per
+          // component (std::round), has to point at the raised voxel
+          const f3 dir = f3_normalized(f3{(float)px, (float)py, (float)pz});
+          px = (int)roundf(dir.x);
+          py = (int)roundf(dir.y);
+          pz = (int)roundf(dir.z);
+          if ((px | py | pz) == 0) continue;
+        }
         // quasi-Euclidean parents are unit LUT offsets, so the parent voxel is inside the halo
         const int tp = t + px + T * (py + T * pz);
         if (s_r[tp]) {
