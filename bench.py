@@ -385,6 +385,17 @@ def main():
                            "vertices_per_update": round(mesh_acc["vertices"] / n, 1),
                            "note": "host wall clock of vbx_mesh_generate (select + count + scan + emit + block table), "
                                    "vertices left device-resident"}
+            # what a host MeshLayer consumer pays on top: the same call plus the copy of the arrays
+            timing_on[0] = False
+            td = 0.0
+            for j in range(8):
+                pose, dp, dc = d_frames[(total + j) % len(d_frames)]
+                gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(),
+                                    n_pts_all[(total + j) % len(d_frames)])
+                tm0 = time.perf_counter()
+                res = gm.mesh_generate(mcfg, True, True, download=True)
+                td += time.perf_counter() - tm0
+            out["mesh"]["ms_per_update_with_download"] = round(td / 8 * 1e3, 4)
             if world == 1 and not args.no_cpu_baseline:
                 out["mesh"]["cpu_reference"] = cpu_mesh_baseline(frames[:12], args.integrator, voxel)
         if mirror:

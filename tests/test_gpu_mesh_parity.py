@@ -106,3 +106,47 @@ def test_mesh_vps8_and_empty_map(oracle):
     store = {}
     _apply(store, gm.mesh_generate(None, True, True))
     assert _compare(store, ml.as_dict()) > 1000
+
+
+def test_mesh_full_frames_configs1(oracle):
+    """BASELINE configs[1] size: two full 640x480 frames, Fast integrator at 0.05 m, incremental
+    meshing after each — every vertex, normal and colour bit-exact."""
+    frames = [scenes.room_frame(k, 100) for k in (0, 1)]
+    om, oi, gm, k, gcfg = _layers(oracle, "fast", 0.05, frames)
+    ml = om.mesh_layer()
+    store = {}
+    for pose, pts, col in frames:
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(k, gcfg, pose[0], pose[1], pts, col)
+        ml.generate(True, True)
+        _apply(store, gm.mesh_generate(None, True, True))
+    assert _compare(store, ml.as_dict()) > 50000
+
+
+def test_mesh_api_errors():
+    from voxblox_amd import capi
+    import ctypes as C
+    gm = capi.Map(0.1, 16, max_blocks=256)
+    pose, pts, col = scenes.room_frame(0, 100, f=80.0, width=160, height=120)
+    gm.integrate(capi.TSDF_MERGED, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
+    nb, nv = C.c_size_t(0), C.c_size_t(0)
+    cfg = capi.mesh_cfg(use_color=0)
+    assert gm.L.vbx_mesh_generate(gm.h, C.byref(cfg), 1, 0, C.byref(nb), C.byref(nv)) == capi.VBX_OK
+    assert nb.value > 0 and nv.value > 0 and nv.value % 3 == 0
+    n = C.c_size_t(0)
+    # the count is always reported; a short table is a capacity error
+    assert gm.L.vbx_mesh_blocks(gm.h, None, None, 0, C.byref(n)) == capi.VBX_OK and n.value == nb.value
+    idx = np.zeros((1, 3), np.int32)
+    off = np.zeros(2, np.uint64)
+    assert gm.L.vbx_mesh_blocks(gm.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                1, C.byref(n)) == capi.VBX_ERR_CAPACITY
+    v = np.zeros((nv.value, 3), np.float32)
+    assert gm.L.vbx_mesh_download(gm.h, v.ctypes.data_as(C.POINTER(C.c_float)), None, None, nv.value - 1) == capi.VBX_ERR_CAPACITY
+    rgba = np.zeros((nv.value, 4), np.uint8)   # colours were not produced by this call
+    assert gm.L.vbx_mesh_download(gm.h, None, None, rgba.ctypes.data_as(C.POINTER(C.c_uint8)), nv.value) == capi.VBX_ERR_INVALID
+    assert gm.L.vbx_mesh_download(gm.h, v.ctypes.data_as(C.POINTER(C.c_float)), None, None, nv.value) == capi.VBX_OK
+    assert np.isfinite(v).all() and np.abs(v).max() < 10.0
+    # clear_updated_flag = 0 left the kMesh bits: the same call again gives the same mesh
+    nb2, nv2 = C.c_size_t(0), C.c_size_t(0)
+    assert gm.L.vbx_mesh_generate(gm.h, C.byref(cfg), 1, 0, C.byref(nb2), C.byref(nv2)) == capi.VBX_OK
+    assert (nb2.value, nv2.value) == (nb.value, nv.value)

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvbx_hip.so")
 
 VBX_OK = 0
+VBX_ERR_INVALID, VBX_ERR_HIP, VBX_ERR_CAPACITY, VBX_ERR_UNSUPPORTED = -1, -2, -3, -4   # include/vbx_hip.h:30-33
 TSDF_SIMPLE, TSDF_MERGED, TSDF_FAST = 1, 2, 3
 LAYER_TSDF, LAYER_ESDF = 0, 1
 UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
