@@ -278,6 +278,9 @@ def main():
             torch.cuda.synchronize()
             tb = time.perf_counter()
             upd = gm.blocks_updated(capi.UPDATE_MAP)
+            if len(upd) > staging.shape[0]:     # finer voxels touch more blocks: grow the staging (outside the clock)
+                staging = gm.pinned_voxels(len(upd) * 5 // 4)
+                tb = time.perf_counter()
             vox, bits, hd = gm.blocks_download(upd, out=staging)
             gm.clear_updated(capi.UPDATE_MAP)
             tc = time.perf_counter()
@@ -339,7 +342,7 @@ def main():
         # whole sweep sequence, timed with HIP events on the launch stream inside the library
         # (vbx_get_timing solve_ms) and averaged over the K timed frames.  The per-launch average
         # (kernel_ms / launches_per_step) is the number to compare with rocprofv3's avg duration
-        # (profiles/r01c_kernel_stats.md).  Algorithmic bytes per frame:
+        # (profiles/r01d_kernel_stats.md).  Algorithmic bytes per frame:
         #   16 B x N_points + 24 B x U (distinct voxels updated), U counted on the device.
         U = counters.get("voxels_touched", 0) / K
         alg_bytes = 16.0 * n_pts + 24.0 * U
@@ -354,10 +357,10 @@ def main():
                     "replay_ms": 2.0 * counters.get("replay_rounds", 0) / K}.get(dom, 1.0)   # 2 sort passes per round
         launches = max(launches, 1.0)
         # HBM bytes of that kernel per frame from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-        # runs, profiles/r01c_pmc_hbm_traffic.json); null when no summary for this kernel exists.
+        # runs, profiles/r01d_pmc_hbm_traffic.json); null when no summary for this kernel exists.
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.json")))["per_frame_bytes"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")))["per_frame_bytes"]
             if args.integrator == "fast" and args.scene == "room" and kname in pmc:
                 traffic = int(pmc[kname]["fetch_bytes"] + pmc[kname]["write_bytes"])
         except (OSError, KeyError, ValueError):
