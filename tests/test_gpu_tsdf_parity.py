@@ -254,3 +254,60 @@ def test_edge_case_clouds(oracle, kind):
     oi.integrate(pose[0], pose[1], pts, col)
     gm.integrate(k, gcfg, pose[0], pose[1], pts, col)
     compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_axis_parallel_rays_quirk_q4(oracle, kind):
+    """SURVEY Q4: `std::abs(x) < 0.0` never holds (integrator_utils.cc:160-178), so a ray component
+    that is exactly 0 divides by zero: t_step = NaN, t_to_next = -inf / +inf / NaN, and Eigen's
+    first-wins minCoeff decides what the walk does (frozen on the start voxel, or one duplicate
+    emission and a ray that ends a voxel short).  Exactly axis-parallel rays from a sensor at a voxel
+    centre / on a voxel face / on a voxel edge: the HIP ray caster replays the same IEEE arithmetic."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    ocfg, gcfg = _cfgs(oracle, 4 * voxel)
+    k = {"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[kind]
+    q = np.array([1, 0, 0, 0], np.float32)
+    dirs = np.array([[0, 0, 2.0], [0, 0, -1.5], [1.7, 0, 0], [-2.2, 0, 0], [0, 1.3, 0], [0, -0.9, 0],   # one non-zero
+                     [1.2, 1.2, 0], [0, -1.1, 2.3], [1.9, 0, -0.7],                                     # two non-zero
+                     [0.4, 0.3, 2.0]], np.float32)                                                      # generic
+    for pos in ([0.05, 0.05, 0.05], [0.0, 0.0, 0.0], [0.1, 0.25, -0.3], [-0.35, 0.2, 0.15]):
+        oracle.lib().orc_fast_reset_counter_set(0)
+        om = oracle.OracleMap(voxel, 16)
+        oi = om.tsdf_integrator(kind, ocfg)
+        gm = capi.Map(voxel, 16, max_blocks=2048)
+        pos = np.array(pos, np.float32)
+        col = np.full((dirs.shape[0], 4), 200, np.uint8)
+        for rep in range(2):
+            oi.stats(reset=True)
+            oi.integrate(pos, q, dirs, col)
+            gm.integrate(k, gcfg, pos, q, dirs, col)
+        g, r = gm.tsdf_dict(), om.tsdf_dict()
+        assert set(g) == set(r), (pos, sorted(set(g) ^ set(r)))
+        compare_tsdf(g, r, exact=True)
+        if kind != "fast":   # the frozen / shortened walks visit the same number of voxels
+            assert gm.counters()["voxel_updates"] == oi.stats()["voxel_updates"]
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_non_finite_points_are_dropped(oracle, kind):
+    """NaN / inf points reach the reference only when a caller skips the finite filter of
+    conversions.h:135-137, and then read uninitialised RayCaster members; oracle and HIP path both
+    treat them as dropped points.  The finite points around them integrate as usual."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    ocfg, gcfg = _cfgs(oracle, 4 * voxel)
+    k = {"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[kind]
+    pose, pts, col = _small_room(2)
+    pts = pts.copy()
+    pts[5] = [np.nan, 0.1, 1.0]
+    pts[77] = [0.3, np.inf, 2.0]
+    pts[300] = [np.nan, np.nan, np.nan]
+    pts[1000] = [0.2, 0.1, -np.inf]
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator(kind, ocfg)
+    gm = capi.Map(voxel, 16, max_blocks=2048)
+    oi.integrate(pose[0], pose[1], pts, col)
+    gm.integrate(k, gcfg, pose[0], pose[1], pts, col)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)

@@ -270,3 +270,19 @@ def test_mesh_integrator_bit_identical(cfg):
     for x, y in zip(sa, sb):
         total += _same_mesh(x, y)
     assert total > 3000
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_axis_parallel_rays_quirk_q4_bit_identical(kind):
+    """SURVEY Q4 (integrator_utils.cc:160-178): exactly axis-parallel rays divide by zero inside
+    setupRayCaster; the walk that results (NaN / inf t-values through minCoeff) is the same in the
+    restatement and in the reference's own ray caster."""
+    q = np.array([1, 0, 0, 0], np.float32)
+    dirs = np.array([[0, 0, 2.0], [0, 0, -1.5], [1.7, 0, 0], [-2.2, 0, 0], [0, 1.3, 0], [0, -0.9, 0],
+                     [1.2, 1.2, 0], [0, -1.1, 2.3], [1.9, 0, -0.7], [0.4, 0.3, 2.0]], np.float32)
+    col = np.full((dirs.shape[0], 4), 200, np.uint8)
+    for pos in ([0.05, 0.05, 0.05], [0.0, 0.0, 0.0], [0.1, 0.25, -0.3], [-0.35, 0.2, 0.15]):
+        frames = [((np.array(pos, np.float32), q), dirs, col)] * 2
+        a, b = _both(kind, frames, voxel=0.1)
+        _same_tsdf(a, b)
+        assert a.num_blocks() > 0
