@@ -311,3 +311,23 @@ def test_non_finite_points_are_dropped(oracle, kind):
     oi.integrate(pose[0], pose[1], pts, col)
     gm.integrate(k, gcfg, pose[0], pose[1], pts, col)
     compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_failures_are_loud(kind):
+    """No silent degradation: a full block pool and coordinates outside the key range fail the call
+    with an error the caller can read (the reference would allocate / has no such limit)."""
+    from voxblox_amd import capi
+    k = {"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[kind]
+    cfg = capi.tsdf_cfg(default_truncation_distance=0.4)
+    pose, pts, col = _small_room(0)
+    gm = capi.Map(0.1, 16, max_blocks=8)
+    with pytest.raises(capi.VbxError, match="capacity"):
+        gm.integrate(k, cfg, pose[0], pose[1], pts, col)
+    gm = capi.Map(0.1, 16, max_blocks=1024)
+    far = np.array([120000.0, 0.0, 0.0], np.float32)      # 1.2e6 voxels from the origin
+    with pytest.raises(capi.VbxError, match="2\\^20 voxels"):
+        gm.integrate(k, cfg, far, pose[1], pts, col)
+    assert gm.num_blocks() == 0                           # nothing was integrated from the rejected cloud
+    gm.integrate(k, cfg, pose[0], pose[1], pts, col)      # and the map is still usable
+    assert gm.num_blocks() > 10

@@ -55,6 +55,11 @@ int check_state_error(vbx_ctx* ctx) {
     ctx->fail("internal: ray march hit a block without a pool slot");
     return VBX_ERR_HIP;
   }
+  if (ctx->h_state.error & 8u) {
+    ctx->fail("point cloud reaches beyond +-2^20 voxels of the map origin (%.0f m at this voxel size): "
+              "voxel keys would alias", 1048576.0 * ctx->map.voxel_size);
+    return VBX_ERR_INVALID;
+  }
   if (ctx->h_state.error & 4u) {
     ctx->fail("internal: voxel list capacity bound violated");
     return VBX_ERR_HIP;

@@ -102,7 +102,8 @@ int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   RayTab tab = make_tab(ctx, false, (uint32_t)n);
   tab.bkey = nullptr;
   hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
-                     freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, order);
+                     freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv,
+                     ctx->d_state);
   tmark(ctx, 1);
   return march_and_fold(ctx, tab, c, /*from_origin=*/true, nullptr, false, nullptr, 0);
 }
@@ -182,7 +183,8 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
   hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
-                     pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), order);
+                     pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), order,
+                     ctx->map.voxel_size_inv, ctx->d_state);
   // bundleRays (tsdf_integrator.cc:340-371): group points by endpoint voxel.  A stable sort
   // of (key, s) keeps each bundle's points in visiting order.
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
@@ -269,7 +271,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
   hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
-                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order);
+                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv, ctx->d_state);
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
   hipLaunchKernelGGL(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,

@@ -46,7 +46,8 @@ __global__ void k_sorted_inverse(const uint64_t* __restrict__ keys, size_t n, ui
 
 __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __restrict__ rgba,
                               size_t n, Pose T, CastCfg c, int freespace, RayTab tab,
-                              float* pcx, float* pcy, float* pcz, const uint32_t* __restrict__ s_of_p) {
+                              float* pcx, float* pcy, float* pcz, const uint32_t* __restrict__ s_of_p,
+                              float voxel_size_inv, DevState* st) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const size_t s = s_of_p ? (size_t)s_of_p[p] : mixed_index_inverse(p, n);
@@ -60,6 +61,16 @@ __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __r
   tab.rgba[s] = rgba[p];
   tab.w[s] = voxel_weight(c, pc);
   tab.flags[s] = (valid ? 1 : 0) | (clearing ? 2 : 0);
+  if (valid) {
+    // voxel and block keys pack 21 bits per axis (pack_block_key and the voxel keys of the
+    // bundle / emit kernels): a ray that leaves +-2^20 voxels fails the call instead of aliasing
+    const float lim = 1048576.0f - (c.trunc + c.max_ray_length_m) * voxel_size_inv - 8.0f;
+    const float far = fmaxf(fmaxf(fabsf(pg.x), fabsf(pg.y)), fabsf(pg.z)) * voxel_size_inv;
+    if (far >= lim && far < __builtin_inff()) {  // non-finite points are dropped further down
+      atomicOr(&st->error, 8u);
+      tab.flags[s] = 0;  // nothing of it is integrated; the call reports VBX_ERR_INVALID
+    }
+  }
   if (pcx) {  // Merged keeps point_C for the bundle mean
     pcx[s] = pc.x;
     pcy[s] = pc.y;
