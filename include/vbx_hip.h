@@ -268,6 +268,11 @@ int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
  * std::stable_sort on n pseudo-random keys, bit field [begin_bit, end_bit). */
 int vbx_selftest_sort(vbx_ctx* ctx, uint32_t n, uint32_t begin_bit, uint32_t end_bit, uint32_t seed, int with_vals);
 
+/* Self-test hook, host only (no GPU needed): the Merged integrator's reconstruction of libstdc++'s
+ * std::unordered_map iteration order (tsdf_integrator.cc:440-456, see vbx_host_tsdf.hpp) against the
+ * container itself, on n distinct keys with pseudo-random hashes & hash_mask. */
+int vbx_selftest_unordered_order(uint32_t n, uint32_t seed, uint32_t hash_mask);
+
 /* HIP-event timing of the last integrate / esdf call on the handle's stream, in ms. */
 typedef struct vbx_timing {
   float total_ms;

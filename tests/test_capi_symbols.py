@@ -94,3 +94,15 @@ def test_factory_error_behaviour():
     assert type(TsdfIntegratorFactory.create("simple", cfg, FakeLayer())).__name__ == "SimpleTsdfIntegrator"
     assert type(TsdfIntegratorFactory.create(2, cfg, FakeLayer())).__name__ == "MergedTsdfIntegrator"
     assert type(TsdfIntegratorFactory.create("fast", cfg, FakeLayer())).__name__ == "FastTsdfIntegrator"
+
+
+@pytest.mark.parametrize("n,mask", [(0, 0xFFFFFFFF), (1, 0xFFFFFFFF), (13, 0xFFFFFFFF), (14, 0xFFFFFFFF), (30, 0xFFFFFFFF),
+                                    (100, 0xFF), (1000, 0), (5000, 0xFFFFFFFF), (31000, 0xFFFFFFFF), (31000, 0x3FF),
+                                    (120000, 0xFFFFFFFF)])
+def test_unordered_map_order_reconstruction_matches_libstdcxx(n, mask):
+    """Host-only self-test (no GPU): the Merged integrator's array replay of libstdc++'s
+    unordered_map iteration order (vbx_host_tsdf.hpp) equals the order of the container itself —
+    across every rehash threshold up to n, with colliding and with identical hashes."""
+    from voxblox_amd import capi
+    for seed in (1, 2, 3):
+        assert capi.lib().vbx_selftest_unordered_order(n, seed, mask) == 0

@@ -42,6 +42,27 @@ struct DBuf {  // growable device buffer
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+struct PBuf {  // growable page-locked host buffer (small per-frame read-backs / uploads)
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = (std::max(bytes, cap + cap / 2) + 4095) & ~size_t(4095);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 

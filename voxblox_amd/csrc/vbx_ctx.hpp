@@ -36,6 +36,9 @@ struct vbx_ctx {
   bool start_sentinel_live = true;
   bool startset_init = false;
   std::vector<int32_t> h_by_s;  // scratch of merged_reference_order
+  PBuf h_mkeys, h_mperm;                                 // its read-back / upload staging
+  std::vector<uint32_t> h_midx, h_mhash, h_morder, h_mseq, h_mruns;
+  std::vector<int32_t> h_mnxt;
   std::vector<uint32_t> h_poff;  // scratch of the blocked observed-set replay
   uint32_t h_poff_total = 0;     // probes of the current replay guess
   // voxel_observed_approx_set_ (reference semantics, fast_observed_set == 0)

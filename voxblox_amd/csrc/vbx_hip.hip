@@ -195,8 +195,11 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
                   &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_hist0, &ctx->b_hist1, &ctx->b_moved, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
-                  &ctx->b_eraised, &ctx->b_eactive};
+                  &ctx->b_eraised, &ctx->b_eactive, &ctx->b_mesh_list, &ctx->b_mesh_cnt, &ctx->b_mesh_off,
+                  &ctx->b_mesh_tab, &ctx->b_mesh_verts, &ctx->b_mesh_normals, &ctx->b_mesh_colors};
   for (DBuf* b : bufs) b->release();
+  ctx->h_mkeys.release();
+  ctx->h_mperm.release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->h_mirror) (void)hipHostFree(ctx->h_mirror);
   for (int i = 0; i < 9; ++i)
@@ -889,6 +892,34 @@ int vbx_mesh_device_ptrs(vbx_ctx* ctx, const float** d_vertices, const float** d
   if (d_vertices) *d_vertices = ctx->b_mesh_verts.as<float>();
   if (d_normals) *d_normals = ctx->b_mesh_normals.as<float>();
   if (d_rgba) *d_rgba = ctx->mesh_has_colors ? ctx->b_mesh_colors.as<uint8_t>() : nullptr;
+  return VBX_OK;
+}
+
+int vbx_selftest_unordered_order(uint32_t n, uint32_t seed, uint32_t hash_mask) {
+  // pseudo-random 32-bit hashes (masked to force bucket collisions when asked)
+  std::vector<uint32_t> h(n);
+  uint64_t x = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed << 17);
+  for (uint32_t i = 0; i < n; ++i) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    h[i] = (uint32_t)(x >> 20) & hash_mask;
+  }
+  std::vector<uint32_t> fast, real, seq, runs;
+  std::vector<int32_t> head, nxt;
+  const auto t0 = std::chrono::steady_clock::now();
+  unordered_iteration_order(h.data(), n, &fast, OrderScratch{&seq, &runs, &head, &nxt});
+  const auto t1 = std::chrono::steady_clock::now();
+  unordered_iteration_order(h.data(), n, &fast, OrderScratch{&seq, &runs, &head, &nxt});
+  const auto t2 = std::chrono::steady_clock::now();
+  unordered_iteration_order_real(h.data(), n, &real);
+  const auto t3 = std::chrono::steady_clock::now();
+  if (getenv("VBX_DEBUG_MERGED"))
+    fprintf(stderr, "order of %u keys: arrays %.1f us (first call %.1f), container %.1f us\n", n,
+            std::chrono::duration<double, std::micro>(t2 - t1).count(),
+            std::chrono::duration<double, std::micro>(t1 - t0).count(),
+            std::chrono::duration<double, std::micro>(t3 - t2).count());
+  if (fast.size() != real.size()) return VBX_ERR_HIP;
+  for (size_t i = 0; i < fast.size(); ++i)
+    if (fast[i] != real[i]) return VBX_ERR_HIP;
   return VBX_OK;
 }
 

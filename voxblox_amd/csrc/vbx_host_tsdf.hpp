@@ -111,59 +111,156 @@ int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
 // MergedTsdfIntegrator::integrateVoxels walks voxel_map / clear_map — std::unordered_map keyed by
 // GlobalIndex with LongIndexHash (block_hash.h:54-64) — from begin() to end()
 // (tsdf_integrator.cc:440-456).  That order is a property of libstdc++'s hashtable (bucket
-// count growth, node splicing) given the hash values and the insertion sequence, so it is
-// obtained the way the reference obtains it: the bundle keys are inserted into the same container,
-// in bundleRays' insertion order (first point of each bundle, visiting order), on the host.
+// count growth, node splicing) given the hash values and the insertion sequence — bundleRays' insertion order:
+// first point of each bundle, visiting order — and is reconstructed on the host.
 // perm[rank in ascending key order] = row in visiting order; non-clearing bundles first (:324-333).
-struct HostL3Hash {
-  size_t operator()(const l3& k) const { return (size_t)long_index_hash(k); }
+//
+// Inserting into the real container costs ~20 ns per bundle in node allocation and cache misses
+// (0.6 ms per 640x480 frame).  The order itself follows from two facts of libstdc++'s _Hashtable
+// (hashtable.h: _M_insert_bucket_begin and _M_rehash_aux for unique keys place a node the same
+// way): a node whose bucket is empty goes to the head of the whole list, a node whose bucket is
+// occupied goes to the head of its bucket's run.  So, for a fixed bucket count, the list is the
+// buckets' runs in DESCENDING order of the bucket's first insertion, each run in DESCENDING
+// insertion order; and a rehash re-inserts the current list, in list order, into the new bucket
+// count before the insertion that triggered it.  The bucket counts and the element counts at
+// which they change depend only on the number of elements (_Prime_rehash_policy), and are read
+// off a real std::unordered_map once.  unordered_iteration_order() replays that with flat arrays;
+// vbx_selftest_unordered_order checks it against the container itself.
+struct HostU32Hash {
+  size_t operator()(const std::pair<uint32_t, uint32_t>& k) const { return (size_t)k.first; }
 };
-struct HostL3Eq {
-  bool operator()(const l3& a, const l3& b) const { return a.x == b.x && a.y == b.y && a.z == b.z; }
+// (number of elements already in the map, bucket count from that insertion on)
+static const std::vector<std::pair<uint32_t, uint32_t>>& rehash_schedule(uint32_t n_needed) {
+  static std::unordered_map<uint32_t, char> probe;  // identity-hashed keys: the policy only counts
+  static std::vector<std::pair<uint32_t, uint32_t>> pts;
+  static uint32_t known = 0;
+  while (known < n_needed) {
+    const size_t before = probe.bucket_count();
+    probe.emplace(known, 0);
+    if (probe.bucket_count() != before) pts.emplace_back(known, (uint32_t)probe.bucket_count());
+    ++known;
+  }
+  return pts;
+}
+// hashes[i] = hash of the i-th inserted (distinct) key; out[r] = insertion index of the r-th
+// element in iteration order
+struct OrderScratch {
+  std::vector<uint32_t>*seq, *runs;
+  std::vector<int32_t>*head, *nxt;
 };
+static void unordered_iteration_order(const uint32_t* hashes, uint32_t n, std::vector<uint32_t>* out,
+                                      const OrderScratch& sc) {
+  out->clear();
+  if (n == 0) return;
+  const auto& sched = rehash_schedule(n);
+  std::vector<uint32_t>& list = *out;  // current iteration order (insertion indices)
+  std::vector<uint32_t>& seq = *sc.seq;
+  std::vector<uint32_t>& run_order = *sc.runs;
+  std::vector<int32_t>& head = *sc.head;
+  std::vector<int32_t>& nxt = *sc.nxt;
+  seq.reserve(n);
+  list.reserve(n);
+  uint32_t done = 0;  // elements inserted so far
+  for (size_t k = 0; k < sched.size() && done < n; ++k) {
+    if (sched[k].first >= n) break;
+    const uint32_t B = sched[k].second;
+    const uint32_t until = (k + 1 < sched.size()) ? std::min(sched[k + 1].first, n) : n;  // B holds for [done, until)
+    // the phase's insertion sequence: the current list (rehash), then the new elements
+    seq.assign(list.begin(), list.end());
+    for (uint32_t i = done; i < until; ++i) seq.push_back(i);
+    const uint32_t m = (uint32_t)seq.size();
+    // counting sort by (run of the bucket, descending time) instead of chasing per-bucket chains:
+    // pass 1 numbers the buckets in order of first use and sizes their runs, pass 2 (backwards in
+    // time) drops every element at the next free place of its run; runs are laid out last-first
+    head.assign(B, -1);            // bucket -> run number
+    run_order.clear();             // run sizes, then run starts
+    if (nxt.size() < m) nxt.resize(m);  // bucket of seq[t]
+    const uint64_t M = ~0ull / B + 1;  // hash % B without a division (Lemire's fastmod, 32-bit operands)
+    const uint32_t* sq = seq.data();
+    for (uint32_t t = 0; t < m; ++t) {
+      const uint32_t b = (uint32_t)(((unsigned __int128)(M * hashes[sq[t]]) * B) >> 64);
+      int32_t r = head[b];
+      if (r < 0) {
+        r = (int32_t)run_order.size();
+        head[b] = r;
+        run_order.push_back(0);
+      }
+      ++run_order[(size_t)r];
+      nxt[t] = r;
+    }
+    uint32_t acc = 0;
+    for (size_t r = run_order.size(); r-- > 0;) {
+      const uint32_t c = run_order[r];
+      run_order[r] = acc;
+      acc += c;
+    }
+    list.resize(m);
+    for (uint32_t t = m; t-- > 0;) list[run_order[(size_t)nxt[t]]++] = sq[t];
+    done = until;
+  }
+}
+// the same from the container itself (self-test and the definition of "right")
+static void unordered_iteration_order_real(const uint32_t* hashes, uint32_t n, std::vector<uint32_t>* out) {
+  std::unordered_map<std::pair<uint32_t, uint32_t>, uint32_t, HostU32Hash> map;
+  for (uint32_t i = 0; i < n; ++i) map.emplace(std::make_pair(hashes[i], i), i);
+  out->clear();
+  for (const auto& kv : map) out->push_back(kv.second);
+}
+
 int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t** perm_out) {
   hipStream_t s = ctx->stream;
-  HIP_TRY(ctx->b_bkeys.ensure((size_t)nb * 8));
-  HIP_TRY(ctx->b_bfirst.ensure((size_t)nb * 4));
+  HIP_TRY(ctx->b_bkeys.ensure((size_t)nb * 8));   // bpack
+  HIP_TRY(ctx->b_bfirst.ensure((size_t)nb * 8));  // the same in insertion order
   HIP_TRY(ctx->b_bperm.ensure((size_t)nb * 4));
-  hipLaunchKernelGGL(k_merged_collect, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+  HIP_TRY(ctx->b_cnt.ensure((n + 1) * 4));        // by_s
+  HIP_TRY(ctx->b_off.ensure((n + 1) * 4));        // flags
+  HIP_TRY(ctx->b_T.ensure((n + 1) * 4));          // positions
+  uint32_t* by_s = ctx->b_cnt.as<uint32_t>();
+  HIP_TRY(hipMemsetAsync(by_s, 0xFF, n * 4, s));
+  hipLaunchKernelGGL(k_merged_mark_first, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(),
-                     (uint32_t)n, ctx->b_bkeys.as<uint64_t>(), ctx->b_bfirst.as<uint32_t>());
-  std::vector<uint64_t> keys(nb);
-  std::vector<uint32_t> first(nb), perm(nb), idx(nb);
-  HIP_TRY(hipMemcpyAsync(keys.data(), ctx->b_bkeys.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(first.data(), ctx->b_bfirst.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+                     (uint32_t)n, by_s, ctx->b_bkeys.as<uint64_t>());
+  hipLaunchKernelGGL(k_merged_first_flags, grid_for(n + 1), dim3(256), 0, s, by_s, (uint32_t)n, ctx->b_off.as<uint32_t>());
+  int rc = exclusive_scan_u32(ctx, ctx->b_off.as<uint32_t>(), ctx->b_T.as<uint32_t>(), n + 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_merged_insertion_order, grid_for(n), dim3(256), 0, s, by_s, ctx->b_T.as<uint32_t>(),
+                     ctx->b_bkeys.as<uint64_t>(), (uint32_t)n, ctx->b_bfirst.as<uint64_t>());
+  HIP_TRY(ctx->h_mkeys.ensure((size_t)nb * 8));
+  HIP_TRY(ctx->h_mperm.ensure((size_t)nb * 4));
+  const uint64_t* packed = ctx->h_mkeys.as<uint64_t>();
+  uint32_t* perm = ctx->h_mperm.as<uint32_t>();
+  HIP_TRY(hipMemcpyAsync(ctx->h_mkeys.p, ctx->b_bfirst.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  // the keys are sorted with the clearing bit on top: [0, n1) normal bundles, [n1, nb) clearing
+  const auto dbg_t0 = std::chrono::steady_clock::now();
+  // voxel_map (normal bundles) is walked before clear_map (tsdf_integrator.cc:324-333): split the
+  // insertion sequence, each part keeps its order
+  std::vector<uint32_t>&hashes = ctx->h_mhash, &order = ctx->h_morder, &idx = ctx->h_midx;
+  hashes.resize(nb);
+  idx.resize(nb);
   uint32_t n1 = 0;
-  while (n1 < nb && !(keys[n1] >> 63)) ++n1;
-  // insertion order = ascending visiting position of each bundle's first point; positions are
-  // unique and < n, so a direct-address pass orders them without a comparison sort
-  std::vector<int32_t>& by_s = ctx->h_by_s;
-  by_s.assign(n, -1);
-  for (uint32_t b = 0; b < nb; ++b) by_s[first[b]] = (int32_t)b;
-  uint32_t q1 = 0, q2 = n1;
-  for (size_t sidx = 0; sidx < n; ++sidx) {
-    const int32_t b = by_s[sidx];
-    if (b < 0) continue;
-    if ((uint32_t)b < n1) idx[q1++] = (uint32_t)b; else idx[q2++] = (uint32_t)b;
+  for (uint32_t q = 0; q < nb; ++q) n1 += !(packed[q] >> 63);
+  {
+    uint32_t q1 = 0, q2 = n1;
+    for (uint32_t q = 0; q < nb; ++q) {
+      const uint64_t v = packed[q];
+      const uint32_t at = (v >> 63) ? q2++ : q1++;
+      hashes[at] = (uint32_t)v;
+      idx[at] = (uint32_t)(v >> 32) & 0x7FFFFFFFu;
+    }
   }
   uint32_t row = 0;
+  const OrderScratch sc{&ctx->h_mseq, &ctx->h_mruns, &ctx->h_by_s, &ctx->h_mnxt};
   for (int pass = 0; pass < 2; ++pass) {
     const uint32_t lo = pass ? n1 : 0, hi = pass ? nb : n1;
-    // node storage from a monotonic arena: the allocator has no influence on the iteration order
-    std::pmr::monotonic_buffer_resource arena((size_t)(hi - lo) * 64 + 4096);
-    std::pmr::unordered_map<l3, uint32_t, HostL3Hash, HostL3Eq> map(&arena);
-    for (uint32_t q = lo; q < hi; ++q) {
-      const uint64_t k = keys[idx[q]] & ~(1ull << 63);
-      const l3 g{(long long)(k & 0x1FFFFFu) - (1ll << 20), (long long)((k >> 21) & 0x1FFFFFu) - (1ll << 20),
-                 (long long)((k >> 42) & 0x1FFFFFu) - (1ll << 20)};
-      map.emplace(g, idx[q]);
-    }
-    for (const auto& kv : map) perm[kv.second] = row++;
+    unordered_iteration_order(hashes.data() + lo, hi - lo, &order, sc);
+    for (uint32_t r = 0; r < hi - lo; ++r) perm[idx[lo + order[r]]] = row++;
   }
-  HIP_TRY(hipMemcpyAsync(ctx->b_bperm.p, perm.data(), (size_t)nb * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));  // perm is a local
+  if (getenv("VBX_DEBUG_MERGED"))
+    fprintf(stderr, "merged host order: nb=%u %.1f us\n", nb,
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
+  // page-locked staging: the copy is queued and the stream goes on (the buffer is rewritten only
+  // after the next frame's read-back has synchronised the stream)
+  HIP_TRY(hipMemcpyAsync(ctx->b_bperm.p, perm, (size_t)nb * 4, hipMemcpyHostToDevice, s));
   *perm_out = ctx->b_bperm.as<uint32_t>();
   return VBX_OK;
 }

@@ -508,15 +508,32 @@ __global__ void k_merged_bundle(const uint64_t* __restrict__ keys, const uint32_
   (void)st;
 }
 
-// Per bundle (ascending key rank): its key and the visiting position of its first point — the
-// order in which bundleRays inserts the keys into its unordered_map.
-__global__ void k_merged_collect(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                 const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank, uint32_t n,
-                                 uint64_t* bkeys, uint32_t* first_s) {
+// The order in which bundleRays inserts the bundle keys into its unordered_map = ascending visiting
+// position of each bundle's first point.  by_s[s] = bundle (ascending key rank) whose first point is
+// visiting position s (else ~0); bpack[b] = clearing << 63 | b << 32 | LongIndexHash(voxel).
+__global__ void k_merged_mark_first(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                    const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank, uint32_t n,
+                                    uint32_t* by_s, uint64_t* bpack) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !head[i]) return;
-  bkeys[rank[i]] = keys[i];
-  first_s[rank[i]] = vals[i];
+  const uint32_t b = rank[i];
+  const uint64_t k = keys[i];
+  by_s[vals[i]] = b;
+  const l3 g{(long long)(k & 0x1FFFFFu) - (1ll << 20), (long long)((k >> 21) & 0x1FFFFFu) - (1ll << 20),
+             (long long)((k >> 42) & 0x1FFFFFu) - (1ll << 20)};
+  bpack[b] = (k & (1ull << 63)) | ((uint64_t)b << 32) | (uint64_t)long_index_hash(g);  // block_hash.h:54-64
+}
+__global__ void k_merged_first_flags(const uint32_t* __restrict__ by_s, uint32_t n, uint32_t* f) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > n) return;
+  f[s] = (s < n && by_s[s] != 0xFFFFFFFFu) ? 1u : 0u;
+}
+__global__ void k_merged_insertion_order(const uint32_t* __restrict__ by_s, const uint32_t* __restrict__ pos,
+                                         const uint64_t* __restrict__ bpack, uint32_t n, uint64_t* out) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t b = by_s[s];
+  if (b != 0xFFFFFFFFu) out[pos[s]] = bpack[b];
 }
 
 }  // namespace
