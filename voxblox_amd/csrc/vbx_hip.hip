@@ -29,6 +29,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <memory_resource>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>

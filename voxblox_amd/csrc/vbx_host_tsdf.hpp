@@ -130,10 +130,12 @@ struct HostU32Hash {
   size_t operator()(const std::pair<uint32_t, uint32_t>& k) const { return (size_t)k.first; }
 };
 // (number of elements already in the map, bucket count from that insertion on)
-static const std::vector<std::pair<uint32_t, uint32_t>>& rehash_schedule(uint32_t n_needed) {
+static std::vector<std::pair<uint32_t, uint32_t>> rehash_schedule(uint32_t n_needed) {
+  static std::mutex mu;  // handles of different threads share the probe
   static std::unordered_map<uint32_t, char> probe;  // identity-hashed keys: the policy only counts
   static std::vector<std::pair<uint32_t, uint32_t>> pts;
   static uint32_t known = 0;
+  std::lock_guard<std::mutex> lock(mu);
   while (known < n_needed) {
     const size_t before = probe.bucket_count();
     probe.emplace(known, 0);
@@ -152,7 +154,7 @@ static void unordered_iteration_order(const uint32_t* hashes, uint32_t n, std::v
                                       const OrderScratch& sc) {
   out->clear();
   if (n == 0) return;
-  const auto& sched = rehash_schedule(n);
+  const auto sched = rehash_schedule(n);
   std::vector<uint32_t>& list = *out;  // current iteration order (insertion indices)
   std::vector<uint32_t>& seq = *sc.seq;
   std::vector<uint32_t>& run_order = *sc.runs;
