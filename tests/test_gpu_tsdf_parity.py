@@ -331,3 +331,38 @@ def test_failures_are_loud(kind):
     assert gm.num_blocks() == 0                           # nothing was integrated from the rejected cloud
     gm.integrate(k, cfg, pose[0], pose[1], pts, col)      # and the map is still usable
     assert gm.num_blocks() > 10
+
+
+@pytest.mark.parametrize("kind,scene,n_frames", [("fast", "room", 40), ("merged", "cow", 16)])
+def test_long_full_resolution_streams_bit_exact(oracle, kind, scene, n_frames):
+    """Soak at BASELINE size: 40 consecutive 640x480 frames of the configs[1] room stream through the
+    Fast integrator (reference observed-voxel set), 16 of the configs[2] orbit through Merged
+    (reference bundle order) — the map after the last frame equals the oracle's bit for bit, so the
+    rare paths (list rebuilds after block allocation, long replay chains, rehash boundaries of the
+    bundle map) are exact too, not only the first frames."""
+    import hashlib
+    from voxblox_amd import capi
+    voxel = 0.05
+    ocfg, gcfg = _cfgs(oracle, 4 * voxel)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator(kind, ocfg)
+    gm = capi.Map(voxel, 16, max_blocks=16384)
+    k = {"merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[kind]
+    for i in range(n_frames):
+        pose, pts, col = scenes.room_frame(i, 100) if scene == "room" else scenes.cow_and_lady_like_frame(5 * i)
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(k, gcfg, pose[0], pose[1], pts, col)
+    g, r = gm.tsdf_dict(), om.tsdf_dict()
+    assert set(g) == set(r) and len(r) > 200
+
+    def digest(d):
+        h = hashlib.sha256()
+        for key in sorted(d):
+            dist, w, rgba, upd = d[key]
+            h.update(np.ascontiguousarray(dist).tobytes()); h.update(np.ascontiguousarray(w).tobytes())
+            h.update(np.ascontiguousarray(rgba).tobytes()); h.update(bytes([int(upd) & 0xFF]))
+        return h.hexdigest()
+    if digest(g) != digest(r):
+        compare_tsdf(g, r, exact=True)   # names the first differing block
+        raise AssertionError("digests differ")
