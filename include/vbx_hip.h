@@ -62,8 +62,9 @@ typedef struct vbx_tsdf_cfg {
   float max_integration_time_s; /* accepted; the GPU path never truncates a frame */
   /* Not in the reference Config.  MergedTsdfIntegrator visits its ray bundles in the iteration
    * order of a std::unordered_map (tsdf_integrator.cc:440-456), which the clamped fold makes
-   * observable.  0 (default): that order, reproduced by replaying the container's insertions on
-   * the host with this library's libstdc++ (bit-exact, ~1 ms per frame at 640x480);
+   * observable.  0 (default): that order, reconstructed from libstdc++'s bucket-count schedule and
+   * node placement rules (bit-exact; ~0.2 ms of host work per frame at 640x480, checked against
+   * the container by vbx_selftest_unordered_order);
    * 1: ascending voxel key (no host step; same voxels, distances differ in the order-sensitive
    * ~1 % of them). */
   int32_t merged_bundle_order;
@@ -78,7 +79,7 @@ typedef struct vbx_tsdf_cfg {
 
 /* EsdfIntegrator::Config, esdf_integrator.h:29-78. */
 typedef struct vbx_esdf_cfg {
-  int32_t full_euclidean_distance;
+  int32_t full_euclidean_distance; /* needs max_distance_m / voxel_size < 120 (int8 parent vectors) */
   float max_distance_m;
   float min_distance_m;
   float default_distance_m;
