@@ -257,7 +257,8 @@ int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t**
     unordered_iteration_order(hashes.data() + lo, hi - lo, &order, sc);
     for (uint32_t r = 0; r < hi - lo; ++r) perm[idx[lo + order[r]]] = row++;
   }
-  if (getenv("VBX_DEBUG_MERGED"))
+  static const bool dbg_merged = getenv("VBX_DEBUG_MERGED") != nullptr;  // read once
+  if (dbg_merged)
     fprintf(stderr, "merged host order: nb=%u %.1f us\n", nb,
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
   // page-locked staging: the copy is queued and the stream goes on (the buffer is rewritten only
@@ -545,7 +546,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         // only a performance hint)
         ctx->fast_redo_grid = std::max<uint32_t>(1, 2 * ctx->h_state.redo_count);
       }
-      if (getenv("VBX_DEBUG")) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
+      static const bool dbg_solver = getenv("VBX_DEBUG") != nullptr;
+      if (dbg_solver) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
       if (n_open == 0) break;
       if (iters > 1000000 || ctx->own_tag < 128) {
         ctx->fail("Fast integrator: early-termination solver did not converge");
@@ -579,7 +581,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     HIP_TRY(hipMemsetAsync(Tcur + R, 0, 4, s));
     HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
     uint32_t rounds = 0;
-    const bool dbg = getenv("VBX_DEBUG") != nullptr;
+    static const bool dbg = getenv("VBX_DEBUG") != nullptr;
     // Replay of the rays [a, b) against the set content left by everything before them (the
     // persistent array: what the frame found, plus the commits of the rays below a).  Runs
     // rounds until no probe count in the range moves (then commits the range's probes) or
