@@ -47,7 +47,7 @@ class EsdfCfg(C.Structure):
                 ("min_diff_m", C.c_float), ("min_weight", C.c_float), ("num_buckets", C.c_int32),
                 ("multi_queue", C.c_int32), ("add_occupied_crust", C.c_int32),
                 ("clear_sphere_radius", C.c_float), ("occupied_sphere_radius", C.c_float),
-                ("oracle_orderfree_sign_mismatch", C.c_int32)]
+                ("oracle_orderfree_sign_mismatch", C.c_int32), ("oracle_unrestricted_wavefront", C.c_int32)]
 
 
 _lib = None

@@ -90,6 +90,7 @@ void orc_esdf_cfg_default(orc_esdf_cfg* c) {
   c->clear_sphere_radius = d.clear_sphere_radius;
   c->occupied_sphere_radius = d.occupied_sphere_radius;
   c->oracle_orderfree_sign_mismatch = 0;
+  c->oracle_unrestricted_wavefront = 0;
 }
 
 orc_map* orc_map_create(float voxel_size, uint32_t vps) { return new orc_map(voxel_size, vps); }
@@ -138,7 +139,7 @@ void orc_tsdf_stats(orc_tsdf_integrator*, uint64_t out[4], int) { out[0] = out[1
 void orc_fast_reset_counter_set(int64_t) {}  // function-static in the reference; moot for n_frames == 1
 
 orc_esdf_integrator* orc_esdf_integrator_create(orc_map* m, const orc_esdf_cfg* c) {
-  if (c->oracle_orderfree_sign_mismatch) return nullptr;  // reference only
+  if (c->oracle_orderfree_sign_mismatch || c->oracle_unrestricted_wavefront) return nullptr;  // reference only
   EsdfIntegrator::Config d;
   d.full_euclidean_distance = c->full_euclidean_distance != 0;
   d.max_distance_m = c->max_distance_m;

@@ -121,6 +121,12 @@ struct EsdfConfig {  // esdf_integrator.h:29-78
   // order.  With this switch the same candidate is applied whenever it moves the voxel
   // closer to the surface (monotone, hence order-free) — the form the HIP path implements.
   bool oracle_orderfree_sign_mismatch = false;
+  // The reference's wavefront only expands voxels it queued, so a voxel that appears next to
+  // settled ones can stay under-relaxed until a later update touches it.  With this switch every
+  // update ends with one more wavefront seeded from every observed voxel of the layer, i.e. at
+  // the fixed point of the reference's own relaxation rule — the result the HIP path computes
+  // (its relaxation is a pull over all neighbours).  Same rules, same arithmetic, no queue gaps.
+  bool oracle_unrestricted_wavefront = false;
 };
 
 struct EsdfStats {
@@ -356,6 +362,20 @@ class EsdfIntegrator {
     }
     processRaiseSet();
     processOpenSet();
+    if (config_.oracle_unrestricted_wavefront) {
+      for (auto& kv : esdf_layer_->block_map) {
+        Block<EsdfVoxel>& b = *kv.second;
+        for (size_t lin = 0; lin < b.num_voxels; ++lin) {
+          EsdfVoxel& v = b.voxels[lin];
+          if (!v.observed) continue;
+          v.in_queue = true;
+          open_.push(globalVoxelIndexFromBlockAndVoxelIndex(kv.first, b.voxelIndexFromLinear(lin),
+                                                            static_cast<int>(esdf_layer_->voxels_per_side)),
+                     v.distance);
+        }
+      }
+      processOpenSet();
+    }
   }
 
   // esdf_integrator.cc:305-369

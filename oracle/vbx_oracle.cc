@@ -88,6 +88,7 @@ void orc_esdf_cfg_default(orc_esdf_cfg* c) {
   c->clear_sphere_radius = d.clear_sphere_radius;
   c->occupied_sphere_radius = d.occupied_sphere_radius;
   c->oracle_orderfree_sign_mismatch = 0;
+  c->oracle_unrestricted_wavefront = 0;
 }
 
 static TsdfConfig toCfg(const orc_tsdf_cfg* c) {
@@ -206,6 +207,7 @@ static EsdfConfig toEsdfCfg(const orc_esdf_cfg* c) {
   d.clear_sphere_radius = c->clear_sphere_radius;
   d.occupied_sphere_radius = c->occupied_sphere_radius;
   d.oracle_orderfree_sign_mismatch = c->oracle_orderfree_sign_mismatch != 0;
+  d.oracle_unrestricted_wavefront = c->oracle_unrestricted_wavefront != 0;
   return d;
 }
 orc_esdf_integrator* orc_esdf_integrator_create(orc_map* m, const orc_esdf_cfg* cfg) {

@@ -54,6 +54,7 @@ typedef struct orc_esdf_cfg {
   float clear_sphere_radius;
   float occupied_sphere_radius;
   int32_t oracle_orderfree_sign_mismatch; /* oracle-only switch, see vbx_esdf.hpp */
+  int32_t oracle_unrestricted_wavefront;  /* oracle-only switch, see vbx_esdf.hpp */
 } orc_esdf_cfg;
 
 void orc_tsdf_cfg_default(orc_tsdf_cfg* cfg);

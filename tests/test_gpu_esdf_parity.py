@@ -482,6 +482,12 @@ def test_esdf_and_mesh_long_full_resolution_stream(oracle):
     om = oracle.OracleMap(VOXEL, 16)
     oi = om.tsdf_integrator("fast", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1))
     oe_inc = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0, oracle_orderfree_sign_mismatch=1))
+    # the same reference rules run to their fixed point after every update (oracle switch): the
+    # semantics of the HIP path, on a third oracle map fed with the same TSDF stream
+    om3 = oracle.OracleMap(VOXEL, 16)
+    oi3 = om3.tsdf_integrator("fast", oracle.tsdf_cfg(default_truncation_distance=TRUNC, integrator_threads=1))
+    oe_fix = om3.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0, oracle_orderfree_sign_mismatch=1,
+                                                 oracle_unrestricted_wavefront=1))
     ml = om.mesh_layer()
     gm = capi.Map(VOXEL, 16, max_blocks=8192)
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
@@ -492,6 +498,8 @@ def test_esdf_and_mesh_long_full_resolution_stream(oracle):
         oi.integrate(pose[0], pose[1], pts, col)
         ml.generate(True, True)
         oe_inc.update_from_tsdf_layer(True)
+        oi3.integrate(pose[0], pose[1], pts, col)
+        oe_fix.update_from_tsdf_layer(True)
         gm.integrate(capi.TSDF_FAST, gt, pose[0], pose[1], pts, col)
         gm.esdf_update(ge, batch=False, clear_updated_flag=True)
         idx, off, v, n, c = gm.mesh_generate(None, True, True)
@@ -539,6 +547,12 @@ def test_esdf_and_mesh_long_full_resolution_stream(oracle):
             e = np.abs(ad[obs].astype(np.float64) - bd[obs])
             n += int(obs.sum()); nd += int((e > 0).sum()); se += float((e * e).sum()); mx = max(mx, float(e.max(initial=0.0)))
         return dict(n=n, differing=nd, rmse=(se / n) ** 0.5, max=mx)
+    s_fix = stats(g, om3.esdf_dict())
+    print("gpu vs reference rules at the fixed point of every update:", s_fix)
+    # measured: 290 of 606 k voxels differ.  They are the voxels a raise did or did not reach: the
+    # raise follows parent pointers, the reference's parent is whichever neighbour lowered the voxel
+    # last (order-dependent), the HIP path's is the first LUT neighbour that explains the distance
+    assert s_fix["differing"] < 1e-3 * s_fix["n"], s_fix
     s_inc, s_bat, s_ref = stats(g, r_inc), stats(g, r_bat), stats(r_inc, r_bat)
     print("gpu vs reference incremental:", s_inc)
     print("gpu vs reference batch:", s_bat)
