@@ -150,3 +150,30 @@ def test_mesh_api_errors():
     nb2, nv2 = C.c_size_t(0), C.c_size_t(0)
     assert gm.L.vbx_mesh_generate(gm.h, C.byref(cfg), 1, 0, C.byref(nb2), C.byref(nv2)) == capi.VBX_OK
     assert (nb2.value, nv2.value) == (nb.value, nv.value)
+
+
+def test_python_class_mirror(oracle):
+    """voxblox_amd.integrator.MeshIntegrator / MeshLayer / Mesh: the reference's class surface in
+    Python, filling a host MeshLayer from vbx_mesh_generate."""
+    from voxblox_amd import capi
+    from voxblox_amd.integrator import MeshIntegrator, MeshLayer
+    frames = [scenes.room_frame(k, 100, f=80.0, width=160, height=120) for k in (0, 6)]
+    om, oi, gm, k, gcfg = _layers(oracle, "merged", 0.1, frames)
+    ml = om.mesh_layer()
+    layer = MeshLayer(0.1 * 16)
+    integrator = MeshIntegrator(MeshIntegrator.Config(), gm, layer)
+    for pose, pts, col in frames:
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(k, gcfg, pose[0], pose[1], pts, col)
+        ml.generate(True, True)
+        integrator.generateMesh(True, True)
+    ref = ml.as_dict()
+    assert set(layer.getAllAllocatedMeshes()) == set(ref) == set(layer.getAllUpdatedMeshes())
+    for key, o in ref.items():
+        m = layer.getMeshPtrByIndex(key)
+        assert np.array_equal(m.vertices.view(np.uint32), o["vertices"].view(np.uint32))
+        assert np.array_equal(m.normals.view(np.uint32), o["normals"].view(np.uint32))
+        assert np.array_equal(m.colors, o["colors"]) and np.array_equal(m.indices, o["indices"])
+        assert np.allclose(m.origin, np.asarray(key, np.float32) * np.float32(1.6))
+    with pytest.raises(ValueError):
+        MeshIntegrator(MeshIntegrator.Config(), None, layer)
