@@ -312,11 +312,21 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
     rc = merged_reference_order(ctx, n, nb, &perm);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_merged_bundle, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                     ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(),
-                     ctx->b_rank.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(),
-                     ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), T, bt,
-                     ctx->b_graze.as<uint64_t>(), perm, ctx->d_state);
+  HIP_TRY(ctx->b_bstart.ensure((size_t)nb * 4));
+  HIP_TRY(ctx->b_mgather.ensure(n * 20));
+  float* gw = ctx->b_mgather.as<float>();
+  float* gx = gw + n;
+  float* gy = gx + n;
+  float* gz = gy + n;
+  uint32_t* gc = reinterpret_cast<uint32_t*>(gz + n);
+  hipLaunchKernelGGL(k_merged_starts, grid_for(n), dim3(256), 0, s, ctx->b_head.as<uint32_t>(),
+                     ctx->b_rank.as<uint32_t>(), (uint32_t)n, ctx->b_bstart.as<uint32_t>());
+  hipLaunchKernelGGL(k_merged_gather, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(),
+                     ctx->b_pcz.as<float>(), gw, gx, gy, gz, gc);
+  hipLaunchKernelGGL(k_merged_bundle8, grid_for((size_t)nb * 8), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_bstart.as<uint32_t>(), nb, (uint32_t)n, gw, gx, gy, gz, gc, T, bt,
+                     ctx->b_graze.as<uint64_t>(), perm);
   tmark(ctx, 1);
   // Non-clearing bundles sort before clearing ones (bit 63), so the graze key list is the
   // sorted prefix of non-clearing bundle keys; entries of clearing bundles stay ~0 (sorted last).

@@ -467,45 +467,98 @@ __global__ void k_merged_heads(const uint64_t* __restrict__ keys, uint32_t n, ui
   head[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 
-// One thread per bundle: running weighted mean of point_C, blended colour, summed weight in
-// push_back (= visiting) order; clearing bundles take their first usable point only
-// (tsdf_integrator.cc:387-405); merged_point_G = T_G_C * merged_point_C (:407).
-__global__ void k_merged_bundle(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank,
-                                uint32_t n, RayTab pt, const float* __restrict__ pcx,
-                                const float* __restrict__ pcy, const float* __restrict__ pcz,
-                                Pose T, RayTab out, uint64_t* graze_keys, const uint32_t* __restrict__ perm,
-                                DevState* st) {
+// Bundle fold (tsdf_integrator.cc:387-407): running weighted mean of point_C, blended colour, summed
+// weight over the bundle's points in push_back (= visiting) order; clearing bundles take their first
+// usable point only; merged_point_G = T_G_C * merged_point_C.
+// bstart[rank] = position of the bundle's first point in the sorted (key, s) list
+__global__ void k_merged_starts(const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank, uint32_t n,
+                                uint32_t* bstart) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !head[i]) return;
-  const uint64_t key = keys[i];
+  if (i < n && head[i]) bstart[rank[i]] = i;
+}
+// point data in sorted (key, s) order, so that a bundle's points are consecutive in memory
+__global__ void k_merged_gather(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                RayTab pt, const float* __restrict__ pcx, const float* __restrict__ pcy,
+                                const float* __restrict__ pcz, float* gw, float* gx, float* gy, float* gz, uint32_t* gc) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || keys[j] == ~0ull) return;
+  const uint32_t s = vals[j];
+  gw[j] = pt.w[s];
+  gx[j] = pcx[s];
+  gy[j] = pcy[s];
+  gz[j] = pcz[s];
+  gc[j] = pt.rgba[s];
+}
+// The fold with eight lanes per bundle: the three coordinates of the running mean and the four
+// colour channels are seven independent chains that only share the running weight (Color::
+// blendTwoColors works per channel, common.h:105-125), so each lane carries one of them, and the
+// eight lanes fetch eight consecutive points at a time (one coalesced read instead of a chain of
+// dependent gathers per point; the longest bundle of a frame — 100 to 300 points when the
+// camera is close to a wall — used to cost ~0.85 us per point).
+__global__ void k_merged_bundle8(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ bstart, uint32_t nb,
+                                 uint32_t n, const float* __restrict__ gw, const float* __restrict__ gx,
+                                 const float* __restrict__ gy, const float* __restrict__ gz,
+                                 const uint32_t* __restrict__ gc, Pose T, RayTab out, uint64_t* graze_keys,
+                                 const uint32_t* __restrict__ perm) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t br = t >> 3;  // rank in ascending key order
+  const int sub = (int)(t & 7u);
+  const int g0 = (int)(threadIdx.x & 63u) & ~7;
+  const bool live = br < nb;
+  const uint32_t i0 = live ? bstart[br] : 0u;
+  const uint64_t key = live ? keys[i0] : ~0ull;
   const bool clearing = (key >> 63) != 0;
-  const uint32_t br = rank[i];                    // rank in ascending key order
-  const uint32_t b = perm ? perm[br] : br;        // row = position in the visiting order of the bundles
-  f3 mp{0.f, 0.f, 0.f};
-  uint32_t mc = 0;
+  float m = 0.0f;   // lanes 0-2: mean coordinate; lanes 3-6: colour channel r, g, b, a as a float
   float mw = 0.0f;
-  for (uint32_t j = i; j < n && keys[j] == key; ++j) {
-    const uint32_t s = vals[j];
-    const float pw = pt.w[s];
-    if (pw < 1e-6f) continue;
-    const f3 pc{pcx[s], pcy[s], pcz[s]};
-    const float tw = mw + pw;
-    mp = {(mp.x * mw + pc.x * pw) / tw, (mp.y * mw + pc.y * pw) / tw, (mp.z * mw + pc.z * pw) / tw};
-    mc = blend_two_colors(mc, mw, pt.rgba[s], pw);
-    mw += pw;
-    if (clearing) break;
+  bool more = live;
+  for (uint32_t base = i0; __any(more); base += 8) {
+    const uint32_t j = base + (uint32_t)sub;
+    const bool mine = more && j < n && keys[j] == key;
+    float pw = 0.f, x = 0.f, y = 0.f, z = 0.f;
+    uint32_t col = 0;
+    if (mine) {
+      pw = gw[j]; x = gx[j]; y = gy[j]; z = gz[j]; col = gc[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool vq = __shfl((int)mine, g0 + q, 64) != 0;
+      const float pwq = __shfl(pw, g0 + q, 64);
+      const float xq = __shfl(x, g0 + q, 64), yq = __shfl(y, g0 + q, 64), zq = __shfl(z, g0 + q, 64);
+      const uint32_t cq = (uint32_t)__shfl((int)col, g0 + q, 64);
+      if (!more) continue;
+      if (!vq) {  // the bundle ended inside this chunk
+        more = false;
+        continue;
+      }
+      if (pwq < 1e-6f) continue;
+      const float tw = mw + pwq;
+      if (sub < 3) {
+        const float cmp = sub == 0 ? xq : (sub == 1 ? yq : zq);
+        m = (m * mw + cmp * pwq) / tw;
+      } else if (sub < 7) {
+        const float w1 = mw / tw, w2 = pwq / tw;
+        const float b = (float)(int)((cq >> (8 * (sub - 3))) & 0xFFu);
+        m = (float)((int)roundf(m * w1 + b * w2) & 0xFF);
+      }
+      mw += pwq;
+      if (clearing) more = false;  // clearing bundles take their first usable point only (:401-404)
+    }
   }
-  const f3 pg = pose_transform(T, mp);
+  // gather the seven results in the group's first lane
+  const float mx = __shfl(m, g0, 64), my = __shfl(m, g0 + 1, 64), mz = __shfl(m, g0 + 2, 64);
+  const uint32_t cr = (uint32_t)(int)__shfl(m, g0 + 3, 64), cg = (uint32_t)(int)__shfl(m, g0 + 4, 64);
+  const uint32_t cb = (uint32_t)(int)__shfl(m, g0 + 5, 64), ca = (uint32_t)(int)__shfl(m, g0 + 6, 64);
+  if (!live || sub != 0) return;
+  const uint32_t b = perm ? perm[br] : br;  // row = position in the visiting order of the bundles
+  const f3 pg = pose_transform(T, f3{mx, my, mz});
   out.px[b] = pg.x;
   out.py[b] = pg.y;
   out.pz[b] = pg.z;
-  out.rgba[b] = mc;
+  out.rgba[b] = cr | (cg << 8) | (cb << 16) | (ca << 24);
   out.w[b] = mw;
   out.flags[b] = 1 | (clearing ? 2 : 0);
   out.bkey[b] = key & ~(1ull << 63);
   if (!clearing && graze_keys) graze_keys[br] = key;  // stays sorted: binary-searched by the march
-  (void)st;
 }
 
 // The order in which bundleRays inserts the bundle keys into its unordered_map = ascending visiting
