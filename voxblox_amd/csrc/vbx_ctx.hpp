@@ -26,6 +26,7 @@ struct vbx_ctx {
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
+  DBuf b_fin;  // per-update fold inputs (sdf, weight, colour) in sorted key order
   DBuf b_bstart, b_mgather;  // Merged: first sorted position of every bundle; point data in sorted order
   DBuf b_T, b_TH, b_U, b_vox, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_bkeys, b_bfirst, b_bperm, b_obsset, b_collided, b_hist0, b_hist1, b_moved;
   uint32_t obs_epoch = 1;

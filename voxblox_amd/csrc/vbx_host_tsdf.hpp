@@ -34,13 +34,19 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   // long runs are collected by k_fold and folded wave-cooperatively afterwards (their number is
   // bounded by total / kFoldShort)
   HIP_TRY(ctx->b_long.ensure(((size_t)total / kFoldShort + 2) * 4));
+  HIP_TRY(ctx->b_fin.ensure((size_t)total * 12));
+  float* in_sdf = ctx->b_fin.as<float>();
+  float* in_uw = in_sdf + total;
+  uint32_t* in_col = reinterpret_cast<uint32_t*>(in_uw + total);
   HIP_TRY(hipMemsetAsync(&ctx->d_state->fold_long_count, 0, 4, s));
-  hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                     (size_t)total, tab, c, m, ctx->b_long.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_fold_inputs, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c,
+                     m, in_sdf, in_uw, in_col);
+  hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m, in_sdf,
+                     in_uw, in_col, ctx->b_long.as<uint32_t>(), ctx->d_state);
   {
     const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);
-    hipLaunchKernelGGL(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                       (size_t)total, tab, c, m, ctx->b_long.as<uint32_t>(), ctx->d_state);
+    hipLaunchKernelGGL(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c,
+                       m, in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), ctx->d_state);
   }
   tmark(ctx, 6);
   ctx->counters.voxel_updates = total;

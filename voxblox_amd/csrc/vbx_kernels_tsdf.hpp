@@ -272,8 +272,28 @@ __device__ inline l3 voxel_of_gid(const MapDev& m, uint32_t gid) {
           (long long)m.blk_idx[3 * slot + 2] * m.vps + lz};
 }
 
-__global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
-                       MapDev m, uint32_t* long_list, DevState* st) {
+// The state-independent half of every update (sdf and adjusted weight, colour) in sorted key order:
+// the gathers by ray index run fully parallel here, and the ordered folds below read consecutive
+// memory instead of chasing a ray index per step (k_fold spent ~1 us per update on that chain).
+__global__ void k_fold_inputs(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c, MapDev m,
+                              float* in_sdf, float* in_uw, uint32_t* in_col) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == ~0ull) return;
+  const uint32_t gid = (uint32_t)(key >> 32);
+  const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
+  const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+  float sdf, uw;
+  tsdf_update_inputs(c, m.voxel_size, pg, voxel_of_gid(m, gid), tab.w[o], &sdf, &uw);
+  in_sdf[i] = sdf;
+  in_uw[i] = uw;
+  in_col[i] = tab.rgba[o];
+}
+
+__global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
+                       const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
+                       const uint32_t* __restrict__ in_col, uint32_t* long_list, DevState* st) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = (i < n) ? keys[i] : ~0ull;
   const uint32_t gid = (uint32_t)(key >> 32);
@@ -289,20 +309,15 @@ __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, 
     long_list[o] = (uint32_t)i;
     return;
   }
-  const l3 g = voxel_of_gid(m, gid);
   float d = m.dist[gid];
   float W = m.weight[gid];
   uint32_t col = m.rgba[gid];
   size_t j = i;
-  uint64_t kj = key;
   while (true) {
-    const uint32_t o = (uint32_t)(kj & 0xFFFFFFFFu);
-    const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
-    tsdf_update(c, m.voxel_size, pg, g, tab.rgba[o], tab.w[o], d, W, col);
+    tsdf_update_state(c, in_sdf[j], in_uw[j], in_col[j], d, W, col);
     ++j;
     if (j >= n) break;
-    kj = keys[j];
-    if ((uint32_t)(kj >> 32) != gid) break;
+    if ((uint32_t)(keys[j] >> 32) != gid) break;
   }
   m.dist[gid] = d;
   m.weight[gid] = W;
@@ -318,22 +333,21 @@ __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, RayTab tab, 
 //      distance updates are verified in parallel against their own W;
 //   3. otherwise the 64 updates are applied in order (operands broadcast lane by lane).
 // All three produce exactly the sequential result of updateTsdfVoxel.
-__global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ keys, size_t n, RayTab tab,
-                                                   CastCfg c, MapDev m, const uint32_t* __restrict__ long_list,
-                                                   DevState* st) {
+__global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
+                                                   const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
+                                                   const uint32_t* __restrict__ in_col,
+                                                   const uint32_t* __restrict__ long_list, DevState* st) {
   const int lane = threadIdx.x & 63;
   const uint32_t n_long = st->fold_long_count;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; seg < n_long; seg += n_waves) {
     const size_t i0 = long_list[seg];
     const uint32_t gid = (uint32_t)(keys[i0] >> 32);
-    const l3 g = voxel_of_gid(m, gid);
     float d = m.dist[gid];
     float W = m.weight[gid];
     uint32_t col = m.rgba[gid];
-    // kU chunks of 64 updates are fetched together (the gathers of px/py/pz/w/rgba by ray index
-    // cost ~2 us of latency per chunk when issued one chunk at a time, and a run of 300k updates
-    // on the sensor's own voxel is 4800 chunks), then folded chunk by chunk in order.
+    // kU chunks of 64 updates are fetched together (a run of 300k updates on the sensor's own
+    // voxel is 4800 chunks), then folded chunk by chunk in order.
     constexpr int kU = 4;
     bool more = true;
     for (size_t base = i0; more; base += 64 * kU) {
@@ -350,10 +364,9 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
         cnt_u[u] = (V == ~0ull) ? 64 : (__ffsll((long long)~V) - 1);
         sdf_u[u] = 0.f; uw_u[u] = 0.f; color_u[u] = 0;
         if (lane < cnt_u[u]) {
-          const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
-          const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
-          tsdf_update_inputs(c, m.voxel_size, pg, g, tab.w[o], &sdf_u[u], &uw_u[u]);
-          color_u[u] = tab.rgba[o];
+          sdf_u[u] = in_sdf[i];
+          uw_u[u] = in_uw[i];
+          color_u[u] = in_col[i];
         }
       }
 #pragma unroll
