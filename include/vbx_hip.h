@@ -261,6 +261,7 @@ typedef struct vbx_counters {
   uint64_t esdf_relaxations;/* ESDF: successful wavefront relaxations */
   uint64_t esdf_sweeps;     /* ESDF: wavefront sweeps */
   uint64_t replay_rounds;   /* Fast, fast_observed_set = 0: rounds of the observed-set replay */
+  uint64_t replay_block_rounds; /* ... of which: rounds run on blocks of consecutive rays (fine voxels) */
 } vbx_counters;
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
 
@@ -287,6 +288,16 @@ typedef struct vbx_timing {
 } vbx_timing;
 int vbx_enable_timing(vbx_ctx* ctx, int enable);
 int vbx_get_timing(vbx_ctx* ctx, vbx_timing* out);
+
+/* Per-kernel profile (measurement only, no reference counterpart; bench.py's roofline block is computed
+ * from it).  While enabled, every kernel launch of the integrate / ESDF / mesh calls is bracketed by two
+ * HIP events on the handle's stream; the table accumulates launches and milliseconds per kernel name
+ * until vbx_profile_reset.  vbx_profile_get writes one line per kernel, "name\tlaunches\ttotal_ms\n"
+ * (NUL-terminated, truncated to cap), the size a full copy needs to *needed and the number of API calls
+ * profiled to *calls.  Costs ~2 us of host time per launch while on: not for the timed region. */
+int vbx_profile_enable(vbx_ctx* ctx, int enable);
+int vbx_profile_reset(vbx_ctx* ctx);
+int vbx_profile_get(vbx_ctx* ctx, char* buf, size_t cap, size_t* needed, uint64_t* calls);
 
 #ifdef __cplusplus
 }

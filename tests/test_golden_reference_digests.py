@@ -72,3 +72,29 @@ def _store_mesh(store, result):
     for i, b in enumerate(idx):
         a, e = int(off[i]), int(off[i + 1])
         store[tuple(int(x) for x in b)] = dict(vertices=v[a:e], normals=n[a:e], colors=None if c is None else c[a:e])
+
+
+@pytest.mark.gpu
+def test_hip_esdf_batch_reproduces_reference_digest():
+    """ESDF golden digest of the reference build replayed on the HIP path where a bit-exact definition
+    exists: updateFromTsdfLayerBatch with min_diff_m = 0 (the wavefront's fixed point is order-free).
+    Distances, flags and updated bits must hash to the reference's digest; parents are excluded (the
+    reference keeps whichever neighbour lowered a voxel last, the HIP path the first LUT neighbour that
+    explains the distance — both valid)."""
+    import numpy as np
+    from voxblox_amd import capi
+    name = "esdf_batch_min_diff0"
+    sc = S.SCENARIOS[name]
+    gm = capi.Map(sc["voxel"], 16, max_blocks=2048)
+    cfg = capi.tsdf_cfg(default_truncation_distance=4 * sc["voxel"], **sc["cfg"])
+    for pose, pts, col in S.frames(sc["n"]):
+        gm.integrate({"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[sc["kind"]], cfg,
+                     pose[0], pose[1], pts, col)
+    ecfg = capi.esdf_cfg(min_distance_m=2 * sc["voxel"], **sc["esdf"]["cfg"])
+    gm.esdf_update(ecfg, batch=True, clear_updated_flag=True)
+    d = {}
+    for i in gm.block_indices(capi.LAYER_ESDF):
+        v, u, _ = gm.block_download(i, capi.LAYER_ESDF)
+        fl = (v["observed"] | (v["hallucinated"] << 1) | (v["in_queue"] << 2) | (v["fixed"] << 3)).astype(np.uint8)
+        d[tuple(int(x) for x in i)] = (v["distance"].copy(), fl, v["parent"].copy(), u)
+    assert S.digest_esdf(d, with_parents=False) == GOLD[name]["esdf_no_parents"]

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_enable_timing", "vbx_get_timing",
+    "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
     "vbx_selftest_unordered_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
 
 
@@ -65,7 +66,8 @@ class EsdfCfg(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("points", "rays_cast", "voxel_updates", "voxels_touched", "blocks_allocated",
-                 "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps", "replay_rounds")]
+                 "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps", "replay_rounds",
+                 "replay_block_rounds")]
 
 
 class Timing(C.Structure):
@@ -142,6 +144,9 @@ def lib():
         "vbx_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
         "vbx_enable_timing": (C.c_int, [vp, C.c_int]),
         "vbx_get_timing": (C.c_int, [vp, C.POINTER(Timing)]),
+        "vbx_profile_enable": (C.c_int, [vp, C.c_int]),
+        "vbx_profile_reset": (C.c_int, [vp]),
+        "vbx_profile_get": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -411,6 +416,25 @@ class Map:
 
     def enable_timing(self, on=True):
         self._chk(self.L.vbx_enable_timing(self.h, int(on)))
+
+    def profile(self, on=True, reset=False):
+        """Per-kernel profile of the following integrate / ESDF / mesh calls (vbx_profile_enable)."""
+        if reset:
+            self._chk(self.L.vbx_profile_reset(self.h))
+        self._chk(self.L.vbx_profile_enable(self.h, int(on)))
+
+    def profile_table(self):
+        """{kernel: (launches, total_ms)}, number of API calls profiled."""
+        need = C.c_size_t(0)
+        calls = C.c_uint64(0)
+        self._chk(self.L.vbx_profile_get(self.h, None, 0, C.byref(need), C.byref(calls)))
+        buf = C.create_string_buffer(int(need.value) + 16)
+        self._chk(self.L.vbx_profile_get(self.h, buf, len(buf), None, None))
+        tab = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split("\t")
+            tab[name] = (int(n), float(ms))
+        return tab, int(calls.value)
 
     def timing(self):
         t = Timing()

@@ -61,6 +61,14 @@ struct vbx_ctx {
   uint32_t own_tag = 0;  // descending
   int own_s_bits = 0;
 
+  // per-kernel profile (vbx_profile_enable): every launch of the hot path bracketed by two events
+  struct ProfRec { const char* name; hipEvent_t e0, e1; };
+  bool prof = false;
+  std::vector<ProfRec> prof_recs;             // launches of the call in flight
+  std::vector<hipEvent_t> prof_pool;          // recycled events
+  std::map<std::string, std::pair<uint64_t, double>> prof_table;  // name -> (launches, total ms)
+  uint64_t prof_calls = 0;
+
   vbx_counters counters{};
   bool timing = false;
   hipEvent_t ev[9] = {};  // 0..7 stage boundaries in order, 8 = end of the exact-set solve inside stage 3
@@ -77,3 +85,51 @@ struct vbx_ctx {
   }
 };
 
+
+// Per-kernel profile: KLAUNCH is hipLaunchKernelGGL plus, when the handle's profile is on, an event
+// before and after the launch on the launch stream; prof_collect (end of every API call) turns the
+// pairs into per-kernel launch counts and durations.  Off (the default) it costs one branch.
+inline hipEvent_t prof_event(vbx_ctx* ctx) {
+  if (!ctx->prof_pool.empty()) {
+    hipEvent_t e = ctx->prof_pool.back();
+    ctx->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+inline void prof_begin(vbx_ctx* ctx, const char* name) {
+  if (!ctx->prof) return;
+  vbx_ctx::ProfRec r{name, prof_event(ctx), prof_event(ctx)};
+  (void)hipEventRecord(r.e0, ctx->stream);
+  ctx->prof_recs.push_back(r);
+}
+inline void prof_end(vbx_ctx* ctx) {
+  if (!ctx->prof || ctx->prof_recs.empty()) return;
+  (void)hipEventRecord(ctx->prof_recs.back().e1, ctx->stream);
+}
+inline void prof_collect(vbx_ctx* ctx) {
+  if (ctx->prof_recs.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (const auto& r : ctx->prof_recs) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      std::string n(r.name);
+      if (!n.empty() && n.front() == '(' && n.back() == ')') n = n.substr(1, n.size() - 2);
+      auto& t = ctx->prof_table[n];
+      t.first += 1;
+      t.second += ms;
+    }
+    ctx->prof_pool.push_back(r.e0);
+    ctx->prof_pool.push_back(r.e1);
+  }
+  ctx->prof_recs.clear();
+  ++ctx->prof_calls;
+}
+#define KLAUNCH(kern, ...)                      \
+  do {                                          \
+    prof_begin(ctx, #kern);                     \
+    hipLaunchKernelGGL(kern, __VA_ARGS__);      \
+    prof_end(ctx);                              \
+  } while (0)

@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
 #include <memory_resource>
 #include <mutex>
 #include <string>
@@ -219,7 +220,9 @@ int vbx_tsdf_integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, c
                               const float quat[4], const float* d_points_C, const uint8_t* d_rgba,
                               size_t n, int freespace_points) {
   if (!ctx) return VBX_ERR_INVALID;
-  return integrate_device(ctx, kind, cfg, pos, quat, d_points_C, d_rgba, n, freespace_points);
+  const int rc = integrate_device(ctx, kind, cfg, pos, quat, d_points_C, d_rgba, n, freespace_points);
+  prof_collect(ctx);
+  return rc;
 }
 
 int vbx_tsdf_integrate(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
@@ -237,13 +240,17 @@ int vbx_tsdf_integrate(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const fl
     HIP_TRY(hipMemcpyAsync(ctx->b_pts.p, points_C, n * 12, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->b_cols.p, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
-  return integrate_device(ctx, kind, cfg, pos, quat, ctx->b_pts.as<float>(),
-                          ctx->b_cols.as<uint8_t>(), n, freespace_points);
+  const int rc = integrate_device(ctx, kind, cfg, pos, quat, ctx->b_pts.as<float>(),
+                                  ctx->b_cols.as<uint8_t>(), n, freespace_points);
+  prof_collect(ctx);
+  return rc;
 }
 
 int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag) {
   if (!ctx || !cfg) return VBX_ERR_INVALID;
-  return esdf_update(ctx, cfg, batch, clear_updated_flag);
+  const int rc = esdf_update(ctx, cfg, batch, clear_updated_flag);
+  prof_collect(ctx);
+  return rc;
 }
 
 int vbx_esdf_update_blocks(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const int32_t* idx_xyz, size_t n, int incremental) {
@@ -851,6 +858,7 @@ int vbx_mesh_generate(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_mesh_updat
                       size_t* n_blocks, size_t* n_vertices) {
   if (!ctx || !cfg) return VBX_ERR_INVALID;
   int rc = mesh_generate(ctx, cfg, only_mesh_updated_blocks, clear_updated_flag);
+  prof_collect(ctx);
   if (rc) return rc;
   if (n_blocks) *n_blocks = ctx->mesh_off.size() - 1;
   if (n_vertices) *n_vertices = (size_t)ctx->mesh_off.back() * 3;
@@ -937,6 +945,38 @@ int vbx_enable_timing(vbx_ctx* ctx, int enable) {
 int vbx_get_timing(vbx_ctx* ctx, vbx_timing* out) {
   if (!ctx || !out) return VBX_ERR_INVALID;
   *out = ctx->last_timing;
+  return VBX_OK;
+}
+int vbx_profile_enable(vbx_ctx* ctx, int enable) {
+  if (!ctx) return VBX_ERR_INVALID;
+  prof_collect(ctx);
+  ctx->prof = enable != 0;
+  return VBX_OK;
+}
+int vbx_profile_reset(vbx_ctx* ctx) {
+  if (!ctx) return VBX_ERR_INVALID;
+  prof_collect(ctx);
+  ctx->prof_table.clear();
+  ctx->prof_calls = 0;
+  return VBX_OK;
+}
+int vbx_profile_get(vbx_ctx* ctx, char* buf, size_t cap, size_t* needed, uint64_t* calls) {
+  if (!ctx) return VBX_ERR_INVALID;
+  prof_collect(ctx);
+  std::string out;
+  char line[256];
+  for (const auto& kv : ctx->prof_table) {
+    snprintf(line, sizeof(line), "%s\t%llu\t%.6f\n", kv.first.c_str(), (unsigned long long)kv.second.first,
+             kv.second.second);
+    out += line;
+  }
+  if (needed) *needed = out.size() + 1;
+  if (calls) *calls = ctx->prof_calls;
+  if (buf && cap) {
+    const size_t n = std::min(out.size(), cap - 1);
+    std::memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
   return VBX_OK;
 }
 

@@ -16,7 +16,7 @@ int sync_state3(vbx_ctx* ctx, const uint32_t* const d_extra[3], uint32_t extra_o
     return VBX_OK;
   }
   const uint32_t seq = ++ctx->sync_seq;
-  hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, ctx->d_mirror, d_extra[0],
+  KLAUNCH(k_publish_state, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, ctx->d_mirror, d_extra[0],
                      d_extra[1], d_extra[2], seq);
   HIP_TRY(hipGetLastError());
   const auto t0 = std::chrono::steady_clock::now();
@@ -109,7 +109,9 @@ int sort_keys(vbx_ctx* ctx, uint64_t* in, uint64_t* out, size_t n, unsigned begi
   size_t tmp = 0;
   HIP_TRY(rocprim::radix_sort_keys<SortCfg>(nullptr, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
   HIP_TRY(ctx->b_tmp.ensure(tmp));
+  prof_begin(ctx, "rocprim::radix_sort_keys");
   HIP_TRY(rocprim::radix_sort_keys<SortCfg>(ctx->b_tmp.p, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
+  prof_end(ctx);
   return VBX_OK;
 }
 int sort_pairs(vbx_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
@@ -118,16 +120,20 @@ int sort_pairs(vbx_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint3
   HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
                                              ctx->stream));
   HIP_TRY(ctx->b_tmp.ensure(tmp));
+  prof_begin(ctx, "rocprim::radix_sort_pairs");
   HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(ctx->b_tmp.p, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
                                              ctx->stream));
+  prof_end(ctx);
   return VBX_OK;
 }
 int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
   size_t tmp = 0;
   HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
   HIP_TRY(ctx->b_tmp.ensure(tmp));
+  prof_begin(ctx, "rocprim::exclusive_scan");
   HIP_TRY(rocprim::exclusive_scan(ctx->b_tmp.p, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(),
                                   ctx->stream));
+  prof_end(ctx);
   return VBX_OK;
 }
 
@@ -141,14 +147,14 @@ int rsort_pass(vbx_ctx* ctx, const uint64_t* kin, const uint32_t* vin, uint64_t*
   hipStream_t s = ctx->stream;
   uint32_t* hist = ctx->b_hist0.as<uint32_t>();
   uint32_t* gofs = ctx->b_hist1.as<uint32_t>();
-  hipLaunchKernelGGL(k_rsort_count<CAP>, dim3(nwg), dim3(kSortThreads), 0, s, kin, n, shift, hist, nwg);
+  KLAUNCH(k_rsort_count<CAP>, dim3(nwg), dim3(kSortThreads), 0, s, kin, n, shift, hist, nwg);
   int rc = exclusive_scan_u32(ctx, hist, gofs, (size_t)(1u << CAP) * nwg);
   if (rc) return rc;
   if (with_vals)
-    hipLaunchKernelGGL((k_rsort_scatter<CAP, true>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n, shift,
+    KLAUNCH((k_rsort_scatter<CAP, true>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n, shift,
                        gofs, nwg);
   else
-    hipLaunchKernelGGL((k_rsort_scatter<CAP, false>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n,
+    KLAUNCH((k_rsort_scatter<CAP, false>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n,
                        shift, gofs, nwg);
   return VBX_OK;
 }

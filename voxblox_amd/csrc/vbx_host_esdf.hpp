@@ -58,9 +58,9 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
     for (;;) {
       for (int i = 0; i < 8; ++i) {
         ++sub;
-        hipLaunchKernelGGL((k_esdf_tile<VPS, true>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, 1, sub,
+        KLAUNCH((k_esdf_tile<VPS, true>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, 1, sub,
                            ctx->d_state);
-        hipLaunchKernelGGL(k_esdf_rotate_active_colour, grid_for(used), dim3(256), 0, s, ctx->map, e, used,
+        KLAUNCH(k_esdf_rotate_active_colour, grid_for(used), dim3(256), 0, s, ctx->map, e, used,
                            (int)(sub & 7u));
       }
       int rc = sync_state(ctx);
@@ -74,7 +74,7 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
     }
   }
   if (mode == 2) {
-    hipLaunchKernelGGL((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, 1u, ctx->d_state);
+    KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, 1u, ctx->d_state);
     ++*sweeps;
     return VBX_OK;
   }
@@ -86,9 +86,9 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
     constexpr int kPerCheck = 3;
     for (int i = 0; i < kPerCheck; ++i) {
       ++sweep_no;
-      hipLaunchKernelGGL((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, sweep_no,
+      KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, sweep_no,
                          ctx->d_state);
-      hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
+      KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
     }
     int rc = sync_state(ctx);
     if (rc) return rc;
@@ -137,21 +137,21 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   if (batch) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
   const bool robot_pending = ctx->esdf_robot_pending && !batch;
   ctx->esdf_robot_pending = false;
-  hipLaunchKernelGGL(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0);
+  KLAUNCH(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0);
   HIP_TRY(hipMemsetAsync(&ctx->d_state->esdf_blocks, 0, 12, s));
   if (list) {
     HIP_TRY(ctx->b_head.ensure(std::max<size_t>(n_list, 1) * 12));
     HIP_TRY(hipMemcpyAsync(ctx->b_head.p, list, n_list * 12, hipMemcpyHostToDevice, s));
     if (n_list)
-      hipLaunchKernelGGL(k_esdf_mark_listed, grid_for(n_list), dim3(256), 0, s, m, e, ctx->b_head.as<int32_t>(),
+      KLAUNCH(k_esdf_mark_listed, grid_for(n_list), dim3(256), 0, s, m, e, ctx->b_head.as<int32_t>(),
                          (uint32_t)n_list);
-    hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
+    KLAUNCH(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
                        list_incremental ? 1 : 0, 2, ctx->d_state);
   } else {
-    hipLaunchKernelGGL(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
+    KLAUNCH(k_esdf_classify, dim3(used, (m.nvox + 255) / 256), dim3(256), 0, s, m, e, c,
                        batch ? 0 : 1, batch ? 0 : 1, ctx->d_state);
   }
-  hipLaunchKernelGGL(k_esdf_seed_active, grid_for((size_t)used * 27), dim3(256), 0, s, m, e, used);
+  KLAUNCH(k_esdf_seed_active, grid_for((size_t)used * 27), dim3(256), 0, s, m, e, used);
   rc = sync_state(ctx);
   if (rc) return rc;
   tmark(ctx, 1);
@@ -165,12 +165,12 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
     if (ctx->h_state.esdf_raise_any || robot_pending) {
       rc = esdf_phase<VPS, FULL>(ctx, e, cr, 0, used, &sweeps);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+      KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
     }
     tmark(ctx, 3);
     rc = esdf_phase<VPS, FULL>(ctx, e, cr, 1, used, &sweeps);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+    KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
     if (!FULL) {  // full-Euclidean parents are part of the state, not a by-product to canonicalise
       rc = esdf_phase<VPS, FULL>(ctx, e, cr, 2, used, &sweeps);
       if (rc) return rc;
@@ -179,7 +179,7 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
     if (ctx->h_state.esdf_raise_any || robot_pending) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
   }
   if (clear_updated_flag && !batch)
-    hipLaunchKernelGGL(k_esdf_clear_tsdf_bit, grid_for(used), dim3(256), 0, s, m, e, used);
+    KLAUNCH(k_esdf_clear_tsdf_bit, grid_for(used), dim3(256), 0, s, m, e, used);
   tmark(ctx, 7);
   rc = sync_state(ctx);
   if (rc) return rc;
@@ -231,12 +231,12 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
     HIP_TRY(hipStreamSynchronize(s));  // xs is a stack-lifetime staging buffer
     sp.xs = bx.as<float>();
     const size_t cube = (size_t)sp.n * sp.n * sp.n;
-    hipLaunchKernelGGL(k_sphere_mark_blocks, grid_for(cube), dim3(256), 0, s, m, sp, ctx->b_newlist.as<uint32_t>(),
+    KLAUNCH(k_sphere_mark_blocks, grid_for(cube), dim3(256), 0, s, m, sp, ctx->b_newlist.as<uint32_t>(),
                        ctx->d_state);
-    hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+    KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
                        ctx->d_state);
-    hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-    hipLaunchKernelGGL(k_sphere_apply, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, pass);
+    KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    KLAUNCH(k_sphere_apply, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, pass);
   }
   ctx->esdf_robot_pending = true;
   rc = sync_state(ctx);

@@ -20,10 +20,10 @@ int mesh_generate_t(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_updated, int
   HIP_TRY(ctx->b_mesh_tab.ensure(n1 * 16));
   uint32_t* head = ctx->b_head.as<uint32_t>();
   uint32_t* rank = ctx->b_rank.as<uint32_t>();
-  hipLaunchKernelGGL(k_mesh_select, grid_for(n1), dim3(256), 0, s, m, used, only_updated, head);
+  KLAUNCH(k_mesh_select, grid_for(n1), dim3(256), 0, s, m, used, only_updated, head);
   rc = exclusive_scan_u32(ctx, head, rank, n1);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_mesh_compact, grid_for(n1), dim3(256), 0, s, used, head, rank, ctx->b_mesh_list.as<uint32_t>(),
+  KLAUNCH(k_mesh_compact, grid_for(n1), dim3(256), 0, s, used, head, rank, ctx->b_mesh_list.as<uint32_t>(),
                      ctx->b_mesh_cnt.as<uint32_t>());
   MeshDev d{};
   d.list = ctx->b_mesh_list.as<uint32_t>();
@@ -35,7 +35,7 @@ int mesh_generate_t(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_updated, int
   d.block_size_inv = (float)(1.0 / (double)d.block_size);     // layer.h:41
   // pass 1 over every pool slot's worth of workgroups: the number of selected blocks is still on
   // the device, surplus workgroups leave at once
-  hipLaunchKernelGGL((k_mesh_block<VPS, false>), dim3(used), dim3(MeshThreads<VPS>::value), 0, s, m, d);
+  KLAUNCH((k_mesh_block<VPS, false>), dim3(used), dim3(MeshThreads<VPS>::value), 0, s, m, d);
   rc = exclusive_scan_u32(ctx, ctx->b_mesh_cnt.as<uint32_t>(), ctx->b_mesh_off.as<uint32_t>(), n1);
   if (rc) return rc;
   const uint32_t* const ex[3] = {rank + used, ctx->b_mesh_off.as<uint32_t>() + used, nullptr};
@@ -50,10 +50,10 @@ int mesh_generate_t(vbx_ctx* ctx, const vbx_mesh_cfg* cfg, int only_updated, int
   d.verts = ctx->b_mesh_verts.as<float>();
   d.normals = ctx->b_mesh_normals.as<float>();
   d.colors = cfg->use_color ? ctx->b_mesh_colors.as<uint32_t>() : nullptr;
-  if (n_tri) hipLaunchKernelGGL((k_mesh_block<VPS, true>), dim3(n_list), dim3(MeshThreads<VPS>::value), 0, s, m, d);
+  if (n_tri) KLAUNCH((k_mesh_block<VPS, true>), dim3(n_list), dim3(MeshThreads<VPS>::value), 0, s, m, d);
   int32_t* tab_idx = ctx->b_mesh_tab.as<int32_t>();
   uint32_t* tab_off = reinterpret_cast<uint32_t*>(tab_idx + 3 * n1);
-  hipLaunchKernelGGL(k_mesh_finish, grid_for((size_t)n_list + 1), dim3(256), 0, s, m, d, clear_flag, tab_idx, tab_off);
+  KLAUNCH(k_mesh_finish, grid_for((size_t)n_list + 1), dim3(256), 0, s, m, d, clear_flag, tab_idx, tab_off);
   ctx->mesh_idx.resize((size_t)n_list * 3);
   ctx->mesh_off.resize((size_t)n_list + 1);
   HIP_TRY(hipMemcpyAsync(ctx->mesh_idx.data(), tab_idx, (size_t)n_list * 12, hipMemcpyDeviceToHost, s));

@@ -10,10 +10,10 @@ int visiting_order(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float* d_pts, si
   HIP_TRY(ctx->b_keys0.ensure(n * 8));
   HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_order.ensure(n * 4));
-  hipLaunchKernelGGL(k_sorted_keys, grid_for(n), dim3(256), 0, ctx->stream, d_pts, n, ctx->b_keys0.as<uint64_t>());
+  KLAUNCH(k_sorted_keys, grid_for(n), dim3(256), 0, ctx->stream, d_pts, n, ctx->b_keys0.as<uint64_t>());
   int rc = stable_sort01(ctx, n, 0, 64, false);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sorted_inverse, grid_for(n), dim3(256), 0, ctx->stream, ctx->b_keys1.as<uint64_t>(), n,
+  KLAUNCH(k_sorted_inverse, grid_for(n), dim3(256), 0, ctx->stream, ctx->b_keys1.as<uint64_t>(), n,
                      ctx->b_order.as<uint32_t>());
   *order = ctx->b_order.as<uint32_t>();
   return VBX_OK;
@@ -39,13 +39,13 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   float* in_uw = in_sdf + total;
   uint32_t* in_col = reinterpret_cast<uint32_t*>(in_uw + total);
   HIP_TRY(hipMemsetAsync(&ctx->d_state->fold_long_count, 0, 4, s));
-  hipLaunchKernelGGL(k_fold_inputs, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c,
+  KLAUNCH(k_fold_inputs, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c,
                      m, in_sdf, in_uw, in_col);
-  hipLaunchKernelGGL(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m, in_sdf,
+  KLAUNCH(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m, in_sdf,
                      in_uw, in_col, ctx->b_long.as<uint32_t>(), ctx->d_state);
   {
     const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);
-    hipLaunchKernelGGL(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c,
+    KLAUNCH(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c,
                        m, in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), ctx->d_state);
   }
   tmark(ctx, 6);
@@ -65,16 +65,16 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
 
   HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
-  hipLaunchKernelGGL(k_ray_count, grid_for(R + 1), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0,
+  KLAUNCH(k_ray_count, grid_for(R + 1), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0,
                      limit, ctx->b_cnt.as<uint32_t>());
   int rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
   if (!blocks_already_marked) {
-    hipLaunchKernelGGL(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, tab, c, m,
+    KLAUNCH(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, tab, c, m,
                        from_origin ? 1 : 0, limit, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-    hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+    KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
                        ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-    hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
     tmark(ctx, 2);
   }
   // total number of keys = off[R]
@@ -87,10 +87,10 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
 
   HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
   HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));
-  hipLaunchKernelGGL(k_ray_emit, grid_for(R), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0, limit,
+  KLAUNCH(k_ray_emit, grid_for(R), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0, limit,
                      ctx->b_off.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), graze_keys, n_graze,
                      ctx->d_state);
-  hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, tab.flags, R, ctx->d_state);
+  KLAUNCH(k_count_cast, grid_for(R), dim3(256), 0, s, tab.flags, R, ctx->d_state);
   tmark(ctx, 4);
   return sort_and_fold(ctx, tab, c, total);
 }
@@ -107,7 +107,7 @@ int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   if (rc) return rc;
   RayTab tab = make_tab(ctx, false, (uint32_t)n);
   tab.bkey = nullptr;
-  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
+  KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
                      freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv,
                      ctx->d_state);
   tmark(ctx, 1);
@@ -225,13 +225,13 @@ int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t**
   HIP_TRY(ctx->b_T.ensure((n + 1) * 4));          // positions
   uint32_t* by_s = ctx->b_cnt.as<uint32_t>();
   HIP_TRY(hipMemsetAsync(by_s, 0xFF, n * 4, s));
-  hipLaunchKernelGGL(k_merged_mark_first, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+  KLAUNCH(k_merged_mark_first, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(),
                      (uint32_t)n, by_s, ctx->b_bkeys.as<uint64_t>());
-  hipLaunchKernelGGL(k_merged_first_flags, grid_for(n + 1), dim3(256), 0, s, by_s, (uint32_t)n, ctx->b_off.as<uint32_t>());
+  KLAUNCH(k_merged_first_flags, grid_for(n + 1), dim3(256), 0, s, by_s, (uint32_t)n, ctx->b_off.as<uint32_t>());
   int rc = exclusive_scan_u32(ctx, ctx->b_off.as<uint32_t>(), ctx->b_T.as<uint32_t>(), n + 1);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_merged_insertion_order, grid_for(n), dim3(256), 0, s, by_s, ctx->b_T.as<uint32_t>(),
+  KLAUNCH(k_merged_insertion_order, grid_for(n), dim3(256), 0, s, by_s, ctx->b_T.as<uint32_t>(),
                      ctx->b_bkeys.as<uint64_t>(), (uint32_t)n, ctx->b_bfirst.as<uint64_t>());
   HIP_TRY(ctx->h_mkeys.ensure((size_t)nb * 8));
   HIP_TRY(ctx->h_mperm.ensure((size_t)nb * 4));
@@ -288,19 +288,19 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   HIP_TRY(ctx->b_pcx.ensure(n * 4)); HIP_TRY(ctx->b_pcy.ensure(n * 4)); HIP_TRY(ctx->b_pcz.ensure(n * 4));
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
-  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
+  KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
                      pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), order,
                      ctx->map.voxel_size_inv, ctx->d_state);
   // bundleRays (tsdf_integrator.cc:340-371): group points by endpoint voxel.  A stable sort
   // of (key, s) keeps each bundle's points in visiting order.
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
-  hipLaunchKernelGGL(k_merged_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, ctx->map,
+  KLAUNCH(k_merged_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, ctx->map,
                      ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
   rc = stable_sort01(ctx, n, 0, 64, true);
   if (rc) return rc;
   HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
-  hipLaunchKernelGGL(k_merged_heads, grid_for(n + 1), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+  KLAUNCH(k_merged_heads, grid_for(n + 1), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      (uint32_t)n, ctx->b_head.as<uint32_t>());
   rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
   if (rc) return rc;
@@ -325,12 +325,12 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   float* gy = gx + n;
   float* gz = gy + n;
   uint32_t* gc = reinterpret_cast<uint32_t*>(gz + n);
-  hipLaunchKernelGGL(k_merged_starts, grid_for(n), dim3(256), 0, s, ctx->b_head.as<uint32_t>(),
+  KLAUNCH(k_merged_starts, grid_for(n), dim3(256), 0, s, ctx->b_head.as<uint32_t>(),
                      ctx->b_rank.as<uint32_t>(), (uint32_t)n, ctx->b_bstart.as<uint32_t>());
-  hipLaunchKernelGGL(k_merged_gather, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+  KLAUNCH(k_merged_gather, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(),
                      ctx->b_pcz.as<float>(), gw, gx, gy, gz, gc);
-  hipLaunchKernelGGL(k_merged_bundle8, grid_for((size_t)nb * 8), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+  KLAUNCH(k_merged_bundle8, grid_for((size_t)nb * 8), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_bstart.as<uint32_t>(), nb, (uint32_t)n, gw, gx, gy, gz, gc, T, bt,
                      ctx->b_graze.as<uint64_t>(), perm);
   tmark(ctx, 1);
@@ -386,24 +386,24 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   if (rc) return rc;
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
-  hipLaunchKernelGGL(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
+  KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
                      pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv, ctx->d_state);
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
-  hipLaunchKernelGGL(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,
+  KLAUNCH(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,
                      ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
   // keys[s] = slot << 32 | s is written in visiting order: a stable sort on the 20 slot bits
   // (+ bit 52, set only in the all-ones key of dropped points) orders by (slot, s)
   rc = stable_sort01(ctx, n, 32, 53, true);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_fast_start_dedupe, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+  KLAUNCH(k_fast_start_dedupe, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
                      ctx->start_offset, ctx->start_sentinel_live ? 1 : 0, pt.flags);
-  hipLaunchKernelGGL(k_fast_start_commit, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+  KLAUNCH(k_fast_start_commit, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
                      ctx->start_offset, ctx->d_state);
   HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
-  hipLaunchKernelGGL(k_compact_flags, grid_for(n + 1), dim3(256), 0, s, pt.flags, (uint32_t)n,
+  KLAUNCH(k_compact_flags, grid_for(n + 1), dim3(256), 0, s, pt.flags, (uint32_t)n,
                      ctx->b_head.as<uint32_t>());
   rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
   if (rc) return rc;
@@ -411,7 +411,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   if (rc) return rc;
   RayTab kt = make_tab(ctx, true, 0);
   kt.bkey = nullptr;
-  hipLaunchKernelGGL(k_compact_rays, grid_for(n), dim3(256), 0, s, pt, ctx->b_head.as<uint32_t>(),
+  KLAUNCH(k_compact_rays, grid_for(n), dim3(256), 0, s, pt, ctx->b_head.as<uint32_t>(),
                      ctx->b_rank.as<uint32_t>(), (uint32_t)n, kt, ctx->d_state);
   rc = sync_state(ctx);
   if (rc) return rc;
@@ -425,7 +425,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   // Layer ("published") when a ray actually reaches it (k_fast_emit).
   HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
-  hipLaunchKernelGGL(k_ray_count, grid_for(R + 1), dim3(256), 0, s, kt, c, m, 0,
+  KLAUNCH(k_ray_count, grid_for(R + 1), dim3(256), 0, s, kt, c, m, 0,
                      (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>());
   rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
@@ -437,16 +437,16 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   const size_t vox_cap = std::min<size_t>((size_t)R * per_ray + 64, 0xFFFFFFF0u);
   HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
   HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
-  hipLaunchKernelGGL(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
+  KLAUNCH(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
                      ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
                      (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
-  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+  KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
                      ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
   // second pass over the queued rays (grid sized for the first-frame worst case; idle
   // workgroups leave at once); capacity / lookup errors surface at the solver's first check
   if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
-  hipLaunchKernelGGL(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
+  KLAUNCH(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
                      ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap,
                      ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
   tmark(ctx, 2);
@@ -537,11 +537,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
           if (writes_list && !have_list) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[sa.cnt_out], 0, 4, s));
           if (iters == 0)
-            hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
+            KLAUNCH(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
           else if (n_open <= 8192)  // few open rays: a whole wave per ray (64 list entries per step)
-            hipLaunchKernelGGL(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
+            KLAUNCH(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
           else
-            hipLaunchKernelGGL(k_fast_sweep<16>, grid_for((size_t)n_open * 16), dim3(256), 0, s, sa, R, ctx->d_state);
+            KLAUNCH(k_fast_sweep<16>, grid_for((size_t)n_open * 16), dim3(256), 0, s, sa, R, ctx->d_state);
           if (writes_ch) {
             tag_rd = sa.tag_wr;
             ch_flip ^= 1;
@@ -579,7 +579,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   rc = run_solver();
   if (rc) return rc;
   if (keep_observed)
-    hipLaunchKernelGGL(k_fast_mark_observed, grid_for((size_t)R * 16), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
+    KLAUNCH(k_fast_mark_observed, grid_for((size_t)R * 16), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
                        ctx->b_vox.as<uint32_t>(), ctx->b_T.as<uint32_t>(), R, ctx->b_obs.as<uint32_t>(),
                        ctx->obs_epoch);
   if (strict_set) {
@@ -630,16 +630,16 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(Ptot, 1)));
         if (!Pb) HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
         if (Pb) {
-          hipLaunchKernelGGL(k_strict_keys, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, a, b, pa, Pb, ctx->b_off.as<uint32_t>(),
+          KLAUNCH(k_strict_keys, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, a, b, pa, Pb, ctx->b_off.as<uint32_t>(),
                              ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
           rc = stable_sort01(ctx, Pb, 44, 64, false);
           if (rc) return rc;
-          hipLaunchKernelGGL(k_strict_outcome, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
+          KLAUNCH(k_strict_outcome, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
                              ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
                              ctx->b_collided.as<uint8_t>());
         }
         if (dbg) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
-        hipLaunchKernelGGL(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
+        KLAUNCH(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
                            R, a, b, ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext,
                            ctx->b_U.as<uint32_t>(), ctx->b_moved.as<uint8_t>(), dbg ? 1 : 0, ctx->d_state);
         std::swap(Tcur, Tnext);
@@ -648,7 +648,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       // converged: the sorted probe list of the last round (whose T equals the final T) is still
       // in keys1 — its last probe per slot is the set's content after ray b - 1
       if (*converged && Pb)
-        hipLaunchKernelGGL(k_strict_commit, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
+        KLAUNCH(k_strict_commit, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
                            ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
       return VBX_OK;
     };
@@ -659,7 +659,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     if (rc) return rc;
     // Blocks pay off only when whole-frame rounds are expensive (millions of probes, i.e. fine
     // voxels): 16-32 blocks cost at least two cheap rounds each.
-    const bool use_blocks = ctx->h_poff_total > 1500000u;
+    static const bool no_blocks = getenv("VBX_REPLAY_NO_BLOCKS") != nullptr;  // measurement switch
+    const bool use_blocks = ctx->h_poff_total > 1500000u && !no_blocks;
     if (!converged && !use_blocks) {
       rc = replay(0, R, 100000, &converged);
       if (rc) return rc;
@@ -668,6 +669,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         return VBX_ERR_HIP;
       }
     }
+    const uint32_t rounds_whole_frame = rounds;
     if (!converged) {
       // Phase 2: long dependency chains (a fresh map, or more probed voxels than set slots: every
       // round then only fixes the next link).  Rays below the lowest one that still moved are
@@ -676,7 +678,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       // the rays before it, so its rounds are cheap (a 1/16 of the probes) and short chains
       // inside a block converge in a few of them.
       HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[2], 0xFF, 4, s));
-      hipLaunchKernelGGL(k_strict_first_moved, grid_for(R), dim3(256), 0, s, ctx->b_moved.as<uint8_t>(), R,
+      KLAUNCH(k_strict_first_moved, grid_for(R), dim3(256), 0, s, ctx->b_moved.as<uint8_t>(), R,
                          &ctx->d_state->act_count[2]);
       rc = exclusive_scan_u32(ctx, Tcur, poff, R + 1);
       if (rc) return rc;
@@ -715,6 +717,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       }
     }
     ctx->counters.replay_rounds = rounds;
+    ctx->counters.replay_block_rounds = use_blocks ? rounds - rounds_whole_frame : 0;
   }
   uint32_t total = 0;
   // offsets of the keys each ray emits
@@ -725,11 +728,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   if (strict_set && ctx->h_state.sentinel_cleared) ctx->obsset_sentinel_live = false;
   ctx->counters.iterations = iters_total;
   tmark(ctx, 3);
-  hipLaunchKernelGGL(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
+  KLAUNCH(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
   if (total == 0) return VBX_OK;
   HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
   HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));
-  hipLaunchKernelGGL(k_fast_emit, grid_for(total), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
+  KLAUNCH(k_fast_emit, grid_for(total), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),
                      ctx->b_vox.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R, total, m,
                      ctx->b_keys0.as<uint64_t>(), ctx->d_state);
   tmark(ctx, 4);
@@ -760,7 +763,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters.points = n;
   if (n == 0) return kind == VBX_TSDF_FAST ? fast_frame_tick(ctx, cfg) : VBX_OK;
   // per-call device counters
-  hipLaunchKernelGGL(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
+  KLAUNCH(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
   Pose T;
   T.t = {pos[0], pos[1], pos[2]};
   T.qw = quat[0]; T.qx = quat[1]; T.qy = quat[2]; T.qz = quat[3];
