@@ -1,20 +1,35 @@
 #!/usr/bin/env python
-"""bench.py — Mpoints/s integrated by the HIP TSDF hot path on MI355X.
+"""bench.py — Mpoints/s integrated by the HIP TSDF hot path on MI355X (BASELINE.json's metric).
 
-Workload (BASELINE.json configs[1]): FastTsdfIntegrator, 640x480 synthetic room-scan stream
-(voxblox_amd.scenes.room_frame), 0.05 m voxels / 16^3 blocks, truncation 4 voxels, all other
-Config defaults.  One "step" = one integratePointCloud() call on one 307,200-point frame
-whose points/colours are already resident in HBM (vbx_tsdf_integrate_device).
+Workloads
+  stream    BASELINE configs[1] (default at --gpus 1): FastTsdfIntegrator, 640x480 synthetic room-scan
+            stream (voxblox_amd.scenes.room_frame), 0.05 m voxels / 16^3 blocks, truncation 4 voxels, every
+            other Config default.  One step = one integratePointCloud() call on one 307,200-point frame
+            whose points/colours are already resident in HBM (vbx_tsdf_integrate_device).
+            Variants: --integrator merged --scene cow (configs[2]), --esdf (configs[3]), --mesh, --voxel.
+  sensors4  BASELINE configs[4] (default at --gpus N > 1): four concurrent 640x480 sensors, 0.02 m voxels,
+            ray-bundle shards over the ranks (whole sensors at N <= 4, two contiguous bands per sensor at
+            N = 8), every rank integrating its shards into a per-step delta map, a sparse RCCL all-to-all
+            of the touched blocks' weighted sums to the block owners, owner merge into the persistent map
+            (voxblox_amd/multi_gpu.py).  One step = all four sensors' frames; the total work
+            per step is the same for every N (strong scaling), and `--gpus 1 --workload sensors4` runs
+            the very same shard + merge on one GPU.
 
-Contract (see the task statement): W untimed warm-up steps, then exactly K timed steps
-bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints
-ONE JSON line.  For --gpus N every rank integrates its own sensor's frame (weak scaling) into a per-frame
-delta map; overlapping block updates are merged with an RCCL reduce-scatter into a persistent
-map distributed by block ownership (voxblox_amd/multi_gpu.py).
+Contract: W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+`--gpus N` without a launcher spawns the N ranks itself (torch.distributed.run, 127.0.0.1) and fails loudly
+when the box has fewer GPUs; under a launcher (RANK set) it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+The JSON line's `roofline` block is computed from the per-kernel table measured in this run (vbx_profile_*:
+two HIP events around every launch on the launch stream, a separate pass over the same stream right after
+the timed region so that the events stay out of `value`); `cpu_baseline` times the reference's own sources
+(oracle/_ref) on this host for integrator_threads in {1,2,4,...,nproc}.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,56 +39,84 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 VOXEL = 0.05
-TRUNC = 4 * VOXEL
 N_STREAM = 100
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 60 for stream, 25 for sensors4)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps (default 5 for stream, 2 for sensors4)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "stream", "sensors4"])
     ap.add_argument("--integrator", default="fast", choices=["fast", "merged", "simple"])
     ap.add_argument("--esdf", action="store_true",
                     help="BASELINE configs[3]: EsdfIntegrator::updateFromTsdfLayer(true) after every frame")
     ap.add_argument("--mesh", action="store_true",
-                    help="MeshIntegrator::generateMesh(only_mesh_updated_blocks=true, clear_updated_flag=true) "
-                         "after every frame (SURVEY 8(f) #4), reported beside the integration")
+                    help="MeshIntegrator::generateMesh(true, true) after every frame (SURVEY 8(f) #4)")
     ap.add_argument("--scene", default="room", choices=["room", "cow"],
                     help="room = configs[1]/[3] stream; cow = configs[2] Cow-and-Lady-style orbit")
-    ap.add_argument("--voxel", type=float, default=VOXEL,
-                    help="voxel size (default = configs[1]'s 0.05 m; 0.02 = configs[4]'s resolution); "
-                         "truncation stays 4 voxels")
+    ap.add_argument("--voxel", type=float, default=0.0, help="voxel size (default 0.05 for stream, 0.02 for sensors4)")
     ap.add_argument("--max-blocks", type=int, default=0, help="block pool capacity (0 = sized from --voxel)")
-    ap.add_argument("--merged-order", type=int, default=0, choices=[0, 1],
-                    help="Merged only: 0 = the reference's unordered_map bundle order (bit-exact, host replay), "
-                         "1 = ascending voxel key (no host step)")
-    ap.add_argument("--fast-set", type=int, default=0, choices=[0, 1],
-                    help="Fast only: 0 = the reference's approximate observed-voxel set (bit-exact, iterative replay), "
-                         "1 = exact voxel set (one solve)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the fast-mode variant measurement")
+    ap.add_argument("--merged-order", type=int, default=0, choices=[0, 1])
+    ap.add_argument("--fast-set", type=int, default=0, choices=[0, 1])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mirror-frames", type=int, default=8,
-                    help="extra untimed-for-`value` frames that also mirror the touched blocks to the host "
-                         "(vbx_blocks_updated + vbx_blocks_download + vbx_clear_updated); 0 = skip")
-    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default run only: skip the short secondary legs (configs[2], configs[3], configs[4] on 1 GPU)")
+    ap.add_argument("--mirror-frames", type=int, default=8, help="stream: frames that also mirror touched blocks to the host")
+    ap.add_argument("--profile-frames", type=int, default=12, help="frames of the per-kernel profile pass (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-reference sample")
     return ap.parse_args()
 
 
-def cpu_baseline(frames, kind, voxel=VOXEL):
-    """Times the oracle (CPU restatement of the reference, reference threading scheme) on a
-    bounded sample of the same stream: threads = host cores, median frame after 3 warm-ups."""
+# ------------------------------------------------------------------------------------------------
+# launcher: --gpus N spawns N ranks
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn(args):
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this box has {have} "
+                         "(one rank per GPU; RCCL refuses two ranks on one device)\n")
+        sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines: the reference's own sources (oracle/_ref) when built, else the restatement
+# ------------------------------------------------------------------------------------------------
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ctypes
     import oracle_py as O
-    cores = os.cpu_count() or 1
-    # oracle/_ref = the reference's own sources (over dependency shims) when it was built;
-    # otherwise the restatement.
     use_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libvbxref.so"))
-    L = O.ref_lib() if use_ref else O.lib()
-    best = None
-    for threads in sorted({1, min(cores, 8), cores}):
+    return O, (O.ref_lib() if use_ref else O.lib()), use_ref
+
+
+def _thread_counts(cores):
+    return sorted({t for t in (1, 2, 4, 8, 16, 32, 64, cores) if t <= cores})
+
+
+def cpu_baseline(frames, kind, voxel, seconds):
+    """integratePointCloud of the reference on a bounded sample of the same frames, for every thread count
+    in {1,2,4,...,nproc} (its own spawn-per-call threading); median frame after 2 warm-up frames."""
+    import ctypes
+    O, L, use_ref = _oracle()
+    cores = os.cpu_count() or 1
+    counts = _thread_counts(cores)
+    per = max(seconds / len(counts), 0.5)
+    by = {}
+    for threads in counts:
         L.orc_fast_reset_counter_set(0)
         m = O.OracleMap(voxel, 16, L=L)
         c = O.TsdfCfg()
@@ -87,41 +130,66 @@ def cpu_baseline(frames, kind, voxel=VOXEL):
             t0 = time.perf_counter()
             it.integrate(pose[0], pose[1], pts, col)
             ts.append(time.perf_counter() - t0)
-            if time.time() - t_begin > 8.0 and i >= 5:
+            if time.time() - t_begin > per and i >= 3:
                 break
-        used = ts[3:] if len(ts) > 4 else ts
+        used = ts[2:] if len(ts) > 3 else ts
         med = float(np.median(used))
-        rec = dict(value=round(frames[0][1].shape[0] / med / 1e6, 3), threads=threads,
-                   frames=len(ts), median_ms=round(med * 1e3, 2))
-        if best is None or rec["value"] > best["value"]:
-            best = rec
+        by[str(threads)] = {"value": round(frames[0][1].shape[0] / med / 1e6, 3), "median_ms": round(med * 1e3, 2),
+                            "frames": len(ts)}
         del it, m
-    return {"value": best["value"], "unit": "Mpoints/s", "cores": best["threads"],
-            "kind": "reference" if use_ref else "port",
-            "sample": f"{best['frames']} frames of the same 640x480 room stream, {kind} integrator "
-                      + ("(reference sources compiled over dependency shims, oracle/_ref), "
-                         if use_ref else "(oracle restatement), ")
-                      + f"median frame {best['median_ms']} ms after 3 warm-up frames, "
-                      f"best of integrator_threads in {{1,{min(cores, 8)},{cores}}} (host has {cores} hw threads)"}
+    best = max(by, key=lambda k: by[k]["value"])
+    return {"value": by[best]["value"], "unit": "Mpoints/s", "cores": int(best),
+            "kind": "reference" if use_ref else "port", "host_hw_threads": cores, "by_threads": by,
+            "sample": f"{kind} integrator, {voxel:g} m voxels, the first frames of the same stream per thread count "
+                      f"(about {per:.1f} s each, median after 2 warm-up frames), "
+                      + ("reference sources compiled over dependency shims (oracle/_ref)" if use_ref
+                         else "oracle restatement")}
+
+
+def cpu_esdf_baseline(frames, voxel, seconds):
+    """Reference Fast integration + EsdfIntegrator::updateFromTsdfLayer(true) after every frame
+    (esdf_integrator.cc:104-122); the ESDF call is what is timed.  Single thread: the ESDF integrator has none."""
+    import ctypes
+    O, L, use_ref = _oracle()
+    L.orc_fast_reset_counter_set(0)
+    m = O.OracleMap(voxel, 16, L=L)
+    c = O.TsdfCfg()
+    L.orc_tsdf_cfg_default(ctypes.byref(c))
+    c.default_truncation_distance = 4 * voxel
+    c.integrator_threads = min(os.cpu_count() or 1, 8)
+    it = m.tsdf_integrator("fast", c)
+    ec = O.EsdfCfg()
+    L.orc_esdf_cfg_default(ctypes.byref(ec))
+    ec.min_distance_m = 2 * voxel
+    e = m.esdf_integrator(ec)
+    ts = []
+    t_begin = time.time()
+    for i, (pose, pts, col) in enumerate(frames):
+        it.integrate(pose[0], pose[1], pts, col)
+        t0 = time.perf_counter()
+        e.update_from_tsdf_layer(True)
+        ts.append(time.perf_counter() - t0)
+        if time.time() - t_begin > seconds and i >= 4:
+            break
+    used = ts[2:] if len(ts) > 3 else ts
+    st = e.stats()
+    return {"ms_per_update": round(float(np.median(used)) * 1e3, 3), "cores": 1, "kind": "reference" if use_ref else "port",
+            "frames": len(ts), "relaxations_per_update": round(st["relaxations"] / max(len(ts), 1), 1),
+            "sample": "updateFromTsdfLayer(true) after every frame of the same stream, median after 2 warm-up frames"}
 
 
 def cpu_mesh_baseline(frames, kind, voxel):
-    """The reference's MeshIntegrator (oracle/_ref when built, else the restatement) after every
-    frame of a short sample of the same stream: generateMesh(true, true), 1 thread and all cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctypes
-    import oracle_py as O
+    O, L, use_ref = _oracle()
     cores = os.cpu_count() or 1
-    use_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libvbxref.so"))
-    L = O.ref_lib() if use_ref else O.lib()
     res = {}
-    for threads in (sorted({1, cores}) if use_ref else [1]):   # the restatement meshes on one thread
+    for threads in (sorted({1, cores}) if use_ref else [1]):
         L.orc_fast_reset_counter_set(0)
         m = O.OracleMap(voxel, 16, L=L)
         c = O.TsdfCfg()
         L.orc_tsdf_cfg_default(ctypes.byref(c))
         c.default_truncation_distance = 4 * voxel
-        c.integrator_threads = cores
+        c.integrator_threads = min(cores, 8)
         it = m.tsdf_integrator(kind, c)
         ml = m.mesh_layer()
         ts = []
@@ -137,148 +205,407 @@ def cpu_mesh_baseline(frames, kind, voxel):
             "sample": f"{len(frames)} frames, median after 2 warm-ups, best of integrator_threads in {sorted(res)}"}
 
 
+# ------------------------------------------------------------------------------------------------
+# per-kernel table -> roofline
+# ------------------------------------------------------------------------------------------------
+def kernel_table(gm, calls_per_step=1.0):
+    tab, calls = gm.profile_table()
+    steps = max(calls / calls_per_step, 1e-9)
+    rows = [{"kernel": k, "launches_per_step": round(n / steps, 2), "avg_us": round(1e3 * ms / n, 2),
+             "us_per_step": round(1e3 * ms / steps, 1)} for k, (n, ms) in tab.items() if n]
+    rows.sort(key=lambda r: -r["us_per_step"])
+    return rows, calls
+
+
+def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
+    """The dominant kernel = the one with the largest time per step in the measured table.  `achieved` =
+    the step's algorithmic bytes over that kernel's time per step (all of its launches in one step — the
+    kernel is launched several times per frame and no single launch processes a frame's bytes); the same
+    bytes over the whole step's device time is `step_frac`."""
+    if not rows:
+        return None
+    dom = rows[0]
+    t = dom["us_per_step"] * 1e-6
+    achieved = alg_bytes_per_step / t / 1e9 if t > 0 else 0.0
+    total_us = sum(r["us_per_step"] for r in rows)
+    return {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+            "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
+            "kernel_us_per_step": dom["us_per_step"], "algorithmic_bytes_per_step": int(alg_bytes_per_step),
+            "algorithmic_bytes": what,
+            "step_frac": round(alg_bytes_per_step / max(device_ms_per_step * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBPS, 6),
+            "device_ms_per_step": round(device_ms_per_step, 4), "all_kernels_us_per_step": round(total_us, 1),
+            "note": "durations from HIP events around every launch on the launch stream (a profiled pass over the "
+                    "same stream right after the timed region; events add ~2-4 us per launch, so short kernels read "
+                    "high against rocprofv3 — profiles/ holds the matching rocprofv3 --kernel-trace --stats summary); "
+                    "traffic: PMC passes live in profiles/, not in this line; latency / dependency bound path far "
+                    "below the HBM roofline (SURVEY 8(d))"}
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def stream_frames(scene, rank, n):
+    from voxblox_amd import scenes
+    if scene == "cow":
+        return [scenes.cow_and_lady_like_frame((k + 50 * rank) % 200) for k in range(min(n, 200))]
+    return [scenes.room_frame((k + 25 * rank) % N_STREAM, N_STREAM) for k in range(min(n, N_STREAM))]
+
+
+def to_device(frames, dev):
+    import torch
+    return [(pose, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), pts.shape[0]) for pose, pts, col in frames]
+
+
+def run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, esdf_cfg=None, mesh_cfg=None):
+    """W warm-up + K timed steps on one map; returns dt, per-stage ms, counters, esdf/mesh accumulators."""
+    from voxblox_amd import capi  # noqa: F401
+    acc = {"stage": {}, "counters": {}, "esdf_ms": 0.0, "esdf_cnt": {}, "mesh_s": 0.0, "mesh_blocks": 0, "mesh_vertices": 0}
+    total = warmup + steps
+    timed = [False]
+
+    def step(i):
+        pose, dp, dc, n = d_frames[i % len(d_frames)]
+        gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+        if timed[0]:
+            for k, v in gm.timing().items():
+                acc["stage"][k] = acc["stage"].get(k, 0.0) + v
+            for k, v in gm.counters().items():
+                acc["counters"][k] = acc["counters"].get(k, 0) + v
+        if esdf_cfg is not None:
+            gm.esdf_update(esdf_cfg, batch=False, clear_updated_flag=True)
+            if timed[0]:
+                acc["esdf_ms"] += gm.timing()["total_ms"]
+                for k, v in gm.counters().items():
+                    if k.startswith("esdf"):
+                        acc["esdf_cnt"][k] = acc["esdf_cnt"].get(k, 0) + v
+        if mesh_cfg is not None:
+            t0 = time.perf_counter()
+            midx, moff = gm.mesh_generate(mesh_cfg, True, True, download=False)
+            if timed[0]:
+                acc["mesh_s"] += time.perf_counter() - t0
+                acc["mesh_blocks"] += len(midx)
+                acc["mesh_vertices"] += int(moff[-1])
+
+    for i in range(warmup):
+        step(i)
+    gm.enable_timing(True)
+    timed[0] = True
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(warmup, total):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timed[0] = False
+    pts = sum(d_frames[i % len(d_frames)][3] for i in range(warmup, total))
+    return dt, pts, acc, step
+
+
+def sensors4_shards(step, rank, world, dev, cache):
+    """This rank's ray shards of one time step: 4 sensors x B bands, B = max(1, world / 4), dealt out in
+    order (sensor-major), so world 1 holds everything, world 4 one sensor each, world 8 half a sensor each."""
+    import torch
+    from voxblox_amd import scenes
+    bands = max(1, world // 4)
+    units = [(s, b) for s in range(4) for b in range(bands)]
+    per = (len(units) + world - 1) // world
+    mine = units[rank * per:(rank + 1) * per]
+    out = []
+    for s, b in mine:
+        key = (s, step % 25)
+        if key not in cache:
+            pose, pts, col = scenes.room_sensor_frame(s, step % 25)
+            cache[key] = (pose, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), pts.shape[0])
+        pose, dp, dc, n = cache[key]
+        lo, hi = b * n // bands, (b + 1) * n // bands
+        out.append((pose[0], pose[1], dp[lo:hi], dc[lo:hi], hi - lo))
+    return out
+
+
+def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup, barrier_fn):
+    import torch
+    from voxblox_amd import capi, multi_gpu
+    max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3) / 4)
+    cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel, fast_observed_set=args.fast_set)
+    kind = capi.TSDF_FAST
+    pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+    deltas = [capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank) for _ in range(2)]
+    sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev) for d in deltas],
+                                                rank, world, dist if world > 1 or os.environ.get("VBX_FORCE_COLLECTIVES") else None,
+                                                device=dev)
+    cache = {}
+    for k in range(min(warmup + steps, 25)):
+        sensors4_shards(k, rank, world, dev, cache)     # synthetic frames generated and uploaded before the clock
+    torch.cuda.synchronize()
+
+    def barrier():
+        sharded.flush()
+        barrier_fn()
+
+    for k in range(warmup):
+        sharded.integrate_shards(kind, cfg, sensors4_shards(k, rank, world, dev, cache))
+    sharded.flush()
+    for key in sharded.stats:
+        sharded.stats[key] = 0
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        sharded.integrate_shards(kind, cfg, sensors4_shards(k, rank, world, dev, cache))
+    barrier()
+    dt = time.perf_counter() - t0
+    f = max(sharded.stats["frames"], 1)
+    exch = {"payload_bytes_per_step": int(sharded.stats["payload_bytes"] / f), "sent_blocks_per_step": round(sharded.stats["sent_blocks"] / f, 1),
+            "integrate_ms_per_step": round(sharded.stats["integrate_s"] / f * 1e3, 3),
+            "exchange_ms_per_step": round(sharded.stats["exchange_s"] / f * 1e3, 3),
+            "wait_ms_per_step": round(sharded.stats["wait_s"] / f * 1e3, 3),
+            "note": "this rank's figures; exchange = export of the touched blocks' sums + all-to-all to the owners + owner "
+                    "merge, pipelined behind the next step's integration (its time is hidden unless wait_ms > 0)"}
+    # per-kernel profile of the integration (delta map 0), outside the clock
+    rows, calls = [], 0
+    alg = {}
+    if args.profile_frames > 0 and rank == 0:
+        d = deltas[0]
+        d.profile(True, reset=True)
+        n_prof = max(1, min(args.profile_frames // 4, 3))
+        units = 0
+        upd = 0
+        for k in range(warmup + steps, warmup + steps + n_prof):
+            d.clear()
+            for pos, quat, dp, dc, n in sensors4_shards(k, rank, world, dev, cache):
+                d.integrate_device(kind, cfg, pos, quat, dp.data_ptr(), dc.data_ptr(), n)
+                units += n
+                upd += d.counters()["voxels_touched"]
+        d.profile(False)
+        rows, calls = kernel_table(d, calls_per_step=calls_per_step_of(d, n_prof))
+        alg = {"points": units / n_prof, "voxels_touched": upd / n_prof}
+    sharded.close()
+    return dt, exch, rows, alg, (pm, deltas)
+
+
+def calls_per_step_of(gm, n_steps):
+    _, calls = gm.profile_table()
+    return max(calls / max(n_steps, 1), 1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn(args)
     import torch
     import torch.distributed as dist
-    from voxblox_amd import capi, scenes
+    from voxblox_amd import capi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_sharded = bool(os.environ.get("VBX_FORCE_SHARDED")) and "RANK" in os.environ
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    kind = {"fast": capi.TSDF_FAST, "merged": capi.TSDF_MERGED, "simple": capi.TSDF_SIMPLE}[args.integrator]
+    if "RANK" in os.environ and world != args.gpus and rank == 0:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus = {world}\n")
 
-    total = args.warmup + args.steps
-    # Synthetic stream: rank r starts its sweep a quarter turn further (its own sensor).
-    if args.scene == "cow":
-        frames = [scenes.cow_and_lady_like_frame((k + 50 * rank) % 200) for k in range(min(total, 200))]
-    else:
-        frames = [scenes.room_frame((k + 25 * rank) % N_STREAM, N_STREAM) for k in range(min(total, N_STREAM))]
-    d_frames = []
-    for pose, pts, col in frames:
-        d_frames.append((pose, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev)))
-    n_pts = frames[0][1].shape[0]
-    n_pts_all = [f[1].shape[0] for f in frames]
-
-    voxel = float(args.voxel)
+    workload = args.workload
+    if workload == "auto":
+        workload = "stream" if (world == 1 and not force_sharded) else "sensors4"
+    voxel = float(args.voxel) or (0.02 if workload == "sensors4" else VOXEL)
     trunc = 4 * voxel
-    max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3))
-    gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-    cfg = capi.tsdf_cfg(default_truncation_distance=trunc, merged_bundle_order=args.merged_order,
-                        fast_observed_set=args.fast_set)
-    sharded = None
-    if not (world > 1 or force_sharded):
-        gm.set_stream(torch.cuda.current_stream().cuda_stream)
-    else:  # every map keeps its own non-blocking stream so that integration and exchange overlap
-        # Ray-bundle sharding: gm is this rank's per-frame delta map; the
-        # persistent map is distributed by block ownership and fed by an RCCL reduce-scatter.
-        from voxblox_amd import multi_gpu
-        pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-        gm2 = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)   # second delta map (double buffer)
-        sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev),
-                                                    [multi_gpu.GpuBackend(gm, dev), multi_gpu.GpuBackend(gm2, dev)],
-                                                    rank, world, dist, device=dev)
-
-    ecfg = capi.esdf_cfg(min_distance_m=trunc / 2)  # ros_params.h:136-137
-    esdf_ms = [0.0]
-
-    def step(i):
-        pose, dp, dc = d_frames[i % len(d_frames)]
-        n_i = n_pts_all[i % len(d_frames)]
-        if sharded is None:
-            gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_i)
-            if args.esdf:
-                tt = gm.timing() if timing_on[0] else None
-                cc = gm.counters()
-                gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
-                if timing_on[0]:
-                    esdf_ms[0] += gm.timing()["total_ms"]
-                    esdf_cnt.update({k: esdf_cnt.get(k, 0) + v for k, v in gm.counters().items() if k.startswith("esdf")})
-                    last_tsdf[0] = (tt, cc)
-            if args.mesh:
-                tt = gm.timing() if (timing_on[0] and not args.esdf) else None
-                cc = gm.counters() if not args.esdf else None
-                tm0 = time.perf_counter()
-                midx, moff = gm.mesh_generate(mcfg, True, True, download=False)
-                if timing_on[0]:
-                    mesh_acc["s"] += time.perf_counter() - tm0
-                    mesh_acc["blocks"] += len(midx)
-                    mesh_acc["vertices"] += int(moff[-1])
-                    mesh_acc["calls"] += 1
-                    if not args.esdf:
-                        last_tsdf[0] = (tt, cc)
-        else:
-            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n_i)
-
-    mcfg = capi.mesh_cfg()
-    mesh_acc = {"s": 0.0, "blocks": 0, "vertices": 0, "calls": 0}
-    timing_on = [False]
-    esdf_cnt = {}
-    last_tsdf = [None]
+    steps = args.steps or (25 if workload == "sensors4" else 60)
+    warmup = args.warmup if args.warmup >= 0 else (2 if workload == "sensors4" else 5)
 
     def barrier():
-        if sharded is not None:
-            sharded.flush()          # the exchange worker must be idle before a collective of ours
-        if world > 1:
+        if world > 1 or force_sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    gm.enable_timing(True)
-    timing_on[0] = True
-    if sharded is not None:
-        sharded.flush()
-        for k in sharded.stats:
-            sharded.stats[k] = 0
-    stage = {}
-    counters = {}
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        step(i)
-        if sharded is not None and i < total - 1:
-            continue   # per-stage figures from the last frame only: no extra calls between frames
-        t, c = last_tsdf[0] if ((args.esdf or args.mesh) and last_tsdf[0]) else (gm.timing(), gm.counters())
-        rep = args.steps if sharded is not None else 1
-        for k, v in t.items():
-            stage[k] = stage.get(k, 0.0) + v * rep
-        for k, v in c.items():
-            counters[k] = counters.get(k, 0) + v * rep
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def finish(out):
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1 or force_sharded:
+            dist.barrier()
+            dist.destroy_process_group()
 
-    # Host-mirror cost, outside the timed region: what a caller that keeps a
-    # host Layer coherent pays per frame on top of the integration.
-    mirror = None
-    if sharded is None and args.mirror_frames > 0 and rank == 0:
-        timing_on[0] = False
-        staging = gm.pinned_voxels(2048)   # page-locked, reused every frame (vbx_host_alloc)
+    base = {"metric": "Mpoints/s integrated (640x480 frame, %g m voxels) + achieved HBM GB/s" % voxel,
+            "unit": "Mpoints/s", "n_gpus": world, "steps": steps, "warmup": warmup, "higher_is_better": True,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+
+    # ---------------------------------------------------------------------------- configs[4]
+    if workload == "sensors4":
+        dt, exch, rows, alg, _maps = run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
+                                                  lambda: barrier())
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        pts_step = 4 * 307200
+        out = dict(base)
+        out.update({"value": round(pts_step * steps / dt / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "strong",
+                    "config": {"workload": "BASELINE configs[4]: FastTsdfIntegrator, 4 concurrent 640x480 synthetic room sensors, "
+                                           "%g m voxels / 16^3 blocks, trunc %g m; one step = all four frames (1,228,800 points)" % (voxel, trunc),
+                               "points_per_step": pts_step, "voxel_size": voxel, "voxels_per_side": 16, "world_size_seen": world,
+                               "semantics": "shard + merge: each ray shard integrated into a zeroed delta map (bit-exact Fast "
+                                            "integrator per shard), deltas merged with mergeVoxelAIntoVoxelB semantics",
+                               "parallelism": ("1 GPU holds all four sensors (same shard + merge, no collective)" if world == 1 else
+                                               f"{world} ranks, {max(1, world // 4)} ray band(s) per sensor, sparse RCCL all-to-all of touched "
+                                               "blocks to their owners pipelined behind the next step's integration, map distributed by block owner")},
+                    "exchange": exch})
+        if rank == 0 and rows:
+            alg_bytes = 16.0 * alg["points"] + 24.0 * alg["voxels_touched"]
+            dev_ms = sum(r["us_per_step"] for r in rows) / 1e3
+            out["roofline"] = roofline_from(rows, alg_bytes, dev_ms, "16 B x points + 24 B x distinct voxels updated, this rank's shards of one step")
+            out["kernels"] = rows[:14]
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from voxblox_amd import scenes
+            fr = [scenes.room_sensor_frame(0, k) for k in range(8)]
+            out["cpu_baseline"] = cpu_baseline(fr, "fast", voxel, args.cpu_seconds)
+        finish(out)
+        return
+
+    # ---------------------------------------------------------------------------- stream (configs[1..3])
+    kind = {"fast": capi.TSDF_FAST, "merged": capi.TSDF_MERGED, "simple": capi.TSDF_SIMPLE}[args.integrator]
+    total = warmup + steps
+    frames = stream_frames(args.scene, rank, total + args.profile_frames + args.mirror_frames + 8)
+    d_frames = to_device(frames, dev)
+    n_pts = frames[0][1].shape[0]
+    max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3))
+    cfg = capi.tsdf_cfg(default_truncation_distance=trunc, merged_bundle_order=args.merged_order, fast_observed_set=args.fast_set)
+    ecfg = capi.esdf_cfg(min_distance_m=trunc / 2) if args.esdf else None  # ros_params.h:136-137
+    mcfg = capi.mesh_cfg() if args.mesh else None
+
+    sharded = None
+    if world > 1 or force_sharded:
+        # weak scaling variant: one sensor's stream per rank, delta map + sparse exchange per frame
+        from voxblox_amd import multi_gpu
+        pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+        dl = [capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank) for _ in range(2)]
+        sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev) for d in dl],
+                                                    rank, world, dist, device=dev)
+        for i in range(warmup):
+            pose, dp, dc, n = d_frames[i % len(d_frames)]
+            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n)
+        sharded.flush()
+        for key in sharded.stats:
+            sharded.stats[key] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(warmup, total):
+            pose, dp, dc, n = d_frames[i % len(d_frames)]
+            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n)
+        sharded.flush()
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        pts_timed = sum(d_frames[i % len(d_frames)][3] for i in range(warmup, total))
+        f = max(sharded.stats["frames"], 1)
+        out = dict(base)
+        out.update({"value": round(world * pts_timed / dt / 1e6, 3), "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "weak",
+                    "config": {"workload": f"{args.integrator.capitalize()}TsdfIntegrator, one 640x480 synthetic {args.scene} stream per rank "
+                                           "(BASELINE configs[1] per GPU), %g m voxels / 16^3 blocks, trunc %g m" % (voxel, trunc),
+                               "points_per_step": n_pts, "voxel_size": voxel, "voxels_per_side": 16, "world_size_seen": world,
+                               "parallelism": f"{world} sensors, one ray shard per GPU, sparse RCCL all-to-all block merge"},
+                    "exchange": {"payload_bytes_per_step": int(sharded.stats["payload_bytes"] / f),
+                                 "exchange_ms_per_step": round(sharded.stats["exchange_s"] / f * 1e3, 3)}})
+        sharded.close()
+        finish(out)
+        return
+
+    gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+    gm.set_stream(torch.cuda.current_stream().cuda_stream)
+    dt, pts_timed, acc, step = run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, ecfg, mcfg)
+    K = steps
+    workload_name = {("fast", "room"): "BASELINE configs[1]", ("merged", "cow"): "BASELINE configs[2]"}.get((args.integrator, args.scene), "variant")
+    if args.esdf and args.integrator == "fast" and args.scene == "room":
+        workload_name = "BASELINE configs[3]"
+    out = dict(base)
+    out.update({"value": round(pts_timed / dt / 1e6, 3), "ms_per_step": round(dt / K * 1e3, 4), "scaling": "weak",
+                "config": {"workload": f"{workload_name}: {args.integrator.capitalize()}TsdfIntegrator, 640x480 synthetic "
+                                       + ("room scan stream" if args.scene == "room" else "Cow-and-Lady-style orbit (room + sphere + cylinder, 10 % pixels dropped)")
+                                       + (", EsdfIntegrator::updateFromTsdfLayer(true) after every frame" if args.esdf else "")
+                                       + (", MeshIntegrator::generateMesh(true, true) after every frame" if args.mesh else "")
+                                       + ", %g m voxels / 16^3 blocks, trunc %g m" % (voxel, trunc),
+                           "points_per_step": n_pts, "voxel_size": voxel, "voxels_per_side": 16, "world_size_seen": world,
+                           "scene": args.scene, "esdf_after_each_frame": bool(args.esdf), "mesh_after_each_frame": bool(args.mesh),
+                           "semantics": "bit-exact vs the 1-thread reference" if (args.merged_order == 0 and args.fast_set == 0)
+                                        else "fast mode (merged_bundle_order=%d, fast_observed_set=%d)" % (args.merged_order, args.fast_set),
+                           "parallelism": "1 GPU, whole cloud"}})
+    stage = {k: round(v / K, 4) for k, v in acc["stage"].items()}
+    out["stage_ms"] = stage
+    out["counters_per_step"] = {k: round(v / K, 1) for k, v in acc["counters"].items() if not k.startswith("esdf")}
+
+    # ---- per-kernel profile pass over the next frames of the same stream (outside the clock)
+    if args.profile_frames > 0:
+        P = args.profile_frames
+        gm.enable_timing(False)
+        gm.profile(True, reset=True)
+        upd = 0
+        pts_prof = 0
+        for i in range(total, total + P):
+            pose, dp, dc, n = d_frames[i % len(d_frames)]
+            gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+            upd += gm.counters()["voxels_touched"]
+            pts_prof += n
+        gm.profile(False)
+        rows, _ = kernel_table(gm, 1.0)
+        alg_bytes = 16.0 * pts_prof / P + 24.0 * upd / P
+        out["roofline"] = roofline_from(rows, alg_bytes, stage.get("total_ms", 0.0),
+                                        "16 B x points + 24 B x distinct voxels updated per frame (SURVEY 8(d))")
+        out["kernels"] = rows[:16]
+        if args.esdf:
+            gm.profile(True, reset=True)
+            blocks = relax = 0
+            for i in range(total + P, total + 2 * P):
+                pose, dp, dc, n = d_frames[i % len(d_frames)]
+                gm.profile(False)
+                gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+                gm.profile(True)
+                gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+                c = gm.counters()
+                blocks += c["esdf_blocks"]
+                relax += c["esdf_relaxations"]
+            gm.profile(False)
+            erows, _ = kernel_table(gm, 1.0)
+            ealg = (52.0 * 4096 * blocks + 40.0 * relax) / P
+            esdf_ms = acc["esdf_ms"] / K
+            out["esdf"] = {"ms_per_update": round(esdf_ms, 4),
+                           "counters_per_update": {k: round(v / K, 1) for k, v in acc["esdf_cnt"].items()},
+                           "roofline": roofline_from(erows, ealg, esdf_ms, "52 B x 4096 x updated blocks + 40 B x successful relaxations (SURVEY 8(d))"),
+                           "kernels": erows[:8]}
+    elif args.esdf:
+        out["esdf"] = {"ms_per_update": round(acc["esdf_ms"] / K, 4)}
+    gm.enable_timing(True)
+
+    if args.mesh and K:
+        out["mesh"] = {"ms_per_update": round(acc["mesh_s"] / K * 1e3, 4), "blocks_per_update": round(acc["mesh_blocks"] / K, 1),
+                       "vertices_per_update": round(acc["mesh_vertices"] / K, 1),
+                       "note": "host wall clock of vbx_mesh_generate, vertices left device-resident"}
+        if not args.no_cpu_baseline:
+            out["mesh"]["cpu_reference"] = cpu_mesh_baseline(frames[:12], args.integrator, voxel)
+
+    # ---- host-mirror cost (SURVEY 8(f) #2), outside the timed region
+    if args.mirror_frames > 0 and not args.esdf and not args.mesh:
+        staging = gm.pinned_voxels(2048)
         gm.clear_updated(capi.UPDATE_MAP)
         torch.cuda.synchronize()
-        nb = 0
-        nbytes = 0
-        t_int = 0.0
-        t_mir = 0.0
+        nb = nbytes = 0
+        t_int = t_mir = 0.0
+        base_i = total + 2 * args.profile_frames
         for j in range(args.mirror_frames):
             ta = time.perf_counter()
-            step(total + j)
+            pose, dp, dc, n = d_frames[(base_i + j) % len(d_frames)]
+            gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
             torch.cuda.synchronize()
             tb = time.perf_counter()
             upd = gm.blocks_updated(capi.UPDATE_MAP)
-            if len(upd) > staging.shape[0]:     # finer voxels touch more blocks: grow the staging (outside the clock)
+            if len(upd) > staging.shape[0]:
                 staging = gm.pinned_voxels(len(upd) * 5 // 4)
                 tb = time.perf_counter()
             vox, bits, hd = gm.blocks_download(upd, out=staging)
@@ -289,138 +616,43 @@ def main():
             nb += len(upd)
             nbytes += vox.nbytes
         M = args.mirror_frames
-        mirror = {"frames": M, "blocks_per_frame": round(nb / M, 1), "MB_per_frame": round(nbytes / M / 1e6, 3),
-                  "integrate_ms": round(t_int / M * 1e3, 4), "mirror_ms": round(t_mir / M * 1e3, 4),
-                  "note": "mirror = list updated blocks + AoS pack kernel + one D2H copy into page-locked staging + clear kMap bits"}
+        out["host_mirror"] = {"frames": M, "blocks_per_frame": round(nb / M, 1), "MB_per_frame": round(nbytes / M / 1e6, 3),
+                              "integrate_ms": round(t_int / M * 1e3, 4), "mirror_ms": round(t_mir / M * 1e3, 4),
+                              "note": "mirror = list updated blocks + AoS pack kernel + one D2H copy into page-locked staging + clear kMap bits"}
 
-    # The non-default fast modes (results differ from the reference on ~1 % of the voxels, see
-    # include/vbx_hip.h), measured beside the bit-exact default for reference.
-    variants = None
-    if sharded is None and rank == 0 and not args.esdf and not args.no_variants and args.integrator in ("fast", "merged") \
-            and args.fast_set == 0 and args.merged_order == 0:
-        vkw = {"fast": dict(fast_observed_set=1), "merged": dict(merged_bundle_order=1)}[args.integrator]
-        vcfg = capi.tsdf_cfg(default_truncation_distance=trunc, **vkw)
-        vm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-        vm.set_stream(torch.cuda.current_stream().cuda_stream)
-        vsteps = max(10, min(args.steps, 40))
-        for i in range(args.warmup + vsteps):
-            if i == args.warmup:
-                torch.cuda.synchronize()
-                tv0 = time.perf_counter()
-            pose, dp, dc = d_frames[i % len(d_frames)]
-            vm.integrate_device(kind, vcfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n_pts_all[i % len(d_frames)])
-        torch.cuda.synchronize()
-        tv = time.perf_counter() - tv0
-        vpts = sum(n_pts_all[i % len(d_frames)] for i in range(args.warmup, args.warmup + vsteps))
-        name = list(vkw.items())[0]
-        variants = {"%s=%d" % name: {"value": round(vpts / tv / 1e6, 3), "unit": "Mpoints/s",
-                                     "ms_per_step": round(tv / vsteps * 1e3, 4), "steps": vsteps,
-                                     "note": "not bit-exact against the reference (exact observed-voxel set / "
-                                             "sorted bundle order); the default mode above is"}}
-        vm.close()
-
-    K = args.steps
-    pts_timed = sum(n_pts_all[i % len(d_frames)] for i in range(args.warmup, total))
-    value = world * pts_timed / dt / 1e6
-    out = {
-        "metric": "Mpoints/s integrated (640x480 frame, %g m voxels) + achieved HBM GB/s" % voxel,
-        "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": K,
-        "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.integrator.capitalize()}TsdfIntegrator, 640x480 synthetic room scan "
-                               "stream (BASELINE configs[1]), %g m voxels / 16^3 blocks, trunc %g m" % (voxel, trunc),
-                   "points_per_step": n_pts, "voxel_size": voxel, "voxels_per_side": 16,
-                   "semantics": "bit-exact vs the 1-thread reference" if (args.merged_order == 0 and args.fast_set == 0)
-                                else "fast mode (merged_bundle_order=%d, fast_observed_set=%d)" % (args.merged_order, args.fast_set),
-                   "parallelism": ("1 GPU, whole cloud" if world == 1 else
-                                   f"{world} sensors, one ray shard per GPU, RCCL reduce-scatter block merge "
-                                   "pipelined behind the next frame's integration, map distributed by block owner")},
-    }
-    if rank == 0:
-        # Roofline of the dominant kernel.  For the Fast integrator that is k_fast_sweep, launched
-        # ~20 times per frame by the early-termination solver; its "launch" here is one frame's
-        # whole sweep sequence, timed with HIP events on the launch stream inside the library
-        # (vbx_get_timing solve_ms) and averaged over the K timed frames.  The per-launch average
-        # (kernel_ms / launches_per_step) is the number to compare with rocprofv3's avg duration
-        # (profiles/r01d_kernel_stats.md).  Algorithmic bytes per frame:
-        #   16 B x N_points + 24 B x U (distinct voxels updated), U counted on the device.
-        U = counters.get("voxels_touched", 0) / K
-        alg_bytes = 16.0 * n_pts + 24.0 * U
-        stages = {k: v / K for k, v in stage.items() if k != "total_ms"}
-        dom = max(stages, key=stages.get) if stages else "total_ms"
-        dom_ms = stages.get(dom, 0.0)
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        kernel_of_stage = {"solve_ms": "k_fast_sweep", "replay_ms": "k_rsort_scatter", "fold_ms": "k_fold", "emit_ms": "k_ray_emit",
-                           "prep_ms": "k_prep_points+sort", "alloc_ms": "k_fast_build_lists", "sort_ms": "rocprim onesweep"}
-        kname = kernel_of_stage.get(dom, dom)
-        launches = {"solve_ms": counters.get("iterations", 0) / K,
-                    "replay_ms": 2.0 * counters.get("replay_rounds", 0) / K}.get(dom, 1.0)   # 2 sort passes per round
-        launches = max(launches, 1.0)
-        # HBM bytes of that kernel per frame from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-        # runs, profiles/r01d_pmc_hbm_traffic.json); null when no summary for this kernel exists.
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")))["per_frame_bytes"]
-            if args.integrator == "fast" and args.scene == "room" and kname in pmc:
-                traffic = int(pmc[kname]["fetch_bytes"] + pmc[kname]["write_bytes"])
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        kdesc = {"k_fast_sweep": "k_fast_sweep (early-termination solver)",
-                 "k_rsort_scatter": "k_rsort_scatter (stable radix sort passes of the observed-set replay rounds)"}.get(kname, kname)
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                           "kernel": kdesc, "launch": "all launches of one frame (stage %s)" % dom,
-                           "kernel_ms": round(dom_ms, 4), "launches_per_step": round(launches, 1),
-                           "avg_launch_us": round(dom_ms * 1e3 / max(launches, 1.0), 2),
-                           "algorithmic_bytes_per_launch": int(alg_bytes),
-                           "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-                           "device_total_ms": round(stage.get("total_ms", 0.0) / K, 4),
-                           "note": "latency/atomic bound irregular path, far below the HBM roofline (SURVEY 8(d)); "
-                                   "traffic = PMC FETCH_SIZE+WRITE_SIZE of this kernel per frame"}
-        out["counters_per_step"] = {k: round(v / K, 1) for k, v in counters.items()}
+    # ---- CPU reference on the same box
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(frames[:60], args.integrator, voxel, args.cpu_seconds)
         if args.esdf:
-            out["esdf"] = {"ms_per_update": round(esdf_ms[0] / K, 4),
-                           "counters_per_update": {k: round(v / K, 1) for k, v in esdf_cnt.items()}}
-        if args.mesh and mesh_acc["calls"]:
-            n = mesh_acc["calls"]
-            out["mesh"] = {"ms_per_update": round(mesh_acc["s"] / n * 1e3, 4),
-                           "blocks_per_update": round(mesh_acc["blocks"] / n, 1),
-                           "vertices_per_update": round(mesh_acc["vertices"] / n, 1),
-                           "note": "host wall clock of vbx_mesh_generate (select + count + scan + emit + block table), "
-                                   "vertices left device-resident"}
-            # what a host MeshLayer consumer pays on top: the same call plus the copy of the arrays
-            timing_on[0] = False
-            td = 0.0
-            for j in range(8):
-                pose, dp, dc = d_frames[(total + j) % len(d_frames)]
-                gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(),
-                                    n_pts_all[(total + j) % len(d_frames)])
-                tm0 = time.perf_counter()
-                res = gm.mesh_generate(mcfg, True, True, download=True)
-                td += time.perf_counter() - tm0
-            out["mesh"]["ms_per_update_with_download"] = round(td / 8 * 1e3, 4)
-            if world == 1 and not args.no_cpu_baseline:
-                out["mesh"]["cpu_reference"] = cpu_mesh_baseline(frames[:12], args.integrator, voxel)
-        if mirror:
-            out["host_mirror"] = mirror
-        if variants:
-            out["variants"] = variants
-        out["config"]["scene"] = args.scene
-        out["config"]["esdf_after_each_frame"] = bool(args.esdf)
-        out["config"]["mesh_after_each_frame"] = bool(args.mesh)
-        if world == 1 and not args.no_cpu_baseline:
-            nf = args.cpu_frames or 40
-            out["cpu_baseline"] = cpu_baseline(frames[:min(nf, len(frames))], args.integrator, voxel)
-        print(json.dumps(out), flush=True)
-    if sharded is not None:
-        sharded.close()
-        if rank == 0 and os.environ.get("VBX_PIPE_DEBUG"):
-            f = max(sharded.stats["frames"], 1)
-            print({k: (round(v / f * 1e3, 3) if k != "frames" else v) for k, v in sharded.stats.items()},
-                  file=sys.stderr)
-    if world > 1 or force_sharded:
-        dist.barrier()
-        dist.destroy_process_group()
+            out["esdf"]["cpu_baseline"] = cpu_esdf_baseline(frames[:40], voxel, min(args.cpu_seconds, 12.0))
+
+    # ---- default run: short secondary legs for the other single-GPU configs
+    default_run = (args.integrator == "fast" and args.scene == "room" and not args.esdf and not args.mesh
+                   and abs(voxel - VOXEL) < 1e-9 and args.fast_set == 0)
+    if default_run and not args.no_extras:
+        extras = {}
+        py = [sys.executable, os.path.abspath(__file__), "--no-extras", "--mirror-frames", "0"]
+        legs = {"configs[2] merged, cow-and-lady-like orbit": ["--integrator", "merged", "--scene", "cow", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
+                "configs[3] fast + esdf update per frame": ["--esdf", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
+                "configs[4] on one GPU (4 sensors, 0.02 m, shard + merge)": ["--workload", "sensors4", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]}
+        del gm
+        torch.cuda.empty_cache()
+        for name, extra in legs.items():
+            try:
+                r = subprocess.run(py + extra, capture_output=True, text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and line:
+                    j = json.loads(line[-1])
+                    keep = {k: j[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "cpu_baseline", "esdf", "exchange", "roofline") if k in j}
+                    if "cpu_baseline" in keep:
+                        keep["cpu_baseline"] = {k: v for k, v in keep["cpu_baseline"].items() if k != "sample"}
+                    extras[name] = keep
+                else:
+                    extras[name] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:  # a secondary leg must never take the headline line down
+                extras[name] = {"error": repr(e)}
+        out["other_configs"] = extras
+    finish(out)
 
 
 if __name__ == "__main__":

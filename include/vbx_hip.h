@@ -240,7 +240,8 @@ int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size
  *   [w*d, w, w*r, w*g, w*b, w*a],  layout d_out[(i*6 + plane)*nvox + linear_index],
  * zeros for blocks this map does not hold.  idx_xyz is a host array, d_out a device pointer. */
 int vbx_blocks_export_sums(vbx_ctx* ctx, const int32_t* idx_xyz, size_t n, float* d_out);
-/* Folds reduced sums (same layout, device pointer) into this map: A = {d = Swd/Sw, w = Sw,
+/* Folds sums (same layout, device pointer) into this map.  A BlockIndex may be listed more than once (several
+ * senders touched the block): its rows are added up first, in row order.  Then A = {d = Swd/Sw, w = Sw,
  * colour = round(Swc/Sw)} merged into the stored voxel B exactly as mergeVoxelAIntoVoxelB does
  * (d = (dA*wA + dB*wB)/(wA+wB), colour = blendTwoColors(A,wA,B,wB), w = wA+wB; nothing when
  * wA+wB <= 0).  Blocks are allocated as needed and get all Update bits.  If apply_caps != 0
@@ -269,6 +270,9 @@ int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
  * under the start-voxel replay, the observed-set replay and the ordered fold — against
  * std::stable_sort on n pseudo-random keys, bit field [begin_bit, end_bit). */
 int vbx_selftest_sort(vbx_ctx* ctx, uint32_t n, uint32_t begin_bit, uint32_t end_bit, uint32_t seed, int with_vals);
+/* Self-test hook: the library's single-launch exclusive prefix sum (ray offsets, compaction, radix histograms,
+ * probe offsets) against a host loop on n pseudo-random counters, `repeats` back-to-back calls. */
+int vbx_selftest_scan(vbx_ctx* ctx, uint32_t n, uint32_t seed, uint32_t repeats);
 
 /* Self-test hook, host only (no GPU needed): the Merged integrator's reconstruction of libstdc++'s
  * std::unordered_map iteration order (tsdf_integrator.cc:440-456, see vbx_host_tsdf.hpp) against the

@@ -129,3 +129,16 @@ def test_stable_radix_sort_selftest():
         for seed in (2, 3):
             gm.selftest_sort(n, b, e, seed, with_vals=True)
             gm.selftest_sort(n, b, e, seed + 10, with_vals=False)
+
+
+def test_single_launch_scan_selftest():
+    """The library's chained exclusive scan (one launch, decoupled look-back over generation-tagged tile
+    words) against a host loop: sizes around the 4096-item tile, the frame-sized cases, millions of
+    counters (more tiles than are resident at once), and back-to-back calls reusing the descriptors."""
+    from voxblox_amd import capi
+    gm = capi.Map(0.1, 16, max_blocks=64)
+    for n in (0, 1, 2, 63, 64, 4095, 4096, 4097, 8192, 70001, 307201, 717000, 1 << 20, 5_000_003):
+        for seed in (0, 1):
+            gm.selftest_scan(n, seed, repeats=3)
+    for rep in range(50):     # many short scans in a row: generation tags and the ticket base advance
+        gm.selftest_scan(300 + 4096 * (rep % 5), rep, repeats=2)

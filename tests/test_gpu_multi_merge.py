@@ -47,7 +47,7 @@ def test_export_merge_matches_reference_merge(oracle):
         assert np.allclose(gw, rw, rtol=1e-6, atol=1e-7)
         assert np.abs(gd - rd).max() <= 1e-6
         assert np.abs(gc.astype(np.int32) - rc.astype(np.int32)).max() <= 1
-    assert sm.last["union_blocks"] > 0
+    assert sm.last["sent_blocks"] > 0 and sm.last["payload_bytes"] == sm.last["sent_blocks"] * 6 * 4096 * 4
 
 
 def test_clear_is_complete():
@@ -77,8 +77,8 @@ def _gpu_worker(rank, world, port, out_q):
     from voxblox_amd import capi, multi_gpu
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    # two ranks share the single test GPU, so the collective layer is gloo here; the RCCL
-    # branch differs only in reduce_scatter_tensor vs all_reduce + slice
+    # two ranks share the single test GPU, so the collective layer is gloo here (RCCL refuses two
+    # ranks on one device); the RCCL branch runs the same all_to_all_single calls on device tensors
     dist.init_process_group("gloo", rank=rank, world_size=world)
     voxel = 0.1
     cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
@@ -148,9 +148,9 @@ def test_two_process_sharded_fast_on_one_gpu(oracle):
 
 
 def test_bench_sharded_path_over_rccl_single_rank():
-    """bench.py's N>1 code path (delta map, key all-gather, RCCL reduce_scatter_tensor, owner
-    merge) launched exactly like the driver launches it, with one rank: the RCCL calls run for
-    real, and the throughput line must come out well-formed."""
+    """bench.py's N>1 code path (delta map, sparse RCCL all-to-all of the touched blocks, owner merge)
+    launched exactly like the driver launches it, with one rank: the RCCL calls run for real, and the
+    throughput line must come out well-formed."""
     import json
     import os
     import subprocess
@@ -160,12 +160,29 @@ def test_bench_sharded_path_over_rccl_single_rank():
     env = dict(os.environ, VBX_FORCE_SHARDED="1", VBX_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
-           "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--mirror-frames", "0"]
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "sensors4", "--voxel", "0.05",
+           "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 1 and out["value"] > 0 and out["steps"] == 4
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["steps"] == 3
+    assert out["config"]["world_size_seen"] == 1 and out["exchange"]["payload_bytes_per_step"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` spawns N ranks itself and must fail loudly when the box has fewer GPUs."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU" in (r.stderr + r.stdout)
 
 
 def test_pipelined_exchange_equals_sequential():

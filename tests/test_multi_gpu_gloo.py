@@ -1,5 +1,6 @@
-"""CPU, world_size 2, gloo: the N>1 path of voxblox_amd.multi_gpu (key all-gather, owner
-layout, staging, reduce(-scatter), owner fold) with an oracle-backed backend, checked against
+"""CPU, world_size 2, gloo: the N>1 path of voxblox_amd.multi_gpu (owner grouping, sparse
+all-to-all of the touched blocks' sums, owner-side sum of duplicate rows, owner fold) with an
+oracle-backed backend, checked against
 the same shard + merge done serially with the reference's mergeVoxelAIntoVoxelB
 (voxel_utils.cc:10-22).  The HIP kernels behind the same protocol are covered by
 tests/test_gpu_multi_merge.py."""
@@ -60,9 +61,21 @@ class OracleBackend:
                 o[i, 2 + ch] = w * c[:, ch].astype(np.float32)
 
     def merge_sums(self, keys, sums, apply_caps, trunc, max_weight):
-        s = sums.numpy()
+        # rows of one block are added in row order first (vbx_blocks_merge_sums)
+        rows = sums.numpy()
+        first = {}
+        acc = []
         for i, k in enumerate(keys):
-            wA = s[i, 1]
+            kk = tuple(int(v) for v in k)
+            if kk in first:
+                acc[first[kk]][1] = acc[first[kk]][1] + rows[i]
+            else:
+                first[kk] = len(acc)
+                acc.append([k, rows[i].copy()])
+        keys = [a[0] for a in acc]
+        s = [a[1] for a in acc]
+        for i, k in enumerate(keys):
+            wA = s[i][1]
             if not (wA > 0).any():
                 continue
             blk = self.m.tsdf_block(k)
@@ -121,19 +134,22 @@ def _worker(rank, world, port, out_q, pipelined=False):
     dist.destroy_process_group()
 
 
-def test_owner_and_layout_are_deterministic():
+def test_owner_grouping_is_deterministic():
     sys.path.insert(0, ROOT)
     from voxblox_amd import multi_gpu
     rng = np.random.RandomState(0)
-    a = rng.randint(-20, 20, (50, 3)).astype(np.int32)
-    b = rng.randint(-20, 20, (70, 3)).astype(np.int32)
-    g1, L1 = multi_gpu.build_layout([a, b], 4)
-    g2, L2 = multi_gpu.build_layout([b, a], 4)
-    assert L1 == L2 and all(np.array_equal(x, y) for x, y in zip(g1, g2))
-    uni = np.unique(np.concatenate([a, b]), axis=0)
-    assert sum(g.shape[0] for g in g1) == uni.shape[0]
-    for r, g in enumerate(g1):
-        assert np.all(multi_gpu.owner_of(g, 4) == r) and g.shape[0] <= L1
+    a = np.unique(rng.randint(-20, 20, (90, 3)).astype(np.int32), axis=0)
+    g1, c1 = multi_gpu.group_by_owner(a, 4)
+    g2, c2 = multi_gpu.group_by_owner(a[rng.permutation(a.shape[0])], 4)      # input order does not matter
+    assert np.array_equal(g1, g2) and np.array_equal(c1, c2) and int(c1.sum()) == a.shape[0]
+    off = 0
+    for r in range(4):
+        g = g1[off:off + int(c1[r])]
+        assert np.all(multi_gpu.owner_of(g, 4) == r)
+        assert np.array_equal(g, multi_gpu._sort_rows_zyx(g))      # (z,y,x) order inside a group
+        off += int(c1[r])
+    g0, c0 = multi_gpu.group_by_owner(np.zeros((0, 3), np.int32), 4)
+    assert g0.shape == (0, 3) and c0.tolist() == [0, 0, 0, 0]
 
 
 @pytest.mark.parametrize("pipelined", [False, True])
@@ -153,7 +169,9 @@ def test_two_rank_shard_and_merge_matches_serial_reference_merge(oracle, pipelin
     for rank, owned, last in results:
         assert not (set(owned) & set(merged)), "a block is owned by two ranks"
         merged.update(owned)
-        assert last["union_blocks"] > 0 and last["padded_rows"] % 2 == 0
+        # sparse exchange: a rank sends exactly the blocks its delta touched, 96 KiB of sums each
+        assert last["sent_blocks"] > 0 and last["payload_bytes"] == last["sent_blocks"] * 6 * 4096 * 4
+        assert last["received_blocks"] >= last["owned_blocks"] > 0
 
     # serial restatement: per frame, per rank delta (fresh map), merged in rank order with the
     # reference's mergeVoxelAIntoVoxelB

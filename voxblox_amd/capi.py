@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
-    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_enable_timing", "vbx_get_timing",
+    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
     "vbx_selftest_unordered_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
 
@@ -125,6 +125,7 @@ def lib():
         "vbx_mesh_download": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u8p, C.c_size_t]),
         "vbx_mesh_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "vbx_selftest_sort": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+        "vbx_selftest_scan": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
         "vbx_num_blocks": (C.c_int, [vp, C.c_int, szp]),
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),
@@ -408,6 +409,9 @@ class Map:
 
     def selftest_sort(self, n, begin_bit, end_bit, seed=0, with_vals=True):
         self._chk(self.L.vbx_selftest_sort(self.h, int(n), int(begin_bit), int(end_bit), int(seed), int(with_vals)))
+
+    def selftest_scan(self, n, seed=0, repeats=1):
+        self._chk(self.L.vbx_selftest_scan(self.h, int(n), int(seed), int(repeats)))
 
     def counters(self):
         c = Counters()

@@ -196,7 +196,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_hist0, &ctx->b_hist1, &ctx->b_moved, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_hist0, &ctx->b_hist1, &ctx->b_moved, &ctx->b_scan_desc, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive, &ctx->b_mesh_list, &ctx->b_mesh_cnt, &ctx->b_mesh_off,
                   &ctx->b_mesh_tab, &ctx->b_mesh_verts, &ctx->b_mesh_normals, &ctx->b_mesh_colors, &ctx->b_bstart, &ctx->b_mgather, &ctx->b_fin};
   for (DBuf* b : bufs) b->release();
@@ -695,22 +695,48 @@ int vbx_blocks_merge_sums(vbx_ctx* ctx, const int32_t* idx, size_t n, const floa
   if (!ctx || (n && (!idx || !d_sums))) return VBX_ERR_INVALID;
   HIP_TRY(hipSetDevice(ctx->device));
   if (n == 0) return VBX_OK;
-  int rc = upload_idx(ctx, idx, n);
+  // rows of the same block (several senders touched it) are summed before the merge, in row order:
+  // group the row numbers by key, keys in first-appearance order
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+  auto key_less = [&](uint32_t a, uint32_t b) {
+    const int32_t *p = idx + 3 * (size_t)a, *q = idx + 3 * (size_t)b;
+    if (p[2] != q[2]) return p[2] < q[2];
+    if (p[1] != q[1]) return p[1] < q[1];
+    return p[0] < q[0];
+  };
+  std::stable_sort(order.begin(), order.end(), key_less);
+  std::vector<int32_t> uniq;
+  std::vector<uint32_t> row_start;
+  for (size_t i = 0; i < n; ++i) {
+    if (i == 0 || key_less(order[i - 1], order[i])) {
+      row_start.push_back((uint32_t)i);
+      uniq.insert(uniq.end(), idx + 3 * (size_t)order[i], idx + 3 * (size_t)order[i] + 3);
+    }
+  }
+  row_start.push_back((uint32_t)n);
+  const size_t nu = row_start.size() - 1;
+  int rc = upload_idx(ctx, uniq.data(), nu);
   if (rc) return rc;
   hipStream_t s = ctx->stream;
   MapDev& m = ctx->map;
+  HIP_TRY(ctx->b_vals0.ensure((nu + 1) * 4));
+  HIP_TRY(ctx->b_vals1.ensure(n * 4));
+  HIP_TRY(hipMemcpyAsync(ctx->b_vals0.p, row_start.data(), (nu + 1) * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_vals1.p, order.data(), n * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
   HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
-  hipLaunchKernelGGL(k_insert_blocks, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+  hipLaunchKernelGGL(k_insert_blocks, grid_for(nu), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)nu,
                      ctx->b_newlist.as<uint32_t>(), ctx->d_state);
   hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
                      ctx->d_state);
   hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(nu), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)nu, 0,
                      ctx->b_rank.as<uint32_t>());
-  hipLaunchKernelGGL(k_merge_sums, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), d_sums,
-                     apply_caps, truncation_distance, max_weight, ctx->d_state);
-  rc = sync_state(ctx);
+  hipLaunchKernelGGL(k_merge_sums, dim3((unsigned)nu), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
+                     ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), d_sums, apply_caps, truncation_distance,
+                     max_weight, ctx->d_state);
+  rc = sync_state(ctx);  // also keeps the host vectors alive until the copies are done
   if (rc) return rc;
   return check_state_error(ctx);
 }
@@ -844,6 +870,35 @@ int vbx_selftest_sort(vbx_ctx* ctx, uint32_t n, uint32_t begin_bit, uint32_t end
                 (unsigned long long)got[i], with_vals ? gotv[i] : 0u, (unsigned long long)keys[idx[i]], idx[i]);
       return VBX_ERR_HIP;
     }
+  }
+  return VBX_OK;
+}
+
+int vbx_selftest_scan(vbx_ctx* ctx, uint32_t n, uint32_t seed, uint32_t repeats) {
+  if (!ctx) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<uint32_t> in(n), got(n);
+  uint64_t x = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed << 21) ^ n;
+  for (uint32_t i = 0; i < n; ++i) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    in[i] = (seed & 1u) ? (uint32_t)(x & 1u) : (uint32_t)(x % 1000u);
+  }
+  HIP_TRY(ctx->b_vals0.ensure(std::max<size_t>(n, 1) * 4));
+  HIP_TRY(ctx->b_vals1.ensure(std::max<size_t>(n, 1) * 4));
+  if (n) HIP_TRY(hipMemcpyAsync(ctx->b_vals0.p, in.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  for (uint32_t rep = 0; rep < std::max<uint32_t>(repeats, 1); ++rep) {  // back-to-back calls reuse the descriptors
+    int rc = exclusive_scan_u32(ctx, ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), n);
+    if (rc) return rc;
+  }
+  if (n) HIP_TRY(hipMemcpyAsync(got.data(), ctx->b_vals1.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  uint32_t run = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (got[i] != run) {
+      ctx->fail("exclusive scan self-test: position %u holds %u, expected %u (n = %u)", i, got[i], run, n);
+      return VBX_ERR_HIP;
+    }
+    run += in[i];
   }
   return VBX_OK;
 }

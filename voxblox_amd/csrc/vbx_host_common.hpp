@@ -126,14 +126,31 @@ int sort_pairs(vbx_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint3
   prof_end(ctx);
   return VBX_OK;
 }
+// Exclusive prefix sum, one launch (k_scan_excl, vbx_sort.hpp).
 int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
-  size_t tmp = 0;
-  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
-  HIP_TRY(ctx->b_tmp.ensure(tmp));
-  prof_begin(ctx, "rocprim::exclusive_scan");
-  HIP_TRY(rocprim::exclusive_scan(ctx->b_tmp.p, tmp, in, out, 0u, n, rocprim::plus<uint32_t>(),
-                                  ctx->stream));
-  prof_end(ctx);
+  if (n == 0) return VBX_OK;
+  if (n > 0xFFFFF000ull) {
+    ctx->fail("exclusive scan: too many elements");
+    return VBX_ERR_INVALID;
+  }
+  const uint32_t ntiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
+  if (ctx->b_scan_desc.cap < (size_t)(ntiles + 1) * 8 + 8) {
+    // descriptors + the ticket counter; zero = "no word of any generation"
+    HIP_TRY(ctx->b_scan_desc.ensure(std::max<size_t>((size_t)(ntiles + 1) * 8 + 8, 1 << 16)));
+    HIP_TRY(hipMemsetAsync(ctx->b_scan_desc.p, 0, ctx->b_scan_desc.cap, ctx->stream));
+    ctx->scan_ticket_base = 0;
+    ctx->scan_gen = 0;
+  }
+  if (++ctx->scan_gen >= 0x3FFFFFFFu) {  // generation tags about to repeat: start over
+    HIP_TRY(hipMemsetAsync(ctx->b_scan_desc.p, 0, ctx->b_scan_desc.cap, ctx->stream));
+    ctx->scan_ticket_base = 0;
+    ctx->scan_gen = 1;
+  }
+  unsigned long long* desc = ctx->b_scan_desc.as<unsigned long long>() + 1;
+  uint32_t* ticket = ctx->b_scan_desc.as<uint32_t>();
+  KLAUNCH(k_scan_excl, dim3(ntiles), dim3(kScanThreads), 0, ctx->stream, in, out, (uint32_t)n, desc, ticket,
+          ctx->scan_ticket_base, ctx->scan_gen);
+  ctx->scan_ticket_base += ntiles;  // wraps like the device counter
   return VBX_OK;
 }
 

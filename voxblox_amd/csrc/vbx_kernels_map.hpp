@@ -255,23 +255,34 @@ __global__ void k_pack_esdf_aos(uint32_t nvox, const float* __restrict__ edist, 
   }
 }
 
-__global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const float* __restrict__ in,
-                             int apply_caps, float trunc, float max_weight, DevState* st) {
+// One workgroup per DISTINCT block: the block's rows of the staging buffer (row_start[b] .. row_start[b+1]
+// of `rows`, ascending = the order the caller listed them: sender rank, then key) are summed in that
+// order, then A = {d = Swd/Sw, w = Sw, colour = round(Swc/Sw)} is merged into the stored voxel
+// (mergeVoxelAIntoVoxelB, voxel_utils.cc:10-22).
+__global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ row_start,
+                             const uint32_t* __restrict__ rows, const float* __restrict__ in, int apply_caps,
+                             float trunc, float max_weight, DevState* st) {
   const uint32_t b = blockIdx.x;
   const uint32_t slot = slots[b];
   if (slot == kInvalidSlot) return;
-  const float* a = in + (size_t)b * 6 * m.nvox;
+  const uint32_t r0 = row_start[b], r1 = row_start[b + 1];
   bool any = false;
   for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
-    const float wA = a[m.nvox + v];
+    float acc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t q = r0; q < r1; ++q) {
+      const float* a = in + (size_t)rows[q] * 6 * m.nvox;
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) acc[pl] += a[pl * m.nvox + v];
+    }
+    const float wA = acc[1];
     if (!(wA > 0.0f)) continue;
     any = true;
     const uint32_t gid = slot * m.nvox + v;
-    const float dA = a[v] / wA;
+    const float dA = acc[0] / wA;
     uint32_t cA = 0;
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
-      const float c = roundf(a[(2 + ch) * m.nvox + v] / wA);
+      const float c = roundf(acc[2 + ch] / wA);
       cA |= ((uint32_t)(int)std_min(std_max(c, 0.0f), 255.0f) & 0xFFu) << (8 * ch);
     }
     const float wB = m.weight[gid];

@@ -1,32 +1,34 @@
-"""Ray-bundle sharding across the GPUs of one node with a block merge over RCCL.
+"""Ray-bundle sharding across the GPUs of one node with a sparse block merge over RCCL.
 
-SURVEY.md §8(e).  One process per GPU.  Per frame every rank integrates ITS shard of the
-rays (a whole sensor, or a contiguous bundle of a cloud) into a zero-initialised per-frame
-delta map; overlapping block updates are then combined with the reference's own merge
-semantics — Block::mergeBlock / mergeVoxelAIntoVoxelB (core/block_inl.h:112-129,
-src/utils/voxel_utils.cc:10-22) is a weighted sum, hence a collective:
+SURVEY.md §8(e).  One process per GPU.  Per frame every rank integrates ITS shards of the
+rays (whole sensors, or contiguous bands of a cloud) into a zero-initialised per-frame delta
+map; overlapping block updates are then combined with the reference's own merge semantics —
+Block::mergeBlock / mergeVoxelAIntoVoxelB (core/block_inl.h:112-129,
+src/utils/voxel_utils.cc:10-22) is a weighted sum, so the partial sums (w*d, w, w*r, w*g, w*b,
+w*a) of every touched block travel to the block's OWNER (owner = hash(BlockIndex) mod world),
+which adds them up and folds them into its shard of the persistent map:
 
-  1. all-gather of each rank's touched BlockIndex list  ->  every rank builds the same union,
-     grouped by owner rank (owner = hash(BlockIndex) mod world), each group padded to the
-     same length L so that chunk r of the staging buffer is exactly rank r's blocks;
-  2. every rank writes its delta voxels as partial sums (w*d, w, w*r, w*g, w*b, w*a) into a
-     dense [world*L, 6, vps^3] buffer (zeros where it has nothing)   (vbx_blocks_export_sums);
-  3. reduce-scatter(sum): rank r receives the summed deltas of the blocks it owns (RCCL over
-     xGMI; payload 96 KiB per union block at vps 16);
-  4. the owner folds them into its shard of the persistent map        (vbx_blocks_merge_sums).
+  1. every rank lists the blocks its delta touched, grouped by owner            (host, tiny)
+  2. all-to-all of the group sizes, then of the BlockIndex rows                 (world ints, 12 B / block)
+  3. vbx_blocks_export_sums writes the touched blocks' six float planes in the same order, one
+     all-to-all-v moves each group to its owner: ONLY touched blocks travel, 96 KiB each at vps 16
+  4. the owner sums the rows of equal BlockIndex in (sender rank, key) order and merges the
+     result into the stored voxels                                              (vbx_blocks_merge_sums)
 
-The persistent map is therefore distributed by block ownership; no rank holds all of it.
-Shard-then-merge is not bit-identical to integrating the whole cloud into one map (the clamp
-of updateTsdfVoxel is applied per delta): parity is defined against the same
-shard + merge done with the CPU oracle (tests/test_multi_gpu_gloo.py).
+Round 1 staged a dense zero-padded [world * L, 6, vps^3] buffer on every rank and
+reduce-scattered all of it (~100 MB per rank and frame at 0.05 m although most blocks are touched
+by one or two ranks); the sparse exchange sends each rank's touched blocks once.
+
+The persistent map is distributed by block ownership; no rank holds all of it.  Shard-then-merge
+is not bit-identical to integrating the whole cloud into one map (the clamp of updateTsdfVoxel is
+applied per delta): parity is defined against the same shard + merge done with the
+CPU oracle (tests/test_multi_gpu_gloo.py).
 
 The collective layer is torch.distributed ("nccl" is RCCL on ROCm; "gloo" for the CPU tests).
 """
 import time
 
 import numpy as np
-
-_SENTINEL = np.iinfo(np.int32).max
 
 
 def owner_of(keys, world):
@@ -44,17 +46,13 @@ def _sort_rows_zyx(keys):
     return k[order]
 
 
-def build_layout(all_keys, world):
-    """all_keys: list (one per rank) of (n_r,3) int32 arrays.  Returns (union_by_owner, L):
-    union_by_owner[r] = sorted unique keys owned by rank r; L = padded group length."""
-    cat = np.concatenate([np.asarray(k, np.int32).reshape(-1, 3) for k in all_keys], 0) \
-        if all_keys else np.zeros((0, 3), np.int32)
-    uni = np.unique(cat, axis=0) if cat.shape[0] else cat
-    uni = _sort_rows_zyx(uni)
-    own = owner_of(uni, world)
-    groups = [uni[own == r] for r in range(world)]
-    L = max([g.shape[0] for g in groups] + [1])
-    return groups, L
+def group_by_owner(keys, world):
+    """keys (n,3) -> (keys reordered: owner 0's rows first, each group in (z,y,x) order; counts[world])."""
+    k = _sort_rows_zyx(keys)
+    own = owner_of(k, world)
+    order = np.argsort(own, kind="stable")
+    counts = np.bincount(own, minlength=int(world)).astype(np.int64)
+    return np.ascontiguousarray(k[order]), counts
 
 
 class ShardedTsdfMap:
@@ -72,71 +70,82 @@ class ShardedTsdfMap:
         import os
         self.force_collectives = bool(os.environ.get("VBX_FORCE_COLLECTIVES")) and dist is not None
 
-    # -- collectives ------------------------------------------------------------------------
-    def _gather_keys(self, keys):
-        import torch
-        if self.world == 1 and not self.force_collectives:
-            return [keys]
-        # RCCL moves device tensors; gloo (CPU tests) gathers host tensors
-        dev = self.d.device if self.dist.get_backend() == "nccl" else torch.device("cpu")
-        n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
-        counts = [torch.zeros_like(n) for _ in range(self.world)]
-        self.dist.all_gather(counts, n)
-        counts = [int(c.item()) for c in counts]
-        m = max(max(counts), 1)
-        pad = np.full((m, 3), _SENTINEL, np.int32)
-        pad[:keys.shape[0]] = keys
-        mine = torch.from_numpy(pad).to(dev)
-        out = [torch.empty_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(out, mine)
-        return [o.cpu().numpy()[:c] for o, c in zip(out, counts)]
+    def _collective(self):
+        return self.world > 1 or self.force_collectives
 
-    def _reduce_scatter(self, sums, L):
-        """sums: [world*L, 6, nvox] -> this rank's [L, 6, nvox] chunk of the elementwise sum."""
+    def _comm_device(self):
         import torch
-        if self.world == 1 and not self.force_collectives:
-            return sums
-        if self.dist.get_backend() == "nccl":
-            out = torch.empty((L,) + tuple(sums.shape[1:]), dtype=sums.dtype, device=sums.device)
-            self.dist.reduce_scatter_tensor(out, sums, op=self.dist.ReduceOp.SUM)
-            return out
-        self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM)  # gloo has no reduce-scatter
-        return sums[self.rank * L:(self.rank + 1) * L]
+        # RCCL moves device tensors; gloo (CPU tests) moves host tensors
+        return self.d.device if self.dist.get_backend() == "nccl" else torch.device("cpu")
 
     # -- one frame --------------------------------------------------------------------------
     def integrate_shard(self, kind, cfg, pos, quat, points, colors, n_points=None):
-        """Integrate this rank's rays into the delta map, merge all ranks' deltas, fold the
-        blocks this rank owns into its persistent shard."""
+        """Integrate one shard of rays into a fresh delta map, send every touched block to its
+        owner, fold the blocks this rank owns into its persistent shard."""
         self.d.clear()
         self.d.integrate(kind, cfg, pos, quat, points, colors, n_points)
         self.exchange_and_merge()
 
+    def integrate_shards(self, kind, cfg, shards):
+        """Several shards of one time step on this rank (e.g. two sensors at world 2): all of them
+        go into the same delta map before ONE exchange.  shards: [(pos, quat, points, colors, n)]."""
+        self.d.clear()
+        for pos, quat, points, colors, n in shards:
+            self.d.integrate(kind, cfg, pos, quat, points, colors, n)
+        self.exchange_and_merge()
+
     def exchange_and_merge(self):
-        keys = _sort_rows_zyx(self.d.block_indices())
-        groups, L = build_layout(self._gather_keys(keys), self.world)
+        import torch
+        send_keys, send_counts = group_by_owner(self.d.block_indices(), self.world)
         nvox = self.d.nvox
-        sums = self.d.zeros((self.world * L, 6, nvox))
-        for r, g in enumerate(groups):
-            if g.shape[0]:
-                self.d.export_sums(g, sums[r * L:r * L + g.shape[0]])
-        mine = self._reduce_scatter(sums, L)
-        g = groups[self.rank]
-        if g.shape[0]:
-            self.p.merge_sums(g, mine[:g.shape[0]], self.apply_caps, self.trunc, self.max_weight)
-        self.last = dict(union_blocks=int(sum(x.shape[0] for x in groups)), owned_blocks=int(g.shape[0]),
-                         padded_rows=int(self.world * L), payload_bytes=int(self.world * L * 6 * nvox * 4))
+        n_send = int(send_keys.shape[0])
+        send = self.d.zeros((max(n_send, 1), 6, nvox))
+        if n_send:
+            self.d.export_sums(send_keys, send[:n_send])
+        if not self._collective():
+            recv_keys, recv = send_keys, send[:n_send]
+            recv_counts = send_counts
+        else:
+            dev = self._comm_device()
+            sc = torch.from_numpy(send_counts).to(dev)
+            rc = torch.zeros_like(sc)
+            self.dist.all_to_all_single(rc, sc)
+            recv_counts = rc.cpu().numpy()
+            n_recv = int(recv_counts.sum())
+            kt = torch.from_numpy(send_keys.reshape(-1)).to(dev)
+            rk = torch.empty(n_recv * 3, dtype=torch.int32, device=dev)
+            self.dist.all_to_all_single(rk, kt, output_split_sizes=[int(c) * 3 for c in recv_counts],
+                                        input_split_sizes=[int(c) * 3 for c in send_counts])
+            recv_keys = rk.cpu().numpy().reshape(-1, 3)
+            payload = send[:n_send].reshape(n_send, 6 * nvox)
+            if payload.device != dev:
+                payload = payload.to(dev)
+            recv = torch.empty((n_recv, 6 * nvox), dtype=torch.float32, device=dev)
+            self.dist.all_to_all_single(recv, payload, output_split_sizes=[int(c) for c in recv_counts],
+                                        input_split_sizes=[int(c) for c in send_counts])
+            recv = recv.reshape(n_recv, 6, nvox)
+            if recv.device != self.p.device:
+                recv = recv.to(self.p.device)
+        if recv_keys.shape[0]:
+            # rows arrive grouped by sender rank, each group in (z,y,x) order: the owner adds the rows
+            # of one block in exactly that order (deterministic), then merges once
+            self.p.merge_sums(recv_keys, recv, self.apply_caps, self.trunc, self.max_weight)
+        self.last = dict(sent_blocks=n_send, received_blocks=int(recv_keys.shape[0]),
+                         owned_blocks=int(np.unique(recv_keys, axis=0).shape[0]) if recv_keys.shape[0] else 0,
+                         payload_bytes=int(n_send * 6 * nvox * 4),
+                         kept_local_bytes=int(send_counts[self.rank] * 6 * nvox * 4) if self.rank < len(send_counts) else 0)
 
 
 class PipelinedShardedTsdfMap:
     """The same frame step with the exchange pipelined behind the next frame's integration.
 
-    Two delta maps alternate: while a worker thread runs frame k's exchange (key all-gather,
-    export, RCCL reduce-scatter, owner merge) on its own HIP stream, the caller already
-    integrates frame k+1 into the other delta map.  The integration is latency-bound (the GPU is
-    mostly idle between its kernels), so the two overlap well; per-frame time tends to
-    max(integrate, exchange) instead of their sum.  Every collective is issued by the worker
-    thread, in frame order, so all ranks issue them in the same order; call flush() before any
-    collective of your own (barriers) and before reading the persistent map."""
+    Two delta maps alternate: while a worker thread runs frame k's exchange (export, RCCL
+    all-to-all, owner merge) on its own HIP stream, the caller already integrates frame k+1 into
+    the other delta map.  The integration is latency-bound (the GPU is mostly idle between its
+    kernels), so the two overlap well; per-frame time tends to max(integrate, exchange) instead of
+    their sum.  Every collective is issued by the worker thread, in frame order, so all ranks issue
+    them in the same order; call flush() before any collective of your own (barriers) and before
+    reading the persistent map."""
 
     def __init__(self, persistent, deltas, rank, world, dist=None, apply_caps=False, truncation=0.0,
                  max_weight=0.0, device=None):
@@ -158,7 +167,8 @@ class PipelinedShardedTsdfMap:
         self._err = None
         self._n = 0
         self.last = {}
-        self.stats = {"frames": 0, "wait_s": 0.0, "integrate_s": 0.0, "exchange_s": 0.0}
+        self.stats = {"frames": 0, "wait_s": 0.0, "integrate_s": 0.0, "exchange_s": 0.0, "payload_bytes": 0,
+                      "sent_blocks": 0}
         self._thread = threading.Thread(target=self._worker, name="vbx-exchange", daemon=True)
         self._thread.start()
 
@@ -179,6 +189,8 @@ class PipelinedShardedTsdfMap:
                     self.sm[i].exchange_and_merge()
                     self.stats["exchange_s"] += time.perf_counter() - t0
                     self.last = self.sm[i].last
+                    self.stats["payload_bytes"] += self.last["payload_bytes"]
+                    self.stats["sent_blocks"] += self.last["sent_blocks"]
                 except BaseException as e:  # surfaced by the next call on the caller's thread
                     self._err = e
                 self._idle[i].set()
@@ -191,7 +203,7 @@ class PipelinedShardedTsdfMap:
             e, self._err = self._err, None
             raise e
 
-    def integrate_shard(self, kind, cfg, pos, quat, points, colors, n_points=None):
+    def integrate_shards(self, kind, cfg, shards):
         i = self._n & 1
         self._n += 1
         t0 = time.perf_counter()
@@ -201,11 +213,15 @@ class PipelinedShardedTsdfMap:
         self._idle[i].clear()
         d = self.sm[i].d
         d.clear()
-        d.integrate(kind, cfg, pos, quat, points, colors, n_points)
+        for pos, quat, points, colors, n in shards:
+            d.integrate(kind, cfg, pos, quat, points, colors, n)
         self._q.put(i)
         self.stats["wait_s"] += t1 - t0
         self.stats["integrate_s"] += time.perf_counter() - t1
         self.stats["frames"] += 1
+
+    def integrate_shard(self, kind, cfg, pos, quat, points, colors, n_points=None):
+        self.integrate_shards(kind, cfg, [(pos, quat, points, colors, n_points)])
 
     def flush(self):
         for e in self._idle:
@@ -242,14 +258,16 @@ class GpuBackend:
         return self.m.block_indices()
 
     def zeros(self, shape):
-        return self._torch.zeros(shape, dtype=self._torch.float32, device=self.device)
+        # export_sums writes every plane of every listed block: no need to clear the staging
+        return self._torch.empty(shape, dtype=self._torch.float32, device=self.device)
 
     def export_sums(self, keys, out_view):
         assert out_view.is_contiguous()
-        self._torch.cuda.current_stream(self.device).synchronize()
+        # vbx_blocks_export_sums synchronises its own stream before returning; the torch stream
+        # that reads the buffer next is ordered behind this host call
         self.m.export_sums(keys, out_view.data_ptr())
 
     def merge_sums(self, keys, sums, apply_caps, trunc, max_weight):
         sums = sums.contiguous()
-        self._torch.cuda.current_stream(self.device).synchronize()
+        self._torch.cuda.current_stream(self.device).synchronize()   # the all-to-all that filled `sums`
         self.m.merge_sums(keys, sums.data_ptr(), apply_caps, trunc, max_weight)
