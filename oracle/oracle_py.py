@@ -76,6 +76,23 @@ def ref_lib():
     return _ref
 
 
+_REF_HIP_LIB = os.path.join(_HERE, "_ref", "libvbxref_hip.so")
+_ref_hip = None
+
+
+def ref_hip_lib():
+    """The orc_* C API served by voxblox's real classes with the HIP drop-in linked in place of
+    tsdf_integrator.cc / esdf_integrator.cc (oracle/Makefile target ref_hip).  This is the PRODUCT path
+    behind the reference's headers — the thing under test, loaded through the harness only because the
+    harness is how the tests talk to voxblox's C++ classes."""
+    global _ref_hip
+    if _ref_hip is None:
+        if not os.path.exists(_REF_HIP_LIB):
+            raise RuntimeError("oracle/_ref/libvbxref_hip.so is not built (make -C oracle ref_hip; needs /root/reference)")
+        _ref_hip = _bind(C.CDLL(_REF_HIP_LIB))
+    return _ref_hip
+
+
 def lib():
     global _lib
     if _lib is not None:

@@ -52,6 +52,10 @@ struct ApproxSetImpl : ApproxSetIface {
 struct orc_approx_set { std::unique_ptr<ApproxSetIface> s; };
 struct orc_bucket_queue { BucketQueue<size_t> q; };
 
+#ifdef VBX_DROPIN
+namespace voxblox { namespace hip { void releaseMirror(const Layer<TsdfVoxel>* tsdf_layer); } }
+#endif
+
 extern "C" {
 
 void orc_tsdf_cfg_default(orc_tsdf_cfg* c) {
@@ -94,7 +98,14 @@ void orc_esdf_cfg_default(orc_esdf_cfg* c) {
 }
 
 orc_map* orc_map_create(float voxel_size, uint32_t vps) { return new orc_map(voxel_size, vps); }
+#ifdef VBX_DROPIN  // libvbxref_hip.so: the integrators are the HIP drop-in; drop the layer's device map with it
+void orc_map_destroy(orc_map* m) {
+  voxblox::hip::releaseMirror(&m->tsdf);
+  delete m;
+}
+#else
 void orc_map_destroy(orc_map* m) { delete m; }
+#endif
 
 orc_tsdf_integrator* orc_tsdf_integrator_create(orc_map* m, int kind, const orc_tsdf_cfg* c) {
   if (c->oracle_merged_sorted_bundles || c->oracle_fast_exact_observed_set) return nullptr;  // reference only

@@ -1,0 +1,136 @@
+// esdf_integrator_hip.cc — replaces voxblox/src/integrator/esdf_integrator.cc.
+//
+// Same class, same signatures (include/voxblox/integrator/esdf_integrator.h, unchanged):
+//   EsdfIntegrator::EsdfIntegrator              esdf_integrator.cc:7-22
+//   addNewRobotPosition                          :25-92
+//   updateFromTsdfLayerBatch / updateFromTsdfLayer / updateFromTsdfBlocks   :94-302
+//   processRaiseSet / processOpenSet / updateVoxelFromNeighbors             :305-530 (device wavefront)
+// The TSDF the update reads is the device copy the HIP TSDF integrators maintain for the same
+// Layer<TsdfVoxel> (device_mirror.h); afterwards the touched ESDF blocks are copied into the host
+// Layer<EsdfVoxel>, and the kEsdf bits the reference clears on the host TSDF blocks are cleared there too.
+#include "voxblox/integrator/esdf_integrator.h"
+
+#include "device_mirror.h"
+
+namespace voxblox {
+namespace hip {
+
+void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
+  static_assert(sizeof(EsdfVoxel) == 20, "EsdfVoxel is {float distance; bool observed, hallucinated, in_queue, fixed; Vector3i parent}");
+  size_t n = 0;
+  CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP, nullptr, 0, &n), VBX_OK)
+      << vbx_last_error(dev.ctx);
+  if (n == 0) return;
+  dev.idx.resize(3 * n);
+  CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP, dev.idx.data(), n, &n), VBX_OK)
+      << vbx_last_error(dev.ctx);
+  const size_t nv = layer->voxels_per_side() * layer->voxels_per_side() * layer->voxels_per_side();
+  dev.esdf_staging.resize(n * nv);
+  dev.bits.resize(n);
+  dev.has_data.resize(n);
+  CHECK_EQ(vbx_blocks_download(dev.ctx, VBX_LAYER_ESDF, dev.idx.data(), n, dev.esdf_staging.data(), dev.bits.data(),
+                               dev.has_data.data()),
+           VBX_OK)
+      << vbx_last_error(dev.ctx);
+  for (size_t i = 0; i < n; ++i) {
+    const BlockIndex bi(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]);
+    Block<EsdfVoxel>::Ptr block = layer->allocateBlockPtrByIndex(bi);
+    const EsdfVoxel* src = dev.esdf_staging.data() + i * nv;
+    for (size_t v = 0; v < nv; ++v) block->getVoxelByLinearIndex(v) = src[v];
+    block->updated() |= std::bitset<Update::kCount>(dev.bits[i]);  // set_updated(true): kMap only (:147)
+  }
+  CHECK_EQ(vbx_clear_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP), VBX_OK) << vbx_last_error(dev.ctx);
+}
+
+namespace {
+vbx_esdf_cfg toC(const EsdfIntegrator::Config& c) {
+  vbx_esdf_cfg o;
+  vbx_esdf_cfg_default(&o);
+  o.full_euclidean_distance = c.full_euclidean_distance;
+  o.max_distance_m = c.max_distance_m;
+  o.min_distance_m = c.min_distance_m;
+  o.default_distance_m = c.default_distance_m;
+  o.min_diff_m = c.min_diff_m;
+  o.min_weight = c.min_weight;
+  o.num_buckets = c.num_buckets;
+  o.multi_queue = c.multi_queue;
+  o.add_occupied_crust = c.add_occupied_crust;
+  o.clear_sphere_radius = c.clear_sphere_radius;
+  o.occupied_sphere_radius = c.occupied_sphere_radius;
+  return o;
+}
+}  // namespace
+}  // namespace hip
+
+EsdfIntegrator::EsdfIntegrator(const Config& config, Layer<TsdfVoxel>* tsdf_layer, Layer<EsdfVoxel>* esdf_layer)
+    : config_(config), tsdf_layer_(tsdf_layer), esdf_layer_(esdf_layer) {
+  CHECK(tsdf_layer_);
+  CHECK(esdf_layer_);
+  voxels_per_side_ = esdf_layer_->voxels_per_side();
+  voxel_size_ = esdf_layer_->voxel_size();
+  CHECK_EQ(esdf_layer_->voxels_per_side(), tsdf_layer_->voxels_per_side());
+  CHECK_NEAR(esdf_layer_->voxel_size(), tsdf_layer_->voxel_size(), 1e-6);
+  open_.setNumBuckets(config_.num_buckets, config_.max_distance_m);
+}
+
+void EsdfIntegrator::addNewRobotPosition(const Point& position) {
+  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  const vbx_esdf_cfg cfg = hip::toC(config_);
+  CHECK_EQ(vbx_esdf_add_new_robot_position(dev.ctx, &cfg, position.data()), VBX_OK) << vbx_last_error(dev.ctx);
+  dev.esdf_pending = true;
+  // EsdfIntegrator::clear() is inline in the header and only empties the host containers; a non-empty
+  // updated_blocks_ is how the next update tells "robot spheres pending" from "clear() was called"
+  updated_blocks_.insert(BlockIndex(0, 0, 0));
+  hip::mirrorEsdfToHost(dev, esdf_layer_);
+}
+
+void EsdfIntegrator::updateFromTsdfLayerBatch() {
+  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  const vbx_esdf_cfg cfg = hip::toC(config_);
+  esdf_layer_->removeAllBlocks();  // esdf_integrator.cc:95
+  CHECK_EQ(vbx_esdf_update(dev.ctx, &cfg, /*batch=*/1, /*clear_updated_flag=*/0), VBX_OK) << vbx_last_error(dev.ctx);
+  dev.esdf_pending = false;
+  updated_blocks_.clear();
+  hip::mirrorEsdfToHost(dev, esdf_layer_);
+}
+
+void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
+  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  const vbx_esdf_cfg cfg = hip::toC(config_);
+  if (dev.esdf_pending && updated_blocks_.empty())  // clear() since addNewRobotPosition
+    CHECK_EQ(vbx_esdf_integrator_clear(dev.ctx), VBX_OK) << vbx_last_error(dev.ctx);
+  CHECK_EQ(vbx_esdf_update(dev.ctx, &cfg, /*batch=*/0, clear_updated_flag ? 1 : 0), VBX_OK) << vbx_last_error(dev.ctx);
+  dev.esdf_pending = false;
+  updated_blocks_.clear();
+  if (clear_updated_flag) {  // esdf_integrator.cc:113-121, on the host copies of the TSDF blocks
+    BlockIndexList tsdf_blocks;
+    tsdf_layer_->getAllUpdatedBlocks(Update::kEsdf, &tsdf_blocks);
+    for (const BlockIndex& block_index : tsdf_blocks)
+      if (tsdf_layer_->hasBlock(block_index)) tsdf_layer_->getBlockByIndex(block_index).updated().reset(Update::kEsdf);
+  }
+  hip::mirrorEsdfToHost(dev, esdf_layer_);
+}
+
+void EsdfIntegrator::updateFromTsdfBlocks(const BlockIndexList& tsdf_blocks, bool incremental) {
+  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  const vbx_esdf_cfg cfg = hip::toC(config_);
+  std::vector<int32_t> idx;
+  idx.reserve(3 * tsdf_blocks.size());
+  for (const BlockIndex& b : tsdf_blocks) {
+    idx.push_back(b.x());
+    idx.push_back(b.y());
+    idx.push_back(b.z());
+  }
+  CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), incremental ? 1 : 0),
+           VBX_OK)
+      << vbx_last_error(dev.ctx);
+  hip::mirrorEsdfToHost(dev, esdf_layer_);
+}
+
+// The wavefront runs on the device inside the update calls; the queue-level entry points of the class are
+// kept for link compatibility and have nothing left to process.
+void EsdfIntegrator::processRaiseSet() {}
+void EsdfIntegrator::processOpenSet() {}
+bool EsdfIntegrator::updateVoxelFromNeighbors(const GlobalIndex&) { return false; }
+
+}  // namespace voxblox
