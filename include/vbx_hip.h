@@ -204,10 +204,18 @@ int vbx_blocks_download(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t 
  * link speed, copies into pageable memory are several times slower.  Any host pointer works. */
 void* vbx_host_alloc(size_t bytes);
 void vbx_host_free(void* p);
-/* Layer::allocateBlockPtrByIndex + overwrite (load_map / tsdfMapCallback path). */
+/* Layer::allocateBlockPtrByIndex + overwrite (load_map / tsdfMapCallback path, tsdf_server.cc:566-578,
+ * 639-653).  vbx_blocks_upload takes n blocks in one call: idx_xyz n x 3, aos_voxels n x vps^3 voxels in the
+ * reference's AoS layout (12 B TsdfVoxel / 20 B EsdfVoxel), one updated-bits byte and (TSDF) one has_data
+ * byte per block; keys are inserted and slots assigned on the device, one staging copy, one unpack kernel. */
 int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos_voxels,
                      uint8_t updated_bits, uint8_t has_data);
-/* Layer::removeBlock / removeDistantBlocks / removeAllBlocks (layer.h:167-182). */
+int vbx_blocks_upload(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t n, const void* aos_voxels,
+                      const uint8_t* updated_bits, const uint8_t* has_data);
+/* Layer::removeBlock / removeDistantBlocks / removeAllBlocks (layer.h:167-182).  A removed block frees its
+ * memory like in the reference: once a pool slot holds no block of either layer its hash entry and the slot
+ * are recycled, so max_blocks bounds the blocks ALIVE at one time, not the blocks ever touched (a sliding
+ * window map keeps running); a map without any block left is back in its initial state. */
 int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]);
 int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance);
 int vbx_clear(vbx_ctx* ctx, int layer);

@@ -142,3 +142,82 @@ def test_single_launch_scan_selftest():
             gm.selftest_scan(n, seed, repeats=3)
     for rep in range(50):     # many short scans in a row: generation tags and the ticket base advance
         gm.selftest_scan(300 + 4096 * (rep % 5), rep, repeats=2)
+
+
+def test_removed_blocks_free_their_slots_sliding_window(oracle):
+    """ADVICE r1: removeDistantBlocks must free memory like Layer::removeDistantBlocks (layer.h:170-182).  A
+    sensor walks through a long corridor of frames while the map keeps only the blocks near it; the pool
+    (max_blocks) is far smaller than the number of blocks ever touched, so the stream only survives if
+    pool slots and hash entries are recycled — and what is left must equal the oracle doing the same."""
+    from voxblox_amd import capi
+    from parity_utils import compare_tsdf
+    voxel = 0.1
+    gm = capi.Map(voxel, 16, max_blocks=160)
+    cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    touched = set()
+    for k in range(40):
+        pose, pts, col = scenes.room_frame(k, 100, f=40.0, width=80, height=60)
+        pos = pose[0] + np.array([2.5 * k, 0, 0], np.float32)         # the whole scene slides along x
+        gm.integrate(capi.TSDF_MERGED, cfg, pos, pose[1], pts, col)
+        oi.integrate(pos, pose[1], pts, col)
+        touched |= {tuple(int(x) for x in i) for i in gm.block_indices()}
+        gm.remove_distant_blocks(pos, 4.0)
+        om.remove_distant_blocks(pos, 4.0)
+        assert gm.num_blocks() == om.num_blocks(0) <= 160
+    assert len(touched) > 3 * 160                                     # far more blocks than the pool ever held at once
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    gm.clear()                                                        # everything gone: the map is as new
+    assert gm.num_blocks() == 0
+    pose, pts, col = scenes.room_frame(3, 100, f=40.0, width=80, height=60)
+    gm.integrate(capi.TSDF_MERGED, cfg, pose[0], pose[1], pts, col)
+    om2 = oracle.OracleMap(voxel, 16)
+    om2.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)).integrate(
+        pose[0], pose[1], pts, col)
+    compare_tsdf(gm.tsdf_dict(), om2.tsdf_dict(), exact=True)
+
+
+def test_batched_block_upload_round_trip():
+    """vbx_blocks_upload (loadMap / tsdfMapCallback path): a whole map copied into a fresh one with one call
+    per layer — voxels, updated bits and has_data identical, also for blocks uploaded twice (overwrite) and
+    into recycled slots."""
+    from voxblox_amd import capi
+    pose, pts, col = scenes.room_frame(2, 100, f=40.0, width=80, height=60)
+    src = capi.Map(0.1, 16, max_blocks=1024)
+    src.integrate(capi.TSDF_FAST, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
+    src.esdf_update(capi.esdf_cfg(min_distance_m=0.2), batch=True, clear_updated_flag=False)
+    idx = src.block_indices()
+    tv, tu, th = src.blocks_download(idx, capi.LAYER_TSDF)
+    eidx = src.block_indices(capi.LAYER_ESDF)
+    ev, eu, _ = src.blocks_download(eidx, capi.LAYER_ESDF)
+    dst = capi.Map(0.1, 16, max_blocks=1024)
+    dst.integrate(capi.TSDF_FAST, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts[:500], col[:500])
+    dst.clear()                                                       # recycled slots underneath
+    for rep in range(2):                                              # the second pass overwrites in place
+        dst.blocks_upload(idx, tv, tu, th, capi.LAYER_TSDF)
+        dst.blocks_upload(eidx, ev, eu, None, capi.LAYER_ESDF)
+    assert dst.num_blocks() == len(idx) and dst.num_blocks(capi.LAYER_ESDF) == len(eidx)
+    tv2, tu2, th2 = dst.blocks_download(idx, capi.LAYER_TSDF)
+    ev2, eu2, _ = dst.blocks_download(eidx, capi.LAYER_ESDF)
+    assert tv2.tobytes() == tv.tobytes() and np.array_equal(tu2, tu) and np.array_equal(th2, th)
+    assert ev2.tobytes() == ev.tobytes() and np.array_equal(eu2, eu)
+
+
+def test_voxel_visit_count_overflow_fails_loudly():
+    """the per-ray voxel counts are scanned in 32 bits; a cloud whose rays visit more than 2^32
+    voxels in one call must be refused (VBX_ERR_CAPACITY), not wrap and write out of bounds."""
+    from voxblox_amd import capi
+    gm = capi.Map(0.01, 16, max_blocks=4096)
+    cfg = capi.tsdf_cfg(default_truncation_distance=0.04, max_ray_length_m=40.0)
+    n = 1_200_000
+    pts = np.tile(np.array([[18.0, 17.0, 16.0]], np.float32), (n, 1))       # ~5100 voxels per ray
+    col = np.full((n, 4), 255, np.uint8)
+    with pytest.raises(capi.VbxError, match="split the cloud"):
+        gm.integrate(capi.TSDF_SIMPLE, cfg, np.zeros(3, np.float32), np.array([1, 0, 0, 0], np.float32), pts, col)
+    assert gm.num_blocks() == 0
+    with pytest.raises(capi.VbxError, match="split the cloud"):              # Fast: the list buffer bound
+        big = np.tile(pts, (2, 1)) + np.random.RandomState(0).uniform(-8, 8, (2 * n, 3)).astype(np.float32)
+        gm.integrate(capi.TSDF_FAST, cfg, np.zeros(3, np.float32), np.array([1, 0, 0, 0], np.float32),
+                     big.astype(np.float32), np.full((2 * n, 4), 255, np.uint8))

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
-    "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
+    "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
     "vbx_selftest_unordered_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
@@ -134,6 +134,7 @@ def lib():
         "vbx_host_alloc": (vp, [C.c_size_t]),
         "vbx_host_free": (None, [vp]),
         "vbx_block_upload": (C.c_int, [vp, C.c_int, i32p, vp, C.c_uint8, C.c_uint8]),
+        "vbx_blocks_upload": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
         "vbx_block_remove": (C.c_int, [vp, C.c_int, i32p]),
         "vbx_remove_distant_blocks": (C.c_int, [vp, C.c_int, f32p, C.c_double]),
         "vbx_clear": (C.c_int, [vp, C.c_int]),
@@ -360,6 +361,20 @@ class Map:
         assert v.shape == (self.vps ** 3,)
         self._chk(self.L.vbx_block_upload(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)),
                                           v.ctypes.data_as(C.c_void_p), updated_bits, has_data))
+
+    def blocks_upload(self, idx_xyz, voxels, updated_bits, has_data=None, layer=LAYER_TSDF):
+        """n blocks at once: idx_xyz (n,3), voxels (n, vps^3) of the layer's AoS dtype, updated_bits (n,) uint8."""
+        idx = np.ascontiguousarray(idx_xyz, np.int32).reshape(-1, 3)
+        n = idx.shape[0]
+        dt = TSDF_VOXEL_DTYPE if layer == LAYER_TSDF else ESDF_VOXEL_DTYPE
+        v = np.ascontiguousarray(voxels, dt)
+        assert v.shape == (n, self.vps ** 3)
+        ub = np.ascontiguousarray(updated_bits, np.uint8).reshape(n)
+        hd = None if has_data is None else np.ascontiguousarray(has_data, np.uint8).reshape(n)
+        u8p = C.POINTER(C.c_uint8)
+        self._chk(self.L.vbx_blocks_upload(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)), n,
+                                           v.ctypes.data_as(C.c_void_p), ub.ctypes.data_as(u8p),
+                                           None if hd is None else hd.ctypes.data_as(u8p)))
 
     def block_remove(self, idx, layer=LAYER_TSDF):
         idx = np.ascontiguousarray(idx, np.int32)

@@ -65,6 +65,7 @@ struct PBuf {  // growable page-locked host buffer (small per-frame read-backs /
 
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
+constexpr uint64_t kTombKey = ~0ull - 1;  // hash entry of a recycled block: lookups walk past it, inserts never claim it
 
 // block flag bits (blk_flags[slot])
 constexpr uint32_t kFlagUpdMask = 0x7;      // Update::kMap|kMesh|kEsdf, core/block.h:15-18
@@ -75,6 +76,9 @@ constexpr uint32_t kFlagEsdfAlloc = 0x1000;   // block exists in Layer<EsdfVoxel
 constexpr uint32_t kFlagEsdfUpdShift = 4;     // ESDF block's Update bits live in bits 4..6
 constexpr uint32_t kFlagEsdfPendClassify = 0x2000;  // EsdfIntegrator::updated_blocks_ member (esdf_integrator.cc:54,80)
 constexpr uint32_t kFlagEsdfPendOpen = 0x4000;      // holds voxels pushed to open_ by addNewRobotPosition (:84)
+constexpr uint32_t kFlagFree = 0x8000;              // slot sits on the free list (belongs to no block)
+// everything that says "this slot holds a block of the ESDF layer" (shared by every removal path)
+constexpr uint32_t kEsdfBits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen;
 
 // Device-resident scalar state, read back at the per-call sync points.
 struct DevState {
@@ -92,6 +96,8 @@ struct DevState {
   uint32_t fold_long_count;
   uint32_t redo_count;       // rays whose voxel list must be rebuilt after slot assignment
   uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)
+  uint32_t tomb_count;       // tombstones in the hash table (recycled blocks)
+  uint32_t live_slots;       // k_reclaim: slots that still hold a block of either layer
   unsigned long long total_keys;
   unsigned long long voxels_touched;
   unsigned long long rays_cast;

@@ -476,135 +476,134 @@ int vbx_blocks_download(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, v
   return VBX_OK;
 }
 
-int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos, uint8_t updated_bits,
-                     uint8_t has_data) {
-  if (!ctx || !idx || !aos) return VBX_ERR_INVALID;
+// Layer::allocateBlockPtrByIndex + a voxel copy for n blocks at once (loadMap, tsdfMapCallback,
+// tsdf_server.cc:566-578, 639-653): keys inserted and slots assigned on the device, the AoS voxels staged
+// with one copy and unpacked by one kernel.
+int vbx_blocks_upload(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, const void* aos,
+                      const uint8_t* updated_bits, const uint8_t* has_data) {
+  if (!ctx || (n && (!idx || !aos || !updated_bits))) return VBX_ERR_INVALID;
   if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
     ctx->fail("unknown layer %d", layer);
     return VBX_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return VBX_OK;
   int rc = VBX_OK;
   if (layer == VBX_LAYER_ESDF) {
     rc = esdf_ensure(ctx);
     if (rc) return rc;
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  uint32_t slot;
-  rc = find_slot_host(ctx, idx, &slot, nullptr);
+  rc = upload_idx(ctx, idx, n);
   if (rc) return rc;
+  hipStream_t s = ctx->stream;
   MapDev& m = ctx->map;
-  uint32_t old_flags = 0;
-  if (slot != kInvalidSlot) HIP_TRY(hipMemcpy(&old_flags, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
-  if (slot == kInvalidSlot) {
-    // host-side insert: take a slot from the free list or the bump pointer
-    rc = sync_state(ctx);
-    if (rc) return rc;
-    if (ctx->h_state.free_count > 0) {
-      HIP_TRY(hipMemcpy(&slot, m.free_list + (ctx->h_state.free_count - 1), 4, hipMemcpyDeviceToHost));
-      ctx->h_state.free_count--;
-    } else {
-      if (ctx->h_state.pool_used >= m.cap_blocks) {
-        ctx->fail("block pool full");
-        return VBX_ERR_CAPACITY;
-      }
-      slot = ctx->h_state.pool_used++;
-    }
-    HIP_TRY(hipMemcpy(&ctx->d_state->pool_used, &ctx->h_state.pool_used, 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(&ctx->d_state->free_count, &ctx->h_state.free_count, 4, hipMemcpyHostToDevice));
-    const uint64_t key = pack_block_key(idx[0], idx[1], idx[2]);
-    uint32_t h = mix_key(key) & m.hmask;
-    for (;;) {
-      uint64_t k;
-      HIP_TRY(hipMemcpy(&k, m.hkeys + h, 8, hipMemcpyDeviceToHost));
-      if (k == kEmptyKey) break;
-      h = (h + 1) & m.hmask;
-    }
-    HIP_TRY(hipMemcpy(m.hkeys + h, &key, 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m.hvals + h, &slot, 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m.blk_idx + 3 * slot, idx, 12, hipMemcpyHostToDevice));
+  const size_t bpb = (size_t)m.nvox * (layer == VBX_LAYER_TSDF ? 12 : 20);
+  HIP_TRY(ctx->b_keys0.ensure(n * bpb));
+  HIP_TRY(ctx->b_graze.ensure(2 * n));
+  HIP_TRY(hipMemcpyAsync(ctx->b_keys0.p, aos, n * bpb, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_graze.p, updated_bits, n, hipMemcpyHostToDevice, s));
+  uint8_t* d_hd = nullptr;
+  if (has_data && layer == VBX_LAYER_TSDF) {
+    d_hd = ctx->b_graze.as<uint8_t>() + n;
+    HIP_TRY(hipMemcpyAsync(d_hd, has_data, n, hipMemcpyHostToDevice, s));
   }
-  const uint32_t nv = m.nvox;
-  const uint32_t esdf_bits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen;
-  if (layer == VBX_LAYER_ESDF) {  // EsdfVoxel AoS (voxel.h:18-37) -> distance + packed state
-    std::vector<float> d(nv);
-    std::vector<uint32_t> st(nv);
-    const uint8_t* in = static_cast<const uint8_t*>(aos);
-    for (uint32_t i = 0; i < nv; ++i) {
-      std::memcpy(&d[i], in + 20 * i, 4);
-      int32_t par[3];
-      std::memcpy(par, in + 20 * i + 8, 12);
-      st[i] = (in[20 * i + 4] ? 1u : 0u) | (in[20 * i + 5] ? 2u : 0u) | (in[20 * i + 6] ? 4u : 0u) |
-              (in[20 * i + 7] ? 8u : 0u) | ((uint32_t)(uint8_t)(int8_t)par[0] << 8) |
-              ((uint32_t)(uint8_t)(int8_t)par[1] << 16) | ((uint32_t)(uint8_t)(int8_t)par[2] << 24);
-    }
-    HIP_TRY(hipMemcpy(ctx->b_edist.as<float>() + (size_t)slot * nv, d.data(), nv * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->b_estate.as<uint32_t>() + (size_t)slot * nv, st.data(), nv * 4, hipMemcpyHostToDevice));
-    const uint32_t flags = (old_flags & ~esdf_bits) | kFlagEsdfAlloc |
-                           (((uint32_t)updated_bits & kFlagUpdMask) << kFlagEsdfUpdShift);
-    HIP_TRY(hipMemcpy(m.blk_flags + slot, &flags, 4, hipMemcpyHostToDevice));
-    return VBX_OK;
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
+  hipLaunchKernelGGL(k_insert_blocks, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+                     ctx->d_state);
+  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
+                     ctx->b_rank.as<uint32_t>());
+  if (layer == VBX_LAYER_TSDF) {
+    hipLaunchKernelGGL(k_unpack_tsdf_aos, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
+                       ctx->b_keys0.as<uint32_t>());
+    // the ESDF layer's membership of the same slot is untouched (the layers are independent)
+    hipLaunchKernelGGL(k_replace_block_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n,
+                       kEsdfBits, kFlagPublished, ctx->b_graze.as<uint8_t>(), 0, d_hd);
+  } else {
+    hipLaunchKernelGGL(k_unpack_esdf_aos, dim3((unsigned)n), dim3(256), 0, s, m.nvox, ctx->b_edist.as<float>(),
+                       ctx->b_estate.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), ctx->b_keys0.as<uint32_t>());
+    hipLaunchKernelGGL(k_replace_block_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n,
+                       ~kEsdfBits, kFlagEsdfAlloc, ctx->b_graze.as<uint8_t>(), (int)kFlagEsdfUpdShift,
+                       (const uint8_t*)nullptr);
   }
-  std::vector<float> d(nv), w(nv);
-  std::vector<uint32_t> c(nv);
-  const uint8_t* in = static_cast<const uint8_t*>(aos);
-  for (uint32_t i = 0; i < nv; ++i) {
-    std::memcpy(&d[i], in + 12 * i, 4);
-    std::memcpy(&w[i], in + 12 * i + 4, 4);
-    std::memcpy(&c[i], in + 12 * i + 8, 4);
+  rc = sync_state(ctx);  // the caller's host buffers are free again
+  if (rc) return rc;
+  return check_state_error(ctx);
+}
+
+int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos, uint8_t updated_bits,
+                     uint8_t has_data) {
+  return vbx_blocks_upload(ctx, layer, idx, 1, aos, &updated_bits, &has_data);
+}
+
+// After a removal: pool slots whose block belongs to neither layer any more give their hash entry up and go
+// on the free list (k_reclaim); a map without any block left is reset to its initial state, and a hash
+// table that has collected too many tombstones is rebuilt.
+static int reclaim_slots(vbx_ctx* ctx) {
+  int rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  if (used == 0) return VBX_OK;
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->live_slots, 0, 4, s));
+  hipLaunchKernelGGL(k_reclaim, grid_for(used), dim3(256), 0, s, m, ctx->d_state);
+  if (ctx->b_obs.p)  // per-voxel "observed this epoch" stamps must not outlive the block (Fast, exact set, n-frame sets)
+    hipLaunchKernelGGL(k_zero_free_slots_u32, dim3(used), dim3(256), 0, s, m, ctx->b_obs.as<uint32_t>());
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  if (ctx->h_state.live_slots == 0) {
+    HIP_TRY(hipMemsetAsync(m.hkeys, 0xFF, (size_t)ctx->hcap * 8, s));
+    HIP_TRY(hipMemsetAsync(m.hvals, 0xFF, (size_t)ctx->hcap * 4, s));
+    HIP_TRY(hipMemsetAsync(m.blk_flags, 0, (size_t)used * 4, s));
+    hipLaunchKernelGGL(k_reset_pool, dim3(1), dim3(1), 0, s, ctx->d_state);
+  } else if (ctx->h_state.tomb_count > ctx->hcap / 4) {
+    HIP_TRY(hipMemsetAsync(m.hkeys, 0xFF, (size_t)ctx->hcap * 8, s));
+    HIP_TRY(hipMemsetAsync(m.hvals, 0xFF, (size_t)ctx->hcap * 4, s));
+    hipLaunchKernelGGL(k_rehash, grid_for(used), dim3(256), 0, s, m, ctx->d_state);
   }
-  HIP_TRY(hipMemcpy(m.dist + (size_t)slot * nv, d.data(), nv * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(m.weight + (size_t)slot * nv, w.data(), nv * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(m.rgba + (size_t)slot * nv, c.data(), nv * 4, hipMemcpyHostToDevice));
-  // the ESDF layer's membership of the same slot is untouched (the layers are independent)
-  const uint32_t flags = (old_flags & esdf_bits) | kFlagPublished | (updated_bits & kFlagUpdMask) | (has_data ? kFlagHasData : 0);
-  HIP_TRY(hipMemcpy(m.blk_flags + slot, &flags, 4, hipMemcpyHostToDevice));
   return VBX_OK;
 }
 
-static int remove_slot(vbx_ctx* ctx, int layer, uint32_t slot, uint32_t hpos) {
-  // Unpublish and zero the block; the hash entry stays and keeps its slot, so the block is
-  // simply a zeroed "candidate" again (no tombstones, no free-list churn).
+static int remove_slot(vbx_ctx* ctx, int layer, uint32_t slot) {
+  // The block is zeroed and leaves the layer; the other layer's membership of the slot is untouched (the
+  // layers are independent, layer.h:167).  reclaim_slots() then frees the slot if nothing is left in it.
   MapDev& m = ctx->map;
-  (void)hpos;
   const uint32_t nv = m.nvox;
-  const uint32_t zero = 0;
+  uint32_t f;
+  HIP_TRY(hipMemcpy(&f, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
   if (layer == VBX_LAYER_ESDF) {
     if (!ctx->esdf_init) return VBX_OK;
-    uint32_t f;
     HIP_TRY(hipMemset(ctx->b_edist.as<float>() + (size_t)slot * nv, 0, nv * 4));
     HIP_TRY(hipMemset(ctx->b_estate.as<uint32_t>() + (size_t)slot * nv, 0, nv * 4));
-    HIP_TRY(hipMemcpy(&f, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
-    f &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
-    HIP_TRY(hipMemcpy(m.blk_flags + slot, &f, 4, hipMemcpyHostToDevice));
-    return VBX_OK;
-  }
-  {  // a removed TSDF block keeps its ESDF flags (the layers are independent, layer.h:167)
-    uint32_t f;
-    HIP_TRY(hipMemcpy(&f, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
-    f &= (kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+    f &= ~kEsdfBits;
+  } else {
     HIP_TRY(hipMemset(m.dist + (size_t)slot * nv, 0, nv * 4));
     HIP_TRY(hipMemset(m.weight + (size_t)slot * nv, 0, nv * 4));
     HIP_TRY(hipMemset(m.rgba + (size_t)slot * nv, 0, nv * 4));
-    HIP_TRY(hipMemcpy(m.blk_flags + slot, &f, 4, hipMemcpyHostToDevice));
-    return VBX_OK;
+    f &= kEsdfBits;
   }
-  HIP_TRY(hipMemset(m.dist + (size_t)slot * nv, 0, nv * 4));
-  HIP_TRY(hipMemset(m.weight + (size_t)slot * nv, 0, nv * 4));
-  HIP_TRY(hipMemset(m.rgba + (size_t)slot * nv, 0, nv * 4));
-  HIP_TRY(hipMemcpy(m.blk_flags + slot, &zero, 4, hipMemcpyHostToDevice));
-  return VBX_OK;
+  HIP_TRY(hipMemcpy(m.blk_flags + slot, &f, 4, hipMemcpyHostToDevice));
+  return reclaim_slots(ctx);
 }
 
 int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]) {
   if (!ctx || !idx) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+    ctx->fail("unknown layer %d", layer);
+    return VBX_ERR_INVALID;
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   uint32_t slot, hpos = 0;
   int rc = find_slot_host(ctx, idx, &slot, &hpos);
   if (rc) return rc;
   if (slot == kInvalidSlot) return VBX_OK;  // unordered_map::erase of a missing key is a no-op
-  return remove_slot(ctx, layer, slot, hpos);
+  (void)hpos;
+  return remove_slot(ctx, layer, slot);
 }
 
 int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance) {
@@ -623,29 +622,29 @@ int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], do
                      ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,
                      ctx->esdf_init ? ctx->b_estate.as<uint32_t>() : (uint32_t*)nullptr, layer,
                      f3{center[0], center[1], center[2]}, max_distance * max_distance, block_size);
-  return VBX_OK;
+  return reclaim_slots(ctx);
 }
 
 int vbx_clear(vbx_ctx* ctx, int layer) {
   if (!ctx) return VBX_ERR_INVALID;
+  if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
+    ctx->fail("unknown layer %d", layer);
+    return VBX_ERR_INVALID;
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   {
     // removeAllBlocks (layer.h:168): every block of the layer is zeroed and leaves it in one
-    // launch (a workgroup per pool slot, slots outside the layer exit at once); the hash entries
-    // stay and turn back into invisible candidates.
+    // launch (a workgroup per pool slot, slots outside the layer exit at once); slots that hold no
+    // block of the other layer either are recycled (reclaim_slots).
     int rc = sync_state(ctx);
     if (rc) return rc;
     const uint32_t used = ctx->h_state.pool_used;
     if (used == 0) return VBX_OK;
-    if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
-      ctx->fail("unknown layer %d", layer);
-      return VBX_ERR_INVALID;
-    }
     hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map,
                        ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,
                        ctx->esdf_init ? ctx->b_estate.as<uint32_t>() : (uint32_t*)nullptr, layer, f3{0.f, 0.f, 0.f},
                        -1.0, 0.0f);  // squared distance > -1: every block
-    return VBX_OK;
+    return reclaim_slots(ctx);
   }
 }
 

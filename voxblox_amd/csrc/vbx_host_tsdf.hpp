@@ -66,7 +66,7 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
   HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
   KLAUNCH(k_ray_count, grid_for(R + 1), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0,
-                     limit, ctx->b_cnt.as<uint32_t>());
+                     limit, ctx->b_cnt.as<uint32_t>(), ctx->d_state);
   int rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
   if (!blocks_already_marked) {
@@ -81,6 +81,11 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
   uint32_t total = 0;
   rc = sync_state(ctx, ctx->b_off.as<uint32_t>() + R, &total);
   if (rc) return rc;
+  if (ctx->h_state.total_keys > 0xFFFFFFF0ull) {  // the 32-bit offsets wrapped: no voxel has been written yet
+    ctx->fail("cloud visits %llu voxels, more than one call can order (2^32): split the cloud",
+              (unsigned long long)ctx->h_state.total_keys);
+    return VBX_ERR_CAPACITY;
+  }
   rc = check_state_error(ctx);
   if (rc) return rc;
   if (total == 0) return VBX_OK;
@@ -426,7 +431,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
   KLAUNCH(k_ray_count, grid_for(R + 1), dim3(256), 0, s, kt, c, m, 0,
-                     (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>());
+                     (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>(), ctx->d_state);
   rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
   // Every ray emits at most sqrt(3) * (max_ray_length + truncation) / voxel_size + 4 voxels
@@ -434,7 +439,12 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   // the exact total; 288 GB of HBM make the slack irrelevant and the buffer is reused.
   const double seg = (double)c.max_ray_length_m + (double)c.trunc;
   const size_t per_ray = (size_t)(1.7320508075688772 * seg * (double)m.voxel_size_inv) + 6;
-  const size_t vox_cap = std::min<size_t>((size_t)R * per_ray + 64, 0xFFFFFFF0u);
+  if ((size_t)R * per_ray + 64 > 0xFFFFFFF0ull) {  // 32-bit list offsets
+    ctx->fail("cloud too large for one call: %u rays of up to %zu voxels exceed 2^32 list entries; split the cloud", R,
+              per_ray);
+    return VBX_ERR_CAPACITY;
+  }
+  const size_t vox_cap = (size_t)R * per_ray + 64;
   HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
   HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
   KLAUNCH(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),

@@ -155,6 +155,43 @@ __global__ void k_deserialize_esdf(uint32_t nvox, float* edist, uint32_t* estate
     estate[gid] = (b & 0xFu) | (((b >> 24) & 0xFF) << 8) | (((b >> 16) & 0xFF) << 16) | (((b >> 8) & 0xFF) << 24);
   }
 }
+// AoS voxels -> SoA pool: the inverse of k_pack_tsdf_aos / k_pack_esdf_aos (vbx_blocks_upload).
+__global__ void k_unpack_tsdf_aos(MapDev m, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ in) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* a = in + (size_t)blockIdx.x * m.nvox * 3;
+  uint32_t* d = reinterpret_cast<uint32_t*>(m.dist) + (size_t)slot * m.nvox;
+  uint32_t* w = reinterpret_cast<uint32_t*>(m.weight) + (size_t)slot * m.nvox;
+  uint32_t* c = m.rgba + (size_t)slot * m.nvox;
+  for (uint32_t i = threadIdx.x; i < m.nvox * 3; i += blockDim.x) {  // coalesced word reads
+    const uint32_t v = i / 3, k = i % 3;
+    (k == 0 ? d : (k == 1 ? w : c))[v] = a[i];
+  }
+}
+__global__ void k_unpack_esdf_aos(uint32_t nvox, float* edist, uint32_t* estate, const uint32_t* __restrict__ slots,
+                                  const uint32_t* __restrict__ in) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  const uint32_t* a = in + (size_t)blockIdx.x * nvox * 5;  // {float d; bool obs, hall, in_queue, fixed; int32 parent[3]}
+  for (uint32_t v = threadIdx.x; v < nvox; v += blockDim.x) {
+    const uint32_t fl = a[5 * v + 1];
+    const uint32_t st = ((fl & 0xFFu) ? 1u : 0u) | ((fl & 0xFF00u) ? 2u : 0u) | ((fl & 0xFF0000u) ? 4u : 0u) |
+                        ((fl & 0xFF000000u) ? 8u : 0u) | ((a[5 * v + 2] & 0xFFu) << 8) | ((a[5 * v + 3] & 0xFFu) << 16) |
+                        ((a[5 * v + 4] & 0xFFu) << 24);
+    edist[(size_t)slot * nvox + v] = __uint_as_float(a[5 * v]);
+    estate[(size_t)slot * nvox + v] = st;
+  }
+}
+// Replaces one layer's flag bits of the listed blocks (vbx_blocks_upload): `keep` masks what survives.
+__global__ void k_replace_block_flags(MapDev m, const uint32_t* __restrict__ slots, uint32_t n, uint32_t keep,
+                                      uint32_t base_bits, const uint8_t* __restrict__ upd, int upd_shift,
+                                      const uint8_t* __restrict__ has_data) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || slots[i] == kInvalidSlot) return;
+  uint32_t f = (m.blk_flags[slots[i]] & keep) | base_bits | (((uint32_t)upd[i] & kFlagUpdMask) << upd_shift);
+  if (has_data && has_data[i]) f |= kFlagHasData;
+  m.blk_flags[slots[i]] = f;
+}
 __global__ void k_set_block_flags(MapDev m, const uint32_t* __restrict__ slots, uint32_t n, uint32_t or_bits,
                                   const uint8_t* __restrict__ has_data, uint32_t has_data_bit) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,8 +366,7 @@ __global__ void k_remove_distant(MapDev m, float* edist, uint32_t* estate, int l
   __syncthreads();
   if (threadIdx.x == 0) {
     // the two layers are independent (layer.h:167): keep the other layer's membership and bits
-    const uint32_t esdf_bits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen;
-    m.blk_flags[slot] = (layer == VBX_LAYER_ESDF) ? (f & ~esdf_bits) : (f & esdf_bits);
+    m.blk_flags[slot] = (layer == VBX_LAYER_ESDF) ? (f & ~kEsdfBits) : (f & kEsdfBits);
   }
 }
 
@@ -341,6 +377,67 @@ __global__ void k_clear_update_bits(MapDev m, uint32_t n_slots, uint32_t need, u
   const uint32_t f = m.blk_flags[s];
   if ((f & need) && (f & bits)) m.blk_flags[s] = f & ~bits;
 }
+// Slot recycling (Layer::removeBlock / removeDistantBlocks / removeAllBlocks free their blocks,
+// layer.h:160-182).  A pool slot whose block belongs to neither layer any more — removed from both, or a
+// candidate no ray ever reached — gives its hash entry up (tombstone) and goes on the free list;
+// k_assign_slots hands free slots out before it grows the pool.  The block's voxels are zero at this
+// point: the removal paths zero them, and a never-published candidate was never written.
+__global__ void k_reclaim(MapDev m, DevState* st) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= st->pool_used) return;
+  const uint32_t f = m.blk_flags[s];
+  if (f & kFlagFree) return;
+  if (f & (kFlagPublished | kFlagEsdfAlloc)) {
+    atomicAdd(&st->live_slots, 1u);
+    return;
+  }
+  const uint64_t key = pack_block_key(m.blk_idx[3 * s], m.blk_idx[3 * s + 1], m.blk_idx[3 * s + 2]);
+  uint32_t h = mix_key(key) & m.hmask;
+  for (uint32_t probes = 0; probes <= m.hmask; ++probes) {
+    const uint64_t k = m.hkeys[h];
+    if (k == key) {
+      m.hkeys[h] = kTombKey;
+      m.hvals[h] = kInvalidSlot;
+      atomicAdd(&st->tomb_count, 1u);
+      break;
+    }
+    if (k == kEmptyKey) break;  // (not reachable: every assigned slot has its entry)
+    h = (h + 1) & m.hmask;
+  }
+  m.blk_flags[s] = kFlagFree;
+  m.free_list[atomicAdd(&st->free_count, 1u)] = s;
+}
+__global__ void k_zero_free_slots_u32(MapDev m, uint32_t* per_voxel) {
+  const uint32_t s = blockIdx.x;
+  if (!(m.blk_flags[s] & kFlagFree)) return;
+  for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) per_voxel[(size_t)s * m.nvox + v] = 0u;
+}
+// Rebuilds the hash table from the pool (drops the tombstones): launched over an emptied table.
+__global__ void k_rehash(MapDev m, DevState* st) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) st->tomb_count = 0;
+  if (s >= st->pool_used) return;
+  if (m.blk_flags[s] & kFlagFree) return;
+  const uint64_t key = pack_block_key(m.blk_idx[3 * s], m.blk_idx[3 * s + 1], m.blk_idx[3 * s + 2]);
+  uint32_t h = mix_key(key) & m.hmask;
+  for (uint32_t probes = 0; probes <= m.hmask; ++probes) {
+    const unsigned long long old = atomicCAS((unsigned long long*)&m.hkeys[h], (unsigned long long)kEmptyKey,
+                                             (unsigned long long)key);
+    if (old == kEmptyKey) {
+      m.hvals[h] = s;
+      return;
+    }
+    h = (h + 1) & m.hmask;
+  }
+}
+// Every block is gone: back to the state of a new map (the voxel arrays are already zero).
+__global__ void k_reset_pool(DevState* st) {
+  st->pool_used = 0;
+  st->free_count = 0;
+  st->tomb_count = 0;
+  st->new_count = 0;
+}
+
 __global__ void k_reset_tsdf_flags(MapDev m, uint32_t n_slots) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;

@@ -101,20 +101,20 @@ __device__ inline bool ray_init(RayCaster& rc, const RayTab& tab, uint32_t o, co
 
 // cnt[o] = number of voxel indices the ray emits (ray_length_in_steps_ + 1), or `limit[o]`.
 __global__ void k_ray_count(RayTab tab, CastCfg c, MapDev m, int from_origin,
-                            const uint32_t* __restrict__ limit, uint32_t* cnt) {
+                            const uint32_t* __restrict__ limit, uint32_t* cnt, DevState* st) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o > tab.R) return;
-  if (o == tab.R) {
-    cnt[o] = 0;
-    return;
-  }
   RayCaster rc;
   uint32_t n = 0;
-  if (ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) {
+  if (o < tab.R && ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) {
     n = (rc.cur == 0) ? rc.steps + 1 : 0;
     if (limit) n = min(n, limit[o]);
   }
-  cnt[o] = n;
+  if (o <= tab.R) cnt[o] = n;  // cnt[R] = 0 terminates the scan
+  // 64-bit total beside the 32-bit offsets: a cloud whose voxel visits do not fit 2^32 must fail, not wrap
+  unsigned long long sum = n;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&st->total_keys, sum);
 }
 
 // Walks every ray and makes sure each block it crosses has a pool slot
