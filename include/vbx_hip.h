@@ -36,7 +36,9 @@ extern "C" {
 typedef struct vbx_map_cfg {
   float voxel_size;
   uint32_t voxels_per_side; /* power of two, 4..32 (reference default 16) */
-  uint32_t max_blocks;      /* capacity of the HBM block pool; 0 = default (65536) */
+  uint32_t max_blocks;      /* initial capacity of the HBM block pool; 0 = default (65536).  The pool doubles
+                               when a call needs more blocks (Layer::allocateBlockPtrByIndex never fails,
+                               layer.h:133-160) up to vbx_set_pool_limit / 2^32 voxel ids / device memory */
 } vbx_map_cfg;
 
 /* TsdfIntegratorBase::Config, tsdf_integrator.h:56-89 (same fields, same defaults via
@@ -112,6 +114,9 @@ const char* vbx_last_error(vbx_ctx* ctx); /* ctx may be NULL: error of the last 
 /* Run all work of this handle on an existing HIP stream (e.g. torch's current stream);
  * NULL restores the handle's own stream. */
 int vbx_set_stream(vbx_ctx* ctx, void* hip_stream);
+/* Upper bound of the block pool's growth in blocks (0 = none but the 32-bit voxel ids and device memory).  A
+ * call that needs more fails with VBX_ERR_CAPACITY, the map unchanged by it. */
+int vbx_set_pool_limit(vbx_ctx* ctx, uint32_t max_blocks_limit);
 
 /* TsdfIntegratorType, tsdf_integrator.h:30-34 */
 #define VBX_TSDF_SIMPLE 1

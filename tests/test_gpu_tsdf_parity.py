@@ -338,13 +338,14 @@ def test_non_finite_points_are_dropped(oracle, kind):
 
 @pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
 def test_failures_are_loud(kind):
-    """No silent degradation: a full block pool and coordinates outside the key range fail the call
-    with an error the caller can read (the reference would allocate / has no such limit)."""
+    """No silent degradation: a block pool that may not grow any further (vbx_set_pool_limit) and coordinates
+    outside the key range fail the call with an error the caller can read."""
     from voxblox_amd import capi
     k = {"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[kind]
     cfg = capi.tsdf_cfg(default_truncation_distance=0.4)
     pose, pts, col = _small_room(0)
     gm = capi.Map(0.1, 16, max_blocks=8)
+    gm.set_pool_limit(16)
     with pytest.raises(capi.VbxError, match="capacity"):
         gm.integrate(k, cfg, pose[0], pose[1], pts, col)
     gm = capi.Map(0.1, 16, max_blocks=1024)
@@ -354,6 +355,18 @@ def test_failures_are_loud(kind):
     assert gm.num_blocks() == 0                           # nothing was integrated from the rejected cloud
     gm.integrate(k, cfg, pose[0], pose[1], pts, col)      # and the map is still usable
     assert gm.num_blocks() > 10
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_block_pool_grows_on_demand(oracle, kind):
+    """Layer::allocateBlockPtrByIndex never fails (layer.h:133-160): a map created with room for 8 blocks
+    integrates a stream that needs ~80 — the pool doubles as often as it takes (new arrays, used slots
+    copied, hash table rebuilt, the allocation pass of the running call repeated) and the result equals the
+    oracle's bit for bit, exactly as with a pool that was large from the start."""
+    frames = [_small_room(k) for k in (0, 6, 12)]
+    om, oi, gm = _run(oracle, kind, 0.1, frames, max_blocks=8)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    assert gm.num_blocks() > 40
 
 
 @pytest.mark.parametrize("kind,scene,n_frames", [("fast", "room", 40), ("merged", "cow", 16)])

@@ -21,7 +21,7 @@ UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
 # every symbol include/vbx_hip.h declares
 EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
-    "vbx_last_error", "vbx_set_stream", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
+    "vbx_last_error", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
@@ -110,6 +110,7 @@ def lib():
         "vbx_destroy": (None, [vp]),
         "vbx_last_error": (C.c_char_p, [vp]),
         "vbx_set_stream": (C.c_int, [vp, vp]),
+        "vbx_set_pool_limit": (C.c_int, [vp, C.c_uint32]),
         "vbx_tsdf_integrate": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, f32p, u8p,
                                          C.c_size_t, C.c_int]),
         "vbx_tsdf_integrate_device": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, vp, vp,
@@ -210,6 +211,10 @@ class Map:
         self.h = self.L.vbx_create(C.byref(cfg), int(device))
         if not self.h:
             raise VbxError(self.L.vbx_last_error(None).decode())
+
+    def set_pool_limit(self, max_blocks_limit):
+        """The pool doubles on demand; this bounds it (0 = unbounded)."""
+        self._chk(self.L.vbx_set_pool_limit(self.h, int(max_blocks_limit)))
 
     def close(self):
         if getattr(self, "h", None):

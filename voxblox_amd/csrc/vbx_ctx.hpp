@@ -9,6 +9,8 @@ struct vbx_ctx {
   vbx_map_cfg mcfg{};
   MapDev map{};
   uint32_t hcap = 0;
+  uint32_t pool_limit = 0;   // vbx_set_pool_limit: the pool never grows beyond this many blocks (0: no limit)
+  uint32_t pool_grown = 0;   // times the pool doubled
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   DevState* d_state = nullptr;

@@ -476,6 +476,30 @@ int vbx_blocks_download(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, v
   return VBX_OK;
 }
 
+// Layer::allocateBlockPtrByIndex for the n BlockIndex rows staged in b_head (upload_idx): keys inserted,
+// slots assigned (the pool grows when it runs out), the rows' slots left in b_rank.
+static int insert_and_lookup(vbx_ctx* ctx, size_t n) {
+  hipStream_t s = ctx->stream;
+  MapDev& m = ctx->map;
+  for (;;) {
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
+    hipLaunchKernelGGL(k_insert_blocks, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
+                       ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+    hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+                       ctx->d_state);
+    hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    int rc = sync_state(ctx);
+    if (rc) return rc;
+    if (!(ctx->h_state.error & 1u)) break;
+    rc = grow_pool(ctx);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
+                     ctx->b_rank.as<uint32_t>());
+  return VBX_OK;
+}
+
 // Layer::allocateBlockPtrByIndex + a voxel copy for n blocks at once (loadMap, tsdfMapCallback,
 // tsdf_server.cc:566-578, 639-653): keys inserted and slots assigned on the device, the AoS voxels staged
 // with one copy and unpacked by one kernel.
@@ -507,15 +531,8 @@ int vbx_blocks_upload(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, con
     d_hd = ctx->b_graze.as<uint8_t>() + n;
     HIP_TRY(hipMemcpyAsync(d_hd, has_data, n, hipMemcpyHostToDevice, s));
   }
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
-  hipLaunchKernelGGL(k_insert_blocks, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
-                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
-                     ctx->d_state);
-  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
-                     ctx->b_rank.as<uint32_t>());
+  rc = insert_and_lookup(ctx, n);
+  if (rc) return rc;
   if (layer == VBX_LAYER_TSDF) {
     hipLaunchKernelGGL(k_unpack_tsdf_aos, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
                        ctx->b_keys0.as<uint32_t>());
@@ -723,15 +740,8 @@ int vbx_blocks_merge_sums(vbx_ctx* ctx, const int32_t* idx, size_t n, const floa
   HIP_TRY(ctx->b_vals1.ensure(n * 4));
   HIP_TRY(hipMemcpyAsync(ctx->b_vals0.p, row_start.data(), (nu + 1) * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->b_vals1.p, order.data(), n * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
-  hipLaunchKernelGGL(k_insert_blocks, grid_for(nu), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)nu,
-                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
-                     ctx->d_state);
-  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-  hipLaunchKernelGGL(k_lookup_slots, grid_for(nu), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)nu, 0,
-                     ctx->b_rank.as<uint32_t>());
+  rc = insert_and_lookup(ctx, nu);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_merge_sums, dim3((unsigned)nu), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
                      ctx->b_vals0.as<uint32_t>(), ctx->b_vals1.as<uint32_t>(), d_sums, apply_caps, truncation_distance,
                      max_weight, ctx->d_state);
@@ -804,15 +814,8 @@ int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n
     HIP_TRY(hipMemcpyAsync(ctx->b_graze.p, has_data, n, hipMemcpyHostToDevice, s));
     d_hd = ctx->b_graze.as<uint8_t>();
   }
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
-  hipLaunchKernelGGL(k_insert_blocks, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n,
-                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-  hipLaunchKernelGGL(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
-                     ctx->d_state);
-  hipLaunchKernelGGL(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
-                     ctx->b_rank.as<uint32_t>());
+  rc = insert_and_lookup(ctx, n);
+  if (rc) return rc;
   if (layer == VBX_LAYER_TSDF) {
     hipLaunchKernelGGL(k_deserialize_tsdf, dim3((unsigned)n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(),
                        ctx->b_keys0.as<uint32_t>());
@@ -999,6 +1002,11 @@ int vbx_enable_timing(vbx_ctx* ctx, int enable) {
 int vbx_get_timing(vbx_ctx* ctx, vbx_timing* out) {
   if (!ctx || !out) return VBX_ERR_INVALID;
   *out = ctx->last_timing;
+  return VBX_OK;
+}
+int vbx_set_pool_limit(vbx_ctx* ctx, uint32_t max_blocks_limit) {
+  if (!ctx) return VBX_ERR_INVALID;
+  ctx->pool_limit = max_blocks_limit;
   return VBX_OK;
 }
 int vbx_profile_enable(vbx_ctx* ctx, int enable) {

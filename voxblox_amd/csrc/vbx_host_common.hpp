@@ -67,6 +67,95 @@ int check_state_error(vbx_ctx* ctx) {
   return VBX_OK;
 }
 
+// Layer::allocateBlockPtrByIndex never fails (layer.h:133-160); the pool here starts at max_blocks and
+// doubles when a call runs out of slots: new arrays, the used slots copied, the hash table rebuilt from
+// the pool.  Keys inserted by the failed allocation pass are dropped with the old table — the caller
+// re-runs that pass.  Bounded by vbx_set_pool_limit, by 2^32 voxel ids and by device memory.
+static hipError_t grow_buf(DBuf& b, size_t new_bytes, size_t keep_bytes, int fill, hipStream_t s) {
+  DBuf n;
+  hipError_t e = n.ensure(new_bytes);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(n.p, fill, n.cap, s);
+  if (e == hipSuccess && keep_bytes) e = hipMemcpyAsync(n.p, b.p, keep_bytes, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    n.release();
+    return e;
+  }
+  b.release();
+  b = n;
+  return hipSuccess;
+}
+int grow_pool(vbx_ctx* ctx) {
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(&ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+  const uint64_t hard = ((1ull << 32) - 1) / m.nvox;  // voxel ids are 32 bit
+  uint64_t limit = ctx->pool_limit ? std::min<uint64_t>(ctx->pool_limit, hard) : hard;
+  const uint64_t new_cap = std::min<uint64_t>(2ull * m.cap_blocks, limit);
+  auto give_up = [&]() {  // leave a consistent map behind: the keys of the failed pass go, pool_used is what exists
+    const uint32_t used_now = std::min(ctx->h_state.pool_used, m.cap_blocks);
+    (void)hipMemcpyAsync(&ctx->d_state->pool_used, &used_now, 4, hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s);
+    (void)hipMemsetAsync(&ctx->d_state->error, 0, 4, s);
+    hipLaunchKernelGGL(k_drop_unassigned_keys, grid_for((size_t)m.hmask + 1), dim3(256), 0, s, m, ctx->d_state);
+    (void)hipStreamSynchronize(s);
+  };
+  if (new_cap <= m.cap_blocks) {
+    give_up();
+    ctx->fail("block pool / hash map capacity exceeded (max_blocks=%u%s)", m.cap_blocks,
+              ctx->pool_limit ? ", growth limited by vbx_set_pool_limit" : ", 2^32 voxel ids");
+    return VBX_ERR_CAPACITY;
+  }
+  const uint32_t used = std::min(ctx->h_state.pool_used, m.cap_blocks);
+  const size_t nv_old = (size_t)used * m.nvox, nv_new = (size_t)new_cap * m.nvox;
+  uint32_t hcap = 1;
+  while (hcap < 4u * new_cap) hcap <<= 1;
+  auto ok = [&](hipError_t e) { return e == hipSuccess; };
+  bool good = ok(grow_buf(ctx->b_dist, nv_new * 4, nv_old * 4, 0, s)) && ok(grow_buf(ctx->b_weight, nv_new * 4, nv_old * 4, 0, s)) &&
+              ok(grow_buf(ctx->b_rgba, nv_new * 4, nv_old * 4, 0, s)) &&
+              ok(grow_buf(ctx->b_blkidx, (size_t)new_cap * 12, (size_t)used * 12, 0, s)) &&
+              ok(grow_buf(ctx->b_blkflags, (size_t)new_cap * 4, (size_t)used * 4, 0, s)) &&
+              ok(grow_buf(ctx->b_freelist, (size_t)new_cap * 4, (size_t)std::min(ctx->h_state.free_count, m.cap_blocks) * 4, 0, s)) &&
+              ok(grow_buf(ctx->b_newlist, (size_t)new_cap * 4, 0, 0, s)) &&
+              ok(grow_buf(ctx->b_hkeys, (size_t)hcap * 8, 0, 0xFF, s)) && ok(grow_buf(ctx->b_hvals, (size_t)hcap * 4, 0, 0xFF, s));
+  if (good && ctx->esdf_init)
+    good = ok(grow_buf(ctx->b_edist, nv_new * 4, nv_old * 4, 0, s)) && ok(grow_buf(ctx->b_estate, nv_new * 4, nv_old * 4, 0, s)) &&
+           ok(grow_buf(ctx->b_eraised, nv_new, nv_old, 0, s)) && ok(grow_buf(ctx->b_eactive, (size_t)new_cap * 4, (size_t)used * 4, 0, s));
+  if (good && ctx->b_obs.p) good = ok(grow_buf(ctx->b_obs, nv_new * 4, nv_old * 4, 0, s));
+  (void)hipGetLastError();
+  if (!good) {
+    give_up();
+    ctx->fail("block pool full (max_blocks=%u) and no device memory to grow it to %llu blocks", m.cap_blocks,
+              (unsigned long long)new_cap);
+    return VBX_ERR_CAPACITY;
+  }
+  // per-voxel claim arrays of the Fast solver are sized by the pool: start over (vbx_host_tsdf.hpp `fresh`)
+  ctx->b_own0.release();
+  ctx->b_own1.release();
+  ctx->b_cl.release();
+  m.cap_blocks = (uint32_t)new_cap;
+  ctx->hcap = hcap;
+  m.hmask = hcap - 1;
+  m.hkeys = ctx->b_hkeys.as<uint64_t>();
+  m.hvals = ctx->b_hvals.as<uint32_t>();
+  m.dist = ctx->b_dist.as<float>();
+  m.weight = ctx->b_weight.as<float>();
+  m.rgba = ctx->b_rgba.as<uint32_t>();
+  m.blk_idx = ctx->b_blkidx.as<int32_t>();
+  m.blk_flags = ctx->b_blkflags.as<uint32_t>();
+  m.free_list = ctx->b_freelist.as<uint32_t>();
+  // pool_used may have been pushed to the old capacity by the failed commit: the blocks that exist are `used`
+  HIP_TRY(hipMemcpyAsync(&ctx->d_state->pool_used, &used, 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
+  if (used) KLAUNCH(k_rehash, grid_for(used), dim3(256), 0, s, m, ctx->d_state);
+  HIP_TRY(hipStreamSynchronize(s));
+  ++ctx->pool_grown;
+  return VBX_OK;
+}
+
 RayTab make_tab(vbx_ctx* ctx, bool second, uint32_t R) {
   RayTab t;
   if (!second) {

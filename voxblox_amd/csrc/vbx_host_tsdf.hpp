@@ -69,18 +69,23 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
                      limit, ctx->b_cnt.as<uint32_t>(), ctx->d_state);
   int rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
-  if (!blocks_already_marked) {
-    KLAUNCH(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, tab, c, m,
-                       from_origin ? 1 : 0, limit, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-    KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
-                       ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-    KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-    tmark(ctx, 2);
-  }
-  // total number of keys = off[R]
   uint32_t total = 0;
-  rc = sync_state(ctx, ctx->b_off.as<uint32_t>() + R, &total);
-  if (rc) return rc;
+  for (;;) {
+    if (!blocks_already_marked) {
+      KLAUNCH(k_ray_mark_blocks, grid_for(R), dim3(256), 0, s, tab, c, m,
+                         from_origin ? 1 : 0, limit, ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+      KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+                         ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+      KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+      tmark(ctx, 2);
+    }
+    // total number of keys = off[R]
+    rc = sync_state(ctx, ctx->b_off.as<uint32_t>() + R, &total);
+    if (rc) return rc;
+    if (!(ctx->h_state.error & 1u) || blocks_already_marked) break;
+    rc = grow_pool(ctx);  // out of slots: double the pool and mark the blocks again
+    if (rc) return rc;
+  }
   if (ctx->h_state.total_keys > 0xFFFFFFF0ull) {  // the 32-bit offsets wrapped: no voxel has been written yet
     ctx->fail("cloud visits %llu voxels, more than one call can order (2^32): split the cloud",
               (unsigned long long)ctx->h_state.total_keys);
@@ -447,48 +452,53 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   const size_t vox_cap = (size_t)R * per_ray + 64;
   HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
   HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
-  KLAUNCH(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
-                     ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
-                     (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
-  KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
-                     ctx->b_newlist.as<uint32_t>(), ctx->d_state);
-  KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
-  // second pass over the queued rays (grid sized for the first-frame worst case; idle
-  // workgroups leave at once); capacity / lookup errors surface at the solver's first check
-  if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
-  KLAUNCH(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
-                     ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap,
-                     ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
+  auto build_lists = [&]() -> int {
+    KLAUNCH(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
+                       ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
+                       (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
+    KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
+                       ctx->b_newlist.as<uint32_t>(), ctx->d_state);
+    KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    // second pass over the queued rays (grid sized for the first-frame worst case; idle
+    // workgroups leave at once); capacity / lookup errors surface at the solver's first check
+    if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
+    KLAUNCH(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
+                       ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap,
+                       ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
+    return VBX_OK;
+  };
+  rc = build_lists();
+  if (rc) return rc;
   tmark(ctx, 2);
 
   // claim arrays + tags (see k_fast_sweep)
-  const size_t nvox_total = (size_t)m.cap_blocks * m.nvox;
   // ray-index bits: sized by the cloud (an upper bound of R) so the tag layout — and with it
   // the claim arrays' contents — stays valid from frame to frame
   const int s_bits = std::max((int)bits_for(std::max<size_t>(n, 2) - 1), ctx->own_s_bits);
-  const bool fresh = (ctx->b_own0.p == nullptr);
-  HIP_TRY(ctx->b_own0.ensure(nvox_total * 4));
-  HIP_TRY(ctx->b_own1.ensure(nvox_total * 4));
-  HIP_TRY(ctx->b_cl.ensure(nvox_total * 4));
-  const uint32_t max_tag = (1u << (32 - s_bits)) - 2;
-  auto reset_tags = [&]() -> int {
-    HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
-    HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
-    HIP_TRY(hipMemsetAsync(ctx->b_cl.p, 0xFF, nvox_total * 4, s));
-    ctx->own_s_bits = s_bits;
-    ctx->own_tag = max_tag;
-    return VBX_OK;
-  };
-  if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 1024) {
-    rc = reset_tags();
-    if (rc) return rc;
-  }
   const bool strict_set = cfg->fast_observed_set == 0;  // the reference's ApproxHashSet semantics
   const bool keep_observed = cfg->clear_checks_every_n_frames > 1 && !strict_set;
-  if (keep_observed && ctx->b_obs.cap < nvox_total * 4) {
-    HIP_TRY(ctx->b_obs.ensure(nvox_total * 4));
-    HIP_TRY(hipMemsetAsync(ctx->b_obs.p, 0, nvox_total * 4, s));
-  }
+  auto ensure_claims = [&]() -> int {  // sized by the pool: again after the pool has grown
+    const size_t nvox_total = (size_t)m.cap_blocks * m.nvox;
+    const bool fresh = (ctx->b_own0.p == nullptr);
+    HIP_TRY(ctx->b_own0.ensure(nvox_total * 4));
+    HIP_TRY(ctx->b_own1.ensure(nvox_total * 4));
+    HIP_TRY(ctx->b_cl.ensure(nvox_total * 4));
+    const uint32_t max_tag = (1u << (32 - s_bits)) - 2;
+    if (fresh || s_bits != ctx->own_s_bits || ctx->own_tag < 1024) {
+      HIP_TRY(hipMemsetAsync(ctx->b_own0.p, 0xFF, nvox_total * 4, s));
+      HIP_TRY(hipMemsetAsync(ctx->b_own1.p, 0xFF, nvox_total * 4, s));
+      HIP_TRY(hipMemsetAsync(ctx->b_cl.p, 0xFF, nvox_total * 4, s));
+      ctx->own_s_bits = s_bits;
+      ctx->own_tag = max_tag;
+    }
+    if (keep_observed && ctx->b_obs.cap < nvox_total * 4) {
+      HIP_TRY(ctx->b_obs.ensure(nvox_total * 4));
+      HIP_TRY(hipMemsetAsync(ctx->b_obs.p, 0, nvox_total * 4, s));
+    }
+    return VBX_OK;
+  };
+  rc = ensure_claims();
+  if (rc) return rc;
   HIP_TRY(ctx->b_T.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_TH.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_U.ensure((size_t)(R + 1) * 4));
@@ -586,7 +596,21 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     ctx->fast_last_iters = std::min<uint32_t>(iters, 64);
     return VBX_OK;
   };
-  rc = run_solver();
+  for (;;) {
+    rc = run_solver();
+    if (rc != VBX_ERR_CAPACITY || !(ctx->h_state.error & 1u)) break;
+    // the pool ran out of slots while the lists were built (Layer::allocateBlockPtrByIndex never fails,
+    // layer.h:133-160): double it, build the lists again, restart the solver
+    rc = grow_pool(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 12, s));
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->redo_count, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->fast_idle_sweep, 0, 4, s));
+    rc = build_lists();
+    if (rc) return rc;
+    rc = ensure_claims();
+    if (rc) return rc;
+  }
   if (rc) return rc;
   if (keep_observed)
     KLAUNCH(k_fast_mark_observed, grid_for((size_t)R * 16), dim3(256), 0, s, ctx->b_off.as<uint32_t>(),

@@ -430,6 +430,18 @@ __global__ void k_rehash(MapDev m, DevState* st) {
     h = (h + 1) & m.hmask;
   }
 }
+// After an allocation pass that could not be served (pool at its limit): keys that were inserted but
+// never got a slot leave the table again, so the next call sees a consistent map instead of entries that
+// resolve to no block.
+__global__ void k_drop_unassigned_keys(MapDev m, DevState* st) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h > m.hmask) return;
+  const uint64_t k = m.hkeys[h];
+  if (k == kEmptyKey || k == kTombKey) return;
+  if (m.hvals[h] != kInvalidSlot) return;
+  m.hkeys[h] = kTombKey;
+  atomicAdd(&st->tomb_count, 1u);
+}
 // Every block is gone: back to the state of a new map (the voxel arrays are already zero).
 __global__ void k_reset_pool(DevState* st) {
   st->pool_used = 0;
