@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--mirror-frames", type=int, default=8, help="stream: frames that also mirror touched blocks to the host")
     ap.add_argument("--profile-frames", type=int, default=12, help="frames of the per-kernel profile pass (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-reference sample")
+    ap.add_argument("--esdf-fidelity-frames", type=int, default=24,
+                    help="--esdf: frames of the lockstep GPU-vs-reference ESDF comparison (0 = skip)")
     return ap.parse_args()
 
 
@@ -176,6 +178,86 @@ def cpu_esdf_baseline(frames, voxel, seconds):
     return {"ms_per_update": round(float(np.median(used)) * 1e3, 3), "cores": 1, "kind": "reference" if use_ref else "port",
             "frames": len(ts), "relaxations_per_update": round(st["relaxations"] / max(len(ts), 1), 1),
             "sample": "updateFromTsdfLayer(true) after every frame of the same stream, median after 2 warm-up frames"}
+
+
+def esdf_fidelity(frames, voxel, n_frames, checkpoints):
+    """configs[3] in lockstep on the HIP path and on the reference (oracle/_ref as the checker): Fast
+    integration + incremental ESDF update after every frame; after every frame the GPU's ESDF layer is
+    compared with the reference's incremental layer, and at the checkpoints with the reference's BATCH
+    result of the same TSDF (updateFromTsdfLayerBatch on a second reference map).  Reported, not asserted:
+    the device wavefront is order-free by design, the reference's result depends on its
+    bucket-queue pop order and on min_diff_m; this is the measured distance between the two."""
+    import ctypes
+    from voxblox_amd import capi
+    O, L, use_ref = _oracle()
+    L.orc_fast_reset_counter_set(0)
+
+    def ref_pair():
+        m = O.OracleMap(voxel, 16, L=L)
+        c = O.TsdfCfg()
+        L.orc_tsdf_cfg_default(ctypes.byref(c))
+        c.default_truncation_distance = 4 * voxel
+        c.integrator_threads = 1
+        ec = O.EsdfCfg()
+        L.orc_esdf_cfg_default(ctypes.byref(ec))
+        ec.min_distance_m = 2 * voxel
+        return m, m.tsdf_integrator("fast", c), m.esdf_integrator(ec)
+
+    mi, ti, ei = ref_pair()       # reference, incremental
+    mb, tb, eb = ref_pair()       # reference, batch at the checkpoints
+    gm = capi.Map(voxel, 16, max_blocks=8192)
+    gcfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    ecfg = capi.esdf_cfg(min_distance_m=2 * voxel)
+
+    def gpu_layer():
+        idx = gm.block_indices(capi.LAYER_ESDF)
+        v, _, _ = gm.blocks_download(idx, capi.LAYER_ESDF)
+        return {tuple(int(x) for x in i): (v[k]["distance"], v[k]["observed"]) for k, i in enumerate(idx)}
+
+    def compare(g, r):
+        se = 0.0
+        n = nd = n4 = 0
+        worst = 0.0
+        mask_diff = 0
+        for k, (rd, rf, _, _) in r.items():
+            obs = (rf & 1).astype(bool)
+            if k not in g:
+                mask_diff += int(obs.sum())
+                continue
+            gd, go = g[k]
+            mask_diff += int((go.astype(bool) != obs).sum())
+            both = obs & go.astype(bool)
+            d = np.abs(gd[both] - rd[both])
+            se += float((d.astype(np.float64) ** 2).sum())
+            n += int(both.sum())
+            nd += int((d > 0).sum())
+            n4 += int((d > 1e-4).sum())
+            if d.size:
+                worst = max(worst, float(d.max()))
+        return {"observed_voxels": n, "observed_mask_differences": mask_diff, "rmse_m": round((se / max(n, 1)) ** 0.5, 6),
+                "max_m": round(worst, 5), "frac_differing": round(nd / max(n, 1), 5), "frac_gt_1e-4_m": round(n4 / max(n, 1), 5)}
+
+    per_frame = []
+    batch = {}
+    for i, (pose, pts, col) in enumerate(frames[:n_frames]):
+        gm.integrate(capi.TSDF_FAST, gcfg, pose[0], pose[1], pts, col)
+        gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+        L.orc_fast_reset_counter_set(0)
+        ti.integrate(pose[0], pose[1], pts, col)
+        ei.update_from_tsdf_layer(True)
+        L.orc_fast_reset_counter_set(0)
+        tb.integrate(pose[0], pose[1], pts, col)
+        if (i + 1) in checkpoints or i + 1 == n_frames:
+            g = gpu_layer()
+            per_frame.append(dict(frame=i + 1, **compare(g, mi.esdf_dict())))
+            eb.update_from_tsdf_layer_batch()
+            batch[str(i + 1)] = compare(g, mb.esdf_dict())
+    gm.close()
+    return {"frames": n_frames, "kind": "reference" if use_ref else "port",
+            "vs_reference_incremental": per_frame, "vs_reference_batch": batch,
+            "note": "GPU incremental stream (updateFromTsdfLayer(true) after every frame, default Config, min_diff_m 1e-3) "
+                    "against the reference's own incremental stream and against its batch update of the same TSDF at the "
+                    "checkpoints; distances in metres over voxels both sides observe"}
 
 
 def cpu_mesh_baseline(frames, kind, voxel):
@@ -625,6 +707,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(frames[:60], args.integrator, voxel, args.cpu_seconds)
         if args.esdf:
             out["esdf"]["cpu_baseline"] = cpu_esdf_baseline(frames[:40], voxel, min(args.cpu_seconds, 12.0))
+            if args.esdf_fidelity_frames > 0:
+                nf = min(args.esdf_fidelity_frames, len(frames))
+                out["esdf"]["fidelity"] = esdf_fidelity(frames, voxel, nf, {max(1, nf // 4), max(1, nf // 2), max(1, 3 * nf // 4)})
 
     # ---- default run: short secondary legs for the other single-GPU configs
     default_run = (args.integrator == "fast" and args.scene == "room" and not args.esdf and not args.mesh

@@ -97,6 +97,10 @@ struct DevState {
   uint32_t redo_count;       // rays whose voxel list must be rebuilt after slot assignment
   uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)
   uint32_t tomb_count;       // tombstones in the hash table (recycled blocks)
+  // observed-set replay rounds run in batches without a host check in between (vbx_host_tsdf.hpp)
+  uint32_t rp_n;             // probes of the round's ray range (device-side size of the round's sort)
+  uint32_t rp_overflow;      // a round needed more probes than the batch was sized for: the rest of the batch idles
+  uint32_t rp_changed_round; // 1 + index of the last round in which a probe count moved
   uint32_t live_slots;       // k_reclaim: slots that still hold a block of either layer
   unsigned long long total_keys;
   unsigned long long voxels_touched;

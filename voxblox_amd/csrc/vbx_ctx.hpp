@@ -47,6 +47,7 @@ struct vbx_ctx {
   std::vector<int32_t> h_mnxt;
   std::vector<uint32_t> h_poff;  // scratch of the blocked observed-set replay
   uint32_t h_poff_total = 0;     // probes of the current replay guess
+  uint32_t rp_last_p = 0;        // probes of the last replay round of the previous frame (sizes the first batch)
   // voxel_observed_approx_set_ (reference semantics, fast_observed_set == 0)
   uint32_t obsset_offset = 0;
   bool obsset_sentinel_live = true;

@@ -249,29 +249,31 @@ int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
 // See vbx_sort.hpp.
 template <int CAP>
 int rsort_pass(vbx_ctx* ctx, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n,
-               int shift, uint32_t nwg, bool with_vals) {
+               const uint32_t* n_dev, int shift, uint32_t nwg, bool with_vals) {
   hipStream_t s = ctx->stream;
   uint32_t* hist = ctx->b_hist0.as<uint32_t>();
   uint32_t* gofs = ctx->b_hist1.as<uint32_t>();
-  KLAUNCH(k_rsort_count<CAP>, dim3(nwg), dim3(kSortThreads), 0, s, kin, n, shift, hist, nwg);
+  KLAUNCH(k_rsort_count<CAP>, dim3(nwg), dim3(kSortThreads), 0, s, kin, n, n_dev, shift, hist, nwg);
   int rc = exclusive_scan_u32(ctx, hist, gofs, (size_t)(1u << CAP) * nwg);
   if (rc) return rc;
   if (with_vals)
-    KLAUNCH((k_rsort_scatter<CAP, true>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n, shift,
+    KLAUNCH((k_rsort_scatter<CAP, true>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n, n_dev, shift,
                        gofs, nwg);
   else
-    KLAUNCH((k_rsort_scatter<CAP, false>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n,
+    KLAUNCH((k_rsort_scatter<CAP, false>), dim3(nwg), dim3(kSortThreads), 0, s, kin, vin, kout, vout, n, n_dev,
                        shift, gofs, nwg);
   return VBX_OK;
 }
-int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit, bool with_vals) {
+// n_dev (optional): the number of keys lives on the device; n64 is then the host's upper bound (grid, buffers).
+int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit, bool with_vals,
+                  const uint32_t* n_dev = nullptr) {
   if (n64 == 0 || end_bit <= begin_bit) {
     // nothing to order: the "sorted" data is the input
     std::swap(ctx->b_keys0, ctx->b_keys1);
     if (with_vals) std::swap(ctx->b_vals0, ctx->b_vals1);
     return VBX_OK;
   }
-  if (n64 > (4u << 20)) {
+  if (n64 > (4u << 20) && !n_dev) {
     // tens of millions of keys (the Simple integrator): bandwidth matters there, not launch
     // count, and rocPRIM's onesweep with 8-bit digits at full occupancy is the faster sort
     HIP_TRY(ctx->b_keys1.ensure(n64 * 8));
@@ -303,18 +305,18 @@ int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit
     uint32_t* vout = with_vals ? (in0 ? ctx->b_vals1 : ctx->b_vals0).as<uint32_t>() : nullptr;
     int rc;
     switch (w) {
-      case 1: rc = rsort_pass<1>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 2: rc = rsort_pass<2>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 3: rc = rsort_pass<3>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 4: rc = rsort_pass<4>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 5: rc = rsort_pass<5>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 6: rc = rsort_pass<6>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 7: rc = rsort_pass<7>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 8: rc = rsort_pass<8>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 9: rc = rsort_pass<9>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 10: rc = rsort_pass<10>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      case 11: rc = rsort_pass<11>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
-      default: rc = rsort_pass<12>(ctx, kin, vin, kout, vout, n, (int)shift, nwg, with_vals); break;
+      case 1: rc = rsort_pass<1>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 2: rc = rsort_pass<2>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 3: rc = rsort_pass<3>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 4: rc = rsort_pass<4>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 5: rc = rsort_pass<5>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 6: rc = rsort_pass<6>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 7: rc = rsort_pass<7>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 8: rc = rsort_pass<8>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 9: rc = rsort_pass<9>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 10: rc = rsort_pass<10>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      case 11: rc = rsort_pass<11>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
+      default: rc = rsort_pass<12>(ctx, kin, vin, kout, vout, n, n_dev, (int)shift, nwg, with_vals); break;
     }
     if (rc) return rc;
     in0 = !in0;

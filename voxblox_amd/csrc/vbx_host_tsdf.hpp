@@ -634,69 +634,108 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     static const bool dbg = getenv("VBX_DEBUG") != nullptr;
     // Replay of the rays [a, b) against the set content left by everything before them (the
     // persistent array: what the frame found, plus the commits of the rays below a).  Runs
-    // rounds until no probe count in the range moves (then commits the range's probes) or
-    // max_rounds is used up.
-    auto replay = [&](uint32_t a, uint32_t b, uint32_t max_rounds, bool* converged) -> int {
+    // rounds until no probe count in the range moves (then commits the range's probes) or about
+    // max_rounds are used up.  Rounds are queued in BATCHES without a host check in between: the
+    // number of probes of a round is only known on the device (k_strict_keys publishes it, the sort
+    // and the outcome kernel read it there), buffers and grids are sized for a bound taken from the
+    // last check (probe counts move by a few percent per round); a round that outgrows the bound
+    // raises rp_overflow, the rest of the batch idles and the host enlarges the bound.  A round
+    // after convergence reproduces the same state, so running past it is harmless.  Per round this
+    // saves the read-back and the pipeline bubble behind it (~15-20 us of ~100).
+    HIP_TRY(ctx->b_collided.ensure(vox_cap));  // outcomes by global probe index (< list entries)
+    auto replay = [&](uint32_t a, uint32_t b, uint32_t max_rounds, uint32_t p_hint, bool* converged) -> int {
       *converged = false;
-      uint32_t Pb = 0, pa = 0;
-      for (uint32_t it = 0;; ++it) {
-        rc = exclusive_scan_u32(ctx, Tcur, poff, R + 1);
+      uint32_t done = 0;  // rounds queued so far in this call
+      uint32_t bound = 0;
+      auto one_scan = [&]() -> int { return exclusive_scan_u32(ctx, Tcur, poff, R + 1); };
+      if (p_hint == 0) {  // no estimate of the range's probe count: ask
+        rc = one_scan();
         if (rc) return rc;
         const uint32_t* const ptrs[3] = {poff + R, poff + a, poff + b};
         uint32_t vals[3] = {0, 0, 0};
-        rc = sync_state3(ctx, ptrs, vals);  // also carries `changed` of the previous round
+        rc = sync_state3(ctx, ptrs, vals);
+        if (rc) return rc;
+        ctx->h_poff_total = vals[0];
+        p_hint = vals[2] - vals[1];
+      }
+      bound = p_hint + p_hint / 4 + 8192;
+      HIP_TRY(hipMemsetAsync(&ctx->d_state->rp_overflow, 0, 8, s));  // rp_overflow, rp_changed_round
+      uint32_t batch = 1;
+      for (;;) {
+        const bool exact_n = bound > (4u << 20);  // tens of millions of probes: rocPRIM's sort, which wants n on the host
+        if (exact_n) batch = 1;
+        const uint32_t first = done;
+        for (uint32_t q = 0; q < batch; ++q, ++done) {
+          rc = one_scan();
+          if (rc) return rc;
+          uint32_t n_sort = bound;
+          if (exact_n) {
+            const uint32_t* const ptrs[3] = {poff + R, poff + a, poff + b};
+            uint32_t vals[3] = {0, 0, 0};
+            rc = sync_state3(ctx, ptrs, vals);
+            if (rc) return rc;
+            ctx->h_poff_total = vals[0];
+            n_sort = vals[2] - vals[1];
+            bound = std::max(bound, n_sort);
+          }
+          HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(bound, 1) * 8));
+          HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(bound, 1) * 8));
+          KLAUNCH(k_strict_keys, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, a, b, bound, ctx->b_off.as<uint32_t>(),
+                             ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
+          rc = stable_sort01(ctx, std::max<uint32_t>(n_sort, 1), 44, 64, false, exact_n ? nullptr : &ctx->d_state->rp_n);
+          if (rc) return rc;
+          KLAUNCH(k_strict_outcome, grid_for(std::max<uint32_t>(n_sort, 1)), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), ctx->d_state,
+                             ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
+                             ctx->b_collided.as<uint8_t>());
+          KLAUNCH(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
+                             R, a, b, ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext,
+                             ctx->b_U.as<uint32_t>(), ctx->b_moved.as<uint8_t>(), done, ctx->d_state);
+          std::swap(Tcur, Tnext);
+          ++rounds;
+        }
+        rc = sync_state(ctx);
         if (rc) return rc;
         if (ctx->h_state.sentinel_cleared) ctx->obsset_sentinel_live = false;
-        const uint32_t Ptot = vals[0];
-        ctx->h_poff_total = Ptot;
-        if (dbg && it > 0)
-          fprintf(stderr, "[vbx] replay rays [%u,%u) round %u: %u probes, %u rays moved (%u grew)\n", a, b, it, Pb,
-                  ctx->h_state.act_count[0], ctx->h_state.act_count[1]);
-        if (it > 0 && !ctx->h_state.changed) {
+        if (a == 0 && b == R) ctx->h_poff_total = ctx->h_state.rp_n;
+        if (dbg)
+          fprintf(stderr, "[vbx] replay rays [%u,%u): %u rounds queued, last change in round %u, %u probes (bound %u)%s\n", a, b,
+                  done, ctx->h_state.rp_changed_round, ctx->h_state.rp_n, bound, ctx->h_state.rp_overflow ? " OVERFLOW" : "");
+        if (ctx->h_state.rp_overflow) {  // the batch stopped short: more room, same state
+          bound = std::max<uint32_t>(2 * bound, ctx->h_state.rp_n + ctx->h_state.rp_n / 4 + 8192);
+          HIP_TRY(hipMemsetAsync(&ctx->d_state->rp_overflow, 0, 4, s));
+          continue;
+        }
+        if (ctx->h_state.rp_changed_round < done) {  // the last round(s) moved nothing
           *converged = true;
           break;
         }
-        if (it >= max_rounds) break;
-        pa = vals[1];
-        Pb = vals[2] - vals[1];
-        HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(Pb, 1) * 8));
-        HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(Pb, 1) * 8));
-        HIP_TRY(ctx->b_collided.ensure((size_t)std::max<uint32_t>(Ptot, 1)));
-        if (!Pb) HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
-        if (Pb) {
-          KLAUNCH(k_strict_keys, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, a, b, pa, Pb, ctx->b_off.as<uint32_t>(),
-                             ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
-          rc = stable_sort01(ctx, Pb, 44, 64, false);
-          if (rc) return rc;
-          KLAUNCH(k_strict_outcome, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
-                             ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
-                             ctx->b_collided.as<uint8_t>());
-        }
-        if (dbg) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 8, s));
-        KLAUNCH(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
-                           R, a, b, ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext,
-                           ctx->b_U.as<uint32_t>(), ctx->b_moved.as<uint8_t>(), dbg ? 1 : 0, ctx->d_state);
-        std::swap(Tcur, Tnext);
-        ++rounds;
+        if (done >= max_rounds) break;
+        bound = std::max(bound, ctx->h_state.rp_n + ctx->h_state.rp_n / 4 + 8192);
+        (void)first;
+        // measured: a check costs about as much as one idle round (the rounds are bound by their ~10
+        // dependent kernels, not by the read-back), so batches stay short: 1, 1, 1, then pairs
+        batch = done >= 3 ? 2 : 1;
       }
+      ctx->rp_last_p = ctx->h_state.rp_n;
       // converged: the sorted probe list of the last round (whose T equals the final T) is still
       // in keys1 — its last probe per slot is the set's content after ray b - 1
-      if (*converged && Pb)
-        KLAUNCH(k_strict_commit, grid_for(Pb), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), Pb,
+      if (*converged && ctx->h_state.rp_n)
+        KLAUNCH(k_strict_commit, grid_for(ctx->h_state.rp_n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                            ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->d_state);
       return VBX_OK;
     };
     // Phase 1: the whole frame at once.  Steady-state frames converge in 1-5 rounds; a round
     // costs ~45 us + 0.07 us per 1000 probes.
     bool converged = false;
-    rc = replay(0, R, 8, &converged);
+    // whole-frame rounds; the previous frame's probe count sizes the first batch (no read-back needed)
+    rc = replay(0, R, 7, ctx->rp_last_p, &converged);
     if (rc) return rc;
     // Blocks pay off only when whole-frame rounds are expensive (millions of probes, i.e. fine
     // voxels): 16-32 blocks cost at least two cheap rounds each.
     static const bool no_blocks = getenv("VBX_REPLAY_NO_BLOCKS") != nullptr;  // measurement switch
     const bool use_blocks = ctx->h_poff_total > 1500000u && !no_blocks;
     if (!converged && !use_blocks) {
-      rc = replay(0, R, 100000, &converged);
+      rc = replay(0, R, 100000, ctx->rp_last_p, &converged);
       if (rc) return rc;
       if (!converged) {
         ctx->fail("Fast integrator: observed-set replay did not converge");
@@ -724,7 +763,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       HIP_TRY(hipMemcpyAsync(hp.data(), poff, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       if (r_lo > 0) {
-        rc = replay(0, r_lo, 8, &converged);  // final already: one round to list the probes, one to confirm
+        rc = replay(0, r_lo, 8, hp[r_lo], &converged);  // final already: one round to list the probes, one to confirm
         if (rc) return rc;
         if (!converged) {
           ctx->fail("Fast integrator: observed-set replay: settled prefix moved again");
@@ -741,7 +780,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           b = (uint32_t)(std::lower_bound(hp.begin() + a + 1, hp.begin() + R, (uint32_t)target) - hp.begin());
           b = std::max(b, a + 1);
         }
-        rc = replay(a, b, 100000, &converged);
+        rc = replay(a, b, 100000, hp[b] - hp[a], &converged);
         if (rc) return rc;
         if (!converged) {
           ctx->fail("Fast integrator: observed-set replay did not converge");

@@ -389,12 +389,19 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
 // so the sort moves 8 bytes per probe and no value array.  (Sorting only the upper 16 slot bits
 // and walking back inside the 16-slot group was slower: groups next to the sensor hold
 // thousands of probes of one hot slot.)
-__global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t r_begin, uint32_t r_end, uint32_t p_begin,
-                              uint32_t P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
+__global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t r_begin, uint32_t r_end, uint32_t n_bound,
+                              const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
                               uint64_t* keys, DevState* st) {
-  // 16 lanes per ray of [r_begin, r_end): the ray's probes are written as one run
+  // 16 lanes per ray of [r_begin, r_end): the ray's probes are written as one run.  The number of probes
+  // is only known on the device (rounds run in batches without a host check): the host sized the key
+  // buffers for n_bound; a round that needs more raises rp_overflow and the rest of the batch idles.
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) st->changed = 0;  // this round's "some probe count moved" flag (set by k_strict_scan)
+  const uint32_t p_begin = poff[r_begin], P = poff[r_end] - p_begin;
+  if (t == 0) {
+    st->rp_n = P;
+    if (P > n_bound) st->rp_overflow = 1;
+  }
+  if (P > n_bound || st->rp_overflow) return;
   const uint32_t r = r_begin + (t >> 4);
   if (r >= r_end) return;
   const uint32_t p0 = poff[r], n = poff[r + 1] - p0, beg = off[r];
@@ -403,7 +410,6 @@ __global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t r_begi
     const uint32_t p = p0 + k;  // ascends in (ray, step) order = time
     keys[p - p_begin] = ((uint64_t)(h & 0xFFFFFu) << 44) | ((uint64_t)(h >> 20) << 32) | p;
   }
-  (void)P;
 }
 __device__ inline uint32_t strict_key_slot(uint64_t key) { return (uint32_t)(key >> 44); }
 __device__ inline uint32_t strict_key_hash(uint64_t key) {
@@ -411,11 +417,12 @@ __device__ inline uint32_t strict_key_hash(uint64_t key) {
 }
 // replaceHash outcome of every probe (approx_hash_array.h:125-134): collision = the slot held
 // this hash already.  set_vals = pseudo_set_ as the frame found it (at offset_).
-__global__ void k_strict_outcome(const uint64_t* __restrict__ keys, uint32_t P,
+__global__ void k_strict_outcome(const uint64_t* __restrict__ keys, const DevState* __restrict__ st,
                                  const uint32_t* __restrict__ set_vals, uint32_t offset, int sentinel_live,
                                  uint8_t* collided_by_p) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
+  const uint32_t P = st->rp_n;
+  if (st->rp_overflow || i >= P) return;
   const uint64_t key = keys[i];
   const uint32_t slot = strict_key_slot(key);
   const uint32_t h = strict_key_hash(key);
@@ -434,7 +441,7 @@ __global__ void k_strict_outcome(const uint64_t* __restrict__ keys, uint32_t P,
 __global__ void __launch_bounds__(256)
 k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R, uint32_t r_begin,
               uint32_t r_end, const uint8_t* __restrict__ collided, int max_consecutive,
-              const uint32_t* __restrict__ T, uint32_t* Tnew, uint32_t* U, uint8_t* moved, int debug_counts,
+              const uint32_t* __restrict__ T, uint32_t* Tnew, uint32_t* U, uint8_t* moved, uint32_t round_idx,
               DevState* st) {
   // rays outside [r_begin, r_end) keep their probe count (they are final, or not in play yet)
   // 16 lanes per ray: 16 outcomes per step, the consecutive-collision counter is the run length
@@ -447,10 +454,11 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
     Tnew[R] = 0;
     U[R] = 0;
   }
-  const bool in_range = r >= r_begin && r < r_end;
+  // an idling round (rp_overflow) hands every probe count on unchanged: the host swaps T / Tnew per round
+  const bool in_range = r >= r_begin && r < r_end && !st->rp_overflow;
   if (r < R && !in_range && gl == 0) {
     Tnew[r] = T[r];
-    moved[r] = 0;
+    if (!st->rp_overflow) moved[r] = 0;
   }
   const bool ray_ok = r < R && in_range;
   const uint32_t t = ray_ok ? T[r] : 0;
@@ -487,14 +495,7 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
     Tnew[r] = tn;
     U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
     moved[r] = (tn != t) ? 1 : 0;
-    if (tn != t) {
-      st->changed = 1;
-      if (debug_counts) {  // same-address atomics serialise (~90/us): only on request (VBX_DEBUG)
-        atomicAdd(&st->act_count[0], 1u);              // rays whose probe count moved this round
-        if (!broke) atomicAdd(&st->act_count[1], 1u);  // of which: guesses that had to grow
-        atomicMin(&st->act_count[2], r);               // lowest ray index that moved
-      }
-    }
+    if (tn != t) st->rp_changed_round = round_idx + 1;  // same value from every writer of the round
   }
 }
 // Lowest ray index whose probe count moved in the last round: every ray below it is final.
@@ -506,9 +507,10 @@ __global__ void k_strict_first_moved(const uint8_t* __restrict__ moved, uint32_t
 }
 
 // The last probe of every slot leaves its hash in the persistent set.
-__global__ void k_strict_commit(const uint64_t* __restrict__ keys, uint32_t P, uint32_t* set_vals, uint32_t offset,
+__global__ void k_strict_commit(const uint64_t* __restrict__ keys, uint32_t* set_vals, uint32_t offset,
                                 DevState* st) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t P = st->rp_n;
   if (i >= P) return;
   const uint64_t key = keys[i];
   const uint32_t slot = strict_key_slot(key);

@@ -39,6 +39,9 @@ __global__ void k_reset_call_state(DevState* st) {
   st->fold_long_count = 0;
   st->fast_idle_sweep = 0;
   st->redo_count = 0;
+  st->rp_n = 0;
+  st->rp_overflow = 0;
+  st->rp_changed_round = 0;
   st->total_keys = 0;
   st->voxels_touched = 0;
   st->rays_cast = 0;

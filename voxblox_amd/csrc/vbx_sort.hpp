@@ -22,8 +22,10 @@ constexpr int kSortMaxBits = 12;
 
 template <int BITS>
 __global__ void __launch_bounds__(kSortThreads)
-k_rsort_count(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t nwg) {
+k_rsort_count(const uint64_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev, int shift,
+              uint32_t* __restrict__ hist, uint32_t nwg) {
   constexpr int NB = 1 << BITS;
+  if (n_dev) n = min(n, *n_dev);  // device-side size (the grid and `hist` are laid out for the host's bound n)
   __shared__ uint32_t s_cnt[NB];
   for (int i = threadIdx.x; i < NB; i += kSortThreads) s_cnt[i] = 0;
   __syncthreads();
@@ -40,8 +42,10 @@ k_rsort_count(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t
 template <int BITS, bool kHasVals>
 __global__ void __launch_bounds__(kSortThreads)
 k_rsort_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
-                uint32_t* __restrict__ vout, uint32_t n, int shift, const uint32_t* __restrict__ gofs, uint32_t nwg) {
+                uint32_t* __restrict__ vout, uint32_t n, const uint32_t* __restrict__ n_dev, int shift,
+                const uint32_t* __restrict__ gofs, uint32_t nwg) {
   constexpr int NB = 1 << BITS;
+  if (n_dev) n = min(n, *n_dev);
   constexpr int NW = kSortThreads / 64;
   __shared__ uint32_t s_run[NW][NB];  // phase 1: per-wave digit counts; phase 3: start of the wave's next chunk per digit
   const int lane = threadIdx.x & 63;
