@@ -65,6 +65,9 @@ def parse():
                     help="default run only: skip the short secondary legs (configs[2], configs[3], configs[4] on 1 GPU)")
     ap.add_argument("--mirror-frames", type=int, default=8, help="stream: frames that also mirror touched blocks to the host")
     ap.add_argument("--profile-frames", type=int, default=12, help="frames of the per-kernel profile pass (0 = skip)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="sensors4: torch = voxblox_amd.multi_gpu over torch.distributed (RCCL), exchange pipelined behind the "
+                         "next step; native = libvbx_shard.so (C++ host path, RCCL called directly, sequential)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-reference sample")
     ap.add_argument("--esdf-fidelity-frames", type=int, default=24,
                     help="--esdf: frames of the lockstep GPU-vs-reference ESDF comparison (0 = skip)")
@@ -420,6 +423,35 @@ def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
     for k in range(min(warmup + steps, 25)):
         sensors4_shards(k, rank, world, dev, cache)     # synthetic frames generated and uploaded before the clock
     torch.cuda.synchronize()
+    if args.exchange == "native":
+        # the C++ host path: libvbx_shard.so calls RCCL itself; torch.distributed only carries the communicator id
+        from voxblox_amd import shard_native
+        ids = [shard_native.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        ns = shard_native.NativeShard(pm, deltas[0], rank, world, ids[0] if world > 1 else None, local_rank)
+
+        def one(k):
+            ns.begin_step()
+            for pos, quat, dp, dc, n in sensors4_shards(k, rank, world, dev, cache):
+                ns.integrate(kind, cfg, pos, quat, dp.data_ptr(), dc.data_ptr(), n)
+            ns.end_step()
+
+        for k in range(warmup):
+            one(k)
+        barrier_fn()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            one(k)
+        barrier_fn()
+        dt = time.perf_counter() - t0
+        st = ns.stats()
+        f = max(st["steps"], 1)
+        exch = {"path": "libvbx_shard.so (C++, RCCL all-to-all-v called directly, sequential with the integration)",
+                "payload_bytes_per_step": int(st["payload_bytes"] / f), "sent_blocks_per_step": round(st["sent_blocks"] / f, 1)}
+        ns.close()
+        sharded.close()
+        return dt, exch, [], {}, (pm, deltas)
 
     def barrier():
         sharded.flush()

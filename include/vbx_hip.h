@@ -113,6 +113,8 @@ const char* vbx_last_error(vbx_ctx* ctx); /* ctx may be NULL: error of the last 
 
 /* Run all work of this handle on an existing HIP stream (e.g. torch's current stream);
  * NULL restores the handle's own stream. */
+/* Layer::voxel_size() / voxels_per_side() (layer.h:205-211) and the pool's current capacity. */
+int vbx_get_map_cfg(vbx_ctx* ctx, vbx_map_cfg* out);
 int vbx_set_stream(vbx_ctx* ctx, void* hip_stream);
 /* Upper bound of the block pool's growth in blocks (0 = none but the 32-bit voxel ids and device memory).  A
  * call that needs more fails with VBX_ERR_CAPACITY, the map unchanged by it. */

@@ -9,6 +9,7 @@
 #include "../../voxblox_amd/host/vbx_integrators.hpp"
 #include "../../voxblox_amd/host/vbx_io.hpp"
 #include "../../voxblox_amd/host/vbx_mesh.hpp"
+#include "../../voxblox_amd/host/vbx_sharded.hpp"
 
 using namespace vbx_host;
 
@@ -165,6 +166,35 @@ int main() {
   std::printf("robot sphere: esdf blocks %zu -> %zu (tsdf %zu)\n", before, esdf.getNumberOfAllocatedBlocks(),
               tsdf.getNumberOfAllocatedBlocks());
   if (esdf.getNumberOfAllocatedBlocks() <= before || tsdf.getNumberOfAllocatedBlocks() != b1.size()) return 16;
+  // Multi-GPU host path (vbx_sharded.hpp over libvbx_shard.so), one rank with a real RCCL communicator: the
+  // cloud in two ray bands -> delta map -> sparse all-to-all-v to the owner (this rank) -> persistent map.
+  {
+    DeviceMap persistent(voxel, 16, 2048, 0), delta(voxel, 16, 2048, 0);
+    uint8_t id[VBX_SHARD_ID_BYTES];
+    ShardedTsdfIntegrator::createCommId(id);
+    ShardedTsdfIntegrator sharded(TsdfIntegratorType::kFast, config, &persistent, &delta, 0, 1, id, 0);
+    // page-locked host memory is device-accessible on ROCm: stands in for the sensor driver's device buffer
+    const size_t n = points.size();
+    float* d_pts = static_cast<float*>(vbx_host_alloc(n * 12));
+    uint8_t* d_col = static_cast<uint8_t*>(vbx_host_alloc(n * 4));
+    if (!d_pts || !d_col) return 30;
+    std::memcpy(d_pts, &points[0].x, n * 12);
+    std::memcpy(d_col, &colors[0].r, n * 4);
+    for (int step = 0; step < 2; ++step) {
+      sharded.beginStep();
+      sharded.integratePointCloudDevice(T_G_C, d_pts, d_col, n / 2);
+      sharded.integratePointCloudDevice(T_G_C, d_pts + 3 * (n / 2), d_col + 4 * (n / 2), n - n / 2);
+      sharded.endStep();
+    }
+    size_t nb = 0;
+    persistent.check(vbx_num_blocks(persistent.ctx(), VBX_LAYER_TSDF, &nb), "vbx_num_blocks");
+    const vbx_shard_stats st = sharded.stats();
+    std::printf("sharded blocks=%zu steps=%llu sent=%llu received=%llu\n", nb, (unsigned long long)st.steps,
+                (unsigned long long)st.sent_blocks, (unsigned long long)st.received_blocks);
+    vbx_host_free(d_pts);
+    vbx_host_free(d_col);
+    if (nb == 0 || st.steps != 2 || st.sent_blocks != st.received_blocks || nb * 2 != st.sent_blocks) return 31;
+  }
   std::printf("shim OK\n");
   return 0;
 }

@@ -20,6 +20,8 @@ def test_shim_demo_matches_oracle(oracle):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shim OK" in out.stdout
+    sh = re.search(r"sharded blocks=(\d+) steps=2 sent=(\d+) received=(\d+)", out.stdout)
+    assert sh and int(sh.group(1)) > 0 and int(sh.group(2)) == int(sh.group(3)), out.stdout   # vbx_sharded.hpp over RCCL
     got = {}
     for line in out.stdout.splitlines():
         m = re.match(r"(simple|merged|fast) blocks=(\d+) observed=(\d+) sum_w=([-\d.]+) sum_d=([-\d.]+)", line)

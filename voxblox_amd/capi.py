@@ -21,7 +21,7 @@ UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
 # every symbol include/vbx_hip.h declares
 EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
-    "vbx_last_error", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
+    "vbx_last_error", "vbx_get_map_cfg", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
@@ -111,6 +111,7 @@ def lib():
         "vbx_last_error": (C.c_char_p, [vp]),
         "vbx_set_stream": (C.c_int, [vp, vp]),
         "vbx_set_pool_limit": (C.c_int, [vp, C.c_uint32]),
+        "vbx_get_map_cfg": (C.c_int, [vp, C.POINTER(MapCfg)]),
         "vbx_tsdf_integrate": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, f32p, u8p,
                                          C.c_size_t, C.c_int]),
         "vbx_tsdf_integrate_device": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, vp, vp,

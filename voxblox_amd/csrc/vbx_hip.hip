@@ -210,6 +210,14 @@ void vbx_destroy(vbx_ctx* ctx) {
   delete ctx;
 }
 
+int vbx_get_map_cfg(vbx_ctx* ctx, vbx_map_cfg* out) {
+  if (!ctx || !out) return VBX_ERR_INVALID;
+  out->voxel_size = ctx->map.voxel_size;
+  out->voxels_per_side = (uint32_t)ctx->map.vps;
+  out->max_blocks = ctx->map.cap_blocks;
+  return VBX_OK;
+}
+
 int vbx_set_stream(vbx_ctx* ctx, void* hip_stream) {
   if (!ctx) return VBX_ERR_INVALID;
   ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;

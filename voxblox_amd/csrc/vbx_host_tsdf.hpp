@@ -643,6 +643,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     // after convergence reproduces the same state, so running past it is harmless.  Per round this
     // saves the read-back and the pipeline bubble behind it (~15-20 us of ~100).
     HIP_TRY(ctx->b_collided.ensure(vox_cap));  // outcomes by global probe index (< list entries)
+    static const uint32_t grow_mult = getenv("VBX_GROW") ? (uint32_t)atoi(getenv("VBX_GROW")) : 4u;  // experiment switch
     auto replay = [&](uint32_t a, uint32_t b, uint32_t max_rounds, uint32_t p_hint, bool* converged) -> int {
       *converged = false;
       uint32_t done = 0;  // rounds queued so far in this call
@@ -689,7 +690,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                              ctx->b_collided.as<uint8_t>());
           KLAUNCH(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
                              R, a, b, ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext,
-                             ctx->b_U.as<uint32_t>(), ctx->b_moved.as<uint8_t>(), done, ctx->d_state);
+                             ctx->b_U.as<uint32_t>(), ctx->b_moved.as<uint8_t>(), done, grow_mult, ctx->d_state);
           std::swap(Tcur, Tnext);
           ++rounds;
         }

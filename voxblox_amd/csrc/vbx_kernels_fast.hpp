@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256)
 k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R, uint32_t r_begin,
               uint32_t r_end, const uint8_t* __restrict__ collided, int max_consecutive,
               const uint32_t* __restrict__ T, uint32_t* Tnew, uint32_t* U, uint8_t* moved, uint32_t round_idx,
-              DevState* st) {
+              uint32_t grow_mult, DevState* st) {
   // rays outside [r_begin, r_end) keep their probe count (they are final, or not in play yet)
   // 16 lanes per ray: 16 outcomes per step, the consecutive-collision counter is the run length
   // of the ballot mask (as in sweep_ray)
@@ -491,7 +491,7 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
     }
   }
   if (gl == 0 && ray_ok) {
-    if (!broke && t < len) tn = min(len, max(4u * t, t + 16u));  // surplus probes vanish again next round
+    if (!broke && t < len) tn = min(len, max(grow_mult * t, t + 16u));  // surplus probes vanish again next round
     Tnew[r] = tn;
     U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
     moved[r] = (tn != t) ? 1 : 0;

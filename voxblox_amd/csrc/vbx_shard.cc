@@ -1,0 +1,243 @@
+// vbx_shard.cc — libvbx_shard.so: ray-bundle sharding over RCCL on top of the C-ABI of vbx_hip.h
+// (include/vbx_shard.h has the protocol).  Host code only: the kernels it needs (export of the touched
+// blocks' weighted sums, owner-side merge with duplicate rows) live in libvbx_hip.so.
+#include "../../include/vbx_shard.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+struct vbx_shard {
+  vbx_ctx* p = nullptr;
+  vbx_ctx* d = nullptr;
+  int rank = 0, world = 1, device = 0;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  size_t nvox = 4096;
+  float* d_send = nullptr;
+  float* d_recv = nullptr;
+  size_t send_cap = 0, recv_cap = 0;  // rows
+  int32_t* d_keys_send = nullptr;
+  int32_t* d_keys_recv = nullptr;
+  size_t ks_cap = 0, kr_cap = 0;      // rows
+  unsigned long long* d_counts = nullptr;  // world*world
+  vbx_shard_stats stats{};
+  std::string err;
+  void fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+  }
+};
+
+namespace {
+thread_local std::string g_err;
+
+#define HIPS(expr)                                                                  \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      s->fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return VBX_ERR_HIP;                                                           \
+    }                                                                               \
+  } while (0)
+#define NCCLS(expr)                                                                 \
+  do {                                                                              \
+    ncclResult_t _e = (expr);                                                       \
+    if (_e != ncclSuccess) {                                                        \
+      s->fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_e), __FILE__, __LINE__); \
+      return VBX_ERR_HIP;                                                           \
+    }                                                                               \
+  } while (0)
+#define VBXS(ctx, expr)                                       \
+  do {                                                        \
+    int _rc = (expr);                                         \
+    if (_rc != VBX_OK) {                                      \
+      s->fail("%s: %s", #expr, vbx_last_error(ctx));          \
+      return _rc;                                             \
+    }                                                         \
+  } while (0)
+
+template <typename T>
+int grow(vbx_shard* s, T** p, size_t* cap, size_t want, size_t elems_per_row) {
+  if (want <= *cap) return VBX_OK;
+  if (*p) HIPS(hipFree(*p));
+  *p = nullptr;
+  const size_t rows = std::max(want, *cap + *cap / 2 + 16);
+  HIPS(hipMalloc((void**)p, rows * elems_per_row * sizeof(T)));
+  *cap = rows;
+  return VBX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vbx_shard_owner_of(const int32_t idx[3], int world) {
+  const long long h = ((long long)idx[0] * 73856093ll) ^ ((long long)idx[1] * 19349663ll) ^ ((long long)idx[2] * 83492791ll);
+  return (int)((h & 0x7FFFFFFFll) % (long long)std::max(world, 1));
+}
+
+int vbx_shard_get_unique_id(uint8_t id[VBX_SHARD_ID_BYTES]) {
+  static_assert(VBX_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return VBX_ERR_HIP;
+  std::memcpy(id, u.internal, VBX_SHARD_ID_BYTES);
+  return VBX_OK;
+}
+
+const char* vbx_shard_last_error(vbx_shard* s) { return s ? s->err.c_str() : g_err.c_str(); }
+
+vbx_shard* vbx_shard_create(vbx_ctx* persistent, vbx_ctx* delta, int rank, int world, const uint8_t id[VBX_SHARD_ID_BYTES],
+                            int device) {
+  if (!persistent || !delta || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) {
+    g_err = "vbx_shard_create: bad argument";
+    return nullptr;
+  }
+  vbx_shard* s = new vbx_shard;
+  s->p = persistent;
+  s->d = delta;
+  s->rank = rank;
+  s->world = world;
+  s->device = device;
+  bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+  if (ok && id) {  // also with world == 1 when an id is given: the collectives then run for real on one rank
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, VBX_SHARD_ID_BYTES);
+    ok = ncclCommInitRank(&s->comm, world, u, rank) == ncclSuccess &&
+         hipMalloc((void**)&s->d_counts, (size_t)world * world * sizeof(unsigned long long)) == hipSuccess;
+  }
+  if (!ok) {
+    g_err = "vbx_shard_create: stream / RCCL communicator initialisation failed";
+    vbx_shard_destroy(s);
+    return nullptr;
+  }
+  vbx_map_cfg cp{}, cd{};
+  if (vbx_get_map_cfg(persistent, &cp) != VBX_OK || vbx_get_map_cfg(delta, &cd) != VBX_OK ||
+      cp.voxels_per_side != cd.voxels_per_side || cp.voxel_size != cd.voxel_size) {
+    g_err = "vbx_shard_create: persistent and delta map must have the same voxel size and voxels per side";
+    vbx_shard_destroy(s);
+    return nullptr;
+  }
+  s->nvox = (size_t)cp.voxels_per_side * cp.voxels_per_side * cp.voxels_per_side;
+  return s;
+}
+
+void vbx_shard_destroy(vbx_shard* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->comm) (void)ncclCommDestroy(s->comm);
+  for (void* q : {(void*)s->d_send, (void*)s->d_recv, (void*)s->d_keys_send, (void*)s->d_keys_recv, (void*)s->d_counts})
+    if (q) (void)hipFree(q);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int vbx_shard_begin_step(vbx_shard* s) {
+  if (!s) return VBX_ERR_INVALID;
+  VBXS(s->d, vbx_clear(s->d, VBX_LAYER_TSDF));
+  return VBX_OK;
+}
+
+int vbx_shard_integrate(vbx_shard* s, int kind, const vbx_tsdf_cfg* cfg, const float pos[3], const float quat[4],
+                        const float* d_points_C, const uint8_t* d_rgba, size_t n, int freespace_points) {
+  if (!s) return VBX_ERR_INVALID;
+  VBXS(s->d, vbx_tsdf_integrate_device(s->d, kind, cfg, pos, quat, d_points_C, d_rgba, n, freespace_points));
+  return VBX_OK;
+}
+
+int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, float max_weight) {
+  if (!s) return VBX_ERR_INVALID;
+  HIPS(hipSetDevice(s->device));
+  // 1. the blocks this step's deltas touched, grouped by owner, (z,y,x) order inside a group
+  size_t n = 0;
+  VBXS(s->d, vbx_num_blocks(s->d, VBX_LAYER_TSDF, &n));
+  std::vector<int32_t> idx(3 * std::max<size_t>(n, 1));
+  if (n) VBXS(s->d, vbx_block_indices(s->d, VBX_LAYER_TSDF, idx.data(), n, &n));  // ascending (z,y,x)
+  const int W = s->world;
+  std::vector<int> owner(n);
+  std::vector<size_t> send_counts(W, 0);
+  for (size_t i = 0; i < n; ++i) {
+    owner[i] = vbx_shard_owner_of(&idx[3 * i], W);
+    ++send_counts[owner[i]];
+  }
+  std::vector<size_t> sdispl(W + 1, 0);
+  for (int r = 0; r < W; ++r) sdispl[r + 1] = sdispl[r] + send_counts[r];
+  std::vector<int32_t> send_keys(3 * std::max<size_t>(n, 1));
+  {
+    std::vector<size_t> cur(sdispl.begin(), sdispl.end() - 1);
+    for (size_t i = 0; i < n; ++i) {  // stable: the (z,y,x) order survives inside every group
+      const size_t at = cur[owner[i]]++;
+      std::memcpy(&send_keys[3 * at], &idx[3 * i], 12);
+    }
+  }
+  // 2. their weighted sums, in the same order
+  const size_t nvox = s->nvox;
+  int rc = grow(s, &s->d_send, &s->send_cap, n, 6 * nvox);
+  if (rc) return rc;
+  if (n) VBXS(s->d, vbx_blocks_export_sums(s->d, send_keys.data(), n, s->d_send));
+  const float* d_in = s->d_send;
+  std::vector<int32_t> recv_keys;
+  size_t n_recv = n;
+  if (!s->comm) {
+    recv_keys = send_keys;
+  } else {
+    // 3. group sizes: all-gather of every rank's send_counts row -> counts[sender][dest]
+    std::vector<unsigned long long> row(W);
+    for (int r = 0; r < W; ++r) row[r] = send_counts[r];
+    HIPS(hipMemcpyAsync(s->d_counts + (size_t)s->rank * W, row.data(), W * sizeof(unsigned long long), hipMemcpyHostToDevice, s->stream));
+    NCCLS(ncclAllGather(s->d_counts + (size_t)s->rank * W, s->d_counts, W, ncclUint64, s->comm, s->stream));
+    std::vector<unsigned long long> all((size_t)W * W);
+    HIPS(hipMemcpyAsync(all.data(), s->d_counts, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIPS(hipStreamSynchronize(s->stream));
+    std::vector<size_t> recv_counts(W), rdispl(W + 1, 0);
+    for (int r = 0; r < W; ++r) {
+      recv_counts[r] = (size_t)all[(size_t)r * W + s->rank];
+      rdispl[r + 1] = rdispl[r] + recv_counts[r];
+    }
+    n_recv = rdispl[W];
+    // 4. BlockIndex rows, then the sums: sparse all-to-all-v (rows arrive grouped by sender rank)
+    rc = grow(s, &s->d_keys_send, &s->ks_cap, n, 3);
+    if (rc) return rc;
+    rc = grow(s, &s->d_keys_recv, &s->kr_cap, n_recv, 3);
+    if (rc) return rc;
+    rc = grow(s, &s->d_recv, &s->recv_cap, n_recv, 6 * nvox);
+    if (rc) return rc;
+    if (n) HIPS(hipMemcpyAsync(s->d_keys_send, send_keys.data(), n * 12, hipMemcpyHostToDevice, s->stream));
+    std::vector<size_t> sc(W), sd(W), rcn(W), rd(W);
+    for (int r = 0; r < W; ++r) { sc[r] = send_counts[r] * 3; sd[r] = sdispl[r] * 3; rcn[r] = recv_counts[r] * 3; rd[r] = rdispl[r] * 3; }
+    NCCLS(ncclAllToAllv(s->d_keys_send, sc.data(), sd.data(), s->d_keys_recv, rcn.data(), rd.data(), ncclInt32, s->comm, s->stream));
+    const size_t row_f = 6 * nvox;
+    for (int r = 0; r < W; ++r) { sc[r] = send_counts[r] * row_f; sd[r] = sdispl[r] * row_f; rcn[r] = recv_counts[r] * row_f; rd[r] = rdispl[r] * row_f; }
+    NCCLS(ncclAllToAllv(s->d_send, sc.data(), sd.data(), s->d_recv, rcn.data(), rd.data(), ncclFloat32, s->comm, s->stream));
+    recv_keys.resize(3 * std::max<size_t>(n_recv, 1));
+    if (n_recv) HIPS(hipMemcpyAsync(recv_keys.data(), s->d_keys_recv, n_recv * 12, hipMemcpyDeviceToHost, s->stream));
+    HIPS(hipStreamSynchronize(s->stream));
+    d_in = s->d_recv;
+  }
+  // 5. owner merge: rows of one block are added in (sender rank, key) order, then merged once
+  if (n_recv) VBXS(s->p, vbx_blocks_merge_sums(s->p, recv_keys.data(), n_recv, d_in, apply_caps, truncation_distance, max_weight));
+  ++s->stats.steps;
+  s->stats.sent_blocks += n;
+  s->stats.received_blocks += n_recv;
+  s->stats.payload_bytes += (uint64_t)n * 6 * nvox * 4;
+  return VBX_OK;
+}
+
+int vbx_shard_get_stats(vbx_shard* s, vbx_shard_stats* out) {
+  if (!s || !out) return VBX_ERR_INVALID;
+  *out = s->stats;
+  return VBX_OK;
+}
+
+}  // extern "C"

@@ -271,6 +271,33 @@ class TsdfIntegratorBase {  // tsdf_integrator.h:51-198
   virtual void integratePointCloud(const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors,
                                    const bool freespace_points = false) = 0;
   const Config& getConfig() const { return config_; }
+  /// Config -> the C-ABI's plain struct (same fields, include/vbx_hip.h)
+  static vbx_tsdf_cfg toC(const Config& config) {
+    vbx_tsdf_cfg c;
+    vbx_tsdf_cfg_default(&c);
+    c.default_truncation_distance = config.default_truncation_distance;
+    c.max_weight = config.max_weight;
+    c.voxel_carving_enabled = config.voxel_carving_enabled;
+    c.min_ray_length_m = config.min_ray_length_m;
+    c.max_ray_length_m = config.max_ray_length_m;
+    c.use_const_weight = config.use_const_weight;
+    c.allow_clear = config.allow_clear;
+    c.use_weight_dropoff = config.use_weight_dropoff;
+    c.use_sparsity_compensation_factor = config.use_sparsity_compensation_factor;
+    c.sparsity_compensation_factor = config.sparsity_compensation_factor;
+    c.integrator_threads = static_cast<int32_t>(config.integrator_threads);
+    if (config.integration_order_mode == "mixed") c.integration_order_mode = 0;
+    else if (config.integration_order_mode == "sorted") c.integration_order_mode = 1;
+    else VBX_CHECK(false, "Unknown integration order mode");  // integrator_utils.cc:12
+    c.enable_anti_grazing = config.enable_anti_grazing;
+    c.start_voxel_subsampling_factor = config.start_voxel_subsampling_factor;
+    c.max_consecutive_ray_collisions = config.max_consecutive_ray_collisions;
+    c.clear_checks_every_n_frames = config.clear_checks_every_n_frames;
+    c.max_integration_time_s = config.max_integration_time_s;
+    c.merged_bundle_order = config.merged_bundle_order;
+    c.fast_observed_set = config.fast_observed_set;
+    return c;
+  }
   void setLayer(Layer<TsdfVoxel>* layer) {  // tsdf_integrator.cc:68-80
     VBX_CHECK(layer != nullptr, "layer");
     layer_ = layer;
@@ -280,29 +307,7 @@ class TsdfIntegratorBase {  // tsdf_integrator.h:51-198
   void integrate(int kind, const Transformation& T_G_C, const Pointcloud& points_C, const Colors& colors,
                  bool freespace_points) {
     VBX_CHECK(points_C.size() == colors.size(), "points_C.size() == colors.size()");  // tsdf_integrator.cc:247
-    vbx_tsdf_cfg c;
-    vbx_tsdf_cfg_default(&c);
-    c.default_truncation_distance = config_.default_truncation_distance;
-    c.max_weight = config_.max_weight;
-    c.voxel_carving_enabled = config_.voxel_carving_enabled;
-    c.min_ray_length_m = config_.min_ray_length_m;
-    c.max_ray_length_m = config_.max_ray_length_m;
-    c.use_const_weight = config_.use_const_weight;
-    c.allow_clear = config_.allow_clear;
-    c.use_weight_dropoff = config_.use_weight_dropoff;
-    c.use_sparsity_compensation_factor = config_.use_sparsity_compensation_factor;
-    c.sparsity_compensation_factor = config_.sparsity_compensation_factor;
-    c.integrator_threads = static_cast<int32_t>(config_.integrator_threads);
-    if (config_.integration_order_mode == "mixed") c.integration_order_mode = 0;
-    else if (config_.integration_order_mode == "sorted") c.integration_order_mode = 1;
-    else VBX_CHECK(false, "Unknown integration order mode");  // integrator_utils.cc:12
-    c.enable_anti_grazing = config_.enable_anti_grazing;
-    c.start_voxel_subsampling_factor = config_.start_voxel_subsampling_factor;
-    c.max_consecutive_ray_collisions = config_.max_consecutive_ray_collisions;
-    c.clear_checks_every_n_frames = config_.clear_checks_every_n_frames;
-    c.max_integration_time_s = config_.max_integration_time_s;
-    c.merged_bundle_order = config_.merged_bundle_order;
-    c.fast_observed_set = config_.fast_observed_set;
+    const vbx_tsdf_cfg c = toC(config_);
     const DeviceMap& m = *layer_->map();
     m.check(vbx_tsdf_integrate(m.ctx(), kind, &c, &T_G_C.getPosition().x, T_G_C.getRotationWxyz().data(),
                                points_C.empty() ? nullptr : &points_C[0].x,
