@@ -38,7 +38,6 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   float* in_sdf = ctx->b_fin.as<float>();
   float* in_uw = in_sdf + total;
   uint32_t* in_col = reinterpret_cast<uint32_t*>(in_uw + total);
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->fold_long_count, 0, 4, s));
   KLAUNCH(k_fold_inputs, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c,
                      m, in_sdf, in_uw, in_col);
   KLAUNCH(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m, in_sdf,
@@ -100,7 +99,6 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
   KLAUNCH(k_ray_emit, grid_for(R), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0, limit,
                      ctx->b_off.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), graze_keys, n_graze,
                      ctx->d_state);
-  KLAUNCH(k_count_cast, grid_for(R), dim3(256), 0, s, tab.flags, R, ctx->d_state);
   tmark(ctx, 4);
   return sort_and_fold(ctx, tab, c, total);
 }
@@ -119,7 +117,7 @@ int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   tab.bkey = nullptr;
   KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
                      freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv,
-                     ctx->d_state);
+                     (uint64_t*)nullptr, (uint32_t*)nullptr, ctx->d_state);
   tmark(ctx, 1);
   return march_and_fold(ctx, tab, c, /*from_origin=*/true, nullptr, false, nullptr, 0);
 }
@@ -300,7 +298,7 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   pt.bkey = nullptr;
   KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
                      pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), order,
-                     ctx->map.voxel_size_inv, ctx->d_state);
+                     ctx->map.voxel_size_inv, (uint64_t*)nullptr, (uint32_t*)nullptr, ctx->d_state);
   // bundleRays (tsdf_integrator.cc:340-371): group points by endpoint voxel.  A stable sort
   // of (key, s) keeps each bundle's points in visiting order.
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
@@ -396,12 +394,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   if (rc) return rc;
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
-  KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
-                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv, ctx->d_state);
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
-  KLAUNCH(k_fast_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, c,
-                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
+  KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
+                     pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv,
+                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>(), ctx->d_state);
   // keys[s] = slot << 32 | s is written in visiting order: a stable sort on the 20 slot bits
   // (+ bit 52, set only in the all-ones key of dropped points) orders by (slot, s)
   rc = stable_sort01(ctx, n, 32, 53, true);
@@ -409,12 +406,10 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   KLAUNCH(k_fast_start_dedupe, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
                      ctx->start_offset, ctx->start_sentinel_live ? 1 : 0, pt.flags);
-  KLAUNCH(k_fast_start_commit, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                     ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
-                     ctx->start_offset, ctx->d_state);
   HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
-  KLAUNCH(k_compact_flags, grid_for(n + 1), dim3(256), 0, s, pt.flags, (uint32_t)n,
-                     ctx->b_head.as<uint32_t>());
+  KLAUNCH(k_fast_start_commit_and_flags, grid_for(n + 1), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
+                     ctx->b_vals1.as<uint32_t>(), (uint32_t)n, ctx->b_startset.as<uint32_t>(),
+                     ctx->start_offset, pt.flags, ctx->b_head.as<uint32_t>(), ctx->d_state);
   rc = exclusive_scan_u32(ctx, ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), n + 1);
   if (rc) return rc;
   rc = ensure_tab(ctx, true, n, false);
@@ -555,7 +550,6 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           sa.ch_wr = chs[ch_flip ^ 1];
           sa.tag_rd = tag_rd;
           sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
-          if (writes_list && !have_list) HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[sa.cnt_out], 0, 4, s));
           if (iters == 0)
             KLAUNCH(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
           else if (n_open <= 8192)  // few open rays: a whole wave per ray (64 list entries per step)
@@ -628,7 +622,6 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     uint32_t* Tnext = ctx->b_TH.as<uint32_t>();
     uint32_t* poff = ctx->b_cnt.as<uint32_t>();
     HIP_TRY(ctx->b_moved.ensure((size_t)R + 1));
-    HIP_TRY(hipMemsetAsync(Tcur + R, 0, 4, s));
     HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
     uint32_t rounds = 0;
     static const bool dbg = getenv("VBX_DEBUG") != nullptr;
@@ -802,7 +795,6 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   if (strict_set && ctx->h_state.sentinel_cleared) ctx->obsset_sentinel_live = false;
   ctx->counters.iterations = iters_total;
   tmark(ctx, 3);
-  KLAUNCH(k_count_cast, grid_for(R), dim3(256), 0, s, kt.flags, R, ctx->d_state);
   if (total == 0) return VBX_OK;
   HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
   HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));

@@ -5,22 +5,7 @@ namespace {
 // ---------------------------------------------------------------------------
 // kernels: Fast integrator (tsdf_integrator.cc:488-590)
 // ---------------------------------------------------------------------------
-// start_voxel_approx_set_.replaceHash(cell at start_voxel_subsampling_factor x resolution),
-// tsdf_integrator.cc:514-519.  key = slot << 32 | s so that a stable radix sort groups the
-// probes of one ApproxHashSet slot in visiting order; val = the 32-bit hash.
-__global__ void k_fast_keys(RayTab pt, uint32_t n, CastCfg c, uint64_t* keys, uint32_t* vals) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  uint64_t key = ~0ull;
-  uint32_t h = 0;
-  if (pt.flags[s] & 1) {
-    const l3 g = grid_index_from_point({pt.px[s], pt.py[s], pt.pz[s]}, c.start_factor_times_inv);
-    h = long_index_hash(g);
-    key = ((uint64_t)(h & 0xFFFFFu) << 32) | s;
-  }
-  keys[s] = key;
-  vals[s] = h;
-}
+// (the start-voxel keys are written by k_prep_points)
 
 // Exact replay of ApproxHashSet<20,10000>::replaceHash over the sorted probes
 // (approx_hash_array.h:125-134): a probe "replaces" iff the value it finds in its slot —
@@ -48,14 +33,17 @@ __global__ void k_fast_start_dedupe(const uint64_t* __restrict__ keys,
   }
   if (!replaced) flags_by_s[s] &= ~1;  // `continue` at tsdf_integrator.cc:517-519
 }
-// Second half of the replay: the last probe of every slot leaves its hash in the set
-// (separate launch so that no thread can read a slot after this frame has written it).
-__global__ void k_fast_start_commit(const uint64_t* __restrict__ keys,
-                                    const uint32_t* __restrict__ vals, uint32_t n,
-                                    uint32_t* set_vals, uint32_t offset, DevState* st) {
+// Second half of the replay: the last probe of every slot leaves its hash in the set (separate launch
+// so that no thread can read a slot after this frame has written it) — and, per point, the keep flag of
+// the rays that survived the start-voxel test (compaction keeps visiting order).
+__global__ void k_fast_start_commit_and_flags(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                              uint32_t n, uint32_t* set_vals, uint32_t offset,
+                                              const uint8_t* __restrict__ flags, uint32_t* keep, DevState* st) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  keep[i] = (i < n && (flags[i] & 1)) ? 1u : 0u;  // indexed by visiting position s
   if (i >= n) return;
-  const uint64_t key = keys[i];
+  const uint64_t key = keys[i];                   // indexed by sorted position
   if (key == ~0ull) return;
   const uint32_t slot = (uint32_t)(key >> 32);
   const bool last = (i + 1 >= n) || ((uint32_t)(keys[i + 1] >> 32) != slot);
@@ -63,13 +51,6 @@ __global__ void k_fast_start_commit(const uint64_t* __restrict__ keys,
     set_vals[slot + offset] = vals[i];
     if (slot + offset == 0) st->sentinel_cleared = 1;
   }
-}
-
-// Compacts the rays that survive the start-voxel test, keeping visiting order.
-__global__ void k_compact_flags(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* keep) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > n) return;
-  keep[s] = (s < n && (flags[s] & 1)) ? 1u : 0u;
 }
 __global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
                                const uint32_t* __restrict__ pos, uint32_t n, RayTab out,
@@ -364,7 +345,10 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
   // the counter after the output one is the NEXT launch's output: zero it here
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st->act_count[(a.cnt_out + 1) % 3] = 0;
-    if (a.init) a.U[R] = 0;  // terminator of the exclusive scan over U
+    if (a.init) {  // terminators of the exclusive scans over U and T
+      a.U[R] = 0;
+      a.TL[R] = 0;
+    }
     if (a.list_in && n_in == 0) atomicMax(&st->fast_idle_sweep, 0xFFFFFFFFu - a.sweep_idx);
   }
   const bool open = sweep_ray<G, false>(a, ray_ok, r, grp, gl);

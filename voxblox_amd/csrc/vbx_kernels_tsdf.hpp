@@ -47,7 +47,7 @@ __global__ void k_sorted_inverse(const uint64_t* __restrict__ keys, size_t n, ui
 __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __restrict__ rgba,
                               size_t n, Pose T, CastCfg c, int freespace, RayTab tab,
                               float* pcx, float* pcy, float* pcz, const uint32_t* __restrict__ s_of_p,
-                              float voxel_size_inv, DevState* st) {
+                              float voxel_size_inv, uint64_t* fast_keys, uint32_t* fast_vals, DevState* st) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const size_t s = s_of_p ? (size_t)s_of_p[p] : mixed_index_inverse(p, n);
@@ -64,25 +64,34 @@ __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __r
   if (valid) {
     // voxel and block keys pack 21 bits per axis (pack_block_key and the voxel keys of the
     // bundle / emit kernels): a ray that leaves +-2^20 voxels fails the call instead of aliasing
+    // (a clearing ray is cut to max_ray_length_m from the sensor, integrator_utils.cc:80-86: a far no-return
+    // sentinel is as harmless as in the reference, what counts is where the sensor is)
     const float lim = 1048576.0f - (c.trunc + c.max_ray_length_m) * voxel_size_inv - 8.0f;
-    const float far = fmaxf(fmaxf(fabsf(pg.x), fabsf(pg.y)), fabsf(pg.z)) * voxel_size_inv;
+    const f3 q = clearing ? c.origin : pg;
+    const float far = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) * voxel_size_inv;
     if (far >= lim && far < __builtin_inff()) {  // non-finite points are dropped further down
       atomicOr(&st->error, 8u);
       tab.flags[s] = 0;  // nothing of it is integrated; the call reports VBX_ERR_INVALID
     }
+  }
+  if (fast_keys) {
+    // Fast: start_voxel_approx_set_.replaceHash(cell at start_voxel_subsampling_factor x resolution),
+    // tsdf_integrator.cc:514-519.  key = slot << 32 | s so that a stable radix sort groups the probes of one
+    // ApproxHashSet slot in visiting order; val = the 32-bit hash.
+    uint64_t key = ~0ull;
+    uint32_t h = 0;
+    if (tab.flags[s] & 1) {
+      h = long_index_hash(grid_index_from_point(pg, c.start_factor_times_inv));
+      key = ((uint64_t)(h & 0xFFFFFu) << 32) | (uint64_t)s;
+    }
+    fast_keys[s] = key;
+    fast_vals[s] = h;
   }
   if (pcx) {  // Merged keeps point_C for the bundle mean
     pcx[s] = pc.x;
     pcy[s] = pc.y;
     pcz[s] = pc.z;
   }
-}
-
-// number of rows with the cast flag set (one atomic per workgroup)
-__global__ void k_count_cast(const uint8_t* __restrict__ flags, uint32_t n, DevState* st) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = __syncthreads_count(i < n && (flags[i] & 1));
-  if (threadIdx.x == 0 && c) atomicAdd(&st->rays_cast, (unsigned long long)c);
 }
 
 // ---------------------------------------------------------------------------
@@ -105,7 +114,9 @@ __global__ void k_ray_count(RayTab tab, CastCfg c, MapDev m, int from_origin,
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   RayCaster rc;
   uint32_t n = 0;
+  bool cast = false;
   if (o < tab.R && ray_init(rc, tab, o, c, m, from_origin != 0, nullptr)) {
+    cast = true;
     n = (rc.cur == 0) ? rc.steps + 1 : 0;
     if (limit) n = min(n, limit[o]);
   }
@@ -115,6 +126,9 @@ __global__ void k_ray_count(RayTab tab, CastCfg c, MapDev m, int from_origin,
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
   if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&st->total_keys, sum);
+  // rays actually cast (the counter of vbx_get_counters): one atomic per wave
+  const unsigned long long casts = __popcll(__ballot(cast));
+  if ((threadIdx.x & 63) == 0 && casts) atomicAdd(&st->rays_cast, casts);
 }
 
 // Walks every ray and makes sure each block it crosses has a pool slot
