@@ -294,7 +294,13 @@ def cpu_mesh_baseline(frames, kind, voxel):
 # per-kernel table -> roofline
 # ------------------------------------------------------------------------------------------------
 def kernel_table(gm, calls_per_step=1.0):
-    tab, calls = gm.profile_table()
+    raw, calls = gm.profile_table()
+    tab = {}
+    for k, (n, ms) in raw.items():      # template instances of one kernel count as that kernel (as rocprofv3 --stats
+        k = k.split("<")[0]             # summaries do once aggregated by name)
+        a = tab.setdefault(k, [0, 0.0])
+        a[0] += n
+        a[1] += ms
     steps = max(calls / calls_per_step, 1e-9)
     rows = [{"kernel": k, "launches_per_step": round(n / steps, 2), "avg_us": round(1e3 * ms / n, 2),
              "us_per_step": round(1e3 * ms / steps, 1)} for k, (n, ms) in tab.items() if n]

@@ -64,8 +64,13 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
 
   HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
+  // 32-bit key offsets: rays x (longest possible path) below 2^32 cannot wrap; only beyond that is the
+  // exact 64-bit total worth its atomics
+  const double seg_len = (double)c.max_ray_length_m + (double)c.trunc;
+  const double per_ray_bound = 1.7320508075688772 * seg_len * (double)m.voxel_size_inv + 6.0;
+  const bool may_wrap = (double)R * per_ray_bound > 4.0e9;
   KLAUNCH(k_ray_count, grid_for(R + 1), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0,
-                     limit, ctx->b_cnt.as<uint32_t>(), ctx->d_state);
+                     limit, ctx->b_cnt.as<uint32_t>(), 1 | (may_wrap ? 2 : 0), ctx->d_state);
   int rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
   uint32_t total = 0;
@@ -85,7 +90,7 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
     rc = grow_pool(ctx);  // out of slots: double the pool and mark the blocks again
     if (rc) return rc;
   }
-  if (ctx->h_state.total_keys > 0xFFFFFFF0ull) {  // the 32-bit offsets wrapped: no voxel has been written yet
+  if (may_wrap && ctx->h_state.total_keys > 0xFFFFFFF0ull) {  // the 32-bit offsets wrapped: no voxel has been written yet
     ctx->fail("cloud visits %llu voxels, more than one call can order (2^32): split the cloud",
               (unsigned long long)ctx->h_state.total_keys);
     return VBX_ERR_CAPACITY;
@@ -431,7 +436,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_cnt.ensure((size_t)(R + 1) * 4));
   HIP_TRY(ctx->b_off.ensure((size_t)(R + 1) * 4));
   KLAUNCH(k_ray_count, grid_for(R + 1), dim3(256), 0, s, kt, c, m, 0,
-                     (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>(), ctx->d_state);
+                     (const uint32_t*)nullptr, ctx->b_cnt.as<uint32_t>(), 0, ctx->d_state);
   rc = exclusive_scan_u32(ctx, ctx->b_cnt.as<uint32_t>(), ctx->b_off.as<uint32_t>(), R + 1);
   if (rc) return rc;
   // Every ray emits at most sqrt(3) * (max_ray_length + truncation) / voxel_size + 4 voxels
@@ -848,7 +853,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   if (rc) return rc;
   rc = check_state_error(ctx);
   if (rc) return rc;
-  ctx->counters.rays_cast = ctx->h_state.rays_cast;
+  ctx->counters.rays_cast = kind == VBX_TSDF_FAST ? ctx->h_state.num_kept : ctx->h_state.rays_cast;  // Fast casts every kept ray
   ctx->counters.voxels_touched = ctx->h_state.voxels_touched;
   ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
   if (ctx->timing) {

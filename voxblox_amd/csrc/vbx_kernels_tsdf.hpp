@@ -110,7 +110,7 @@ __device__ inline bool ray_init(RayCaster& rc, const RayTab& tab, uint32_t o, co
 
 // cnt[o] = number of voxel indices the ray emits (ray_length_in_steps_ + 1), or `limit[o]`.
 __global__ void k_ray_count(RayTab tab, CastCfg c, MapDev m, int from_origin,
-                            const uint32_t* __restrict__ limit, uint32_t* cnt, DevState* st) {
+                            const uint32_t* __restrict__ limit, uint32_t* cnt, int want_totals, DevState* st) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   RayCaster rc;
   uint32_t n = 0;
@@ -121,14 +121,27 @@ __global__ void k_ray_count(RayTab tab, CastCfg c, MapDev m, int from_origin,
     if (limit) n = min(n, limit[o]);
   }
   if (o <= tab.R) cnt[o] = n;  // cnt[R] = 0 terminates the scan
-  // 64-bit total beside the 32-bit offsets: a cloud whose voxel visits do not fit 2^32 must fail, not wrap
+  if (!want_totals) return;    // (uniform: a kernel argument)
+  // rays actually cast, and — where rays x longest path could pass 2^32 — a 64-bit total beside the 32-bit
+  // offsets, so that such a cloud fails instead of wrapping.  One atomic per workgroup each: same-address
+  // atomics serialise at ~90 per microsecond, a per-wave atomic made this kernel 10x slower.
+  __shared__ unsigned long long s_sum[4];
+  __shared__ uint32_t s_cast[4];
   unsigned long long sum = n;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&st->total_keys, sum);
-  // rays actually cast (the counter of vbx_get_counters): one atomic per wave
   const unsigned long long casts = __popcll(__ballot(cast));
-  if ((threadIdx.x & 63) == 0 && casts) atomicAdd(&st->rays_cast, casts);
+  if ((threadIdx.x & 63) == 0) {
+    s_sum[threadIdx.x >> 6] = sum;
+    s_cast[threadIdx.x >> 6] = (uint32_t)casts;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    const uint32_t cc = s_cast[0] + s_cast[1] + s_cast[2] + s_cast[3];
+    if ((want_totals & 2) && t) atomicAdd(&st->total_keys, t);
+    if ((want_totals & 1) && cc) atomicAdd(&st->rays_cast, (unsigned long long)cc);
+  }
 }
 
 // Walks every ray and makes sure each block it crosses has a pool slot
