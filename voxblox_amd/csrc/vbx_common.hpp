@@ -101,6 +101,9 @@ struct DevState {
   uint32_t rp_n;             // probes of the round's ray range (device-side size of the round's sort)
   uint32_t rp_overflow;      // a round needed more probes than the batch was sized for: the rest of the batch idles
   uint32_t rp_changed_round; // 1 + index of the last round in which a probe count moved
+  int32_t bbox_min[3];       // Merged: bounding box of the cloud's endpoint voxels (k_bbox_reduce)
+  int32_t bbox_max[3];
+  uint32_t bbox_wide;        // a point whose voxel index is not usable for the box: absolute keys this frame
   uint32_t live_slots;       // k_reclaim: slots that still hold a block of either layer
   unsigned long long total_keys;
   unsigned long long voxels_touched;
@@ -153,6 +156,15 @@ struct CastCfg {  // by-value kernel argument: TsdfIntegratorBase::Config + deri
   int max_consecutive;
   float start_factor_times_inv;  // start_voxel_subsampling_factor * voxel_size_inv_
 };
+
+// Merged: bundle keys are the endpoint voxel index RELATIVE to the cloud's bounding box, packed in as many
+// bits as the box needs (a room is 7-8 bits per axis where the absolute index reserves 21), so the bundling
+// sort runs two radix passes instead of six.  Order = (clearing, z, y, x), as with the absolute keys.
+struct KeyFrame {
+  int xmin, ymin, zmin;
+  int bx, by, bz;  // bits per axis
+};
+__host__ __device__ inline int keyframe_bits(const KeyFrame& f) { return f.bx + f.by + f.bz + 1; }  // + clearing
 
 struct RayTab {  // SoA ray table indexed by integration order o
   float* px;

@@ -122,7 +122,7 @@ int integrate_simple(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   tab.bkey = nullptr;
   KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, ctx->stream, d_pts, d_rgba, n, T, c,
                      freespace, tab, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv,
-                     (uint64_t*)nullptr, (uint32_t*)nullptr, ctx->d_state);
+                     (uint64_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, ctx->d_state);
   tmark(ctx, 1);
   return march_and_fold(ctx, tab, c, /*from_origin=*/true, nullptr, false, nullptr, 0);
 }
@@ -228,7 +228,7 @@ static void unordered_iteration_order_real(const uint32_t* hashes, uint32_t n, s
   for (const auto& kv : map) out->push_back(kv.second);
 }
 
-int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t** perm_out) {
+int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const KeyFrame& kf, const uint32_t** perm_out) {
   hipStream_t s = ctx->stream;
   HIP_TRY(ctx->b_bkeys.ensure((size_t)nb * 8));   // bpack
   HIP_TRY(ctx->b_bfirst.ensure((size_t)nb * 8));  // the same in insertion order
@@ -240,7 +240,7 @@ int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const uint32_t**
   HIP_TRY(hipMemsetAsync(by_s, 0xFF, n * 4, s));
   KLAUNCH(k_merged_mark_first, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), ctx->b_head.as<uint32_t>(), ctx->b_rank.as<uint32_t>(),
-                     (uint32_t)n, by_s, ctx->b_bkeys.as<uint64_t>());
+                     (uint32_t)n, kf, by_s, ctx->b_bkeys.as<uint64_t>());
   KLAUNCH(k_merged_first_flags, grid_for(n + 1), dim3(256), 0, s, by_s, (uint32_t)n, ctx->b_off.as<uint32_t>());
   int rc = exclusive_scan_u32(ctx, ctx->b_off.as<uint32_t>(), ctx->b_T.as<uint32_t>(), n + 1);
   if (rc) return rc;
@@ -301,16 +301,30 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   HIP_TRY(ctx->b_pcx.ensure(n * 4)); HIP_TRY(ctx->b_pcy.ensure(n * 4)); HIP_TRY(ctx->b_pcz.ensure(n * 4));
   RayTab pt = make_tab(ctx, false, (uint32_t)n);
   pt.bkey = nullptr;
+  const uint32_t prep_blocks = grid_for(n).x;
+  HIP_TRY(ctx->b_bbox.ensure((size_t)prep_blocks * 6 * 4));
   KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
                      pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(), ctx->b_pcz.as<float>(), order,
-                     ctx->map.voxel_size_inv, (uint64_t*)nullptr, (uint32_t*)nullptr, ctx->d_state);
+                     ctx->map.voxel_size_inv, (uint64_t*)nullptr, (uint32_t*)nullptr, ctx->b_bbox.as<int32_t>(), ctx->d_state);
+  KLAUNCH(k_bbox_reduce, dim3(1), dim3(256), 0, s, ctx->b_bbox.as<int32_t>(), prep_blocks, ctx->d_state);
+  rc = sync_state(ctx);
+  if (rc) return rc;
   // bundleRays (tsdf_integrator.cc:340-371): group points by endpoint voxel.  A stable sort
-  // of (key, s) keeps each bundle's points in visiting order.
+  // of (key, s) keeps each bundle's points in visiting order.  Keys are relative to the cloud's bounding
+  // box: a room needs 7-8 bits per axis (two radix passes) where the absolute index takes 3 x 21 (six).
+  KeyFrame kf{-(1 << 20), -(1 << 20), -(1 << 20), 21, 21, 21};  // the absolute packing (clearing bit = bit 63)
+  if (!ctx->h_state.bbox_wide && ctx->h_state.bbox_min[0] <= ctx->h_state.bbox_max[0]) {
+    kf.xmin = ctx->h_state.bbox_min[0]; kf.ymin = ctx->h_state.bbox_min[1]; kf.zmin = ctx->h_state.bbox_min[2];
+    kf.bx = (int)bits_for((uint64_t)(ctx->h_state.bbox_max[0] - kf.xmin));
+    kf.by = (int)bits_for((uint64_t)(ctx->h_state.bbox_max[1] - kf.ymin));
+    kf.bz = (int)bits_for((uint64_t)(ctx->h_state.bbox_max[2] - kf.zmin));
+  }
   HIP_TRY(ctx->b_keys0.ensure(n * 8)); HIP_TRY(ctx->b_keys1.ensure(n * 8));
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
-  KLAUNCH(k_merged_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, ctx->map,
+  KLAUNCH(k_merged_keys, grid_for(n), dim3(256), 0, s, pt, (uint32_t)n, ctx->map, kf,
                      ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>());
-  rc = stable_sort01(ctx, n, 0, 64, true);
+  // one bit above the clearing bit: set only in the all-ones key of dropped points, which thereby sort last
+  rc = stable_sort01(ctx, n, 0, (unsigned)std::min(64, keyframe_bits(kf) + 1), true);
   if (rc) return rc;
   HIP_TRY(ctx->b_head.ensure((n + 1) * 4)); HIP_TRY(ctx->b_rank.ensure((n + 1) * 4));
   KLAUNCH(k_merged_heads, grid_for(n + 1), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
@@ -328,7 +342,7 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   RayTab bt = make_tab(ctx, true, nb);
   const uint32_t* perm = nullptr;
   if (cfg->merged_bundle_order == 0) {
-    rc = merged_reference_order(ctx, n, nb, &perm);
+    rc = merged_reference_order(ctx, n, nb, kf, &perm);
     if (rc) return rc;
   }
   HIP_TRY(ctx->b_bstart.ensure((size_t)nb * 4));
@@ -344,7 +358,7 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(),
                      ctx->b_pcz.as<float>(), gw, gx, gy, gz, gc);
   KLAUNCH(k_merged_bundle8, grid_for((size_t)nb * 8), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                     ctx->b_bstart.as<uint32_t>(), nb, (uint32_t)n, gw, gx, gy, gz, gc, T, bt,
+                     ctx->b_bstart.as<uint32_t>(), nb, (uint32_t)n, gw, gx, gy, gz, gc, T, kf, bt,
                      ctx->b_graze.as<uint64_t>(), perm);
   tmark(ctx, 1);
   // Non-clearing bundles sort before clearing ones (bit 63), so the graze key list is the
@@ -403,7 +417,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_vals0.ensure(n * 4)); HIP_TRY(ctx->b_vals1.ensure(n * 4));
   KLAUNCH(k_prep_points, grid_for(n), dim3(256), 0, s, d_pts, d_rgba, n, T, c, freespace,
                      pt, (float*)nullptr, (float*)nullptr, (float*)nullptr, order, ctx->map.voxel_size_inv,
-                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>(), ctx->d_state);
+                     ctx->b_keys0.as<uint64_t>(), ctx->b_vals0.as<uint32_t>(), (int32_t*)nullptr, ctx->d_state);
   // keys[s] = slot << 32 | s is written in visiting order: a stable sort on the 20 slot bits
   // (+ bit 52, set only in the all-ones key of dropped points) orders by (slot, s)
   rc = stable_sort01(ctx, n, 32, 53, true);

@@ -39,6 +39,9 @@ __global__ void k_reset_call_state(DevState* st) {
   st->fold_long_count = 0;
   st->fast_idle_sweep = 0;
   st->redo_count = 0;
+  st->bbox_min[0] = st->bbox_min[1] = st->bbox_min[2] = 0x7FFFFFFF;
+  st->bbox_max[0] = st->bbox_max[1] = st->bbox_max[2] = -0x7FFFFFFF;
+  st->bbox_wide = 0;
   st->rp_n = 0;
   st->rp_overflow = 0;
   st->rp_changed_round = 0;

@@ -47,8 +47,51 @@ __global__ void k_sorted_inverse(const uint64_t* __restrict__ keys, size_t n, ui
 __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __restrict__ rgba,
                               size_t n, Pose T, CastCfg c, int freespace, RayTab tab,
                               float* pcx, float* pcy, float* pcz, const uint32_t* __restrict__ s_of_p,
-                              float voxel_size_inv, uint64_t* fast_keys, uint32_t* fast_vals, DevState* st) {
+                              float voxel_size_inv, uint64_t* fast_keys, uint32_t* fast_vals, int32_t* bbox_partial,
+                              DevState* st) {
   const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (bbox_partial) {
+    // Merged: bounding box of the endpoint voxels (bundleRays' keys, tsdf_integrator.cc:359-361), one
+    // partial result per workgroup; k_bbox_reduce folds them
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {-0x7FFFFFFF, -0x7FFFFFFF, -0x7FFFFFFF};
+    if (p < n) {
+      const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+      bool clearing = false;
+      if (point_valid(c, pc, freespace != 0, &clearing)) {
+        const f3 pg = pose_transform(T, pc);
+        const float far = fabsf(pg.x) + fabsf(pg.y) + fabsf(pg.z);  // NaN / inf in any component propagates
+        if (far * voxel_size_inv < 1048000.0f) {
+          const l3 g = grid_index_from_point(pg, voxel_size_inv);
+          lo[0] = hi[0] = (int)g.x; lo[1] = hi[1] = (int)g.y; lo[2] = hi[2] = (int)g.z;
+        } else {
+          // a non-finite point (the reference never sees one: conversions.h:135-137; the oracle lets it form a
+          // bundle that casts nothing) or one beyond the key range: its voxel index is garbage and
+          // must not stretch the box — the frame falls back to the absolute 3 x 21-bit keys, under which such a
+          // point makes exactly the bundle it made before the keys became box-relative
+          st->bbox_wide = 1;
+        }
+      }
+    }
+    __shared__ int s_lo[4][3], s_hi[4][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        lo[a] = min(lo[a], __shfl_xor(lo[a], d));
+        hi[a] = max(hi[a], __shfl_xor(hi[a], d));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6][a] = lo[a];
+        s_hi[threadIdx.x >> 6][a] = hi[a];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      const int a = threadIdx.x;
+      bbox_partial[6 * blockIdx.x + a] = min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a]));
+      bbox_partial[6 * blockIdx.x + 3 + a] = max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a]));
+    }
+  }
   if (p >= n) return;
   const size_t s = s_of_p ? (size_t)s_of_p[p] : mixed_index_inverse(p, n);
   const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
@@ -479,18 +522,59 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
 // ---------------------------------------------------------------------------
 // kernels: Merged integrator bundling (tsdf_integrator.cc:340-407)
 // ---------------------------------------------------------------------------
-// key[s] = clearing << 63 | packed endpoint voxel index; invalid points sort last.
-__global__ void k_merged_keys(RayTab pt, uint32_t n, MapDev m, uint64_t* keys, uint32_t* vals) {
+// One workgroup folds the per-workgroup boxes of k_prep_points into DevState::bbox_min / bbox_max.
+__global__ void k_bbox_reduce(const int32_t* __restrict__ partial, uint32_t nblocks, DevState* st) {
+  int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {-0x7FFFFFFF, -0x7FFFFFFF, -0x7FFFFFFF};
+  for (uint32_t b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = min(lo[a], partial[6 * b + a]);
+      hi[a] = max(hi[a], partial[6 * b + 3 + a]);
+    }
+  __shared__ int s_lo[4][3], s_hi[4][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], d));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], d));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_lo[threadIdx.x >> 6][a] = lo[a];
+      s_hi[threadIdx.x >> 6][a] = hi[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    st->bbox_min[a] = min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a]));
+    st->bbox_max[a] = max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a]));
+  }
+}
+
+// Bundle key of an endpoint voxel relative to the cloud's bounding box (KeyFrame): clearing bit on top, then
+// z, y, x; invalid points (all ones) sort last.  merged_key_voxel / merged_key_packed undo it.
+__device__ inline uint64_t merged_key(const KeyFrame& f, const l3& g, bool clearing) {
+  uint64_t k = (uint64_t)(g.x - f.xmin) | ((uint64_t)(g.y - f.ymin) << f.bx) | ((uint64_t)(g.z - f.zmin) << (f.bx + f.by));
+  if (clearing) k |= 1ull << (f.bx + f.by + f.bz);
+  return k;
+}
+__device__ inline bool merged_key_clearing(const KeyFrame& f, uint64_t k) { return ((k >> (f.bx + f.by + f.bz)) & 1ull) != 0; }
+__device__ inline l3 merged_key_voxel(const KeyFrame& f, uint64_t k) {
+  return {(long long)(k & ((1ull << f.bx) - 1ull)) + f.xmin, (long long)((k >> f.bx) & ((1ull << f.by) - 1ull)) + f.ymin,
+          (long long)((k >> (f.bx + f.by)) & ((1ull << f.bz) - 1ull)) + f.zmin};
+}
+// the voxel in the 3 x 21-bit packing the ray march compares against (anti-grazing, k_ray_emit)
+__device__ inline uint64_t merged_key_packed(const KeyFrame& f, uint64_t k) {
+  const l3 g = merged_key_voxel(f, k);
+  return ((uint64_t)(g.z + (1ll << 20)) << 42) | ((uint64_t)(g.y + (1ll << 20)) << 21) | (uint64_t)(g.x + (1ll << 20));
+}
+__global__ void k_merged_keys(RayTab pt, uint32_t n, MapDev m, KeyFrame f, uint64_t* keys, uint32_t* vals) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const uint8_t fl = pt.flags[s];
   uint64_t key = ~0ull;
-  if (fl & 1) {
-    const l3 g = grid_index_from_point({pt.px[s], pt.py[s], pt.pz[s]}, m.voxel_size_inv);
-    key = ((uint64_t)(g.z + (1ll << 20)) << 42) | ((uint64_t)(g.y + (1ll << 20)) << 21) |
-          (uint64_t)(g.x + (1ll << 20));
-    if (fl & 2) key |= 1ull << 63;
-  }
+  if (fl & 1) key = merged_key(f, grid_index_from_point({pt.px[s], pt.py[s], pt.pz[s]}, m.voxel_size_inv), (fl & 2) != 0);
   keys[s] = key;
   vals[s] = s;
 }
@@ -538,7 +622,7 @@ __global__ void k_merged_gather(const uint64_t* __restrict__ keys, const uint32_
 __global__ void k_merged_bundle8(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ bstart, uint32_t nb,
                                  uint32_t n, const float* __restrict__ gw, const float* __restrict__ gx,
                                  const float* __restrict__ gy, const float* __restrict__ gz,
-                                 const uint32_t* __restrict__ gc, Pose T, RayTab out, uint64_t* graze_keys,
+                                 const uint32_t* __restrict__ gc, Pose T, KeyFrame kf, RayTab out, uint64_t* graze_keys,
                                  const uint32_t* __restrict__ perm) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t br = t >> 3;  // rank in ascending key order
@@ -547,7 +631,7 @@ __global__ void k_merged_bundle8(const uint64_t* __restrict__ keys, const uint32
   const bool live = br < nb;
   const uint32_t i0 = live ? bstart[br] : 0u;
   const uint64_t key = live ? keys[i0] : ~0ull;
-  const bool clearing = (key >> 63) != 0;
+  const bool clearing = live && merged_key_clearing(kf, key);
   float m = 0.0f;   // lanes 0-2: mean coordinate; lanes 3-6: colour channel r, g, b, a as a float
   float mw = 0.0f;
   bool more = live;
@@ -597,8 +681,9 @@ __global__ void k_merged_bundle8(const uint64_t* __restrict__ keys, const uint32
   out.rgba[b] = cr | (cg << 8) | (cb << 16) | (ca << 24);
   out.w[b] = mw;
   out.flags[b] = 1 | (clearing ? 2 : 0);
-  out.bkey[b] = key & ~(1ull << 63);
-  if (!clearing && graze_keys) graze_keys[br] = key;  // stays sorted: binary-searched by the march
+  const uint64_t packed = merged_key_packed(kf, key);
+  out.bkey[b] = packed;
+  if (!clearing && graze_keys) graze_keys[br] = packed;  // (z,y,x) order either way: stays sorted for the march's binary search
 }
 
 // The order in which bundleRays inserts the bundle keys into its unordered_map = ascending visiting
@@ -606,15 +691,15 @@ __global__ void k_merged_bundle8(const uint64_t* __restrict__ keys, const uint32
 // visiting position s (else ~0); bpack[b] = clearing << 63 | b << 32 | LongIndexHash(voxel).
 __global__ void k_merged_mark_first(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                     const uint32_t* __restrict__ head, const uint32_t* __restrict__ rank, uint32_t n,
-                                    uint32_t* by_s, uint64_t* bpack) {
+                                    KeyFrame kf, uint32_t* by_s, uint64_t* bpack) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !head[i]) return;
   const uint32_t b = rank[i];
   const uint64_t k = keys[i];
   by_s[vals[i]] = b;
-  const l3 g{(long long)(k & 0x1FFFFFu) - (1ll << 20), (long long)((k >> 21) & 0x1FFFFFu) - (1ll << 20),
-             (long long)((k >> 42) & 0x1FFFFFu) - (1ll << 20)};
-  bpack[b] = (k & (1ull << 63)) | ((uint64_t)b << 32) | (uint64_t)long_index_hash(g);  // block_hash.h:54-64
+  const l3 g = merged_key_voxel(kf, k);
+  bpack[b] = (merged_key_clearing(kf, k) ? (1ull << 63) : 0ull) | ((uint64_t)b << 32) |
+             (uint64_t)long_index_hash(g);  // block_hash.h:54-64
 }
 __global__ void k_merged_first_flags(const uint32_t* __restrict__ by_s, uint32_t n, uint32_t* f) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
