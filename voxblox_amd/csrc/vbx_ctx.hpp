@@ -26,6 +26,8 @@ struct vbx_ctx {
   DBuf b_pts, b_cols;                                   // staged host input
   DBuf t_px, t_py, t_pz, t_rgba, t_w, t_flags, t_bkey;  // ray table A (per point, order s)
   DBuf u_px, u_py, u_pz, u_rgba, u_w, u_flags, u_bkey;  // ray table B (bundles / kept rays)
+  DBuf w_px, w_py, w_pz, w_rgba, w_w, w_flags, w_bkey;  // ray table C (Merged: bundles in key order, before the order permutation)
+  hipEvent_t ev_copy = nullptr;  // Merged: the insertion-order list has reached the host
   DBuf b_pcx, b_pcy, b_pcz;                             // Merged: point_C per s
   DBuf b_cnt, b_off, b_keys0, b_keys1, b_vals0, b_vals1, b_tmp, b_head, b_rank, b_graze;
   DBuf b_fin;  // per-update fold inputs (sdf, weight, colour) in sorted key order

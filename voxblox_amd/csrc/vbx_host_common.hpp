@@ -156,6 +156,22 @@ int grow_pool(vbx_ctx* ctx) {
   return VBX_OK;
 }
 
+RayTab make_tab_c(vbx_ctx* ctx, uint32_t R) {  // table C
+  RayTab t;
+  t.px = ctx->w_px.as<float>(); t.py = ctx->w_py.as<float>(); t.pz = ctx->w_pz.as<float>();
+  t.rgba = ctx->w_rgba.as<uint32_t>(); t.w = ctx->w_w.as<float>();
+  t.flags = ctx->w_flags.as<uint8_t>(); t.bkey = ctx->w_bkey.as<uint64_t>();
+  t.R = R;
+  return t;
+}
+int ensure_tab_c(vbx_ctx* ctx, size_t R) {
+  const size_t n = R + 1;
+  HIP_TRY(ctx->w_px.ensure(n * 4)); HIP_TRY(ctx->w_py.ensure(n * 4)); HIP_TRY(ctx->w_pz.ensure(n * 4));
+  HIP_TRY(ctx->w_rgba.ensure(n * 4)); HIP_TRY(ctx->w_w.ensure(n * 4)); HIP_TRY(ctx->w_flags.ensure(n));
+  HIP_TRY(ctx->w_bkey.ensure(n * 8));
+  return VBX_OK;
+}
+
 RayTab make_tab(vbx_ctx* ctx, bool second, uint32_t R) {
   RayTab t;
   if (!second) {

@@ -228,7 +228,10 @@ static void unordered_iteration_order_real(const uint32_t* hashes, uint32_t n, s
   for (const auto& kv : map) out->push_back(kv.second);
 }
 
-int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const KeyFrame& kf, const uint32_t** perm_out) {
+// Two halves: _begin queues the device part and the copy of the insertion-order list to the host; _finish waits
+// for that copy, replays the hashtable and uploads the permutation.  The caller queues the bundle fold in
+// between, so the GPU folds while the host reconstructs the order (~0.18 ms each, formerly one after the other).
+int merged_reference_order_begin(vbx_ctx* ctx, size_t n, uint32_t nb, const KeyFrame& kf) {
   hipStream_t s = ctx->stream;
   HIP_TRY(ctx->b_bkeys.ensure((size_t)nb * 8));   // bpack
   HIP_TRY(ctx->b_bfirst.ensure((size_t)nb * 8));  // the same in insertion order
@@ -248,10 +251,15 @@ int merged_reference_order(vbx_ctx* ctx, size_t n, uint32_t nb, const KeyFrame& 
                      ctx->b_bkeys.as<uint64_t>(), (uint32_t)n, ctx->b_bfirst.as<uint64_t>());
   HIP_TRY(ctx->h_mkeys.ensure((size_t)nb * 8));
   HIP_TRY(ctx->h_mperm.ensure((size_t)nb * 4));
+  HIP_TRY(hipMemcpyAsync(ctx->h_mkeys.p, ctx->b_bfirst.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventRecord(ctx->ev_copy, s));
+  return VBX_OK;
+}
+int merged_reference_order_finish(vbx_ctx* ctx, uint32_t nb, const uint32_t** perm_out) {
+  hipStream_t s = ctx->stream;
   const uint64_t* packed = ctx->h_mkeys.as<uint64_t>();
   uint32_t* perm = ctx->h_mperm.as<uint32_t>();
-  HIP_TRY(hipMemcpyAsync(ctx->h_mkeys.p, ctx->b_bfirst.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipEventSynchronize(ctx->ev_copy));
   const auto dbg_t0 = std::chrono::steady_clock::now();
   // voxel_map (normal bundles) is walked before clear_map (tsdf_integrator.cc:324-333): split the
   // insertion sequence, each part keeps its order
@@ -340,9 +348,11 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   HIP_TRY(ctx->b_graze.ensure((size_t)nb * 8));
   HIP_TRY(hipMemsetAsync(ctx->b_graze.p, 0xFF, (size_t)nb * 8, s));
   RayTab bt = make_tab(ctx, true, nb);
-  const uint32_t* perm = nullptr;
-  if (cfg->merged_bundle_order == 0) {
-    rc = merged_reference_order(ctx, n, nb, kf, &perm);
+  const bool ref_order = cfg->merged_bundle_order == 0;
+  if (ref_order) {
+    rc = merged_reference_order_begin(ctx, n, nb, kf);
+    if (rc) return rc;
+    rc = ensure_tab_c(ctx, nb);
     if (rc) return rc;
   }
   HIP_TRY(ctx->b_bstart.ensure((size_t)nb * 4));
@@ -357,9 +367,16 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   KLAUNCH(k_merged_gather, grid_for(n), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
                      ctx->b_vals1.as<uint32_t>(), (uint32_t)n, pt, ctx->b_pcx.as<float>(), ctx->b_pcy.as<float>(),
                      ctx->b_pcz.as<float>(), gw, gx, gy, gz, gc);
+  // the fold writes its rows in key order (table C) while the host works out the visiting order
   KLAUNCH(k_merged_bundle8, grid_for((size_t)nb * 8), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(),
-                     ctx->b_bstart.as<uint32_t>(), nb, (uint32_t)n, gw, gx, gy, gz, gc, T, kf, bt,
-                     ctx->b_graze.as<uint64_t>(), perm);
+                     ctx->b_bstart.as<uint32_t>(), nb, (uint32_t)n, gw, gx, gy, gz, gc, T, kf,
+                     ref_order ? make_tab_c(ctx, nb) : bt, ctx->b_graze.as<uint64_t>(), (const uint32_t*)nullptr);
+  if (ref_order) {
+    const uint32_t* perm = nullptr;
+    rc = merged_reference_order_finish(ctx, nb, &perm);
+    if (rc) return rc;
+    KLAUNCH(k_merged_permute_rows, grid_for(nb), dim3(256), 0, s, make_tab_c(ctx, nb), perm, nb, bt);
+  }
   tmark(ctx, 1);
   // Non-clearing bundles sort before clearing ones (bit 63), so the graze key list is the
   // sorted prefix of non-clearing bundle keys; entries of clearing bundles stay ~0 (sorted last).

@@ -686,6 +686,21 @@ __global__ void k_merged_bundle8(const uint64_t* __restrict__ keys, const uint32
   if (!clearing && graze_keys) graze_keys[br] = packed;  // (z,y,x) order either way: stays sorted for the march's binary search
 }
 
+// Rows of the bundle table from key order (as folded) into the visiting order of the bundles: the fold runs
+// while the host still reconstructs that order (vbx_host_tsdf.hpp), the permutation arrives afterwards.
+__global__ void k_merged_permute_rows(RayTab in, const uint32_t* __restrict__ perm, uint32_t nb, RayTab out) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t r = perm[b];
+  out.px[r] = in.px[b];
+  out.py[r] = in.py[b];
+  out.pz[r] = in.pz[b];
+  out.rgba[r] = in.rgba[b];
+  out.w[r] = in.w[b];
+  out.flags[r] = in.flags[b];
+  out.bkey[r] = in.bkey[b];
+}
+
 // The order in which bundleRays inserts the bundle keys into its unordered_map = ascending visiting
 // position of each bundle's first point.  by_s[s] = bundle (ascending key rank) whose first point is
 // visiting position s (else ~0); bpack[b] = clearing << 63 | b << 32 | LongIndexHash(voxel).
