@@ -369,6 +369,24 @@ def test_block_pool_grows_on_demand(oracle, kind):
     assert gm.num_blocks() > 40
 
 
+@pytest.mark.parametrize("kind,extra", [("simple", {}), ("simple", {"use_const_weight": 1}),
+                                        ("simple", {"max_weight": 300.0}), ("simple", {"use_weight_dropoff": 0}),
+                                        ("merged", {"use_const_weight": 1, "max_weight": 2000.0})])
+def test_giant_runs_full_resolution_stream(oracle, kind, extra):
+    """640x480 frames from nearly the same pose: the sensor's own voxel collects one update per ray (300k
+    in a row), its neighbours tens of thousands.  Those runs are folded by a workgroup in rounds of 4096
+    updates under the claim 'distance and colour stay, the weight advances by integer steps inside its
+    binade' (k_fold_giant) with every update verified literally; the weight passes through all binades up
+    to max_weight in the first frame, saturates, and is then an identity — all bit-exact against the
+    1-thread order."""
+    frames = [scenes.room_frame(k, 100) for k in (0, 1, 2, 3)]
+    om, oi, gm = _run(oracle, kind, 0.05, frames, max_blocks=8192, **extra)
+    st = compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    assert st["observed_voxels"] > 100000
+    w = np.concatenate([np.asarray(v[1]).ravel() for v in gm.tsdf_dict().values()])
+    assert (w == np.float32(extra.get("max_weight", 10000.0))).sum() > 10      # saturated voxels exist
+
+
 @pytest.mark.parametrize("kind,scene,n_frames", [("fast", "room", 40), ("merged", "cow", 16)])
 def test_long_full_resolution_streams_bit_exact(oracle, kind, scene, n_frames):
     """Soak at BASELINE size: 40 consecutive 640x480 frames of the configs[1] room stream through the

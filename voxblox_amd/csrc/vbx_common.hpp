@@ -93,7 +93,9 @@ struct DevState {
   uint32_t esdf_raise_any;
   uint32_t esdf_relax_blocks;
   uint32_t act_count[3];
-  uint32_t fold_long_count;
+  uint32_t fold_giant_count;     // runs of >= kFoldGiant updates handed to k_fold_giant
+  uint32_t fold_long_count[16];  // long runs handed to k_fold_long, one list per stripe (same-address atomics
+                                 // serialise at ~90 per microsecond: a single counter cost the Simple fold 2 ms)
   uint32_t redo_count;       // rays whose voxel list must be rebuilt after slot assignment
   uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)
   uint32_t tomb_count;       // tombstones in the hash table (recycled blocks)
@@ -106,7 +108,7 @@ struct DevState {
   uint32_t bbox_wide;        // a point whose voxel index is not usable for the box: absolute keys this frame
   uint32_t live_slots;       // k_reclaim: slots that still hold a block of either layer
   unsigned long long total_keys;
-  unsigned long long voxels_touched;
+  unsigned long long voxels_touched[64];  // distinct voxels updated, striped by workgroup for the same reason
   unsigned long long rays_cast;
   unsigned long long num_kept;
 };

@@ -20,7 +20,7 @@ int visiting_order(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float* d_pts, si
 }
 
 // Order the emitted (voxel, order) keys and fold them per voxel (keys in b_keys0).
-int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t total) {
+int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t total, bool giant_runs = true) {
   MapDev& m = ctx->map;
   hipStream_t s = ctx->stream;
   // gids are below pool_used * nvox; h_state holds the value from after this call's slot
@@ -33,7 +33,12 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   tmark(ctx, 5);
   // long runs are collected by k_fold and folded wave-cooperatively afterwards (their number is
   // bounded by total / kFoldShort)
-  HIP_TRY(ctx->b_long.ensure(((size_t)total / kFoldShort + 2) * 4));
+  const uint32_t long_cap = total / kFoldShort + 2;  // per stripe (any stripe could hold all of them)
+  // giant runs (one update per ray on the voxels around the sensor: Simple and Merged; Fast updates a voxel
+  // once per call unless its approximate set forgets it) go to a workgroup each
+  giant_runs = giant_runs && total > kFoldGiant;
+  HIP_TRY(ctx->b_long.ensure(((size_t)long_cap * 16 + kGiantCap) * 4));
+  uint32_t* giant_list = giant_runs ? ctx->b_long.as<uint32_t>() + (size_t)long_cap * 16 : nullptr;
   HIP_TRY(ctx->b_fin.ensure((size_t)total * 12));
   float* in_sdf = ctx->b_fin.as<float>();
   float* in_uw = in_sdf + total;
@@ -41,11 +46,14 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   KLAUNCH(k_fold_inputs, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c,
                      m, in_sdf, in_uw, in_col);
   KLAUNCH(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m, in_sdf,
-                     in_uw, in_col, ctx->b_long.as<uint32_t>(), ctx->d_state);
+                     in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
+  if (giant_runs)
+    KLAUNCH(k_fold_giant, dim3(256), dim3(64 * kGiantWaves), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
+                       in_sdf, in_uw, in_col, giant_list, ctx->d_state);
   {
     const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);
     KLAUNCH(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c,
-                       m, in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), ctx->d_state);
+                       m, in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, ctx->d_state);
   }
   tmark(ctx, 6);
   ctx->counters.voxel_updates = total;
@@ -838,7 +846,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                      ctx->b_vox.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), R, total, m,
                      ctx->b_keys0.as<uint64_t>(), ctx->d_state);
   tmark(ctx, 4);
-  return sort_and_fold(ctx, kt, c, total);
+  return sort_and_fold(ctx, kt, c, total, /*giant_runs=*/false);
 }
 
 int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
@@ -885,8 +893,15 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   rc = check_state_error(ctx);
   if (rc) return rc;
   ctx->counters.rays_cast = kind == VBX_TSDF_FAST ? ctx->h_state.num_kept : ctx->h_state.rays_cast;  // Fast casts every kept ray
-  ctx->counters.voxels_touched = ctx->h_state.voxels_touched;
+  ctx->counters.voxels_touched = 0;
+  for (int i = 0; i < 64; ++i) ctx->counters.voxels_touched += ctx->h_state.voxels_touched[i];
   ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
+#ifdef VBX_FOLD_STATS  // measurement build (tools/fold_stats.py): chunks of k_fold_long by case
+  ctx->counters.iterations = ctx->h_state.act_count[0];
+  ctx->counters.esdf_blocks = ctx->h_state.act_count[1];
+  ctx->counters.esdf_relaxations = ctx->h_state.act_count[2];
+  ctx->counters.esdf_sweeps = ctx->h_state.fold_long_count[0];
+#endif
   if (ctx->timing) {
     (void)hipEventSynchronize(ctx->ev[7]);  // the state read-back spins on mapped memory; the runtime may not have retired the events yet
     float t[8] = {0};

@@ -36,7 +36,8 @@ __global__ void k_reset_call_state(DevState* st) {
   st->esdf_raise_any = 0;
   st->esdf_relax_blocks = 0;
   st->act_count[0] = st->act_count[1] = st->act_count[2] = 0;
-  st->fold_long_count = 0;
+  for (int i = 0; i < 16; ++i) st->fold_long_count[i] = 0;
+  st->fold_giant_count = 0;
   st->fast_idle_sweep = 0;
   st->redo_count = 0;
   st->bbox_min[0] = st->bbox_min[1] = st->bbox_min[2] = 0x7FFFFFFF;
@@ -46,7 +47,7 @@ __global__ void k_reset_call_state(DevState* st) {
   st->rp_overflow = 0;
   st->rp_changed_round = 0;
   st->total_keys = 0;
-  st->voxels_touched = 0;
+  for (int i = 0; i < 64; ++i) st->voxels_touched[i] = 0;
   st->rays_cast = 0;
   st->num_kept = 0;
 }

@@ -331,6 +331,10 @@ __device__ inline void tsdf_update_state(const CastCfg& c, float sdf, float uw, 
 }
 
 constexpr uint32_t kFoldShort = 48;  // longer runs go to the wave-cooperative kernel
+constexpr uint32_t kFoldGiant = 8192;  // and these to the workgroup-cooperative one (k_fold_giant)
+constexpr int kGiantWaves = 16;
+constexpr int kGU = 4;
+constexpr uint32_t kGiantCap = 1u << 16;  // giant runs listed per call; beyond that they are folded as long runs
 
 __device__ inline l3 voxel_of_gid(const MapDev& m, uint32_t gid) {
   const uint32_t slot = gid / m.nvox;
@@ -363,22 +367,41 @@ __global__ void k_fold_inputs(const uint64_t* __restrict__ keys, size_t n, RayTa
 
 __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
                        const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
-                       const uint32_t* __restrict__ in_col, uint32_t* long_list, DevState* st) {
+                       const uint32_t* __restrict__ in_col, uint32_t* long_list, uint32_t long_cap,
+                       uint32_t* giant_list, DevState* st) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = (i < n) ? keys[i] : ~0ull;
   const uint32_t gid = (uint32_t)(key >> 32);
   const bool head = (key != ~0ull) && !(i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid);
+  // a long run (the keys of a voxel are contiguous, so one look ahead tells): handed to k_fold_long
+  // untouched.  One list per stripe, one atomic per workgroup and list.
+  bool is_long = head && i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid;
+  if (is_long && giant_list && i + kFoldGiant < n && (uint32_t)(keys[i + kFoldGiant] >> 32) == gid) {
+    const uint32_t idx = atomicAdd(&st->fold_giant_count, 1u);  // a handful per frame
+    if (idx < kGiantCap) {
+      giant_list[idx] = (uint32_t)i;
+      is_long = false;
+    }
+  }
+  const bool is_giant = head && !is_long && i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid;
+  __shared__ uint32_t s_long, s_base;
+  if (threadIdx.x == 0) s_long = 0;
   const int nheads = __syncthreads_count(head);
-  if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched, (unsigned long long)nheads);
-  if (!head) return;  // only segment heads fold
-
-  // a long run (the keys of a voxel are contiguous, so one look ahead tells): hand it to
-  // k_fold_long untouched
-  if (i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid) {
-    const uint32_t o = atomicAdd(&st->fold_long_count, 1u);
-    long_list[o] = (uint32_t)i;
+  const uint32_t stripe = blockIdx.x & 15u;
+  uint32_t my = 0;
+  if (is_long) my = atomicAdd(&s_long, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (nheads) atomicAdd(&st->voxels_touched[blockIdx.x & 63u], (unsigned long long)nheads);
+    if (s_long) s_base = atomicAdd(&st->fold_long_count[stripe], s_long);
+  }
+  __syncthreads();
+  if (is_long) {
+    long_list[(size_t)stripe * long_cap + s_base + my] = (uint32_t)i;
     return;
   }
+  if (!head || is_giant) return;  // only segment heads fold
+
   float d = m.dist[gid];
   float W = m.weight[gid];
   uint32_t col = m.rgba[gid];
@@ -394,127 +417,315 @@ __global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, CastCfg c, M
   m.rgba[gid] = col;
 }
 
-// Long runs (the voxels around the sensor origin collect one update per ray): one wave per run,
-// 64 updates per step.  The state-independent part of the 64 updates (sdf, weight) is computed
-// in parallel; the ordered fold over them is then done by the cheapest exact method:
+// Long runs (the voxels around the sensor origin collect one update per ray) are folded by whole
+// waves, 64 updates per step.  The state-independent part of the 64 updates (sdf, weight) was
+// computed in parallel by k_fold_inputs; the ordered fold over them is done by the cheapest exact
+// method:
 //   1. every update is a no-op on the current state (saturated free-space voxel)  -> skip;
-//   2. the distance provably stays where it is (clamped at +-trunc) and no colour changes:
-//      only the weight chain W <- min(max_weight, W + w) is evaluated in order, then all 64
-//      distance updates are verified in parallel against their own W;
+//   2. the distance stays where it is (clamped at +-trunc) and no colour changes: only the weight
+//      chain W <- min(max_weight, W + w) is evaluated in order (weight_stretches), then every
+//      update is verified in parallel: applied literally to (d, its own W, col) it must give
+//      (d, the next lane's W, col) — by induction over the lanes that IS the sequential result;
 //   3. otherwise the 64 updates are applied in order (operands broadcast lane by lane).
 // All three produce exactly the sequential result of updateTsdfVoxel.
+
+// The weight of one binade as integers: W = k0 * 2^(e-23).
+struct Binade {
+  int e, k0;
+};
+__device__ inline Binade binade_of(float W) {
+  const uint32_t wb = __float_as_uint(W);
+  return {(int)((wb >> 23) & 0xFFu) - 127, (int)(wb & 0x7FFFFFu) | 0x800000};
+}
+// rn(w / u) for u = 2^(e-23), or `exact = false` when fl(W + w) cannot be written as (k + that) * u for
+// every k of the binade: negative or huge w, or w / u exactly halfway (ties depend on k).
+__device__ inline int binade_increment(float uw, int e, bool* exact) {
+  const float f = ldexpf(uw, 23 - e);
+  *exact = uw >= 0.0f && f < 8388608.0f && (f - floorf(f)) != 0.5f;
+  return *exact ? (int)rintf(f) : 0;
+}
+__device__ inline int wave_prefix_incl(int v, int lane) {
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const int t = __shfl_up(v, dlt);
+    if (lane >= dlt) v += t;
+  }
+  return v;
+}
+
+// The chain W <- min(max_weight, W + w_j) over the first `cnt` lanes, in lane order; returns the final
+// W and leaves in *Wmine the value each lane's update starts from.  Float addition does not associate,
+// but the chain need not run one element at a time: while W stays inside one binade [2^e, 2^(e+1)) it
+// is an integer multiple k of u = 2^(e-23), and
+//     fl(W + w) = (k + rn(w / u)) * u        (w >= 0, w / u not a tie, k + w / u < 2^24),
+// so the chain over the lanes is an INTEGER prefix sum of rn(w_j / u), which associates.  Lanes are
+// consumed in stretches: a stretch ends where the binade is left, max_weight is reached, or a tie /
+// negative weight / W < epsilon needs the literal rule; that one element is then applied as written in
+// updateTsdfVoxel (tsdf_integrator.cc:183-195) and the next stretch starts behind it.
+// (tests/cpp/weight_chain_model.c checks the same procedure against the plain loop on the CPU; on the
+// device every result is verified by the caller anyway.)
+__device__ inline float weight_stretches(const CastCfg& c, float W, float uw, int cnt, int lane, float* Wmine_out) {
+  float Wrun = W, Wmine = W;
+  int start = 0;
+  while (start < cnt) {
+    if (Wrun == c.max_weight && __all(uw >= 0.0f)) {  // saturated: min(max, max + w) == max
+      if (lane >= start) Wmine = Wrun;
+      break;
+    }
+    const Binade bn = binade_of(Wrun);
+    const bool active = lane >= start && lane < cnt;
+    bool exact = false;
+    int inc = 0;
+    if (active && Wrun >= 1e-6f) inc = binade_increment(uw, bn.e, &exact);
+    const int pre = wave_prefix_incl(inc, lane);
+    const float Wafter = ldexpf((float)(bn.k0 + pre), bn.e - 23);  // exact where k0 + pre < 2^24
+    const bool good = !active || (exact && (bn.k0 + pre) <= 0xFFFFFF && Wafter <= c.max_weight);
+    const unsigned long long bad = __ballot(!good);
+    const int stop = bad ? (__ffsll((long long)bad) - 1) : 64;  // first lane outside the stretch
+    if (stop > start) {
+      if (lane >= start && lane < stop) Wmine = ldexpf((float)(bn.k0 + pre - inc), bn.e - 23);
+      Wrun = __shfl(Wafter, stop - 1);
+      start = stop;
+    } else {  // element `start` by the literal rule
+      const float uws = __shfl(uw, start);
+      if (lane == start) Wmine = Wrun;
+      const float nw = Wrun + uws;
+      if (!(nw < 1e-6f)) Wrun = std_min(c.max_weight, nw);
+      ++start;
+    }
+  }
+  *Wmine_out = Wmine;
+  return Wrun;
+}
+
+// One lane's update applied literally to (d, Wpre, col): does it give exactly (d, Wpost, col)?
+__device__ inline bool update_keeps(const CastCfg& c, float sdf, float uw, uint32_t color, float d, float Wpre,
+                                    float Wpost, uint32_t col) {
+  float d1 = d, W1 = Wpre;
+  uint32_t c1 = col;
+  tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
+  return __float_as_uint(d1) == __float_as_uint(d) && __float_as_uint(W1) == __float_as_uint(Wpost) && c1 == col;
+}
+
+// Folds the first `cnt` lanes' updates, in lane order, into (d, W, col).  Wave-uniform state.
+__device__ inline void fold_chunk(const CastCfg& c, int cnt, float sdf, float uw, uint32_t color, int lane, float& d,
+                                  float& W, uint32_t& col, DevState* st) {
+  // 1. identity test against the current state
+  const bool same = lane >= cnt || update_keeps(c, sdf, uw, color, d, W, W, col);
+  const bool all_same = __all(same);
+#ifdef VBX_FOLD_STATS
+  if (lane == 0) atomicAdd(&st->act_count[all_same ? 0 : 1], 1u);
+#endif
+  if (all_same) return;
+  // 2. weight chain + parallel verification
+  if (!__any(lane < cnt && fabsf(sdf) < c.trunc)) {
+    float Wmine;
+    const float Wend = weight_stretches(c, W, uw, cnt, lane, &Wmine);
+    const float Wnext = __shfl_down(Wmine, 1);
+    const float Wpost = (lane == cnt - 1 || lane == 63) ? Wend : Wnext;
+    const bool ok = lane >= cnt || update_keeps(c, sdf, uw, color, d, Wmine, Wpost, col);
+    if (__all(ok)) {
+      W = Wend;
+      return;
+    }
+  }
+  // 3. generic ordered application
+#ifdef VBX_FOLD_STATS
+  if (lane == 0) atomicAdd(&st->act_count[2], 1u);
+#endif
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    if (j < cnt) {
+      const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), j));
+      const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+      const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)color, j);
+      tsdf_update_state(c, sj, wj, cj, d, W, col);
+    }
+  }
+}
+
+// kU chunks of 64 updates of the run of voxel `gid`, starting at `base`: inputs are fetched without
+// waiting for the keys (every index below n is readable), cnt[u] = how many lanes of chunk u still
+// belong to the run (the keys of a voxel are contiguous, so they are a prefix).
+template <int kU>
+__device__ inline void load_chunks(const uint64_t* __restrict__ keys, size_t n, const float* __restrict__ in_sdf,
+                                   const float* __restrict__ in_uw, const uint32_t* __restrict__ in_col, uint32_t gid,
+                                   size_t base, int lane, float* sdf_u, float* uw_u, uint32_t* color_u, int* cnt_u) {
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const size_t i = base + 64 * u + lane;
+    const bool in = i < n;
+    const uint64_t key = in ? keys[i] : ~0ull;
+    const float s = in ? in_sdf[i] : 0.f;
+    const float w = in ? in_uw[i] : 0.f;
+    const uint32_t cc = in ? in_col[i] : 0u;
+    const bool mine = (key != ~0ull) && ((uint32_t)(key >> 32) == gid);
+    const unsigned long long V = __ballot(mine);
+    cnt_u[u] = (V == ~0ull) ? 64 : (__ffsll((long long)~V) - 1);
+    const bool live = lane < cnt_u[u];
+    sdf_u[u] = live ? s : 0.f;
+    uw_u[u] = live ? w : 0.f;
+    color_u[u] = live ? cc : 0u;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
                                                    const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
                                                    const uint32_t* __restrict__ in_col,
-                                                   const uint32_t* __restrict__ long_list, DevState* st) {
+                                                   const uint32_t* __restrict__ long_list, uint32_t long_cap, DevState* st) {
   const int lane = threadIdx.x & 63;
-  const uint32_t n_long = st->fold_long_count;
+  uint32_t n_long = 0;
+  for (int q = 0; q < 16; ++q) n_long += st->fold_long_count[q];
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; seg < n_long; seg += n_waves) {
-    const size_t i0 = long_list[seg];
+    // seg-th entry over the 16 striped lists
+    uint32_t rest = seg;
+    int q = 0;
+    while (rest >= st->fold_long_count[q]) rest -= st->fold_long_count[q++];
+    const size_t i0 = long_list[(size_t)q * long_cap + rest];
     const uint32_t gid = (uint32_t)(keys[i0] >> 32);
     float d = m.dist[gid];
     float W = m.weight[gid];
     uint32_t col = m.rgba[gid];
-    // kU chunks of 64 updates are fetched together (a run of 300k updates on the sensor's own
-    // voxel is 4800 chunks), then folded chunk by chunk in order.
     constexpr int kU = 4;
     bool more = true;
     for (size_t base = i0; more; base += 64 * kU) {
       float sdf_u[kU], uw_u[kU];
       uint32_t color_u[kU];
       int cnt_u[kU];
+      load_chunks<kU>(keys, n, in_sdf, in_uw, in_col, gid, base, lane, sdf_u, uw_u, color_u, cnt_u);
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const size_t i = base + 64 * u + lane;
-        const uint64_t key = (i < n) ? keys[i] : ~0ull;
-        const bool mine = (key != ~0ull) && ((uint32_t)(key >> 32) == gid);
-        const unsigned long long V = __ballot(mine);
-        // keys of one voxel are contiguous: the valid lanes are a prefix
-        cnt_u[u] = (V == ~0ull) ? 64 : (__ffsll((long long)~V) - 1);
-        sdf_u[u] = 0.f; uw_u[u] = 0.f; color_u[u] = 0;
-        if (lane < cnt_u[u]) {
-          sdf_u[u] = in_sdf[i];
-          uw_u[u] = in_uw[i];
-          color_u[u] = in_col[i];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const int cnt = cnt_u[u];
-        if (cnt == 0) { more = false; break; }
-        const float sdf = sdf_u[u], uw = uw_u[u];
-        const uint32_t color = color_u[u];
-        const bool inband = fabsf(sdf) < c.trunc;
-        // 1. identity test against the current state
-        bool same = true;
-        if (lane < cnt) {
-          float d1 = d, W1 = W;
-          uint32_t c1 = col;
-          tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
-          same = (__float_as_uint(d1) == __float_as_uint(d)) && (__float_as_uint(W1) == __float_as_uint(W)) && (c1 == col);
-        }
-        if (!__all(same)) {
-          // 2. weight chain + parallel verification that d does not move
-          bool done = false;
-          if (!__any(lane < cnt && inband)) {
-            // the chain itself: operands come out of the lanes with v_readlane (constant lane
-            // index, fully unrolled) — a ds_bpermute per element made this loop the whole cost
-            // of the fold (~2.7 us per 64 updates)
-            float Wrun = W, Wmine = W;
-            if (cnt == 64 && W >= 1e-6f && __all(uw >= 0.0f)) {
-              // full chunk, weights only grow: the `new_weight < kFloatEpsilon` exit of
-              // updateTsdfVoxel (tsdf_integrator.cc:183-186) cannot trigger, so the chain is two
-              // dependent VALU ops per update with no branches
-#pragma unroll
-              for (int j = 0; j < 64; ++j) {
-                const float uwj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
-                Wmine = (lane == j) ? Wrun : Wmine;
-                Wrun = std_min(c.max_weight, Wrun + uwj);
-              }
-            } else {
-#pragma unroll
-              for (int j = 0; j < 64; ++j) {
-                if (j < cnt) {
-                  const float uwj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
-                  if (lane == j) Wmine = Wrun;
-                  const float nw = Wrun + uwj;
-                  if (!(nw < 1e-6f)) Wrun = std_min(c.max_weight, nw);
-                }
-              }
-            }
-            bool ok = true;
-            if (lane < cnt) {
-              float d1 = d, W1 = Wmine;
-              uint32_t c1 = col;
-              tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
-              ok = (__float_as_uint(d1) == __float_as_uint(d));
-            }
-            if (__all(ok)) {
-              W = Wrun;
-              done = true;
-            }
-          }
-          // 3. generic ordered application
-          if (!done) {
-#pragma unroll
-            for (int j = 0; j < 64; ++j) {
-              if (j < cnt) {
-                const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), j));
-                const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
-                const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)color, j);
-                tsdf_update_state(c, sj, wj, cj, d, W, col);
-              }
-            }
-          }
-        }
-        if (cnt < 64) { more = false; break; }
+        if (cnt_u[u] == 0) { more = false; break; }
+        fold_chunk(c, cnt_u[u], sdf_u[u], uw_u[u], color_u[u], lane, d, W, col, st);
+        if (cnt_u[u] < 64) { more = false; break; }
       }
     }
     if (lane == 0) {
       m.dist[gid] = d;
       m.weight[gid] = W;
       m.rgba[gid] = col;
+    }
+  }
+}
+
+// Giant runs (kFoldGiant updates and more: the sensor's own voxel collects one update per ray, its
+// neighbours tens of thousands): a single wave walking 300k updates is a 4 ms chain of dependent
+// loads, so these get a whole workgroup of 16 waves and proceed in rounds of 16 x kGU x 64 updates.
+// In a round every wave takes one segment and assumes the cheap case for everything before it — the
+// distance and colour stay put and the weight advances inside its current binade (or sits at
+// max_weight) — under which the weight in front of every update is an integer prefix sum across the
+// whole round (lanes, chunks, waves).  Each update is then applied literally to (d, its claimed W,
+// col) and must return (d, the next update's claimed W, col); the prefix of segments for which that
+// holds is exactly the sequential result (induction as in fold_chunk).  The first segment where it
+// does not hold is folded by its wave with fold_chunk from the exact state in front of it, and the
+// next round starts behind it.
+__global__ void __launch_bounds__(64 * kGiantWaves) k_fold_giant(const uint64_t* __restrict__ keys, size_t n, CastCfg c,
+                                                                 MapDev m, const float* __restrict__ in_sdf,
+                                                                 const float* __restrict__ in_uw,
+                                                                 const uint32_t* __restrict__ in_col,
+                                                                 const uint32_t* __restrict__ giant_list, DevState* st) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __shared__ float s_d, s_W;
+  __shared__ uint32_t s_col;
+  __shared__ int s_tot[kGiantWaves], s_act[kGiantWaves], s_ok[kGiantWaves];
+  const uint32_t n_giant = min(st->fold_giant_count, kGiantCap);
+  for (uint32_t g = blockIdx.x; g < n_giant; g += gridDim.x) {
+    const size_t i0 = giant_list[g];
+    const uint32_t gid = (uint32_t)(keys[i0] >> 32);
+    __syncthreads();  // the previous run's last reads of the shared state
+    if (threadIdx.x == 0) {
+      s_d = m.dist[gid];
+      s_W = m.weight[gid];
+      s_col = m.rgba[gid];
+    }
+    size_t pos = i0;
+    while (true) {
+      __syncthreads();
+      const float d = s_d, W = s_W;
+      const uint32_t col = s_col;
+      float sdf_u[kGU], uw_u[kGU];
+      uint32_t color_u[kGU];
+      int cnt_u[kGU], inc_u[kGU], pre_u[kGU];  // pre: inclusive prefix inside the segment
+      load_chunks<kGU>(keys, n, in_sdf, in_uw, in_col, gid, pos + (size_t)wave * (64 * kGU), lane, sdf_u, uw_u,
+                       color_u, cnt_u);
+      const bool saturated = W == c.max_weight;
+      const Binade bn = binade_of(W);
+      bool claim = W >= 1e-6f;  // every update of the segment can be written as an integer step
+      int run = 0, active = 0;
+#pragma unroll
+      for (int u = 0; u < kGU; ++u) {
+        bool exact = true;
+        int inc = 0;
+        if (lane < cnt_u[u]) {
+          if (saturated) exact = uw_u[u] >= 0.0f;
+          else inc = binade_increment(uw_u[u], bn.e, &exact);
+        }
+        claim = claim && exact && inc <= 0xFFFF;  // keeps every sum of a round inside an int
+        inc_u[u] = inc;
+        pre_u[u] = run + wave_prefix_incl(inc, lane);
+        run = __shfl(pre_u[u], 63);
+        active += cnt_u[u];
+      }
+      if (lane == 0) {
+        s_tot[wave] = run;
+        s_act[wave] = active;
+      }
+      __syncthreads();
+      int before = 0;
+      for (int w2 = 0; w2 < wave; ++w2) before += s_tot[w2];
+      // verify every update of the segment against its claimed weights
+      bool ok = __all(claim) && (long long)bn.k0 + before + run <= 0xFFFFFF;
+      if (ok) {
+#pragma unroll
+        for (int u = 0; u < kGU; ++u) {
+          if (lane < cnt_u[u]) {
+            const float Wpre = saturated ? W : ldexpf((float)(bn.k0 + before + pre_u[u] - inc_u[u]), bn.e - 23);
+            const float Wpost = saturated ? W : ldexpf((float)(bn.k0 + before + pre_u[u]), bn.e - 23);
+            ok = ok && update_keeps(c, sdf_u[u], uw_u[u], color_u[u], d, Wpre, Wpost, col);
+          }
+        }
+        ok = __all(ok);
+      }
+      if (lane == 0) s_ok[wave] = ok ? 1 : 0;
+      __syncthreads();
+      // first segment that failed, first segment in which the run ended
+      int fail = kGiantWaves, last = kGiantWaves, upto = 0;
+      for (int w2 = 0; w2 < kGiantWaves; ++w2) {
+        if (fail == kGiantWaves && !s_ok[w2]) fail = w2;
+        if (last == kGiantWaves && s_act[w2] < 64 * kGU) last = w2;
+      }
+      const int good = min(fail, last == kGiantWaves ? kGiantWaves : last + 1);  // segments taken as claimed
+      for (int w2 = 0; w2 < good; ++w2) upto += s_tot[w2];
+      const float Wgood = saturated ? W : ldexpf((float)(bn.k0 + upto), bn.e - 23);
+      const bool ended = last < fail || (fail == last && fail < kGiantWaves);  // the run ends inside this round
+      __syncthreads();  // everyone has read s_d / s_W / s_ok
+      if (fail < kGiantWaves && fail <= last) {
+        if (wave == fail) {  // fold the failed segment from the exact state in front of it
+          float d2 = d, W2 = Wgood;
+          uint32_t col2 = col;
+#pragma unroll
+          for (int u = 0; u < kGU; ++u)
+            if (cnt_u[u] > 0) fold_chunk(c, cnt_u[u], sdf_u[u], uw_u[u], color_u[u], lane, d2, W2, col2, st);
+          if (lane == 0) {
+            s_d = d2;
+            s_W = W2;
+            s_col = col2;
+          }
+        }
+        pos += (size_t)(fail + 1) * (64 * kGU);
+      } else {
+        if (threadIdx.x == 0) s_W = Wgood;
+        pos += (size_t)kGiantWaves * (64 * kGU);
+      }
+      if (ended) break;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m.dist[gid] = s_d;
+      m.weight[gid] = s_W;
+      m.rgba[gid] = s_col;
     }
   }
 }
