@@ -5,7 +5,7 @@ from voxblox_amd import capi, scenes
 capi.LIB_PATH = os.environ["VBX_LIB"]
 gm = capi.Map(0.05, 16, max_blocks=8192)
 cfg = capi.tsdf_cfg(default_truncation_distance=0.2)
-for k in range(8):
+for k in range(12):
     pose, pts, col = scenes.room_frame(k, 100)
     gm.integrate(capi.TSDF_SIMPLE, cfg, pose[0], pose[1], pts, col)
     c = gm.counters()

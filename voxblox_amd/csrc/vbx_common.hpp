@@ -93,6 +93,9 @@ struct DevState {
   uint32_t esdf_raise_any;
   uint32_t esdf_relax_blocks;
   uint32_t act_count[3];
+#ifdef VBX_FOLD_STATS
+  uint32_t dbg[16];
+#endif
   uint32_t fold_giant_count;     // runs of >= kFoldGiant updates handed to k_fold_giant
   uint32_t fold_long_count[16];  // long runs handed to k_fold_long, one list per stripe (same-address atomics
                                  // serialise at ~90 per microsecond: a single counter cost the Simple fold 2 ms)

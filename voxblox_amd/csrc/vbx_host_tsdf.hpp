@@ -36,20 +36,28 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   const uint32_t long_cap = total / kFoldShort + 2;  // per stripe (any stripe could hold all of them)
   // giant runs (one update per ray on the voxels around the sensor: Simple and Merged; Fast updates a voxel
   // once per call unless its approximate set forgets it) go to a workgroup each
+  const bool many_per_voxel = giant_runs;
   giant_runs = giant_runs && total > kFoldGiant;
-  HIP_TRY(ctx->b_long.ensure(((size_t)long_cap * 16 + kGiantCap) * 4));
+  HIP_TRY(ctx->b_long.ensure(((size_t)long_cap * 16 + kGiantCap) * 4 + (size_t)total / 256 + 1));
   uint32_t* giant_list = giant_runs ? ctx->b_long.as<uint32_t>() + (size_t)long_cap * 16 : nullptr;
+  uint8_t* ident = giant_runs ? reinterpret_cast<uint8_t*>(ctx->b_long.as<uint32_t>() + (size_t)long_cap * 16 + kGiantCap) : nullptr;
   HIP_TRY(ctx->b_fin.ensure((size_t)total * 12));
   float* in_sdf = ctx->b_fin.as<float>();
   float* in_uw = in_sdf + total;
   uint32_t* in_col = reinterpret_cast<uint32_t*>(in_uw + total);
   KLAUNCH(k_fold_inputs, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c,
-                     m, in_sdf, in_uw, in_col);
-  KLAUNCH(k_fold, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m, in_sdf,
-                     in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
-  if (giant_runs)
+                     m, in_sdf, in_uw, in_col, ident);
+  if (many_per_voxel) {
+    KLAUNCH(k_fold<16>, grid_for(total, 256 * 16), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
+                       in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
+  } else {
+    KLAUNCH(k_fold<2>, grid_for(total, 256 * 2), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
+                       in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
+  }
+  if (giant_runs) {
     KLAUNCH(k_fold_giant, dim3(256), dim3(64 * kGiantWaves), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
-                       in_sdf, in_uw, in_col, giant_list, ctx->d_state);
+                       in_sdf, in_uw, in_col, giant_list, ident, ctx->d_state);
+  }
   {
     const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);
     KLAUNCH(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c,
@@ -901,6 +909,9 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters.esdf_blocks = ctx->h_state.act_count[1];
   ctx->counters.esdf_relaxations = ctx->h_state.act_count[2];
   ctx->counters.esdf_sweeps = ctx->h_state.fold_long_count[0];
+  fprintf(stderr, "fold dbg:");
+  for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", ctx->h_state.dbg[i]);
+  fprintf(stderr, "\n");
 #endif
   if (ctx->timing) {
     (void)hipEventSynchronize(ctx->ev[7]);  // the state read-back spins on mapped memory; the runtime may not have retired the events yet

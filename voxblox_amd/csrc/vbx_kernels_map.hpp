@@ -38,6 +38,9 @@ __global__ void k_reset_call_state(DevState* st) {
   st->act_count[0] = st->act_count[1] = st->act_count[2] = 0;
   for (int i = 0; i < 16; ++i) st->fold_long_count[i] = 0;
   st->fold_giant_count = 0;
+#ifdef VBX_FOLD_STATS
+  for (int i = 0; i < 16; ++i) st->dbg[i] = 0;
+#endif
   st->fast_idle_sweep = 0;
   st->redo_count = 0;
   st->bbox_min[0] = st->bbox_min[1] = st->bbox_min[2] = 0x7FFFFFFF;

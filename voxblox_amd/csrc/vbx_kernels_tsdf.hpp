@@ -333,7 +333,7 @@ __device__ inline void tsdf_update_state(const CastCfg& c, float sdf, float uw, 
 constexpr uint32_t kFoldShort = 48;  // longer runs go to the wave-cooperative kernel
 constexpr uint32_t kFoldGiant = 8192;  // and these to the workgroup-cooperative one (k_fold_giant)
 constexpr int kGiantWaves = 16;
-constexpr int kGU = 4;
+constexpr int kGU = 8;
 constexpr uint32_t kGiantCap = 1u << 16;  // giant runs listed per call; beyond that they are folded as long runs
 
 __device__ inline l3 voxel_of_gid(const MapDev& m, uint32_t gid) {
@@ -346,88 +346,151 @@ __device__ inline l3 voxel_of_gid(const MapDev& m, uint32_t gid) {
           (long long)m.blk_idx[3 * slot + 2] * m.vps + lz};
 }
 
+// One lane's update applied literally to (d, Wpre, col): does it give exactly (d, Wpost, col)?
+__device__ inline bool update_keeps(const CastCfg& c, float sdf, float uw, uint32_t color, float d, float Wpre,
+                                    float Wpost, uint32_t col) {
+  float d1 = d, W1 = Wpre;
+  uint32_t c1 = col;
+  tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
+  return __float_as_uint(d1) == __float_as_uint(d) && __float_as_uint(W1) == __float_as_uint(Wpost) && c1 == col;
+}
+
 // The state-independent half of every update (sdf and adjusted weight, colour) in sorted key order:
 // the gathers by ray index run fully parallel here, and the ordered folds below read consecutive
 // memory instead of chasing a ray index per step (k_fold spent ~1 us per update on that chain).
-__global__ void k_fold_inputs(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c, MapDev m,
-                              float* in_sdf, float* in_uw, uint32_t* in_col) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t key = keys[i];
-  if (key == ~0ull) return;
-  const uint32_t gid = (uint32_t)(key >> 32);
-  const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
-  const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
-  float sdf, uw;
-  tsdf_update_inputs(c, m.voxel_size, pg, voxel_of_gid(m, gid), tab.w[o], &sdf, &uw);
-  in_sdf[i] = sdf;
-  in_uw[i] = uw;
-  in_col[i] = tab.rgba[o];
-}
-
-__global__ void k_fold(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
-                       const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
-                       const uint32_t* __restrict__ in_col, uint32_t* long_list, uint32_t long_cap,
-                       uint32_t* giant_list, DevState* st) {
+// ident (optional): one byte per aligned segment of 256 keys = per workgroup — 1 when the whole segment
+// belongs to one voxel and every update in it leaves that voxel's CURRENT state untouched (a
+// saturated free-space voxel next to the sensor).  k_fold_giant jumps over such segments while the
+// voxel still has the state it had here.
+__global__ void __launch_bounds__(256) k_fold_inputs(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
+                                                     MapDev m, float* in_sdf, float* in_uw, uint32_t* in_col,
+                                                     uint8_t* ident) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = (i < n) ? keys[i] : ~0ull;
+  const bool live = key != ~0ull;
   const uint32_t gid = (uint32_t)(key >> 32);
-  const bool head = (key != ~0ull) && !(i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid);
-  // a long run (the keys of a voxel are contiguous, so one look ahead tells): handed to k_fold_long
-  // untouched.  One list per stripe, one atomic per workgroup and list.
-  bool is_long = head && i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid;
-  if (is_long && giant_list && i + kFoldGiant < n && (uint32_t)(keys[i + kFoldGiant] >> 32) == gid) {
-    const uint32_t idx = atomicAdd(&st->fold_giant_count, 1u);  // a handful per frame
-    if (idx < kGiantCap) {
-      giant_list[idx] = (uint32_t)i;
-      is_long = false;
+  float sdf = 0.f, uw = 0.f;
+  uint32_t color = 0;
+  if (live) {
+    const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
+    const f3 pg{tab.px[o], tab.py[o], tab.pz[o]};
+    tsdf_update_inputs(c, m.voxel_size, pg, voxel_of_gid(m, gid), tab.w[o], &sdf, &uw);
+    color = tab.rgba[o];
+    in_sdf[i] = sdf;
+    in_uw[i] = uw;
+    in_col[i] = color;
+  }
+  if (!ident) return;
+  __shared__ uint32_t s_gid;
+  if (threadIdx.x == 0) s_gid = gid;
+  __syncthreads();
+  const bool one_voxel = __syncthreads_and(live && gid == s_gid) != 0;
+  bool keeps = false;
+  if (one_voxel) {
+    const float d0 = m.dist[gid], W0 = m.weight[gid];
+    keeps = update_keeps(c, sdf, uw, color, d0, W0, W0, m.rgba[gid]);
+  }
+  const bool all_keep = __syncthreads_and(keeps) != 0;
+  if (threadIdx.x == 0) ident[blockIdx.x] = all_keep ? 1 : 0;
+}
+
+// The fold proper.  Every workgroup owns a tile of 4096 consecutive keys: it finds the heads of the runs
+// (the keys of a voxel are contiguous after the sort), hands long runs to k_fold_long and giant ones to
+// k_fold_giant (one look ahead at distance kFoldShort / kFoldGiant tells), collects the short ones in
+// LDS and then folds those one run per thread.  Collecting first matters: with a hundred updates per
+// voxel only one key in a hundred is a head, and a head walking its run in place kept a whole wave
+// resident for one or two active lanes (0.9 ms of dependent loads per Simple frame).
+// (kFoldTile keys per thread: 16 where voxels collect many updates, 2 for the Fast integrator whose runs
+// are single updates — there every key is a head and a big tile only serialises them.)
+template <int kFoldTile>
+__global__ void __launch_bounds__(256) k_fold(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
+                                              const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
+                                              const uint32_t* __restrict__ in_col, uint32_t* long_list,
+                                              uint32_t long_cap, uint32_t* giant_list, DevState* st) {
+  __shared__ uint32_t s_short[256 * kFoldTile];
+  __shared__ uint32_t s_long[256 * kFoldTile / kFoldShort + 8];  // long heads are more than kFoldShort apart
+  __shared__ uint32_t s_nshort, s_nlong, s_nheads, s_base;
+  if (threadIdx.x == 0) s_nshort = s_nlong = s_nheads = 0;
+  __syncthreads();
+  const size_t tile0 = (size_t)blockIdx.x * (256 * kFoldTile);
+  uint32_t nheads = 0;
+#pragma unroll 4
+  for (int t = 0; t < kFoldTile; ++t) {
+    const size_t i = tile0 + (size_t)t * 256 + threadIdx.x;
+    if (i >= n) break;
+    const uint64_t key = keys[i];
+    const uint32_t gid = (uint32_t)(key >> 32);
+    if (key == ~0ull || (i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid)) continue;  // not a head
+    ++nheads;
+    if (i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid) {
+      if (giant_list && i + kFoldGiant < n && (uint32_t)(keys[i + kFoldGiant] >> 32) == gid) {
+        const uint32_t idx = atomicAdd(&st->fold_giant_count, 1u);  // a hundred per frame
+        if (idx < kGiantCap) {
+          giant_list[idx] = (uint32_t)i;
+          continue;
+        }
+      }
+      s_long[atomicAdd(&s_nlong, 1u)] = (uint32_t)i;
+    } else {
+      s_short[atomicAdd(&s_nshort, 1u)] = (uint32_t)i;
     }
   }
-  const bool is_giant = head && !is_long && i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid;
-  __shared__ uint32_t s_long, s_base;
-  if (threadIdx.x == 0) s_long = 0;
-  const int nheads = __syncthreads_count(head);
+  if (nheads) atomicAdd(&s_nheads, nheads);
+  __syncthreads();
+  // same-address atomics retire at ~90 per microsecond: one per workgroup and counter, counters striped
   const uint32_t stripe = blockIdx.x & 15u;
-  uint32_t my = 0;
-  if (is_long) my = atomicAdd(&s_long, 1u);
-  __syncthreads();
   if (threadIdx.x == 0) {
-    if (nheads) atomicAdd(&st->voxels_touched[blockIdx.x & 63u], (unsigned long long)nheads);
-    if (s_long) s_base = atomicAdd(&st->fold_long_count[stripe], s_long);
+    if (s_nheads) atomicAdd(&st->voxels_touched[blockIdx.x & 63u], (unsigned long long)s_nheads);
+    if (s_nlong) s_base = atomicAdd(&st->fold_long_count[stripe], s_nlong);
   }
   __syncthreads();
-  if (is_long) {
-    long_list[(size_t)stripe * long_cap + s_base + my] = (uint32_t)i;
-    return;
-  }
-  if (!head || is_giant) return;  // only segment heads fold
+  if (threadIdx.x < s_nlong) long_list[(size_t)stripe * long_cap + s_base + threadIdx.x] = s_long[threadIdx.x];
 
-  float d = m.dist[gid];
-  float W = m.weight[gid];
-  uint32_t col = m.rgba[gid];
-  size_t j = i;
-  while (true) {
-    tsdf_update_state(c, in_sdf[j], in_uw[j], in_col[j], d, W, col);
-    ++j;
-    if (j >= n) break;
-    if ((uint32_t)(keys[j] >> 32) != gid) break;
+  for (uint32_t e = threadIdx.x; e < s_nshort; e += 256) {
+    size_t j = s_short[e];
+    const uint32_t gid = (uint32_t)(keys[j] >> 32);
+    float d = m.dist[gid];
+    float W = m.weight[gid];
+    uint32_t col = m.rgba[gid];
+    bool more = true;
+    while (more) {  // four updates per trip: their loads do not depend on each other
+      bool mine[4];
+      float sdf[4], uw[4];
+      uint32_t color[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mine[u] = j + u < n && (uint32_t)(keys[j + u] >> 32) == gid;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        mine[u] = mine[u] && (u == 0 || mine[u - 1]);
+        sdf[u] = mine[u] ? in_sdf[j + u] : 0.f;
+        uw[u] = mine[u] ? in_uw[j + u] : 0.f;
+        color[u] = mine[u] ? in_col[j + u] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (mine[u]) tsdf_update_state(c, sdf[u], uw[u], color[u], d, W, col);
+      more = mine[3];
+      j += 4;
+    }
+    m.dist[gid] = d;
+    m.weight[gid] = W;
+    m.rgba[gid] = col;
   }
-  m.dist[gid] = d;
-  m.weight[gid] = W;
-  m.rgba[gid] = col;
 }
 
 // Long runs (the voxels around the sensor origin collect one update per ray) are folded by whole
 // waves, 64 updates per step.  The state-independent part of the 64 updates (sdf, weight) was
 // computed in parallel by k_fold_inputs; the ordered fold over them is done by the cheapest exact
 // method:
-//   1. every update is a no-op on the current state (saturated free-space voxel)  -> skip;
-//   2. the distance stays where it is (clamped at +-trunc) and no colour changes: only the weight
-//      chain W <- min(max_weight, W + w) is evaluated in order (weight_stretches), then every
-//      update is verified in parallel: applied literally to (d, its own W, col) it must give
-//      (d, the next lane's W, col) — by induction over the lanes that IS the sequential result;
-//   3. otherwise the 64 updates are applied in order (operands broadcast lane by lane).
-// All three produce exactly the sequential result of updateTsdfVoxel.
+//   1. the distance stays where it is (clamped at +-trunc) and no colour changes — free space, the
+//      bulk of a frame: only the weight chain W <- min(max_weight, W + w) is evaluated in order
+//      (weight_stretches), then every update is verified in parallel: applied literally to
+//      (d, the weight in front of it, col) it must give (d, the weight behind it, col) — by
+//      induction over the lanes that IS the sequential result (and for a saturated voxel the
+//      identity);
+//   2. otherwise the 64 updates are applied in order — the weights still come from the chain, the
+//      state-independent operands are precomputed per lane and broadcast.
+// Both produce exactly the sequential result of updateTsdfVoxel.
 
 // The weight of one binade as integers: W = k0 * 2^(e-23).
 struct Binade {
@@ -444,12 +507,15 @@ __device__ inline int binade_increment(float uw, int e, bool* exact) {
   *exact = uw >= 0.0f && f < 8388608.0f && (f - floorf(f)) != 0.5f;
   return *exact ? (int)rintf(f) : 0;
 }
-__device__ inline int wave_prefix_incl(int v, int lane) {
-#pragma unroll
-  for (int dlt = 1; dlt < 64; dlt <<= 1) {
-    const int t = __shfl_up(v, dlt);
-    if (lane >= dlt) v += t;
-  }
+// Inclusive prefix sum over the 64 lanes on the DPP data path (no LDS round trips): shifts inside the
+// rows of 16, then the row totals are broadcast into the following rows.
+__device__ inline int wave_prefix_incl(int v, int /*lane*/) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 
@@ -464,12 +530,13 @@ __device__ inline int wave_prefix_incl(int v, int lane) {
 // updateTsdfVoxel (tsdf_integrator.cc:183-195) and the next stretch starts behind it.
 // (tests/cpp/weight_chain_model.c checks the same procedure against the plain loop on the CPU; on the
 // device every result is verified by the caller anyway.)
-__device__ inline float weight_stretches(const CastCfg& c, float W, float uw, int cnt, int lane, float* Wmine_out) {
-  float Wrun = W, Wmine = W;
+__device__ inline float weight_stretches(const CastCfg& c, float W, float uw, int cnt, int lane, float* Wmine_out,
+                                         float* Wpost_out) {
+  float Wrun = W, Wmine = W, Wpost = W;  // per lane: the weight in front of and behind its update
   int start = 0;
   while (start < cnt) {
     if (Wrun == c.max_weight && __all(uw >= 0.0f)) {  // saturated: min(max, max + w) == max
-      if (lane >= start) Wmine = Wrun;
+      if (lane >= start) Wmine = Wpost = Wrun;
       break;
     }
     const Binade bn = binade_of(Wrun);
@@ -483,64 +550,95 @@ __device__ inline float weight_stretches(const CastCfg& c, float W, float uw, in
     const unsigned long long bad = __ballot(!good);
     const int stop = bad ? (__ffsll((long long)bad) - 1) : 64;  // first lane outside the stretch
     if (stop > start) {
-      if (lane >= start && lane < stop) Wmine = ldexpf((float)(bn.k0 + pre - inc), bn.e - 23);
-      Wrun = __shfl(Wafter, stop - 1);
+      if (lane >= start && lane < stop) {
+        Wmine = ldexpf((float)(bn.k0 + pre - inc), bn.e - 23);
+        Wpost = Wafter;
+      }
+      Wrun = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Wafter), stop - 1));
       start = stop;
     } else {  // element `start` by the literal rule
-      const float uws = __shfl(uw, start);
-      if (lane == start) Wmine = Wrun;
+      const float uws = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), start));
       const float nw = Wrun + uws;
-      if (!(nw < 1e-6f)) Wrun = std_min(c.max_weight, nw);
+      const float Wnew = (nw < 1e-6f) ? Wrun : std_min(c.max_weight, nw);
+      if (lane == start) {
+        Wmine = Wrun;
+        Wpost = Wnew;
+      }
+      Wrun = Wnew;
       ++start;
     }
   }
   *Wmine_out = Wmine;
+  *Wpost_out = Wpost;
   return Wrun;
-}
-
-// One lane's update applied literally to (d, Wpre, col): does it give exactly (d, Wpost, col)?
-__device__ inline bool update_keeps(const CastCfg& c, float sdf, float uw, uint32_t color, float d, float Wpre,
-                                    float Wpost, uint32_t col) {
-  float d1 = d, W1 = Wpre;
-  uint32_t c1 = col;
-  tsdf_update_state(c, sdf, uw, color, d1, W1, c1);
-  return __float_as_uint(d1) == __float_as_uint(d) && __float_as_uint(W1) == __float_as_uint(Wpost) && c1 == col;
 }
 
 // Folds the first `cnt` lanes' updates, in lane order, into (d, W, col).  Wave-uniform state.
 __device__ inline void fold_chunk(const CastCfg& c, int cnt, float sdf, float uw, uint32_t color, int lane, float& d,
                                   float& W, uint32_t& col, DevState* st) {
-  // 1. identity test against the current state
-  const bool same = lane >= cnt || update_keeps(c, sdf, uw, color, d, W, W, col);
-  const bool all_same = __all(same);
+  // 1. weight chain, then every update verified against its own weights (a saturated voxel falls out
+  // of weight_stretches at once and this is the identity test)
+  float Wmine, Wpost;
+  const float Wend = weight_stretches(c, W, uw, cnt, lane, &Wmine, &Wpost);
+  {
+    const bool all_ok = __all(lane >= cnt || update_keeps(c, sdf, uw, color, d, Wmine, Wpost, col));
 #ifdef VBX_FOLD_STATS
-  if (lane == 0) atomicAdd(&st->act_count[all_same ? 0 : 1], 1u);
+    if (lane == 0) atomicAdd(&st->act_count[all_ok ? 0 : 1], 1u);
 #endif
-  if (all_same) return;
-  // 2. weight chain + parallel verification
-  if (!__any(lane < cnt && fabsf(sdf) < c.trunc)) {
-    float Wmine;
-    const float Wend = weight_stretches(c, W, uw, cnt, lane, &Wmine);
-    const float Wnext = __shfl_down(Wmine, 1);
-    const float Wpost = (lane == cnt - 1 || lane == 63) ? Wend : Wnext;
-    const bool ok = lane >= cnt || update_keeps(c, sdf, uw, color, d, Wmine, Wpost, col);
-    if (__all(ok)) {
+    if (all_ok) {
       W = Wend;
       return;
     }
   }
-  // 3. generic ordered application
+  // 2. ordered application.  The weights depend on neither d nor col, so the chain above stands; what
+  // is left in order are two short dependent chains (d, and col where |sdf| < trunc) whose other
+  // operands — products, sums, the normalised blend weights with their two divisions — are computed
+  // for all 64 updates at once.  (The generic loop below cost ~100 instructions per update, executed by
+  // a whole wave for one voxel: 7 % of the chunks took half of the kernel.)
 #ifdef VBX_FOLD_STATS
   if (lane == 0) atomicAdd(&st->act_count[2], 1u);
 #endif
+  const float nw = Wmine + uw;
+  const bool skipped = nw < 1e-6f;  // updateTsdfVoxel returns before touching anything (tsdf_integrator.cc:192-194)
+  const float Wlit = skipped ? Wmine : std_min(c.max_weight, nw);
+  if (__all(lane >= cnt || __float_as_uint(Wlit) == __float_as_uint(Wpost))) {  // the chain is the literal one
+    const unsigned long long act = __ballot(lane < cnt && !skipped);
+    const unsigned long long inb = __ballot(lane < cnt && fabsf(sdf) < c.trunc);
+    const float p = sdf * uw;
+    const float w1n = Wmine / nw, w2n = uw / nw;  // Color::blendTwoColors normalises by w1 + w2 == nw
+    float cb[4];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    if (j < cnt) {
-      const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), j));
-      const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
-      const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)color, j);
-      tsdf_update_state(c, sj, wj, cj, d, W, col);
+    for (int ch = 0; ch < 4; ++ch) cb[ch] = (float)(int)((color >> (8 * ch)) & 0xFF) * w2n;
+#pragma unroll 1
+    for (int j = 0; j < cnt; ++j) {
+      if (!((act >> j) & 1ull)) continue;
+      const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j));
+      const float Wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Wmine), j));
+      const float nwj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nw), j));
+      const float nsdf = (pj + d * Wj) / nwj;
+      if ((inb >> j) & 1ull) {
+        const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1n), j));
+        uint32_t out = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          const float a = (float)(int)((col >> (8 * ch)) & 0xFF);
+          const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[ch]), j));
+          out |= ((uint32_t)(int)roundf(a * w1 + b) & 0xFFu) << (8 * ch);
+        }
+        col = out;
+      }
+      d = (nsdf > 0.0f) ? std_min(c.trunc, nsdf) : std_max(-c.trunc, nsdf);
     }
+    W = Wend;
+    return;
+  }
+  // 3. the literal loop (not reached as long as weight_stretches does what it says)
+#pragma unroll 1
+  for (int j = 0; j < cnt; ++j) {
+    const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sdf), j));
+    const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uw), j));
+    const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)color, j);
+    tsdf_update_state(c, sj, wj, cj, d, W, col);
   }
 }
 
@@ -574,14 +672,26 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
                                                    const uint32_t* __restrict__ in_col,
                                                    const uint32_t* __restrict__ long_list, uint32_t long_cap, DevState* st) {
   const int lane = threadIdx.x & 63;
-  uint32_t n_long = 0;
-  for (int q = 0; q < 16; ++q) n_long += st->fold_long_count[q];
+  uint32_t n_long = 0, per_stripe[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    per_stripe[q] = st->fold_long_count[q];
+    n_long += per_stripe[q];
+  }
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+#ifdef VBX_FOLD_STATS
+  uint32_t dbg_iters = 0;
+#endif
   for (uint32_t seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; seg < n_long; seg += n_waves) {
     // seg-th entry over the 16 striped lists
     uint32_t rest = seg;
     int q = 0;
-    while (rest >= st->fold_long_count[q]) rest -= st->fold_long_count[q++];
+#pragma unroll
+    for (int t = 0; t < 15; ++t)
+      if (q == t && rest >= per_stripe[t]) {
+        rest -= per_stripe[t];
+        q = t + 1;
+      }
     const size_t i0 = long_list[(size_t)q * long_cap + rest];
     const uint32_t gid = (uint32_t)(keys[i0] >> 32);
     float d = m.dist[gid];
@@ -589,11 +699,18 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
     uint32_t col = m.rgba[gid];
     constexpr int kU = 4;
     bool more = true;
+#ifdef VBX_FOLD_STATS
+    if (lane == 0) atomicAdd(&st->dbg[7], 1u);
+#endif
     for (size_t base = i0; more; base += 64 * kU) {
       float sdf_u[kU], uw_u[kU];
       uint32_t color_u[kU];
       int cnt_u[kU];
       load_chunks<kU>(keys, n, in_sdf, in_uw, in_col, gid, base, lane, sdf_u, uw_u, color_u, cnt_u);
+#ifdef VBX_FOLD_STATS
+      ++dbg_iters;
+      if (lane == 0) atomicAdd(&st->dbg[8], 1u);
+#endif
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (cnt_u[u] == 0) { more = false; break; }
@@ -607,6 +724,9 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
       m.rgba[gid] = col;
     }
   }
+#ifdef VBX_FOLD_STATS
+  if (lane == 0) atomicMax(&st->dbg[9], dbg_iters);
+#endif
 }
 
 // Giant runs (kFoldGiant updates and more: the sensor's own voxel collects one update per ray, its
@@ -624,27 +744,70 @@ __global__ void __launch_bounds__(64 * kGiantWaves) k_fold_giant(const uint64_t*
                                                                  MapDev m, const float* __restrict__ in_sdf,
                                                                  const float* __restrict__ in_uw,
                                                                  const uint32_t* __restrict__ in_col,
-                                                                 const uint32_t* __restrict__ giant_list, DevState* st) {
+                                                                 const uint32_t* __restrict__ giant_list,
+                                                                 const uint8_t* __restrict__ ident, DevState* st) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   __shared__ float s_d, s_W;
   __shared__ uint32_t s_col;
-  __shared__ int s_tot[kGiantWaves], s_act[kGiantWaves], s_ok[kGiantWaves];
+  __shared__ int s_tot[kGiantWaves], s_act[kGiantWaves], s_ok[kGiantWaves], s_first[kGiantWaves];
   const uint32_t n_giant = min(st->fold_giant_count, kGiantCap);
   for (uint32_t g = blockIdx.x; g < n_giant; g += gridDim.x) {
     const size_t i0 = giant_list[g];
     const uint32_t gid = (uint32_t)(keys[i0] >> 32);
     __syncthreads();  // the previous run's last reads of the shared state
+#ifdef VBX_FOLD_STATS
+    uint32_t dbg_rounds = 0;
+    if (threadIdx.x == 0) atomicAdd(&st->dbg[0], 1u);
+#endif
+    // the state the ident bytes were computed against
+    const float d0 = m.dist[gid], W0 = m.weight[gid];
+    const uint32_t col0 = m.rgba[gid];
     if (threadIdx.x == 0) {
-      s_d = m.dist[gid];
-      s_W = m.weight[gid];
-      s_col = m.rgba[gid];
+      s_d = d0;
+      s_W = W0;
+      s_col = col0;
     }
-    size_t pos = i0;
+    // rounds work on aligned segments of 256 keys (the granularity of ident): the run's head up to the
+    // first boundary is folded by wave 0
+    size_t pos = (i0 + 255) & ~(size_t)255;
+    if (pos > n) pos = n;
+    if (wave == 0 && pos > i0) {
+      float sdf_u[kGU], uw_u[kGU];
+      uint32_t color_u[kGU];
+      int cnt_u[kGU];
+      load_chunks<kGU>(keys, pos, in_sdf, in_uw, in_col, gid, i0, lane, sdf_u, uw_u, color_u, cnt_u);
+      float d2 = d0, W2 = W0;
+      uint32_t col2 = col0;
+#pragma unroll
+      for (int u = 0; u < kGU; ++u)
+        if (cnt_u[u] > 0) fold_chunk(c, cnt_u[u], sdf_u[u], uw_u[u], color_u[u], lane, d2, W2, col2, st);
+      if (lane == 0) {
+        s_d = d2;
+        s_W = W2;
+        s_col = col2;
+      }
+    }
     while (true) {
       __syncthreads();
       const float d = s_d, W = s_W;
       const uint32_t col = s_col;
+      if (__float_as_uint(d) == __float_as_uint(d0) && __float_as_uint(W) == __float_as_uint(W0) && col == col0) {
+        // untouched so far: jump over the segments k_fold_inputs found to be identities, 1024 at a time
+        const size_t seg = pos / 256 + threadIdx.x;
+        const bool skip = (seg + 1) * 256 <= n && ident[seg] && (uint32_t)(keys[seg * 256 + 255] >> 32) == gid;
+        const unsigned long long stay = __ballot(!skip);
+        if (lane == 0) s_first[wave] = stay ? (__ffsll((long long)stay) - 1) : 64;
+        __syncthreads();
+        int first = 64 * kGiantWaves;
+        for (int w2 = kGiantWaves - 1; w2 >= 0; --w2)
+          if (s_first[w2] < 64) first = 64 * w2 + s_first[w2];
+        pos += (size_t)first * 256;
+#ifdef VBX_FOLD_STATS
+        if (threadIdx.x == 0) { atomicAdd(&st->dbg[3], 1u); atomicAdd(&st->dbg[4], (uint32_t)first); }
+#endif
+        if (first == 64 * kGiantWaves) continue;
+      }
       float sdf_u[kGU], uw_u[kGU];
       uint32_t color_u[kGU];
       int cnt_u[kGU], inc_u[kGU], pre_u[kGU];  // pre: inclusive prefix inside the segment
@@ -665,7 +828,7 @@ __global__ void __launch_bounds__(64 * kGiantWaves) k_fold_giant(const uint64_t*
         claim = claim && exact && inc <= 0xFFFF;  // keeps every sum of a round inside an int
         inc_u[u] = inc;
         pre_u[u] = run + wave_prefix_incl(inc, lane);
-        run = __shfl(pre_u[u], 63);
+        run = __builtin_amdgcn_readlane(pre_u[u], 63);
         active += cnt_u[u];
       }
       if (lane == 0) {
@@ -701,6 +864,10 @@ __global__ void __launch_bounds__(64 * kGiantWaves) k_fold_giant(const uint64_t*
       const float Wgood = saturated ? W : ldexpf((float)(bn.k0 + upto), bn.e - 23);
       const bool ended = last < fail || (fail == last && fail < kGiantWaves);  // the run ends inside this round
       __syncthreads();  // everyone has read s_d / s_W / s_ok
+#ifdef VBX_FOLD_STATS
+      ++dbg_rounds;
+      if (threadIdx.x == 0) { atomicAdd(&st->dbg[1], 1u); if (fail < kGiantWaves && fail <= last) atomicAdd(&st->dbg[2], 1u); }
+#endif
       if (fail < kGiantWaves && fail <= last) {
         if (wave == fail) {  // fold the failed segment from the exact state in front of it
           float d2 = d, W2 = Wgood;
@@ -722,6 +889,9 @@ __global__ void __launch_bounds__(64 * kGiantWaves) k_fold_giant(const uint64_t*
       if (ended) break;
     }
     __syncthreads();
+#ifdef VBX_FOLD_STATS
+    if (threadIdx.x == 0) { atomicMax(&st->dbg[5], dbg_rounds); atomicMax(&st->dbg[6], (uint32_t)(pos - i0)); }
+#endif
     if (threadIdx.x == 0) {
       m.dist[gid] = s_d;
       m.weight[gid] = s_W;
