@@ -376,7 +376,7 @@ def test_giant_runs_full_resolution_stream(oracle, kind, extra):
     """640x480 frames from nearly the same pose: the sensor's own voxel collects one update per ray (300k
     in a row), its neighbours tens of thousands.  Those runs are folded by a workgroup in rounds of 4096
     updates under the claim 'distance and colour stay, the weight advances by integer steps inside its
-    binade' (k_fold_giant) with every update verified literally; the weight passes through all binades up
+    binade' (fold_giant_runs) with every update verified literally; the weight passes through all binades up
     to max_weight in the first frame, saturates, and is then an identity — all bit-exact against the
     1-thread order."""
     frames = [scenes.room_frame(k, 100) for k in (0, 1, 2, 3)]

@@ -96,8 +96,8 @@ struct DevState {
 #ifdef VBX_FOLD_STATS
   uint32_t dbg[16];
 #endif
-  uint32_t fold_giant_count;     // runs of >= kFoldGiant updates handed to k_fold_giant
-  uint32_t fold_long_count[16];  // long runs handed to k_fold_long, one list per stripe (same-address atomics
+  uint32_t fold_giant_count;     // runs of >= kFoldGiant updates handed to fold_giant_runs
+  uint32_t fold_long_count[16];  // long runs handed to fold_long_runs, one list per stripe (same-address atomics
                                  // serialise at ~90 per microsecond: a single counter cost the Simple fold 2 ms)
   uint32_t redo_count;       // rays whose voxel list must be rebuilt after slot assignment
   uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)

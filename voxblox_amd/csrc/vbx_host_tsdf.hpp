@@ -54,14 +54,12 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
     KLAUNCH(k_fold<2>, grid_for(total, 256 * 2), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
                        in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
   }
-  if (giant_runs) {
-    KLAUNCH(k_fold_giant, dim3(256), dim3(64 * kGiantWaves), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
-                       in_sdf, in_uw, in_col, giant_list, ident, ctx->d_state);
-  }
   {
+    const unsigned giant_blocks = giant_runs ? 128 : 0;
     const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);
-    KLAUNCH(k_fold_long, dim3((waves + 3) / 4), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c,
-                       m, in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, ctx->d_state);
+    KLAUNCH(k_fold_runs, dim3(giant_blocks + (waves + kGiantWaves - 1) / kGiantWaves), dim3(64 * kGiantWaves), 0, s,
+                       ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m, in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(),
+                       long_cap, giant_list, ident, giant_blocks, ctx->d_state);
   }
   tmark(ctx, 6);
   ctx->counters.voxel_updates = total;

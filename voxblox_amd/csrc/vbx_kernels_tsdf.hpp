@@ -331,7 +331,7 @@ __device__ inline void tsdf_update_state(const CastCfg& c, float sdf, float uw, 
 }
 
 constexpr uint32_t kFoldShort = 48;  // longer runs go to the wave-cooperative kernel
-constexpr uint32_t kFoldGiant = 8192;  // and these to the workgroup-cooperative one (k_fold_giant)
+constexpr uint32_t kFoldGiant = 8192;  // and these to the workgroup-cooperative one (fold_giant_runs)
 constexpr int kGiantWaves = 16;
 constexpr int kGU = 8;
 constexpr uint32_t kGiantCap = 1u << 16;  // giant runs listed per call; beyond that they are folded as long runs
@@ -360,7 +360,7 @@ __device__ inline bool update_keeps(const CastCfg& c, float sdf, float uw, uint3
 // memory instead of chasing a ray index per step (k_fold spent ~1 us per update on that chain).
 // ident (optional): one byte per aligned segment of 256 keys = per workgroup — 1 when the whole segment
 // belongs to one voxel and every update in it leaves that voxel's CURRENT state untouched (a
-// saturated free-space voxel next to the sensor).  k_fold_giant jumps over such segments while the
+// saturated free-space voxel next to the sensor).  fold_giant_runs jumps over such segments while the
 // voxel still has the state it had here.
 __global__ void __launch_bounds__(256) k_fold_inputs(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
                                                      MapDev m, float* in_sdf, float* in_uw, uint32_t* in_col,
@@ -395,8 +395,8 @@ __global__ void __launch_bounds__(256) k_fold_inputs(const uint64_t* __restrict_
 }
 
 // The fold proper.  Every workgroup owns a tile of 4096 consecutive keys: it finds the heads of the runs
-// (the keys of a voxel are contiguous after the sort), hands long runs to k_fold_long and giant ones to
-// k_fold_giant (one look ahead at distance kFoldShort / kFoldGiant tells), collects the short ones in
+// (the keys of a voxel are contiguous after the sort), hands long runs to fold_long_runs and giant ones to
+// fold_giant_runs, both in k_fold_runs (one look ahead at distance kFoldShort / kFoldGiant tells), collects the short ones in
 // LDS and then folds those one run per thread.  Collecting first matters: with a hundred updates per
 // voxel only one key in a hundred is a head, and a head walking its run in place kept a whole wave
 // resident for one or two active lanes (0.9 ms of dependent loads per Simple frame).
@@ -667,10 +667,10 @@ __device__ inline void load_chunks(const uint64_t* __restrict__ keys, size_t n, 
   }
 }
 
-__global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
-                                                   const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
-                                                   const uint32_t* __restrict__ in_col,
-                                                   const uint32_t* __restrict__ long_list, uint32_t long_cap, DevState* st) {
+__device__ inline void fold_long_runs(uint32_t first_wave, uint32_t n_waves, const uint64_t* __restrict__ keys, size_t n,
+                                      const CastCfg& c, const MapDev& m, const float* __restrict__ in_sdf,
+                                      const float* __restrict__ in_uw, const uint32_t* __restrict__ in_col,
+                                      const uint32_t* __restrict__ long_list, uint32_t long_cap, DevState* st) {
   const int lane = threadIdx.x & 63;
   uint32_t n_long = 0, per_stripe[16];
 #pragma unroll
@@ -678,11 +678,10 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
     per_stripe[q] = st->fold_long_count[q];
     n_long += per_stripe[q];
   }
-  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
 #ifdef VBX_FOLD_STATS
   uint32_t dbg_iters = 0;
 #endif
-  for (uint32_t seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; seg < n_long; seg += n_waves) {
+  for (uint32_t seg = first_wave; seg < n_long; seg += n_waves) {
     // seg-th entry over the 16 striped lists
     uint32_t rest = seg;
     int q = 0;
@@ -740,19 +739,18 @@ __global__ void __launch_bounds__(256) k_fold_long(const uint64_t* __restrict__ 
 // holds is exactly the sequential result (induction as in fold_chunk).  The first segment where it
 // does not hold is folded by its wave with fold_chunk from the exact state in front of it, and the
 // next round starts behind it.
-__global__ void __launch_bounds__(64 * kGiantWaves) k_fold_giant(const uint64_t* __restrict__ keys, size_t n, CastCfg c,
-                                                                 MapDev m, const float* __restrict__ in_sdf,
-                                                                 const float* __restrict__ in_uw,
-                                                                 const uint32_t* __restrict__ in_col,
-                                                                 const uint32_t* __restrict__ giant_list,
-                                                                 const uint8_t* __restrict__ ident, DevState* st) {
+__device__ inline void fold_giant_runs(uint32_t first, uint32_t stride, const uint64_t* __restrict__ keys, size_t n,
+                                       const CastCfg& c, const MapDev& m, const float* __restrict__ in_sdf,
+                                       const float* __restrict__ in_uw, const uint32_t* __restrict__ in_col,
+                                       const uint32_t* __restrict__ giant_list, const uint8_t* __restrict__ ident,
+                                       DevState* st) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   __shared__ float s_d, s_W;
   __shared__ uint32_t s_col;
   __shared__ int s_tot[kGiantWaves], s_act[kGiantWaves], s_ok[kGiantWaves], s_first[kGiantWaves];
   const uint32_t n_giant = min(st->fold_giant_count, kGiantCap);
-  for (uint32_t g = blockIdx.x; g < n_giant; g += gridDim.x) {
+  for (uint32_t g = first; g < n_giant; g += stride) {
     const size_t i0 = giant_list[g];
     const uint32_t gid = (uint32_t)(keys[i0] >> 32);
     __syncthreads();  // the previous run's last reads of the shared state
@@ -898,6 +896,24 @@ __global__ void __launch_bounds__(64 * kGiantWaves) k_fold_giant(const uint64_t*
       m.rgba[gid] = s_col;
     }
   }
+}
+
+// Long and giant runs in one launch (they are different voxels): the first `giant_blocks` workgroups take
+// the giant runs — the sensor's own voxel keeps one of them busy for most of the kernel, so they start
+// first — and the waves of all the others share the long ones.
+__global__ void __launch_bounds__(64 * kGiantWaves) k_fold_runs(const uint64_t* __restrict__ keys, size_t n, CastCfg c,
+                                                                MapDev m, const float* __restrict__ in_sdf,
+                                                                const float* __restrict__ in_uw,
+                                                                const uint32_t* __restrict__ in_col,
+                                                                const uint32_t* __restrict__ long_list, uint32_t long_cap,
+                                                                const uint32_t* __restrict__ giant_list,
+                                                                const uint8_t* __restrict__ ident, uint32_t giant_blocks,
+                                                                DevState* st) {
+  if (blockIdx.x < giant_blocks)
+    fold_giant_runs(blockIdx.x, giant_blocks, keys, n, c, m, in_sdf, in_uw, in_col, giant_list, ident, st);
+  else
+    fold_long_runs((blockIdx.x - giant_blocks) * kGiantWaves + (threadIdx.x >> 6),
+                   (gridDim.x - giant_blocks) * kGiantWaves, keys, n, c, m, in_sdf, in_uw, in_col, long_list, long_cap, st);
 }
 
 // ---------------------------------------------------------------------------
