@@ -3,6 +3,8 @@ usage: python tools/kernel_table.py VOXEL N [SKIP] [fast|merged|simple]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from voxblox_amd import capi, scenes
+if "VBX_LIB" in os.environ:
+    capi.LIB_PATH = os.environ["VBX_LIB"]   # A/B builds
 voxel = float(sys.argv[1]); nf = int(sys.argv[2]); skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 kind = {"fast": capi.TSDF_FAST, "merged": capi.TSDF_MERGED, "simple": capi.TSDF_SIMPLE}[sys.argv[4] if len(sys.argv) > 4 else "fast"]
 gm = capi.Map(voxel, 16, max_blocks=int(8192 * max(1.0, (0.05 / voxel) ** 3)))
