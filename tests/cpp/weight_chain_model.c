@@ -1,3 +1,11 @@
+/* CPU model of weight_stretches() (voxblox_amd/csrc/vbx_kernels_tsdf.hpp): the weight chain
+ *     W <- min(max_weight, W + w_j)        (updateTsdfVoxel, tsdf_integrator.cc:188-208)
+ * of 64 updates evaluated in stretches — inside one binade [2^e, 2^(e+1)) the weight is an integer
+ * multiple k of u = 2^(e-23) and fl(W + w) = (k + rn(w / u)) * u, so a stretch is an integer prefix sum —
+ * against the plain sequential float loop, bit for bit, over random weights (1/z^2, constants, powers
+ * of two that produce ties, zeros, negative values) and starting weights (zero, small, binade
+ * boundaries, near max_weight).  TEST INFRASTRUCTURE ONLY (tests/test_oracle_known_answers.py runs it);
+ * on the device every result of the chain is verified against the literal update as well. */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -296,3 +296,16 @@ def test_raycaster_emits_manhattan_plus_one(oracle):
     assert tuple(fwd[0]) == (2, -5, 1)   # floor(origin * 20 + 1e-6)
     assert n2 == n and set(map(tuple, rev)) >= {tuple(fwd[0]), tuple(fwd[-1])}
     assert tuple(rev[0]) == tuple(fwd[-1]) and tuple(rev[-1]) == tuple(fwd[0])
+
+
+def test_weight_chain_integer_prefix_model(tmp_path):
+    """The claim behind the fold's parallel weight chain (weight_stretches in vbx_kernels_tsdf.hpp): inside
+    one binade the float chain W <- min(max_weight, W + w) is an integer prefix sum.  A C model of the same
+    stretch procedure is compared bit for bit with the sequential loop on 400 k random chunks."""
+    import os, subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "weight_chain_model.c")
+    exe = str(tmp_path / "weight_chain_model")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("ok chunks 400000")
