@@ -266,37 +266,10 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
 }
 
 // ---------------------------------------------------------------------------
-// kernel: ordered per-voxel fold == updateTsdfVoxel (tsdf_integrator.cc:150-209) applied to
-// each voxel's updates in ascending integration order.  One thread per segment head.
+// kernels: ordered per-voxel fold == updateTsdfVoxel (tsdf_integrator.cc:150-209) applied to
+// each voxel's updates in ascending integration order, split into its state-independent half
+// (tsdf_update_inputs) and the state-dependent rest (tsdf_update_state).
 // ---------------------------------------------------------------------------
-__device__ inline void tsdf_update(const CastCfg& c, float voxel_size, f3 pg, l3 g,
-                                   uint32_t color, float weight, float& d, float& W,
-                                   uint32_t& col) {
-  const f3 center = center_point_from_grid_index(g, voxel_size);
-  // computeDistance, tsdf_integrator.cc:216-228
-  const f3 a = f3_sub(center, c.origin);
-  const f3 b = f3_sub(pg, c.origin);
-  const float dist_G = f3_norm(b);
-  const float dist_G_V = f3_dot(a, b) / dist_G;
-  const float sdf = dist_G - dist_G_V;
-
-  float uw = weight;
-  const float eps = voxel_size;
-  if (c.dropoff && sdf < -eps) {
-    uw = weight * (c.trunc + sdf) / (c.trunc - eps);
-    uw = std_max(uw, 0.0f);
-  }
-  if (c.sparsity) {
-    if (fabsf(sdf) < c.trunc) uw *= c.sparsity_factor;
-  }
-  const float nw = W + uw;
-  if (nw < 1e-6f) return;
-  const float nsdf = (sdf * uw + d * W) / nw;
-  if (fabsf(sdf) < c.trunc) col = blend_two_colors(col, W, color, uw);
-  d = (nsdf > 0.0f) ? std_min(c.trunc, nsdf) : std_max(-c.trunc, nsdf);
-  W = std_min(c.max_weight, nw);
-}
-
 // Everything of updateTsdfVoxel that does not depend on the voxel's state (tsdf_integrator.cc:
 // 157-183): the projective sdf and the (drop-off / sparsity adjusted) weight of one update.
 __device__ inline void tsdf_update_inputs(const CastCfg& c, float voxel_size, f3 pg, l3 g, float weight,
