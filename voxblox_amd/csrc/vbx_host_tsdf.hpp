@@ -31,13 +31,19 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   int rc = stable_sort01(ctx, total, 32, std::min(64u, end_bit + 1), false);
   if (rc) return rc;
   tmark(ctx, 5);
+  if (!giant_runs) {  // Fast: single updates per voxel
+    KLAUNCH(k_fold_direct, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c, m,
+                       ctx->d_state);
+    tmark(ctx, 6);
+    ctx->counters.voxel_updates = total;
+    return VBX_OK;
+  }
   // long runs are collected by k_fold and folded wave-cooperatively afterwards (their number is
   // bounded by total / kFoldShort)
   const uint32_t long_cap = total / kFoldShort + 2;  // per stripe (any stripe could hold all of them)
   // giant runs (one update per ray on the voxels around the sensor: Simple and Merged; Fast updates a voxel
   // once per call unless its approximate set forgets it) go to a workgroup each
-  const bool many_per_voxel = giant_runs;
-  giant_runs = giant_runs && total > kFoldGiant;
+  giant_runs = total > kFoldGiant;
   HIP_TRY(ctx->b_long.ensure(((size_t)long_cap * 16 + kGiantCap) * 4 + (size_t)total / 256 + 1));
   uint32_t* giant_list = giant_runs ? ctx->b_long.as<uint32_t>() + (size_t)long_cap * 16 : nullptr;
   uint8_t* ident = giant_runs ? reinterpret_cast<uint8_t*>(ctx->b_long.as<uint32_t>() + (size_t)long_cap * 16 + kGiantCap) : nullptr;
@@ -47,13 +53,8 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   uint32_t* in_col = reinterpret_cast<uint32_t*>(in_uw + total);
   KLAUNCH(k_fold_inputs, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c,
                      m, in_sdf, in_uw, in_col, ident);
-  if (many_per_voxel) {
-    KLAUNCH(k_fold<16>, grid_for(total, 256 * 16), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
-                       in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
-  } else {
-    KLAUNCH(k_fold<2>, grid_for(total, 256 * 2), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
-                       in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
-  }
+  KLAUNCH(k_fold<16>, grid_for(total, 256 * 16), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, c, m,
+                     in_sdf, in_uw, in_col, ctx->b_long.as<uint32_t>(), long_cap, giant_list, ctx->d_state);
   {
     const unsigned giant_blocks = giant_runs ? 128 : 0;
     const unsigned waves = (unsigned)std::min<size_t>(8192, (size_t)total / kFoldShort + 1);

@@ -367,14 +367,44 @@ __global__ void __launch_bounds__(256) k_fold_inputs(const uint64_t* __restrict_
   if (threadIdx.x == 0) ident[blockIdx.x] = all_keep ? 1 : 0;
 }
 
+// The whole fold in one kernel for the Fast integrator, whose runs are single updates (a voxel is updated
+// once per call unless the approximate observed set forgets it): one thread per key, a run's head
+// computes the inputs of its updates on the spot and applies them in order.  Three launches less per
+// frame than inputs / tiles / long runs, and no staging arrays.
+__global__ void __launch_bounds__(256) k_fold_direct(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
+                                                     MapDev m, DevState* st) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t key = (i < n) ? keys[i] : ~0ull;
+  const uint32_t gid = (uint32_t)(key >> 32);
+  const bool head = key != ~0ull && !(i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid);
+  const int nheads = __syncthreads_count(head);
+  if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched[blockIdx.x & 63u], (unsigned long long)nheads);
+  if (!head) return;
+  const l3 g = voxel_of_gid(m, gid);
+  float d = m.dist[gid];
+  float W = m.weight[gid];
+  uint32_t col = m.rgba[gid];
+  uint64_t k = key;
+  for (size_t j = i;;) {
+    const uint32_t o = (uint32_t)(k & 0xFFFFFFFFu);
+    float sdf, uw;
+    tsdf_update_inputs(c, m.voxel_size, f3{tab.px[o], tab.py[o], tab.pz[o]}, g, tab.w[o], &sdf, &uw);
+    tsdf_update_state(c, sdf, uw, tab.rgba[o], d, W, col);
+    if (++j >= n) break;
+    k = keys[j];
+    if ((uint32_t)(k >> 32) != gid) break;
+  }
+  m.dist[gid] = d;
+  m.weight[gid] = W;
+  m.rgba[gid] = col;
+}
+
 // The fold proper.  Every workgroup owns a tile of 4096 consecutive keys: it finds the heads of the runs
 // (the keys of a voxel are contiguous after the sort), hands long runs to fold_long_runs and giant ones to
 // fold_giant_runs, both in k_fold_runs (one look ahead at distance kFoldShort / kFoldGiant tells), collects the short ones in
 // LDS and then folds those one run per thread.  Collecting first matters: with a hundred updates per
 // voxel only one key in a hundred is a head, and a head walking its run in place kept a whole wave
 // resident for one or two active lanes (0.9 ms of dependent loads per Simple frame).
-// (kFoldTile keys per thread: 16 where voxels collect many updates, 2 for the Fast integrator whose runs
-// are single updates — there every key is a head and a big tile only serialises them.)
 template <int kFoldTile>
 __global__ void __launch_bounds__(256) k_fold(const uint64_t* __restrict__ keys, size_t n, CastCfg c, MapDev m,
                                               const float* __restrict__ in_sdf, const float* __restrict__ in_uw,
