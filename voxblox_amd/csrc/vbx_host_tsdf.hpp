@@ -31,7 +31,7 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
   int rc = stable_sort01(ctx, total, 32, std::min(64u, end_bit + 1), false);
   if (rc) return rc;
   tmark(ctx, 5);
-  if (!giant_runs) {  // Fast: single updates per voxel
+  if (!giant_runs) {  // Fast: two or three updates per voxel (measured: 0.3-0.9 M updates on 0.1-0.4 M voxels)
     KLAUNCH(k_fold_direct, grid_for(total), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), (size_t)total, tab, c, m,
                        ctx->d_state);
     tmark(ctx, 6);

@@ -367,8 +367,8 @@ __global__ void __launch_bounds__(256) k_fold_inputs(const uint64_t* __restrict_
   if (threadIdx.x == 0) ident[blockIdx.x] = all_keep ? 1 : 0;
 }
 
-// The whole fold in one kernel for the Fast integrator, whose runs are single updates (a voxel is updated
-// once per call unless the approximate observed set forgets it): one thread per key, a run's head
+// The whole fold in one kernel for the Fast integrator, whose runs are two or three updates (a voxel is updated
+// again only when the approximate observed set forgot it): one thread per key, a run's head
 // computes the inputs of its updates on the spot and applies them in order.  Three launches less per
 // frame than inputs / tiles / long runs, and no staging arrays.
 __global__ void __launch_bounds__(256) k_fold_direct(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
