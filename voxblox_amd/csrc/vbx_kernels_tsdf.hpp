@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) k_fold_inputs(const uint64_t* __restrict_
 
 // The whole fold in one kernel for the Fast integrator, whose runs are two or three updates (a voxel is updated
 // again only when the approximate observed set forgot it): one thread per key, a run's head
-// computes the inputs of its updates on the spot and applies them in order.  Three launches less per
+// computes the inputs of its updates on the spot and applies them in order.  Two launches less per
 // frame than inputs / tiles / long runs, and no staging arrays.
 __global__ void __launch_bounds__(256) k_fold_direct(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
                                                      MapDev m, DevState* st) {
