@@ -64,6 +64,10 @@ int check_state_error(vbx_ctx* ctx) {
     ctx->fail("internal: voxel list capacity bound violated");
     return VBX_ERR_HIP;
   }
+  if (ctx->h_state.error & 64u) {
+    ctx->fail("internal: fused radix pass gave up waiting for an earlier tile");
+    return VBX_ERR_HIP;
+  }
   return VBX_OK;
 }
 
@@ -280,6 +284,90 @@ int rsort_pass(vbx_ctx* ctx, const uint64_t* kin, const uint32_t* vin, uint64_t*
                        shift, gofs, nwg);
   return VBX_OK;
 }
+// The fused variant of a sort (vbx_sort.hpp): one histogram launch, then one launch per pass.
+constexpr int kFsRing = 256;  // histogram slots between two clears
+template <int BITS>
+int fused_pass(vbx_ctx* ctx, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n,
+               const uint32_t* n_dev, int shift, uint32_t ntiles, bool with_vals, const uint32_t* hist) {
+  if (++ctx->fs_gen >= 0x7FFFFFFFu) {  // generation tags about to repeat: start over
+    HIP_TRY(hipMemsetAsync(ctx->b_fs_desc.p, 0, ctx->b_fs_desc.cap, ctx->stream));
+    ctx->fs_ticket_base = 0;
+    ctx->fs_gen = 1;
+  }
+  uint32_t* ticket = ctx->b_fs_desc.as<uint32_t>();
+  unsigned long long* flags = ctx->b_fs_desc.as<unsigned long long>() + 1;
+  uint16_t* cnt16 = reinterpret_cast<uint16_t*>(flags + kFsMaxTiles);
+  if (with_vals)
+    KLAUNCH((k_rsort_fused<BITS, true>), dim3(ntiles), dim3(kFsThreads), 0, ctx->stream, kin, vin, kout, vout, n, n_dev,
+            shift, hist, cnt16, flags, ticket, ctx->fs_ticket_base, ctx->fs_gen, ctx->d_state);
+  else
+    KLAUNCH((k_rsort_fused<BITS, false>), dim3(ntiles), dim3(kFsThreads), 0, ctx->stream, kin, vin, kout, vout, n,
+            n_dev, shift, hist, cnt16, flags, ticket, ctx->fs_ticket_base, ctx->fs_gen, ctx->d_state);
+  ctx->fs_ticket_base += ntiles;  // wraps like the device counter
+  return VBX_OK;
+}
+int stable_sort_fused(vbx_ctx* ctx, uint32_t n, unsigned begin_bit, unsigned end_bit, bool with_vals,
+                      const uint32_t* n_dev) {
+  const unsigned bits = end_bit - begin_bit;
+  FsPasses ps{};
+  ps.np = (int)((bits + kFsMaxBits - 1) / kFsMaxBits);
+  const unsigned per = (bits + ps.np - 1) / ps.np;
+  for (int p = 0; p < ps.np; ++p) {
+    const unsigned sh = begin_bit + p * per, w = std::min(per, end_bit - sh);
+    ps.shift[p] = (int)sh;
+    ps.mask[p] = (1u << w) - 1u;
+  }
+  const uint32_t ntiles = (n + kFsTile - 1) / kFsTile;
+  const size_t slot_bytes = (size_t)kFsMaxPasses * (1 << kFsMaxBits) * 4;
+  if (ctx->b_fs_hist.cap < slot_bytes * kFsRing) {
+    HIP_TRY(ctx->b_fs_hist.ensure(slot_bytes * kFsRing));
+    HIP_TRY(hipMemsetAsync(ctx->b_fs_hist.p, 0, ctx->b_fs_hist.cap, ctx->stream));
+    ctx->fs_ring_pos = 0;
+  }
+  const size_t desc_bytes = 8 + (size_t)kFsMaxTiles * 8 + (size_t)kFsMaxTiles * (1 << kFsMaxBits) * 2;
+  if (ctx->b_fs_desc.cap < desc_bytes) {
+    HIP_TRY(ctx->b_fs_desc.ensure(desc_bytes));
+    HIP_TRY(hipMemsetAsync(ctx->b_fs_desc.p, 0, ctx->b_fs_desc.cap, ctx->stream));
+    ctx->fs_ticket_base = 0;
+    ctx->fs_gen = 0;
+  }
+  if (ctx->fs_ring_pos == kFsRing) {  // every slot used once: clear them all (stream-ordered behind their readers)
+    HIP_TRY(hipMemsetAsync(ctx->b_fs_hist.p, 0, slot_bytes * kFsRing, ctx->stream));
+    ctx->fs_ring_pos = 0;
+  }
+  uint32_t* hist = ctx->b_fs_hist.as<uint32_t>() + (size_t)ctx->fs_ring_pos++ * kFsMaxPasses * (1 << kFsMaxBits);
+  HIP_TRY(ctx->b_keys1.ensure((size_t)n * 8));
+  if (with_vals) HIP_TRY(ctx->b_vals1.ensure((size_t)n * 4));
+  KLAUNCH(k_rsort_hist, dim3(ntiles), dim3(kFsThreads), 0, ctx->stream, ctx->b_keys0.as<uint64_t>(), n, n_dev, ps, hist);
+  bool in0 = true;
+  for (int p = 0; p < ps.np; ++p) {
+    const uint64_t* kin = (in0 ? ctx->b_keys0 : ctx->b_keys1).as<uint64_t>();
+    uint64_t* kout = (in0 ? ctx->b_keys1 : ctx->b_keys0).as<uint64_t>();
+    const uint32_t* vin = with_vals ? (in0 ? ctx->b_vals0 : ctx->b_vals1).as<uint32_t>() : nullptr;
+    uint32_t* vout = with_vals ? (in0 ? ctx->b_vals1 : ctx->b_vals0).as<uint32_t>() : nullptr;
+    const uint32_t* h = hist + (size_t)p * (1 << kFsMaxBits);
+    int w = 0;
+    while ((1u << w) <= ps.mask[p]) ++w;
+    int rc;
+    switch (w) {
+      case 4: rc = fused_pass<4>(ctx, kin, vin, kout, vout, n, n_dev, ps.shift[p], ntiles, with_vals, h); break;
+      case 5: rc = fused_pass<5>(ctx, kin, vin, kout, vout, n, n_dev, ps.shift[p], ntiles, with_vals, h); break;
+      case 6: rc = fused_pass<6>(ctx, kin, vin, kout, vout, n, n_dev, ps.shift[p], ntiles, with_vals, h); break;
+      case 7: rc = fused_pass<7>(ctx, kin, vin, kout, vout, n, n_dev, ps.shift[p], ntiles, with_vals, h); break;
+      case 8: rc = fused_pass<8>(ctx, kin, vin, kout, vout, n, n_dev, ps.shift[p], ntiles, with_vals, h); break;
+      case 9: rc = fused_pass<9>(ctx, kin, vin, kout, vout, n, n_dev, ps.shift[p], ntiles, with_vals, h); break;
+      default: rc = fused_pass<10>(ctx, kin, vin, kout, vout, n, n_dev, ps.shift[p], ntiles, with_vals, h); break;
+    }
+    if (rc) return rc;
+    in0 = !in0;
+  }
+  if (in0) {
+    std::swap(ctx->b_keys0, ctx->b_keys1);
+    if (with_vals) std::swap(ctx->b_vals0, ctx->b_vals1);
+  }
+  return VBX_OK;
+}
+
 // n_dev (optional): the number of keys lives on the device; n64 is then the host's upper bound (grid, buffers).
 int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit, bool with_vals,
                   const uint32_t* n_dev = nullptr) {
@@ -302,6 +390,13 @@ int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit
   }
   const uint32_t n = (uint32_t)n64;
   const unsigned bits = end_bit - begin_bit;
+  if (ctx->fs_enabled < 0) {
+    const char* e = getenv("VBX_SORT_FUSED");  // =0 selects the three-launch passes
+    ctx->fs_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (ctx->fs_enabled && n <= (uint32_t)kFsMaxTiles * kFsTile && bits <= (unsigned)kFsMaxBits * kFsMaxPasses &&
+      (bits + ((bits + kFsMaxBits - 1) / kFsMaxBits) - 1) / ((bits + kFsMaxBits - 1) / kFsMaxBits) >= 4)
+    return stable_sort_fused(ctx, n, begin_bit, end_bit, with_vals, n_dev);
   const unsigned passes = (bits + kSortMaxBits - 1) / kSortMaxBits;
   const unsigned per = (bits + passes - 1) / passes;  // digit width, <= 12
   const uint32_t nwg = (n + kSortTile - 1) / kSortTile;

@@ -99,6 +99,200 @@ k_rsort_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ v
 }
 
 // ---------------------------------------------------------------------------
+// Fused pass (the default up to 4 M keys and 30-bit fields; VBX_SORT_FUSED=0 selects the three launches
+// above; see stable_sort01): count, prefix and scatter of
+// one digit in ONE launch, after one histogram launch per sort — three launches for a 20-bit field
+// instead of six.  A small kernel of this path lasts 8-12 us of which its waves run 2-3 (dispatch ramp and
+// the write-back / invalidate at its boundaries are the rest, profiles/r02_pmc_fast_instructions.txt), and
+// the Fast integrator sorts seven times per frame.
+//   k_rsort_hist   digit histograms of ALL passes in one read of the keys -> hist[pass][digit] (global
+//                  atomics into a slot of a ring the host keeps zeroed)
+//   k_rsort_fused  tiles of 8192 keys, taken by ticket (a tile only waits for tiles that already run, so
+//                  no residency assumption).  A tile counts its digits per wave in LDS, publishes the
+//                  tile's counts (16 bit each, write-through stores, drained, then ONE flag word tagged
+//                  with the call's generation: the per-XCD L2s are not coherent), waits for the flags of
+//                  all earlier tiles, sums their count rows (8-byte agent-scope loads, eight in flight per
+//                  lane, four row groups across the workgroup) and scatters exactly like k_rsort_scatter.
+// Every spin is bounded: a tile that gives up raises DevState::error bit 64 and the call fails loudly.
+// ---------------------------------------------------------------------------
+constexpr int kFsThreads = 1024;
+constexpr int kFsWaves = kFsThreads / 64;
+constexpr int kFsItems = 8;
+constexpr int kFsTile = kFsThreads * kFsItems;  // 8192 keys per workgroup
+constexpr int kFsMaxTiles = 512;                // <= 4 M keys (beyond that rocPRIM sorts)
+constexpr int kFsMaxBits = 10;                  // one digit per thread
+constexpr int kFsMaxPasses = 3;
+constexpr uint32_t kFsSpinMax = 1u << 20;
+struct FsPasses {
+  int np;
+  int shift[kFsMaxPasses];
+  uint32_t mask[kFsMaxPasses];
+};
+
+__global__ void __launch_bounds__(kFsThreads)
+k_rsort_hist(const uint64_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev, FsPasses ps,
+             uint32_t* hist) {
+  if (n_dev) n = min(n, *n_dev);
+  __shared__ uint32_t s_h[kFsMaxPasses][1 << kFsMaxBits];
+  for (int i = threadIdx.x; i < kFsMaxPasses * (1 << kFsMaxBits); i += kFsThreads) (&s_h[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kFsTile;
+#pragma unroll
+  for (int e = 0; e < kFsItems; ++e) {
+    const uint32_t i = base + e * kFsThreads + threadIdx.x;
+    if (i < n) {
+      const uint64_t k = keys[i];
+      for (int p = 0; p < ps.np; ++p) atomicAdd(&s_h[p][(uint32_t)(k >> ps.shift[p]) & ps.mask[p]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < ps.np; ++p)
+    for (uint32_t d = threadIdx.x; d <= ps.mask[p]; d += kFsThreads)
+      if (s_h[p][d]) atomicAdd(&hist[p * (1 << kFsMaxBits) + d], s_h[p][d]);
+}
+
+template <int BITS, bool kHasVals>
+__global__ void __launch_bounds__(kFsThreads)
+k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
+              uint32_t* __restrict__ vout, uint32_t n, const uint32_t* __restrict__ n_dev, int shift,
+              const uint32_t* __restrict__ hist, uint16_t* cnt16, unsigned long long* flags, uint32_t* ticket,
+              uint32_t ticket_base, uint32_t gen, DevState* st) {
+  constexpr int NB = 1 << BITS;
+  constexpr int WORDS = NB / 4;             // 8-byte words per count row
+  constexpr int GROUPS = kFsThreads / WORDS;  // row groups of the look-back
+  static_assert(BITS >= 4 && BITS <= kFsMaxBits, "one digit per thread, at least one word per row");
+  if (n_dev) n = min(n, *n_dev);
+  __shared__ uint32_t s_run[kFsWaves][NB];  // per-wave digit counts, then the start of the wave's next chunk per digit
+  __shared__ uint32_t s_base[NB];           // global start of the digit + keys of earlier tiles
+  __shared__ __attribute__((aligned(8))) uint16_t s_c16[NB];
+  __shared__ uint32_t s_wsum[kFsWaves];
+  __shared__ uint32_t s_tile;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+  for (int i = threadIdx.x; i < kFsWaves * NB; i += kFsThreads) (&s_run[0][0])[i] = 0;
+  // exclusive scan of the digit histogram -> start of every digit in the output
+  const uint32_t hv = (threadIdx.x < NB) ? hist[threadIdx.x] : 0u;
+  uint32_t hincl = hv;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(hincl, d);
+    if (lane >= d) hincl += o;
+  }
+  if (lane == 63) s_wsum[w] = hincl;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  if ((unsigned long long)tile * kFsTile >= n) return;  // uniform: an empty tile has no successors that need it
+  {
+    uint32_t wb = 0;
+#pragma unroll
+    for (int ww = 0; ww < kFsWaves; ++ww)
+      if (ww < w) wb += s_wsum[ww];
+    if (threadIdx.x < NB) s_base[threadIdx.x] = wb + hincl - hv;
+  }
+  // a wave owns 64 * kFsItems consecutive keys; its chunk c is keys [wbase + 64 c, wbase + 64 c + 64)
+  const uint32_t wbase = tile * kFsTile + w * (64 * kFsItems);
+  uint64_t key[kFsItems];
+  uint32_t dig[kFsItems];
+#pragma unroll
+  for (int c = 0; c < kFsItems; ++c) {
+    const uint32_t i = wbase + c * 64 + lane;
+    key[c] = (i < n) ? kin[i] : 0;
+    dig[c] = (uint32_t)(key[c] >> shift) & (NB - 1);
+    if (i < n) atomicAdd(&s_run[w][dig[c]], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < NB) {  // exclusive prefix over the waves; the tile's count of the digit
+    uint32_t acc = 0;
+#pragma unroll
+    for (int ww = 0; ww < kFsWaves; ++ww) {
+      const uint32_t cnt = s_run[ww][threadIdx.x];
+      s_run[ww][threadIdx.x] = acc;
+      acc += cnt;
+    }
+    s_c16[threadIdx.x] = (uint16_t)acc;  // <= 8192
+  }
+  __syncthreads();
+  // publish: the count row write-through, every writing wave drained, then the flag
+  unsigned long long* row = reinterpret_cast<unsigned long long*>(cnt16 + (size_t)tile * NB);
+  if (threadIdx.x < WORDS)
+    __hip_atomic_store(row + threadIdx.x, reinterpret_cast<const unsigned long long*>(s_c16)[threadIdx.x],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned long long want = ((unsigned long long)gen << 32) | 1ull;
+  if (threadIdx.x == 0) __hip_atomic_store(&flags[tile], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // earlier tiles: thread t waits for tile t
+  bool gave_up = false;
+  if (threadIdx.x < tile) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+      if (++spins > kFsSpinMax) {
+        gave_up = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  if (__syncthreads_or(gave_up ? 1 : 0)) {
+    if (threadIdx.x == 0) atomicOr(&st->error, 64u);
+    return;
+  }
+  // sum of the earlier tiles' rows: word column q, row group g; eight loads in flight per lane
+  {
+    const int q = threadIdx.x % WORDS, g = threadIdx.x / WORDS;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const unsigned long long* col = reinterpret_cast<const unsigned long long*>(cnt16) + q;
+    for (uint32_t r0 = g; r0 < tile; r0 += 8 * GROUPS) {
+      unsigned long long x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t r = r0 + j * GROUPS;
+        x[j] = (r < tile) ? __hip_atomic_load(col + (size_t)r * WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0 += (uint32_t)(x[j] & 0xFFFFu);
+        a1 += (uint32_t)((x[j] >> 16) & 0xFFFFu);
+        a2 += (uint32_t)((x[j] >> 32) & 0xFFFFu);
+        a3 += (uint32_t)(x[j] >> 48);
+      }
+    }
+    if (a0) atomicAdd(&s_base[4 * q + 0], a0);
+    if (a1) atomicAdd(&s_base[4 * q + 1], a1);
+    if (a2) atomicAdd(&s_base[4 * q + 2], a2);
+    if (a3) atomicAdd(&s_base[4 * q + 3], a3);
+  }
+  __syncthreads();
+  if (threadIdx.x < NB) {
+    const uint32_t b = s_base[threadIdx.x];
+#pragma unroll
+    for (int ww = 0; ww < kFsWaves; ++ww) s_run[ww][threadIdx.x] += b;
+  }
+  __syncthreads();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int c = 0; c < kFsItems; ++c) {
+    const uint32_t i = wbase + c * 64 + lane;
+    const bool act = i < n;
+    unsigned long long mask = __ballot(act);  // lanes of this chunk holding the same digit
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+      const unsigned long long m = __ballot((dig[c] >> b) & 1u);
+      mask &= ((dig[c] >> b) & 1u) ? m : ~m;
+    }
+    if (act) {
+      const uint32_t rank = (uint32_t)__popcll(mask & lt);
+      const uint32_t start = s_run[w][dig[c]];  // every lane of the group reads before its leader writes
+      const uint32_t pos = start + rank;
+      kout[pos] = key[c];
+      if (kHasVals) vout[pos] = vin[i];
+      if (rank == 0) s_run[w][dig[c]] = start + (uint32_t)__popcll(mask);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Exclusive prefix sum of uint32, ONE launch (chained scan with decoupled look-back).
 // The path scans 10^5..10^6 counters eight to forty times per frame (ray offsets, compaction, the
 // digit histograms of every radix pass, the replay's probe offsets); rocPRIM's scan is two launches
