@@ -124,11 +124,25 @@ def test_stable_radix_sort_selftest():
     gm = capi.Map(0.1, 16, max_blocks=64)
     cases = [(0, 32, 52), (1, 32, 52), (63, 0, 64), (64, 44, 64), (2047, 32, 53), (2048, 32, 56), (2049, 32, 57),
              (100_000, 44, 64), (307_200, 32, 53), (1_000_003, 44, 64), (400_000, 32, 56), (50_000, 0, 64),
-             (70_000, 7, 8), (70_000, 13, 26), (70_000, 20, 20)]
+             (70_000, 7, 8), (70_000, 13, 26), (70_000, 20, 20),
+             # tile boundaries of the fused pass (8192 keys per workgroup), its widest field, many tiles
+             (8191, 32, 52), (8192, 0, 20), (8193, 32, 52), (16_385, 3, 33), (3_000_001, 32, 57)]
     for n, b, e in cases:
         for seed in (2, 3):
             gm.selftest_sort(n, b, e, seed, with_vals=True)
             gm.selftest_sort(n, b, e, seed + 10, with_vals=False)
+
+
+def test_three_launch_radix_passes(monkeypatch):
+    """VBX_SORT_FUSED=0 (read when a handle sorts for the first time) selects count / scan / scatter as three
+    launches per pass — the form every sort had before the fused pass, kept for fields wider than 30 bits and
+    as the A/B switch."""
+    from voxblox_amd import capi
+    monkeypatch.setenv("VBX_SORT_FUSED", "0")
+    gm = capi.Map(0.1, 16, max_blocks=64)
+    for n, b, e in [(1, 32, 52), (2049, 32, 57), (307_200, 32, 53), (1_000_003, 44, 64)]:
+        gm.selftest_sort(n, b, e, 4, with_vals=True)
+        gm.selftest_sort(n, b, e, 14, with_vals=False)
 
 
 def test_single_launch_scan_selftest():
