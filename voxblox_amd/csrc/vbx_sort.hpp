@@ -30,10 +30,18 @@ k_rsort_count(const uint64_t* __restrict__ keys, uint32_t n, const uint32_t* __r
   for (int i = threadIdx.x; i < NB; i += kSortThreads) s_cnt[i] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * kSortTile;
+  // loads first, unconditionally (index 0 stands in beyond n): a load inside the `if` with its LDS atomic
+  // compiles to load - wait - atomic per item, eight dependent memory round trips instead of one
+  uint64_t kv[kSortItems];
 #pragma unroll
   for (int e = 0; e < kSortItems; ++e) {
     const uint32_t i = base + e * kSortThreads + threadIdx.x;  // order is irrelevant for counting
-    if (i < n) atomicAdd(&s_cnt[(uint32_t)(keys[i] >> shift) & (NB - 1)], 1u);
+    kv[e] = keys[(i < n) ? i : 0u];
+  }
+#pragma unroll
+  for (int e = 0; e < kSortItems; ++e) {
+    const uint32_t i = base + e * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&s_cnt[(uint32_t)(kv[e] >> shift) & (NB - 1)], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += kSortThreads) hist[(size_t)d * nwg + blockIdx.x] = s_cnt[d];
@@ -57,9 +65,14 @@ k_rsort_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ v
   uint64_t key[kSortItems];
   uint32_t dig[kSortItems];
 #pragma unroll
+  for (int c = 0; c < kSortItems; ++c) {  // all loads in flight before the first LDS atomic (see k_rsort_count)
+    const uint32_t i = wbase + c * 64 + lane;
+    key[c] = kin[(i < n) ? i : 0u];
+  }
+#pragma unroll
   for (int c = 0; c < kSortItems; ++c) {
     const uint32_t i = wbase + c * 64 + lane;
-    key[c] = (i < n) ? kin[i] : 0;
+    if (i >= n) key[c] = 0;
     dig[c] = (uint32_t)(key[c] >> shift) & (NB - 1);
     if (i < n) atomicAdd(&s_run[w][dig[c]], 1u);
   }
@@ -137,13 +150,17 @@ k_rsort_hist(const uint64_t* __restrict__ keys, uint32_t n, const uint32_t* __re
   for (int i = threadIdx.x; i < kFsMaxPasses * (1 << kFsMaxBits); i += kFsThreads) (&s_h[0][0])[i] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * kFsTile;
+  uint64_t kv[kFsItems];
+#pragma unroll
+  for (int e = 0; e < kFsItems; ++e) {  // all loads in flight before the first LDS atomic (see k_rsort_count)
+    const uint32_t i = base + e * kFsThreads + threadIdx.x;
+    kv[e] = keys[(i < n) ? i : 0u];
+  }
 #pragma unroll
   for (int e = 0; e < kFsItems; ++e) {
     const uint32_t i = base + e * kFsThreads + threadIdx.x;
-    if (i < n) {
-      const uint64_t k = keys[i];
-      for (int p = 0; p < ps.np; ++p) atomicAdd(&s_h[p][(uint32_t)(k >> ps.shift[p]) & ps.mask[p]], 1u);
-    }
+    if (i < n)
+      for (int p = 0; p < ps.np; ++p) atomicAdd(&s_h[p][(uint32_t)(kv[e] >> ps.shift[p]) & ps.mask[p]], 1u);
   }
   __syncthreads();
   for (int p = 0; p < ps.np; ++p)
@@ -195,9 +212,14 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
   uint64_t key[kFsItems];
   uint32_t dig[kFsItems];
 #pragma unroll
+  for (int c = 0; c < kFsItems; ++c) {  // all loads in flight before the first LDS atomic (see k_rsort_count)
+    const uint32_t i = wbase + c * 64 + lane;
+    key[c] = kin[(i < n) ? i : 0u];
+  }
+#pragma unroll
   for (int c = 0; c < kFsItems; ++c) {
     const uint32_t i = wbase + c * 64 + lane;
-    key[c] = (i < n) ? kin[i] : 0;
+    if (i >= n) key[c] = 0;
     dig[c] = (uint32_t)(key[c] >> shift) & (NB - 1);
     if (i < n) atomicAdd(&s_run[w][dig[c]], 1u);
   }
@@ -246,12 +268,13 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
     for (uint32_t r0 = g; r0 < tile; r0 += 8 * GROUPS) {
       unsigned long long x[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 8; ++j) {  // unconditional loads (row r0 stands in beyond the tile), masked below
         const uint32_t r = r0 + j * GROUPS;
-        x[j] = (r < tile) ? __hip_atomic_load(col + (size_t)r * WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        x[j] = __hip_atomic_load(col + (size_t)((r < tile) ? r : r0) * WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        if (r0 + j * GROUPS >= tile) x[j] = 0ull;
         a0 += (uint32_t)(x[j] & 0xFFFFu);
         a1 += (uint32_t)((x[j] >> 16) & 0xFFFFu);
         a2 += (uint32_t)((x[j] >> 32) & 0xFFFFu);
