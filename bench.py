@@ -575,6 +575,14 @@ def main():
                                                f"{world} ranks, {max(1, world // 4)} ray band(s) per sensor, sparse RCCL all-to-all of touched "
                                                "blocks to their owners pipelined behind the next step's integration, map distributed by block owner")},
                     "exchange": exch})
+        if world > 1:
+            # the driver's N = 1 run of `bench.py` is configs[1] (the metric's own configuration), a different workload:
+            # the one-GPU point of THIS curve is the same shard + merge on one GPU
+            out["n1_same_workload"] = {"command": "python bench.py --gpus 1 --workload sensors4",
+                                       "measured": "profiles/r02_bench_sensors4_1gpu.json: 8.1 Mpoints/s, 151.6 ms per step "
+                                                   "(MI355X, round 2)",
+                                       "note": "strong-scaling efficiency at N = value / (N x that value); do not divide by the "
+                                               "configs[1] line"}
         if rank == 0 and rows:
             alg_bytes = 16.0 * alg["points"] + 24.0 * alg["voxels_touched"]
             dev_ms = sum(r["us_per_step"] for r in rows) / 1e3
