@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--merged-order", type=int, default=0, choices=[0, 1])
     ap.add_argument("--fast-set", type=int, default=0, choices=[0, 1])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the vbx_tsdf_integrate (host pointers) leg")
     ap.add_argument("--no-extras", action="store_true",
                     help="default run only: skip the short secondary legs (configs[2], configs[3], configs[4] on 1 GPU)")
     ap.add_argument("--mirror-frames", type=int, default=8, help="stream: frames that also mirror touched blocks to the host")
@@ -112,15 +113,25 @@ def _thread_counts(cores):
     return sorted({t for t in (1, 2, 4, 8, 16, 32, 64, cores) if t <= cores})
 
 
-def cpu_baseline(frames, kind, voxel, seconds):
-    """integratePointCloud of the reference on a bounded sample of the same frames, for every thread count
-    in {1,2,4,...,nproc} (its own spawn-per-call threading); median frame after 2 warm-up frames."""
+def cpu_baseline_frames(voxel):
+    """Frames every thread count (and every leg of a run) is timed on: 2 warm-up + 10 timed at >= 0.05 m,
+    2 + 4 at finer voxels (a 0.02 m frame costs the reference 0.5-1 s)."""
+    return (2, 10) if voxel >= 0.049 else (2, 4)
+
+
+def cpu_baseline(frames, kind, voxel, seconds=None):
+    """integratePointCloud of the reference on a FIXED sample of the same stream — the same frame list for every
+    thread count in {1,2,4,...,nproc} (its own spawn-per-call threading) and for every leg of a run, so that the
+    figures are comparable: frames[0:2] untimed, median over the next frames.  `seconds` is ignored (kept for
+    callers that still pass a budget): the sample is bounded by its frame count."""
     import ctypes
     O, L, use_ref = _oracle()
     cores = os.cpu_count() or 1
     counts = _thread_counts(cores)
-    per = max(seconds / len(counts), 0.5)
+    n_warm, n_timed = cpu_baseline_frames(voxel)
+    sample = frames[:n_warm + n_timed]
     by = {}
+    t_all = time.time()
     for threads in counts:
         L.orc_fast_reset_counter_set(0)
         m = O.OracleMap(voxel, 16, L=L)
@@ -130,23 +141,21 @@ def cpu_baseline(frames, kind, voxel, seconds):
         c.integrator_threads = threads
         it = m.tsdf_integrator(kind, c)
         ts = []
-        t_begin = time.time()
-        for i, (pose, pts, col) in enumerate(frames):
+        for pose, pts, col in sample:
             t0 = time.perf_counter()
             it.integrate(pose[0], pose[1], pts, col)
             ts.append(time.perf_counter() - t0)
-            if time.time() - t_begin > per and i >= 3:
-                break
-        used = ts[2:] if len(ts) > 3 else ts
+        used = ts[n_warm:] if len(ts) > n_warm else ts
         med = float(np.median(used))
-        by[str(threads)] = {"value": round(frames[0][1].shape[0] / med / 1e6, 3), "median_ms": round(med * 1e3, 2),
+        by[str(threads)] = {"value": round(sample[0][1].shape[0] / med / 1e6, 3), "median_ms": round(med * 1e3, 2),
                             "frames": len(ts)}
         del it, m
     best = max(by, key=lambda k: by[k]["value"])
     return {"value": by[best]["value"], "unit": "Mpoints/s", "cores": int(best),
             "kind": "reference" if use_ref else "port", "host_hw_threads": cores, "by_threads": by,
-            "sample": f"{kind} integrator, {voxel:g} m voxels, the first frames of the same stream per thread count "
-                      f"(about {per:.1f} s each, median after 2 warm-up frames), "
+            "cpu_seconds_spent": round(time.time() - t_all, 1),
+            "sample": f"{kind} integrator, {voxel:g} m voxels, frames 0..{len(sample) - 1} of the same stream for EVERY thread count "
+                      f"(the first {n_warm} untimed, median of the other {len(sample) - n_warm}), "
                       + ("reference sources compiled over dependency shims (oracle/_ref)" if use_ref
                          else "oracle restatement")}
 
@@ -308,6 +317,31 @@ def kernel_table(gm, calls_per_step=1.0):
     return rows, calls
 
 
+def pmc_traffic(kernel, tag_files=("r03_pmc_hbm_traffic.json",)):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate runs with --kernel-trace only, the driver-shaped command; tools/collect_profiles.sh +
+    tools/summarize_profiles.py).  Counters cannot be read from inside this process, so the figure comes from the
+    file; None when the file is missing or does not list the kernel."""
+    for f in tag_files:
+        path = os.path.join(ROOT, "profiles", f)
+        if not os.path.exists(path):
+            continue
+        try:
+            j = json.load(open(path))
+            k = j["per_frame_bytes"].get(kernel)
+            if not k or not k.get("launches_per_frame"):
+                continue
+            per_launch = (k["fetch_bytes"] + k["write_bytes"]) / k["launches_per_frame"]
+            return {"bytes_per_launch": int(per_launch), "fetch_bytes_per_step": int(k["fetch_bytes"]),
+                    "write_bytes_per_step": int(k["write_bytes"]), "launches_per_step": k["launches_per_frame"],
+                    "all_kernels_bytes_per_step": int(j.get("total_bytes_per_frame", 0)),
+                    "source": "profiles/" + f, "frames": j.get("frames_desc", j.get("frames")),
+                    "corrections": j.get("units")}
+        except Exception:
+            continue
+    return None
+
+
 def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
     """The dominant kernel = the one with the largest time per step in the measured table.  `achieved` =
     the step's algorithmic bytes over that kernel's time per step (all of its launches in one step — the
@@ -319,8 +353,10 @@ def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
     t = dom["us_per_step"] * 1e-6
     achieved = alg_bytes_per_step / t / 1e9 if t > 0 else 0.0
     total_us = sum(r["us_per_step"] for r in rows)
+    tr = pmc_traffic(dom["kernel"]) if "distinct voxels updated per frame" in what else None
     return {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": (tr["bytes_per_launch"] if tr else None),
+            "traffic_detail": tr,
             "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
             "kernel_us_per_step": dom["us_per_step"], "algorithmic_bytes_per_step": int(alg_bytes_per_step),
             "algorithmic_bytes": what,
@@ -329,7 +365,9 @@ def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
             "note": "durations from HIP events around every launch on the launch stream (a profiled pass over the "
                     "same stream right after the timed region; events add ~2-4 us per launch, so short kernels read "
                     "high against rocprofv3 — profiles/ holds the matching rocprofv3 --kernel-trace --stats summary); "
-                    "traffic: PMC passes live in profiles/, not in this line; latency / dependency bound path far "
+                    "traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of this kernel from the committed PMC passes of the "
+                    "driver-shaped command (traffic_detail.source; null when that file is absent), against "
+                    "algorithmic_bytes_per_step / launches_per_step per launch; latency / dependency bound path far "
                     "below the HBM roofline (SURVEY 8(d))"}
 
 
@@ -397,19 +435,15 @@ def sensors4_shards(step, rank, world, dev, cache):
     """This rank's ray shards of one time step: 4 sensors x B bands, B = max(1, world / 4), dealt out in
     order (sensor-major), so world 1 holds everything, world 4 one sensor each, world 8 half a sensor each."""
     import torch
-    from voxblox_amd import scenes
-    bands = max(1, world // 4)
-    units = [(s, b) for s in range(4) for b in range(bands)]
-    per = (len(units) + world - 1) // world
-    mine = units[rank * per:(rank + 1) * per]
+    from voxblox_amd import multi_gpu, scenes
     out = []
-    for s, b in mine:
+    for s, b, bands in multi_gpu.deal_sensor_units(world)[rank]:
         key = (s, step % 25)
         if key not in cache:
             pose, pts, col = scenes.room_sensor_frame(s, step % 25)
             cache[key] = (pose, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), pts.shape[0])
         pose, dp, dc, n = cache[key]
-        lo, hi = b * n // bands, (b + 1) * n // bands
+        lo, hi = multi_gpu.band_of(n, b, bands)
         out.append((pose[0], pose[1], dp[lo:hi], dc[lo:hi], hi - lo))
     return out
 
@@ -748,6 +782,27 @@ def main():
                               "integrate_ms": round(t_int / M * 1e3, 4), "mirror_ms": round(t_mir / M * 1e3, 4),
                               "note": "mirror = list updated blocks + AoS pack kernel + one D2H copy into page-locked staging + clear kMap bits"}
 
+    # ---- the entry point voxblox callers use: vbx_tsdf_integrate with HOST pointers (Pointcloud::data(), pageable
+    # memory), i.e. the same step plus the 16 B/point staging copy.  Same frames, same warm-up, a map of its own;
+    # reported beside `value`, which by the bench contract times resident inputs.
+    if not args.esdf and not args.mesh and not args.no_host_path:
+        gh = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+        for i in range(warmup):
+            pose, pts, col = frames[i % len(frames)]
+            gh.integrate(kind, cfg, pose[0], pose[1], pts, col)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, total):
+            pose, pts, col = frames[i % len(frames)]
+            gh.integrate(kind, cfg, pose[0], pose[1], pts, col)
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t0
+        out["host_pointer_path"] = {"value": round(pts_timed / dth / 1e6, 3), "unit": "Mpoints/s", "ms_per_step": round(dth / K * 1e3, 4),
+                                    "note": "vbx_tsdf_integrate (the drop-in's entry: pageable host points + colours copied to HBM "
+                                            "inside the call), same frames and warm-up as `value`"}
+        gh.close()
+        del gh
+
     # ---- CPU reference on the same box
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(frames[:60], args.integrator, voxel, args.cpu_seconds)
@@ -762,10 +817,10 @@ def main():
                    and abs(voxel - VOXEL) < 1e-9 and args.fast_set == 0)
     if default_run and not args.no_extras:
         extras = {}
-        py = [sys.executable, os.path.abspath(__file__), "--no-extras", "--mirror-frames", "0"]
+        py = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-host-path", "--mirror-frames", "0"]
         legs = {"configs[2] merged, cow-and-lady-like orbit": ["--integrator", "merged", "--scene", "cow", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
                 "configs[3] fast + esdf update per frame": ["--esdf", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
-                "configs[4] on one GPU (4 sensors, 0.02 m, shard + merge)": ["--workload", "sensors4", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]}
+                "configs[4] on one GPU (4 sensors, 0.02 m, shard + merge)": ["--workload", "sensors4", "--steps", "4", "--warmup", "1"]}
         del gm
         torch.cuda.empty_cache()
         for name, extra in legs.items():

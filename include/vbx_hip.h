@@ -61,7 +61,9 @@ typedef struct vbx_tsdf_cfg {
   float start_voxel_subsampling_factor;
   int32_t max_consecutive_ray_collisions;
   int32_t clear_checks_every_n_frames;
-  float max_integration_time_s; /* accepted; the GPU path never truncates a frame */
+  float max_integration_time_s; /* Fast only (tsdf_integrator.cc:496-499): <= 0 integrates nothing, like the
+                                   reference; a positive budget cannot cut a frame short on the device — a
+                                   call that ran past it sets vbx_counters.time_budget_exceeded and warns once */
   /* Not in the reference Config.  MergedTsdfIntegrator visits its ray bundles in the iteration
    * order of a std::unordered_map (tsdf_integrator.cc:440-456), which the clamped fold makes
    * observable.  0 (default): that order, reconstructed from libstdc++'s bucket-count schedule and
@@ -224,6 +226,8 @@ int vbx_blocks_upload(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t n,
  * are recycled, so max_blocks bounds the blocks ALIVE at one time, not the blocks ever touched (a sliding
  * window map keeps running); a map without any block left is back in its initial state. */
 int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]);
+/* The same for n blocks with one pass over the pool (what a host loop mirroring Layer::removeBlock should call). */
+int vbx_blocks_remove(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t n);
 int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance);
 int vbx_clear(vbx_ctx* ctx, int layer);
 /* block.updated().reset(bit) over all blocks of a layer (mesher / ESDF consumers). */
@@ -278,6 +282,7 @@ typedef struct vbx_counters {
   uint64_t esdf_sweeps;     /* ESDF: wavefront sweeps */
   uint64_t replay_rounds;   /* Fast, fast_observed_set = 0: rounds of the observed-set replay */
   uint64_t replay_block_rounds; /* ... of which: rounds run on blocks of consecutive rays (fine voxels) */
+  uint64_t time_budget_exceeded; /* Fast: 1 if the last call outran cfg->max_integration_time_s (see there) */
 } vbx_counters;
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
 

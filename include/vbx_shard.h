@@ -13,7 +13,7 @@
  *
  * This is the C++ host path a voxblox_ros node links (no Python, no torch): libvbx_shard.so = this file's
  * entry points over libvbx_hip.so and librccl.so.  voxblox_amd/multi_gpu.py is the same protocol over
- * torch.distributed (RCCL on GPUs, gloo in the CPU tests); tests/test_gpu_shard_native.py checks that both
+ * torch.distributed (RCCL on GPUs, gloo in the CPU tests); tests/test_shard_native.py checks that both
  * produce the same map.  The reference has no multi-device path: there is no reference interface to cite
  * beyond the merge functions above.
  */

@@ -141,6 +141,7 @@ def _bind(L):
         "orc_esdf_block_set": (C.c_int, [vp, i32p, f32p, u8p, i32p, C.c_uint8]),
         "orc_remove_distant_blocks": (None, [vp, C.c_int, f32p, C.c_double]),
         "orc_clear": (None, [vp, C.c_int]),
+        "orc_dropin_stats": (None, [vp, u64p]),
         "orc_tsdf_count_observed": (C.c_uint64, [vp]),
         "orc_grid_index_from_point": (None, [f32p, C.c_float, i64p]),
         "orc_center_point_from_grid_index": (None, [i64p, C.c_float, f32p]),
@@ -308,6 +309,12 @@ class OracleMap:
 
     def clear(self, layer=0):
         self.L.orc_clear(self.h, layer)
+
+    def dropin_stats(self):
+        """libvbxref_hip.so: blocks the drop-in uploaded to / removed from the device while reconciling host edits."""
+        out = np.zeros(2, np.uint64)
+        self.L.orc_dropin_stats(self.h, _p(out, C.c_uint64))
+        return dict(uploaded_blocks=int(out[0]), removed_blocks=int(out[1]))
 
 
 class OracleTsdfIntegrator:

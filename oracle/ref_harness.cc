@@ -53,7 +53,10 @@ struct orc_approx_set { std::unique_ptr<ApproxSetIface> s; };
 struct orc_bucket_queue { BucketQueue<size_t> q; };
 
 #ifdef VBX_DROPIN
-namespace voxblox { namespace hip { void releaseMirror(const Layer<TsdfVoxel>* tsdf_layer); } }
+namespace voxblox { namespace hip {
+void releaseMirror(const Layer<TsdfVoxel>* tsdf_layer);
+void mirrorStats(const Layer<TsdfVoxel>* tsdf_layer, uint64_t* uploaded_blocks, uint64_t* removed_blocks);
+} }
 #endif
 
 extern "C" {
@@ -285,6 +288,14 @@ void orc_remove_distant_blocks(orc_map* m, int layer, const float c[3], double m
   else m->esdf.removeDistantBlocks(Point(c[0], c[1], c[2]), max_distance);
 }
 void orc_clear(orc_map* m, int layer) { if (layer == 0) m->tsdf.removeAllBlocks(); else m->esdf.removeAllBlocks(); }
+void orc_dropin_stats(orc_map* m, uint64_t out[2]) {
+  out[0] = out[1] = 0;
+#ifdef VBX_DROPIN
+  voxblox::hip::mirrorStats(&m->tsdf, &out[0], &out[1]);
+#else
+  (void)m;
+#endif
+}
 uint64_t orc_tsdf_count_observed(orc_map* m) {
   uint64_t n = 0;
   BlockIndexList l;

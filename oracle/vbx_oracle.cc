@@ -297,6 +297,7 @@ void orc_remove_distant_blocks(orc_map* m, int layer, const float c[3], double m
 void orc_clear(orc_map* m, int layer) {
   if (layer == 0) m->tsdf.block_map.clear(); else m->esdf.block_map.clear();
 }
+void orc_dropin_stats(orc_map*, uint64_t out[2]) { out[0] = out[1] = 0; }  // no device behind the restatement
 uint64_t orc_tsdf_count_observed(orc_map* m) {
   uint64_t n = 0;
   for (const auto& kv : m->tsdf.block_map)

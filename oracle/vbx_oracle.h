@@ -103,6 +103,9 @@ int orc_tsdf_block_set(orc_map* m, const int32_t idx[3], const float* dist, cons
                        const uint8_t* rgba, uint8_t updated_bits);
 void orc_remove_distant_blocks(orc_map* m, int layer, const float center[3], double max_distance);
 void orc_clear(orc_map* m, int layer);
+/* libvbxref_hip.so only (the HIP drop-in behind voxblox's headers): blocks the drop-in has uploaded to / removed
+ * from the device map of this map's TSDF layer while reconciling host-side Layer edits; zeros elsewhere. */
+void orc_dropin_stats(orc_map* m, uint64_t out[2]);
 /* counts voxels with weight > 1e-6 (evaluation_utils.cc:75-78 "observed") */
 uint64_t orc_tsdf_count_observed(orc_map* m);
 

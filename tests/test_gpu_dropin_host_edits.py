@@ -1,0 +1,183 @@
+"""-m gpu: host-side Layer edits between calls reach the device map of the drop-in without any change to the
+caller ("callers read/mutate the same host Layer directly between calls").  Everything here goes
+through voxblox's REAL classes and containers (oracle/_ref/libvbxref_hip.so = the reference's headers and
+remaining sources + voxblox_amd/host/dropin/*.cc) and is compared with the pure-CPU build of the same code
+doing the same edits:
+
+  * Layer::removeDistantBlocks after every frame            (layer.h:170-182; caller tsdf_server.cc:315)
+  * a TSDF layer that was LOADED into the host Layer, then EsdfIntegrator::updateFromTsdfLayerBatch and
+    further integration                                      (io::LoadBlocksFromFile, tsdf_server.cc:566-578;
+                                                              esdf_server / tsdf_to_esdf)
+  * an in-place overwrite of an existing block without any marker (deserializeMsgToLayer kUpdate,
+    conversions_inl.h:80-88): caught by the sampled voxel fingerprint
+  * Update bits set by the host on an existing block (Block::mergeBlock, block_inl.h:120)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import scenarios as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+VOXEL = 0.1
+
+
+def _cfg(oracle, L):
+    c = oracle.TsdfCfg()
+    L.orc_tsdf_cfg_default(C.byref(c))
+    c.default_truncation_distance = 4 * VOXEL
+    c.integrator_threads = 1
+    return c
+
+
+def _cpu_lib(oracle):
+    """The checker: the reference's own sources where they are built (oracle/_ref/libvbxref.so), else the restatement."""
+    return oracle.ref_lib() if oracle.ref_available() else oracle.lib()
+
+
+def _same_tsdf(a, b):
+    da, db = a.tsdf_dict(), b.tsdf_dict()
+    assert set(da) == set(db), (len(da), len(db), sorted(set(da) ^ set(db))[:4])
+    for k in da:
+        assert np.array_equal(da[k][0].view(np.uint32), db[k][0].view(np.uint32)), k
+        assert np.array_equal(da[k][1].view(np.uint32), db[k][1].view(np.uint32)), k
+        assert np.array_equal(da[k][2], db[k][2]), k
+    return len(da)
+
+
+@pytest.mark.parametrize("kind", ["fast", "merged"])
+def test_remove_distant_blocks_after_every_frame(oracle, kind):
+    """tsdf_server's loop: integratePointcloud, then removeDistantBlocks around the sensor.  The device must drop
+    the same blocks (a block that comes back later starts from weight 0, and its pool slot is free meanwhile)."""
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    maps = []
+    for L in (H, R):
+        L.orc_fast_reset_counter_set(0)
+        m = oracle.OracleMap(VOXEL, 16, L=L)
+        it = m.tsdf_integrator(kind, _cfg(oracle, L))
+        for pose, pts, col in S.frames(6, step=9):
+            it.integrate(pose[0], pose[1], pts, col)
+            m.remove_distant_blocks(pose[0], 2.6)
+        maps.append((m, it))
+    n = _same_tsdf(maps[0][0], maps[1][0])
+    st = maps[0][0].dropin_stats()
+    assert n > 10 and st["removed_blocks"] > 10, (n, st)      # blocks really left, on the device too
+    assert st["uploaded_blocks"] == 0, st                      # and nothing was re-uploaded: the mirror's own writes are not "edits"
+
+
+def _loaded_pair(oracle, n_frames=3):
+    """(hip map filled through the HOST Layer only, cpu map) holding the same TSDF layer."""
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    R.orc_fast_reset_counter_set(0)
+    src = oracle.OracleMap(VOXEL, 16, L=R)
+    it = src.tsdf_integrator("simple", _cfg(oracle, R))
+    for pose, pts, col in S.frames(n_frames):
+        it.integrate(pose[0], pose[1], pts, col)
+    dst = oracle.OracleMap(VOXEL, 16, L=H)
+    for k, (d, w, c, _) in src.tsdf_dict().items():
+        dst.tsdf_block_set(k, d, w, c, 7)      # Layer::addBlockFromProto sets all Update bits (layer_inl.h:227)
+        src.tsdf_block_set(k, d, w, c, 7)
+    return dst, src
+
+
+def test_esdf_batch_over_a_loaded_tsdf_layer(oracle):
+    """esdf_server / tsdf_to_esdf: the TSDF layer comes from a file, no integrator ever ran on it.  The ESDF drop-in
+    must see it (it used to see an empty device map): flags and updated bits equal to the CPU build's, distances
+    bit-exact against the order-free form of the sign-mismatch rule (as in test_real_voxblox_esdf_class_over_hip)."""
+    dst, src = _loaded_pair(oracle)
+    n_blocks = dst.num_blocks(0)
+
+    def esdf_cfg(L):
+        c = oracle.EsdfCfg()
+        L.orc_esdf_cfg_default(C.byref(c))
+        c.min_distance_m = 2 * VOXEL
+        c.min_diff_m = 0.0
+        return c
+
+    e = dst.esdf_integrator(esdf_cfg(oracle.ref_hip_lib()))
+    e.update_from_tsdf_layer_batch()
+    st = dst.dropin_stats()
+    assert st["uploaded_blocks"] == n_blocks > 20, (st, n_blocks)
+    # checker: the restatement with the order-free sign-mismatch switch, on the same TSDF
+    chk = oracle.OracleMap(VOXEL, 16)
+    for k, (d, w, c, _) in src.tsdf_dict().items():
+        chk.tsdf_block_set(k, d, w, c, 7)
+    oc = esdf_cfg(oracle.lib())
+    oc.oracle_orderfree_sign_mismatch = 1
+    chk.esdf_integrator(oc).update_from_tsdf_layer_batch()
+    g, o = dst.esdf_dict(), chk.esdf_dict()
+    assert set(g) == set(o) and len(g) > 20
+    for k in o:
+        assert np.array_equal(g[k][1], o[k][1]) and g[k][3] == o[k][3], k
+        assert np.array_equal(g[k][0].view(np.uint32), o[k][0].view(np.uint32)), k
+
+
+def test_integration_continues_on_a_loaded_layer(oracle):
+    """loadMap, then the sensor keeps running: the frames must fold into the LOADED voxels (weights, clamps), not
+    into an empty device map that then overwrites the host's blocks."""
+    dst, src = _loaded_pair(oracle)
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    frames = S.frames(6)[3:]
+    for L, m in ((H, dst), (R, src)):
+        L.orc_fast_reset_counter_set(0)
+        it = m.tsdf_integrator("fast", _cfg(oracle, L))
+        for pose, pts, col in frames:
+            it.integrate(pose[0], pose[1], pts, col)
+    assert _same_tsdf(dst, src) > 20
+
+
+def test_in_place_overwrite_of_an_existing_block_is_seen(oracle):
+    """deserializeMsgToLayer(kUpdate) writes new voxels into a block the layer already has and marks nothing
+    (conversions_inl.h:80-88).  The sampled fingerprint of the voxel array tells; the next frame then folds into
+    the overwritten values on both sides."""
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    frames = S.frames(4)
+    maps = []
+    for L in (H, R):
+        L.orc_fast_reset_counter_set(0)
+        m = oracle.OracleMap(VOXEL, 16, L=L)
+        it = m.tsdf_integrator("merged", _cfg(oracle, L))
+        for pose, pts, col in frames[:2]:
+            it.integrate(pose[0], pose[1], pts, col)
+        d = m.tsdf_dict()
+        victims = sorted(k for k in d if (d[k][1] > 0).sum() > 3000)[:3]   # well-filled blocks: every sampled line moves
+        assert victims
+        for k in victims:   # a different map's values for the same block: halve the distances, double the weights
+            dist, w, c, bits = d[k]
+            m.tsdf_block_set(k, dist * np.float32(0.5), w * np.float32(2.0), c[:, ::-1].copy(), bits)   # bits untouched
+        for pose, pts, col in frames[2:]:
+            it.integrate(pose[0], pose[1], pts, col)
+        maps.append(m)
+    assert _same_tsdf(maps[0], maps[1]) > 10
+    st = maps[0].dropin_stats()
+    assert st["uploaded_blocks"] == 3, st
+
+
+def test_update_bits_set_by_the_host_trigger_an_upload(oracle):
+    """Block::mergeBlock / addBlockFromProto set updated() (block_inl.h:120, layer_inl.h:227).  After a consumer has
+    cleared a bit (the mesher clears kMesh), a bit that is back means the host wrote the block."""
+    H = oracle.ref_hip_lib()
+    H.orc_fast_reset_counter_set(0)
+    m = oracle.OracleMap(VOXEL, 16, L=H)
+    it = m.tsdf_integrator("fast", _cfg(oracle, H))
+    frames = S.frames(3)
+    it.integrate(frames[0][0][0], frames[0][0][1], frames[0][1], frames[0][2])
+    ml = m.mesh_layer()
+    ml.generate(True, True)                      # the reference's CPU mesher clears kMesh on the host blocks
+    it.integrate(frames[1][0][0], frames[1][0][1], frames[1][1], frames[1][2])
+    assert m.dropin_stats()["uploaded_blocks"] == 0
+    ml.generate(True, True)
+    d = m.tsdf_dict()
+    k = sorted(d)[0]
+    assert (d[k][3] & 2) == 0                    # kMesh is clear on the host
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8))
+    it.integrate(frames[2][0][0], frames[2][0][1], *empty)   # any drop-in call: the mirror learns which bits the consumers cleared
+    assert m.dropin_stats()["uploaded_blocks"] == 0
+    m.tsdf_block_set(k, d[k][0], d[k][1], d[k][2], 7)   # same voxels, all bits set again
+    it.integrate(frames[2][0][0], frames[2][0][1], frames[2][1], frames[2][2])
+    assert m.dropin_stats()["uploaded_blocks"] == 1

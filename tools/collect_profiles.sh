@@ -7,21 +7,22 @@ R=$PWD
 OUT=$R/gpurun_out/profiles_new
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-COMMON="--no-cpu-baseline --no-extras --mirror-frames 0 --profile-frames 0"
+COMMON="--no-cpu-baseline --no-extras --no-host-path --mirror-frames 0 --profile-frames 0"
 stats() {  # name, bench args...
   local name=$1; shift
   rm -rf /tmp/p_$name
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -- python $R/bench.py $COMMON "$@" > $OUT/${name}_bench.log 2>&1
   cp /tmp/p_$name/*/*kernel_stats.csv $OUT/${name}_kernel_stats.csv
 }
-stats fast --steps 40 --warmup 5
+stats fast --steps 20 --warmup 5
 stats esdf --esdf --steps 20 --warmup 3 --esdf-fidelity-frames 0
 stats merged_cow --integrator merged --scene cow --steps 20 --warmup 3
 stats simple --integrator simple --steps 6 --warmup 2
 stats sensors4 --workload sensors4 --steps 2 --warmup 1
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/p_$C -- python $R/bench.py $COMMON --steps 8 --warmup 2 > $OUT/pmc_$C.log 2>&1
+  # the driver-shaped command (20 timed steps after 5 warm-up steps): the summary keeps the timed frames only
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/p_$C -- python $R/bench.py $COMMON --steps 20 --warmup 5 > $OUT/pmc_$C.log 2>&1
   cp /tmp/p_$C/*/*counter_collection.csv $OUT/pmc_${C}_counter_collection.csv
 done
 cd $R

@@ -4,8 +4,8 @@ usage: python tools/summarize_profiles.py gpurun_out/profiles_new r02"""
 import collections, csv, json, os, re, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
-FRAMES = {"fast": 40, "esdf": 20, "merged_cow": 20, "simple": 6, "sensors4": 2}
-WHAT = {"fast": "BASELINE configs[1]: Fast integrator, 640x480 room stream, 0.05 m (frames 5..44)",
+FRAMES = {"fast": 20, "esdf": 20, "merged_cow": 20, "simple": 6, "sensors4": 2}
+WHAT = {"fast": "BASELINE configs[1]: Fast integrator, 640x480 room stream, 0.05 m (the driver-shaped run: frames 5..24 timed after 5 warm-up frames)",
         "esdf": "BASELINE configs[3]: Fast + EsdfIntegrator::updateFromTsdfLayer(true) per frame",
         "merged_cow": "BASELINE configs[2]: Merged integrator, cow-and-lady-like orbit",
         "simple": "Simple integrator on the room stream",
@@ -47,22 +47,30 @@ for name, frames in FRAMES.items():
     print("\n".join(lines[:16]))
 
 per = {}
-frames_pmc = 10
+PMC_WARMUP, PMC_STEPS = 5, 20  # the driver-shaped command; only the timed frames are kept
+frames_pmc = PMC_STEPS
 for name, col in (('FETCH_SIZE', 'FETCH_SIZE'), ('WRITE_SIZE', 'WRITE_SIZE')):
     f = f'{src}/pmc_{name}_counter_collection.csv'
     if not os.path.exists(f):
         continue
-    for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] != col:
+    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == col]
+    rows.sort(key=lambda r: int(r.get('Dispatch_Id', 0)))
+    frame = -1  # every frame starts with exactly one k_prep_points launch
+    for r in rows:
+        k = short(r['Kernel_Name'])
+        if k == 'k_prep_points':
+            frame += 1
+        if frame < PMC_WARMUP or frame >= PMC_WARMUP + PMC_STEPS:
             continue
-        d = per.setdefault(short(r['Kernel_Name']), {'launches': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
+        d = per.setdefault(k, {'launches': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
         d[col] += float(r['Counter_Value'])
         if name == 'FETCH_SIZE':
             d['launches'] += 1
 if per:
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
-                      "--no-cpu-baseline --no-extras --mirror-frames 0 --profile-frames 0 --steps 8 --warmup 2 (two separate passes)",
+                      "--no-cpu-baseline --no-extras --no-host-path --mirror-frames 0 --profile-frames 0 --steps 20 --warmup 5 (two separate passes)",
            "frames": frames_pmc,
+           "frames_desc": "frames 5..24 of the stream = the 20 timed steps of the driver's `bench.py --steps 20 --warmup 5` (warm-up frames dropped by dispatch order)",
            "units": "rocprofv3 reports KB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE halves wide coalesced (16 B/lane) "
                     "streams; these kernels read 4-8 B/lane, left uncorrected; Infinity-Cache hits are counted",
            "per_frame_bytes": {}}

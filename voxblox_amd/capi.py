@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_get_map_cfg", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
-    "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_remove_distant_blocks",
+    "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_blocks_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
     "vbx_selftest_unordered_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
@@ -67,7 +67,7 @@ class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("points", "rays_cast", "voxel_updates", "voxels_touched", "blocks_allocated",
                  "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps", "replay_rounds",
-                 "replay_block_rounds")]
+                 "replay_block_rounds", "time_budget_exceeded")]
 
 
 class Timing(C.Structure):
@@ -138,6 +138,7 @@ def lib():
         "vbx_block_upload": (C.c_int, [vp, C.c_int, i32p, vp, C.c_uint8, C.c_uint8]),
         "vbx_blocks_upload": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, vp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
         "vbx_block_remove": (C.c_int, [vp, C.c_int, i32p]),
+        "vbx_blocks_remove": (C.c_int, [vp, C.c_int, i32p, C.c_size_t]),
         "vbx_remove_distant_blocks": (C.c_int, [vp, C.c_int, f32p, C.c_double]),
         "vbx_clear": (C.c_int, [vp, C.c_int]),
         "vbx_clear_updated": (C.c_int, [vp, C.c_int, C.c_int]),
@@ -385,6 +386,11 @@ class Map:
     def block_remove(self, idx, layer=LAYER_TSDF):
         idx = np.ascontiguousarray(idx, np.int32)
         self._chk(self.L.vbx_block_remove(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def blocks_remove(self, idx, layer=LAYER_TSDF):
+        """Layer::removeBlock for a list of BlockIndex rows: one pass over the pool."""
+        idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 3)
+        self._chk(self.L.vbx_blocks_remove(self.h, layer, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.shape[0]))
 
     def remove_distant_blocks(self, center, max_distance, layer=LAYER_TSDF):
         c = np.ascontiguousarray(center, np.float32)

@@ -11,6 +11,7 @@ struct vbx_ctx {
   uint32_t hcap = 0;
   uint32_t pool_limit = 0;   // vbx_set_pool_limit: the pool never grows beyond this many blocks (0: no limit)
   uint32_t pool_grown = 0;   // times the pool doubled
+  bool warned_time_budget = false;  // Fast: max_integration_time_s overrun reported once
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   DevState* d_state = nullptr;

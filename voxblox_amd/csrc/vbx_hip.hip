@@ -600,42 +600,31 @@ static int reclaim_slots(vbx_ctx* ctx) {
   return VBX_OK;
 }
 
-static int remove_slot(vbx_ctx* ctx, int layer, uint32_t slot) {
-  // The block is zeroed and leaves the layer; the other layer's membership of the slot is untouched (the
-  // layers are independent, layer.h:167).  reclaim_slots() then frees the slot if nothing is left in it.
-  MapDev& m = ctx->map;
-  const uint32_t nv = m.nvox;
-  uint32_t f;
-  HIP_TRY(hipMemcpy(&f, m.blk_flags + slot, 4, hipMemcpyDeviceToHost));
-  if (layer == VBX_LAYER_ESDF) {
-    if (!ctx->esdf_init) return VBX_OK;
-    HIP_TRY(hipMemset(ctx->b_edist.as<float>() + (size_t)slot * nv, 0, nv * 4));
-    HIP_TRY(hipMemset(ctx->b_estate.as<uint32_t>() + (size_t)slot * nv, 0, nv * 4));
-    f &= ~kEsdfBits;
-  } else {
-    HIP_TRY(hipMemset(m.dist + (size_t)slot * nv, 0, nv * 4));
-    HIP_TRY(hipMemset(m.weight + (size_t)slot * nv, 0, nv * 4));
-    HIP_TRY(hipMemset(m.rgba + (size_t)slot * nv, 0, nv * 4));
-    f &= kEsdfBits;
-  }
-  HIP_TRY(hipMemcpy(m.blk_flags + slot, &f, 4, hipMemcpyHostToDevice));
-  return reclaim_slots(ctx);
-}
-
-int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]) {
-  if (!ctx || !idx) return VBX_ERR_INVALID;
+// Layer::removeBlock for n blocks (layer.h:160-165): one lookup kernel, one removal kernel (a workgroup per listed
+// block), ONE reclaim pass — a host loop over single removals paid two read-backs and a pass over the pool each.
+int vbx_blocks_remove(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n) {
+  if (!ctx || (n && !idx)) return VBX_ERR_INVALID;
   if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {
     ctx->fail("unknown layer %d", layer);
     return VBX_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  uint32_t slot, hpos = 0;
-  int rc = find_slot_host(ctx, idx, &slot, &hpos);
+  if (n == 0) return VBX_OK;
+  if (layer == VBX_LAYER_ESDF && !ctx->esdf_init) return VBX_OK;  // no ESDF block exists
+  int rc = upload_idx(ctx, idx, n);
   if (rc) return rc;
-  if (slot == kInvalidSlot) return VBX_OK;  // unordered_map::erase of a missing key is a no-op
-  (void)hpos;
-  return remove_slot(ctx, layer, slot);
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, ctx->map, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
+                     ctx->b_rank.as<uint32_t>());
+  hipLaunchKernelGGL(k_remove_listed, dim3((unsigned)n), dim3(256), 0, s, ctx->map,
+                     ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,
+                     ctx->esdf_init ? ctx->b_estate.as<uint32_t>() : (uint32_t*)nullptr, layer, ctx->b_rank.as<uint32_t>());
+  return reclaim_slots(ctx);  // synchronises: idx is a caller-owned host buffer
+}
+
+int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]) {
+  if (!ctx || !idx) return VBX_ERR_INVALID;
+  return vbx_blocks_remove(ctx, layer, idx, 1);
 }
 
 int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance) {

@@ -231,11 +231,22 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
     HIP_TRY(hipStreamSynchronize(s));  // xs is a stack-lifetime staging buffer
     sp.xs = bx.as<float>();
     const size_t cube = (size_t)sp.n * sp.n * sp.n;
-    KLAUNCH(k_sphere_mark_blocks, grid_for(cube), dim3(256), 0, s, m, sp, ctx->b_newlist.as<uint32_t>(),
-                       ctx->d_state);
-    KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
-                       ctx->d_state);
-    KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    // Layer::allocateBlockPtrByIndex never fails (layer.h:133-160): a pass that runs out of pool slots doubles
+    // the pool and marks its blocks again, like every other allocating call (grow_pool also drops the keys the
+    // failed pass left without a slot; a refused growth leaves a consistent map and VBX_ERR_CAPACITY).
+    for (;;) {
+      KLAUNCH(k_sphere_mark_blocks, grid_for(cube), dim3(256), 0, s, m, sp, ctx->b_newlist.as<uint32_t>(),
+                         ctx->d_state);
+      KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m, ctx->b_newlist.as<uint32_t>(),
+                         ctx->d_state);
+      KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+      rc = sync_state(ctx);
+      if (rc) return rc;
+      if (!(ctx->h_state.error & 1u)) break;
+      rc = grow_pool(ctx);
+      if (rc) return rc;
+      e = esdf_dev(ctx);  // the ESDF arrays moved with the pool
+    }
     KLAUNCH(k_sphere_apply, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, pass);
   }
   ctx->esdf_robot_pending = true;

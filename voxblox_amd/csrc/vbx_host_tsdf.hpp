@@ -879,6 +879,14 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters = vbx_counters{};
   ctx->counters.points = n;
   if (n == 0) return kind == VBX_TSDF_FAST ? fast_frame_tick(ctx, cfg) : VBX_OK;
+  // FastTsdfIntegrator stops taking points once max_integration_time_s of wall clock are used up
+  // (tsdf_integrator.cc:496-499; Simple and Merged have no such check).  A budget that is already spent at the
+  // first point (<= 0, NaN) integrates nothing, exactly like the reference; a positive one is compared with
+  // the call's wall time afterwards: the device path cannot stop half way through a frame, so a call that ran
+  // past its budget says so (counters.time_budget_exceeded, one warning per handle) instead of pretending.
+  const bool has_budget = kind == VBX_TSDF_FAST && cfg->max_integration_time_s < 1.0e30f;
+  if (kind == VBX_TSDF_FAST && !(cfg->max_integration_time_s * 1000000.0f > 0.0f)) return fast_frame_tick(ctx, cfg);
+  const auto t_call0 = std::chrono::steady_clock::now();
   // per-call device counters
   KLAUNCH(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
   Pose T;
@@ -903,6 +911,19 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters.voxels_touched = 0;
   for (int i = 0; i < 64; ++i) ctx->counters.voxels_touched += ctx->h_state.voxels_touched[i];
   ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
+  if (has_budget) {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
+    if (!(us < (double)cfg->max_integration_time_s * 1000000.0)) {
+      ctx->counters.time_budget_exceeded = 1;
+      if (!ctx->warned_time_budget) {
+        ctx->warned_time_budget = true;
+        fprintf(stderr, "[vbx] FastTsdfIntegrator: the frame took %.0f us, max_integration_time_s allows %.0f us; the "
+                        "reference would have dropped the rest of the cloud, the device path integrated all of it "
+                        "(reported once; see vbx_counters.time_budget_exceeded)\n", us,
+                (double)cfg->max_integration_time_s * 1000000.0);
+      }
+    }
+  }
 #ifdef VBX_FOLD_STATS  // measurement build (tools/fold_stats.py): chunks of k_fold_long by case
   ctx->counters.iterations = ctx->h_state.act_count[0];
   ctx->counters.esdf_blocks = ctx->h_state.act_count[1];

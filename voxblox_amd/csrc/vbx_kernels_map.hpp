@@ -380,6 +380,28 @@ __global__ void k_remove_distant(MapDev m, float* edist, uint32_t* estate, int l
   }
 }
 
+// Layer::removeBlock for a list of blocks (layer.h:160-165), one workgroup per listed block: slots[b] = the block's
+// pool slot or kInvalidSlot (unordered_map::erase of a missing key is a no-op).  Same effect per block as
+// k_remove_distant; a BlockIndex listed twice is harmless (the second workgroup writes the same zeros).
+__global__ void k_remove_listed(MapDev m, float* edist, uint32_t* estate, int layer, const uint32_t* __restrict__ slots) {
+  const uint32_t slot = slots[blockIdx.x];
+  if (slot == kInvalidSlot) return;
+  const uint32_t f = m.blk_flags[slot];
+  const uint32_t need = (layer == VBX_LAYER_ESDF) ? kFlagEsdfAlloc : kFlagPublished;
+  if (!(f & need)) return;
+  const size_t base = (size_t)slot * m.nvox;
+  if (layer == VBX_LAYER_ESDF) {
+    if (edist)
+      for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) { edist[base + v] = 0.f; estate[base + v] = 0u; }
+  } else {
+    for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
+      m.dist[base + v] = 0.f; m.weight[base + v] = 0.f; m.rgba[base + v] = 0u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) m.blk_flags[slot] = (layer == VBX_LAYER_ESDF) ? (f & ~kEsdfBits) : (f & kEsdfBits);
+}
+
 // Block::updated().reset(bits) on every block of one layer
 __global__ void k_clear_update_bits(MapDev m, uint32_t n_slots, uint32_t need, uint32_t bits) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;

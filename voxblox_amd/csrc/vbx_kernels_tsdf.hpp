@@ -110,7 +110,10 @@ __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __r
     // (a clearing ray is cut to max_ray_length_m from the sensor, integrator_utils.cc:80-86: a far no-return
     // sentinel is as harmless as in the reference, what counts is where the sensor is)
     const float lim = 1048576.0f - (c.trunc + c.max_ray_length_m) * voxel_size_inv - 8.0f;
-    const f3 q = clearing ? c.origin : pg;
+    // Merged bundles clearing points by their ENDPOINT voxel (tsdf_integrator.cc:352-367; pcx != nullptr marks
+    // that caller): there the endpoint itself must fit the key, or distinct far endpoints would alias into one
+    // bundle — such a cloud fails loudly instead.
+    const f3 q = (clearing && !pcx) ? c.origin : pg;
     const float far = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) * voxel_size_inv;
     if (far >= lim && far < __builtin_inff()) {  // non-finite points are dropped further down
       atomicOr(&st->error, 8u);

@@ -27,7 +27,7 @@ struct vbx_shard {
   int32_t* d_keys_send = nullptr;
   int32_t* d_keys_recv = nullptr;
   size_t ks_cap = 0, kr_cap = 0;      // rows
-  unsigned long long* d_counts = nullptr;  // world*world
+  unsigned long long* d_counts = nullptr;  // world rows of [counts to each rank..., status]
   vbx_shard_stats stats{};
   std::string err;
   void fail(const char* fmt, ...) {
@@ -114,7 +114,7 @@ vbx_shard* vbx_shard_create(vbx_ctx* persistent, vbx_ctx* delta, int rank, int w
     ncclUniqueId u;
     std::memcpy(u.internal, id, VBX_SHARD_ID_BYTES);
     ok = ncclCommInitRank(&s->comm, world, u, rank) == ncclSuccess &&
-         hipMalloc((void**)&s->d_counts, (size_t)world * world * sizeof(unsigned long long)) == hipSuccess;
+         hipMalloc((void**)&s->d_counts, (size_t)world * (world + 1) * sizeof(unsigned long long)) == hipSuccess;
   }
   if (!ok) {
     g_err = "vbx_shard_create: stream / RCCL communicator initialisation failed";
@@ -156,9 +156,11 @@ int vbx_shard_integrate(vbx_shard* s, int kind, const vbx_tsdf_cfg* cfg, const f
   return VBX_OK;
 }
 
-int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, float max_weight) {
-  if (!s) return VBX_ERR_INVALID;
-  HIPS(hipSetDevice(s->device));
+// Everything a rank does BEFORE the first collective of a step: list the delta's blocks grouped by owner and export
+// their weighted sums.  A failure here must not leave the other ranks blocked in the collectives, so the status
+// travels with the group sizes (vbx_shard_end_step).
+static int prepare_step(vbx_shard* s, std::vector<int32_t>& send_keys, std::vector<size_t>& send_counts,
+                        std::vector<size_t>& sdispl, size_t* n_out) {
   // 1. the blocks this step's deltas touched, grouped by owner, (z,y,x) order inside a group
   size_t n = 0;
   VBXS(s->d, vbx_num_blocks(s->d, VBX_LAYER_TSDF, &n));
@@ -166,14 +168,14 @@ int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, 
   if (n) VBXS(s->d, vbx_block_indices(s->d, VBX_LAYER_TSDF, idx.data(), n, &n));  // ascending (z,y,x)
   const int W = s->world;
   std::vector<int> owner(n);
-  std::vector<size_t> send_counts(W, 0);
+  send_counts.assign(W, 0);
   for (size_t i = 0; i < n; ++i) {
     owner[i] = vbx_shard_owner_of(&idx[3 * i], W);
     ++send_counts[owner[i]];
   }
-  std::vector<size_t> sdispl(W + 1, 0);
+  sdispl.assign(W + 1, 0);
   for (int r = 0; r < W; ++r) sdispl[r + 1] = sdispl[r] + send_counts[r];
-  std::vector<int32_t> send_keys(3 * std::max<size_t>(n, 1));
+  send_keys.assign(3 * std::max<size_t>(n, 1), 0);
   {
     std::vector<size_t> cur(sdispl.begin(), sdispl.end() - 1);
     for (size_t i = 0; i < n; ++i) {  // stable: the (z,y,x) order survives inside every group
@@ -182,37 +184,68 @@ int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, 
     }
   }
   // 2. their weighted sums, in the same order
-  const size_t nvox = s->nvox;
-  int rc = grow(s, &s->d_send, &s->send_cap, n, 6 * nvox);
+  int rc = grow(s, &s->d_send, &s->send_cap, n, 6 * s->nvox);
   if (rc) return rc;
   if (n) VBXS(s->d, vbx_blocks_export_sums(s->d, send_keys.data(), n, s->d_send));
+  *n_out = n;
+  return VBX_OK;
+}
+
+int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, float max_weight) {
+  if (!s) return VBX_ERR_INVALID;
+  HIPS(hipSetDevice(s->device));
+  const int W = s->world;
+  std::vector<int32_t> send_keys;
+  std::vector<size_t> send_counts, sdispl;
+  size_t n = 0;
+  const int local_rc = prepare_step(s, send_keys, send_counts, sdispl, &n);
+  if (!s->comm) {
+    if (local_rc) return local_rc;
+  }
+  const size_t nvox = s->nvox;
   const float* d_in = s->d_send;
   std::vector<int32_t> recv_keys;
   size_t n_recv = n;
   if (!s->comm) {
     recv_keys = send_keys;
   } else {
-    // 3. group sizes: all-gather of every rank's send_counts row -> counts[sender][dest]
-    std::vector<unsigned long long> row(W);
-    for (int r = 0; r < W; ++r) row[r] = send_counts[r];
-    HIPS(hipMemcpyAsync(s->d_counts + (size_t)s->rank * W, row.data(), W * sizeof(unsigned long long), hipMemcpyHostToDevice, s->stream));
-    NCCLS(ncclAllGather(s->d_counts + (size_t)s->rank * W, s->d_counts, W, ncclUint64, s->comm, s->stream));
-    std::vector<unsigned long long> all((size_t)W * W);
+    // 3. group sizes: all-gather of every rank's row [send_counts..., status] -> counts[sender][dest], status[sender].
+    //    A rank that failed locally sends zero counts and its error code: every rank sees it in the same
+    //    collective and all of them leave the step together (no rank is left waiting in the all-to-all).
+    const size_t RW = (size_t)W + 1;
+    std::vector<unsigned long long> row(RW, 0ull);
+    if (local_rc == VBX_OK)
+      for (int r = 0; r < W; ++r) row[r] = send_counts[r];
+    row[W] = (unsigned long long)(long long)local_rc;
+    HIPS(hipMemcpyAsync(s->d_counts + (size_t)s->rank * RW, row.data(), RW * sizeof(unsigned long long), hipMemcpyHostToDevice, s->stream));
+    NCCLS(ncclAllGather(s->d_counts + (size_t)s->rank * RW, s->d_counts, RW, ncclUint64, s->comm, s->stream));
+    std::vector<unsigned long long> all((size_t)W * RW);
     HIPS(hipMemcpyAsync(all.data(), s->d_counts, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIPS(hipStreamSynchronize(s->stream));
+    for (int r = 0; r < W; ++r) {
+      const int st = (int)(long long)all[(size_t)r * RW + W];
+      if (st != VBX_OK) {
+        if (r != s->rank) s->fail("vbx_shard_end_step: rank %d failed before the exchange (status %d); step abandoned on every rank", r, st);
+        return local_rc ? local_rc : st;
+      }
+    }
     std::vector<size_t> recv_counts(W), rdispl(W + 1, 0);
     for (int r = 0; r < W; ++r) {
-      recv_counts[r] = (size_t)all[(size_t)r * W + s->rank];
+      recv_counts[r] = (size_t)all[(size_t)r * RW + s->rank];
       rdispl[r + 1] = rdispl[r] + recv_counts[r];
     }
     n_recv = rdispl[W];
-    // 4. BlockIndex rows, then the sums: sparse all-to-all-v (rows arrive grouped by sender rank)
-    rc = grow(s, &s->d_keys_send, &s->ks_cap, n, 3);
-    if (rc) return rc;
-    rc = grow(s, &s->d_keys_recv, &s->kr_cap, n_recv, 3);
-    if (rc) return rc;
-    rc = grow(s, &s->d_recv, &s->recv_cap, n_recv, 6 * nvox);
-    if (rc) return rc;
+    // 4. BlockIndex rows, then the sums: sparse all-to-all-v (rows arrive grouped by sender rank).  The only local
+    //    failure left between here and the collectives is device memory for the receive side: that rank aborts the
+    //    communicator, so that the others' collectives return an error instead of waiting for it.
+    int rc = grow(s, &s->d_keys_send, &s->ks_cap, n, 3);
+    if (!rc) rc = grow(s, &s->d_keys_recv, &s->kr_cap, n_recv, 3);
+    if (!rc) rc = grow(s, &s->d_recv, &s->recv_cap, n_recv, 6 * nvox);
+    if (rc) {
+      (void)ncclCommAbort(s->comm);
+      s->comm = nullptr;
+      return rc;
+    }
     if (n) HIPS(hipMemcpyAsync(s->d_keys_send, send_keys.data(), n * 12, hipMemcpyHostToDevice, s->stream));
     std::vector<size_t> sc(W), sd(W), rcn(W), rd(W);
     for (int r = 0; r < W; ++r) { sc[r] = send_counts[r] * 3; sd[r] = sdispl[r] * 3; rcn[r] = recv_counts[r] * 3; rd[r] = rdispl[r] * 3; }

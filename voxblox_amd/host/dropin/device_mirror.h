@@ -19,33 +19,67 @@
 
 #include <vbx_hip.h>
 
+#include "voxblox/core/block_hash.h"
 #include "voxblox/core/layer.h"
 #include "voxblox/core/voxel.h"
 
 namespace voxblox {
 namespace hip {
 
+/// What the mirror last left in (or last took from) one host block: the Block object's address (kReplace /
+/// removeBlock + re-allocate put a NEW object under the same BlockIndex, layer_inl.h:203-210), its Update bits
+/// (consumers only ever clear bits: mesh_integrator.h:181, esdf_integrator.cc:116-118; bits that appear were set
+/// by the host — Block::mergeBlock block_inl.h:120, Layer::addBlockFromProto layer_inl.h:227) and a sampled
+/// fingerprint of the voxel array (in-place writes without any marker: deserializeMsgToLayer's kUpdate,
+/// conversions_inl.h:80-88).
+struct HostBlockRecord {
+  const void* block = nullptr;
+  uint8_t bits = 0;
+  uint64_t fingerprint = 0;
+};
+typedef AnyIndexHashMapType<HostBlockRecord>::type HostBlockRecords;  // block_hash.h:33-41
+
 struct DeviceMirror {
   vbx_ctx* ctx = nullptr;
   const Layer<EsdfVoxel>* esdf_layer = nullptr;  // set by the EsdfIntegrator that shares the map
   bool esdf_pending = false;                     // addNewRobotPosition since the last update
+  uint64_t last_use = 0;                         // LRU stamp of the association table
+  HostBlockRecords tsdf_known, esdf_known;       // the blocks the device holds, as the host last saw them
   std::vector<TsdfVoxel> tsdf_staging;
   std::vector<EsdfVoxel> esdf_staging;
   std::vector<int32_t> idx;
   std::vector<uint8_t> bits, has_data;
+  // reconcile statistics (tests, INTEGRATION.md figures)
+  uint64_t uploaded_blocks = 0, removed_blocks = 0;
 };
 
-/// The device map of a host TSDF layer (created on first use; a host layer without blocks resets it:
-/// a fresh Layer at a recycled address, or removeAllBlocks()).
+/// The device map of a host TSDF layer (created on first use).  The association table is keyed by the layer's
+/// address and bounded: beyond kMaxMirrors live entries the least recently used one is dropped — safe, because
+/// the host layer is coherent after every call and a layer that comes back is uploaded again by reconcile*().
 DeviceMirror& mirrorOf(Layer<TsdfVoxel>* tsdf_layer);
-/// Drops the association (call before destroying a Layer whose address may be reused while blocks remain).
+/// Drops the association and frees the device map (a Layer has no destructor hook the drop-in could use).
 void releaseMirror(const Layer<TsdfVoxel>* tsdf_layer);
 
-/// Copies every TSDF block carrying the kMap bit on the device into the host layer (AoS voxels,
-/// updated bits, has_data) and clears the device's kMap bits (they double as the mirror's dirty set).
+/// HOST -> DEVICE, on entry to every drop-in call.  The host Layer is the source of truth between calls: its
+/// callers edit it directly (Layer::removeDistantBlocks tsdf_server.cc:315, removeAllBlocks, io::LoadBlocksFromFile
+/// :566-578, deserializeMsgToLayer :639-653).  Blocks the host no longer has are removed on the device
+/// (vbx_blocks_remove), blocks that are new, replaced, carry Update bits the mirror did not leave, or whose
+/// sampled voxel fingerprint moved are uploaded (vbx_blocks_upload) — one batched call each.
+void reconcileTsdfFromHost(DeviceMirror& dev, Layer<TsdfVoxel>* tsdf_layer);
+void reconcileEsdfFromHost(DeviceMirror& dev, Layer<EsdfVoxel>* esdf_layer);
+
+/// DEVICE -> HOST, on return: copies every TSDF block carrying the kMap bit on the device into the host layer
+/// (AoS voxels, updated bits, has_data) and clears the device's kMap bits (they double as the mirror's dirty set).
 void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* tsdf_layer);
 /// The same for ESDF blocks.
 void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* esdf_layer);
+
+/// Reconcile counters of a layer's mirror (0 if none): blocks uploaded to / removed from the device so far.
+void mirrorStats(const Layer<TsdfVoxel>* tsdf_layer, uint64_t* uploaded_blocks, uint64_t* removed_blocks);
+
+/// Sampled fingerprint of a block's voxel array: `lines` 64-byte lines spread evenly over the array
+/// (VBX_DROPIN_FINGERPRINT_LINES, default 8; 0 = every line).
+uint64_t voxelFingerprint(const void* voxels, size_t bytes);
 
 }  // namespace hip
 }  // namespace voxblox

@@ -38,6 +38,10 @@ void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
     const EsdfVoxel* src = dev.esdf_staging.data() + i * nv;
     for (size_t v = 0; v < nv; ++v) block->getVoxelByLinearIndex(v) = src[v];
     block->updated() |= std::bitset<Update::kCount>(dev.bits[i]);  // set_updated(true): kMap only (:147)
+    HostBlockRecord& rec = dev.esdf_known[bi];
+    rec.block = block.get();
+    rec.bits = static_cast<uint8_t>(block->updated().to_ulong());
+    rec.fingerprint = voxelFingerprint(&block->getVoxelByLinearIndex(0), nv * sizeof(EsdfVoxel));
   }
   CHECK_EQ(vbx_clear_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP), VBX_OK) << vbx_last_error(dev.ctx);
 }
@@ -75,6 +79,8 @@ EsdfIntegrator::EsdfIntegrator(const Config& config, Layer<TsdfVoxel>* tsdf_laye
 
 void EsdfIntegrator::addNewRobotPosition(const Point& position) {
   hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::reconcileTsdfFromHost(dev, tsdf_layer_);
+  hip::reconcileEsdfFromHost(dev, esdf_layer_);
   const vbx_esdf_cfg cfg = hip::toC(config_);
   CHECK_EQ(vbx_esdf_add_new_robot_position(dev.ctx, &cfg, position.data()), VBX_OK) << vbx_last_error(dev.ctx);
   dev.esdf_pending = true;
@@ -86,8 +92,10 @@ void EsdfIntegrator::addNewRobotPosition(const Point& position) {
 
 void EsdfIntegrator::updateFromTsdfLayerBatch() {
   hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::reconcileTsdfFromHost(dev, tsdf_layer_);  // a TSDF layer that was LOADED, not integrated (esdf_server, tsdf_to_esdf)
   const vbx_esdf_cfg cfg = hip::toC(config_);
   esdf_layer_->removeAllBlocks();  // esdf_integrator.cc:95
+  dev.esdf_known.clear();          // the batch update drops the device's ESDF layer as well
   CHECK_EQ(vbx_esdf_update(dev.ctx, &cfg, /*batch=*/1, /*clear_updated_flag=*/0), VBX_OK) << vbx_last_error(dev.ctx);
   dev.esdf_pending = false;
   updated_blocks_.clear();
@@ -96,6 +104,8 @@ void EsdfIntegrator::updateFromTsdfLayerBatch() {
 
 void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
   hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::reconcileTsdfFromHost(dev, tsdf_layer_);
+  hip::reconcileEsdfFromHost(dev, esdf_layer_);
   const vbx_esdf_cfg cfg = hip::toC(config_);
   if (dev.esdf_pending && updated_blocks_.empty())  // clear() since addNewRobotPosition
     CHECK_EQ(vbx_esdf_integrator_clear(dev.ctx), VBX_OK) << vbx_last_error(dev.ctx);
@@ -113,6 +123,8 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
 
 void EsdfIntegrator::updateFromTsdfBlocks(const BlockIndexList& tsdf_blocks, bool incremental) {
   hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::reconcileTsdfFromHost(dev, tsdf_layer_);
+  hip::reconcileEsdfFromHost(dev, esdf_layer_);
   const vbx_esdf_cfg cfg = hip::toC(config_);
   std::vector<int32_t> idx;
   idx.reserve(3 * tsdf_blocks.size());

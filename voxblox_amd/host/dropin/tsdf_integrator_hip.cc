@@ -10,6 +10,8 @@
 // (abort), the reference's own error convention.
 #include "voxblox/integrator/tsdf_integrator.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -24,37 +26,187 @@ std::map<const void*, DeviceMirror*>& table() {
   static std::map<const void*, DeviceMirror*> t;
   return t;
 }
+constexpr size_t kMaxMirrors = 8;       // live (layer address -> device map) associations before the LRU one goes
+constexpr uint32_t kInitialBlocks = 4096;  // initial pool of a mirror (~200 MB at vps 16); it doubles on demand
+uint64_t g_tick = 0;
+
+void destroyMirror(DeviceMirror* m) {
+  if (m->ctx) vbx_destroy(m->ctx);
+  delete m;
+}
+
+// (No cleanup at process exit: the HIP runtime may already be gone when static destructors run; the driver frees
+// a dying process's device memory.  Long-lived processes drop maps through releaseMirror() or the LRU bound.)
+
+int fingerprintLines() {
+  static const int lines = [] {
+    const char* e = getenv("VBX_DROPIN_FINGERPRINT_LINES");
+    return e ? atoi(e) : 8;
+  }();
+  return lines;
+}
 }  // namespace
+
+uint64_t voxelFingerprint(const void* voxels, size_t bytes) {
+  // 64-byte lines at evenly spread positions, eight 8-byte words each, folded with a multiply-xorshift.  A
+  // whole-block overwrite (deserializeFromIntegers, mergeBlock) moves it with near certainty; a single-voxel
+  // poke between two sampled lines does not — VBX_DROPIN_FINGERPRINT_LINES=0 reads every line.
+  const size_t n_lines = bytes / 64;
+  const int want = fingerprintLines();
+  const size_t lines = (want <= 0 || (size_t)want > n_lines) ? n_lines : (size_t)want;
+  const unsigned char* base = static_cast<const unsigned char*>(voxels);
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
+  for (size_t k = 0; k < lines; ++k) {
+    const size_t line = (lines == n_lines) ? k : (k * n_lines) / lines + (n_lines / lines) / 2;
+    uint64_t w[8];
+    std::memcpy(w, base + line * 64, 64);
+    for (int j = 0; j < 8; ++j) {
+      h ^= w[j] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+      h *= 0xFF51AFD7ED558CCDull;
+      h ^= h >> 29;
+    }
+  }
+  return h;
+}
 
 DeviceMirror& mirrorOf(Layer<TsdfVoxel>* layer) {
   CHECK_NOTNULL(layer);
   std::lock_guard<std::mutex> lock(g_mu);
   DeviceMirror*& m = table()[layer];
+  if (m != nullptr) {  // a different Layer at a recycled address: the geometry tells
+    vbx_map_cfg have;
+    CHECK_EQ(vbx_get_map_cfg(m->ctx, &have), VBX_OK) << vbx_last_error(m->ctx);
+    if (have.voxel_size != layer->voxel_size() || have.voxels_per_side != layer->voxels_per_side()) {
+      destroyMirror(m);
+      m = nullptr;
+    }
+  }
   if (m == nullptr) {
     m = new DeviceMirror;
     vbx_map_cfg cfg;
     cfg.voxel_size = layer->voxel_size();
     cfg.voxels_per_side = static_cast<uint32_t>(layer->voxels_per_side());
-    cfg.max_blocks = 0;
+    cfg.max_blocks = kInitialBlocks;
     m->ctx = vbx_create(&cfg, /*device=*/0);
     CHECK(m->ctx != nullptr) << vbx_last_error(nullptr);
-  } else if (layer->getNumberOfAllocatedBlocks() == 0u) {
-    // the host layer is the source of truth for existence: an empty one means removeAllBlocks() or a
-    // new Layer at a recycled address
-    size_t n = 0;
-    CHECK_EQ(vbx_num_blocks(m->ctx, VBX_LAYER_TSDF, &n), VBX_OK) << vbx_last_error(m->ctx);
-    if (n) CHECK_EQ(vbx_clear(m->ctx, VBX_LAYER_TSDF), VBX_OK) << vbx_last_error(m->ctx);
+    if (table().size() > kMaxMirrors) {  // bound the table: drop the least recently used association
+      const void* victim = nullptr;
+      uint64_t oldest = ~0ull;
+      for (auto& kv : table())
+        if (kv.first != layer && kv.second && !kv.second->esdf_pending && kv.second->last_use < oldest) {
+          oldest = kv.second->last_use;
+          victim = kv.first;
+        }
+      if (victim) {
+        destroyMirror(table()[victim]);
+        table().erase(victim);
+      }
+    }
   }
-  return *m;
+  DeviceMirror& dev = *table()[layer];
+  dev.last_use = ++g_tick;
+  return dev;
 }
 
 void releaseMirror(const Layer<TsdfVoxel>* layer) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = table().find(layer);
   if (it == table().end()) return;
-  vbx_destroy(it->second->ctx);
-  delete it->second;
+  destroyMirror(it->second);
   table().erase(it);
+}
+
+void mirrorStats(const Layer<TsdfVoxel>* layer, uint64_t* uploaded_blocks, uint64_t* removed_blocks) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = table().find(layer);
+  if (uploaded_blocks) *uploaded_blocks = it == table().end() ? 0 : it->second->uploaded_blocks;
+  if (removed_blocks) *removed_blocks = it == table().end() ? 0 : it->second->removed_blocks;
+}
+
+namespace {
+// Shared by the two layers: which host blocks must go up, which device blocks must go.
+template <typename VoxelType>
+void reconcileFromHost(DeviceMirror& dev, Layer<VoxelType>* layer, int vbx_layer, HostBlockRecords* known,
+                       std::vector<VoxelType>* staging) {
+  const size_t nv = layer->voxels_per_side() * layer->voxels_per_side() * layer->voxels_per_side();
+  if (layer->getNumberOfAllocatedBlocks() == 0u) {  // removeAllBlocks(), or a new Layer at a recycled address
+    if (!known->empty()) {
+      CHECK_EQ(vbx_clear(dev.ctx, vbx_layer), VBX_OK) << vbx_last_error(dev.ctx);
+      dev.removed_blocks += known->size();
+      known->clear();
+    }
+    return;
+  }
+  BlockIndexList host_blocks;
+  layer->getAllAllocatedBlocks(&host_blocks);
+  // 1. blocks the host dropped (removeDistantBlocks, removeBlock)
+  if (known->size() > 0) {
+    std::vector<int32_t> gone;
+    for (auto it = known->begin(); it != known->end();) {
+      if (layer->hasBlock(it->first)) {
+        ++it;
+        continue;
+      }
+      gone.push_back(it->first.x());
+      gone.push_back(it->first.y());
+      gone.push_back(it->first.z());
+      it = known->erase(it);
+    }
+    if (!gone.empty()) {
+      CHECK_EQ(vbx_blocks_remove(dev.ctx, vbx_layer, gone.data(), gone.size() / 3), VBX_OK) << vbx_last_error(dev.ctx);
+      dev.removed_blocks += gone.size() / 3;
+    }
+  }
+  // 2. blocks the host created, replaced or wrote to
+  dev.idx.clear();
+  dev.bits.clear();
+  dev.has_data.clear();
+  std::vector<typename Block<VoxelType>::Ptr> up;
+  std::vector<uint64_t> up_fp;
+  for (const BlockIndex& bi : host_blocks) {
+    typename Block<VoxelType>::Ptr block = layer->getBlockPtrByIndex(bi);
+    const uint8_t bits = static_cast<uint8_t>(block->updated().to_ulong());
+    const uint64_t fp = voxelFingerprint(&block->getVoxelByLinearIndex(0), nv * sizeof(VoxelType));
+    auto it = known->find(bi);
+    if (it != known->end() && it->second.block == block.get() && (bits & ~it->second.bits) == 0 &&
+        it->second.fingerprint == fp) {
+      it->second.bits = bits;  // consumers cleared bits: remember, so that a later set() shows
+      continue;
+    }
+    up.push_back(block);
+    up_fp.push_back(fp);
+    dev.idx.push_back(bi.x());
+    dev.idx.push_back(bi.y());
+    dev.idx.push_back(bi.z());
+    // kMap is the MIRROR's dirty bit on the device (a block uploaded from the host is not dirty); kMesh / kEsdf
+    // travel: the device-side ESDF update must see a loaded block as updated (esdf_integrator.cc:104-110)
+    dev.bits.push_back(static_cast<uint8_t>(bits & ~VBX_UPDATE_MAP));
+    dev.has_data.push_back(block->has_data() ? 1 : 0);
+    HostBlockRecord& rec = (*known)[bi];
+    rec.block = block.get();
+    rec.bits = bits;
+    rec.fingerprint = fp;
+  }
+  if (up.empty()) return;
+  staging->resize(up.size() * nv);
+  for (size_t i = 0; i < up.size(); ++i)
+    std::memcpy(static_cast<void*>(staging->data() + i * nv), &up[i]->getVoxelByLinearIndex(0), nv * sizeof(VoxelType));
+  CHECK_EQ(vbx_blocks_upload(dev.ctx, vbx_layer, dev.idx.data(), up.size(), staging->data(), dev.bits.data(),
+                             dev.has_data.data()),
+           VBX_OK)
+      << vbx_last_error(dev.ctx);
+  dev.uploaded_blocks += up.size();
+}
+}  // namespace
+
+void reconcileTsdfFromHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
+  static_assert(sizeof(TsdfVoxel) == 12, "TsdfVoxel is {float distance; float weight; Color color}");
+  reconcileFromHost<TsdfVoxel>(dev, layer, VBX_LAYER_TSDF, &dev.tsdf_known, &dev.tsdf_staging);
+}
+
+void reconcileEsdfFromHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
+  static_assert(sizeof(EsdfVoxel) == 20, "EsdfVoxel is {float distance; bool observed, hallucinated, in_queue, fixed; Vector3i parent}");
+  reconcileFromHost<EsdfVoxel>(dev, layer, VBX_LAYER_ESDF, &dev.esdf_known, &dev.esdf_staging);
 }
 
 void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
@@ -83,6 +235,10 @@ void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
     // cleared since (mesher: kMesh, ESDF: kEsdf) come back only if the device set them again
     block->updated() |= std::bitset<Update::kCount>(dev.bits[i]);
     block->has_data() = dev.has_data[i] != 0;  // the integrators never set it
+    HostBlockRecord& rec = dev.tsdf_known[bi];
+    rec.block = block.get();
+    rec.bits = static_cast<uint8_t>(block->updated().to_ulong());
+    rec.fingerprint = voxelFingerprint(&block->getVoxelByLinearIndex(0), nv * sizeof(TsdfVoxel));
   }
   // kMap doubles as the mirror's dirty bit on the device; kMesh / kEsdf stay for the device-side
   // mesher / ESDF
@@ -125,6 +281,7 @@ void integrateOnDevice(int kind, const TsdfIntegratorBase::Config& config, Layer
                        bool freespace_points) {
   CHECK_EQ(points_C.size(), colors.size());  // tsdf_integrator.cc:247
   DeviceMirror& dev = mirrorOf(layer);
+  reconcileTsdfFromHost(dev, layer);  // removeDistantBlocks / loadMap / tsdfMapCallback since the last call
   const vbx_tsdf_cfg cfg = toC(config);
   const Point pos = T_G_C.getPosition();
   const auto& q = T_G_C.getRotation().toImplementation();  // Eigen::Quaternionf

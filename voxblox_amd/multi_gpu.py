@@ -55,6 +55,22 @@ def group_by_owner(keys, world):
     return np.ascontiguousarray(k[order]), counts
 
 
+def deal_sensor_units(world, n_sensors=4):
+    """BASELINE configs[4]'s ray-bundle shards: n_sensors x B contiguous bands, B = max(1, world / n_sensors),
+    dealt out in order (sensor-major).  Returns units[rank] = [(sensor, band, bands)]: world 1 holds everything,
+    world 4 one sensor each, world 8 half a sensor each."""
+    world = max(int(world), 1)
+    bands = max(1, world // n_sensors)
+    units = [(s, b, bands) for s in range(n_sensors) for b in range(bands)]
+    per = (len(units) + world - 1) // world
+    return [units[r * per:(r + 1) * per] for r in range(world)]
+
+
+def band_of(n_points, band, bands):
+    """[lo, hi) of a cloud's `band`-th of `bands` contiguous ray bands (row-major clouds: image stripes)."""
+    return band * n_points // bands, (band + 1) * n_points // bands
+
+
 class ShardedTsdfMap:
     """persistent / delta: objects with the small backend protocol used below
     (voxblox_amd.multi_gpu.GpuBackend for the HIP path)."""

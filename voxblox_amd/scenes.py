@@ -139,13 +139,13 @@ def room_frame(k, n_frames=100, f=320.0, width=W, height=H):
     return (pos.astype(np.float32), q.astype(np.float32)), pts, _colors(u, v, face + 1)
 
 
-def room_sensor_frame(sensor, step, n_steps=25):
+def room_sensor_frame(sensor, step, n_steps=25, f=320.0, width=W, height=H):
     """BASELINE config 5: four cameras at yaw 0/90/180/270 deg from (+-0.5, -0.2, +-0.5)."""
     th = np.pi / 2 * sensor + 2.0 * np.pi * step / (4.0 * n_steps)
     base = [(0.5, 0.5), (0.5, -0.5), (-0.5, -0.5), (-0.5, 0.5)][sensor % 4]
     pos = np.array([base[0], -0.2, base[1]])
     q = _quat_yaw_y(th)
-    d, u, v = pixel_dirs(320.0)
+    d, u, v = pixel_dirs(f, width=width, height=height, cx=width / 2.0, cy=height / 2.0)
     dG = d @ quat_to_R(q).T
     t, face = _box_interior_exit(pos, dG, ROOM_LO, ROOM_HI)
     pts = (d * t[:, None]).astype(np.float32)
