@@ -94,6 +94,16 @@ typedef struct vbx_esdf_cfg {
   int32_t add_occupied_crust;
   float clear_sphere_radius;
   float occupied_sphere_radius;
+  /* Not in the reference Config.  0 (default): order-free wavefronts run to their exact fixed points on the whole
+   * chip (bit-exact against the reference for batch updates with min_diff_m = 0, an envelope otherwise).
+   * 1: the reference's own order — updateFromTsdfBlocks' voxel walk, the FIFO raise queue, BucketQueue pop order
+   * with num_buckets / multi_queue, min_diff_m gating, updateVoxelFromNeighbors incl. its unscaled LUT distance,
+   * the sign-mismatch rule as written (esdf_integrator.cc:124-530, bucket_queue.h:41-80) — replayed sequentially by
+   * one wave: the reference's bits, at a fraction of the default path's speed.  The blocks are visited in the order
+   * of the list given to vbx_esdf_update_blocks; vbx_esdf_update visits them in ascending (z,y,x) order (the
+   * reference's order there is the iteration order of the caller's std::unordered_map — the drop-in passes it down).
+   * Not available while addNewRobotPosition work is pending (VBX_ERR_UNSUPPORTED). */
+  int32_t reference_order;
 } vbx_esdf_cfg;
 
 /* MeshIntegratorConfig, mesh/mesh_integrator.h:47-66 (integrator_threads has no meaning here). */
@@ -190,6 +200,11 @@ int vbx_esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const
 #define VBX_UPDATE_MAP 1
 #define VBX_UPDATE_MESH 2
 #define VBX_UPDATE_ESDF 4
+/* Not an Update::Status bit.  ESDF layer only: "voxels changed on the device since vbx_clear_updated(…, VBX_UPDATE_DIRTY)".
+ * The reference's wavefront writes neighbour blocks in place without flagging them (esdf_integrator.cc:305-496 only
+ * flags the blocks it classifies, :147); a host mirror must take those too.  Accepted by vbx_blocks_updated and
+ * vbx_clear_updated in update_mask; never reported in updated_bits. */
+#define VBX_UPDATE_DIRTY 8
 
 /* Layer::getNumberOfAllocatedBlocks / getAllAllocatedBlocks (layer.h:184-193, 205).  Indices
  * are returned in ascending (z,y,x) order. */

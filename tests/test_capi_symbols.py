@@ -56,7 +56,10 @@ def test_oracle_and_capi_defaults_agree(oracle):
     assert g.merged_bundle_order == 0 and g.fast_observed_set == 0
     oe, ge = oracle.esdf_cfg(), capi.esdf_cfg()
     for name, _ in capi.EsdfCfg._fields_:
+        if name == "reference_order":
+            continue   # HIP-only field; 0 = the order-free default path
         assert getattr(oe, name) == getattr(ge, name), name
+    assert ge.reference_order == 0
     assert oe.oracle_orderfree_sign_mismatch == 0  # oracle-only switch defaults to the reference
 
 

@@ -1,0 +1,179 @@
+"""-m gpu: EsdfIntegrator in the reference's own order on the HIP path (vbx_esdf_cfg.reference_order = 1,
+voxblox_amd/csrc/vbx_kernels_esdf_strict.hpp): processRaiseSet / processOpenSet with the BucketQueue's pop order,
+min_diff_m gating, updateVoxelFromNeighbors incl. its unscaled LUT distance and the sign-mismatch rule as written
+(esdf_integrator.cc:124-530, bucket_queue.h:41-80).  Bit-exact — distances, all four flags,
+parents, updated bits — against the reference build's golden digests (tests/golden/reference_digests.json, produced
+by the reference's own sources) and against the oracle on the same TSDF layer and the same block visiting order.
+
+The reference visits the updated TSDF blocks in the iteration order of the host Layer's std::unordered_map
+(layer.h:194-203); that order is an INPUT of the algorithm here: the tests take it from the oracle's container
+(which reproduces libstdc++'s order) and hand it to vbx_esdf_update_blocks, exactly as the drop-in hands down the
+order of the caller's host Layer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import scenarios as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+import json  # noqa: E402
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_digests.json")))["scenarios"]
+KIND = {"simple": 1, "merged": 2, "fast": 3}
+
+
+def _gpu_esdf_dict(gm):
+    from voxblox_amd import capi
+    g = {}
+    idx = gm.block_indices(capi.LAYER_ESDF)
+    if len(idx) == 0:
+        return g
+    v, u, _ = gm.blocks_download(idx, capi.LAYER_ESDF)
+    for k, i in enumerate(idx):
+        fl = (v[k]["observed"] | (v[k]["hallucinated"] << 1) | (v[k]["in_queue"] << 2) | (v[k]["fixed"] << 3)).astype(np.uint8)
+        g[tuple(int(x) for x in i)] = (v[k]["distance"].copy(), fl, v[k]["parent"].copy(), int(u[k]))
+    return g
+
+
+def _assert_same_esdf(g, o, what=""):
+    assert set(g) == set(o), (what, len(g), len(o), sorted(set(g) ^ set(o))[:4])
+    for k in o:
+        assert np.array_equal(g[k][1], o[k][1]), (what, k, "flags")
+        assert np.array_equal(g[k][0].view(np.uint32), o[k][0].view(np.uint32)), (what, k, "distance",
+                                                                                float(np.abs(g[k][0] - o[k][0]).max()))
+        assert np.array_equal(g[k][2], o[k][2]), (what, k, "parent")
+        assert g[k][3] == o[k][3], (what, k, "updated bits")
+
+
+def _updated_esdf_blocks_in_container_order(om):
+    """Layer::getAllUpdatedBlocks(Update::kEsdf) (layer.h:194-203) of the oracle's TSDF layer."""
+    out = []
+    for i in om.block_indices(0):
+        b = om.tsdf_block(i)
+        if b[3] & 4:
+            out.append(i)
+    return np.array(out, np.int32).reshape(-1, 3)
+
+
+def _lockstep(oracle, sc, esdf_kw, n_frames=None, list_mode="container", check_every_frame=True):
+    """TSDF integration + incremental ESDF update after every frame on both sides; returns the two maps."""
+    import ctypes as C
+    from voxblox_amd import capi
+    L = oracle.lib()
+    L.orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(sc["voxel"], 16)
+    oc = oracle.tsdf_cfg(default_truncation_distance=4 * sc["voxel"], integrator_threads=1, **sc["cfg"])
+    oi = om.tsdf_integrator(sc["kind"], oc)
+    oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=2 * sc["voxel"], **esdf_kw))
+    gm = capi.Map(sc["voxel"], 16, max_blocks=2048)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * sc["voxel"], **sc["cfg"])
+    ge = capi.esdf_cfg(min_distance_m=2 * sc["voxel"], reference_order=1, **esdf_kw)
+    for f, (pose, pts, col) in enumerate(S.frames(n_frames or sc["n"])):
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(KIND[sc["kind"]], gc, pose[0], pose[1], pts, col)
+        if list_mode == "container":
+            lst = _updated_esdf_blocks_in_container_order(om)
+            oe.update_from_tsdf_layer(True)
+            gm.esdf_update_blocks(ge, lst, incremental=True)
+            gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
+        else:   # vbx_esdf_update's own order: ascending (z,y,x); the oracle gets the same list
+            lst = _updated_esdf_blocks_in_container_order(om)
+            lst = lst[np.lexsort((lst[:, 0], lst[:, 1], lst[:, 2]))]
+            oe.update_from_tsdf_blocks(lst, incremental=True)
+            for i in lst:   # updateFromTsdfBlocks clears nothing (:124-302): clear Update::kEsdf by hand
+                d, w, c, bits = om.tsdf_block(i)
+                om.tsdf_block_set(i, d, w, c, bits & ~4)
+            gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+        if check_every_frame:
+            _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")
+    return gm, om
+
+
+def test_reference_order_reproduces_the_golden_incremental_digest(oracle):
+    """The reference build's `esdf_incremental` scenario (Merged integrator, default EsdfIntegrator::Config with
+    min_diff_m = 1e-3, updateFromTsdfLayer(true) after every frame): the HIP layer must hash to the digest the
+    reference's own sources produced — parents and updated bits included."""
+    name = "esdf_incremental"
+    sc = S.SCENARIOS[name]
+    gm, om = _lockstep(oracle, sc, sc["esdf"]["cfg"])
+    assert S.digest_esdf(om.esdf_dict()) == GOLD[name]["esdf"]          # the checker itself reproduces the reference
+    assert S.digest_esdf(_gpu_esdf_dict(gm)) == GOLD[name]["esdf"]
+    c = gm.counters()
+    assert c["esdf_relaxations"] > 0 and c["esdf_sweeps"] > 0
+
+
+def test_reference_order_reproduces_the_golden_batch_digest(oracle):
+    """updateFromTsdfLayerBatch, min_diff_m = 0 — the scenario where the default path needed the sign-mismatch rule
+    switched in the oracle: in reference order the UNSWITCHED golden digest comes out."""
+    from voxblox_amd import capi
+    name = "esdf_batch_min_diff0"
+    sc = S.SCENARIOS[name]
+    ref = S.run_on_oracle_api(oracle, oracle.lib(), sc)
+    assert S.digest_esdf(ref.esdf_dict()) == GOLD[name]["esdf"]
+    gm = capi.Map(sc["voxel"], 16, max_blocks=2048)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * sc["voxel"], **sc["cfg"])
+    for pose, pts, col in S.frames(sc["n"]):
+        gm.integrate(KIND[sc["kind"]], gc, pose[0], pose[1], pts, col)
+    ge = capi.esdf_cfg(min_distance_m=2 * sc["voxel"], reference_order=1, **sc["esdf"]["cfg"])
+    # getAllAllocatedBlocks order of the reference's TSDF layer (esdf_integrator.cc:96-101)
+    gm.esdf_update_blocks(ge, ref.block_indices(0), incremental=False)
+    assert S.digest_esdf(_gpu_esdf_dict(gm)) == GOLD[name]["esdf"]
+
+
+@pytest.mark.parametrize("esdf_kw", [
+    dict(),                                              # Config defaults: 20 buckets, min_diff_m 1e-3
+    dict(multi_queue=1),
+    dict(num_buckets=3, min_diff_m=0.01),
+    dict(num_buckets=1),
+    dict(full_euclidean_distance=1),
+    dict(full_euclidean_distance=1, multi_queue=1, min_diff_m=0.0),
+    dict(max_distance_m=1.0, default_distance_m=1.0),
+], ids=["default", "multi_queue", "three_buckets", "one_bucket", "full_euclidean", "full_multi_min_diff0", "short_range"])
+def test_reference_order_variants_bit_exact_vs_oracle(oracle, esdf_kw):
+    """Config variants the queue order depends on, fast integrator at 0.1 m, 5 frames, compared after every frame."""
+    sc = dict(kind="fast", voxel=0.1, n=5, cfg={})
+    _lockstep(oracle, sc, esdf_kw)
+
+
+def test_reference_order_own_block_order_and_clear_flag(oracle):
+    """vbx_esdf_update(reference_order = 1) without a list: ascending (z,y,x) over the blocks carrying Update::kEsdf,
+    which it clears (updateFromTsdfLayer(true), esdf_integrator.cc:113-121) — bit-exact against the oracle fed the
+    same list."""
+    from voxblox_amd import capi
+    sc = dict(kind="merged", voxel=0.1, n=4, cfg={})
+    gm, om = _lockstep(oracle, sc, dict(), list_mode="own")
+    assert len(gm.blocks_updated(capi.UPDATE_ESDF)) == 0
+
+
+def test_reference_order_batch_with_crust_at_finer_voxels(oracle):
+    """Batch update at 0.05 m with add_occupied_crust (esdf_integrator.cc:152-161), every allocated block listed."""
+    from voxblox_amd import capi
+    L = oracle.lib()
+    L.orc_fast_reset_counter_set(0)
+    voxel = 0.05
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("fast", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    gm = capi.Map(voxel, 16, max_blocks=4096)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    for pose, pts, col in S.frames(3):
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+    kw = dict(min_distance_m=2 * voxel, add_occupied_crust=1)
+    lst = om.block_indices(0).copy()
+    om.esdf_integrator(oracle.esdf_cfg(**kw)).update_from_tsdf_layer_batch()
+    gm.esdf_update_blocks(capi.esdf_cfg(reference_order=1, **kw), lst, incremental=False)
+    _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), "batch crust")
+
+
+def test_reference_order_refuses_pending_robot_work():
+    from voxblox_amd import capi
+    gm = capi.Map(0.1, 16, max_blocks=1024)
+    pose, pts, col = S.frames(1)[0]
+    gm.integrate(capi.TSDF_FAST, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
+    cfg = capi.esdf_cfg(min_distance_m=0.2, clear_sphere_radius=0.5, occupied_sphere_radius=1.0, reference_order=1)
+    gm.esdf_add_new_robot_position(cfg, pose[0])
+    with pytest.raises(capi.VbxError):
+        gm.esdf_update(cfg, batch=False, clear_updated_flag=True)

@@ -60,7 +60,8 @@ class EsdfCfg(C.Structure):
                 ("min_distance_m", C.c_float), ("default_distance_m", C.c_float),
                 ("min_diff_m", C.c_float), ("min_weight", C.c_float), ("num_buckets", C.c_int32),
                 ("multi_queue", C.c_int32), ("add_occupied_crust", C.c_int32),
-                ("clear_sphere_radius", C.c_float), ("occupied_sphere_radius", C.c_float)]
+                ("clear_sphere_radius", C.c_float), ("occupied_sphere_radius", C.c_float),
+                ("reference_order", C.c_int32)]
 
 
 class Counters(C.Structure):

@@ -77,8 +77,10 @@ constexpr uint32_t kFlagEsdfUpdShift = 4;     // ESDF block's Update bits live i
 constexpr uint32_t kFlagEsdfPendClassify = 0x2000;  // EsdfIntegrator::updated_blocks_ member (esdf_integrator.cc:54,80)
 constexpr uint32_t kFlagEsdfPendOpen = 0x4000;      // holds voxels pushed to open_ by addNewRobotPosition (:84)
 constexpr uint32_t kFlagFree = 0x8000;              // slot sits on the free list (belongs to no block)
+constexpr uint32_t kFlagEsdfDirty = 0x10000;        // the ESDF block's voxels changed since the host mirror last took them
+                                                    // (VBX_UPDATE_DIRTY; the wavefront writes blocks the reference never flags)
 // everything that says "this slot holds a block of the ESDF layer" (shared by every removal path)
-constexpr uint32_t kEsdfBits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen;
+constexpr uint32_t kEsdfBits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen | kFlagEsdfDirty;
 
 // Device-resident scalar state, read back at the per-call sync points.
 struct DevState {

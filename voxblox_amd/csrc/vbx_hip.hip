@@ -48,6 +48,7 @@ using namespace vbx;
 #include "vbx_kernels_tsdf.hpp"
 #include "vbx_kernels_fast.hpp"
 #include "vbx_kernels_esdf.hpp"
+#include "vbx_kernels_esdf_strict.hpp"
 #include "vbx_kernels_mesh.hpp"
 #include "vbx_ctx.hpp"
 #include "vbx_sort.hpp"
@@ -95,6 +96,7 @@ void vbx_esdf_cfg_default(vbx_esdf_cfg* c) {  // esdf_integrator.h:37-77
   c->add_occupied_crust = 0;
   c->clear_sphere_radius = 1.5f;
   c->occupied_sphere_radius = 5.0f;
+  c->reference_order = 0;
 }
 
 const char* vbx_last_error(vbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -314,7 +316,10 @@ static int list_blocks(vbx_ctx* ctx, int layer, uint32_t need_mask, std::vector<
   for (uint32_t sl = 0; sl < used; ++sl) {
     if (layer == VBX_LAYER_ESDF) {
       if (!(flags[sl] & kFlagEsdfAlloc)) continue;
-      if (need_mask && !((flags[sl] >> kFlagEsdfUpdShift) & need_mask)) continue;
+      // VBX_UPDATE_DIRTY (8): voxels changed since the mirror last took the block — a device-side bit next to the
+      // block's Update bits (the wavefront writes blocks the reference never flags as updated)
+      const uint32_t have = ((flags[sl] >> kFlagEsdfUpdShift) & kFlagUpdMask) | ((flags[sl] & kFlagEsdfDirty) ? 8u : 0u);
+      if (need_mask && !(have & need_mask)) continue;
     } else {
       if (!(flags[sl] & kFlagPublished)) continue;
       if (need_mask && !(flags[sl] & need_mask)) continue;
@@ -355,7 +360,7 @@ int vbx_block_indices(vbx_ctx* ctx, int layer, int32_t* idx, size_t cap, size_t*
 int vbx_blocks_updated(vbx_ctx* ctx, int layer, int update_mask, int32_t* idx, size_t cap, size_t* n) {
   if (!ctx || !n || (cap && !idx)) return VBX_ERR_INVALID;
   std::vector<std::pair<uint64_t, uint32_t>> v;
-  int rc = list_blocks(ctx, layer, (uint32_t)update_mask & kFlagUpdMask, &v);
+  int rc = list_blocks(ctx, layer, (uint32_t)update_mask & (kFlagUpdMask | 8u), &v);
   if (rc) return rc;
   return emit_list(v, idx, cap, n);
 }
@@ -680,7 +685,8 @@ int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask) {
   if (rc) return rc;
   const uint32_t used = ctx->h_state.pool_used;
   if (used == 0) return VBX_OK;
-  const uint32_t bits = (layer == VBX_LAYER_ESDF) ? (((uint32_t)update_mask & kFlagUpdMask) << kFlagEsdfUpdShift)
+  const uint32_t bits = (layer == VBX_LAYER_ESDF) ? ((((uint32_t)update_mask & kFlagUpdMask) << kFlagEsdfUpdShift) |
+                                                     (((uint32_t)update_mask & 8u) ? kFlagEsdfDirty : 0u))
                                                   : ((uint32_t)update_mask & kFlagUpdMask);
   hipLaunchKernelGGL(k_clear_update_bits, grid_for(used), dim3(256), 0, ctx->stream, ctx->map, used,
                      layer == VBX_LAYER_ESDF ? kFlagEsdfAlloc : kFlagPublished, bits);

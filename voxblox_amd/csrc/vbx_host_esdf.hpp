@@ -255,9 +255,136 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
   return check_state_error(ctx);
 }
 
+// cfg->reference_order: the whole update as ONE sequential replay on the device (vbx_kernels_esdf_strict.hpp).
+int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag, const int32_t* list,
+                       size_t n_list, int list_incremental) {
+  MapDev& m = ctx->map;
+  hipStream_t s = ctx->stream;
+  if (cfg->num_buckets < 1 || cfg->num_buckets > kStrictMaxBuckets) {
+    ctx->fail("ESDF reference order: num_buckets must be in 1..%d", kStrictMaxBuckets);  // CHECK_NE(num_buckets_, 0), bucket_queue.h:42
+    return VBX_ERR_INVALID;
+  }
+  int rc = esdf_ensure(ctx);
+  if (rc) return rc;
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  ctx->counters = vbx_counters{};
+  if (used == 0) return VBX_OK;
+  if (ctx->esdf_robot_pending && !batch) {
+    ctx->fail("ESDF reference order: addNewRobotPosition work is pending; run that update with reference_order = 0");
+    return VBX_ERR_UNSUPPORTED;
+  }
+  ctx->esdf_robot_pending = false;
+  EsdfDev e = esdf_dev(ctx);
+  const size_t nv = (size_t)used * m.nvox;
+  for (int i = 0; i < 9; ++i) ctx->ev_hit[i] = false;
+  tmark(ctx, 0);
+  if (batch) {  // esdf_layer_->removeAllBlocks(), esdf_integrator.cc:95
+    HIP_TRY(hipMemsetAsync(e.dist, 0, nv * 4, s));
+    HIP_TRY(hipMemsetAsync(e.state, 0, nv * 4, s));
+    HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
+  }
+  KLAUNCH(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0);
+  // the blocks in visiting order -> pool slots
+  std::vector<uint32_t> h_slots;
+  size_t n = 0;
+  HIP_TRY(ctx->b_rank.ensure(std::max<size_t>(std::max<size_t>(n_list, used), 1) * 4));
+  if (list) {
+    n = n_list;
+    HIP_TRY(ctx->b_head.ensure(std::max<size_t>(n, 1) * 12));
+    HIP_TRY(hipMemcpyAsync(ctx->b_head.p, list, n * 12, hipMemcpyHostToDevice, s));
+    if (n)
+      KLAUNCH(k_lookup_slots, grid_for(n), dim3(256), 0, s, m, ctx->b_head.as<int32_t>(), (uint32_t)n, 1,
+                         ctx->b_rank.as<uint32_t>());
+    HIP_TRY(hipStreamSynchronize(s));  // `list` is a caller-owned host buffer
+  } else {
+    // getAllAllocatedBlocks (batch, :97) / getAllUpdatedBlocks(Update::kEsdf) (:106): ascending (z,y,x) here
+    std::vector<uint32_t> flags(used);
+    std::vector<int32_t> idx((size_t)used * 3);
+    HIP_TRY(hipMemcpy(flags.data(), m.blk_flags, (size_t)used * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(idx.data(), m.blk_idx, (size_t)used * 12, hipMemcpyDeviceToHost));
+    std::vector<std::pair<uint64_t, uint32_t>> v;
+    for (uint32_t sl = 0; sl < used; ++sl) {
+      if (!(flags[sl] & kFlagPublished)) continue;
+      if (!batch && !(flags[sl] & 4u)) continue;
+      v.emplace_back(pack_block_key(idx[3 * sl], idx[3 * sl + 1], idx[3 * sl + 2]), sl);
+    }
+    std::sort(v.begin(), v.end());
+    h_slots.resize(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h_slots[i] = v[i].second;
+    n = h_slots.size();
+    if (n) HIP_TRY(hipMemcpyAsync(ctx->b_rank.p, h_slots.data(), n * 4, hipMemcpyHostToDevice, s));
+  }
+  // queue arena: a voxel sits in open_ at most once at a time without multi_queue and in raise_ at most once per
+  // update, so 2 x voxels bounds what is queued at once; multi_queue can hold more (loud failure if it does)
+  const size_t n_chunks = std::max<size_t>(256, (size_t)(cfg->multi_queue ? 8 : 2) * nv / (kSqChunk - 1) + (size_t)cfg->num_buckets + 16);
+  HIP_TRY(ctx->b_keys0.ensure(n_chunks * kSqChunk * 4));
+  HIP_TRY(ctx->b_keys1.ensure(n_chunks * 4 + 64));
+  HIP_TRY(ctx->b_vals0.ensure(64));
+  StrictArgs a{};
+  a.m = m;
+  a.e = e;
+  a.c.max_distance = cfg->max_distance_m;
+  a.c.min_distance = cfg->min_distance_m;
+  a.c.default_distance = cfg->default_distance_m;
+  a.c.min_diff = cfg->min_diff_m;
+  a.c.min_weight = cfg->min_weight;
+  a.c.add_occupied_crust = cfg->add_occupied_crust != 0;
+  a.c.voxel_size = m.voxel_size;
+  a.full = cfg->full_euclidean_distance != 0;
+  a.multi_queue = cfg->multi_queue != 0;
+  a.num_buckets = cfg->num_buckets;
+  a.incremental = list ? (list_incremental != 0) : (batch ? 0 : 1);
+  a.batch_crust = (!a.incremental && cfg->add_occupied_crust) ? 1 : 0;
+  a.list_slots = ctx->b_rank.as<uint32_t>();
+  a.n_list = (uint32_t)n;
+  a.arena = ctx->b_keys0.as<uint32_t>();
+  a.free_stack = ctx->b_keys1.as<uint32_t>();
+  a.n_chunks = (uint32_t)std::min<size_t>(n_chunks, 0xFFFFFFF0u);
+  a.stats = ctx->b_vals0.as<unsigned long long>();
+  a.max_pops = 1ull << 40;
+  KLAUNCH(k_esdf_strict, dim3(1), dim3(64), 0, s, a);
+  if (clear_updated_flag && !batch && !list && n)
+    KLAUNCH(k_esdf_strict_clear_tsdf_bit, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n);
+  tmark(ctx, 7);
+  unsigned long long st[8] = {0};
+  HIP_TRY(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (st[7] == 1) {
+    ctx->fail("ESDF reference order: queue arena exhausted (%zu chunks)", n_chunks);
+    return VBX_ERR_CAPACITY;
+  }
+  if (st[7] != 0) {
+    ctx->fail("ESDF reference order: the replay stopped with work left in its queues");
+    return VBX_ERR_HIP;
+  }
+  ctx->counters.esdf_blocks = st[6];
+  ctx->counters.esdf_relaxations = st[5];
+  ctx->counters.esdf_sweeps = st[4] + st[3];  // queue pops (open + raise) take the place of sweeps
+  if (ctx->timing) {
+    (void)hipEventSynchronize(ctx->ev[7]);
+    vbx_timing& o = ctx->last_timing;
+    o = vbx_timing{};
+    (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
+  }
+  return VBX_OK;
+}
+
 int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag,
                 const int32_t* list = nullptr, size_t n_list = 0, int list_incremental = 0) {
   HIP_TRY(hipSetDevice(ctx->device));
+  if (cfg->reference_order) {
+    if (ctx->map.vps < 4 || ctx->map.vps > 32) {
+      ctx->fail("ESDF: voxels_per_side out of range");
+      return VBX_ERR_UNSUPPORTED;
+    }
+    if (cfg->full_euclidean_distance && !(cfg->max_distance_m / ctx->map.voxel_size < 120.0f)) {
+      ctx->fail("ESDF: full_euclidean_distance needs max_distance_m / voxel_size < 120 (int8 parent vectors)");
+      return VBX_ERR_UNSUPPORTED;
+    }
+    return esdf_update_strict(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
+  }
   const bool full = cfg->full_euclidean_distance != 0;
   if (full && !(cfg->max_distance_m / ctx->map.voxel_size < 120.0f)) {
     // parent vectors are kept as int8 per component (the range Block::serializeToIntegers keeps,

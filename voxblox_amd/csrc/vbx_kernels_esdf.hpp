@@ -71,7 +71,7 @@ __global__ void k_esdf_classify(MapDev m, EsdfDev e, EsdfCfgDev c, int increment
   const uint32_t lin = blockIdx.y * blockDim.x + threadIdx.x;
   if (lin >= m.nvox) return;
   if (lin == 0) {
-    atomicOr(&m.blk_flags[slot], kFlagEsdfAlloc | (1u << kFlagEsdfUpdShift));  // set_updated(true): kMap only
+    atomicOr(&m.blk_flags[slot], kFlagEsdfAlloc | (1u << kFlagEsdfUpdShift) | kFlagEsdfDirty);  // set_updated(true): kMap only
     atomicOr(&e.active[slot], 8u);  // processed by this update
     atomicAdd(&st->esdf_blocks, 1u);
   }
@@ -190,13 +190,13 @@ __global__ void k_sphere_apply(MapDev m, EsdfDev e, SphereDev sp, float default_
       if (es & kEsdfHallucinated) e.raised[gid] = 1;  // raise_.push
       e.dist[gid] = default_distance;
       e.state[gid] = (es & 0xFFu) | kEsdfObserved | kEsdfHallucinated;  // parent.setZero()
-      want |= kFlagEsdfPendClassify;
+      want |= kFlagEsdfPendClassify | kFlagEsdfDirty;
     }
   } else {
     if (!(es & kEsdfObserved)) {
       e.dist[gid] = -default_distance;
       e.state[gid] = (es & 0xFFu) | kEsdfObserved | kEsdfHallucinated;
-      want |= kFlagEsdfPendClassify;
+      want |= kFlagEsdfPendClassify | kFlagEsdfDirty;
     } else {
       want |= kFlagEsdfPendOpen;  // open_.push(global_index, distance) — in_queue stays clear (:81-85)
     }
@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     e.state[g] = s_s[t];
     if (mode == 0) e.raised[g] = s_r[t];
   }
+  if (tid == 0) atomicOr(&m.blk_flags[slot], kFlagEsdfDirty);  // the wavefront changed this block: the host mirror must take it
   if (mode != 2) {
     if (tid < 27 && s_nb[tid] != kInvalidSlot) atomicOr(&e.active[s_nb[tid]], 2u | 4u);
     if (tid == 0) {

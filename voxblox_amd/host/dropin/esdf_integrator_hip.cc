@@ -10,6 +10,8 @@
 // Layer<EsdfVoxel>, and the kEsdf bits the reference clears on the host TSDF blocks are cleared there too.
 #include "voxblox/integrator/esdf_integrator.h"
 
+#include <cstdlib>
+
 #include "device_mirror.h"
 
 namespace voxblox {
@@ -18,11 +20,11 @@ namespace hip {
 void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
   static_assert(sizeof(EsdfVoxel) == 20, "EsdfVoxel is {float distance; bool observed, hallucinated, in_queue, fixed; Vector3i parent}");
   size_t n = 0;
-  CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP, nullptr, 0, &n), VBX_OK)
+  CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_DIRTY, nullptr, 0, &n), VBX_OK)
       << vbx_last_error(dev.ctx);
   if (n == 0) return;
   dev.idx.resize(3 * n);
-  CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP, dev.idx.data(), n, &n), VBX_OK)
+  CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_DIRTY, dev.idx.data(), n, &n), VBX_OK)
       << vbx_last_error(dev.ctx);
   const size_t nv = layer->voxels_per_side() * layer->voxels_per_side() * layer->voxels_per_side();
   dev.esdf_staging.resize(n * nv);
@@ -43,7 +45,10 @@ void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
     rec.bits = static_cast<uint8_t>(block->updated().to_ulong());
     rec.fingerprint = voxelFingerprint(&block->getVoxelByLinearIndex(0), nv * sizeof(EsdfVoxel));
   }
-  CHECK_EQ(vbx_clear_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP), VBX_OK) << vbx_last_error(dev.ctx);
+  // the device's copy of the block's Update bits is only a carrier towards the host (nothing on the device reads an
+  // ESDF block's bits): clear it with the dirty mark, so that a block the wavefront touches later does not bring a
+  // stale kMap back
+  CHECK_EQ(vbx_clear_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP | VBX_UPDATE_DIRTY), VBX_OK) << vbx_last_error(dev.ctx);
 }
 
 namespace {
@@ -61,7 +66,28 @@ vbx_esdf_cfg toC(const EsdfIntegrator::Config& c) {
   o.add_occupied_crust = c.add_occupied_crust;
   o.clear_sphere_radius = c.clear_sphere_radius;
   o.occupied_sphere_radius = c.occupied_sphere_radius;
+  // EsdfIntegrator::Config is the reference's struct: the switch for the reference-order replay (vbx_hip.h,
+  // vbx_esdf_cfg::reference_order) comes from the environment of the process that links the drop-in
+  static const bool reference_order = [] {
+    const char* e = getenv("VBX_ESDF_REFERENCE_ORDER");
+    return e && e[0] && e[0] != '0';
+  }();
+  o.reference_order = reference_order ? 1 : 0;
   return o;
+}
+
+// The reference visits the blocks in the iteration order of the CALLER'S containers (Layer::getAllUpdatedBlocks /
+// getAllAllocatedBlocks over std::unordered_map, then updated_blocks_; esdf_integrator.cc:96-101, :105-109): in
+// reference-order mode that order is taken from the host layer and handed down with the call.
+std::vector<int32_t> flatten(const BlockIndexList& l) {
+  std::vector<int32_t> idx;
+  idx.reserve(3 * l.size());
+  for (const BlockIndex& b : l) {
+    idx.push_back(b.x());
+    idx.push_back(b.y());
+    idx.push_back(b.z());
+  }
+  return idx;
 }
 }  // namespace
 }  // namespace hip
@@ -96,7 +122,17 @@ void EsdfIntegrator::updateFromTsdfLayerBatch() {
   const vbx_esdf_cfg cfg = hip::toC(config_);
   esdf_layer_->removeAllBlocks();  // esdf_integrator.cc:95
   dev.esdf_known.clear();          // the batch update drops the device's ESDF layer as well
-  CHECK_EQ(vbx_esdf_update(dev.ctx, &cfg, /*batch=*/1, /*clear_updated_flag=*/0), VBX_OK) << vbx_last_error(dev.ctx);
+  if (cfg.reference_order) {
+    BlockIndexList tsdf_blocks;
+    tsdf_layer_->getAllAllocatedBlocks(&tsdf_blocks);  // :96-97, in the host container's order
+    const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
+    CHECK_EQ(vbx_clear(dev.ctx, VBX_LAYER_ESDF), VBX_OK) << vbx_last_error(dev.ctx);
+    CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), /*incremental=*/0),
+             VBX_OK)
+        << vbx_last_error(dev.ctx);
+  } else {
+    CHECK_EQ(vbx_esdf_update(dev.ctx, &cfg, /*batch=*/1, /*clear_updated_flag=*/0), VBX_OK) << vbx_last_error(dev.ctx);
+  }
   dev.esdf_pending = false;
   updated_blocks_.clear();
   hip::mirrorEsdfToHost(dev, esdf_layer_);
@@ -109,7 +145,19 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
   const vbx_esdf_cfg cfg = hip::toC(config_);
   if (dev.esdf_pending && updated_blocks_.empty())  // clear() since addNewRobotPosition
     CHECK_EQ(vbx_esdf_integrator_clear(dev.ctx), VBX_OK) << vbx_last_error(dev.ctx);
-  CHECK_EQ(vbx_esdf_update(dev.ctx, &cfg, /*batch=*/0, clear_updated_flag ? 1 : 0), VBX_OK) << vbx_last_error(dev.ctx);
+  if (cfg.reference_order) {
+    CHECK(!dev.esdf_pending) << "VBX_ESDF_REFERENCE_ORDER does not cover addNewRobotPosition";
+    BlockIndexList tsdf_blocks;
+    tsdf_layer_->getAllUpdatedBlocks(Update::kEsdf, &tsdf_blocks);  // :105-106, in the host container's order
+    const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
+    CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), /*incremental=*/1),
+             VBX_OK)
+        << vbx_last_error(dev.ctx);
+    if (clear_updated_flag)  // every block carrying the bit was in the list
+      CHECK_EQ(vbx_clear_updated(dev.ctx, VBX_LAYER_TSDF, VBX_UPDATE_ESDF), VBX_OK) << vbx_last_error(dev.ctx);
+  } else {
+    CHECK_EQ(vbx_esdf_update(dev.ctx, &cfg, /*batch=*/0, clear_updated_flag ? 1 : 0), VBX_OK) << vbx_last_error(dev.ctx);
+  }
   dev.esdf_pending = false;
   updated_blocks_.clear();
   if (clear_updated_flag) {  // esdf_integrator.cc:113-121, on the host copies of the TSDF blocks
