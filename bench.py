@@ -455,8 +455,14 @@ def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
     cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel, fast_observed_set=args.fast_set)
     kind = capi.TSDF_FAST
     pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-    deltas = [capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank) for _ in range(2)]
-    sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev) for d in deltas],
+    # one delta map per ray shard of this rank (x 2: the exchange of step k runs behind the integration of step k + 1):
+    # the shards of a step are integrated concurrently, one host thread and one HIP stream each
+    n_units = max(1, len(multi_gpu.deal_sensor_units(world)[rank]))
+    delta_sets = [[capi.Map(voxel, 16, max_blocks=max(2048, max_blocks // n_units), device=local_rank) for _ in range(n_units)]
+                  for _ in range(2)]
+    deltas = [delta_sets[0][0], delta_sets[1][0]]
+    sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev),
+                                                [[multi_gpu.GpuBackend(d, dev) for d in ds] for ds in delta_sets],
                                                 rank, world, dist if world > 1 or os.environ.get("VBX_FORCE_COLLECTIVES") else None,
                                                 device=dev)
     cache = {}
@@ -469,25 +475,31 @@ def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
         ids = [shard_native.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
-        ns = shard_native.NativeShard(pm, deltas[0], rank, world, ids[0] if world > 1 else None, local_rank)
+        ns = shard_native.NativeShard(pm, delta_sets[0][0], rank, world, ids[0] if world > 1 else None, local_rank)
+        for d in delta_sets[0][1:] + delta_sets[1]:
+            ns.add_delta(d)
+        ns.set_pipelined(True)
 
         def one(k):
             ns.begin_step()
-            for pos, quat, dp, dc, n in sensors4_shards(k, rank, world, dev, cache):
-                ns.integrate(kind, cfg, pos, quat, dp.data_ptr(), dc.data_ptr(), n)
+            ns.integrate_shards(kind, cfg, [(pos, quat, dp.data_ptr(), dc.data_ptr(), n)
+                                            for pos, quat, dp, dc, n in sensors4_shards(k, rank, world, dev, cache)])
             ns.end_step()
 
         for k in range(warmup):
             one(k)
+        ns.wait()
         barrier_fn()
         t0 = time.perf_counter()
         for k in range(warmup, warmup + steps):
             one(k)
+        ns.wait()
         barrier_fn()
         dt = time.perf_counter() - t0
         st = ns.stats()
         f = max(st["steps"], 1)
-        exch = {"path": "libvbx_shard.so (C++, RCCL all-to-all-v called directly, sequential with the integration)",
+        exch = {"path": "libvbx_shard.so (C++, RCCL all-to-all-v called directly; shards integrated concurrently, one delta map "
+                        "each; exchange on a worker thread behind the next step's integration)",
                 "payload_bytes_per_step": int(st["payload_bytes"] / f), "sent_blocks_per_step": round(st["sent_blocks"] / f, 1)}
         ns.close()
         sharded.close()
@@ -603,8 +615,10 @@ def main():
                     "config": {"workload": "BASELINE configs[4]: FastTsdfIntegrator, 4 concurrent 640x480 synthetic room sensors, "
                                            "%g m voxels / 16^3 blocks, trunc %g m; one step = all four frames (1,228,800 points)" % (voxel, trunc),
                                "points_per_step": pts_step, "voxel_size": voxel, "voxels_per_side": 16, "world_size_seen": world,
-                               "semantics": "shard + merge: each ray shard integrated into a zeroed delta map (bit-exact Fast "
-                                            "integrator per shard), deltas merged with mergeVoxelAIntoVoxelB semantics",
+                               "semantics": "shard + merge: each ray shard (a sensor, or a band of one) integrated into a zeroed delta "
+                                            "map of its own (bit-exact Fast integrator per shard, the shards of a rank concurrently), "
+                                            "deltas merged in shard order with mergeVoxelAIntoVoxelB semantics — the merged map "
+                                            "depends on the shard layout, not on the number of ranks",
                                "parallelism": ("1 GPU holds all four sensors (same shard + merge, no collective)" if world == 1 else
                                                f"{world} ranks, {max(1, world // 4)} ray band(s) per sensor, sparse RCCL all-to-all of touched "
                                                "blocks to their owners pipelined behind the next step's integration, map distributed by block owner")},

@@ -53,6 +53,23 @@ int vbx_shard_integrate(vbx_shard* s, int kind, const vbx_tsdf_cfg* cfg, const f
                         const float* d_points_C, const uint8_t* d_rgba, size_t n, int freespace_points);
 int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, float max_weight);
 
+/* More delta maps (same geometry; owned by the caller).  With n delta maps shard i of a step goes into delta i % n:
+ * as many deltas as shards = every ray shard (a sensor, or a band of one) has a delta map of its own, the shards of a
+ * step are integrated CONCURRENTLY (one host thread and one HIP stream per delta map — the integration is a chain of
+ * small dependent launches that leaves most of the chip idle) and the merged map depends on the shard layout only,
+ * not on how the shards were dealt to the ranks.  vbx_shard_integrate keeps integrating into delta 0. */
+int vbx_shard_add_delta(vbx_shard* s, vbx_ctx* delta);
+/* All shards of this rank's step at once: pos_xyz n x 3, quat_wxyz n x 4, device pointers and point counts per shard. */
+int vbx_shard_integrate_shards(vbx_shard* s, int kind, const vbx_tsdf_cfg* cfg, size_t n_shards, const float* pos_xyz,
+                               const float* quat_wxyz, const float* const* d_points_C, const uint8_t* const* d_rgba,
+                               const size_t* n_points, int freespace_points);
+/* on != 0: the registered delta maps (an even number) become two alternating sets; vbx_shard_end_step then starts the
+ * exchange + owner merge on a worker thread and returns, so that it runs behind the next step's integration (the same
+ * overlap voxblox_amd.multi_gpu.PipelinedShardedTsdfMap has); a failed exchange is reported by the next
+ * vbx_shard_end_step or by vbx_shard_wait, which also must be called before the persistent map is read. */
+int vbx_shard_set_pipelined(vbx_shard* s, int on);
+int vbx_shard_wait(vbx_shard* s);
+
 typedef struct vbx_shard_stats {
   uint64_t steps;
   uint64_t sent_blocks;      /* blocks this rank's deltas touched (= rows sent, own ones included) */

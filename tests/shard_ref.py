@@ -9,29 +9,33 @@ import numpy as np
 from test_multi_gpu_gloo import merge_A_into_B
 
 
-def serial_shard_merge(O, voxel, kind, ocfg, steps, vps=16):
-    """steps[k][rank] = [(pos, quat, points, colors), ...]  ->  {BlockIndex: (d, w, rgba)} of the merged map."""
+def serial_shard_merge(O, voxel, kind, ocfg, steps, vps=16, deltas_per_rank=1):
+    """steps[k][rank] = [(pos, quat, points, colors), ...]  ->  {BlockIndex: (d, w, rgba)} of the merged map.
+    deltas_per_rank: shard i of a rank goes into that rank's delta i % deltas_per_rank (ShardedTsdfMap's rule);
+    1 = every shard of a rank into one delta map, one after the other."""
     nv = vps ** 3
     ref = {}
     for per_rank in steps:
-        sums = {}    # BlockIndex -> six float32 planes, rows added in rank order
+        sums = {}    # BlockIndex -> six float32 planes, rows added in (rank, delta) order
         order = []
         for shards in per_rank:
             if not shards:
                 continue
-            m = O.OracleMap(voxel, vps)
-            for pos, quat, pts, col in shards:
-                O.lib().orc_fast_reset_counter_set(0)
-                m.tsdf_integrator(kind, ocfg).integrate(pos, quat, pts, col)
-            # the rows of one sender arrive in (z,y,x) order; the order across blocks does not matter for the sums
-            for key, (d, w, c, _) in m.tsdf_dict().items():
-                sA = np.stack([w * d, w] + [w * c[:, ch].astype(np.float32) for ch in range(4)]).astype(np.float32)
-                if key in sums:
-                    sums[key] = (sums[key] + sA).astype(np.float32)
-                else:
-                    sums[key] = sA
-                    order.append(key)
-            del m
+            nd = max(1, min(deltas_per_rank, len(shards)))
+            for u in range(nd):
+                m = O.OracleMap(voxel, vps)
+                for pos, quat, pts, col in [sh for i, sh in enumerate(shards) if i % deltas_per_rank == u]:
+                    O.lib().orc_fast_reset_counter_set(0)
+                    m.tsdf_integrator(kind, ocfg).integrate(pos, quat, pts, col)
+                # the rows of one sender arrive in (delta, z,y,x) order; the order across blocks does not matter for the sums
+                for key, (d, w, c, _) in m.tsdf_dict().items():
+                    sA = np.stack([w * d, w] + [w * c[:, ch].astype(np.float32) for ch in range(4)]).astype(np.float32)
+                    if key in sums:
+                        sums[key] = (sums[key] + sA).astype(np.float32)
+                    else:
+                        sums[key] = sA
+                        order.append(key)
+                del m
         for key in order:
             sA = sums[key]
             if not (sA[1] > 0).any():

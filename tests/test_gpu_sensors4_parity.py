@@ -45,30 +45,35 @@ def _reference(oracle, layout_world, n_steps):
     key = ("ref", layout_world, n_steps)
     if key not in _cache:
         ocfg = oracle.tsdf_cfg(default_truncation_distance=4 * VOXEL, integrator_threads=1)
-        # world-1 execution of a layout = every shard of the step goes into the ONE rank's delta map
+        # one delta map per ray shard (the layout bench.py runs): all shards of the step on the ONE rank of this box
         steps = [[[sh for rank in _shards_of_step(k, layout_world) for sh in rank]] for k in range(n_steps)]
-        _cache[key] = serial_shard_merge(oracle, VOXEL, "fast", ocfg, steps)
+        _cache[key] = serial_shard_merge(oracle, VOXEL, "fast", ocfg, steps, deltas_per_rank=layout_world)
     return _cache[key]
 
 
 @pytest.mark.parametrize("layout_world", [4, 8], ids=["whole_sensors", "two_bands_per_sensor"])
 @pytest.mark.parametrize("path", ["torch", "native"])
 def test_configs4_full_size_step_equals_serial_oracle_shard_merge(oracle, path, layout_world):
-    """Two full time steps (the second merges into a populated persistent map) of configs[4] on this GPU: all
-    shards of a step into one delta map, exchange with one rank, owner merge."""
+    """Two full time steps (the second merges into a populated persistent map) of configs[4] on this GPU: every
+    shard of a step into a delta map of its own, all of them concurrently, exchange with one rank behind the next
+    step, owner merge in shard order."""
     import torch
     from voxblox_amd import capi, multi_gpu, shard_native
     n_steps = 2
     dev = torch.device("cuda", 0)
     cfg = capi.tsdf_cfg(default_truncation_distance=4 * VOXEL)
     pm = capi.Map(VOXEL, 16, max_blocks=16384)
-    deltas = [capi.Map(VOXEL, 16, max_blocks=16384) for _ in range(2)]
+    nu = layout_world      # shards per step = delta maps per set: every shard a delta map of its own, integrated concurrently
+    sets = [[capi.Map(VOXEL, 16, max_blocks=4096) for _ in range(nu)] for _ in range(2)]
     replay_block_rounds = 0
     if path == "torch":
-        sm = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev) for d in deltas],
+        sm = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [[multi_gpu.GpuBackend(d, dev) for d in ds] for ds in sets],
                                                0, 1, device=dev)
     else:
-        sm = shard_native.NativeShard(pm, deltas[0], 0, 1, shard_native.unique_id())   # a real one-rank RCCL communicator
+        sm = shard_native.NativeShard(pm, sets[0][0], 0, 1, shard_native.unique_id())   # a real one-rank RCCL communicator
+        for d in sets[0][1:] + sets[1]:
+            sm.add_delta(d)
+        sm.set_pipelined(True)
     for k in range(n_steps):
         shards = [sh for rank in _shards_of_step(k, layout_world) for sh in rank]
         dsh = [(p, q, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), pts.shape[0]) for p, q, pts, col in shards]
@@ -76,10 +81,11 @@ def test_configs4_full_size_step_equals_serial_oracle_shard_merge(oracle, path, 
             sm.integrate_shards(capi.TSDF_FAST, cfg, dsh)
         else:
             sm.begin_step()
-            for p, q, dp, dc, n in dsh:
-                sm.integrate(capi.TSDF_FAST, cfg, p, q, dp.data_ptr(), dc.data_ptr(), n)
-                replay_block_rounds += deltas[0].counters()["replay_block_rounds"]
+            sm.integrate_shards(capi.TSDF_FAST, cfg, [(p, q, dp.data_ptr(), dc.data_ptr(), n) for p, q, dp, dc, n in dsh])
+            replay_block_rounds += sum(d.counters()["replay_block_rounds"] for d in sets[k & 1])
             sm.end_step()
+    if path == "native":
+        sm.wait()
     sm.close()
     torch.cuda.synchronize()
     got = pm.tsdf_dict()
@@ -108,14 +114,18 @@ def _rank_worker(rank, world, port, path, out_dir, n_steps, width, height, f, vo
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
     pm = capi.Map(voxel, 16, max_blocks=4096, device=rank)
-    deltas = [capi.Map(voxel, 16, max_blocks=4096, device=rank) for _ in range(2)]
+    nu = max(1, len(multi_gpu.deal_sensor_units(world)[rank]))
+    sets = [[capi.Map(voxel, 16, max_blocks=2048, device=rank) for _ in range(nu)] for _ in range(2)]
     if path == "torch":
-        sm = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev) for d in deltas],
+        sm = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [[multi_gpu.GpuBackend(d, dev) for d in ds] for ds in sets],
                                                rank, world, dist, device=dev)
     else:
         ids = [shard_native.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        sm = shard_native.NativeShard(pm, deltas[0], rank, world, ids[0], rank)
+        sm = shard_native.NativeShard(pm, sets[0][0], rank, world, ids[0], rank)
+        for d in sets[0][1:] + sets[1]:
+            sm.add_delta(d)
+        sm.set_pipelined(True)
     import test_gpu_sensors4_parity as T
     for k in range(n_steps):
         mine = T._shards_of_step(k, world, width, height, f)[rank]
@@ -124,9 +134,10 @@ def _rank_worker(rank, world, port, path, out_dir, n_steps, width, height, f, vo
             sm.integrate_shards(capi.TSDF_FAST, cfg, dsh)
         else:
             sm.begin_step()
-            for p, q, dp, dc, n in dsh:
-                sm.integrate(capi.TSDF_FAST, cfg, p, q, dp.data_ptr(), dc.data_ptr(), n)
+            sm.integrate_shards(capi.TSDF_FAST, cfg, [(p, q, dp.data_ptr(), dc.data_ptr(), n) for p, q, dp, dc, n in dsh])
             sm.end_step()
+    if path == "native":
+        sm.wait()
     sm.close()
     torch.cuda.synchronize()
     owned = pm.tsdf_dict()
@@ -174,6 +185,6 @@ def test_one_rccl_rank_per_gpu_equals_serial_oracle_merge(oracle, path, tmp_path
             merged[kk] = (z["d"][i], z["w"][i], z["c"][i], 7)
     ocfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
     steps = [_shards_of_step(k, world, width, height, f) for k in range(n_steps)]
-    ref = serial_shard_merge(oracle, voxel, "fast", ocfg, steps)
+    ref = serial_shard_merge(oracle, voxel, "fast", ocfg, steps, deltas_per_rank=8)   # every shard a delta map of its own
     assert len(ref) > 100
     assert_merged_equal(merged, ref)

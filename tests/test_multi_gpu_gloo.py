@@ -207,3 +207,65 @@ def test_two_rank_shard_and_merge_matches_serial_reference_merge(oracle, pipelin
         keys = np.array(list(owned.keys()), np.int32).reshape(-1, 3)
         if keys.shape[0]:
             assert np.all(multi_gpu.owner_of(keys, 2) == rank)
+
+
+def _worker_multi_delta(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import oracle_py as O
+    from voxblox_amd import multi_gpu, scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    voxel = 0.1
+    cfg = O.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
+    # two ray shards per rank and step, a delta map each, integrated concurrently; pipelined exchange
+    sm = multi_gpu.PipelinedShardedTsdfMap(OracleBackend(O, voxel), [[OracleBackend(O, voxel) for _ in range(2)] for _ in range(2)],
+                                           rank, world, dist)
+    for k in range(3):
+        pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
+        n = pts.shape[0]
+        q = n // (2 * world)
+        shards = [(pose[0], pose[1], pts[(2 * rank + j) * q:(2 * rank + j + 1) * q], col[(2 * rank + j) * q:(2 * rank + j + 1) * q], None)
+                  for j in range(2)]
+        sm.integrate_shards("merged", cfg, shards)
+    sm.close()
+    owned = {tuple(int(v) for v in i): sm.p.m.tsdf_block(i) for i in sm.p.block_indices()}
+    out_q.put((rank, owned))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_two_concurrent_shards_each_matches_serial_merge(oracle):
+    """ShardedTsdfMap with one delta map per ray shard (the layout bench.py runs for configs[4]): shards of a rank
+    integrated concurrently, rows of a block added in (rank, delta) = global shard order at the owner."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from shard_ref import assert_merged_equal, serial_shard_merge
+    from voxblox_amd import scenes
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_multi_delta, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    merged = {}
+    for rank, owned in results:
+        assert not (set(owned) & set(merged))
+        merged.update(owned)
+    voxel = 0.1
+    cfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
+    steps = []
+    for k in range(3):
+        pose, pts, col = scenes.room_frame(7 * k, 100, f=40.0, width=80, height=60)
+        qn = pts.shape[0] // 4
+        steps.append([[(pose[0], pose[1], pts[(2 * r + j) * qn:(2 * r + j + 1) * qn], col[(2 * r + j) * qn:(2 * r + j + 1) * qn])
+                       for j in range(2)] for r in range(2)])
+    ref = serial_shard_merge(oracle, voxel, "merged", cfg, steps, deltas_per_rank=2)
+    assert len(ref) > 20
+    assert_merged_equal(merged, ref)

@@ -12,11 +12,19 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct vbx_shard {
   vbx_ctx* p = nullptr;
-  vbx_ctx* d = nullptr;
+  vbx_ctx* d = nullptr;                 // delta 0 (the one given to vbx_shard_create)
+  std::vector<vbx_ctx*> deltas;         // every registered delta map, d first
+  int n_sets = 1;                       // 2: the deltas are two alternating sets and the exchange runs behind the next step
+  int cur_set = 0;                      // the set the current step integrates into
+  size_t used_in_set = 1;               // deltas of the current set that received shards this step
+  std::thread worker;                   // the previous step's exchange (pipelined mode)
+  int worker_rc = VBX_OK;
+  bool worker_running = false;
   int rank = 0, world = 1, device = 0;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
@@ -106,6 +114,7 @@ vbx_shard* vbx_shard_create(vbx_ctx* persistent, vbx_ctx* delta, int rank, int w
   vbx_shard* s = new vbx_shard;
   s->p = persistent;
   s->d = delta;
+  s->deltas.push_back(delta);
   s->rank = rank;
   s->world = world;
   s->device = device;
@@ -134,6 +143,7 @@ vbx_shard* vbx_shard_create(vbx_ctx* persistent, vbx_ctx* delta, int rank, int w
 
 void vbx_shard_destroy(vbx_shard* s) {
   if (!s) return;
+  if (s->worker.joinable()) s->worker.join();
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->comm) (void)ncclCommDestroy(s->comm);
@@ -143,62 +153,179 @@ void vbx_shard_destroy(vbx_shard* s) {
   delete s;
 }
 
+static size_t set_size(const vbx_shard* s) { return s->deltas.size() / (size_t)s->n_sets; }
+static vbx_ctx* delta_of(const vbx_shard* s, int set, size_t u) { return s->deltas[(size_t)set * set_size(s) + u]; }
+
+static int join_worker(vbx_shard* s) {
+  if (s->worker.joinable()) s->worker.join();
+  s->worker_running = false;
+  const int rc = s->worker_rc;
+  s->worker_rc = VBX_OK;
+  return rc;
+}
+
+int vbx_shard_add_delta(vbx_shard* s, vbx_ctx* delta) {
+  if (!s || !delta) return VBX_ERR_INVALID;
+  vbx_map_cfg c0{}, c1{};
+  if (vbx_get_map_cfg(s->d, &c0) != VBX_OK || vbx_get_map_cfg(delta, &c1) != VBX_OK || c0.voxels_per_side != c1.voxels_per_side ||
+      c0.voxel_size != c1.voxel_size) {
+    s->fail("vbx_shard_add_delta: every delta map must have the persistent map's voxel size and voxels per side");
+    return VBX_ERR_INVALID;
+  }
+  s->deltas.push_back(delta);
+  return VBX_OK;
+}
+
+int vbx_shard_set_pipelined(vbx_shard* s, int on) {
+  if (!s) return VBX_ERR_INVALID;
+  int rc = join_worker(s);
+  if (rc) return rc;
+  if (on && (s->deltas.size() < 2 || s->deltas.size() % 2)) {
+    s->fail("vbx_shard_set_pipelined: needs an even number of delta maps (two alternating sets)");
+    return VBX_ERR_INVALID;
+  }
+  s->n_sets = on ? 2 : 1;
+  s->cur_set = 0;
+  return VBX_OK;
+}
+
+int vbx_shard_wait(vbx_shard* s) {
+  if (!s) return VBX_ERR_INVALID;
+  return join_worker(s);
+}
+
 int vbx_shard_begin_step(vbx_shard* s) {
   if (!s) return VBX_ERR_INVALID;
-  VBXS(s->d, vbx_clear(s->d, VBX_LAYER_TSDF));
+  // pipelined: the exchange of the previous step may still read the OTHER set; the one that used THIS set (two steps
+  // ago) was joined by the end_step in between
+  for (size_t u = 0; u < set_size(s); ++u) VBXS(delta_of(s, s->cur_set, u), vbx_clear(delta_of(s, s->cur_set, u), VBX_LAYER_TSDF));
+  s->used_in_set = 1;
   return VBX_OK;
 }
 
 int vbx_shard_integrate(vbx_shard* s, int kind, const vbx_tsdf_cfg* cfg, const float pos[3], const float quat[4],
                         const float* d_points_C, const uint8_t* d_rgba, size_t n, int freespace_points) {
   if (!s) return VBX_ERR_INVALID;
-  VBXS(s->d, vbx_tsdf_integrate_device(s->d, kind, cfg, pos, quat, d_points_C, d_rgba, n, freespace_points));
+  vbx_ctx* d = delta_of(s, s->cur_set, 0);
+  VBXS(d, vbx_tsdf_integrate_device(d, kind, cfg, pos, quat, d_points_C, d_rgba, n, freespace_points));
+  return VBX_OK;
+}
+
+int vbx_shard_integrate_shards(vbx_shard* s, int kind, const vbx_tsdf_cfg* cfg, size_t n_shards, const float* pos_xyz,
+                               const float* quat_wxyz, const float* const* d_points_C, const uint8_t* const* d_rgba,
+                               const size_t* n_points, int freespace_points) {
+  if (!s || !cfg || (n_shards && (!pos_xyz || !quat_wxyz || !d_points_C || !d_rgba || !n_points))) return VBX_ERR_INVALID;
+  const size_t nd = set_size(s);
+  const size_t used = std::max<size_t>(1, std::min(nd, n_shards));
+  s->used_in_set = std::max(s->used_in_set, used);
+  std::vector<int> rcs(used, VBX_OK);
+  auto run = [&](size_t u) {  // shard i goes into delta i % nd; the shards of one delta one after the other
+    (void)hipSetDevice(s->device);
+    vbx_ctx* d = delta_of(s, s->cur_set, u);
+    for (size_t i = u; i < n_shards && rcs[u] == VBX_OK; i += nd)
+      rcs[u] = vbx_tsdf_integrate_device(d, kind, cfg, pos_xyz + 3 * i, quat_wxyz + 4 * i, d_points_C[i], d_rgba[i], n_points[i],
+                                         freespace_points);
+  };
+  std::vector<std::thread> th;
+  for (size_t u = 1; u < used; ++u) th.emplace_back(run, u);  // one host thread + one HIP stream per delta map
+  run(0);
+  for (std::thread& t : th) t.join();
+  for (size_t u = 0; u < used; ++u)
+    if (rcs[u] != VBX_OK) {
+      s->fail("vbx_shard_integrate_shards: delta %zu: %s", u, vbx_last_error(delta_of(s, s->cur_set, u)));
+      return rcs[u];
+    }
   return VBX_OK;
 }
 
 // Everything a rank does BEFORE the first collective of a step: list the delta's blocks grouped by owner and export
 // their weighted sums.  A failure here must not leave the other ranks blocked in the collectives, so the status
 // travels with the group sizes (vbx_shard_end_step).
-static int prepare_step(vbx_shard* s, std::vector<int32_t>& send_keys, std::vector<size_t>& send_counts,
+static int prepare_step(vbx_shard* s, int set, size_t used, std::vector<int32_t>& send_keys, std::vector<size_t>& send_counts,
                         std::vector<size_t>& sdispl, size_t* n_out) {
-  // 1. the blocks this step's deltas touched, grouped by owner, (z,y,x) order inside a group
-  size_t n = 0;
-  VBXS(s->d, vbx_num_blocks(s->d, VBX_LAYER_TSDF, &n));
-  std::vector<int32_t> idx(3 * std::max<size_t>(n, 1));
-  if (n) VBXS(s->d, vbx_block_indices(s->d, VBX_LAYER_TSDF, idx.data(), n, &n));  // ascending (z,y,x)
+  // 1. the blocks this step's deltas touched: rows owner-major, then delta order, then (z,y,x) — at the owner the rows
+  //    of one block arrive in (sender rank, delta, key) order = the global shard order, whatever the world size
   const int W = s->world;
-  std::vector<int> owner(n);
+  std::vector<std::vector<int32_t>> idx(used);
+  std::vector<std::vector<int>> owner(used);
+  std::vector<std::vector<size_t>> cnt(used, std::vector<size_t>(W, 0));
   send_counts.assign(W, 0);
-  for (size_t i = 0; i < n; ++i) {
-    owner[i] = vbx_shard_owner_of(&idx[3 * i], W);
-    ++send_counts[owner[i]];
+  for (size_t u = 0; u < used; ++u) {
+    vbx_ctx* d = delta_of(s, set, u);
+    size_t n = 0;
+    VBXS(d, vbx_num_blocks(d, VBX_LAYER_TSDF, &n));
+    idx[u].assign(3 * std::max<size_t>(n, 1), 0);
+    if (n) VBXS(d, vbx_block_indices(d, VBX_LAYER_TSDF, idx[u].data(), n, &n));  // ascending (z,y,x)
+    idx[u].resize(3 * n);
+    owner[u].resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      owner[u][i] = vbx_shard_owner_of(&idx[u][3 * i], W);
+      ++cnt[u][owner[u][i]];
+      ++send_counts[owner[u][i]];
+    }
   }
   sdispl.assign(W + 1, 0);
   for (int r = 0; r < W; ++r) sdispl[r + 1] = sdispl[r] + send_counts[r];
-  send_keys.assign(3 * std::max<size_t>(n, 1), 0);
-  {
-    std::vector<size_t> cur(sdispl.begin(), sdispl.end() - 1);
-    for (size_t i = 0; i < n; ++i) {  // stable: the (z,y,x) order survives inside every group
-      const size_t at = cur[owner[i]]++;
-      std::memcpy(&send_keys[3 * at], &idx[3 * i], 12);
+  const size_t n_total = sdispl[W];
+  send_keys.assign(3 * std::max<size_t>(n_total, 1), 0);
+  // start row of segment (owner o, delta u)
+  std::vector<std::vector<size_t>> seg(used, std::vector<size_t>(W, 0));
+  for (int o = 0; o < W; ++o) {
+    size_t at = sdispl[o];
+    for (size_t u = 0; u < used; ++u) {
+      seg[u][o] = at;
+      at += cnt[u][o];
     }
   }
-  // 2. their weighted sums, in the same order
-  int rc = grow(s, &s->d_send, &s->send_cap, n, 6 * s->nvox);
+  for (size_t u = 0; u < used; ++u) {
+    std::vector<size_t> cur(seg[u]);
+    for (size_t i = 0; i < owner[u].size(); ++i) {  // stable: the (z,y,x) order survives inside every segment
+      const size_t at = cur[owner[u][i]]++;
+      std::memcpy(&send_keys[3 * at], &idx[u][3 * i], 12);
+    }
+  }
+  // 2. their weighted sums, in the same order: one export per (delta, owner) segment (one per delta when there is one)
+  int rc = grow(s, &s->d_send, &s->send_cap, n_total, 6 * s->nvox);
   if (rc) return rc;
-  if (n) VBXS(s->d, vbx_blocks_export_sums(s->d, send_keys.data(), n, s->d_send));
-  *n_out = n;
+  for (size_t u = 0; u < used; ++u) {
+    vbx_ctx* d = delta_of(s, set, u);
+    if (used == 1) {
+      if (n_total) VBXS(d, vbx_blocks_export_sums(d, send_keys.data(), n_total, s->d_send));
+      break;
+    }
+    for (int o = 0; o < W; ++o)
+      if (cnt[u][o])
+        VBXS(d, vbx_blocks_export_sums(d, &send_keys[3 * seg[u][o]], cnt[u][o], s->d_send + seg[u][o] * 6 * s->nvox));
+  }
+  *n_out = n_total;
   return VBX_OK;
 }
 
+static int exchange_and_merge(vbx_shard* s, int set, size_t used, int apply_caps, float truncation_distance, float max_weight);
+
 int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, float max_weight) {
   if (!s) return VBX_ERR_INVALID;
+  // the exchange of the step before this one (pipelined mode) must be through: collectives are issued in step order
+  int rc = join_worker(s);
+  if (rc) return rc;
+  const int set = s->cur_set;
+  const size_t used = s->used_in_set;
+  if (s->n_sets == 1) return exchange_and_merge(s, set, used, apply_caps, truncation_distance, max_weight);
+  // pipelined: this step's exchange runs on a worker thread (its own stream) while the caller integrates the next
+  // step into the other set of delta maps; its status surfaces at the next end_step / vbx_shard_wait
+  s->cur_set ^= 1;
+  s->worker_running = true;
+  s->worker = std::thread([=]() { s->worker_rc = exchange_and_merge(s, set, used, apply_caps, truncation_distance, max_weight); });
+  return VBX_OK;
+}
+
+static int exchange_and_merge(vbx_shard* s, int set, size_t used, int apply_caps, float truncation_distance, float max_weight) {
   HIPS(hipSetDevice(s->device));
   const int W = s->world;
   std::vector<int32_t> send_keys;
   std::vector<size_t> send_counts, sdispl;
   size_t n = 0;
-  const int local_rc = prepare_step(s, send_keys, send_counts, sdispl, &n);
+  const int local_rc = prepare_step(s, set, used, send_keys, send_counts, sdispl, &n);
   if (!s->comm) {
     if (local_rc) return local_rc;
   }

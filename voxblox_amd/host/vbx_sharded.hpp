@@ -34,6 +34,11 @@ class ShardedTsdfIntegrator {
   static void createCommId(uint8_t id[VBX_SHARD_ID_BYTES]) {
     if (vbx_shard_get_unique_id(id) != VBX_OK) die("ncclGetUniqueId failed");
   }
+  /// further delta maps: shard i of a step goes into delta i % n, concurrently (vbx_shard.h)
+  void addDelta(DeviceMap* delta) { check(vbx_shard_add_delta(shard_, delta->ctx())); }
+  /// two alternating sets of delta maps: endStep() returns while the exchange runs behind the next step
+  void setPipelined(bool on) { check(vbx_shard_set_pipelined(shard_, on ? 1 : 0)); }
+  void wait() { check(vbx_shard_wait(shard_)); }
   void beginStep() { check(vbx_shard_begin_step(shard_)); }
   void integratePointCloudDevice(const Transformation& T_G_C, const float* d_points_C, const uint8_t* d_rgba, size_t n,
                                  bool freespace_points = false) {

@@ -72,16 +72,24 @@ def band_of(n_points, band, bands):
 
 
 class ShardedTsdfMap:
-    """persistent / delta: objects with the small backend protocol used below
-    (voxblox_amd.multi_gpu.GpuBackend for the HIP path)."""
+    """persistent / delta(s): objects with the small backend protocol used below (voxblox_amd.multi_gpu.GpuBackend
+    for the HIP path).  `delta` may be ONE delta map or a LIST of them: shard i of a step goes into delta
+    i % len(deltas) — with as many deltas as shards every ray shard (sensor, or band of a sensor) has a delta map of its
+    own, the shards of a step are integrated CONCURRENTLY (one host thread and one HIP stream per delta map; the
+    integration is a chain of small dependent launches that leaves most of the chip idle) and the merged map depends
+    on the shard layout only, not on how the shards were dealt to the ranks.  Shards that share a delta map are
+    integrated one after the other into it (one delta for everything = the sequential form)."""
 
     def __init__(self, persistent, delta, rank, world, dist=None, apply_caps=False,
                  truncation=0.0, max_weight=0.0):
-        self.p, self.d = persistent, delta
+        self.p = persistent
+        self.deltas = list(delta) if isinstance(delta, (list, tuple)) else [delta]
+        self.d = self.deltas[0]
         self.rank, self.world = int(rank), int(world)
         self.dist = dist
         self.apply_caps, self.trunc, self.max_weight = apply_caps, truncation, max_weight
         self.last = {}
+        self._used = 1
         # run the collectives even with one rank (exercises the RCCL calls on a 1-GPU box)
         import os
         self.force_collectives = bool(os.environ.get("VBX_FORCE_COLLECTIVES")) and dist is not None
@@ -98,26 +106,82 @@ class ShardedTsdfMap:
     def integrate_shard(self, kind, cfg, pos, quat, points, colors, n_points=None):
         """Integrate one shard of rays into a fresh delta map, send every touched block to its
         owner, fold the blocks this rank owns into its persistent shard."""
-        self.d.clear()
-        self.d.integrate(kind, cfg, pos, quat, points, colors, n_points)
-        self.exchange_and_merge()
+        self.integrate_shards(kind, cfg, [(pos, quat, points, colors, n_points)])
+
+    def integrate_only(self, kind, cfg, shards):
+        """The integration half of a step: shard i into delta i % len(deltas), the deltas concurrently."""
+        nd = len(self.deltas)
+        self._used = max(1, min(nd, len(shards)))
+        groups = [[sh for i, sh in enumerate(shards) if i % nd == u] for u in range(self._used)]
+
+        def run(u):
+            d = self.deltas[u]
+            d.clear()
+            for pos, quat, points, colors, n in groups[u]:
+                d.integrate(kind, cfg, pos, quat, points, colors, n)
+
+        if not shards:
+            self.deltas[0].clear()
+        elif self._used == 1:
+            run(0)
+        else:
+            import threading
+            errs = []
+
+            def guarded(u):
+                try:
+                    run(u)
+                except BaseException as e:   # re-raised on the caller's thread
+                    errs.append(e)
+
+            th = [threading.Thread(target=guarded, args=(u,), name=f"vbx-shard-{u}") for u in range(1, self._used)]
+            for t in th:
+                t.start()
+            guarded(0)
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
 
     def integrate_shards(self, kind, cfg, shards):
-        """Several shards of one time step on this rank (e.g. two sensors at world 2): all of them
-        go into the same delta map before ONE exchange.  shards: [(pos, quat, points, colors, n)]."""
-        self.d.clear()
-        for pos, quat, points, colors, n in shards:
-            self.d.integrate(kind, cfg, pos, quat, points, colors, n)
+        """The shards of one time step on this rank (e.g. two sensors at world 2), then ONE exchange.
+        shards: [(pos, quat, points, colors, n)]."""
+        self.integrate_only(kind, cfg, shards)
         self.exchange_and_merge()
 
     def exchange_and_merge(self):
         import torch
-        send_keys, send_counts = group_by_owner(self.d.block_indices(), self.world)
         nvox = self.d.nvox
-        n_send = int(send_keys.shape[0])
-        send = self.d.zeros((max(n_send, 1), 6, nvox))
-        if n_send:
-            self.d.export_sums(send_keys, send[:n_send])
+        W = self.world
+        # rows per (owner, delta): owner-major, then delta order, then (z,y,x) — at the owner the rows of one block
+        # therefore arrive in (sender rank, delta, key) order = the global shard order, whatever the world size
+        per = [group_by_owner(d.block_indices(), W) for d in self.deltas[:self._used]]
+        send_counts = np.zeros(W, np.int64)
+        for _, c in per:
+            send_counts += c
+        n_send = int(send_counts.sum())
+        if len(per) == 1:
+            send_keys = per[0][0]
+            send = self.d.zeros((max(n_send, 1), 6, nvox))
+            if n_send:
+                self.d.export_sums(send_keys, send[:n_send])
+        else:
+            tmp = []
+            for (k, c), d in zip(per, self.deltas):
+                t = d.zeros((max(int(k.shape[0]), 1), 6, nvox))
+                if k.shape[0]:
+                    d.export_sums(k, t[:k.shape[0]])
+                tmp.append(t)
+            key_parts, row_parts = [], []
+            offs = [np.concatenate([[0], np.cumsum(c)]) for _, c in per]
+            for o in range(W):
+                for u, (k, c) in enumerate(per):
+                    a, b = int(offs[u][o]), int(offs[u][o + 1])
+                    if b > a:
+                        key_parts.append(k[a:b])
+                        row_parts.append(tmp[u][a:b])
+            send_keys = np.ascontiguousarray(np.concatenate(key_parts)) if key_parts else np.zeros((0, 3), np.int32)
+            send = torch.cat(row_parts) if row_parts else self.d.zeros((1, 6, nvox))
         if not self._collective():
             recv_keys, recv = send_keys, send[:n_send]
             recv_counts = send_counts
@@ -143,7 +207,7 @@ class ShardedTsdfMap:
             if recv.device != self.p.device:
                 recv = recv.to(self.p.device)
         if recv_keys.shape[0]:
-            # rows arrive grouped by sender rank, each group in (z,y,x) order: the owner adds the rows
+            # rows arrive grouped by sender rank, each group in (delta, z,y,x) order: the owner adds the rows
             # of one block in exactly that order (deterministic), then merges once
             self.p.merge_sums(recv_keys, recv, self.apply_caps, self.trunc, self.max_weight)
         self.last = dict(sent_blocks=n_send, received_blocks=int(recv_keys.shape[0]),
@@ -155,9 +219,9 @@ class ShardedTsdfMap:
 class PipelinedShardedTsdfMap:
     """The same frame step with the exchange pipelined behind the next frame's integration.
 
-    Two delta maps alternate: while a worker thread runs frame k's exchange (export, RCCL
-    all-to-all, owner merge) on its own HIP stream, the caller already integrates frame k+1 into
-    the other delta map.  The integration is latency-bound (the GPU is mostly idle between its
+    Two delta maps (or two sets of per-shard delta maps, see ShardedTsdfMap) alternate: while a worker thread
+    runs frame k's exchange (export, RCCL all-to-all, owner merge) on its own HIP stream, the caller already
+    integrates frame k+1 into the other set.  The integration is latency-bound (the GPU is mostly idle between its
     kernels), so the two overlap well; per-frame time tends to max(integrate, exchange) instead of
     their sum.  Every collective is issued by the worker thread, in frame order, so all ranks issue
     them in the same order; call flush() before any collective of your own (barriers) and before
@@ -168,7 +232,7 @@ class PipelinedShardedTsdfMap:
         import queue
         import sys
         import threading
-        assert len(deltas) == 2
+        assert len(deltas) == 2   # two delta maps, or two equally long LISTS of delta maps (one per concurrent shard)
         # the caller's thread comes back from a ~1 ms native call and must not wait long for the
         # GIL while the worker is between its own native calls (default switch interval: 5 ms)
         sys.setswitchinterval(5e-5)
@@ -227,10 +291,7 @@ class PipelinedShardedTsdfMap:
         t1 = time.perf_counter()
         self._check()
         self._idle[i].clear()
-        d = self.sm[i].d
-        d.clear()
-        for pos, quat, points, colors, n in shards:
-            d.integrate(kind, cfg, pos, quat, points, colors, n)
+        self.sm[i].integrate_only(kind, cfg, shards)
         self._q.put(i)
         self.stats["wait_s"] += t1 - t0
         self.stats["integrate_s"] += time.perf_counter() - t1

@@ -12,7 +12,8 @@ ID_BYTES = 128
 # every symbol include/vbx_shard.h declares
 EXPORTED_SYMBOLS = ("vbx_shard_get_unique_id", "vbx_shard_create", "vbx_shard_destroy", "vbx_shard_last_error",
                     "vbx_shard_begin_step", "vbx_shard_integrate", "vbx_shard_end_step", "vbx_shard_get_stats",
-                    "vbx_shard_owner_of")
+                    "vbx_shard_owner_of", "vbx_shard_add_delta", "vbx_shard_integrate_shards", "vbx_shard_set_pipelined",
+                    "vbx_shard_wait")
 _lib = None
 
 
@@ -34,7 +35,12 @@ def lib():
                "vbx_shard_integrate": (C.c_int, [vp, C.c_int, C.POINTER(capi.TsdfCfg), fp, fp, vp, vp, C.c_size_t, C.c_int]),
                "vbx_shard_end_step": (C.c_int, [vp, C.c_int, C.c_float, C.c_float]),
                "vbx_shard_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
-               "vbx_shard_owner_of": (C.c_int, [i32p, C.c_int])}
+               "vbx_shard_owner_of": (C.c_int, [i32p, C.c_int]),
+               "vbx_shard_add_delta": (C.c_int, [vp, vp]),
+               "vbx_shard_integrate_shards": (C.c_int, [vp, C.c_int, C.POINTER(capi.TsdfCfg), C.c_size_t, fp, fp,
+                                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
+               "vbx_shard_set_pipelined": (C.c_int, [vp, C.c_int]),
+               "vbx_shard_wait": (C.c_int, [vp])}
         for name, (res, args) in sig.items():
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
@@ -81,6 +87,29 @@ class NativeShard:
         fp = C.POINTER(C.c_float)
         self._chk(self.L.vbx_shard_integrate(self.h, int(kind), C.byref(cfg), pos.ctypes.data_as(fp), quat.ctypes.data_as(fp),
                                              C.c_void_p(int(d_points_ptr)), C.c_void_p(int(d_rgba_ptr)), int(n), int(freespace)))
+
+    def add_delta(self, delta):
+        """A further delta map (capi.Map): shard i of a step goes into delta i % n, the deltas run concurrently."""
+        self._more = getattr(self, "_more", []) + [delta]   # keep it alive
+        self._chk(self.L.vbx_shard_add_delta(self.h, delta.h))
+
+    def set_pipelined(self, on=True):
+        self._chk(self.L.vbx_shard_set_pipelined(self.h, int(on)))
+
+    def wait(self):
+        self._chk(self.L.vbx_shard_wait(self.h))
+
+    def integrate_shards(self, kind, cfg, shards, freespace=False):
+        """shards: [(pos, quat, d_points_ptr, d_rgba_ptr, n)] — all shards of this rank's step, integrated concurrently."""
+        n = len(shards)
+        pos = np.ascontiguousarray(np.stack([np.asarray(s[0], np.float32) for s in shards]) if n else np.zeros((0, 3)), np.float32)
+        quat = np.ascontiguousarray(np.stack([np.asarray(s[1], np.float32) for s in shards]) if n else np.zeros((0, 4)), np.float32)
+        pts = (C.c_void_p * max(n, 1))(*[int(s[2]) for s in shards])
+        col = (C.c_void_p * max(n, 1))(*[int(s[3]) for s in shards])
+        cnt = (C.c_size_t * max(n, 1))(*[int(s[4]) for s in shards])
+        fp = C.POINTER(C.c_float)
+        self._chk(self.L.vbx_shard_integrate_shards(self.h, int(kind), C.byref(cfg), n, pos.ctypes.data_as(fp), quat.ctypes.data_as(fp),
+                                                    pts, col, cnt, int(freespace)))
 
     def end_step(self, apply_caps=False, truncation=0.0, max_weight=0.0):
         self._chk(self.L.vbx_shard_end_step(self.h, int(apply_caps), float(truncation), float(max_weight)))
