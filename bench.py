@@ -218,12 +218,16 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
     mi, ti, ei = ref_pair()       # reference, incremental
     mb, tb, eb = ref_pair()       # reference, batch at the checkpoints
     gm = capi.Map(voxel, 16, max_blocks=8192)
+    gs = capi.Map(voxel, 16, max_blocks=8192)   # the same stream with the ESDF in the reference's own order
     gcfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
     ecfg = capi.esdf_cfg(min_distance_m=2 * voxel)
+    scfg = capi.esdf_cfg(min_distance_m=2 * voxel, reference_order=1)
+    strict_ms = []
 
-    def gpu_layer():
-        idx = gm.block_indices(capi.LAYER_ESDF)
-        v, _, _ = gm.blocks_download(idx, capi.LAYER_ESDF)
+    def gpu_layer(m=None):
+        m = m or gm
+        idx = m.block_indices(capi.LAYER_ESDF)
+        v, _, _ = m.blocks_download(idx, capi.LAYER_ESDF)
         return {tuple(int(x) for x in i): (v[k]["distance"], v[k]["observed"]) for k, i in enumerate(idx)}
 
     def compare(g, r):
@@ -256,7 +260,15 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
         gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
         L.orc_fast_reset_counter_set(0)
         ti.integrate(pose[0], pose[1], pts, col)
+        # reference order: the blocks carrying Update::kEsdf in the iteration order of the reference's own container
+        # (Layer::getAllUpdatedBlocks, layer.h:194-203) are an input of the replay
+        order = np.array([b for b in mi.block_indices(0) if mi.tsdf_block(b)[3] & 4], np.int32).reshape(-1, 3)
         ei.update_from_tsdf_layer(True)
+        gs.integrate(capi.TSDF_FAST, gcfg, pose[0], pose[1], pts, col)
+        t0 = time.perf_counter()
+        gs.esdf_update_blocks(scfg, order, incremental=True)
+        strict_ms.append((time.perf_counter() - t0) * 1e3)
+        gs.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
         L.orc_fast_reset_counter_set(0)
         tb.integrate(pose[0], pose[1], pts, col)
         if (i + 1) in checkpoints or i + 1 == n_frames:
@@ -264,8 +276,14 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
             per_frame.append(dict(frame=i + 1, **compare(g, mi.esdf_dict())))
             eb.update_from_tsdf_layer_batch()
             batch[str(i + 1)] = compare(g, mb.esdf_dict())
+    strict = compare(gpu_layer(gs), mi.esdf_dict())
+    strict["ms_per_update"] = round(float(np.median(strict_ms)), 3)
+    strict["note"] = ("vbx_esdf_cfg.reference_order = 1 (the reference's queue order replayed by one wave, DESIGN 4.4), same stream, "
+                      "final layer against the reference's incremental layer: frac_differing must be 0")
     gm.close()
+    gs.close()
     return {"frames": n_frames, "kind": "reference" if use_ref else "port",
+            "reference_order_mode_vs_reference_incremental": strict,
             "vs_reference_incremental": per_frame, "vs_reference_batch": batch,
             "note": "GPU incremental stream (updateFromTsdfLayer(true) after every frame, default Config, min_diff_m 1e-3) "
                     "against the reference's own incremental stream and against its batch update of the same TSDF at the "

@@ -221,6 +221,8 @@ struct BlockWalk {
   int sx, sy, sz;
   int bx, by, bz;
   uint32_t lin;   // lx + vps * (ly + lz * vps), block_inl.h:15-17
+  uint32_t h;     // LongIndexHash of the current voxel (block_hash.h:54-64): x + 17191 y + 17191^2 z mod 2^32, so a
+                  // step along one axis adds or subtracts that axis' multiplier
   bool entered;   // the current voxel is the walk's first or lies in another block than the previous one
 
   __device__ inline void start(const RayCaster& rc, int vps, float vps_inv) {
@@ -231,6 +233,7 @@ struct BlockWalk {
     const i3 l = local_from_global(g, vps);
     bx = b.x; by = b.y; bz = b.z;
     lin = (uint32_t)(l.x + vps * (l.y + l.z * vps));
+    h = long_index_hash(g);
     entered = true;
   }
   // One DDA step (integrator_utils.cc:111-125) from the current voxel to the next.
@@ -244,6 +247,7 @@ struct BlockWalk {
     ty = (a == 1) ? nty : ty;
     tz = (a == 2) ? ntz : tz;
     const int s = (a == 0) ? sx : ((a == 1) ? sy : sz);
+    h += (uint32_t)s * ((a == 0) ? 1u : ((a == 1) ? 17191u : 295530481u));
     const int shift = a * vps_log2;
     const int la = (int)((lin >> shift) & (uint32_t)(vps - 1)) + s;
     const bool lo = la < 0, hi = la >= vps;

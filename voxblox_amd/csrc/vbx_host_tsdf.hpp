@@ -497,10 +497,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   }
   const size_t vox_cap = (size_t)R * per_ray + 64;
   HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
+  HIP_TRY(ctx->b_vhash.ensure(vox_cap * 4));
   HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
   auto build_lists = [&]() -> int {
     KLAUNCH(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
-                       ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
+                       ctx->b_vox.as<uint32_t>(), ctx->b_vhash.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
                        (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
     KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
                        ctx->b_newlist.as<uint32_t>(), ctx->d_state);
@@ -509,7 +510,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     // workgroups leave at once); capacity / lookup errors surface at the solver's first check
     if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
     KLAUNCH(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
-                       ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), (uint32_t)vox_cap,
+                       ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), ctx->b_vhash.as<uint32_t>(), (uint32_t)vox_cap,
                        ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
     return VBX_OK;
   };
@@ -663,14 +664,13 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
                        ctx->obs_epoch);
   if (strict_set) {
     tmark(ctx, 8);
-    // refinement rounds (see k_strict_keys): T lives in b_T / b_TH alternately, probe offsets in b_cnt
+    // refinement rounds (see k_strict_keys): T lives in b_T (updated in place), probe offsets in b_cnt
     if (!ctx->obsset_init) {
       HIP_TRY(ctx->b_obsset.ensure((size_t)kSetSize * 4));
       HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kSetSize * 4, s));
       ctx->obsset_init = true;
     }
     uint32_t* Tcur = ctx->b_T.as<uint32_t>();
-    uint32_t* Tnext = ctx->b_TH.as<uint32_t>();
     uint32_t* poff = ctx->b_cnt.as<uint32_t>();
     HIP_TRY(ctx->b_moved.ensure((size_t)R + 1));
     HIP_TRY(hipMemsetAsync(&ctx->d_state->sentinel_cleared, 0, 4, s));
@@ -726,16 +726,15 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(bound, 1) * 8));
           HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(bound, 1) * 8));
           KLAUNCH(k_strict_keys, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, a, b, bound, ctx->b_off.as<uint32_t>(),
-                             ctx->b_vox.as<uint32_t>(), m, ctx->b_keys0.as<uint64_t>(), ctx->d_state);
+                             ctx->b_vhash.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), ctx->d_state);
           rc = stable_sort01(ctx, std::max<uint32_t>(n_sort, 1), 44, 64, false, exact_n ? nullptr : &ctx->d_state->rp_n);
           if (rc) return rc;
           KLAUNCH(k_strict_outcome, grid_for(std::max<uint32_t>(n_sort, 1)), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), ctx->d_state,
                              ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,
                              ctx->b_collided.as<uint8_t>());
-          KLAUNCH(k_strict_scan, grid_for((size_t)(R + 1) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
-                             R, a, b, ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur, Tnext,
+          KLAUNCH(k_strict_scan, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, ctx->b_off.as<uint32_t>(),
+                             R, a, b, ctx->b_collided.as<uint8_t>(), c.max_consecutive, Tcur,
                              ctx->b_U.as<uint32_t>(), ctx->b_moved.as<uint8_t>(), done, grow_mult, ctx->d_state);
-          std::swap(Tcur, Tnext);
           ++rounds;
         }
         rc = sync_state(ctx);
@@ -759,7 +758,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         (void)first;
         // measured: a check costs about as much as one idle round (the rounds are bound by their ~10
         // dependent kernels, not by the read-back), so batches stay short: 1, 1, 1, then pairs
-        batch = done >= 3 ? 2 : 1;
+        // a block of the fine-voxel replay needs a few dozen rounds (each fixes the next link of its dependency chains):
+        // there the checks are spread further (measured at 0.02 m: rounds 187 -> see DESIGN 4.3)
+        static const uint32_t blk_batch = getenv("VBX_REPLAY_BATCH") ? (uint32_t)atoi(getenv("VBX_REPLAY_BATCH")) : 2u;
+        if (a != 0 || b != R) batch = done >= 2 ? blk_batch : 1;
+        else batch = done >= 3 ? 2 : 1;
       }
       ctx->rp_last_p = ctx->h_state.rp_n;
       // converged: the sorted probe list of the last round (whose T equals the final T) is still
@@ -815,7 +818,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           return VBX_ERR_HIP;
         }
       }
-      constexpr uint32_t kBlocks = 16;
+      static const uint32_t kBlocks = getenv("VBX_REPLAY_BLOCKS") ? (uint32_t)atoi(getenv("VBX_REPLAY_BLOCKS")) : 16u;  // measurement switch
       const uint64_t p_lo = hp[r_lo], p_hi = hp[R];
       uint32_t a = r_lo;
       for (uint32_t j = 1; j <= kBlocks && a < R; ++j) {

@@ -76,7 +76,7 @@ constexpr int kListRPW = 64;  // rays per wave in k_fast_build_lists
 template <int RPW>
 __global__ void __launch_bounds__(256)
 k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
-                   uint32_t* vox, uint32_t vox_cap, uint32_t* new_list, const uint32_t* __restrict__ redo_in,
+                   uint32_t* vox, uint32_t* vhash, uint32_t vox_cap, uint32_t* new_list, const uint32_t* __restrict__ redo_in,
                    uint32_t* redo_out, DevState* st) {
   // First pass (redo_in == nullptr): blocks met for the first time are inserted into the map
   // here (the block part of allocateStorageAndGetVoxelPtr, tsdf_integrator.cc:97-126); they
@@ -89,6 +89,7 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
   // 16 list entries in LDS, then ALL 64 lanes write them out ray by ray as 64-byte runs (4 rays
   // per store instruction) instead of scattered dwords.
   __shared__ uint32_t s_buf[4][RPW][17];  // [wave][ray][entry], padded against bank conflicts
+  __shared__ uint32_t s_h[4][RPW][17];    // the entries' LongIndexHash values (what the observed-set replay probes with)
   __shared__ uint64_t s_keys[4][RPW][17]; // keys, then pool slots, of the blocks a ray enters within a chunk
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -132,6 +133,7 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
       int nt = 0;
       for (int j = 0; j < 16; ++j) {
         uint32_t e = 0xFFFFFFFFu;
+        if (lane < RPW) s_h[wv][lane][j] = bw.h;
         if (k0 + j < len) {
           e = bw.lin;
           if (bw.entered) {
@@ -164,7 +166,10 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
         const int src = q * 4 + sub;  // lane whose ray is being written
         const uint32_t sbase = __shfl(base, src);
         const uint32_t slen = __shfl(len, src);
-        if (k0 + e < slen) vox[sbase + k0 + e] = s_buf[wv][src][e];
+        if (k0 + e < slen) {
+          vox[sbase + k0 + e] = s_buf[wv][src][e];
+          vhash[sbase + k0 + e] = s_h[wv][src][e];
+        }
       }
     }
     if (redo) redo_out[atomicAdd(&st->redo_count, 1u)] = r;
@@ -374,11 +379,13 @@ __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, Dev
 // and walking back inside the 16-slot group was slower: groups next to the sensor hold
 // thousands of probes of one hot slot.)
 __global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t r_begin, uint32_t r_end, uint32_t n_bound,
-                              const uint32_t* __restrict__ off, const uint32_t* __restrict__ vox, MapDev m,
-                              uint64_t* keys, DevState* st) {
+                              const uint32_t* __restrict__ off, const uint32_t* __restrict__ vhash, uint64_t* keys,
+                              DevState* st) {
   // 16 lanes per ray of [r_begin, r_end): the ray's probes are written as one run.  The number of probes
   // is only known on the device (rounds run in batches without a host check): the host sized the key
   // buffers for n_bound; a round that needs more raises rp_overflow and the rest of the batch idles.
+  // The hashes come from the list k_fast_build_lists left beside the voxel ids; four loads per lane are in flight
+  // (a ray of 400 probes is otherwise a chain of 25 dependent trips that the whole launch waits for).
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t p_begin = poff[r_begin], P = poff[r_end] - p_begin;
   if (t == 0) {
@@ -389,10 +396,17 @@ __global__ void k_strict_keys(const uint32_t* __restrict__ poff, uint32_t r_begi
   const uint32_t r = r_begin + (t >> 4);
   if (r >= r_end) return;
   const uint32_t p0 = poff[r], n = poff[r + 1] - p0, beg = off[r];
-  for (uint32_t k = t & 15u; k < n; k += 16) {
-    const uint32_t h = long_index_hash(voxel_of_gid(m, vox[beg + k]));
-    const uint32_t p = p0 + k;  // ascends in (ray, step) order = time
-    keys[p - p_begin] = ((uint64_t)(h & 0xFFFFFu) << 44) | ((uint64_t)(h >> 20) << 32) | p;
+  for (uint32_t k = t & 15u; k < n; k += 64) {
+    uint32_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = vhash[beg + ((k + 16 * j < n) ? k + 16 * j : k)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t kk = k + 16 * j;
+      if (kk >= n) break;
+      const uint32_t p = p0 + kk;  // ascends in (ray, step) order = time
+      keys[p - p_begin] = ((uint64_t)(h[j] & 0xFFFFFu) << 44) | ((uint64_t)(h[j] >> 20) << 32) | p;
+    }
   }
 }
 __device__ inline uint32_t strict_key_slot(uint64_t key) { return (uint32_t)(key >> 44); }
@@ -424,27 +438,22 @@ __global__ void k_strict_outcome(const uint64_t* __restrict__ keys, const DevSta
 // terminating run must probe further: its guess grows and the next round tells.
 __global__ void __launch_bounds__(256)
 k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ off, uint32_t R, uint32_t r_begin,
-              uint32_t r_end, const uint8_t* __restrict__ collided, int max_consecutive,
-              const uint32_t* __restrict__ T, uint32_t* Tnew, uint32_t* U, uint8_t* moved, uint32_t round_idx,
-              uint32_t grow_mult, DevState* st) {
-  // rays outside [r_begin, r_end) keep their probe count (they are final, or not in play yet)
+              uint32_t r_end, const uint8_t* __restrict__ collided, int max_consecutive, uint32_t* T, uint32_t* U,
+              uint8_t* moved, uint32_t round_idx, uint32_t grow_mult, DevState* st) {
+  // Only the rays of [r_begin, r_end) are in play: the grid covers that range and T is updated IN PLACE (a ray reads
+  // nothing but its own count and its own outcomes).  Rays outside keep their count (they are final, or not in play
+  // yet); an idling round (rp_overflow) changes nothing.
   // 16 lanes per ray: 16 outcomes per step, the consecutive-collision counter is the run length
-  // of the ballot mask (as in sweep_ray)
+  // of the ballot mask (as in sweep_ray); the next step's outcomes are in flight while this step's ballots run
   constexpr int G = 16;
   const int lane = threadIdx.x & 63;
   const int grp = lane / G, gl = lane % G;
-  const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) / G;
-  if (r == R && gl == 0) {
-    Tnew[R] = 0;
+  const uint32_t r = r_begin + (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // terminators of the exclusive scans over T and U
+    T[R] = 0;
     U[R] = 0;
   }
-  // an idling round (rp_overflow) hands every probe count on unchanged: the host swaps T / Tnew per round
-  const bool in_range = r >= r_begin && r < r_end && !st->rp_overflow;
-  if (r < R && !in_range && gl == 0) {
-    Tnew[r] = T[r];
-    if (!st->rp_overflow) moved[r] = 0;
-  }
-  const bool ray_ok = r < R && in_range;
+  const bool ray_ok = r < r_end && !st->rp_overflow;
   const uint32_t t = ray_ok ? T[r] : 0;
   const uint32_t len = ray_ok ? off[r + 1] - off[r] : 0;
   const uint32_t p0 = ray_ok ? poff[r] : 0;
@@ -453,10 +462,12 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
   int carry = 0;
   uint32_t tn = t;
   bool broke = false, done = (t == 0);
+  uint8_t c_pf = (gl < t) ? collided[p0 + gl] : 0;
   for (uint32_t base = 0; __any(!done); base += G) {
     const uint32_t k = base + gl;
     const bool act = !done && k < t;
-    const bool c = act && collided[p0 + k] != 0;
+    const bool c = act && c_pf != 0;
+    c_pf = (!done && k + G < t) ? collided[p0 + k + G] : 0;
     const unsigned long long C = (__ballot(c) >> (grp * G)) & gmask;
     const unsigned long long z = ~C & below;
     const int run = z ? (gl - (63 - __clzll((long long)z))) : (gl + 1);
@@ -476,7 +487,7 @@ k_strict_scan(const uint32_t* __restrict__ poff, const uint32_t* __restrict__ of
   }
   if (gl == 0 && ray_ok) {
     if (!broke && t < len) tn = min(len, max(grow_mult * t, t + 16u));  // surplus probes vanish again next round
-    Tnew[r] = tn;
+    if (tn != t) T[r] = tn;
     U[r] = broke ? tn - 1 : tn;  // the terminating probe's voxel is not updated
     moved[r] = (tn != t) ? 1 : 0;
     if (tn != t) st->rp_changed_round = round_idx + 1;  // same value from every writer of the round
