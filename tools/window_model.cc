@@ -274,6 +274,30 @@ extern "C" int frontier_model(const float* pos, const float* quat, const float* 
         Tg[r] = guess_mode == 0 ? t : std::min<uint32_t>(len, (uint32_t)guess_const);
       }
     }
+    if (guess_mode == 2) {
+      // guess = the rays taken guess_const at a time: every ray of a window evaluated against the set content the
+      // window found (no look at the other rays of the window), then the window's probes written in time order
+      std::vector<uint64_t> gset(1u << 20, 0ull);
+      uint64_t wrong = 0;
+      for (uint32_t r0 = 0; r0 < R; r0 += (uint32_t)guess_const) {
+        const uint32_t r1 = std::min<uint32_t>(R, r0 + (uint32_t)guess_const);
+        for (uint32_t r = r0; r < r1; ++r) {
+          int cons = 0;
+          uint32_t t = 0;
+          for (uint32_t k = off[r]; k < off[r + 1]; ++k) {
+            ++t;
+            if (gset[hash[k] & 0xFFFFFu] == (uint64_t)hash[k]) ++cons; else cons = 0;
+            if (cons > maxc) break;
+          }
+          Tg[r] = t;
+          wrong += (t != Tseq[r]);
+        }
+        for (uint32_t r = r0; r < r1; ++r)
+          for (uint32_t k = 0; k < Tg[r]; ++k) gset[hash[off[r] + k] & 0xFFFFFu] = hash[off[r] + k];
+      }
+      fprintf(stderr, "windowed guess (W=%d): %llu of %u rays differ from the sequential result\n", guess_const,
+              (unsigned long long)wrong, R);
+    }
   }
   std::vector<uint64_t> set(1u << 20, 0ull);
   struct E { uint32_t slot, p, hash; };
