@@ -48,7 +48,7 @@ int esdf_ensure(vbx_ctx* ctx) {
 
 template <int VPS, bool FULL>
 int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, uint32_t used,
-               uint32_t* sweeps) {
+               uint32_t* sweeps, uint32_t* g_sweep) {
   hipStream_t s = ctx->stream;
   HIP_TRY(hipMemsetAsync(&ctx->d_state->changed, 0, 4, s));
   if (FULL && mode == 1) {
@@ -74,7 +74,9 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
     }
   }
   if (mode == 2) {
-    KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, 1u, ctx->d_state);
+    ++*g_sweep;
+    KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, 1u, ctx->d_state,
+                       FULL ? 0u : *g_sweep, 1);
     ++*sweeps;
     return VBX_OK;
   }
@@ -86,9 +88,12 @@ int esdf_phase(vbx_ctx* ctx, const EsdfDev& e, const EsdfCfgDev& c, int mode, ui
     constexpr int kPerCheck = 3;
     for (int i = 0; i < kPerCheck; ++i) {
       ++sweep_no;
+      ++*g_sweep;
+      // quasi-Euclidean: the blocks of a sweep are found by their tag (= update-wide sweep number; the first sweep of a
+      // phase takes everything touched so far) — no rotate launch between the sweeps
       KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, ctx->map, e, c, mode, sweep_no,
-                         ctx->d_state);
-      KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
+                         ctx->d_state, FULL ? 0u : *g_sweep, sweep_no == 1 ? 1 : 0);
+      if (FULL) KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 0);
     }
     int rc = sync_state(ctx);
     if (rc) return rc;
@@ -157,22 +162,23 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   tmark(ctx, 1);
   ctx->counters.esdf_blocks = ctx->h_state.esdf_blocks;
   uint32_t sweeps = 0;
+  uint32_t g_sweep = 0;  // sweep number across the phases of this update (the tile kernel's scheduling tag)
   // The wavefronts run to their exact fixed points: min_diff_m only gates the TSDF->ESDF copy
   // of phase 1 (see DESIGN.md §ESDF for why the relaxation itself uses strict improvement).
   EsdfCfgDev cr = c;
   cr.min_diff = 0.0f;
   if (ctx->h_state.esdf_blocks || robot_pending) {
     if (ctx->h_state.esdf_raise_any || robot_pending) {
-      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 0, used, &sweeps);
+      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 0, used, &sweeps, &g_sweep);
       if (rc) return rc;
-      KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+      if (FULL) KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
     }
     tmark(ctx, 3);
-    rc = esdf_phase<VPS, FULL>(ctx, e, cr, 1, used, &sweeps);
+    rc = esdf_phase<VPS, FULL>(ctx, e, cr, 1, used, &sweeps, &g_sweep);
     if (rc) return rc;
-    KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
+    if (FULL) KLAUNCH(k_esdf_rotate_active, grid_for(used), dim3(256), 0, s, e, used, 1);
     if (!FULL) {  // full-Euclidean parents are part of the state, not a by-product to canonicalise
-      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 2, used, &sweeps);
+      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 2, used, &sweeps, &g_sweep);
       if (rc) return rc;
     }
     tmark(ctx, 6);

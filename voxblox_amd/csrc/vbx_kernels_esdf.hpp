@@ -22,7 +22,9 @@ struct EsdfDev {
   float* dist;
   uint32_t* state;    // bits 0-3 flags, 8-15 / 16-23 / 24-31 parent x/y/z (int8)
   uint8_t* raised;    // 1 = raised during the current update
-  uint32_t* active;   // per slot: 1 = process this sweep, 2 = process next sweep, 4 = touched
+  uint32_t* active;   // per slot: 1 = process this sweep, 2 = process next sweep (full-Euclidean colour sweeps), 4 = touched,
+                      // 8 / 16 / 32 = classification marks; bits 8..31 = the update-wide sweep number at which the block
+                      // runs next (quasi-Euclidean sweeps: a tag instead of a rotate launch after every sweep)
 };
 struct EsdfCfgDev {
   float max_distance, min_distance, default_distance, min_diff, min_weight;
@@ -262,7 +264,7 @@ constexpr int kEsdfThreads = 1024;  // one workgroup relaxes one block; big fron
 // previous iteration's state before any of them is written (Jacobi).
 template <int VPS, bool FULL>
 __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
-                                                   uint32_t sweep_no, DevState* st) {
+                                                   uint32_t sweep_no, DevState* st, uint32_t g_sweep = 0, int first = 0) {
   constexpr int T = VPS + 2;
   constexpr int NT = T * T * T;
   constexpr int NV = VPS * VPS * VPS;
@@ -275,7 +277,12 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
   __shared__ int s_flag;
   const uint32_t slot = blockIdx.x;
   if (!(m.blk_flags[slot] & kFlagEsdfAlloc)) return;
-  if (!(e.active[slot] & 1u)) return;
+  {
+    const uint32_t a = e.active[slot];
+    // g_sweep != 0: tagged scheduling — the block runs in the sweep it was tagged for, and in the first sweep of a
+    // phase if anything touched it during this update; g_sweep == 0: the rotating flags of the colour sweeps
+    if (g_sweep ? !((a >> 8) == g_sweep || (first && (a & 4u))) : !(a & 1u)) return;
+  }
   if (FULL && mode == 1 && esdf_block_colour(m, slot) != (int)(sweep_no & 7u)) return;
   const int tid = threadIdx.x;
   if (tid < 27) {
@@ -515,7 +522,22 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
   }
   if (tid == 0) atomicOr(&m.blk_flags[slot], kFlagEsdfDirty);  // the wavefront changed this block: the host mirror must take it
   if (mode != 2) {
-    if (tid < 27 && s_nb[tid] != kInvalidSlot) atomicOr(&e.active[s_nb[tid]], 2u | 4u);
+    if (tid < 27 && s_nb[tid] != kInvalidSlot) {
+      if (g_sweep) {  // tag the block and its neighbours for the next sweep (max of the tags: a later mark must not be lost)
+        uint32_t* w = &e.active[s_nb[tid]];
+        uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+          const uint32_t tag = max(old >> 8, g_sweep + 1u);
+          const uint32_t want = (tag << 8) | (old & 0xFFu) | 4u;
+          if (want == old) break;
+          const uint32_t prev = atomicCAS(w, old, want);
+          if (prev == old) break;
+          old = prev;
+        }
+      } else {
+        atomicOr(&e.active[s_nb[tid]], 2u | 4u);
+      }
+    }
     if (tid == 0) {
       atomicMax(&st->changed, sweep_no);  // the last sweep (1-based, per phase) in which a block changed
       atomicAdd(&st->esdf_relax_blocks, 1u);

@@ -130,7 +130,10 @@ k_rsort_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ v
 // ---------------------------------------------------------------------------
 constexpr int kFsThreads = 1024;
 constexpr int kFsWaves = kFsThreads / 64;
-constexpr int kFsItems = 8;
+#ifndef KFS_ITEMS
+#define KFS_ITEMS 8
+#endif
+constexpr int kFsItems = KFS_ITEMS;
 constexpr int kFsTile = kFsThreads * kFsItems;  // 8192 keys per workgroup
 constexpr int kFsMaxTiles = 512;                // <= 4 M keys (beyond that rocPRIM sorts)
 constexpr int kFsMaxBits = 10;                  // one digit per thread
