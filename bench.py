@@ -587,9 +587,18 @@ def main():
     force_sharded = bool(os.environ.get("VBX_FORCE_SHARDED")) and "RANK" in os.environ
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # test hook (tests/test_gpu_multi_merge.py): several ranks on ONE GPU over gloo, so that the N > 1 control flow of
+    # this file — shard dealing, pipelined exchange, barriers, the MAX over ranks — runs on a one-GPU box (RCCL refuses
+    # two ranks on one device).  Never set by the driver.
+    one_gpu_gloo = os.environ.get("VBX_BENCH_ONE_GPU_GLOO") == "1"
+    if one_gpu_gloo:
+        local_rank = 0
     if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if "RANK" in os.environ and world != args.gpus and rank == 0:
@@ -624,7 +633,7 @@ def main():
         dt, exch, rows, alg, _maps = run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
                                                   lambda: barrier())
         if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=("cpu" if dist.get_backend() == "gloo" else dev), dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         pts_step = 4 * 307200
@@ -645,8 +654,8 @@ def main():
             # the driver's N = 1 run of `bench.py` is configs[1] (the metric's own configuration), a different workload:
             # the one-GPU point of THIS curve is the same shard + merge on one GPU
             out["n1_same_workload"] = {"command": "python bench.py --gpus 1 --workload sensors4",
-                                       "measured": "profiles/r02_bench_sensors4_1gpu.json: 8.1 Mpoints/s, 151.6 ms per step "
-                                                   "(MI355X, round 2)",
+                                       "measured": "profiles/r03_bench_sensors4_1gpu.json: 16.9 Mpoints/s, 72.5 ms per step "
+                                                   "(MI355X, round 3; the four sensors' delta maps integrated concurrently)",
                                        "note": "strong-scaling efficiency at N = value / (N x that value); do not divide by the "
                                                "configs[1] line"}
         if rank == 0 and rows:

@@ -210,3 +210,28 @@ def test_pipelined_exchange_equals_sequential():
         assert np.array_equal(a[k][0].view(np.uint32), b[k][0].view(np.uint32))
         assert np.array_equal(a[k][1].view(np.uint32), b[k][1].view(np.uint32))
         assert np.array_equal(a[k][2], b[k][2])
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's N > 1 flow end to end — launched the way the driver launches it, two ranks, configs[4] dealt out at
+    world 2 (two sensors per rank, a delta map each, integrated concurrently), the exchange between the ranks pipelined
+    behind the next step, barriers, MAX over ranks — on ONE GPU: the collective layer is gloo here because RCCL refuses
+    two ranks on one device (VBX_BENCH_ONE_GPU_GLOO, a test hook).  The native exchange needs RCCL and is covered per
+    rank by tests/test_shard_native.py and test_gpu_sensors4_parity.py."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from test_multi_gpu_gloo import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBX_BENCH_ONE_GPU_GLOO="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--voxel", "0.05", "--no-cpu-baseline", "--profile-frames", "0"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["steps"] == 2
+    assert out["config"]["world_size_seen"] == 2 and out["exchange"]["payload_bytes_per_step"] > 0
+    assert "n1_same_workload" in out
