@@ -566,8 +566,9 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     sa.U = ctx->b_U.as<uint32_t>();
     sa.obs = keep_observed ? ctx->b_obs.as<uint32_t>() : nullptr;
     sa.obs_epoch = ctx->obs_epoch;
-    // sweep 0: publish the full-path possible claims (TH = path length);
-    // sweep 1: lower bounds only (TH cannot move while there are no certain claims);
+    // k_fast_seed_claims: the first max_consecutive + 1 probes of every ray are certain (TL), TH = path length;
+    // sweep 0: upper bounds from those certain claims, possible claims published up to them (h_only);
+    // sweep 1: lower bounds only;
     // sweeps 2..: both bounds, open rays only.  (A persistent tail kernel with grid barriers
     // instead of launches was measured slower: 1.07 vs 0.98 ms — barrier + L2 write-back per
     // sweep cost more than a launch.)
@@ -580,6 +581,10 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     bool have_list = false;
     uint32_t* lists[2] = {ctx->b_act0.as<uint32_t>(), ctx->b_act1.as<uint32_t>()};
     uint32_t* chs[2] = {ctx->b_own0.as<uint32_t>(), ctx->b_own1.as<uint32_t>()};
+    static const bool full_path_start = getenv("VBX_SOLVER_FULL_PATH_START") != nullptr;  // A/B switch: round 2's first sweep
+    if (!full_path_start)
+      KLAUNCH(k_fast_seed_claims, grid_for(R + 1), dim3(256), 0, s, sa.off, sa.vox, R, sa.cl, sa.tag_cl, s_bits, c.max_consecutive,
+                         sa.TL, sa.TH, sa.U);
     for (;;) {
       {
         // sweeps per host check (an idle sweep is ~5 us, a check ~30 us): the first three give
@@ -588,7 +593,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         int kBatch = (iters == 0) ? 3 : 4;
         if (iters == 3 && ctx->fast_last_iters > 7) kBatch = (int)ctx->fast_last_iters - 3 + 1;
         for (int b = 0; b < kBatch; ++b) {
-          sa.init = (iters == 0) ? 1 : 0;
+          sa.init = (full_path_start && iters == 0) ? 1 : 0;
+          sa.h_only = (!full_path_start && iters == 0) ? 1 : 0;
           sa.sweep_idx = iters;
           sa.l_only = (iters == 1) ? 1 : 0;
           const bool writes_ch = !sa.l_only;
@@ -602,7 +608,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           sa.ch_wr = chs[ch_flip ^ 1];
           sa.tag_rd = tag_rd;
           sa.tag_wr = writes_ch ? --ctx->own_tag : 0;
-          if (iters == 0)
+          if (iters == 0 && full_path_start)
             KLAUNCH(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
           else if (n_open <= 8192)  // few open rays: a whole wave per ray (64 list entries per step)
             KLAUNCH(k_fast_sweep<64>, grid_for((size_t)n_open * 64), dim3(256), 0, s, sa, R, ctx->d_state);
