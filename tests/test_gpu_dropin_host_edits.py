@@ -181,3 +181,54 @@ def test_update_bits_set_by_the_host_trigger_an_upload(oracle):
     m.tsdf_block_set(k, d[k][0], d[k][1], d[k][2], 7)   # same voxels, all bits set again
     it.integrate(frames[2][0][0], frames[2][0][1], frames[2][1], frames[2][2])
     assert m.dropin_stats()["uploaded_blocks"] == 1
+
+
+def test_loaded_esdf_layer_is_uploaded_and_updated_incrementally(oracle):
+    """esdf_server::loadMap loads BOTH layers into the host maps and then keeps updating incrementally.  The ESDF
+    drop-in must take the host's ESDF blocks (reconcileEsdfFromHost -> vbx_blocks_upload of the 20-byte EsdfVoxel AoS)
+    as the state the next incremental update starts from: afterwards the observed masks equal the CPU build's and the
+    distances lie inside the reference's own incremental envelope (the default device wavefront is order-free,
+    test_sdf_integrators.cc:270), exactly as for a layer the drop-in computed itself."""
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    frames = S.frames(6)
+
+    def esdf_cfg(L):
+        c = oracle.EsdfCfg()
+        L.orc_esdf_cfg_default(C.byref(c))
+        c.min_distance_m = 2 * VOXEL
+        return c
+
+    # source of the "file": three frames through the CPU build, TSDF + incremental ESDF
+    R.orc_fast_reset_counter_set(0)
+    src = oracle.OracleMap(VOXEL, 16, L=R)
+    it = src.tsdf_integrator("merged", _cfg(oracle, R))
+    es = src.esdf_integrator(esdf_cfg(R))
+    for pose, pts, col in frames[:3]:
+        it.integrate(pose[0], pose[1], pts, col)
+        es.update_from_tsdf_layer(True)
+    t_src, e_src = src.tsdf_dict(), src.esdf_dict()
+    maps = []
+    for L in (H, R):   # two fresh maps filled in the same order, then the same three frames on each
+        L.orc_fast_reset_counter_set(0)
+        m = oracle.OracleMap(VOXEL, 16, L=L)
+        for k in sorted(t_src):
+            m.tsdf_block_set(k, t_src[k][0], t_src[k][1], t_src[k][2], 3)          # kEsdf clear: nothing pending
+        for k in sorted(e_src):
+            m.esdf_block_set(k, e_src[k][0], e_src[k][1], e_src[k][2], e_src[k][3])
+        ti = m.tsdf_integrator("merged", _cfg(oracle, L))
+        ei = m.esdf_integrator(esdf_cfg(L))
+        for pose, pts, col in frames[3:]:
+            ti.integrate(pose[0], pose[1], pts, col)
+            ei.update_from_tsdf_layer(True)
+        maps.append(m)
+    assert maps[0].dropin_stats()["uploaded_blocks"] >= len(t_src) + len(e_src)
+    _same_tsdf(maps[0], maps[1])
+    g, r = maps[0].esdf_dict(), maps[1].esdf_dict()
+    assert set(g) == set(r) and len(g) >= len(e_src)
+    se = n = 0
+    for k in r:
+        assert np.array_equal(g[k][1] & 1, r[k][1] & 1), k
+        obs = (r[k][1] & 1).astype(bool)
+        se += float(((g[k][0][obs] - r[k][0][obs]) ** 2).sum())
+        n += int(obs.sum())
+    assert n > 10000 and (se / n) ** 0.5 < 1e-2, (n, (se / max(n, 1)) ** 0.5)
