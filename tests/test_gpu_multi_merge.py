@@ -168,6 +168,12 @@ def test_bench_sharded_path_over_rccl_single_rank():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["steps"] == 3
     assert out["config"]["world_size_seen"] == 1 and out["exchange"]["payload_bytes_per_step"] > 0
+    # the N > 1 default (configs[1] per rank, weak scaling) through the same one-rank RCCL communicator
+    cmd = [c for c in cmd if c not in ("--workload", "sensors4")]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["exchange"]["payload_bytes_per_step"] > 0
 
 
 def test_bench_refuses_more_ranks_than_gpus():
@@ -232,6 +238,15 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["steps"] == 2
-    assert out["config"]["world_size_seen"] == 2 and out["exchange"]["payload_bytes_per_step"] > 0
-    assert "n1_same_workload" in out
+    # the default at N > 1: configs[1] on every GPU (weak scaling of the metric's own workload) ...
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 2
+    assert out["config"]["world_size_seen"] == 2 and out["config"]["points_per_step"] == 2 * 307200
+    assert out["exchange"]["payload_bytes_per_step"] > 0
+    # ... with configs[4] dealt out over the ranks as a secondary leg of the same launch
+    leg = list(out["other_configs"].values())[0]
+    assert "error" not in leg and leg["value"] > 0 and leg["exchange"]["payload_bytes_per_step"] > 0
+    # and configs[4] as the workload proper
+    r = subprocess.run(cmd + ["--workload", "sensors4"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and "n1_same_workload" in out
