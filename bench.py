@@ -486,7 +486,7 @@ def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
                   for _ in range(2)]
     deltas = [delta_sets[0][0], delta_sets[1][0]]
     sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev),
-                                                [[multi_gpu.GpuBackend(d, dev) for d in ds] for ds in delta_sets],
+                                                [[multi_gpu.GpuBackend(d, dev, keep_slots=True) for d in ds] for ds in delta_sets],
                                                 rank, world, dist if world > 1 or os.environ.get("VBX_FORCE_COLLECTIVES") else None,
                                                 device=dev)
     cache = {}

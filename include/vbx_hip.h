@@ -245,6 +245,11 @@ int vbx_block_remove(vbx_ctx* ctx, int layer, const int32_t idx[3]);
 int vbx_blocks_remove(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size_t n);
 int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], double max_distance);
 int vbx_clear(vbx_ctx* ctx, int layer);
+/* vbx_clear(TSDF) for a scratch map that will see the same region again (the per-step delta maps of the multi-GPU
+ * sharding): the blocks are zeroed and leave the layer — vbx_num_blocks is 0 afterwards, nothing is listed, exported or
+ * downloaded — but their pool slots and hash entries stay as invisible candidates, so the next frame need not allocate
+ * its blocks again.  Observable behaviour equals vbx_clear; the pool keeps the union of the blocks ever touched. */
+int vbx_clear_keep_slots(vbx_ctx* ctx);
 /* block.updated().reset(bit) over all blocks of a layer (mesher / ESDF consumers). */
 int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask);
 

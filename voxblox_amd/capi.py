@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "vbx_last_error", "vbx_get_map_cfg", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_blocks_remove", "vbx_remove_distant_blocks",
-    "vbx_clear", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
+    "vbx_clear", "vbx_clear_keep_slots", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
     "vbx_selftest_unordered_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
 
@@ -142,6 +142,7 @@ def lib():
         "vbx_blocks_remove": (C.c_int, [vp, C.c_int, i32p, C.c_size_t]),
         "vbx_remove_distant_blocks": (C.c_int, [vp, C.c_int, f32p, C.c_double]),
         "vbx_clear": (C.c_int, [vp, C.c_int]),
+        "vbx_clear_keep_slots": (C.c_int, [vp]),
         "vbx_clear_updated": (C.c_int, [vp, C.c_int, C.c_int]),
         "vbx_blocks_serialize": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, C.POINTER(C.c_uint32), u8p]),
         "vbx_blocks_deserialize": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, C.POINTER(C.c_uint32), u8p]),
@@ -399,6 +400,10 @@ class Map:
 
     def clear(self, layer=LAYER_TSDF):
         self._chk(self.L.vbx_clear(self.h, layer))
+
+    def clear_keep_slots(self):
+        """vbx_clear(TSDF) that keeps the blocks' pool slots as invisible candidates (scratch / delta maps)."""
+        self._chk(self.L.vbx_clear_keep_slots(self.h))
 
     def clear_updated(self, mask, layer=LAYER_TSDF):
         self._chk(self.L.vbx_clear_updated(self.h, layer, mask))

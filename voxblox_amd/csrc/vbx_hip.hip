@@ -674,6 +674,25 @@ int vbx_clear(vbx_ctx* ctx, int layer) {
   }
 }
 
+// removeAllBlocks for a scratch map that will see the same region again (the per-step delta maps of the sharding):
+// every TSDF block is zeroed and leaves the layer, but its hash entry and pool slot stay behind as an invisible
+// candidate (exactly the state a block has between the moment a ray's path first met it and the moment a ray reaches
+// it) — the next frame finds its blocks allocated instead of allocating all of them again and re-walking every ray
+// that met a new block.  Falls back to vbx_clear when the map also holds ESDF blocks.
+int vbx_clear_keep_slots(vbx_ctx* ctx) {
+  if (!ctx) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  // (per-voxel "observed this epoch" stamps of the exact-set n-frame mode must not outlive their block either)
+  if (ctx->esdf_init || ctx->b_obs.p) return vbx_clear(ctx, VBX_LAYER_TSDF);
+  int rc = sync_state(ctx);
+  if (rc) return rc;
+  const uint32_t used = ctx->h_state.pool_used;
+  if (used == 0) return VBX_OK;
+  hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map, (float*)nullptr, (uint32_t*)nullptr,
+                     VBX_LAYER_TSDF, f3{0.f, 0.f, 0.f}, -1.0, 0.0f);  // squared distance > -1: every block
+  return VBX_OK;
+}
+
 int vbx_clear_updated(vbx_ctx* ctx, int layer, int update_mask) {
   if (!ctx) return VBX_ERR_INVALID;
   if (layer != VBX_LAYER_TSDF && layer != VBX_LAYER_ESDF) {

@@ -635,7 +635,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         ctx->fast_redo_grid = std::max<uint32_t>(1, 2 * ctx->h_state.redo_count);
       }
       static const bool dbg_solver = getenv("VBX_DEBUG") != nullptr;
-      if (dbg_solver) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u\n", iters, n_open, R);
+      if (dbg_solver) fprintf(stderr, "[vbx] fast solver: after %u sweeps %u open rays of %u (redo rays %u, blocks published so far %u, pool used %u)\n", iters, n_open, R,
+                              ctx->h_state.redo_count, ctx->h_state.blocks_published, ctx->h_state.pool_used);
       if (n_open == 0) break;
       if (iters > 1000000 || ctx->own_tag < 128) {
         ctx->fail("Fast integrator: early-termination solver did not converge");

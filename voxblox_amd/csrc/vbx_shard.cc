@@ -198,7 +198,7 @@ int vbx_shard_begin_step(vbx_shard* s) {
   if (!s) return VBX_ERR_INVALID;
   // pipelined: the exchange of the previous step may still read the OTHER set; the one that used THIS set (two steps
   // ago) was joined by the end_step in between
-  for (size_t u = 0; u < set_size(s); ++u) VBXS(delta_of(s, s->cur_set, u), vbx_clear(delta_of(s, s->cur_set, u), VBX_LAYER_TSDF));
+  for (size_t u = 0; u < set_size(s); ++u) VBXS(delta_of(s, s->cur_set, u), vbx_clear_keep_slots(delta_of(s, s->cur_set, u)));
   s->used_in_set = 1;
   return VBX_OK;
 }
