@@ -303,6 +303,8 @@ typedef struct vbx_counters {
   uint64_t replay_rounds;   /* Fast, fast_observed_set = 0: rounds of the observed-set replay */
   uint64_t replay_block_rounds; /* ... of which: rounds run on blocks of consecutive rays (fine voxels) */
   uint64_t time_budget_exceeded; /* Fast: 1 if the last call outran cfg->max_integration_time_s (see there) */
+  uint64_t esdf_respeculated; /* ESDF: 1 if a phase needed more sweeps than were queued ahead of the read-back and the
+                                 update was finished sweep by sweep (VBX_ESDF_RAISE_SWEEPS / VBX_ESDF_LOWER_SWEEPS) */
 } vbx_counters;
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
 

@@ -563,3 +563,34 @@ def test_esdf_and_mesh_long_full_resolution_stream(oracle):
     assert s_bat["differing"] < 0.02 * s_bat["n"] and s_bat["rmse"] < 5e-3 and s_bat["max"] < 1.5 * VOXEL, s_bat
     assert s_bat["differing"] < s_ref["differing"] and s_bat["rmse"] < s_ref["rmse"]
     assert s_inc["rmse"] <= s_ref["rmse"] + s_bat["rmse"]
+
+
+def test_esdf_update_finished_sweep_by_sweep_gives_the_same_layer(monkeypatch):
+    """The update queues its raise / lower sweeps ahead of one read-back; when a phase needs more sweeps than were
+    queued, the later launches leave and the host finishes sweep by sweep (vbx_counters.esdf_respeculated).  Forced
+    here by queuing ONE sweep per phase: distances, flags, parents and updated bits equal the default run bit for bit,
+    frame after frame."""
+    from voxblox_amd import capi
+    frames = [scenes.room_frame(2 * k, 100, f=160.0, width=320, height=240) for k in range(5)]
+    gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
+    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2)
+    def run(expect_requeued):
+        gm = capi.Map(VOXEL, 16, max_blocks=4096)   # reads the environment at its first update
+        snaps, requeued = [], 0
+        for pose, pts, col in frames:
+            gm.integrate(capi.TSDF_MERGED, gt, pose[0], pose[1], pts, col)
+            gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+            requeued += gm.counters()["esdf_respeculated"]
+            assert len(gm.blocks_updated(capi.UPDATE_ESDF)) == 0
+            snaps.append(_gpu_esdf(gm))
+        assert requeued >= 3 or not expect_requeued   # (the default run may need it too while the map is first built)
+        return snaps
+    ref = run(False)
+    monkeypatch.setenv("VBX_ESDF_RAISE_SWEEPS", "1")
+    monkeypatch.setenv("VBX_ESDF_LOWER_SWEEPS", "1")
+    low = run(True)
+    for a, b in zip(ref, low):
+        assert set(a) == set(b)
+        for k in a:
+            assert np.array_equal(a[k][0].view(np.uint32), b[k][0].view(np.uint32)), k
+            assert np.array_equal(a[k][1], b[k][1]) and np.array_equal(a[k][2], b[k][2]) and a[k][3] == b[k][3], k

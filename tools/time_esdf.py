@@ -1,8 +1,10 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import numpy as np, torch
 torch.cuda.init()
 from voxblox_amd import capi, scenes
+import os
+if os.environ.get('VBX_LIB'): capi.LIB_PATH = os.environ['VBX_LIB']
 dev = torch.device("cuda", 0)
 gm = capi.Map(0.05, 16, max_blocks=8192)
 cfg = capi.tsdf_cfg(default_truncation_distance=0.2)
@@ -24,5 +26,5 @@ for timing in (False, True):
             if timing:
                 tm = gm.timing(); ev = ev + tm['total_ms'] if 'ev' in dir() else tm['total_ms']; parts.append((round(tm['total_ms'],2), round(tm['prep_ms'],2), round(tm['solve_ms'],2), round(tm['fold_ms'],2), gm.counters()['esdf_sweeps'], round((t2-t1)*1e3,2)))
     n = len(d) - 5
-    print(parts)
+    print(parts[-3:])
     print("timing", timing, "integrate ms", ti / n * 1e3, "esdf ms", te / n * 1e3, gm.timing() if timing else "", gm.counters())

@@ -94,6 +94,7 @@ struct DevState {
   uint32_t esdf_blocks;
   uint32_t esdf_raise_any;
   uint32_t esdf_relax_blocks;
+  uint32_t esdf_phase_changed[2];  // raise / lower: the last update-wide sweep number in which a block changed
   uint32_t act_count[3];
 #ifdef VBX_FOLD_STATS
   uint32_t dbg[16];

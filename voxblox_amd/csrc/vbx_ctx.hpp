@@ -65,6 +65,7 @@ struct vbx_ctx {
   DBuf b_edist, b_estate, b_eraised, b_eactive;
   bool esdf_init = false;
   bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
+  int esdf_spec_raise = 0, esdf_spec_lower = 0;  // sweeps queued ahead of the read-back (esdf_update_t)
   // mesher output of the last vbx_mesh_generate call (vbx_host_mesh.hpp)
   DBuf b_mesh_list, b_mesh_cnt, b_mesh_off, b_mesh_tab, b_mesh_verts, b_mesh_normals, b_mesh_colors;
   std::vector<int32_t> mesh_idx;        // block index per meshed block

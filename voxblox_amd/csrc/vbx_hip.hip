@@ -1072,3 +1072,15 @@ int vbx_profile_get(vbx_ctx* ctx, char* buf, size_t cap, size_t* needed, uint64_
 }
 
 }  // extern "C"
+
+#ifdef VBX_ESDF_STATS
+// measurement build only (tools/esdf_tile_stats.py)
+extern "C" int vbx_debug_esdf_stats(unsigned long long out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_esdf_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_esdf_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -2,8 +2,16 @@
 // Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
 
 namespace {
-__global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int drop_layer, int keep_classify_pending) {
+__global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int drop_layer, int keep_classify_pending,
+                                   DevState* st) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) {  // the update's counters
+    st->esdf_blocks = 0;
+    st->esdf_raise_any = 0;
+    st->esdf_relax_blocks = 0;
+    st->esdf_phase_changed[0] = 0;
+    st->esdf_phase_changed[1] = 0;
+  }
   if (s >= n_slots) return;
   // blocks addNewRobotPosition left work in: 8 = take part in this update (their voxels sit in
   // open_/raise_), 16 = also re-run the TSDF classification on them
@@ -14,6 +22,19 @@ __global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int dr
   uint32_t nf = f & ~((keep_classify_pending ? 0u : kFlagEsdfPendClassify) | kFlagEsdfPendOpen);
   if (drop_layer) nf &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
   if (nf != f) m.blk_flags[s] = nf;
+}
+// End of a speculatively queued update (esdf_update_t): drops the raise marks of the touched blocks and, on request, the
+// TSDF blocks' Update::kEsdf bit — unless a phase did not converge in the sweeps queued for it (the host then finishes
+// the update sweep by sweep and clears with the plain calls).
+__global__ void k_esdf_finish(MapDev m, EsdfDev e, uint32_t nvox, DevState* st, TileGuard gd, int clear_tsdf_bit) {
+  if (gd.guard0 && st->esdf_phase_changed[0] >= gd.guard0) return;
+  if (gd.guard1 && st->esdf_phase_changed[1] >= gd.guard1) return;
+  const uint32_t slot = blockIdx.x;
+  const uint32_t a = e.active[slot];
+  if (clear_tsdf_bit && threadIdx.x == 0 && (a & 8u)) m.blk_flags[slot] &= ~4u;  // updated().reset(Update::kEsdf), esdf_integrator.cc:113-121
+  if (!(a & 4u) || !(gd.force || st->esdf_raise_any)) return;
+  uint32_t* r = reinterpret_cast<uint32_t*>(e.raised + (size_t)slot * nvox);
+  for (uint32_t i = threadIdx.x; i < nvox / 4; i += blockDim.x) r[i] = 0;
 }
 __global__ void k_esdf_clear_tsdf_bit(MapDev m, EsdfDev e, uint32_t n_slots) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,8 +163,7 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   if (batch) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
   const bool robot_pending = ctx->esdf_robot_pending && !batch;
   ctx->esdf_robot_pending = false;
-  KLAUNCH(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0);
-  HIP_TRY(hipMemsetAsync(&ctx->d_state->esdf_blocks, 0, 12, s));
+  KLAUNCH(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0, ctx->d_state);
   if (list) {
     HIP_TRY(ctx->b_head.ensure(std::max<size_t>(n_list, 1) * 12));
     HIP_TRY(hipMemcpyAsync(ctx->b_head.p, list, n_list * 12, hipMemcpyHostToDevice, s));
@@ -157,16 +177,93 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
                        batch ? 0 : 1, batch ? 0 : 1, ctx->d_state);
   }
   KLAUNCH(k_esdf_seed_active, grid_for((size_t)used * 27), dim3(256), 0, s, m, e, used);
-  rc = sync_state(ctx);
-  if (rc) return rc;
-  tmark(ctx, 1);
-  ctx->counters.esdf_blocks = ctx->h_state.esdf_blocks;
   uint32_t sweeps = 0;
   uint32_t g_sweep = 0;  // sweep number across the phases of this update (the tile kernel's scheduling tag)
   // The wavefronts run to their exact fixed points: min_diff_m only gates the TSDF->ESDF copy
   // of phase 1 (see DESIGN.md §ESDF for why the relaxation itself uses strict improvement).
   EsdfCfgDev cr = c;
   cr.min_diff = 0.0f;
+  if (!FULL && (m.nvox & 3u) == 0) {
+    // Quasi-Euclidean: the whole update is queued behind ONE read-back.  A sweep that finds nothing to do costs
+    // ~4.5 us on the device, a host check ~13 us of idle stream plus the idle sweeps queued in front of it — and the
+    // phases of a frame-to-frame update need 3-4 sweeps each (tools/esdf_timeline.sh).  Every launch behind the
+    // raise sweeps carries the number of the last raise sweep, every launch behind the lower sweeps that of the last
+    // lower sweep: if a phase was still changing blocks in its last queued sweep the later launches leave at once,
+    // and the update is finished below the way it used to run (sweep by sweep, with a check every third).
+    if (ctx->esdf_spec_raise <= 0) {
+      const char* e1 = getenv("VBX_ESDF_RAISE_SWEEPS");
+      const char* e2 = getenv("VBX_ESDF_LOWER_SWEEPS");
+      ctx->esdf_spec_raise = e1 ? std::max(1, atoi(e1)) : 6;
+      ctx->esdf_spec_lower = e2 ? std::max(1, atoi(e2)) : 6;
+    }
+    tmark(ctx, 1);
+    TileGuard gd{0, 0, 1, robot_pending ? 1 : 0};
+    for (int i = 0; i < ctx->esdf_spec_raise; ++i) {
+      ++g_sweep;
+      KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, m, e, cr, 0, g_sweep, ctx->d_state, g_sweep,
+              i == 0 ? 1 : 0, gd);
+    }
+    const uint32_t g_raise = g_sweep;
+    tmark(ctx, 3);
+    gd.guard0 = g_raise;
+    for (int i = 0; i < ctx->esdf_spec_lower; ++i) {
+      ++g_sweep;
+      KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, m, e, cr, 1, g_sweep - g_raise, ctx->d_state,
+              g_sweep, i == 0 ? 1 : 0, gd);
+    }
+    const uint32_t g_lower = g_sweep;
+    gd.guard1 = g_lower;
+    ++g_sweep;
+    KLAUNCH((k_esdf_tile<VPS, FULL>), dim3(used), dim3(kEsdfThreads), 0, s, m, e, cr, 2, 1u, ctx->d_state, g_sweep, 1, gd);
+    tmark(ctx, 6);
+    KLAUNCH(k_esdf_finish, dim3(used), dim3(256), 0, s, m, e, m.nvox, ctx->d_state, gd,
+            (clear_updated_flag && !batch) ? 1 : 0);
+    tmark(ctx, 7);
+    rc = sync_state(ctx);
+    if (rc) return rc;
+    ctx->counters.esdf_blocks = ctx->h_state.esdf_blocks;
+    const bool any = ctx->h_state.esdf_blocks || robot_pending;
+    const bool raise_any = any && (ctx->h_state.esdf_raise_any || robot_pending);
+    const uint32_t ch0 = ctx->h_state.esdf_phase_changed[0], ch1 = ctx->h_state.esdf_phase_changed[1];
+    const bool raise_done = !raise_any || ch0 < g_raise;
+    const bool lower_done = !any || (raise_done && ch1 < g_lower);
+    if (raise_any) sweeps += std::min(ch0 + 1, g_raise);
+    if (any && raise_done) sweeps += (ch1 > g_raise ? std::min(ch1 - g_raise + 1, g_lower - g_raise) : 1) + 1;
+    if (!lower_done) {
+      ctx->counters.esdf_respeculated += 1;
+      if (!raise_done) {
+        rc = esdf_phase<VPS, FULL>(ctx, e, cr, 0, used, &sweeps, &g_sweep);
+        if (rc) return rc;
+      }
+      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 1, used, &sweeps, &g_sweep);
+      if (rc) return rc;
+      rc = esdf_phase<VPS, FULL>(ctx, e, cr, 2, used, &sweeps, &g_sweep);
+      if (rc) return rc;
+      if (raise_any) HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
+      if (clear_updated_flag && !batch) KLAUNCH(k_esdf_clear_tsdf_bit, grid_for(used), dim3(256), 0, s, m, e, used);
+      tmark(ctx, 7);
+      rc = sync_state(ctx);
+      if (rc) return rc;
+    }
+    ctx->counters.esdf_sweeps = sweeps;
+    ctx->counters.esdf_relaxations = ctx->h_state.esdf_relax_blocks;
+    if (ctx->timing) {
+      (void)hipEventSynchronize(ctx->ev[7]);
+      vbx_timing& o = ctx->last_timing;
+      o = vbx_timing{};
+      float t = 0;
+      (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
+      (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]);
+      o.prep_ms = t;  // phase 1 (classification)
+      (void)hipEventElapsedTime(&t, ctx->ev[1], ctx->ev[3]); o.solve_ms = t;  // raise
+      (void)hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[6]); o.fold_ms = t;   // lower + canonical parents
+    }
+    return VBX_OK;
+  }
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  tmark(ctx, 1);
+  ctx->counters.esdf_blocks = ctx->h_state.esdf_blocks;
   if (ctx->h_state.esdf_blocks || robot_pending) {
     if (ctx->h_state.esdf_raise_any || robot_pending) {
       rc = esdf_phase<VPS, FULL>(ctx, e, cr, 0, used, &sweeps, &g_sweep);
@@ -291,7 +388,7 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     HIP_TRY(hipMemsetAsync(e.state, 0, nv * 4, s));
     HIP_TRY(hipMemsetAsync(e.raised, 0, nv, s));
   }
-  KLAUNCH(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0);
+  KLAUNCH(k_esdf_reset_flags, grid_for(used), dim3(256), 0, s, m, e, used, batch ? 1 : 0, list ? 1 : 0, ctx->d_state);
   // the blocks in visiting order -> pool slots
   std::vector<uint32_t> h_slots;
   size_t n = 0;

@@ -23,7 +23,8 @@ struct EsdfDev {
   uint32_t* state;    // bits 0-3 flags, 8-15 / 16-23 / 24-31 parent x/y/z (int8)
   uint8_t* raised;    // 1 = raised during the current update
   uint32_t* active;   // per slot: 1 = process this sweep, 2 = process next sweep (full-Euclidean colour sweeps), 4 = touched,
-                      // 8 / 16 / 32 = classification marks; bits 8..31 = the update-wide sweep number at which the block
+                      // 8 / 16 / 32 = classification marks, 64 = written by the raise phase of this update, 128 = has been
+                      // through the lower phase of this update (k_esdf_tile's first pass); bits 8..31 = the update-wide sweep number at which the block
                       // runs next (quasi-Euclidean sweeps: a tag instead of a rotate launch after every sweep)
 };
 struct EsdfCfgDev {
@@ -255,6 +256,9 @@ __global__ void k_esdf_rotate_active(EsdfDev e, uint32_t n_slots, int reseed) {
 //   mode 1: processOpenSet (:371-496) as a pull relaxation over the 26-neighbourhood.
 //   mode 2: parent = first LUT neighbour that explains the converged distance exactly.
 constexpr int kEsdfThreads = 1024;  // one workgroup relaxes one block; big frontiers need the lanes
+#ifdef VBX_ESDF_STATS  // measurement build (tools/esdf_tile_stats.py): what a lower-phase workgroup spends its time on
+__device__ unsigned long long g_esdf_stats[16];
+#endif
 // FULL = Config::full_euclidean_distance: parents are accumulated vectors to the source voxel and a
 // step costs voxel_size * (|parent - direction| - |parent|) (esdf_integrator.cc:419-428).  The
 // result of that propagation depends on the path (the reference's on its queue order), so this
@@ -262,9 +266,19 @@ constexpr int kEsdfThreads = 1024;  // one workgroup relaxes one block; big fron
 // colour (parity of the block index, 8 colours) per launch, so no two adjacent blocks are relaxed
 // concurrently, and inside the tile every iteration evaluates all queued voxels against the
 // previous iteration's state before any of them is written (Jacobi).
+// Sweeps of the quasi-Euclidean update are queued ahead of the host's convergence check (esdf_update_t): a launch
+// carries the conditions under which it still makes sense — guard0 / guard1: the raise / lower phase must have gone
+// idle before the sweep with that number (otherwise the phase has not converged in the sweeps queued for it: every
+// workgroup leaves, the host finds out at its one read-back and continues sweep by sweep); force = addNewRobotPosition
+// left raise marks the classification counters do not know about.
+struct TileGuard {
+  uint32_t guard0, guard1;
+  int speculative, force;
+};
 template <int VPS, bool FULL>
 __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e, EsdfCfgDev c, int mode,
-                                                   uint32_t sweep_no, DevState* st, uint32_t g_sweep = 0, int first = 0) {
+                                                   uint32_t sweep_no, DevState* st, uint32_t g_sweep = 0, int first = 0,
+                                                   TileGuard gd = TileGuard{0, 0, 0, 0}) {
   constexpr int T = VPS + 2;
   constexpr int NT = T * T * T;
   constexpr int NV = VPS * VPS * VPS;
@@ -276,15 +290,25 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
   __shared__ uint32_t s_nb[27];
   __shared__ int s_flag;
   const uint32_t slot = blockIdx.x;
+  if (gd.speculative) {
+    if (gd.guard0 && st->esdf_phase_changed[0] >= gd.guard0) return;
+    if (gd.guard1 && st->esdf_phase_changed[1] >= gd.guard1) return;
+    if (!gd.force && (st->esdf_blocks == 0 || (mode == 0 && !st->esdf_raise_any))) return;
+  }
   if (!(m.blk_flags[slot] & kFlagEsdfAlloc)) return;
+  const uint32_t act0 = e.active[slot];
   {
-    const uint32_t a = e.active[slot];
+    const uint32_t a = act0;
     // g_sweep != 0: tagged scheduling — the block runs in the sweep it was tagged for, and in the first sweep of a
     // phase if anything touched it during this update; g_sweep == 0: the rotating flags of the colour sweeps
     if (g_sweep ? !((a >> 8) == g_sweep || (first && (a & 4u))) : !(a & 1u)) return;
   }
   if (FULL && mode == 1 && esdf_block_colour(m, slot) != (int)(sweep_no & 7u)) return;
   const int tid = threadIdx.x;
+#ifdef VBX_ESDF_STATS
+  const unsigned long long t_begin = wall_clock64();
+  unsigned long long t_loaded = 0, n_iter = 0, n_eval = 0, t_compact = 0, t_relax = 0;
+#endif
   if (tid < 27) {
     const int dx = tid % 3 - 1, dy = (tid / 3) % 3 - 1, dz = tid / 9 - 1;
     uint32_t s2 = map_find(m, pack_block_key(m.blk_idx[3 * slot] + dx, m.blk_idx[3 * slot + 1] + dy,
@@ -316,6 +340,9 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     s_r[t] = r;
   }
   __syncthreads();
+#ifdef VBX_ESDF_STATS
+  t_loaded = wall_clock64();
+#endif
 
   const float sq2 = (float)1.4142135623730951, sq3 = (float)1.7320508075688772;
   bool any_change = false;
@@ -328,7 +355,87 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     float d = s_d[t];
     bool upd = false;
     uint32_t best_parent = 0;
-    // fully unrolled: the 52 LDS reads of one voxel issue back to back
+    if (!FULL) {
+      // The 26 neighbours in LUT order against the running value, as selects: the 52 LDS reads of a voxel issue in two
+      // batches of 26 and nothing branches.  The loop is bound by its VALU work (a workgroup evaluates ~1000 voxels per
+      // iteration on 4 SIMDs, tools/esdf_tile_stats.py), so the common case gets the short form: every usable
+      // neighbour has the sign of the voxel (esdf_integrator.cc:437-458), computed on magnitudes — negation is exact, so
+      // |v| + dist and the comparison give the bits of v - dist and its comparison.  A voxel with a usable neighbour
+      // of the other sign takes the general form below from the start.
+      const float step[3] = {1.0f * c.voxel_size, sq2 * c.voxel_size, sq3 * c.voxel_size};
+      const bool dpos = d > 0.0f;
+      const float sgn = dpos ? 1.0f : -1.0f;
+      float D = d * sgn;
+      bool mismatch = false;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t sv[13];
+        float dv[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+          const int i = 13 * h + j;
+          const int tv = t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2]);
+          sv[j] = s_s[tv];
+          dv[j] = s_d[tv];
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+          const int i = 13 * h + j;
+          const float v = dv[j];
+          const bool ok = (sv[j] & kEsdfObserved) && fabsf(v) < c.max_distance;  // !(v >= max || v <= -max)
+          const bool same = (v > 0.0f) == dpos;
+          mismatch |= ok && !same;
+          const float C = v * sgn + step[i < 6 ? 0 : (i < 18 ? 1 : 2)];
+          const bool imp = ok && same && (C + c.min_diff < D);
+          D = imp ? C : D;
+          best_parent = imp ? pack_parent(kNbOff[i][0], kNbOff[i][1], kNbOff[i][2]) : best_parent;  // -direction: toward the pusher
+        }
+      }
+      if (!mismatch) {
+        *d_out = D * sgn;
+        *s_out = (s & 0xFFu) | best_parent;
+        return best_parent != 0;
+      }
+      best_parent = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t sv[13];
+        float dv[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+          const int i = 13 * h + j;
+          const int tv = t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2]);
+          sv[j] = s_s[tv];
+          dv[j] = s_d[tv];
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+          const int i = 13 * h + j;
+          const float dist = step[i < 6 ? 0 : (i < 18 ? 1 : 2)];
+          const float v = dv[j];
+          const bool ok = (sv[j] & kEsdfObserved) && !(v >= c.max_distance || v <= -c.max_distance);
+          const bool vpos = v > 0.0f, dp = d > 0.0f;
+          // same sign (esdf_integrator.cc:437-458)
+          const float cs = dp ? v + dist : v - dist;
+          const bool imp_s = dp ? (cs + c.min_diff < d) : (cs - c.min_diff > d);
+          // sign mismatch (:459-488) in its order-free form: see the FULL branch below for the rule
+          const float sgv = vpos ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+          const float potential = v - sgv * dist;
+          const float sgp = potential > 0.0f ? 1.0f : (potential < 0.0f ? -1.0f : 0.0f);
+          const float sgd = dp ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+          const float cm = (sgp == d) ? potential : sgd * dist;
+          const bool imp_m = fabsf(cm) < fabsf(d);
+          const bool same = (vpos == dp);
+          const bool imp = ok && (same ? imp_s : imp_m);
+          d = imp ? (same ? cs : cm) : d;
+          best_parent = imp ? pack_parent(kNbOff[i][0], kNbOff[i][1], kNbOff[i][2]) : best_parent;
+          upd |= imp;
+        }
+      }
+      *d_out = d;
+      *s_out = (s & 0xFFu) | best_parent;
+      return upd;
+    }
 #pragma unroll
     for (int i = 0; i < 26; ++i) {
       const int tv = t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2]);
@@ -338,7 +445,7 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
       if (dv >= c.max_distance || dv <= -c.max_distance) continue;
       float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
       uint32_t parent = pack_parent(kNbOff[i][0], kNbOff[i][1], kNbOff[i][2]);  // -direction: toward the pusher
-      if (FULL) {
+      {
         // new_parent = voxel->parent - direction; the step costs the growth of the parent vector
         int px, py, pz;
         unpack_parent(sv, &px, &py, &pz);
@@ -390,25 +497,74 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     uint8_t* s_need = s_r;  // the raise marks are not used while lowering
     for (int t = tid; t < NT; t += kEsdfThreads) s_need[t] = 0;
     __syncthreads();
+    // First pass: every voxel of a block whose interior this update has written (classification, robot spheres, the
+    // raise phase) and that has not been through this phase yet.  Any other block stands at a local fixed point — of
+    // its last run in this phase, or of the previous update, which ended at a global one — and only its halo can
+    // have changed: the voxels next to the halo.
+    const bool shell_only = !FULL && ((act0 & 128u) || !(act0 & (8u | 16u | 64u)));
     for (int v = tid; v < NV; v += kEsdfThreads) {
       const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
-      s_need[(lx + 1) + T * ((ly + 1) + T * (lz + 1))] = 1;  // first pass: everything
+      const bool shell = lx == 0 || lx == VPS - 1 || ly == 0 || ly == VPS - 1 || lz == 0 || lz == VPS - 1;
+      if (shell || !shell_only) s_need[(lx + 1) + T * ((ly + 1) + T * (lz + 1))] = 1;
     }
+    bool converged = false;
     for (int iter = 0; iter < 64 * VPS; ++iter) {
+#ifdef VBX_ESDF_STATS
+      const unsigned long long t_it0 = wall_clock64();
+#endif
       if (tid == 0) s_qn = 0;
       __syncthreads();
-      for (int v = tid; v < NV; v += kEsdfThreads) {
-        const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
-        const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
-        if (s_need[t]) {
-          s_need[t] = 0;
-          const uint32_t sv = s_s[t];
-          if ((sv & kEsdfObserved) && !(sv & kEsdfFixed)) s_q[atomicAdd(&s_qn, 1)] = (uint16_t)t;
+      {
+        // a thread's voxels: flags and states read together, ONE queue reservation per thread
+        constexpr int PER = (NV + kEsdfThreads - 1) / kEsdfThreads;
+        int tt[PER];
+        uint8_t nd[PER];
+        uint32_t sv[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          const int v = min(tid + k * kEsdfThreads, NV - 1);
+          const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+          tt[k] = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+          nd[k] = s_need[tt[k]];
+          sv[k] = s_s[tt[k]];
+        }
+        // one reservation per WAVE: ballots give every entry its rank (a per-lane atomicAdd on the one counter
+        // serialises 1024 LDS atomics per pass)
+        const int lane = tid & 63;
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        unsigned long long mk[PER];
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          if (tid + k * kEsdfThreads >= NV) nd[k] = 0;
+          if (nd[k]) s_need[tt[k]] = 0;
+          nd[k] = (nd[k] && (sv[k] & kEsdfObserved) && !(sv[k] & kEsdfFixed)) ? 1 : 0;
+          mk[k] = __ballot(nd[k]);
+          total += (int)__popcll(mk[k]);
+        }
+        if (total) {  // wave-uniform
+          int at = 0;
+          if (lane == 0) at = atomicAdd(&s_qn, total);
+          at = __shfl(at, 0);
+#pragma unroll
+          for (int k = 0; k < PER; ++k) {
+            if (nd[k]) s_q[at + (int)__popcll(mk[k] & lt)] = (uint16_t)tt[k];
+            at += (int)__popcll(mk[k]);
+          }
         }
       }
       __syncthreads();
       const int qn = s_qn;
-      if (qn == 0) break;
+      if (qn == 0) {
+        converged = true;
+        break;
+      }
+#ifdef VBX_ESDF_STATS
+      ++n_iter;
+      n_eval += (unsigned long long)qn;
+      const unsigned long long t_it1 = wall_clock64();
+      t_compact += t_it1 - t_it0;
+#endif
       if (FULL) {
         // Jacobi: NV / kEsdfThreads queue entries per thread at most, evaluated against the state
         // of the previous iteration, written after the barrier
@@ -443,20 +599,38 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
         }
       }
       __syncthreads();
+#ifdef VBX_ESDF_STATS
+      t_relax += wall_clock64() - t_it1;
+#endif
     }
+    if (!FULL && converged && !(act0 & 128u) && tid == 0) atomicOr(&e.active[slot], 128u);
   } else {
-  for (int iter = 0; iter < 4 * VPS; ++iter) {
-    bool changed = false;
-    for (int v = tid; v < NV; v += kEsdfThreads) {
-      const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
-      const int t = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
-      uint32_t s = s_s[t];
-      if (!(s & kEsdfObserved) || (s & kEsdfFixed)) continue;
-      float d = s_d[t];
-      if (mode == 0) {
+  constexpr int PER = (NV + kEsdfThreads - 1) / kEsdfThreads;
+  int tt[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int v = min(tid + k * kEsdfThreads, NV - 1);
+    const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
+    tt[k] = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
+  }
+  if (mode == 0) {
+    // raise closure: the reads of a thread's voxels issue together, then the reads of their parent voxels
+    for (int iter = 0; iter < 4 * VPS; ++iter) {
+      uint32_t sv[PER];
+      float dv[PER];
+      int tp[PER];
+      bool cand[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        sv[k] = s_s[tt[k]];
+        dv[k] = s_d[tt[k]];
+        cand[k] = s_r[tt[k]] == 0 && tid + k * kEsdfThreads < NV;
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
         int px, py, pz;
-        unpack_parent(s, &px, &py, &pz);
-        if ((px | py | pz) == 0 || s_r[t]) continue;
+        unpack_parent(sv[k], &px, &py, &pz);
+        cand[k] = cand[k] && (sv[k] & kEsdfObserved) && !(sv[k] & kEsdfFixed) && (px | py | pz) != 0;
         if (FULL) {
           // esdf_integrator.cc:340-348: the parent *direction*, parent.normalized() rounded per
           // component (std::round), has to point at the raised voxel
@@ -464,53 +638,96 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
           px = (int)roundf(dir.x);
           py = (int)roundf(dir.y);
           pz = (int)roundf(dir.z);
-          if ((px | py | pz) == 0) continue;
+          cand[k] = cand[k] && (px | py | pz) != 0;
         }
         // quasi-Euclidean parents are unit LUT offsets, so the parent voxel is inside the halo
-        const int tp = t + px + T * (py + T * pz);
-        if (s_r[tp]) {
-          s_d[t] = (float)signum(d) * c.default_distance;
-          s_s[t] = s & 0xFFu;
-          s_r[t] = 1;
+        tp[k] = cand[k] ? tt[k] + px + T * (py + T * pz) : tt[k];
+      }
+      uint8_t rp[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) rp[k] = s_r[tp[k]];
+      bool changed = false;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if (cand[k] && rp[k]) {
+          s_d[tt[k]] = (float)signum(dv[k]) * c.default_distance;
+          s_s[tt[k]] = sv[k] & 0xFFu;
+          s_r[tt[k]] = 1;
           changed = true;
         }
-        continue;
       }
-      // mode 2: canonical parent
-      {
-        int px, py, pz;
-        unpack_parent(s, &px, &py, &pz);
-        if ((px | py | pz) == 0) continue;
-        for (int i = 0; i < 26; ++i) {
-          const int tv = t + c_nb_off[i][0] + T * (c_nb_off[i][1] + T * c_nb_off[i][2]);
-          const uint32_t sv = s_s[tv];
-          if (!(sv & kEsdfObserved)) continue;
-          const float dv = s_d[tv];
-          if (dv >= c.max_distance || dv <= -c.max_distance) continue;
-          const float dist = (i < 6 ? 1.0f : (i < 18 ? sq2 : sq3)) * c.voxel_size;
-          bool hit;
-          if (dv > 0 && d > 0) hit = (dv + dist == d);
-          else if (dv <= 0 && d <= 0) hit = (dv - dist == d);
-          else {  // the sign-mismatch rule: d == potential or sign(d) * dist
-            const float potential = dv - (float)signum(dv) * dist;
-            const float cand = ((float)signum(potential) == d) ? potential : (float)signum(d) * dist;
-            hit = (cand == d);
-          }
-          if (hit) {
-            const uint32_t ns = (s & 0xFFu) | pack_parent(c_nb_off[i][0], c_nb_off[i][1], c_nb_off[i][2]);
-            if (ns != s) { s_s[t] = ns; changed = true; }
-            break;
-          }
+      any_change |= changed;
+      if (!__syncthreads_or(changed ? 1 : 0)) break;
+    }
+  } else {
+    // mode 2: canonical parent — the first LUT neighbour that explains the converged distance exactly; per voxel the
+    // 52 reads in two batches, the first hit picked by selects
+    const float step[3] = {1.0f * c.voxel_size, sq2 * c.voxel_size, sq3 * c.voxel_size};
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (tid + k * kEsdfThreads >= NV) continue;
+      const int t = tt[k];
+      const uint32_t s = s_s[t];
+      if (!(s & kEsdfObserved) || (s & kEsdfFixed) || (s >> 8) == 0) continue;
+      const float d = s_d[t];
+      bool found = false;
+      uint32_t ns = s;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t sv[13];
+        float dv[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+          const int i = 13 * h + j;
+          const int tv = t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2]);
+          sv[j] = s_s[tv];
+          dv[j] = s_d[tv];
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+          const int i = 13 * h + j;
+          const float dist = step[i < 6 ? 0 : (i < 18 ? 1 : 2)];
+          const float v = dv[j];
+          const bool ok = (sv[j] & kEsdfObserved) && !(v >= c.max_distance || v <= -c.max_distance);
+          const bool vpos = v > 0.0f, dpos = d > 0.0f;
+          const float cs = dpos ? v + dist : v - dist;
+          // the sign-mismatch rule: d == potential or sign(d) * dist
+          const float sgv = vpos ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+          const float potential = v - sgv * dist;
+          const float sgp = potential > 0.0f ? 1.0f : (potential < 0.0f ? -1.0f : 0.0f);
+          const float sgd = dpos ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+          const float cm = (sgp == d) ? potential : sgd * dist;
+          const bool hit = ok && (((vpos == dpos) ? cs : cm) == d);
+          if (hit && !found) ns = (s & 0xFFu) | pack_parent(kNbOff[i][0], kNbOff[i][1], kNbOff[i][2]);
+          found |= hit;
         }
       }
+      if (ns != s) {
+        s_s[t] = ns;
+        any_change = true;
+      }
     }
-    any_change |= changed;
-    const int more = __syncthreads_or(changed ? 1 : 0);
-    if (!more || mode == 2) break;
   }
   }
   if (any_change) s_flag = 1;
   __syncthreads();
+#ifdef VBX_ESDF_STATS
+  if (tid == 0 && mode == 1) {
+    const unsigned long long t_end = wall_clock64();
+    atomicAdd(&g_esdf_stats[0], 1ull);
+    atomicAdd(&g_esdf_stats[1], n_iter);
+    atomicMax(&g_esdf_stats[2], n_iter);
+    atomicAdd(&g_esdf_stats[3], n_eval);
+    atomicAdd(&g_esdf_stats[4], t_loaded - t_begin);
+    atomicAdd(&g_esdf_stats[5], t_end - t_loaded);
+    atomicMax(&g_esdf_stats[6], t_end - t_loaded);
+    atomicMax(&g_esdf_stats[7], t_loaded - t_begin);
+    if (s_flag) atomicAdd(&g_esdf_stats[8], 1ull);
+    atomicMax(&g_esdf_stats[9], n_eval);
+    atomicAdd(&g_esdf_stats[10], t_compact);
+    atomicAdd(&g_esdf_stats[11], t_relax);
+  }
+#endif
   if (!s_flag) return;
   for (int v = tid; v < NV; v += kEsdfThreads) {
     const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
@@ -520,6 +737,7 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     e.state[g] = s_s[t];
     if (mode == 0) e.raised[g] = s_r[t];
   }
+  if (tid == 0 && mode == 0 && !(act0 & 64u)) atomicOr(&e.active[slot], 64u);  // the raise phase wrote this block's interior
   if (tid == 0) atomicOr(&m.blk_flags[slot], kFlagEsdfDirty);  // the wavefront changed this block: the host mirror must take it
   if (mode != 2) {
     if (tid < 27 && s_nb[tid] != kInvalidSlot) {
@@ -540,6 +758,7 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     }
     if (tid == 0) {
       atomicMax(&st->changed, sweep_no);  // the last sweep (1-based, per phase) in which a block changed
+      if (g_sweep) atomicMax(&st->esdf_phase_changed[mode], g_sweep);
       atomicAdd(&st->esdf_relax_blocks, 1u);
     }
   }
