@@ -286,6 +286,9 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
   __shared__ uint32_t s_s[NT];
   __shared__ uint8_t s_r[NT];     // raise marks (mode 0) / need flags (mode 1): never both
   __shared__ uint16_t s_q[NV];    // mode 1: dense work queue
+  // mode 1, quasi-Euclidean: what a voxel offers its neighbours — its distance if it is observed and inside
+  // +-max_distance, NaN otherwise (one LDS read and no validity test per neighbour in the relaxation)
+  __shared__ float s_w[FULL ? 1 : NT];
   __shared__ int s_qn;
   __shared__ uint32_t s_nb[27];
   __shared__ int s_flag;
@@ -366,31 +369,29 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
       const bool dpos = d > 0.0f;
       const float sgn = dpos ? 1.0f : -1.0f;
       float D = d * sgn;
-      bool mismatch = false;
+      float vmin = __builtin_inff();  // the smallest sign-adjusted offer: <= 0 (< 0 for d <= 0) is a usable neighbour of the other sign
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        uint32_t sv[13];
-        float dv[13];
+        float w[13];
 #pragma unroll
         for (int j = 0; j < 13; ++j) {
           const int i = 13 * h + j;
-          const int tv = t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2]);
-          sv[j] = s_s[tv];
-          dv[j] = s_d[tv];
+          w[j] = s_w[t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2])];
         }
 #pragma unroll
         for (int j = 0; j < 13; ++j) {
           const int i = 13 * h + j;
-          const float v = dv[j];
-          const bool ok = (sv[j] & kEsdfObserved) && fabsf(v) < c.max_distance;  // !(v >= max || v <= -max)
-          const bool same = (v > 0.0f) == dpos;
-          mismatch |= ok && !same;
-          const float C = v * sgn + step[i < 6 ? 0 : (i < 18 ? 1 : 2)];
-          const bool imp = ok && same && (C + c.min_diff < D);
+          const float V = w[j] * sgn;  // NaN stays NaN: no offer
+          vmin = __builtin_fminf(vmin, V);
+          const float C = V + step[i < 6 ? 0 : (i < 18 ? 1 : 2)];
+          // min_diff_m does not gate the wavefront (the host passes 0: DESIGN.md 4.4), so the test is the bare comparison;
+          // an offer of the other sign is found through vmin and redone in the general form
+          const bool imp = C < D;
           D = imp ? C : D;
           best_parent = imp ? pack_parent(kNbOff[i][0], kNbOff[i][1], kNbOff[i][2]) : best_parent;  // -direction: toward the pusher
         }
       }
+      const bool mismatch = dpos ? (vmin <= 0.0f) : (vmin < 0.0f);
       if (!mismatch) {
         *d_out = D * sgn;
         *s_out = (s & 0xFFu) | best_parent;
@@ -484,6 +485,7 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     if (upd) {
       s_d[t] = d;
       s_s[t] = s;
+      if (!FULL) s_w[t] = (fabsf(d) < c.max_distance) ? d : __builtin_nanf("");
     }
     return upd;
   };
@@ -495,7 +497,10 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     // proportional to the number of changes, not to iterations x block size.  (A push-based
     // queue with an atomic visited bitset was measured slower: 3.1 vs 2.2 ms per update.)
     uint8_t* s_need = s_r;  // the raise marks are not used while lowering
-    for (int t = tid; t < NT; t += kEsdfThreads) s_need[t] = 0;
+    for (int t = tid; t < NT; t += kEsdfThreads) {
+      s_need[t] = 0;
+      if (!FULL) s_w[t] = ((s_s[t] & kEsdfObserved) && fabsf(s_d[t]) < c.max_distance) ? s_d[t] : __builtin_nanf("");
+    }
     __syncthreads();
     // First pass: every voxel of a block whose interior this update has written (classification, robot spheres, the
     // raise phase) and that has not been through this phase yet.  Any other block stands at a local fixed point — of
