@@ -618,7 +618,64 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     const int lx = v % VPS, ly = (v / VPS) % VPS, lz = v / (VPS * VPS);
     tt[k] = (lx + 1) + T * ((ly + 1) + T * (lz + 1));
   }
-  if (mode == 0) {
+  if (mode == 0 && !FULL) {
+    // Raise closure by pointer jumping.  A voxel the raise can reach (observed, not fixed, with a parent, not raised yet)
+    // points at its parent voxel, every other voxel of the tile at itself; per round a voxel takes over the raise mark
+    // of the voxel it points at and then points where that one pointed: a parent chain of length n inside the tile is
+    // closed in log2(n) rounds instead of n.  (In place: a pointer only ever moves along the voxel's own chain, a mark
+    // only ever comes from a voxel on it, so the order of the lanes does not matter; 13 rounds cover any chain or
+    // cycle of the 18^3 tile.)
+    uint16_t* s_nx = reinterpret_cast<uint16_t*>(s_w);
+    for (int t = tid; t < NT; t += kEsdfThreads) s_nx[t] = (uint16_t)t;
+    uint32_t sv[PER];
+    float dv[PER];
+    bool cand[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      sv[k] = s_s[tt[k]];
+      dv[k] = s_d[tt[k]];
+      cand[k] = s_r[tt[k]] == 0 && tid + k * kEsdfThreads < NV;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int px, py, pz;
+      unpack_parent(sv[k], &px, &py, &pz);
+      cand[k] = cand[k] && (sv[k] & kEsdfObserved) && !(sv[k] & kEsdfFixed) && (px | py | pz) != 0;
+      // quasi-Euclidean parents are unit LUT offsets, so the parent voxel is inside the halo
+      if (cand[k]) s_nx[tt[k]] = (uint16_t)(tt[k] + px + T * (py + T * pz));
+    }
+    __syncthreads();
+    for (int iter = 0; iter < 13; ++iter) {
+      int nx[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) nx[k] = s_nx[tt[k]];
+      uint8_t rp[PER];
+      int nn[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        rp[k] = s_r[nx[k]];
+        nn[k] = s_nx[nx[k]];
+      }
+      bool moved = false;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if (!cand[k]) continue;
+        if (rp[k]) {
+          s_d[tt[k]] = (float)signum(dv[k]) * c.default_distance;
+          s_s[tt[k]] = sv[k] & 0xFFu;
+          s_r[tt[k]] = 1;
+          cand[k] = false;
+          moved = true;
+          any_change = true;  // only a raise changes the block: a moved pointer is scratch
+        } else if (nn[k] != nx[k]) {
+          s_nx[tt[k]] = (uint16_t)nn[k];
+          moved = true;
+        }
+      }
+      if (!__syncthreads_or(moved ? 1 : 0)) break;
+    }
+  } else if (mode == 0) {
     // raise closure: the reads of a thread's voxels issue together, then the reads of their parent voxels
     for (int iter = 0; iter < 4 * VPS; ++iter) {
       uint32_t sv[PER];
@@ -668,6 +725,11 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
     // mode 2: canonical parent — the first LUT neighbour that explains the converged distance exactly; per voxel the
     // 52 reads in two batches, the first hit picked by selects
     const float step[3] = {1.0f * c.voxel_size, sq2 * c.voxel_size, sq3 * c.voxel_size};
+    if (!FULL) {  // the neighbours' offers as in the lower phase
+      for (int t = tid; t < NT; t += kEsdfThreads)
+        s_w[t] = ((s_s[t] & kEsdfObserved) && fabsf(s_d[t]) < c.max_distance) ? s_d[t] : __builtin_nanf("");
+      __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       if (tid + k * kEsdfThreads >= NV) continue;
@@ -677,6 +739,38 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
       const float d = s_d[t];
       bool found = false;
       uint32_t ns = s;
+      if (!FULL) {
+        // short form (no usable neighbour of the other sign, see the lower phase): one read, a product, a sum, a
+        // comparison and a select per neighbour; walked from the last LUT entry to the first, so the first hit stays
+        const bool dpos = d > 0.0f;
+        const float sgn = dpos ? 1.0f : -1.0f;
+        const float D = d * sgn;
+        float vmin = __builtin_inff();
+        uint32_t sel = 0;
+#pragma unroll
+        for (int h = 1; h >= 0; --h) {
+          float w[13];
+#pragma unroll
+          for (int j = 0; j < 13; ++j) {
+            const int i = 13 * h + j;
+            w[j] = s_w[t + kNbOff[i][0] + T * (kNbOff[i][1] + T * kNbOff[i][2])];
+          }
+#pragma unroll
+          for (int j = 12; j >= 0; --j) {
+            const int i = 13 * h + j;
+            const float V = w[j] * sgn;
+            vmin = __builtin_fminf(vmin, V);
+            sel = (V + step[i < 6 ? 0 : (i < 18 ? 1 : 2)] == D) ? pack_parent(kNbOff[i][0], kNbOff[i][1], kNbOff[i][2]) : sel;
+          }
+        }
+        if (!(dpos ? (vmin <= 0.0f) : (vmin < 0.0f))) {
+          if (sel != 0 && ((s & 0xFFu) | sel) != s) {
+            s_s[t] = (s & 0xFFu) | sel;
+            any_change = true;
+          }
+          continue;
+        }
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         uint32_t sv[13];
