@@ -103,6 +103,8 @@ struct DevState {
   uint32_t fold_long_count[16];  // long runs handed to fold_long_runs, one list per stripe (same-address atomics
                                  // serialise at ~90 per microsecond: a single counter cost the Simple fold 2 ms)
   uint32_t redo_count;       // rays whose voxel list must be rebuilt after slot assignment
+  uint32_t fix_count;        // list entries in blocks that got their pool slot after the list pass (k_fast_fixup)
+  uint32_t fix_overflow;     // ... more of them than the fix-up buffer holds: the queued rays are rebuilt instead
   uint32_t fast_idle_sweep;  // 0xFFFFFFFF - index of the first Fast sweep that found no open ray (0: none yet)
   uint32_t tomb_count;       // tombstones in the hash table (recycled blocks)
   // observed-set replay rounds run in batches without a host check in between (vbx_host_tsdf.hpp)
@@ -219,12 +221,13 @@ __device__ inline uint32_t map_find(const MapDev& m, uint64_t key) {
 
 // Insert-if-absent; the pool slot is assigned afterwards by k_assign_slots (temp_block_map_
 // + updateLayerWithStoredBlocks, tsdf_integrator.cc:107-126, 137-147).
-__device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* new_list,
-                                      DevState* st) {
+// Returns the table position of the key (0xFFFFFFFF if the table is full).
+__device__ inline uint32_t map_insert_key_pos(const MapDev& m, uint64_t key, uint32_t* new_list,
+                                              DevState* st) {
   uint32_t h = mix_key(key) & m.hmask;
   for (uint32_t probes = 0; probes <= m.hmask; ++probes) {
     uint64_t k = __hip_atomic_load(&m.hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == key) return;
+    if (k == key) return h;
     if (k == kEmptyKey) {
       const unsigned long long old =
           atomicCAS((unsigned long long*)&m.hkeys[h], (unsigned long long)kEmptyKey,
@@ -232,13 +235,18 @@ __device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* n
       if (old == kEmptyKey) {
         const uint32_t i = atomicAdd(&st->new_count, 1u);
         if (i < m.cap_blocks) new_list[i] = h; else atomicOr(&st->error, 1u);
-        return;
+        return h;
       }
-      if (old == key) return;
+      if (old == key) return h;
     }
     h = (h + 1) & m.hmask;
   }
   atomicOr(&st->error, 1u);
+  return 0xFFFFFFFFu;
+}
+__device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* new_list,
+                                      DevState* st) {
+  (void)map_insert_key_pos(m, key, new_list, st);
 }
 
 // Marks a block as part of the Layer and sets all Update bits (tsdf_integrator.cc:128).  The

@@ -199,7 +199,7 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
                   &ctx->b_cnt, &ctx->b_off, &ctx->b_keys0, &ctx->b_keys1, &ctx->b_vals0,
                   &ctx->b_vals1, &ctx->b_tmp, &ctx->b_head, &ctx->b_rank, &ctx->b_graze, &ctx->b_T,
-                  &ctx->b_U, &ctx->b_vox, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_hist0, &ctx->b_hist1, &ctx->b_moved, &ctx->b_scan_desc, &ctx->b_fs_hist, &ctx->b_fs_desc, &ctx->b_bbox, &ctx->w_px, &ctx->w_py, &ctx->w_pz, &ctx->w_rgba, &ctx->w_w, &ctx->w_flags, &ctx->w_bkey, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
+                  &ctx->b_U, &ctx->b_vox, &ctx->b_vhash, &ctx->b_TH, &ctx->b_cl, &ctx->b_act0, &ctx->b_act1, &ctx->b_long, &ctx->b_order, &ctx->b_obs, &ctx->b_sphere0, &ctx->b_sphere1, &ctx->b_redo, &ctx->b_fix, &ctx->b_bkeys, &ctx->b_bfirst, &ctx->b_bperm, &ctx->b_obsset, &ctx->b_collided, &ctx->b_hist0, &ctx->b_hist1, &ctx->b_moved, &ctx->b_scan_desc, &ctx->b_fs_hist, &ctx->b_fs_desc, &ctx->b_bbox, &ctx->w_px, &ctx->w_py, &ctx->w_pz, &ctx->w_rgba, &ctx->w_w, &ctx->w_flags, &ctx->w_bkey, &ctx->b_startset, &ctx->b_own0, &ctx->b_own1, &ctx->b_edist, &ctx->b_estate,
                   &ctx->b_eraised, &ctx->b_eactive, &ctx->b_mesh_list, &ctx->b_mesh_cnt, &ctx->b_mesh_off,
                   &ctx->b_mesh_tab, &ctx->b_mesh_verts, &ctx->b_mesh_normals, &ctx->b_mesh_colors, &ctx->b_bstart, &ctx->b_mgather, &ctx->b_fin};
   for (DBuf* b : bufs) b->release();

@@ -499,19 +499,25 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   HIP_TRY(ctx->b_vox.ensure(vox_cap * 4));
   HIP_TRY(ctx->b_vhash.ensure(vox_cap * 4));
   HIP_TRY(ctx->b_redo.ensure((size_t)(R + 1) * 4));
+  // open list entries (blocks that get their slot after the list pass): room for 2 M of them, the frames of a moving
+  // sensor produce a few thousand; beyond that the second pass below rebuilds the queued rays
+  const uint32_t fix_cap = (uint32_t)std::min<size_t>(vox_cap, (size_t)2 << 20);
+  HIP_TRY(ctx->b_fix.ensure((size_t)fix_cap * 12));
   auto build_lists = [&]() -> int {
     KLAUNCH(k_fast_build_lists<kListRPW>, dim3((R + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m, ctx->b_off.as<uint32_t>(),
                        ctx->b_vox.as<uint32_t>(), ctx->b_vhash.as<uint32_t>(), (uint32_t)vox_cap, ctx->b_newlist.as<uint32_t>(),
-                       (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state);
+                       (const uint32_t*)nullptr, ctx->b_redo.as<uint32_t>(), ctx->d_state, ctx->b_fix.as<uint32_t>(), fix_cap);
     KLAUNCH(k_assign_slots, grid_for(m.cap_blocks), dim3(256), 0, s, m,
                        ctx->b_newlist.as<uint32_t>(), ctx->d_state);
     KLAUNCH(k_commit_alloc, dim3(1), dim3(1), 0, s, m, ctx->d_state);
+    KLAUNCH(k_fast_fixup, dim3(256), dim3(256), 0, s, m, ctx->b_fix.as<uint32_t>(), fix_cap, ctx->b_vox.as<uint32_t>(), ctx->d_state);
     // second pass over the queued rays (grid sized for the first-frame worst case; idle
     // workgroups leave at once); capacity / lookup errors surface at the solver's first check
     if (ctx->fast_redo_grid == 0) ctx->fast_redo_grid = R;  // first frame: every block is new
     KLAUNCH(k_fast_build_lists<kListRPW>, dim3((std::max<uint32_t>(ctx->fast_redo_grid, 1024) + 4 * kListRPW - 1) / (4 * kListRPW)), dim3(256), 0, s, kt, c, m,
                        ctx->b_off.as<uint32_t>(), ctx->b_vox.as<uint32_t>(), ctx->b_vhash.as<uint32_t>(), (uint32_t)vox_cap,
-                       ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state);
+                       ctx->b_newlist.as<uint32_t>(), ctx->b_redo.as<uint32_t>(), (uint32_t*)nullptr, ctx->d_state,
+                       (uint32_t*)nullptr, 0u);
     return VBX_OK;
   };
   rc = build_lists();
@@ -657,7 +663,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     rc = grow_pool(ctx);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(&ctx->d_state->act_count[0], 0, 12, s));
-    HIP_TRY(hipMemsetAsync(&ctx->d_state->redo_count, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(&ctx->d_state->redo_count, 0, 12, s));  // + fix_count, fix_overflow
     HIP_TRY(hipMemsetAsync(&ctx->d_state->fast_idle_sweep, 0, 4, s));
     rc = build_lists();
     if (rc) return rc;

@@ -77,12 +77,17 @@ template <int RPW>
 __global__ void __launch_bounds__(256)
 k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
                    uint32_t* vox, uint32_t* vhash, uint32_t vox_cap, uint32_t* new_list, const uint32_t* __restrict__ redo_in,
-                   uint32_t* redo_out, DevState* st) {
+                   uint32_t* redo_out, DevState* st, uint32_t* fix, uint32_t fix_cap) {
   // First pass (redo_in == nullptr): blocks met for the first time are inserted into the map
   // here (the block part of allocateStorageAndGetVoxelPtr, tsdf_integrator.cc:97-126); they
-  // only get their pool slot after this kernel, so a ray that crossed one is queued in
-  // redo_out and rebuilt by the second pass (redo_in = that queue).  In steady state a frame
-  // adds a handful of blocks, so the second pass touches a few hundred rays.
+  // only get their pool slot after this kernel.  The list entries inside such a block are left
+  // open and recorded as {list position, table position of the block, voxel} in `fix`;
+  // k_fast_fixup fills them in once the slots are assigned.  (Until round 3 the rays that had
+  // crossed a new block were walked a second time: a few hundred rays in steady state, but a
+  // launch lasts as long as its longest walk — 85 us of a 1.4 ms frame.)  That second pass
+  // (redo_in = the queued rays) remains for the frames whose open entries overflow `fix`: the
+  // first frames of a map, where every block is new.
+  if (redo_in && !st->fix_overflow) return;
   // RPW rays per wave, one per lane in the low lanes: the walk is a serial dependency chain per
   // ray, so with all 64 lanes busy the 70k rays of a frame are ~1 wave per SIMD and nothing
   // hides the latencies; fewer rays per wave means more resident waves.  Every ray lane stages
@@ -112,18 +117,20 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
     BlockWalk bw{};
     if (live) bw.start(rc, m.vps, m.vps_inv);
     uint32_t slot = kInvalidSlot;
+    uint32_t pend = 0;  // 1 + table position of the current block while it has no slot yet
     bool redo = false;
-    auto lookup = [&](uint64_t key) -> uint32_t {
+    auto lookup = [&](uint64_t key) -> uint64_t {  // slot | (1 + table position) << 32 for a block without one
       const uint32_t sl = map_find(m, key);
+      uint32_t pos1 = 0;
       if (sl == kInvalidSlot) {
         if (redo_in) {
           atomicOr(&st->error, 2u);
         } else {
-          map_insert_key(m, key, new_list, st);
+          pos1 = map_insert_key_pos(m, key, new_list, st) + 1u;
           redo = true;
         }
       }
-      return sl;
+      return ((uint64_t)pos1 << 32) | sl;
     };
     for (uint32_t k0 = 0; __any(k0 < len); k0 += 16) {
       // (a) 16 DDA steps, no memory traffic: linear voxel index + "enters a new block" mark
@@ -147,18 +154,38 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
       }
       // (b) the lookups, rank by rank: all lanes issue their t-th lookup together
       for (int t = 0; __any(t < nt); ++t)
-        if (t < nt) tkeys[t] = (uint64_t)lookup(tkeys[t]);
+        if (t < nt) tkeys[t] = lookup(tkeys[t]);
       // (c) entries -> global voxel ids
       for (int j = 0; j < 16; ++j) {
         const uint32_t e = (lane < RPW) ? s_buf[wv][lane][j] : 0xFFFFFFFFu;
         uint32_t gid = 0xFFFFFFFFu;
+        bool open_entry = false;
         if (e != 0xFFFFFFFFu) {
           if (e & 0x80000000u) {
-            slot = (uint32_t)tkeys[(e >> 24) & 0x7Fu];
+            const uint64_t tk = tkeys[(e >> 24) & 0x7Fu];
+            slot = (uint32_t)tk;
+            pend = (uint32_t)(tk >> 32);
           }
           if (slot != kInvalidSlot) gid = slot * m.nvox + (e & 0xFFFFFFu);
+          else open_entry = pend != 0;
         }
         if (lane < RPW) s_buf[wv][lane][j] = gid;
+        const unsigned long long om = __ballot(open_entry);
+        if (om) {  // one reservation per wave and step
+          uint32_t at = 0;
+          if (lane == (int)(__ffsll((long long)om) - 1)) at = atomicAdd(&st->fix_count, (uint32_t)__popcll(om));
+          at = __shfl(at, __ffsll((long long)om) - 1);
+          if (open_entry) {
+            const uint32_t i = at + (uint32_t)__popcll(om & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            if (i < fix_cap) {
+              fix[3 * (size_t)i] = base + k0 + j;
+              fix[3 * (size_t)i + 1] = pend - 1u;
+              fix[3 * (size_t)i + 2] = e & 0xFFFFFFu;
+            } else {
+              st->fix_overflow = 1;
+            }
+          }
+        }
       }
       // wave-synchronous flush (same wave wrote and reads; LDS ops of one wave are ordered)
       const int sub = lane >> 4, e = lane & 15;
@@ -173,6 +200,20 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
       }
     }
     if (redo) redo_out[atomicAdd(&st->redo_count, 1u)] = r;
+  }
+}
+
+// The open entries of k_fast_build_lists once k_assign_slots has run: entry = slot of its block * nvox + voxel.
+__global__ void k_fast_fixup(MapDev m, const uint32_t* __restrict__ fix, uint32_t fix_cap, uint32_t* vox, DevState* st) {
+  if (st->fix_overflow) return;  // the queued rays are rebuilt as a whole
+  const uint32_t n = min(st->fix_count, fix_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t slot = __hip_atomic_load(&m.hvals[fix[3 * (size_t)i + 1]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot == kInvalidSlot) {
+      atomicOr(&st->error, 2u);  // (with error bit 0: the pool ran out and the host grows it)
+      continue;
+    }
+    vox[fix[3 * (size_t)i]] = slot * m.nvox + fix[3 * (size_t)i + 2];
   }
 }
 

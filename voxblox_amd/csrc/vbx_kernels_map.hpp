@@ -43,6 +43,8 @@ __global__ void k_reset_call_state(DevState* st) {
 #endif
   st->fast_idle_sweep = 0;
   st->redo_count = 0;
+  st->fix_count = 0;
+  st->fix_overflow = 0;
   st->bbox_min[0] = st->bbox_min[1] = st->bbox_min[2] = 0x7FFFFFFF;
   st->bbox_max[0] = st->bbox_max[1] = st->bbox_max[2] = -0x7FFFFFFF;
   st->bbox_wide = 0;
