@@ -705,15 +705,20 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       *converged = false;
       uint32_t done = 0;  // rounds queued so far in this call
       uint32_t bound = 0;
-      auto one_scan = [&]() -> int { return exclusive_scan_u32(ctx, Tcur, poff, R + 1); };
+      // probe offsets of the rays in play: a block of rays only needs its own (offsets from the block's first probe;
+      // every kernel of a round takes them relative to poff[a])
+      const bool whole = (a == 0 && b == R);
+      auto one_scan = [&]() -> int {
+        return whole ? exclusive_scan_u32(ctx, Tcur, poff, R + 1) : exclusive_scan_u32(ctx, Tcur + a, poff + a, b - a + 1);
+      };
       if (p_hint == 0) {  // no estimate of the range's probe count: ask
         rc = one_scan();
         if (rc) return rc;
-        const uint32_t* const ptrs[3] = {poff + R, poff + a, poff + b};
+        const uint32_t* const ptrs[3] = {poff + b, poff + a, poff + b};
         uint32_t vals[3] = {0, 0, 0};
         rc = sync_state3(ctx, ptrs, vals);
         if (rc) return rc;
-        ctx->h_poff_total = vals[0];
+        if (whole) ctx->h_poff_total = vals[0];
         p_hint = vals[2] - vals[1];
       }
       bound = p_hint + p_hint / 4 + 8192;
@@ -728,11 +733,11 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
           if (rc) return rc;
           uint32_t n_sort = bound;
           if (exact_n) {
-            const uint32_t* const ptrs[3] = {poff + R, poff + a, poff + b};
+            const uint32_t* const ptrs[3] = {poff + b, poff + a, poff + b};
             uint32_t vals[3] = {0, 0, 0};
             rc = sync_state3(ctx, ptrs, vals);
             if (rc) return rc;
-            ctx->h_poff_total = vals[0];
+            if (whole) ctx->h_poff_total = vals[0];
             n_sort = vals[2] - vals[1];
             bound = std::max(bound, n_sort);
           }

@@ -155,37 +155,62 @@ k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__
       // (b) the lookups, rank by rank: all lanes issue their t-th lookup together
       for (int t = 0; __any(t < nt); ++t)
         if (t < nt) tkeys[t] = lookup(tkeys[t]);
+      // open entries of this chunk (blocks without a slot yet): ONE reservation in `fix` per wave and chunk, and none
+      // once the buffer has overflowed — a frame in which every block is new has millions of them, and a reservation
+      // per step was 126 ms of same-address atomics at 0.02 m
+      bool lane_pending = pend != 0;
+      for (int t = 0; t < nt; ++t) lane_pending |= (tkeys[t] >> 32) != 0;
+      uint32_t fix_at = 0xFFFFFFFFu;  // this lane's first item (0xFFFFFFFF: do not record)
+      if (__any(lane_pending) && !redo_in) {
+        uint32_t cnt = 0;
+        if (lane_pending) {
+          uint32_t sl = slot, pd = pend;
+          for (int j = 0; j < 16; ++j) {
+            const uint32_t e = (lane < RPW) ? s_buf[wv][lane][j] : 0xFFFFFFFFu;
+            if (e == 0xFFFFFFFFu) continue;
+            if (e & 0x80000000u) {
+              const uint64_t tk = tkeys[(e >> 24) & 0x7Fu];
+              sl = (uint32_t)tk;
+              pd = (uint32_t)(tk >> 32);
+            }
+            cnt += (sl == kInvalidSlot && pd != 0) ? 1u : 0u;
+          }
+        }
+        uint32_t incl = cnt;  // inclusive scan over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = __shfl_up(incl, d);
+          if (lane >= d) incl += o;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        if (total && !__hip_atomic_load(&st->fix_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          uint32_t at = 0;
+          if (lane == 0) at = atomicAdd(&st->fix_count, total);
+          at = __shfl(at, 0);
+          if (at + total <= fix_cap) fix_at = at + incl - cnt;
+          else if (lane == 0) st->fix_overflow = 1;
+        }
+      }
       // (c) entries -> global voxel ids
       for (int j = 0; j < 16; ++j) {
         const uint32_t e = (lane < RPW) ? s_buf[wv][lane][j] : 0xFFFFFFFFu;
         uint32_t gid = 0xFFFFFFFFu;
-        bool open_entry = false;
         if (e != 0xFFFFFFFFu) {
           if (e & 0x80000000u) {
             const uint64_t tk = tkeys[(e >> 24) & 0x7Fu];
             slot = (uint32_t)tk;
             pend = (uint32_t)(tk >> 32);
           }
-          if (slot != kInvalidSlot) gid = slot * m.nvox + (e & 0xFFFFFFu);
-          else open_entry = pend != 0;
-        }
-        if (lane < RPW) s_buf[wv][lane][j] = gid;
-        const unsigned long long om = __ballot(open_entry);
-        if (om) {  // one reservation per wave and step
-          uint32_t at = 0;
-          if (lane == (int)(__ffsll((long long)om) - 1)) at = atomicAdd(&st->fix_count, (uint32_t)__popcll(om));
-          at = __shfl(at, __ffsll((long long)om) - 1);
-          if (open_entry) {
-            const uint32_t i = at + (uint32_t)__popcll(om & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-            if (i < fix_cap) {
-              fix[3 * (size_t)i] = base + k0 + j;
-              fix[3 * (size_t)i + 1] = pend - 1u;
-              fix[3 * (size_t)i + 2] = e & 0xFFFFFFu;
-            } else {
-              st->fix_overflow = 1;
-            }
+          if (slot != kInvalidSlot) {
+            gid = slot * m.nvox + (e & 0xFFFFFFu);
+          } else if (pend != 0 && fix_at != 0xFFFFFFFFu) {
+            fix[3 * (size_t)fix_at] = base + k0 + j;
+            fix[3 * (size_t)fix_at + 1] = pend - 1u;
+            fix[3 * (size_t)fix_at + 2] = e & 0xFFFFFFu;
+            ++fix_at;
           }
         }
+        if (lane < RPW) s_buf[wv][lane][j] = gid;
       }
       // wave-synchronous flush (same wave wrote and reads; LDS ops of one wave are ordered)
       const int sub = lane >> 4, e = lane & 15;
