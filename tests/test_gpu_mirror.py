@@ -133,6 +133,18 @@ def test_stable_radix_sort_selftest():
             gm.selftest_sort(n, b, e, seed + 10, with_vals=False)
 
 
+def test_stable_radix_sort_beyond_one_lookback_group():
+    """More than 512 tiles (4 M keys): the tiles of the fused pass form groups, a group hands its running totals to the
+    next (csrc/vbx_sort.hpp) — the Simple integrator's 35-43 M updates and whole-frame replay rounds at fine voxels.
+    Sizes around the group boundary, several groups, two and three passes, keys and pairs."""
+    from voxblox_amd import capi
+    gm = capi.Map(0.1, 16, max_blocks=64)
+    for n, b, e in [(512 * 8192, 44, 64), (512 * 8192 + 1, 32, 52), (1024 * 8192 + 77, 32, 58), (9_000_001, 44, 64),
+                    (20_000_003, 32, 58)]:
+        gm.selftest_sort(n, b, e, 2, with_vals=False)
+        gm.selftest_sort(n, b, e, 3, with_vals=(n < 10_000_000))
+
+
 def test_three_launch_radix_passes(monkeypatch):
     """VBX_SORT_FUSED=0 (read when a handle sorts for the first time) selects count / scan / scatter as three
     launches per pass — the form every sort had before the fused pass, kept for fields wider than 30 bits and

@@ -36,7 +36,7 @@ struct vbx_ctx {
   DBuf b_T, b_TH, b_U, b_vox, b_vhash, b_cl, b_act0, b_act1, b_long, b_order, b_obs, b_sphere0, b_sphere1, b_redo, b_fix, b_bkeys, b_bfirst, b_bperm, b_obsset, b_collided, b_hist0, b_hist1, b_moved;
   DBuf b_scan_desc;  // k_scan_excl: ticket counter + tile descriptors
   DBuf b_fs_hist, b_fs_desc;  // fused radix pass (vbx_sort.hpp): histogram ring; ticket + flags + count rows
-  uint32_t fs_ring_pos = 0, fs_ticket_base = 0, fs_gen = 0;
+  uint32_t fs_ring_pos = 0, fs_ticket_base = 0, fs_gen = 0, fs_desc_tiles = 0;
   int fs_enabled = -1;  // VBX_SORT_FUSED, read once
   DBuf b_bbox;       // Merged: per-workgroup bounding boxes of the endpoint voxels
   uint32_t scan_ticket_base = 0, scan_gen = 0;

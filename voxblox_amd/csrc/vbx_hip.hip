@@ -35,7 +35,6 @@
 #include <unordered_map>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
 
 #include "../../include/vbx_hip.h"
 #include "vbx_device_math.hpp"

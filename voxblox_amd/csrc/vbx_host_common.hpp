@@ -205,36 +205,6 @@ int ensure_tab(vbx_ctx* ctx, bool second, size_t R, bool with_bkey) {
   return VBX_OK;
 }
 
-// rocPRIM is used only for the two generic primitives of the pipeline (LSD radix sort,
-// exclusive scan); everything domain-specific is a kernel in this file.
-// Frame-sized inputs (3e5..1e6 keys) sit below rocPRIM's default merge-sort limit, where it runs
-// ~20 launch-bound merge passes over the full 64-bit key; the callers here only need a STABLE
-// sort on a 20..26-bit field (the inputs are already in visiting order), which is 3-4 onesweep
-// passes.  MergeSortLimit = 0 selects the LSD onesweep path for every size.
-using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                           rocprim::default_config, 0>;
-int sort_keys(vbx_ctx* ctx, uint64_t* in, uint64_t* out, size_t n, unsigned begin_bit,
-              unsigned end_bit) {
-  size_t tmp = 0;
-  HIP_TRY(rocprim::radix_sort_keys<SortCfg>(nullptr, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
-  HIP_TRY(ctx->b_tmp.ensure(tmp));
-  prof_begin(ctx, "rocprim::radix_sort_keys");
-  HIP_TRY(rocprim::radix_sort_keys<SortCfg>(ctx->b_tmp.p, tmp, in, out, n, begin_bit, end_bit, ctx->stream));
-  prof_end(ctx);
-  return VBX_OK;
-}
-int sort_pairs(vbx_ctx* ctx, uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, size_t n,
-               unsigned begin_bit, unsigned end_bit) {
-  size_t tmp = 0;
-  HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
-                                             ctx->stream));
-  HIP_TRY(ctx->b_tmp.ensure(tmp));
-  prof_begin(ctx, "rocprim::radix_sort_pairs");
-  HIP_TRY(rocprim::radix_sort_pairs<SortCfg>(ctx->b_tmp.p, tmp, kin, kout, vin, vout, n, begin_bit, end_bit,
-                                             ctx->stream));
-  prof_end(ctx);
-  return VBX_OK;
-}
 // Exclusive prefix sum, one launch (k_scan_excl, vbx_sort.hpp).
 int exclusive_scan_u32(vbx_ctx* ctx, uint32_t* in, uint32_t* out, size_t n) {
   if (n == 0) return VBX_OK;
@@ -294,15 +264,20 @@ int fused_pass(vbx_ctx* ctx, const uint64_t* kin, const uint32_t* vin, uint64_t*
     ctx->fs_ticket_base = 0;
     ctx->fs_gen = 1;
   }
+  // ticket | tile flags | group flags | group totals | tile count rows (laid out for fs_desc_tiles tiles)
+  const size_t T = ctx->fs_desc_tiles, G = T / kFsGroupBig;
+  const uint32_t gsize = ntiles <= (uint32_t)kFsGroup ? (uint32_t)kFsGroup : (uint32_t)kFsGroupBig;
   uint32_t* ticket = ctx->b_fs_desc.as<uint32_t>();
   unsigned long long* flags = ctx->b_fs_desc.as<unsigned long long>() + 1;
-  uint16_t* cnt16 = reinterpret_cast<uint16_t*>(flags + kFsMaxTiles);
+  unsigned long long* gflags = flags + T;
+  uint32_t* gpre = reinterpret_cast<uint32_t*>(gflags + G);
+  uint16_t* cnt16 = reinterpret_cast<uint16_t*>(gpre + G * (1 << kFsMaxBits));
   if (with_vals)
     KLAUNCH((k_rsort_fused<BITS, true>), dim3(ntiles), dim3(kFsThreads), 0, ctx->stream, kin, vin, kout, vout, n, n_dev,
-            shift, hist, cnt16, flags, ticket, ctx->fs_ticket_base, ctx->fs_gen, ctx->d_state);
+            shift, hist, cnt16, flags, ticket, ctx->fs_ticket_base, ctx->fs_gen, ctx->d_state, gflags, gpre, gsize);
   else
     KLAUNCH((k_rsort_fused<BITS, false>), dim3(ntiles), dim3(kFsThreads), 0, ctx->stream, kin, vin, kout, vout, n,
-            n_dev, shift, hist, cnt16, flags, ticket, ctx->fs_ticket_base, ctx->fs_gen, ctx->d_state);
+            n_dev, shift, hist, cnt16, flags, ticket, ctx->fs_ticket_base, ctx->fs_gen, ctx->d_state, gflags, gpre, gsize);
   ctx->fs_ticket_base += ntiles;  // wraps like the device counter
   return VBX_OK;
 }
@@ -324,10 +299,12 @@ int stable_sort_fused(vbx_ctx* ctx, uint32_t n, unsigned begin_bit, unsigned end
     HIP_TRY(hipMemsetAsync(ctx->b_fs_hist.p, 0, ctx->b_fs_hist.cap, ctx->stream));
     ctx->fs_ring_pos = 0;
   }
-  const size_t desc_bytes = 8 + (size_t)kFsMaxTiles * 8 + (size_t)kFsMaxTiles * (1 << kFsMaxBits) * 2;
-  if (ctx->b_fs_desc.cap < desc_bytes) {
+  if (ntiles > ctx->fs_desc_tiles) {  // descriptors laid out for a whole number of groups; zero = "no word of any generation"
+    const size_t T = ((size_t)ntiles + kFsGroup - 1) / kFsGroup * kFsGroup, G = T / kFsGroupBig;
+    const size_t desc_bytes = 8 + T * 8 + G * 8 + G * (1 << kFsMaxBits) * 4 + T * (1 << kFsMaxBits) * 2;
     HIP_TRY(ctx->b_fs_desc.ensure(desc_bytes));
     HIP_TRY(hipMemsetAsync(ctx->b_fs_desc.p, 0, ctx->b_fs_desc.cap, ctx->stream));
+    ctx->fs_desc_tiles = (uint32_t)T;
     ctx->fs_ticket_base = 0;
     ctx->fs_gen = 0;
   }
@@ -338,7 +315,7 @@ int stable_sort_fused(vbx_ctx* ctx, uint32_t n, unsigned begin_bit, unsigned end
   uint32_t* hist = ctx->b_fs_hist.as<uint32_t>() + (size_t)ctx->fs_ring_pos++ * kFsMaxPasses * (1 << kFsMaxBits);
   HIP_TRY(ctx->b_keys1.ensure((size_t)n * 8));
   if (with_vals) HIP_TRY(ctx->b_vals1.ensure((size_t)n * 4));
-  KLAUNCH(k_rsort_hist, dim3(ntiles), dim3(kFsThreads), 0, ctx->stream, ctx->b_keys0.as<uint64_t>(), n, n_dev, ps, hist);
+  KLAUNCH(k_rsort_hist, dim3(std::min<uint32_t>(ntiles, 512u)), dim3(kFsThreads), 0, ctx->stream, ctx->b_keys0.as<uint64_t>(), n, n_dev, ps, hist);
   bool in0 = true;
   for (int p = 0; p < ps.np; ++p) {
     const uint64_t* kin = (in0 ? ctx->b_keys0 : ctx->b_keys1).as<uint64_t>();
@@ -377,16 +354,9 @@ int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit
     if (with_vals) std::swap(ctx->b_vals0, ctx->b_vals1);
     return VBX_OK;
   }
-  if (n64 > (4u << 20) && !n_dev) {
-    // tens of millions of keys (the Simple integrator): bandwidth matters there, not launch
-    // count, and rocPRIM's onesweep with 8-bit digits at full occupancy is the faster sort
-    HIP_TRY(ctx->b_keys1.ensure(n64 * 8));
-    if (with_vals) {
-      HIP_TRY(ctx->b_vals1.ensure(n64 * 4));
-      return sort_pairs(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), ctx->b_vals0.as<uint32_t>(),
-                        ctx->b_vals1.as<uint32_t>(), n64, begin_bit, end_bit);
-    }
-    return sort_keys(ctx, ctx->b_keys0.as<uint64_t>(), ctx->b_keys1.as<uint64_t>(), n64, begin_bit, end_bit);
+  if (n64 > 0xFFFFF000ull) {
+    ctx->fail("stable sort: too many keys");
+    return VBX_ERR_INVALID;
   }
   const uint32_t n = (uint32_t)n64;
   const unsigned bits = end_bit - begin_bit;
@@ -394,7 +364,7 @@ int stable_sort01(vbx_ctx* ctx, size_t n64, unsigned begin_bit, unsigned end_bit
     const char* e = getenv("VBX_SORT_FUSED");  // =0 selects the three-launch passes
     ctx->fs_enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  if (ctx->fs_enabled && n <= (uint32_t)kFsMaxTiles * kFsTile && bits <= (unsigned)kFsMaxBits * kFsMaxPasses &&
+  if (ctx->fs_enabled && bits <= (unsigned)kFsMaxBits * kFsMaxPasses &&
       (bits + ((bits + kFsMaxBits - 1) / kFsMaxBits) - 1) / ((bits + kFsMaxBits - 1) / kFsMaxBits) >= 4)
     return stable_sort_fused(ctx, n, begin_bit, end_bit, with_vals, n_dev);
   const unsigned passes = (bits + kSortMaxBits - 1) / kSortMaxBits;

@@ -725,27 +725,16 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       HIP_TRY(hipMemsetAsync(&ctx->d_state->rp_overflow, 0, 8, s));  // rp_overflow, rp_changed_round
       uint32_t batch = 1;
       for (;;) {
-        const bool exact_n = bound > (4u << 20);  // tens of millions of probes: rocPRIM's sort, which wants n on the host
-        if (exact_n) batch = 1;
         const uint32_t first = done;
         for (uint32_t q = 0; q < batch; ++q, ++done) {
           rc = one_scan();
           if (rc) return rc;
           uint32_t n_sort = bound;
-          if (exact_n) {
-            const uint32_t* const ptrs[3] = {poff + b, poff + a, poff + b};
-            uint32_t vals[3] = {0, 0, 0};
-            rc = sync_state3(ctx, ptrs, vals);
-            if (rc) return rc;
-            if (whole) ctx->h_poff_total = vals[0];
-            n_sort = vals[2] - vals[1];
-            bound = std::max(bound, n_sort);
-          }
           HIP_TRY(ctx->b_keys0.ensure((size_t)std::max<uint32_t>(bound, 1) * 8));
           HIP_TRY(ctx->b_keys1.ensure((size_t)std::max<uint32_t>(bound, 1) * 8));
           KLAUNCH(k_strict_keys, grid_for((size_t)(b - a) * 16), dim3(256), 0, s, poff, a, b, bound, ctx->b_off.as<uint32_t>(),
                              ctx->b_vhash.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), ctx->d_state);
-          rc = stable_sort01(ctx, std::max<uint32_t>(n_sort, 1), 44, 64, false, exact_n ? nullptr : &ctx->d_state->rp_n);
+          rc = stable_sort01(ctx, std::max<uint32_t>(n_sort, 1), 44, 64, false, &ctx->d_state->rp_n);
           if (rc) return rc;
           KLAUNCH(k_strict_outcome, grid_for(std::max<uint32_t>(n_sort, 1)), dim3(256), 0, s, ctx->b_keys1.as<uint64_t>(), ctx->d_state,
                              ctx->b_obsset.as<uint32_t>(), ctx->obsset_offset, ctx->obsset_sentinel_live ? 1 : 0,

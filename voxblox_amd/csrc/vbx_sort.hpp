@@ -126,7 +126,12 @@ k_rsort_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ v
 //                  with the call's generation: the per-XCD L2s are not coherent), waits for the flags of
 //                  all earlier tiles, sums their count rows (8-byte agent-scope loads, eight in flight per
 //                  lane, four row groups across the workgroup) and scatters exactly like k_rsort_scatter.
-// Every spin is bounded: a tile that gives up raises DevState::error bit 64 and the call fails loudly.
+// Beyond 512 tiles (4 M keys: the Simple integrator's 35-43 M updates, whole-frame replay rounds at fine voxels) the
+// tiles form GROUPS of 512: a tile looks back over the rows of its own group only, and the last tile of a group
+// publishes the group's running totals per digit (32 bit) behind a flag of its own, which the tiles of the next group
+// add.  Every wait is for a tile with an earlier ticket, i.e. one that is running or done.
+// Every spin is bounded: a tile that gives up raises DevState::error bit 64 and the call fails loudly (the passes
+// ping-pong between two buffers, so there is no input left to run a slower form on).
 // ---------------------------------------------------------------------------
 constexpr int kFsThreads = 1024;
 constexpr int kFsWaves = kFsThreads / 64;
@@ -135,7 +140,9 @@ constexpr int kFsWaves = kFsThreads / 64;
 #endif
 constexpr int kFsItems = KFS_ITEMS;
 constexpr int kFsTile = kFsThreads * kFsItems;  // 8192 keys per workgroup
-constexpr int kFsMaxTiles = 512;                // <= 4 M keys (beyond that rocPRIM sorts)
+constexpr int kFsGroup = 512;                   // tiles per look-back group (4 M keys) — a sort of up to one group is one group
+constexpr int kFsGroupBig = 64;                 // ... of a sort with more tiles: a tile sums at most 63 count rows (the rows of
+                                                // 511 predecessors were 4 x the key traffic of a 37 M key pass)
 constexpr int kFsMaxBits = 10;                  // one digit per thread
 constexpr int kFsMaxPasses = 3;
 constexpr uint32_t kFsSpinMax = 1u << 20;
@@ -152,18 +159,22 @@ k_rsort_hist(const uint64_t* __restrict__ keys, uint32_t n, const uint32_t* __re
   __shared__ uint32_t s_h[kFsMaxPasses][1 << kFsMaxBits];
   for (int i = threadIdx.x; i < kFsMaxPasses * (1 << kFsMaxBits); i += kFsThreads) (&s_h[0][0])[i] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * kFsTile;
-  uint64_t kv[kFsItems];
+  // (a workgroup takes every gridDim.x-th tile: the host caps the grid, so that a sort of tens of millions of keys
+  // ends in a few hundred flushes of the LDS counters instead of thousands)
+  for (uint32_t tile = blockIdx.x; (unsigned long long)tile * kFsTile < n; tile += gridDim.x) {
+    const uint32_t base = tile * kFsTile;
+    uint64_t kv[kFsItems];
 #pragma unroll
-  for (int e = 0; e < kFsItems; ++e) {  // all loads in flight before the first LDS atomic (see k_rsort_count)
-    const uint32_t i = base + e * kFsThreads + threadIdx.x;
-    kv[e] = keys[(i < n) ? i : 0u];
-  }
+    for (int e = 0; e < kFsItems; ++e) {  // all loads in flight before the first LDS atomic (see k_rsort_count)
+      const uint32_t i = base + e * kFsThreads + threadIdx.x;
+      kv[e] = keys[(i < n) ? i : 0u];
+    }
 #pragma unroll
-  for (int e = 0; e < kFsItems; ++e) {
-    const uint32_t i = base + e * kFsThreads + threadIdx.x;
-    if (i < n)
-      for (int p = 0; p < ps.np; ++p) atomicAdd(&s_h[p][(uint32_t)(kv[e] >> ps.shift[p]) & ps.mask[p]], 1u);
+    for (int e = 0; e < kFsItems; ++e) {
+      const uint32_t i = base + e * kFsThreads + threadIdx.x;
+      if (i < n)
+        for (int p = 0; p < ps.np; ++p) atomicAdd(&s_h[p][(uint32_t)(kv[e] >> ps.shift[p]) & ps.mask[p]], 1u);
+    }
   }
   __syncthreads();
   for (int p = 0; p < ps.np; ++p)
@@ -176,7 +187,7 @@ __global__ void __launch_bounds__(kFsThreads)
 k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
               uint32_t* __restrict__ vout, uint32_t n, const uint32_t* __restrict__ n_dev, int shift,
               const uint32_t* __restrict__ hist, uint16_t* cnt16, unsigned long long* flags, uint32_t* ticket,
-              uint32_t ticket_base, uint32_t gen, DevState* st) {
+              uint32_t ticket_base, uint32_t gen, DevState* st, unsigned long long* gflags, uint32_t* gpre, uint32_t gsize) {
   constexpr int NB = 1 << BITS;
   constexpr int WORDS = NB / 4;             // 8-byte words per count row
   constexpr int GROUPS = kFsThreads / WORDS;  // row groups of the look-back
@@ -203,12 +214,15 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
   __syncthreads();
   const uint32_t tile = s_tile;
   if ((unsigned long long)tile * kFsTile >= n) return;  // uniform: an empty tile has no successors that need it
+  const uint32_t group = tile / gsize, local = tile % gsize, gfirst = group * gsize;
+  uint32_t hstart = 0;  // start of this thread's digit in the output
   {
     uint32_t wb = 0;
 #pragma unroll
     for (int ww = 0; ww < kFsWaves; ++ww)
       if (ww < w) wb += s_wsum[ww];
-    if (threadIdx.x < NB) s_base[threadIdx.x] = wb + hincl - hv;
+    hstart = wb + hincl - hv;
+    if (threadIdx.x < NB) s_base[threadIdx.x] = hstart;
   }
   // a wave owns 64 * kFsItems consecutive keys; its chunk c is keys [wbase + 64 c, wbase + 64 c + 64)
   const uint32_t wbase = tile * kFsTile + w * (64 * kFsItems);
@@ -247,16 +261,21 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
   __syncthreads();
   const unsigned long long want = ((unsigned long long)gen << 32) | 1ull;
   if (threadIdx.x == 0) __hip_atomic_store(&flags[tile], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // earlier tiles: thread t waits for tile t
+  // earlier tiles of the group: thread t waits for the group's tile t; the last thread for the group before
   bool gave_up = false;
-  if (threadIdx.x < tile) {
-    uint32_t spins = 0;
-    while (__hip_atomic_load(&flags[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-      if (++spins > kFsSpinMax) {
-        gave_up = true;
-        break;
+  {
+    const unsigned long long* f = nullptr;
+    if (threadIdx.x < local) f = &flags[gfirst + threadIdx.x];
+    else if (group > 0 && threadIdx.x == kFsThreads - 1) f = &gflags[group - 1];
+    if (f) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        if (++spins > kFsSpinMax) {
+          gave_up = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
       }
-      __builtin_amdgcn_s_sleep(2);
     }
   }
   if (__syncthreads_or(gave_up ? 1 : 0)) {
@@ -268,7 +287,7 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
     const int q = threadIdx.x % WORDS, g = threadIdx.x / WORDS;
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const unsigned long long* col = reinterpret_cast<const unsigned long long*>(cnt16) + q;
-    for (uint32_t r0 = g; r0 < tile; r0 += 8 * GROUPS) {
+    for (uint32_t r0 = gfirst + g; r0 < tile; r0 += 8 * GROUPS) {
       unsigned long long x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {  // unconditional loads (row r0 stands in beyond the tile), masked below
@@ -291,9 +310,19 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
   }
   __syncthreads();
   if (threadIdx.x < NB) {
-    const uint32_t b = s_base[threadIdx.x];
+    uint32_t b = s_base[threadIdx.x];
+    if (group > 0)  // keys of the groups before
+      b += __hip_atomic_load(&gpre[(size_t)(group - 1) * (1 << kFsMaxBits) + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (local == gsize - 1)  // the group's last tile: totals up to and including this tile, for the next group
+      __hip_atomic_store(&gpre[(size_t)group * (1 << kFsMaxBits) + threadIdx.x], b - hstart + (uint32_t)s_c16[threadIdx.x],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int ww = 0; ww < kFsWaves; ++ww) s_run[ww][threadIdx.x] += b;
+  }
+  if (local == gsize - 1) {  // uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&gflags[group], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
