@@ -30,6 +30,10 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --esdf --no-extras > $OUT/bench_esdf.json 2> $OUT/bench_esdf.err
 python bench.py --integrator merged --scene cow --no-extras > $OUT/bench_merged_cow.json 2> $OUT/bench_merged_cow.err
 python bench.py --integrator simple --no-extras --steps 10 --warmup 2 > $OUT/bench_simple.json 2> $OUT/bench_simple.err
-python bench.py --workload sensors4 --gpus 1 --steps 6 --warmup 1 > $OUT/bench_sensors4_1gpu.json 2> $OUT/bench_sensors4_1gpu.err
+python bench.py --workload sensors4 --gpus 1 --steps 6 --warmup 2 > $OUT/bench_sensors4_1gpu.json 2> $OUT/bench_sensors4_1gpu.err
 python bench.py --mesh --no-extras > $OUT/bench_mesh.json 2> $OUT/bench_mesh.err
+# kernel timelines (one frame / one ESDF update, with the idle gap before every kernel)
+bash tools/frame_timeline.sh 0.05 24 20 > $OUT/timeline_0p05.txt 2>&1
+bash tools/frame_timeline.sh 0.02 6 4 > $OUT/timeline_0p02.txt 2>&1
+bash tools/esdf_timeline.sh 24 20 > $OUT/timeline_esdf.txt 2>&1
 ls -la $OUT

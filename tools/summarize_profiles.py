@@ -86,3 +86,7 @@ for f in ("bench", "bench_esdf", "bench_merged_cow", "bench_simple", "bench_sens
     p = f'{src}/{f}.json'
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, f'profiles/{tag}_{f}.json')
+for f in ("timeline_0p05", "timeline_0p02", "timeline_esdf"):
+    p = f'{src}/{f}.txt'
+    if os.path.exists(p) and os.path.getsize(p) > 10:
+        shutil.copy(p, f'profiles/{tag}_{f}.txt')

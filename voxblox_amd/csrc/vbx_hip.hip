@@ -1083,3 +1083,15 @@ extern "C" int vbx_debug_esdf_stats(unsigned long long out[16], int reset) {
   return 0;
 }
 #endif
+
+#ifdef VBX_SORT_STATS
+// measurement build only (tools/sort_stats.py)
+extern "C" int vbx_debug_sort_stats(unsigned long long out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sort_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -429,6 +429,16 @@ __global__ void k_fast_seed_claims(const uint32_t* __restrict__ off, const uint3
   TH[r] = len;
 }
 
+// The solver stopped before every ray was final (reference observed set: the replay finishes the job): an open ray enters
+// the replay with its upper bound.
+__global__ void k_fast_open_guess(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_dev, uint32_t n_bound,
+                                  uint32_t* T, const uint32_t* __restrict__ TH) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= min(n_bound, *n_dev)) return;
+  const uint32_t r = list[i];
+  T[r] = TH[r];
+}
+
 template <int G>
 __global__ void __launch_bounds__(256) k_fast_sweep(SweepArgs a, uint32_t R, DevState* st) {
   const int lane = threadIdx.x & 63;

@@ -182,6 +182,12 @@ k_rsort_hist(const uint64_t* __restrict__ keys, uint32_t n, const uint32_t* __re
       if (s_h[p][d]) atomicAdd(&hist[p * (1 << kFsMaxBits) + d], s_h[p][d]);
 }
 
+#ifdef VBX_SORT_STATS  // measurement build (tools/sort_stats.py): where a tile of the fused pass spends its time
+__device__ unsigned long long g_sort_stats[16];
+#define SORT_T(i) if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_sort_stats[i], t_ - t_prev); atomicMax(&g_sort_stats[8 + i], t_ - t_prev); t_prev = t_; }
+#else
+#define SORT_T(i)
+#endif
 template <int BITS, bool kHasVals>
 __global__ void __launch_bounds__(kFsThreads)
 k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
@@ -200,6 +206,10 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
   __shared__ uint32_t s_tile;
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
+#ifdef VBX_SORT_STATS
+  unsigned long long t_prev = wall_clock64();
+  if (threadIdx.x == 0) atomicAdd(&g_sort_stats[7], 1ull);
+#endif
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
   for (int i = threadIdx.x; i < kFsWaves * NB; i += kFsThreads) (&s_run[0][0])[i] = 0;
   // exclusive scan of the digit histogram -> start of every digit in the output
@@ -241,6 +251,7 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
     if (i < n) atomicAdd(&s_run[w][dig[c]], 1u);
   }
   __syncthreads();
+  SORT_T(0)  // ticket, LDS clear, histogram scan, key loads, per-wave counting
   if (threadIdx.x < NB) {  // exclusive prefix over the waves; the tile's count of the digit
     uint32_t acc = 0;
 #pragma unroll
@@ -261,6 +272,7 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
   __syncthreads();
   const unsigned long long want = ((unsigned long long)gen << 32) | 1ull;
   if (threadIdx.x == 0) __hip_atomic_store(&flags[tile], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  SORT_T(1)  // wave prefix, row publish + drain, flag
   // earlier tiles of the group: thread t waits for the group's tile t; the last thread for the group before
   bool gave_up = false;
   {
@@ -282,6 +294,7 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
     if (threadIdx.x == 0) atomicOr(&st->error, 64u);
     return;
   }
+  SORT_T(2)  // waiting for the flags
   // sum of the earlier tiles' rows: word column q, row group g; eight loads in flight per lane
   {
     const int q = threadIdx.x % WORDS, g = threadIdx.x / WORDS;
@@ -325,6 +338,7 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
     if (threadIdx.x == 0) __hip_atomic_store(&gflags[group], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  SORT_T(3)  // row sums, bases
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int c = 0; c < kFsItems; ++c) {
@@ -345,6 +359,11 @@ k_rsort_fused(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin
       if (rank == 0) s_run[w][dig[c]] = start + (uint32_t)__popcll(mask);
     }
   }
+#ifdef VBX_SORT_STATS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#endif
+  SORT_T(4)  // ranking and scatter (stores drained in the measurement build)
 }
 
 // ---------------------------------------------------------------------------
