@@ -695,7 +695,7 @@ def main():
         from voxblox_amd import multi_gpu
         pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
         dl = [capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank) for _ in range(2)]
-        sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev) for d in dl],
+        sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev, keep_slots=True) for d in dl],
                                                     rank, world, dist, device=dev)
         for i in range(warmup):
             pose, dp, dc, n = d_frames[i % len(d_frames)]

@@ -1,4 +1,4 @@
-// vbx_host_common.hpp — host helpers: state read-back, ray tables, rocPRIM sort/scan wrappers, stage timing
+// vbx_host_common.hpp — host helpers: state read-back, ray tables, sort / scan drivers (vbx_sort.hpp), stage timing
 // Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
 
 namespace {

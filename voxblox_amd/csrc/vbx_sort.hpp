@@ -7,7 +7,7 @@
 // ~105 us for a 20-bit field, all of it launch/latency.  Here a pass takes a digit of up to 12
 // bits (20..24-bit fields in TWO passes) and consists of exactly three launches:
 //   k_rsort_count    per-workgroup digit histogram (LDS atomics)      -> hist[digit][workgroup]
-//   exclusive scan   over hist in digit-major order (rocPRIM scan)     -> global base per (digit, workgroup)
+//   exclusive scan   over hist in digit-major order (k_scan_excl)      -> global base per (digit, workgroup)
 //   k_rsort_scatter  stable placement: a workgroup's 2048 keys are split over its 4 waves in
 //                    memory order; per wave a running counter per digit lives in LDS, and inside
 //                    a 64-key chunk the rank among equal digits comes from ballots (wave64

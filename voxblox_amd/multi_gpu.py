@@ -33,6 +33,7 @@ import numpy as np
 
 import os as _os
 _FULL_CLEAR = bool(_os.environ.get("VBX_DELTA_FULL_CLEAR"))   # A/B switch: delta maps released completely every step
+_FORCE_KEEP = _os.environ.get("VBX_DELTA_KEEP") == "1"   # measurement switch: every delta map keeps its slots
 
 
 def owner_of(keys, world):
@@ -332,7 +333,7 @@ class GpuBackend:
 
     def clear(self):
         # a delta map sees the same region step after step: its blocks leave the layer but keep their pool slots
-        if self.keep_slots and not _FULL_CLEAR:
+        if (self.keep_slots or _FORCE_KEEP) and not _FULL_CLEAR:
             self.m.clear_keep_slots()
         else:
             self.m.clear()
