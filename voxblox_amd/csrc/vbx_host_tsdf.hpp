@@ -801,7 +801,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
     // Blocks pay off only when whole-frame rounds are expensive (millions of probes, i.e. fine
     // voxels): 16-32 blocks cost at least two cheap rounds each.
     static const bool no_blocks = getenv("VBX_REPLAY_NO_BLOCKS") != nullptr;  // measurement switch
-    const bool use_blocks = ctx->h_poff_total > 1500000u && !no_blocks;
+    static const uint32_t blocks_min = getenv("VBX_REPLAY_BLOCKS_MIN") ? (uint32_t)atoi(getenv("VBX_REPLAY_BLOCKS_MIN")) : 1500000u;  // measurement switch
+    const bool use_blocks = ctx->h_poff_total > blocks_min && !no_blocks;
     if (!converged && !use_blocks) {
       rc = replay(0, R, 100000, ctx->rp_last_p, &converged);
       if (rc) return rc;

@@ -72,7 +72,10 @@ __global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
 // ray visits walking from the surface towards the sensor (cast_from_origin = false,
 // tsdf_integrator.cc:521-525).  Built once per frame; the solver and the emit step then work
 // on these lists instead of re-running the DDA and the block hash lookups.
-constexpr int kListRPW = 64;  // rays per wave in k_fast_build_lists
+#ifndef VBX_LIST_RPW
+#define VBX_LIST_RPW 64
+#endif
+constexpr int kListRPW = VBX_LIST_RPW;  // rays per wave in k_fast_build_lists (32 and 16 measured: see DESIGN 4.3b)
 template <int RPW>
 __global__ void __launch_bounds__(256)
 k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
