@@ -78,9 +78,12 @@ constexpr uint32_t kFlagEsdfPendClassify = 0x2000;  // EsdfIntegrator::updated_b
 constexpr uint32_t kFlagEsdfPendOpen = 0x4000;      // holds voxels pushed to open_ by addNewRobotPosition (:84)
 constexpr uint32_t kFlagFree = 0x8000;              // slot sits on the free list (belongs to no block)
 constexpr uint32_t kFlagEsdfDirty = 0x10000;        // the ESDF block's voxels changed since the host mirror last took them
+constexpr uint32_t kFlagEsdfUnsettled = 0x20000;    // the ESDF block's voxels were written from outside (vbx_blocks_upload): its next
+                                                    // lower-phase run relaxes every voxel, not only the shell (k_esdf_tile)
                                                     // (VBX_UPDATE_DIRTY; the wavefront writes blocks the reference never flags)
 // everything that says "this slot holds a block of the ESDF layer" (shared by every removal path)
-constexpr uint32_t kEsdfBits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen | kFlagEsdfDirty;
+constexpr uint32_t kEsdfBits = kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfPendClassify | kFlagEsdfPendOpen | kFlagEsdfDirty |
+                               kFlagEsdfUnsettled;
 
 // Device-resident scalar state, read back at the per-call sync points.
 struct DevState {

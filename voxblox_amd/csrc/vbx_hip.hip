@@ -562,7 +562,7 @@ int vbx_blocks_upload(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, con
     hipLaunchKernelGGL(k_unpack_esdf_aos, dim3((unsigned)n), dim3(256), 0, s, m.nvox, ctx->b_edist.as<float>(),
                        ctx->b_estate.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), ctx->b_keys0.as<uint32_t>());
     hipLaunchKernelGGL(k_replace_block_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n,
-                       ~kEsdfBits, kFlagEsdfAlloc, ctx->b_graze.as<uint8_t>(), (int)kFlagEsdfUpdShift,
+                       ~kEsdfBits, kFlagEsdfAlloc | kFlagEsdfUnsettled, ctx->b_graze.as<uint8_t>(), (int)kFlagEsdfUpdShift,
                        (const uint8_t*)nullptr);
   }
   rc = sync_state(ctx);  // the caller's host buffers are free again

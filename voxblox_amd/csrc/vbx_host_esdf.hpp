@@ -17,10 +17,11 @@ __global__ void k_esdf_reset_flags(MapDev m, EsdfDev e, uint32_t n_slots, int dr
   // open_/raise_), 16 = also re-run the TSDF classification on them
   const uint32_t f = m.blk_flags[s];
   const uint32_t pend = f & (kFlagEsdfPendClassify | kFlagEsdfPendOpen);
-  e.active[s] = (pend && !drop_layer) ? (8u | ((pend & kFlagEsdfPendClassify) ? 16u : 0u)) : 0u;
+  e.active[s] = ((pend && !drop_layer) ? (8u | ((pend & kFlagEsdfPendClassify) ? 16u : 0u)) : 0u) |
+                (((f & kFlagEsdfUnsettled) && !drop_layer) ? 64u : 0u);  // uploaded voxels: a full first pass when the block runs
   // updateFromTsdfBlocks does not consume updated_blocks_: the classification stays pending
   uint32_t nf = f & ~((keep_classify_pending ? 0u : kFlagEsdfPendClassify) | kFlagEsdfPendOpen);
-  if (drop_layer) nf &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift));
+  if (drop_layer) nf &= ~(kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfUnsettled);
   if (nf != f) m.blk_flags[s] = nf;
 }
 // End of a speculatively queued update (esdf_update_t): drops the raise marks of the touched blocks and, on request, the

@@ -608,7 +608,10 @@ __global__ void __launch_bounds__(kEsdfThreads) k_esdf_tile(MapDev m, EsdfDev e,
       t_relax += wall_clock64() - t_it1;
 #endif
     }
-    if (!FULL && converged && !(act0 & 128u) && tid == 0) atomicOr(&e.active[slot], 128u);
+    if (!FULL && converged && !(act0 & 128u) && tid == 0) {
+      atomicOr(&e.active[slot], 128u);
+      if (!shell_only && (m.blk_flags[slot] & kFlagEsdfUnsettled)) atomicAnd(&m.blk_flags[slot], ~kFlagEsdfUnsettled);
+    }
   } else {
   constexpr int PER = (NV + kEsdfThreads - 1) / kEsdfThreads;
   int tt[PER];
