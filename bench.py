@@ -71,9 +71,11 @@ def parse():
                     help="default run only: skip the short secondary legs (configs[2], configs[3], configs[4] on 1 GPU)")
     ap.add_argument("--mirror-frames", type=int, default=8, help="stream: frames that also mirror touched blocks to the host")
     ap.add_argument("--profile-frames", type=int, default=12, help="frames of the per-kernel profile pass (0 = skip)")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
-                    help="sensors4: torch = voxblox_amd.multi_gpu over torch.distributed (RCCL), exchange pipelined behind the "
-                         "next step; native = libvbx_shard.so (C++ host path, RCCL called directly, sequential)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "native"],
+                    help="sensors4: torch = voxblox_amd.multi_gpu over torch.distributed (RCCL); native = libvbx_shard.so (the C++ host "
+                         "path: its own threads per ray bundle, RCCL called directly); both run the exchange behind the next step.  "
+                         "auto = native on one GPU (sixteen concurrent bundles: no interpreter lock between the launching threads), "
+                         "torch on several (the path the multi-rank CPU tests cover)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-reference sample")
     ap.add_argument("--esdf-fidelity-frames", type=int, default=24,
                     help="--esdf: frames of the lockstep GPU-vs-reference ESDF comparison (0 = skip)")
@@ -493,7 +495,8 @@ def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
     for k in range(min(warmup + steps, 25)):
         sensors4_shards(k, rank, world, dev, cache)     # synthetic frames generated and uploaded before the clock
     torch.cuda.synchronize()
-    if args.exchange == "native":
+    use_native = args.exchange == "native" or (args.exchange == "auto" and world == 1)
+    if use_native:
         # the C++ host path: libvbx_shard.so calls RCCL itself; torch.distributed only carries the communicator id
         from voxblox_amd import shard_native
         ids = [shard_native.unique_id() if rank == 0 else None]
@@ -526,31 +529,30 @@ def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
                         "each; exchange on a worker thread behind the next step's integration)",
                 "payload_bytes_per_step": int(st["payload_bytes"] / f), "sent_blocks_per_step": round(st["sent_blocks"] / f, 1)}
         ns.close()
-        sharded.close()
-        return dt, exch, [], {}, (pm, deltas)
+    else:
+        def barrier():
+            sharded.flush()
+            barrier_fn()
 
-    def barrier():
+        for k in range(warmup):
+            sharded.integrate_shards(kind, cfg, sensors4_shards(k, rank, world, dev, cache))
         sharded.flush()
-        barrier_fn()
-
-    for k in range(warmup):
-        sharded.integrate_shards(kind, cfg, sensors4_shards(k, rank, world, dev, cache))
-    sharded.flush()
-    for key in sharded.stats:
-        sharded.stats[key] = 0
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(warmup, warmup + steps):
-        sharded.integrate_shards(kind, cfg, sensors4_shards(k, rank, world, dev, cache))
-    barrier()
-    dt = time.perf_counter() - t0
-    f = max(sharded.stats["frames"], 1)
-    exch = {"payload_bytes_per_step": int(sharded.stats["payload_bytes"] / f), "sent_blocks_per_step": round(sharded.stats["sent_blocks"] / f, 1),
-            "integrate_ms_per_step": round(sharded.stats["integrate_s"] / f * 1e3, 3),
-            "exchange_ms_per_step": round(sharded.stats["exchange_s"] / f * 1e3, 3),
-            "wait_ms_per_step": round(sharded.stats["wait_s"] / f * 1e3, 3),
-            "note": "this rank's figures; exchange = export of the touched blocks' sums + all-to-all to the owners + owner "
-                    "merge, pipelined behind the next step's integration (its time is hidden unless wait_ms > 0)"}
+        for key in sharded.stats:
+            sharded.stats[key] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            sharded.integrate_shards(kind, cfg, sensors4_shards(k, rank, world, dev, cache))
+        barrier()
+        dt = time.perf_counter() - t0
+        f = max(sharded.stats["frames"], 1)
+        exch = {"path": "voxblox_amd.multi_gpu (Python host path over torch.distributed)",
+                "payload_bytes_per_step": int(sharded.stats["payload_bytes"] / f), "sent_blocks_per_step": round(sharded.stats["sent_blocks"] / f, 1),
+                "integrate_ms_per_step": round(sharded.stats["integrate_s"] / f * 1e3, 3),
+                "exchange_ms_per_step": round(sharded.stats["exchange_s"] / f * 1e3, 3),
+                "wait_ms_per_step": round(sharded.stats["wait_s"] / f * 1e3, 3),
+                "note": "this rank's figures; exchange = export of the touched blocks' sums + all-to-all to the owners + owner "
+                        "merge, pipelined behind the next step's integration (its time is hidden unless wait_ms > 0)"}
     # per-kernel profile of the integration (delta map 0), outside the clock
     rows, calls = [], 0
     alg = {}
@@ -654,9 +656,11 @@ def main():
                                             "map of its own (bit-exact Fast integrator per shard, the shards of a rank concurrently), "
                                             "deltas merged in shard order with mergeVoxelAIntoVoxelB semantics — the merged map "
                                             "depends on the shard layout, not on the number of ranks",
-                               "parallelism": ("1 GPU holds all four sensors (same shard + merge, no collective)" if world == 1 else
-                                               f"{world} ranks, {max(1, world // 4)} ray band(s) per sensor, sparse RCCL all-to-all of touched "
-                                               "blocks to their owners pipelined behind the next step's integration, map distributed by block owner")},
+                               "ray_bundles_per_step": 16,
+                               "parallelism": ("4 ray bands per sensor = 16 bundles per step (the same layout for every number of GPUs); " +
+                                               ("1 GPU integrates all of them concurrently (same shard + merge, no collective)" if world == 1 else
+                                                f"{world} ranks, {16 // world if world <= 16 else 1} bundle(s) each, sparse RCCL all-to-all of touched "
+                                                "blocks to their owners pipelined behind the next step's integration, map distributed by block owner"))},
                     "exchange": exch})
         if world > 1:
             # the driver's N = 1 run of `bench.py` is configs[1] (the metric's own configuration), a different workload:

@@ -60,12 +60,23 @@ def group_by_owner(keys, world):
     return np.ascontiguousarray(k[order]), counts
 
 
-def deal_sensor_units(world, n_sensors=4):
-    """BASELINE configs[4]'s ray-bundle shards: n_sensors x B contiguous bands, B = max(1, world / n_sensors),
-    dealt out in order (sensor-major).  Returns units[rank] = [(sensor, band, bands)]: world 1 holds everything,
-    world 4 one sensor each, world 8 half a sensor each."""
+BANDS_PER_SENSOR = 4   # ray bundles per 640x480 frame (76,800 rays each)
+
+
+def deal_sensor_units(world, n_sensors=4, bands=None):
+    """BASELINE configs[4]'s ray-bundle shards: n_sensors x B contiguous bands of a frame, dealt out in order
+    (sensor-major).  Returns units[rank] = [(sensor, band, bands)].
+
+    B is a property of the sharded integrator, not of the number of GPUs: BANDS_PER_SENSOR = 4 for every world up to
+    16 ranks (more bands only when there are more ranks than shards), so the merged map — which depends on the shard
+    layout and on nothing else — is the same map on 1, 2, 4, 8 and 16 GPUs.  A quarter frame per bundle is the measured
+    optimum on one MI355X (68.9 / 53.3 / 42.7-46.2 / 57.5 ms per four-sensor step with 1 / 2 / 4 / 8 bands through the
+    Python host path, 38.0 with 4 through libvbx_shard.so): the observed-set replay of a bundle is a chain of dependent
+    rounds whose length grows with the rays that interact (22 rounds for a quarter frame, 315 for a whole one), and the
+    bundles of a step run concurrently.  `bands` overrides it (the parity tests also run whole sensors and halves)."""
     world = max(int(world), 1)
-    bands = max(1, world // n_sensors)
+    if bands is None:
+        bands = max(int(_os.environ.get("VBX_SHARD_BANDS", BANDS_PER_SENSOR)), (world + n_sensors - 1) // n_sensors)
     units = [(s, b, bands) for s in range(n_sensors) for b in range(bands)]
     per = (len(units) + world - 1) // world
     return [units[r * per:(r + 1) * per] for r in range(world)]
