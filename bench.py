@@ -666,8 +666,9 @@ def main():
             # the driver's N = 1 run of `bench.py` is configs[1] (the metric's own configuration), a different workload:
             # the one-GPU point of THIS curve is the same shard + merge on one GPU
             out["n1_same_workload"] = {"command": "python bench.py --gpus 1 --workload sensors4",
-                                       "measured": "profiles/r03_bench_sensors4_1gpu.json: 16.9 Mpoints/s, 72.5 ms per step "
-                                                   "(MI355X, round 3; the four sensors' delta maps integrated concurrently)",
+                                       "measured": "profiles/r03_bench_sensors4_1gpu.json: 32.5 Mpoints/s, 37.8 ms per step "
+                                                   "(MI355X, round 3; the same sixteen ray bundles, all on one GPU, libvbx_shard.so host path; "
+                                                   "43-55 ms through the Python host path the N > 1 runs use)",
                                        "note": "strong-scaling efficiency at N = value / (N x that value); do not divide by the "
                                                "configs[1] line"}
         if rank == 0 and rows:
@@ -754,7 +755,7 @@ def main():
                 out["other_configs"] = {"configs[4]: 4 sensors, %g m, ray shards dealt over the ranks (strong scaling)" % v4: {
                     "value": round(4 * 307200 * s4 / dt4 / 1e6, 3), "unit": "Mpoints/s", "ms_per_step": round(dt4 / s4 * 1e3, 4), "steps": s4,
                     "points_per_step": 4 * 307200, "exchange": exch4,
-                    "one_gpu_same_workload": "profiles/r03_bench_sensors4_1gpu.json: 14.7-18.1 Mpoints/s, 68-84 ms per step (four host threads launching ~14,000 kernels per step: the spread is the host's)"}}
+                    "one_gpu_same_workload": "profiles/r03_bench_sensors4_1gpu.json: 32.5 Mpoints/s, 37.8 ms per step (sixteen bundles on one GPU through libvbx_shard.so; 43-55 ms through the Python host path this leg uses)"}}
             except Exception as e:  # a secondary leg must never take the headline line down
                 out["other_configs"] = {"configs[4]": {"error": repr(e)}}
         finish(out)
