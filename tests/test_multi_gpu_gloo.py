@@ -269,3 +269,25 @@ def test_two_ranks_two_concurrent_shards_each_matches_serial_merge(oracle):
     ref = serial_shard_merge(oracle, voxel, "merged", cfg, steps, deltas_per_rank=2)
     assert len(ref) > 20
     assert_merged_equal(merged, ref)
+
+
+def test_ray_bundle_layout_is_the_same_for_every_world_size():
+    """multi_gpu.deal_sensor_units: configs[4] is cut into 4 sensors x BANDS_PER_SENSOR bundles whatever the number of
+    ranks (so the merged map — a function of the bundle layout — is the same on 1, 2, 4, 8 and 16 GPUs); the ranks take
+    consecutive bundles, every bundle exactly once; more ranks than bundles cut finer."""
+    from voxblox_amd import multi_gpu
+    ref = [u for units in multi_gpu.deal_sensor_units(1) for u in units]
+    assert len(ref) == 4 * multi_gpu.BANDS_PER_SENSOR and ref == [(s, b, multi_gpu.BANDS_PER_SENSOR) for s in range(4)
+                                                                   for b in range(multi_gpu.BANDS_PER_SENSOR)]
+    for world in (2, 4, 8, 16):
+        dealt = multi_gpu.deal_sensor_units(world)
+        assert len(dealt) == world and [u for units in dealt for u in units] == ref
+        assert {len(units) for units in dealt} == {len(ref) // world}
+    finer = multi_gpu.deal_sensor_units(32)
+    assert len(finer) == 32 and all(len(u) == 1 and u[0][2] == 8 for u in finer)
+    # the bands of a cloud tile it exactly
+    n = 307200
+    edges = [multi_gpu.band_of(n, b, 4) for b in range(4)]
+    assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(3))
+    # explicit layouts for the parity tests
+    assert [u for units in multi_gpu.deal_sensor_units(1, bands=1) for u in units] == [(s, 0, 1) for s in range(4)]
