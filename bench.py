@@ -13,8 +13,9 @@ Workloads
             merged there into ONE map distributed by block owner: weak scaling of the metric's own workload
             (`value` = N x 307,200 points per step / time); BASELINE configs[4] runs as a short secondary leg of the same launch.
   sensors4  BASELINE configs[4] (`--workload sensors4`): four concurrent 640x480 sensors, 0.02 m voxels,
-            ray-bundle shards over the ranks (whole sensors at N <= 4, two contiguous bands per sensor at
-            N = 8), every rank integrating its shards into a per-step delta map, a sparse RCCL all-to-all
+            sixteen ray bundles per step (four contiguous bands per frame — the same layout for every N, so the merged
+            map does not depend on the number of GPUs) dealt over the ranks, every rank integrating its bundles
+            concurrently into per-step delta maps of their own, a sparse RCCL all-to-all
             of the touched blocks' weighted sums to the block owners, owner merge into the persistent map
             (voxblox_amd/multi_gpu.py).  One step = all four sensors' frames; the total work
             per step is the same for every N (strong scaling), and `--gpus 1 --workload sensors4` runs
