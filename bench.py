@@ -379,7 +379,8 @@ def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
     t = dom["us_per_step"] * 1e-6
     achieved = alg_bytes_per_step / t / 1e9 if t > 0 else 0.0
     total_us = sum(r["us_per_step"] for r in rows)
-    tr = pmc_traffic(dom["kernel"]) if "distinct voxels updated per frame" in what else None
+    tr = (pmc_traffic(dom["kernel"]) if "distinct voxels updated per frame" in what else
+          pmc_traffic(dom["kernel"], ("r03_pmc_esdf_traffic.json",)) if "updated blocks" in what else None)
     return {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": (tr["bytes_per_launch"] if tr else None),
             "traffic_detail": tr,
