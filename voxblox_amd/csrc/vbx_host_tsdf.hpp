@@ -736,7 +736,8 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
       }
       bound = p_hint + p_hint / 4 + 8192;
       HIP_TRY(hipMemsetAsync(&ctx->d_state->rp_overflow, 0, 8, s));  // rp_overflow, rp_changed_round
-      uint32_t batch = 1;
+      static const uint32_t first_batch = getenv("VBX_REPLAY_FIRST_BATCH") ? (uint32_t)std::max(1, atoi(getenv("VBX_REPLAY_FIRST_BATCH"))) : 1u;  // measurement switch
+      uint32_t batch = (a == 0 && b == R) ? first_batch : 1u;
       for (;;) {
         const uint32_t first = done;
         for (uint32_t q = 0; q < batch; ++q, ++done) {
