@@ -1,0 +1,875 @@
+// vbx_esdf_replay_core.hpp — processOpenSet in the REFERENCE'S OWN ORDER, in parallel (cfg.reference_order = 1)
+//
+// The reference pops one voxel at a time from a BucketQueue (lowest non-empty bucket, FIFO inside) and relaxes its
+// 26 neighbours (esdf_integrator.cc:371-496, bucket_queue.h:41-80); with min_diff_m > 0, in_queue de-duplication
+// and the sign-mismatch branch the result is DEFINED by that order.  This file replays it exactly, many pops at a
+// time:
+//
+//   super-step   the FIFO prefix (<= kmax entries) of the lowest non-empty bucket b = BASE records; a record is
+//                one pop.  A pop whose push lands BELOW b spawns an EXCURSION record: the reference pops that
+//                entry (and what it pushes below b, transitively) before it returns to b.  Records carry a pop
+//                time T = (base index << 24 | rank inside the base record's excursion); ranks come from running
+//                the queue discipline over the excursion's records only (rp_sim_subtree).
+//   fold         every voxel next to a record ("target") owns the list of events that concern it — an offer from
+//                each record on a neighbour (the reference's `for idx` body for that neighbour), a pop for each
+//                record on itself — sorts it by T and replays it from the voxel's state at the start of the
+//                super-step, taking each popping voxel's distance / parent AT ITS POP TIME from the previous
+//                iteration.  Outputs: the state of its own records at their pop times, which pushes went below b
+//                (liveness of excursion records on this voxel, new ones), the voxel's final state.
+//   iterate      until nothing changes.  Every event depends only on events with smaller T, so after k iterations
+//                the first k events are exact and stay exact: a self-consistent prefix IS the reference's result.
+//                If the iteration is stopped early (iteration cap, an excursion larger than smax, capacity), the
+//                prefix in front of the earliest change is committed and the rest stays queued.
+//   commit       targets write their state as of the cut; the committed records' pushes are appended to the bucket
+//                FIFOs in (T, LUT index) order = the order in which the reference pushed them.
+//
+// The code is a set of PHASES: plain functions of (arguments, thread id) with no synchronisation inside — a phase
+// runs to completion before the next starts (on the device a kernel boundary, vbx_kernels_esdf_replay.hpp; in
+// tools/esdf_replay_emul.cc a serial loop, which is how this file is checked against the oracle without a GPU) —
+// and rp_control, run by one thread after every phase, which picks the next.  The two SCAN phases (PH_RANK, PH_PUSH) are
+// collective: this file gives their per-item count / apply functions, the prefix sum itself lives outside.
+//
+// The includer defines RP_FN (function qualifiers), RP_LD / RP_LD64 (coherent read of a word other workgroups updated
+// with atomics) and provides atomicAdd / atomicCAS / atomicMin / atomicOr / atomicExch on uint32_t and unsigned long long.
+#pragma once
+
+namespace rp {
+
+constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kMaxBuckets = 255;
+constexpr uint32_t kEv = 128;              // events a target can hold
+constexpr uint32_t kOwn = 31;              // event code of a record's own pop (LUT indices are 0..25)
+constexpr unsigned long long kNever = ~0ull;
+constexpr uint32_t kRankBits = 24;
+constexpr uint32_t kRankMask = (1u << kRankBits) - 1;
+
+// EsdfVoxel flags in the state word (bits 0-3), parent int8 x/y/z in bits 8-31 — the layout of EsdfDev::state
+constexpr uint32_t kObserved = 1, kHallucinated = 2, kInQueue = 4, kFixed = 8;
+
+enum Phase : uint32_t {
+  PH_DONE = 0,
+  PH_BEGIN,        // control only: pick the next super-step
+  PH_PLACE_BASE,   // thread per (base record, position 0..26)
+  PH_FOLD,         // thread per dirty target
+  PH_APPLY,        // thread per (changed or new record, position)
+  PH_SIM,          // thread per excursion whose membership changed
+  PH_MINCUT,       // thread per change point
+  PH_COMMIT_FOLD,  // thread per target
+  PH_RANK,         // SCAN over base records: committed records per base record -> dense pop ranks
+  PH_RANK_WRITE,   // thread per record
+  PH_PUSH,         // SCAN over committed records in pop order, up to four buckets at a time: FIFO positions, entries written
+  PH_CLEANUP,      // thread per target / record
+};
+// A SCAN phase is collective and lives outside this file: for i = 0 .. n_threads - 1 in order, c = rp_scan_count(i),
+// rp_scan_apply(i, running sums), running sums += c; the totals go to Ctl::scan_tot.
+struct Cnt4 { uint32_t v[4]; };
+
+struct Cfg {
+  float max_distance, min_diff, voxel_size;
+  int full, multi_queue, num_buckets;
+  uint32_t kmax, smax, max_iters;
+};
+
+// control block (device memory, one instance).  Part A is written by rp_control only (every workgroup reads it at
+// the start of a launch); part B is updated with atomics while a phase runs, and rp_control reads it through RP_LD
+// (an atomic read-modify-write: the per-XCD L2s are not coherent, a plain load may see an old line).
+struct Ctl {
+  // ---- A
+  uint32_t phase, done;
+  uint32_t n_threads;                        // threads (items) the current phase needs
+  uint32_t bucket, K, base_head;             // super-step: bucket b, base records, FIFO index of base record 0
+  uint32_t n_rec, iter;
+  uint32_t read;                             // dirty target lists: FOLD reads list `read`, marks go to 1 - read
+  uint32_t a_chg, a_born, a_tgt;             // copies of n_chg / n_born / n_tgt as the last phase left them
+  unsigned long long cut;
+  uint32_t n_commit;                         // committed records
+  uint32_t scan_tot[4];
+  uint32_t push_b[4], push_n;                // buckets of the current PH_PUSH pass
+  uint32_t push_next;                        // first bucket not yet handled by a PH_PUSH pass
+  uint32_t head[kMaxBuckets + 1], tail[kMaxBuckets + 1];  // FIFO indices per bucket (entries ever popped / pushed)
+  uint32_t reserved[kMaxBuckets + 1];        // chunks of the bucket's FIFO that are backed by the arena
+  uint32_t k_cur[kMaxBuckets + 1];           // base records the bucket's next super-step may take (slow start after a cut)
+  uint32_t chunk_top;
+  // ---- B
+  uint32_t error;                            // 1 record capacity, 2 target capacity, 4 queue arena, 8 no progress, 16 event overflow at base record 0
+  uint32_t n_tgt, n_dirty[2];
+  uint32_t n_chg, n_born, n_sd, n_cp;
+  uint32_t k_limit;                          // base records from here on cannot take part (event list overflow)
+  unsigned long long first_change, smax_cut;
+  uint32_t push_cnt[kMaxBuckets + 1];        // pushes per bucket seen by COMMIT_FOLD (upper bound of what gets queued)
+  uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
+  // statistics
+  unsigned long long st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank;
+  unsigned long long st_phase_steps[16], st_phase_threads[16];
+};
+
+struct Args {
+  Cfg c;
+  Ctl* ctl;
+  // the ESDF layer (pool slot * nvox + linear index) and block adjacency
+  float* dist;
+  uint32_t* state;
+  const uint32_t* nbslot;   // [slot][27]: pool slot of the ESDF block at offset (dx,dy,dz) = ((k%3)-1, (k/3%3)-1, (k/9)-1), kNone if the ESDF layer has none
+  uint32_t* blk_dirty;      // per slot word that gets `dirty_bit` or-ed in when a voxel of the block changes (may be null)
+  uint32_t dirty_bit;
+  uint32_t nvox;
+  int vps;
+  // bucket FIFOs
+  uint32_t* arena;
+  uint32_t* chunk_tab;      // [bucket][max_chunks]
+  uint32_t max_chunks;
+  // records
+  uint32_t rec_cap;
+  uint32_t* rec_vox;
+  uint32_t* rec_pusher;     // kNone: base record
+  uint32_t* rec_base;       // the base record whose excursion the record belongs to (itself for a base record)
+  uint32_t* rec_meta;       // lut | bucket << 8 | live << 16; "next" copy in rec_meta_n (bucket, live)
+  uint32_t* rec_meta_n;
+  uint32_t* rec_poison;     // 1: a target could not take the record's event — the record stays out of every super-step fold
+  unsigned long long* rec_T;
+  float* rec_d;             // voxel distance at pop time (current guess) / next
+  float* rec_d_n;
+  uint32_t* rec_s;          // voxel state word at pop time
+  uint32_t* rec_s_n;
+  uint32_t* rec_kid;        // [rec][26]: excursion record + 1 spawned by this record's push to LUT neighbour k
+  uint32_t* rec_tgts;       // [rec][27]: targets of the 26 neighbours and (26) of the voxel itself
+  uint32_t* rec_push;       // [rec][26] bytes packed in 7 words: bucket + 1 of the committed push to neighbour k
+  // targets
+  uint32_t tgt_cap;
+  uint32_t* vox2tgt;        // [pool voxels]: target + 1
+  uint32_t* tgt_gid;
+  uint32_t* tgt_cnt;
+  uint32_t* tgt_ev;         // [tgt][kEv]: record << 5 | code
+  uint32_t* tgt_dirty;
+  uint32_t* dl[2];          // dirty target lists
+  // per-iteration lists
+  uint32_t* chg;            // records whose pop-time state / liveness changed
+  uint32_t* born;           // [.][6]: pusher, lut, bucket, gid, first guess of the pop-time distance / state
+  uint32_t* cp;             // change points (records)
+  uint32_t* sd_list;        // base records whose excursion must be re-ranked
+  uint32_t* sub_dirty;      // [kmax]
+  uint32_t* sub_n;          // [kmax] ranked excursion records of the base record
+  uint32_t* sub_slot;       // [kmax] slot + 1 of the base record's list in sub_list
+  uint32_t* sub_list;       // [slots][smax] ranked records of the last ranking
+  uint32_t* sub_slots_used;
+  unsigned long long* sim_q;  // [slots][smax] scratch of the ranking
+  uint32_t sub_slots_cap;
+  // commit
+  uint32_t* ord;            // committed records in pop order
+  uint32_t* off0;           // [kmax] dense rank of base record i
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------------
+RP_FN int rp_signum(float v) { return (v > 0.f) - (v < 0.f); }
+RP_FN uint32_t rp_pack_parent(int x, int y, int z) {
+  return ((uint32_t)(x & 0xFF) << 8) | ((uint32_t)(y & 0xFF) << 16) | ((uint32_t)(z & 0xFF) << 24);
+}
+RP_FN void rp_unpack_parent(uint32_t s, int* x, int* y, int* z) {
+  *x = (int)(int8_t)(s >> 8); *y = (int)(int8_t)(s >> 16); *z = (int)(int8_t)(s >> 24);
+}
+RP_FN void rp_lut_offset(int idx, int* dx, int* dy, int* dz) {  // neighbor_tools.cc:8-34, column order
+  // 6 faces, 12 edges, 8 corners — packed as 2-bit fields (value + 1) per axis
+  const unsigned char t[26] = {
+      // x | y << 2 | z << 4, each 0..2
+      0 | (1 << 2) | (1 << 4), 2 | (1 << 2) | (1 << 4), 1 | (0 << 2) | (1 << 4), 1 | (2 << 2) | (1 << 4),
+      1 | (1 << 2) | (0 << 4), 1 | (1 << 2) | (2 << 4), 0 | (0 << 2) | (1 << 4), 0 | (2 << 2) | (1 << 4),
+      2 | (0 << 2) | (1 << 4), 2 | (2 << 2) | (1 << 4), 1 | (0 << 2) | (0 << 4), 1 | (0 << 2) | (2 << 4),
+      1 | (2 << 2) | (0 << 4), 1 | (2 << 2) | (2 << 4), 0 | (1 << 2) | (0 << 4), 2 | (1 << 2) | (0 << 4),
+      0 | (1 << 2) | (2 << 4), 2 | (1 << 2) | (2 << 4), 0 | (0 << 2) | (0 << 4), 0 | (0 << 2) | (2 << 4),
+      0 | (2 << 2) | (0 << 4), 0 | (2 << 2) | (2 << 4), 2 | (0 << 2) | (0 << 4), 2 | (0 << 2) | (2 << 4),
+      2 | (2 << 2) | (0 << 4), 2 | (2 << 2) | (2 << 4)};
+  const int v = t[idx];
+  *dx = (v & 3) - 1; *dy = ((v >> 2) & 3) - 1; *dz = ((v >> 4) & 3) - 1;
+}
+RP_FN float rp_lut_distance(int idx) {
+  const float sq2 = (float)1.4142135623730951, sq3 = (float)1.7320508075688772;  // std::sqrt(2), std::sqrt(3) as float
+  return idx < 6 ? 1.0f : (idx < 18 ? sq2 : sq3);
+}
+RP_FN float rp_parent_norm(int x, int y, int z) {  // Eigen Vector3i::cast<float>().norm(): sqrt(c0 + (c1 + c2))
+  const float fx = (float)x, fy = (float)y, fz = (float)z;
+  return sqrtf(fx * fx + (fy * fy + fz * fz));
+}
+// BucketQueue::push's bucket (bucket_queue.h:41-50)
+RP_FN int rp_bucket_of(const Cfg& c, float value_f) {
+  double value = (double)value_f;
+  const double max_val = (double)c.max_distance;
+  if (value > max_val) value = max_val;
+  int b = (int)floor(fabs(value) / max_val * (double)(c.num_buckets - 1));
+  if (b >= c.num_buckets) b = c.num_buckets - 1;
+  if (b < 0) b = 0;
+  return b;
+}
+// the voxel `idx` (LUT) away from gid, kNone when the ESDF layer has no block there
+RP_FN uint32_t rp_neighbour(const Args& a, uint32_t gid, int idx) {
+  const uint32_t slot = gid / a.nvox, lin = gid % a.nvox;
+  const int vps = a.vps;
+  int dx, dy, dz;
+  rp_lut_offset(idx, &dx, &dy, &dz);
+  int nx = (int)(lin % vps) + dx, ny = (int)((lin / vps) % vps) + dy, nz = (int)(lin / (vps * vps)) + dz;
+  int cx = 1, cy = 1, cz = 1;
+  if (nx < 0) { nx += vps; cx = 0; } else if (nx >= vps) { nx -= vps; cx = 2; }
+  if (ny < 0) { ny += vps; cy = 0; } else if (ny >= vps) { ny -= vps; cy = 2; }
+  if (nz < 0) { nz += vps; cz = 0; } else if (nz >= vps) { nz -= vps; cz = 2; }
+  uint32_t s2 = slot;
+  if (cx != 1 || cy != 1 || cz != 1) {
+    s2 = a.nbslot[(size_t)slot * 27 + (cx + 3 * cy + 9 * cz)];
+    if (s2 == kNone) return kNone;
+  }
+  return s2 * a.nvox + (uint32_t)(nx + vps * (ny + vps * nz));
+}
+RP_FN uint32_t rp_queue_entry(const Args& a, int q, uint32_t idx) {
+  return a.arena[(size_t)a.chunk_tab[(size_t)q * a.max_chunks + (idx / kChunk)] * kChunk + (idx % kChunk)];
+}
+RP_FN void rp_queue_store(const Args& a, int q, uint32_t idx, uint32_t v) {
+  a.arena[(size_t)a.chunk_tab[(size_t)q * a.max_chunks + (idx / kChunk)] * kChunk + (idx % kChunk)] = v;
+}
+// chunks for FIFO indices [tail, tail + n) of queue q (control thread only)
+RP_FN bool rp_queue_reserve(const Args& a, int q, uint32_t n) {
+  Ctl& c = *a.ctl;
+  if (n == 0) return true;
+  const uint32_t last = (c.tail[q] + n - 1) / kChunk;
+  for (uint32_t j = c.reserved[q]; j <= last; ++j) {
+    if (c.chunk_top >= a.max_chunks || j >= a.max_chunks) { c.error |= 4; return false; }
+    a.chunk_tab[(size_t)q * a.max_chunks + j] = c.chunk_top++;
+  }
+  if (last + 1 > c.reserved[q]) c.reserved[q] = last + 1;
+  return true;
+}
+
+RP_FN uint32_t rp_meta_lut(uint32_t m) { return m & 0xFF; }
+RP_FN uint32_t rp_meta_bucket(uint32_t m) { return (m >> 8) & 0xFF; }
+RP_FN bool rp_meta_live(uint32_t m) { return (m >> 16) & 1; }
+RP_FN uint32_t rp_meta(uint32_t lut, uint32_t bucket, bool live) { return lut | (bucket << 8) | ((uint32_t)live << 16); }
+
+RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
+  if (t == kNone) return;
+  if (atomicExch(&a.tgt_dirty[t], 1u) == 0u) {
+    Ctl& c = *a.ctl;
+    const uint32_t w = 1u - c.read;
+    const uint32_t k = atomicAdd(&c.n_dirty[w], 1u);
+    a.dl[w][k] = t;   // k < tgt_cap: a target is listed at most once per list
+  }
+}
+
+// the target of voxel gid (created on first use)
+RP_FN uint32_t rp_target(const Args& a, uint32_t gid) {
+  Ctl& c = *a.ctl;
+  const uint32_t v = a.vox2tgt[gid];
+  if (v != 0u) return v - 1u;
+  const uint32_t id = atomicAdd(&c.n_tgt, 1u);
+  if (id >= a.tgt_cap) { atomicOr(&c.error, 2u); return kNone; }
+  const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, id + 1u);
+  if (old != 0u) {  // somebody else made it: `id` stays an empty hole
+    a.tgt_gid[id] = kNone;
+    return old - 1u;
+  }
+  a.tgt_gid[id] = gid;
+  return id;
+}
+
+// record `r` (voxel gid) announces itself to the target at position p (0..25 LUT neighbour, 26 the voxel itself)
+RP_FN void rp_place(const Args& a, uint32_t r, uint32_t gid, uint32_t p) {
+  Ctl& c = *a.ctl;
+  const uint32_t ngid = p == 26 ? gid : rp_neighbour(a, gid, (int)p);
+  uint32_t t = kNone;
+  if (ngid != kNone) t = rp_target(a, ngid);
+  a.rec_tgts[(size_t)r * 27 + p] = t;
+  if (t == kNone) return;
+  const uint32_t k = atomicAdd(&a.tgt_cnt[t], 1u);
+  if (k < kEv) {
+    a.tgt_ev[(size_t)t * kEv + k] = (r << 5) | (p == 26 ? kOwn : p);
+  } else {
+    // the target cannot hear this record: the record must stay out of the super-step
+    a.rec_poison[r] = 1u;
+    atomicAdd(&c.st_poison, 1ull);
+    if (r < c.K) atomicMin(&c.k_limit, r);
+  }
+  rp_mark_dirty(a, t);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the relaxation of one neighbour, esdf_integrator.cc:405-491.  (vd, vs): the popped voxel at its pop time; (nd, ns):
+// the neighbour now.  Returns true and the new distance / parent bits if the neighbour is written.
+// ------------------------------------------------------------------------------------------------------------
+RP_FN bool rp_relax(const Cfg& c, float vd, uint32_t vs, float nd, int lut, float* out_d, uint32_t* out_parent) {
+  int dx, dy, dz;
+  rp_lut_offset(lut, &dx, &dy, &dz);
+  float distance = rp_lut_distance(lut) * c.voxel_size;
+  int npx = -dx, npy = -dy, npz = -dz;
+  if (c.full) {  // :419-428
+    int vpx, vpy, vpz;
+    rp_unpack_parent(vs, &vpx, &vpy, &vpz);
+    npx = vpx - dx; npy = vpy - dy; npz = vpz - dz;
+    distance = c.voxel_size * (rp_parent_norm(npx, npy, npz) - rp_parent_norm(vpx, vpy, vpz));
+    if ((double)distance < 0.0) return false;
+  }
+  float new_d;
+  if (vd > 0 && nd > 0) {                                        // :431-444
+    if (!(vd + distance + c.min_diff < nd)) return false;
+    new_d = vd + distance;
+  } else if (vd <= 0 && nd <= 0) {                               // :446-459
+    if (!(vd - distance - c.min_diff > nd)) return false;
+    new_d = vd - distance;
+  } else {                                                       // :461-491
+    const float potential = vd - (float)rp_signum(vd) * distance;
+    if (!(fabsf(potential - nd) > distance)) return false;
+    if ((float)rp_signum(potential) == nd) new_d = potential;    // :464 compares signum(int) with the float distance
+    else new_d = (float)rp_signum(nd) * distance;
+  }
+  *out_d = new_d;
+  *out_parent = rp_pack_parent(npx, npy, npz);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the fold of one target.  limit: only events with T < limit.  commit: write the voxel and the records' pushes
+// instead of the iteration's outputs.
+// ------------------------------------------------------------------------------------------------------------
+struct FoldEv {
+  unsigned long long T;
+  uint32_t code;  // record << 5 | lut
+};
+
+constexpr uint32_t kFast = 24;   // events a fold sorts in registers; longer lists are walked by repeated selection
+constexpr uint32_t kLp = 16;     // pushes below b one fold can see (one per pop of the voxel, plus one)
+
+RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool commit) {
+  Ctl& c = *a.ctl;
+  const uint32_t gid = a.tgt_gid[t];
+  if (gid == kNone) return;
+  const int b = (int)c.bucket;
+  uint32_t n_all = a.tgt_cnt[t];
+  if (n_all > kEv) n_all = kEv;
+  FoldEv ev[kFast];
+  uint32_t n = 0;
+  bool slow = false;
+  for (uint32_t k = 0; k < n_all; ++k) {
+    const uint32_t code = a.tgt_ev[(size_t)t * kEv + k];
+    const uint32_t r = code >> 5;
+    const uint32_t m = a.rec_meta[r];
+    const unsigned long long T = a.rec_T[r];
+    if (!rp_meta_live(m) || a.rec_poison[r] || !(T < limit)) continue;
+    if (n == kFast) { slow = true; break; }
+    // insertion by T (events of one record on one target are unique, so are the T)
+    uint32_t j = n++;
+    while (j > 0 && ev[j - 1].T > T) { ev[j] = ev[j - 1]; --j; }
+    ev[j].T = T; ev[j].code = code;
+  }
+  const float d0 = a.dist[gid];
+  const uint32_t s0 = a.state[gid];
+  float d = d0;
+  uint32_t s = s0;
+  const bool usable = (s0 & kObserved) && !(s0 & kFixed);
+  uint32_t relax = 0;
+  // pushes below b seen in this fold: record, lut | bucket << 8, and the voxel as the push left it
+  uint32_t lp_rec[kLp], lp_lb[kLp], lp_s[kLp];
+  float lp_d[kLp];
+  uint32_t n_lp = 0;
+  unsigned long long last_T = 0;
+  bool first = true;
+  for (uint32_t k = 0;; ++k) {
+    uint32_t code;
+    if (!slow) {
+      if (k >= n) break;
+      code = ev[k].code;
+    } else {
+      // the live event with the smallest T behind last_T
+      unsigned long long best = kNever;
+      code = 0;
+      for (uint32_t q = 0; q < n_all; ++q) {
+        const uint32_t cq = a.tgt_ev[(size_t)t * kEv + q];
+        const uint32_t rq = cq >> 5;
+        const unsigned long long T = a.rec_T[rq];
+        if (!(T < limit) || !(T < best) || (!first && !(T > last_T))) continue;
+        if (!rp_meta_live(a.rec_meta[rq]) || a.rec_poison[rq]) continue;
+        best = T; code = cq;
+      }
+      if (best == kNever) break;
+      last_T = best;
+      first = false;
+    }
+    const uint32_t r = code >> 5, lut = code & 31;
+    if (lut == kOwn) {
+      // the pop: processOpenSet reads the voxel here (:381-392)
+      if (!commit) {
+        a.rec_d_n[r] = d;
+        a.rec_s_n[r] = s;
+      }
+      s &= ~kInQueue;                                            // :386
+      continue;
+    }
+    const float vd = a.rec_d[r];
+    const uint32_t vs = a.rec_s[r];
+    if (!(vs & kObserved) || vd >= a.c.max_distance || vd <= -a.c.max_distance) continue;  // :389-392
+    if (!usable) continue;                                       // :414-417
+    float nd;
+    uint32_t np;
+    if (!rp_relax(a.c, vd, vs, d, (int)lut, &nd, &np)) continue;
+    ++relax;
+    d = nd;
+    s = (s & 0xFFu) | np;
+    if (a.c.multi_queue || !(s & kInQueue)) {
+      s |= kInQueue;
+      const int nb = rp_bucket_of(a.c, nd);
+      if (commit) {
+        // rec_push[r][lut] = bucket + 1 (bytes; a record's 26 bytes are written by 26 different targets)
+        const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
+        atomicOr(&a.rec_push[w], (uint32_t)(nb + 1) << sh);
+        atomicAdd(&c.push_cnt[nb], 1u);
+      } else if (nb < b) {
+        if (n_lp == kLp) {
+          // no room to describe this push: the pushing record leaves the super-step (the cut falls in front of it)
+          if (atomicExch(&a.rec_poison[r], 1u) == 0u) {
+            atomicAdd(&c.st_poison, 1ull);
+            if (r < c.K) atomicMin(&c.k_limit, r);
+            const uint32_t base = a.rec_base[r];
+            if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
+            a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+          }
+          continue;
+        }
+        lp_rec[n_lp] = r; lp_lb[n_lp] = lut | ((uint32_t)nb << 8);
+        lp_d[n_lp] = d; lp_s[n_lp] = s;
+        ++n_lp;
+      }
+    }
+  }
+  if (commit) {
+    if (d != d0 || s != s0) {
+      a.dist[gid] = d;
+      a.state[gid] = s;
+      if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+    }
+    if (relax) atomicAdd(&c.st_relax, (unsigned long long)relax);
+    return;
+  }
+  // ---- outputs of an iteration
+  for (uint32_t k = 0; k < n_all; ++k) {
+    const uint32_t code = a.tgt_ev[(size_t)t * kEv + k];
+    if ((code & 31) != kOwn) continue;
+    const uint32_t r = code >> 5;
+    const uint32_t m = a.rec_meta[r];
+    if (a.rec_poison[r]) continue;
+    bool changed = false;
+    uint32_t mn = m;
+    if (a.rec_pusher[r] != kNone) {
+      // an excursion record lives iff this fold pushed it below b
+      bool found = false;
+      uint32_t bucket = rp_meta_bucket(m);
+      for (uint32_t j = 0; j < n_lp; ++j)
+        if (lp_rec[j] == a.rec_pusher[r] && (lp_lb[j] & 0xFF) == rp_meta_lut(m)) { found = true; bucket = lp_lb[j] >> 8; lp_rec[j] = kNone; }
+      mn = rp_meta(rp_meta_lut(m), bucket, found);
+      if (mn != m) changed = true;
+    }
+    if (rp_meta_live(m) && a.rec_T[r] != kNever) {
+      // it popped in this fold: did its pop-time state move?
+      if (__float_as_uint(a.rec_d_n[r]) != __float_as_uint(a.rec_d[r]) || a.rec_s_n[r] != a.rec_s[r]) changed = true;
+    } else {
+      a.rec_d_n[r] = a.rec_d[r];
+      a.rec_s_n[r] = a.rec_s[r];
+    }
+    a.rec_meta_n[r] = mn;
+    if (changed) a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+  }
+  for (uint32_t j = 0; j < n_lp; ++j) {
+    if (lp_rec[j] == kNone) continue;  // matched an existing record
+    // a push below b without a record yet (an existing record for (pusher, lut) sits on THIS voxel and was matched above)
+    if (a.rec_kid[(size_t)lp_rec[j] * 26 + (lp_lb[j] & 0xFF)] != 0u) continue;  // (dead record that is not on this list cannot happen; be safe)
+    const uint32_t k = atomicAdd(&c.n_born, 1u);
+    a.born[(size_t)k * 6 + 0] = lp_rec[j];
+    a.born[(size_t)k * 6 + 1] = lp_lb[j] & 0xFF;
+    a.born[(size_t)k * 6 + 2] = lp_lb[j] >> 8;
+    a.born[(size_t)k * 6 + 3] = gid;
+    a.born[(size_t)k * 6 + 4] = __float_as_uint(lp_d[j]);   // first guess of the record's pop-time state: the voxel as this push left it
+    a.born[(size_t)k * 6 + 5] = lp_s[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// phases
+// ------------------------------------------------------------------------------------------------------------
+RP_FN void rp_phase_place_base(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  const uint32_t r = tid / 27, p = tid % 27;
+  if (r >= c.K) return;
+  const uint32_t gid = rp_queue_entry(a, (int)c.bucket, c.base_head + r);
+  if (p == 26) {
+    a.rec_vox[r] = gid;
+    a.rec_pusher[r] = kNone;
+    a.rec_base[r] = r;
+    a.rec_meta[r] = rp_meta(0, c.bucket, true);
+    a.rec_meta_n[r] = a.rec_meta[r];
+    a.rec_T[r] = (unsigned long long)r << kRankBits;
+    a.rec_d[r] = a.dist[gid];
+    a.rec_s[r] = a.state[gid];
+    a.rec_d_n[r] = a.rec_d[r];
+    a.rec_s_n[r] = a.rec_s[r];
+    a.sub_dirty[r] = 0;
+    a.sub_n[r] = 0;
+    a.sub_slot[r] = 0;
+  }
+  rp_place(a, r, gid, p);
+}
+
+RP_FN void rp_phase_fold(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  if (tid >= c.n_threads) return;
+  const uint32_t t = a.dl[c.read][tid];
+  a.tgt_dirty[t] = 0;
+  rp_fold(a, t, kNever, false);
+}
+
+RP_FN void rp_mark_sub_dirty(const Args& a, uint32_t r) {
+  Ctl& c = *a.ctl;
+  const uint32_t base = a.rec_base[r];
+  if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
+}
+
+RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  const uint32_t item = tid / 27, p = tid % 27;
+  if (item < c.a_chg) {
+    const uint32_t r = a.chg[item];
+    if (p == 26) {
+      const uint32_t m = a.rec_meta[r], mn = a.rec_meta_n[r];
+      uint32_t point = r;
+      if (mn != m) {
+        // liveness / bucket of an excursion record: the change happened at its pusher's pop
+        point = a.rec_pusher[r];
+        rp_mark_sub_dirty(a, point);
+      }
+      a.cp[atomicAdd(&c.n_cp, 1u)] = point;
+      a.rec_d[r] = a.rec_d_n[r];
+      a.rec_s[r] = a.rec_s_n[r];
+      a.rec_meta[r] = mn;
+    }
+    rp_mark_dirty(a, a.rec_tgts[(size_t)r * 27 + p]);
+    return;
+  }
+  const uint32_t j = item - c.a_chg;
+  if (j >= c.a_born) return;
+  const uint32_t r = c.n_rec + j;   // (control checked the capacity)
+  const uint32_t pusher = a.born[(size_t)j * 6], lut = a.born[(size_t)j * 6 + 1], bucket = a.born[(size_t)j * 6 + 2];
+  const uint32_t gid = a.born[(size_t)j * 6 + 3];
+  if (p == 26) {
+    a.rec_vox[r] = gid;
+    a.rec_pusher[r] = pusher;
+    a.rec_base[r] = a.rec_base[pusher];
+    a.rec_meta[r] = rp_meta(lut, bucket, true);
+    a.rec_meta_n[r] = a.rec_meta[r];
+    a.rec_T[r] = kNever;
+    a.rec_d[r] = __uint_as_float(a.born[(size_t)j * 6 + 4]);
+    a.rec_s[r] = a.born[(size_t)j * 6 + 5];
+    a.rec_d_n[r] = a.rec_d[r];
+    a.rec_s_n[r] = a.rec_s[r];
+    a.rec_kid[(size_t)pusher * 26 + lut] = r + 1;
+    a.cp[atomicAdd(&c.n_cp, 1u)] = pusher;
+    rp_mark_sub_dirty(a, pusher);
+  }
+  rp_place(a, r, gid, p);
+}
+
+// pop times of the excursion of base record `base`: the reference's queue discipline (lowest bucket first, FIFO
+// inside, bucket_queue.h:58-80) over the live excursion records; children enter in LUT order when their pusher pops
+RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  if (tid >= c.n_threads) return;
+  const uint32_t base = a.sd_list[tid];
+  a.sub_dirty[base] = 0;
+  uint32_t slot = a.sub_slot[base];
+  if (slot == 0) {
+    slot = atomicAdd(a.sub_slots_used, 1u) + 1u;
+    if (slot > a.sub_slots_cap) { atomicOr(&c.error, 1u); return; }
+    a.sub_slot[base] = slot;
+  }
+  uint32_t* list = a.sub_list + (size_t)(slot - 1) * a.c.smax;
+  unsigned long long* q = a.sim_q + (size_t)(slot - 1) * a.c.smax;   // pending entries: record | next entry << 32
+  for (uint32_t k = 0; k < a.sub_n[base]; ++k) a.rec_T[list[k]] = kNever;
+  // one FIFO per bucket below b, linked through q; lowest = a lower bound of the lowest non-empty bucket
+  unsigned short head[kMaxBuckets + 1], tail[kMaxBuckets + 1];
+  const int nb = (int)c.bucket;
+  for (int k = 0; k < nb; ++k) head[k] = tail[k] = 0xFFFF;
+  uint32_t n_q = 0, rank = 0;
+  int lowest = nb;
+  bool truncated = false;
+  uint32_t cur = base;
+  for (;;) {
+    // the children of `cur` enter their buckets in LUT order
+    for (int lut = 0; lut < 26 && !truncated; ++lut) {
+      const uint32_t kid = a.rec_kid[(size_t)cur * 26 + lut];
+      if (kid == 0u) continue;
+      const uint32_t m = a.rec_meta[kid - 1];
+      if (!rp_meta_live(m)) continue;
+      if (n_q >= a.c.smax || n_q >= 0xFFFFu) { truncated = true; atomicAdd(&c.st_trunc_q, 1ull); break; }
+      const int kb = (int)rp_meta_bucket(m);
+      q[n_q] = (unsigned long long)(kid - 1) | (0xFFFFull << 32);
+      if (tail[kb] == 0xFFFF) head[kb] = (unsigned short)n_q;
+      else q[tail[kb]] = (q[tail[kb]] & 0xFFFFFFFFull) | ((unsigned long long)n_q << 32);
+      tail[kb] = (unsigned short)n_q;
+      if (kb < lowest) lowest = kb;
+      ++n_q;
+    }
+    if (truncated) break;
+    while (lowest < nb && head[lowest] == 0xFFFF) ++lowest;   // BucketQueue::front / pop
+    if (lowest >= nb) break;
+    const unsigned long long e = q[head[lowest]];
+    const uint32_t r = (uint32_t)(e & 0xFFFFFFFFull);
+    head[lowest] = (unsigned short)(e >> 32);
+    if (head[lowest] == 0xFFFF) tail[lowest] = 0xFFFF;
+    if (rank >= a.c.smax - 1 || a.rec_poison[r]) { truncated = true; atomicAdd(&c.st_trunc_rank, 1ull); break; }
+    ++rank;
+    a.rec_T[r] = ((unsigned long long)base << kRankBits) | rank;
+    list[rank - 1] = r;
+    cur = r;
+  }
+  a.sub_n[base] = rank;
+  // an excursion that does not fit stops the super-step behind its last ranked record
+  if (truncated) atomicMin(&c.smax_cut, ((unsigned long long)base << kRankBits) | (rank + 1));
+}
+
+RP_FN void rp_phase_mincut(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  if (tid >= c.n_threads) return;
+  atomicMin(&c.first_change, a.rec_T[a.cp[tid]]);
+}
+
+RP_FN void rp_phase_commit_fold(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  if (tid >= c.a_tgt) return;
+  rp_fold(a, tid, c.cut, true);
+}
+
+// SCAN counts / applies.  PH_RANK: item = base record i, count = its committed records (itself included), apply =
+// dense pop rank of base record i.  PH_PUSH: item = j-th committed record in pop order, count[k] = its entries for
+// bucket push_b[k], apply = they are written behind the bucket's tail in LUT order.
+RP_FN uint32_t rp_push_bits(const Args& a, uint32_t r, uint32_t bucket, unsigned long long cut) {
+  uint32_t bits = 0;
+  for (uint32_t lut = 0; lut < 26; ++lut) {
+    const uint32_t v = (a.rec_push[r * 7 + lut / 4] >> ((lut % 4) * 8)) & 0xFF;
+    if (v != bucket + 1) continue;
+    // an entry that was popped inside this super-step is not queued
+    const uint32_t kid = a.rec_kid[(size_t)r * 26 + lut];
+    if (kid != 0u) {
+      const uint32_t k = kid - 1;
+      if (rp_meta_live(a.rec_meta[k]) && a.rec_T[k] < cut) continue;
+    }
+    bits |= 1u << lut;
+  }
+  return bits;
+}
+RP_FN Cnt4 rp_scan_count(const Args& a, uint32_t i) {
+  const Ctl& c = *a.ctl;
+  Cnt4 n = {{0, 0, 0, 0}};
+  if (c.phase == PH_RANK) {
+    const unsigned long long T0 = (unsigned long long)i << kRankBits;
+    if (T0 < c.cut) {
+      n.v[0] = 1 + a.sub_n[i];
+      if ((c.cut >> kRankBits) == i) n.v[0] = (uint32_t)(c.cut & kRankMask);  // ranks in front of the cut's, plus the base record
+    }
+  } else {
+    const uint32_t r = a.ord[i];
+    for (uint32_t k = 0; k < c.push_n; ++k) {
+      uint32_t x = rp_push_bits(a, r, c.push_b[k], c.cut), cnt = 0;
+      for (; x; x &= x - 1) ++cnt;
+      n.v[k] = cnt;
+    }
+  }
+  return n;
+}
+RP_FN void rp_scan_apply(const Args& a, uint32_t i, const Cnt4& prefix) {
+  const Ctl& c = *a.ctl;
+  if (c.phase == PH_RANK) {
+    a.off0[i] = prefix.v[0];
+    return;
+  }
+  const uint32_t r = a.ord[i];
+  const uint32_t gid = a.rec_vox[r];
+  for (uint32_t k = 0; k < c.push_n; ++k) {
+    const uint32_t bits = rp_push_bits(a, r, c.push_b[k], c.cut);
+    uint32_t pos = c.tail[c.push_b[k]] + prefix.v[k];
+    for (uint32_t lut = 0; lut < 26; ++lut)
+      if ((bits >> lut) & 1u) rp_queue_store(a, (int)c.push_b[k], pos++, rp_neighbour(a, gid, (int)lut));
+  }
+}
+RP_FN void rp_phase_rank_write(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  if (tid >= c.n_rec) return;
+  const uint32_t m = a.rec_meta[tid];
+  const unsigned long long T = a.rec_T[tid];
+  if (!rp_meta_live(m) || !(T < c.cut)) return;
+  const uint32_t base = (uint32_t)(T >> kRankBits);
+  a.ord[a.off0[base] + (uint32_t)(T & kRankMask)] = tid;
+}
+RP_FN void rp_phase_cleanup(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  if (tid < c.a_tgt) {
+    const uint32_t gid = a.tgt_gid[tid];
+    if (gid != kNone) a.vox2tgt[gid] = 0;
+    a.tgt_cnt[tid] = 0;
+    a.tgt_dirty[tid] = 0;
+  }
+  if (tid < c.n_rec) {
+    for (int k = 0; k < 26; ++k) a.rec_kid[(size_t)tid * 26 + k] = 0;
+    for (int k = 0; k < 7; ++k) a.rec_push[tid * 7 + k] = 0;
+    a.rec_poison[tid] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// control: one thread, after every phase
+// ------------------------------------------------------------------------------------------------------------
+RP_FN void rp_stop(Ctl& c) { c.phase = PH_DONE; c.done = 1; c.n_threads = 0; }
+
+RP_FN void rp_begin_superstep(const Args& a) {
+  Ctl& c = *a.ctl;
+  int b = 0;
+  while (b < a.c.num_buckets && c.head[b] == c.tail[b]) ++b;
+  if (b == a.c.num_buckets) { rp_stop(c); return; }
+  c.bucket = (uint32_t)b;
+  uint32_t K = c.tail[b] - c.head[b];
+  if (c.k_cur[b] == 0 || c.k_cur[b] > a.c.kmax) c.k_cur[b] = a.c.kmax;
+  if (K > c.k_cur[b]) K = c.k_cur[b];
+  c.K = K;
+  c.base_head = c.head[b];
+  c.n_rec = K;
+  c.n_tgt = 0;
+  c.iter = 0;
+  c.read = 1;            // PLACE_BASE marks into list 0
+  c.n_dirty[0] = c.n_dirty[1] = 0;
+  c.n_chg = c.n_born = c.n_sd = c.n_cp = 0;
+  c.k_limit = kNone;
+  c.first_change = kNever;
+  c.smax_cut = kNever;
+  c.cut = kNever;
+  *a.sub_slots_used = 0;
+  ++c.st_supersteps;
+  c.phase = PH_PLACE_BASE;
+  c.n_threads = K * 27;
+}
+
+RP_FN void rp_start_commit(const Args& a) {
+  Ctl& c = *a.ctl;
+  const unsigned long long first_change = RP_LD64(c.first_change), smax_cut = RP_LD64(c.smax_cut);
+  const uint32_t k_limit = RP_LD(c.k_limit);
+  unsigned long long cut = first_change < smax_cut ? first_change : smax_cut;
+  if (k_limit != kNone) {
+    const unsigned long long kl = (unsigned long long)k_limit << kRankBits;
+    if (kl < cut) cut = kl;
+  }
+  if (cut != kNever) { if (smax_cut <= first_change) ++c.st_cut_smax; else ++c.st_cut_iters; }
+  if (cut == 0) { c.error |= (k_limit == 0 ? 16u : 8u); rp_stop(c); return; }
+  c.cut = cut;
+  c.a_tgt = RP_LD(c.n_tgt);
+  for (int k = 0; k < a.c.num_buckets; ++k) c.push_cnt[k] = 0;
+  c.phase = PH_COMMIT_FOLD;
+  c.n_threads = c.a_tgt;
+}
+
+// the next (up to four) buckets that receive entries from this commit, chunks reserved for the most they can get
+RP_FN void rp_next_push_pass(const Args& a) {
+  Ctl& c = *a.ctl;
+  c.push_n = 0;
+  int b = (int)c.push_next;
+  for (; b < a.c.num_buckets && c.push_n < 4; ++b) {
+    const uint32_t bound = RP_LD(c.push_cnt[b]);
+    if (bound == 0) continue;
+    if (!rp_queue_reserve(a, b, bound)) { rp_stop(c); return; }
+    c.push_b[c.push_n++] = (uint32_t)b;
+  }
+  c.push_next = (uint32_t)b;
+  if (c.push_n == 0) {
+    c.phase = PH_CLEANUP;
+    c.n_threads = c.a_tgt > c.n_rec ? c.a_tgt : c.n_rec;
+    return;
+  }
+  c.phase = PH_PUSH;
+  c.n_threads = c.n_commit;
+}
+
+RP_FN void rp_control(const Args& a) {
+  Ctl& c = *a.ctl;
+  ++c.st_steps;
+  ++c.st_phase_steps[c.phase & 15];
+  c.st_phase_threads[c.phase & 15] += c.n_threads;
+  if (RP_LD(c.error)) { rp_stop(c); return; }
+  switch (c.phase) {
+    case PH_BEGIN:
+      rp_begin_superstep(a);
+      break;
+    case PH_PLACE_BASE:
+    case PH_SIM:
+    case PH_APPLY: {
+      const uint32_t n_cp = RP_LD(c.n_cp);
+      if (c.phase == PH_APPLY) {
+        c.n_rec += c.a_born;
+        c.st_exc += c.a_born;
+        c.n_chg = c.n_born = 0;
+        const uint32_t n_sd = RP_LD(c.n_sd);
+        if (n_sd) { c.phase = PH_SIM; c.n_threads = n_sd; break; }
+      }
+      if (c.phase == PH_SIM) c.n_sd = 0;
+      // next iteration, or stop
+      if (c.phase != PH_PLACE_BASE && n_cp == 0) { rp_start_commit(a); break; }   // (cannot happen: APPLY always leaves a change point)
+      if (c.iter >= a.c.max_iters) { c.phase = PH_MINCUT; c.n_threads = n_cp; break; }
+      c.n_cp = 0;
+      c.read = 1u - c.read;
+      c.n_dirty[1u - c.read] = 0;
+      ++c.iter;
+      ++c.st_iters;
+      c.n_threads = RP_LD(c.n_dirty[c.read]);
+      c.st_folds += c.n_threads;
+      c.phase = PH_FOLD;
+      break;
+    }
+    case PH_FOLD: {
+      c.a_chg = RP_LD(c.n_chg);
+      c.a_born = RP_LD(c.n_born);
+      if (c.a_chg == 0 && c.a_born == 0) { c.n_cp = 0; rp_start_commit(a); break; }   // fixed point
+      if (c.n_rec + c.a_born > a.rec_cap) { c.error |= 1u; rp_stop(c); break; }
+      c.phase = PH_APPLY;
+      c.n_threads = (c.a_chg + c.a_born) * 27;
+      break;
+    }
+    case PH_MINCUT:
+      rp_start_commit(a);
+      break;
+    case PH_COMMIT_FOLD:
+      c.phase = PH_RANK;
+      c.n_threads = c.K;
+      break;
+    case PH_RANK:
+      c.n_commit = c.scan_tot[0];
+      c.phase = PH_RANK_WRITE;
+      c.n_threads = c.n_rec;
+      break;
+    case PH_RANK_WRITE:
+      c.push_next = 0;
+      rp_next_push_pass(a);
+      break;
+    case PH_PUSH:
+      for (uint32_t k = 0; k < c.push_n; ++k) c.tail[c.push_b[k]] += c.scan_tot[k];
+      rp_next_push_pass(a);
+      break;
+    case PH_CLEANUP: {
+      // the committed base records leave their FIFO
+      uint32_t nb = (uint32_t)(c.cut >> kRankBits);
+      if (c.cut == kNever || nb > c.K) nb = c.K;
+      else if ((c.cut & kRankMask) != 0) nb += 1;   // the cut lies inside base record nb's excursion: it has popped
+      c.head[c.bucket] += nb;
+      c.st_pops += c.n_commit;
+      // a cut throws the work behind it away: take about as much as got through next time, ramp up after clean steps
+      if (c.cut != kNever) c.k_cur[c.bucket] = nb * 2 > 32 ? nb * 2 : 32;
+      else c.k_cur[c.bucket] = c.k_cur[c.bucket] * 4 > a.c.kmax ? a.c.kmax : c.k_cur[c.bucket] * 4;
+      rp_begin_superstep(a);
+      break;
+    }
+    default:
+      rp_stop(c);
+      break;
+  }
+}
+
+}  // namespace rp
