@@ -63,6 +63,14 @@ struct vbx_ctx {
   DBuf b_own0, b_own1;
   // ESDF layer (allocated on first use)
   DBuf b_edist, b_estate, b_eraised, b_eactive;
+  // parallel reference-order open set (vbx_kernels_esdf_replay.hpp): control block, records, targets, lists
+  DBuf rp_ctl, rp_nbslot, rp_chunk_tab, rp_rec_u32, rp_rec_T, rp_rec_kid, rp_rec_tgts, rp_rec_push, rp_vox2tgt, rp_tgt_u32, rp_tgt_ev, rp_dl,
+      rp_lists, rp_sub, rp_sub_list, rp_sim_q, rp_ord, rp_scan_desc;
+  size_t rp_vox2tgt_zeroed = 0;   // bytes of rp_vox2tgt known to be zero
+  uint32_t rp_rec_cap = 0, rp_tgt_cap = 0, rp_kmax = 0, rp_smax = 0;
+  hipGraph_t rp_graph = nullptr;
+  hipGraphExec_t rp_graph_exec = nullptr;
+  std::vector<uint64_t> rp_graph_key;  // the kernel arguments the graph was captured with
   bool esdf_init = false;
   bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
   int esdf_spec_raise = 0, esdf_spec_lower = 0;  // sweeps queued ahead of the read-back (esdf_update_t)

@@ -841,7 +841,7 @@ RP_FN void rp_control(const Args& a) {
       c.n_threads = c.K;
       break;
     case PH_RANK:
-      c.n_commit = c.scan_tot[0];
+      c.n_commit = RP_LD(c.scan_tot[0]);
       c.phase = PH_RANK_WRITE;
       c.n_threads = c.n_rec;
       break;
@@ -850,7 +850,7 @@ RP_FN void rp_control(const Args& a) {
       rp_next_push_pass(a);
       break;
     case PH_PUSH:
-      for (uint32_t k = 0; k < c.push_n; ++k) c.tail[c.push_b[k]] += c.scan_tot[k];
+      for (uint32_t k = 0; k < c.push_n; ++k) c.tail[c.push_b[k]] += RP_LD(c.scan_tot[k]);
       rp_next_push_pass(a);
       break;
     case PH_CLEANUP: {

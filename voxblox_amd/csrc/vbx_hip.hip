@@ -47,6 +47,7 @@ using namespace vbx;
 #include "vbx_kernels_tsdf.hpp"
 #include "vbx_kernels_fast.hpp"
 #include "vbx_kernels_esdf.hpp"
+#include "vbx_kernels_esdf_replay.hpp"
 #include "vbx_kernels_esdf_strict.hpp"
 #include "vbx_kernels_mesh.hpp"
 #include "vbx_ctx.hpp"

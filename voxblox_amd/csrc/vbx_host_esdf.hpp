@@ -359,6 +359,188 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
   return check_state_error(ctx);
 }
 
+// ---- the parallel open set of reference_order (vbx_esdf_replay_core.hpp) ------------------------------------------
+constexpr int kRpGraphSteps = 48;   // launches per captured graph; the host looks at Ctl::done between graphs
+constexpr int kRpGrid = 512;        // workgroups of k_rp_step (grid-stride over the phase's items)
+
+static uint32_t rp_env_u32(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
+// buffers of the replay, sized for kmax base records per super-step
+int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used) {
+  hipStream_t s = ctx->stream;
+  const MapDev& m = ctx->map;
+  const uint32_t kmax = rp_env_u32("VBX_RP_KMAX", 16384), smax = rp_env_u32("VBX_RP_SMAX", 256);
+  const uint32_t rec_cap = kmax * 8 + 65536, tgt_cap = rec_cap * 3;
+  const bool fresh = !ctx->rp_ctl.p;
+  HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl)));
+  HIP_TRY(ctx->rp_nbslot.ensure((size_t)std::max<uint32_t>(used, 1) * 27 * 4));
+  HIP_TRY(ctx->rp_chunk_tab.ensure((size_t)(num_buckets + 1) * n_chunks * 4));
+  if (fresh || ctx->rp_rec_cap != rec_cap || ctx->rp_tgt_cap != tgt_cap || ctx->rp_smax != smax) {
+    HIP_TRY(ctx->rp_rec_u32.ensure((size_t)rec_cap * 4 * 10));
+    HIP_TRY(ctx->rp_rec_T.ensure((size_t)rec_cap * 8));
+    HIP_TRY(ctx->rp_rec_kid.ensure((size_t)rec_cap * 26 * 4));
+    HIP_TRY(ctx->rp_rec_tgts.ensure((size_t)rec_cap * 27 * 4));
+    HIP_TRY(ctx->rp_rec_push.ensure((size_t)rec_cap * 7 * 4));
+    HIP_TRY(ctx->rp_tgt_u32.ensure((size_t)tgt_cap * 4 * 3));
+    HIP_TRY(ctx->rp_tgt_ev.ensure((size_t)tgt_cap * rp::kEv * 4));
+    HIP_TRY(ctx->rp_dl.ensure((size_t)tgt_cap * 4 * 2));
+    HIP_TRY(ctx->rp_lists.ensure((size_t)rec_cap * 4 * (1 + 6 + 2) + (size_t)kmax * 4));
+    HIP_TRY(ctx->rp_sub.ensure((size_t)kmax * 4 * 4 + 64));
+    const uint32_t sub_slots = 8192;
+    HIP_TRY(ctx->rp_sub_list.ensure((size_t)sub_slots * smax * 4));
+    HIP_TRY(ctx->rp_sim_q.ensure((size_t)sub_slots * smax * 8));
+    HIP_TRY(ctx->rp_ord.ensure((size_t)rec_cap * 4));
+    HIP_TRY(ctx->rp_scan_desc.ensure((size_t)(rec_cap / kRpThreads + 2) * 4 * 8 + 64));
+    // what the phases expect to be zero between super-steps
+    HIP_TRY(hipMemsetAsync(ctx->rp_rec_u32.p, 0, (size_t)rec_cap * 4 * 10, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_rec_kid.p, 0, (size_t)rec_cap * 26 * 4, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_rec_push.p, 0, (size_t)rec_cap * 7 * 4, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0, (size_t)tgt_cap * 4 * 3, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_sub.p, 0, (size_t)kmax * 4 * 4 + 64, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_scan_desc.p, 0, ctx->rp_scan_desc.cap, s));
+    ctx->rp_rec_cap = rec_cap;
+    ctx->rp_tgt_cap = tgt_cap;
+    ctx->rp_kmax = kmax;
+    ctx->rp_smax = smax;
+  }
+  // voxel -> target map over the whole pool (zero between super-steps; a pool that grew gets a zeroed tail)
+  const size_t vbytes = (size_t)m.cap_blocks * m.nvox * 4;
+  if (ctx->rp_vox2tgt.cap < vbytes) {
+    HIP_TRY(ctx->rp_vox2tgt.ensure(vbytes));
+    ctx->rp_vox2tgt_zeroed = 0;
+  }
+  if (ctx->rp_vox2tgt_zeroed < vbytes) {
+    HIP_TRY(hipMemsetAsync(ctx->rp_vox2tgt.p, 0, ctx->rp_vox2tgt.cap, s));
+    ctx->rp_vox2tgt_zeroed = ctx->rp_vox2tgt.cap;
+  }
+  return VBX_OK;
+}
+
+rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t n_chunks) {
+  const MapDev& m = ctx->map;
+  rp::Args a{};
+  a.c.max_distance = cfg->max_distance_m;
+  a.c.min_diff = cfg->min_diff_m;
+  a.c.voxel_size = m.voxel_size;
+  a.c.full = cfg->full_euclidean_distance != 0;
+  a.c.multi_queue = cfg->multi_queue != 0;
+  a.c.num_buckets = cfg->num_buckets;
+  a.c.kmax = ctx->rp_kmax;
+  a.c.smax = ctx->rp_smax;
+  a.c.max_iters = rp_env_u32("VBX_RP_MAX_ITERS", 64);
+  a.ctl = ctx->rp_ctl.as<rp::Ctl>();
+  a.dist = e.dist;
+  a.state = e.state;
+  a.nbslot = ctx->rp_nbslot.as<uint32_t>();
+  a.blk_dirty = m.blk_flags;
+  a.dirty_bit = kFlagEsdfDirty;
+  a.nvox = m.nvox;
+  a.vps = m.vps;
+  a.arena = ctx->b_keys0.as<uint32_t>();
+  a.chunk_tab = ctx->rp_chunk_tab.as<uint32_t>();
+  a.max_chunks = (uint32_t)n_chunks;
+  const uint32_t R = ctx->rp_rec_cap, T = ctx->rp_tgt_cap, K = ctx->rp_kmax;
+  a.rec_cap = R;
+  uint32_t* ru = ctx->rp_rec_u32.as<uint32_t>();
+  a.rec_vox = ru; a.rec_pusher = ru + (size_t)R; a.rec_base = ru + (size_t)2 * R; a.rec_meta = ru + (size_t)3 * R;
+  a.rec_meta_n = ru + (size_t)4 * R; a.rec_poison = ru + (size_t)5 * R; a.rec_s = ru + (size_t)6 * R; a.rec_s_n = ru + (size_t)7 * R;
+  a.rec_d = reinterpret_cast<float*>(ru + (size_t)8 * R); a.rec_d_n = reinterpret_cast<float*>(ru + (size_t)9 * R);
+  a.rec_T = ctx->rp_rec_T.as<unsigned long long>();
+  a.rec_kid = ctx->rp_rec_kid.as<uint32_t>();
+  a.rec_tgts = ctx->rp_rec_tgts.as<uint32_t>();
+  a.rec_push = ctx->rp_rec_push.as<uint32_t>();
+  a.tgt_cap = T;
+  a.vox2tgt = ctx->rp_vox2tgt.as<uint32_t>();
+  uint32_t* tu = ctx->rp_tgt_u32.as<uint32_t>();
+  a.tgt_gid = tu; a.tgt_cnt = tu + (size_t)T; a.tgt_dirty = tu + (size_t)2 * T;
+  a.tgt_ev = ctx->rp_tgt_ev.as<uint32_t>();
+  a.dl[0] = ctx->rp_dl.as<uint32_t>(); a.dl[1] = a.dl[0] + (size_t)T;
+  uint32_t* l = ctx->rp_lists.as<uint32_t>();
+  a.chg = l; a.born = l + (size_t)R; a.cp = l + (size_t)7 * R; a.sd_list = l + (size_t)9 * R;
+  uint32_t* su = ctx->rp_sub.as<uint32_t>();
+  a.sub_dirty = su; a.sub_n = su + (size_t)K; a.sub_slot = su + (size_t)2 * K; a.off0 = su + (size_t)3 * K;
+  a.sub_slots_used = su + (size_t)4 * K;
+  a.sub_list = ctx->rp_sub_list.as<uint32_t>();
+  a.sim_q = ctx->rp_sim_q.as<unsigned long long>();
+  a.sub_slots_cap = 8192;
+  a.ord = ctx->rp_ord.as<uint32_t>();
+  return a;
+}
+
+// runs the replay to the end of open_; the queue (arena, chunk table, heads / tails in the control block) is what
+// k_esdf_strict(stop_before_open) left
+int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned long long* relax) {
+  hipStream_t s = ctx->stream;
+  RpScan sc;
+  sc.desc = ctx->rp_scan_desc.as<unsigned long long>() + 8;
+  sc.ticket = ctx->rp_scan_desc.as<uint32_t>();
+  sc.max_tiles = ctx->rp_rec_cap / kRpThreads + 1;
+  // the step kernel's arguments change only when a buffer moves: one captured graph per argument set
+  std::vector<uint64_t> key(sizeof(rp::Args) / 8 + 4, 0);
+  memcpy(key.data(), &a, sizeof(rp::Args));
+  key[key.size() - 1] = (uint64_t)(uintptr_t)sc.desc;
+  key[key.size() - 2] = (uint64_t)(uintptr_t)s;
+  const bool use_graph = rp_env_u32("VBX_RP_GRAPH", 1) != 0;
+  if (use_graph && (!ctx->rp_graph_exec || key != ctx->rp_graph_key)) {
+    if (ctx->rp_graph_exec) { (void)hipGraphExecDestroy(ctx->rp_graph_exec); ctx->rp_graph_exec = nullptr; }
+    if (ctx->rp_graph) { (void)hipGraphDestroy(ctx->rp_graph); ctx->rp_graph = nullptr; }
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < kRpGraphSteps; ++i) hipLaunchKernelGGL(k_rp_step, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc);
+    HIP_TRY(hipStreamEndCapture(s, &ctx->rp_graph));
+    HIP_TRY(hipGraphInstantiate(&ctx->rp_graph_exec, ctx->rp_graph, nullptr, nullptr, 0));
+    ctx->rp_graph_key = key;
+  }
+  // Ctl::sc.ticket: [0] = 0, [1] = generation >= 1 (descriptors of older scans read as "not there")
+  uint32_t h_ticket[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h_ticket, sc.ticket, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_ticket[1] == 0 || h_ticket[0] != 0) {
+    h_ticket[0] = 0;
+    h_ticket[1] = std::max<uint32_t>(h_ticket[1], 1u);
+    HIP_TRY(hipMemcpyAsync(sc.ticket, h_ticket, 8, hipMemcpyHostToDevice, s));
+  }
+  KLAUNCH(k_rp_begin, dim3(1), dim3(1), 0, s, a);
+  uint32_t h_done[2] = {0, 0};
+  const uint64_t max_graphs = 1u << 20;
+  for (uint64_t g = 0; g < max_graphs; ++g) {
+    if (use_graph) {
+      prof_begin(ctx, "k_rp_step x graph");
+      HIP_TRY(hipGraphLaunch(ctx->rp_graph_exec, s));
+      prof_end(ctx);
+    } else {
+      for (int i = 0; i < kRpGraphSteps; ++i) KLAUNCH(k_rp_step, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc);
+    }
+    HIP_TRY(hipMemcpyAsync(h_done, &a.ctl->phase, 8, hipMemcpyDeviceToHost, s));   // phase, done
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h_done[1]) break;
+  }
+  rp::Ctl hc;
+  HIP_TRY(hipMemcpyAsync(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (getenv("VBX_RP_STATS")) {
+    static const char* names[] = {"done", "begin", "place", "fold", "apply", "sim", "mincut", "cfold", "rank", "rwrite", "push", "cleanup"};
+    fprintf(stderr, "[rp] pops %llu relax %llu supersteps %llu iters %llu folds %llu exc %llu cuts(iters %llu smax %llu) steps %llu poison %llu error %u\n[rp] steps:",
+            hc.st_pops, hc.st_relax, hc.st_supersteps, hc.st_iters, hc.st_folds, hc.st_exc, hc.st_cut_iters, hc.st_cut_smax, hc.st_steps,
+            hc.st_poison, hc.error);
+    for (int k = 1; k < 12; ++k) fprintf(stderr, " %s %llu(%llu)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k]);
+    fprintf(stderr, "\n");
+  }
+  if (!hc.done) {
+    ctx->fail("ESDF reference order: the replay did not finish");
+    return VBX_ERR_HIP;
+  }
+  if (hc.error) {
+    ctx->fail("ESDF reference order: replay error 0x%x (1 records, 2 targets, 4 queue arena, 8 no progress, 16 event list at the first record, 64 scan wait)", hc.error);
+    return (hc.error & ~(8u | 64u)) ? VBX_ERR_CAPACITY : VBX_ERR_HIP;
+  }
+  *pops = hc.st_pops;
+  *relax = hc.st_relax;
+  return VBX_OK;
+}
+
 // cfg->reference_order: the whole update as ONE sequential replay on the device (vbx_kernels_esdf_strict.hpp).
 int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag, const int32_t* list,
                        size_t n_list, int list_incremental) {
@@ -422,10 +604,14 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   }
   // queue arena: a voxel sits in open_ at most once at a time without multi_queue and in raise_ at most once per
   // update, so 2 x voxels bounds what is queued at once; multi_queue can hold more (loud failure if it does)
-  const size_t n_chunks = std::max<size_t>(256, (size_t)(cfg->multi_queue ? 8 : 2) * nv / (kSqChunk - 1) + (size_t)cfg->num_buckets + 16);
+  // (chunks are not reused inside an update: the arena holds every push of the update)
+  const size_t n_chunks = std::max<size_t>(1024, (size_t)(cfg->multi_queue ? 16 : 4) * nv / kSqChunk + (size_t)4 * cfg->num_buckets + 64);
   HIP_TRY(ctx->b_keys0.ensure(n_chunks * kSqChunk * 4));
-  HIP_TRY(ctx->b_keys1.ensure(n_chunks * 4 + 64));
   HIP_TRY(ctx->b_vals0.ensure(64));
+  const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0;
+  rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->rp_ctl.p, 0, sizeof(rp::Ctl), s));
   StrictArgs a{};
   a.m = m;
   a.e = e;
@@ -444,11 +630,21 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   a.list_slots = ctx->b_rank.as<uint32_t>();
   a.n_list = (uint32_t)n;
   a.arena = ctx->b_keys0.as<uint32_t>();
-  a.free_stack = ctx->b_keys1.as<uint32_t>();
+  a.chunk_tab = ctx->rp_chunk_tab.as<uint32_t>();
   a.n_chunks = (uint32_t)std::min<size_t>(n_chunks, 0xFFFFFFF0u);
+  a.rctl = ctx->rp_ctl.as<rp::Ctl>();
+  a.stop_before_open = replay ? 1 : 0;
   a.stats = ctx->b_vals0.as<unsigned long long>();
   a.max_pops = 1ull << 40;
   KLAUNCH(k_esdf_strict, dim3(1), dim3(64), 0, s, a);
+  unsigned long long rp_pops = 0, rp_relax = 0;
+  if (replay) {
+    // processOpenSet: the parallel replay over the queue the kernel above filled
+    KLAUNCH(k_rp_nbslot, grid_for((size_t)used * 27), dim3(256), 0, s, m, used, ctx->rp_nbslot.as<uint32_t>());
+    const rp::Args ra = rp_args(ctx, cfg, e, a.n_chunks);
+    rc = rp_run(ctx, ra, &rp_pops, &rp_relax);
+    if (rc) return rc;
+  }
   if (clear_updated_flag && !batch && !list && n)
     KLAUNCH(k_esdf_strict_clear_tsdf_bit, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n);
   tmark(ctx, 7);
@@ -464,8 +660,8 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     return VBX_ERR_HIP;
   }
   ctx->counters.esdf_blocks = st[6];
-  ctx->counters.esdf_relaxations = st[5];
-  ctx->counters.esdf_sweeps = st[4] + st[3];  // queue pops (open + raise) take the place of sweeps
+  ctx->counters.esdf_relaxations = st[5] + rp_relax;
+  ctx->counters.esdf_sweeps = st[4] + st[3] + rp_pops;  // queue pops (open + raise) take the place of sweeps
   if (ctx->timing) {
     (void)hipEventSynchronize(ctx->ev[7]);
     vbx_timing& o = ctx->last_timing;

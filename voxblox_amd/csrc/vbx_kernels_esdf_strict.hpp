@@ -14,9 +14,12 @@
 // (LUT order within a pop, voxel order within a block).  It is a sequential algorithm run at one wave's speed —
 // the opt-in for callers who need the reference's bits, not the fast path.
 //
-// Queues: chunked FIFOs of voxel ids (pool slot * vps^3 + linear index) in one arena; queue number_of_buckets is
-// raise_, 0 .. num_buckets - 1 are the buckets of open_.  A chunk is kSqChunk words: word 0 = next chunk, the rest
-// entries; emptied chunks go back on a free stack, so the arena holds what is queued at one time.
+// Queues: FIFOs of voxel ids (pool slot * vps^3 + linear index) in the chunked arena the parallel replay uses
+// (vbx_esdf_replay_core.hpp: a FIFO index i of queue q lives in arena[chunk_tab[q][i / 1024] * 1024 + i % 1024], chunks
+// are handed out by a bump counter and never reused inside an update); queue num_buckets is raise_, 0 .. num_buckets - 1
+// are the buckets of open_.  With stop_before_open this kernel runs updateFromTsdfBlocks' voxel loop and
+// processRaiseSet only and leaves open_ to the replay; otherwise it also pops open_ one voxel at a time (the round-3
+// form, kept for A/B checks: VBX_ESDF_REPLAY=0).
 
 namespace {
 constexpr uint32_t kSqChunk = 1024;
@@ -35,8 +38,10 @@ struct StrictArgs {
   const uint32_t* list_slots;  // pool slots of the listed TSDF blocks in visiting order (kInvalidSlot: no such TSDF block)
   uint32_t n_list;
   uint32_t* arena;
-  uint32_t* free_stack;
+  uint32_t* chunk_tab;     // [num_buckets + 1][n_chunks]
   uint32_t n_chunks;
+  rp::Ctl* rctl;           // the replay's control block: FIFO heads / tails are handed over here
+  int stop_before_open;
   unsigned long long* stats;  // [0] lower [1] raise [2] new [3] raised pops [4] open pops [5] relaxations [6] blocks [7] error
   unsigned long long max_pops;
 };
@@ -49,73 +54,35 @@ __device__ inline void drain_stores() { __builtin_amdgcn_fence(__ATOMIC_RELEASE,
 
 struct StrictQueues {
   // wave-uniform state in LDS (every lane writes the same value; reads are broadcasts)
-  volatile uint32_t head_chunk[kStrictMaxBuckets + 1], head_pos[kStrictMaxBuckets + 1];
-  volatile uint32_t tail_chunk[kStrictMaxBuckets + 1], tail_pos[kStrictMaxBuckets + 1];
-  volatile uint32_t count[kStrictMaxBuckets + 1];
-  volatile uint32_t free_top, bump, err;
+  volatile uint32_t head[kStrictMaxBuckets + 1], tail[kStrictMaxBuckets + 1];            // FIFO indices
+  volatile uint32_t head_chunk[kStrictMaxBuckets + 1], tail_chunk[kStrictMaxBuckets + 1];  // arena chunk of head / tail - 1
+  volatile uint32_t bump, err;
   volatile int last_bucket;           // BucketQueue::last_bucket_index_
   volatile unsigned long long n_open;  // BucketQueue::num_elements_
 };
 
-__device__ inline uint32_t sq_alloc(StrictQueues& q, const StrictArgs& a) {
-  uint32_t c;
-  if (q.free_top > 0) {
-    const uint32_t t = q.free_top - 1;
-    c = ld_u32(&a.free_stack[t]);
-    q.free_top = t;
-  } else if (q.bump < a.n_chunks) {
-    c = q.bump;
-    q.bump = c + 1;
-  } else {
-    q.err = 1;  // arena exhausted: the entry is dropped, the host reports VBX_ERR_CAPACITY
-    c = 0;
-  }
-  return c;
-}
-__device__ inline void sq_free(StrictQueues& q, const StrictArgs& a, uint32_t c) {
-  const uint32_t t = q.free_top;
-  if ((threadIdx.x & 63) == 0) a.free_stack[t] = c;
-  q.free_top = t + 1;
-  drain_stores();
-}
 // wave-uniform push / pop (every lane calls with the same arguments)
 __device__ inline void sq_push(StrictQueues& q, const StrictArgs& a, int qi, uint32_t gid) {
   if (q.err) return;
-  if (q.tail_chunk[qi] == kSqNone) {
-    const uint32_t c = sq_alloc(q, a);
-    q.head_chunk[qi] = c; q.tail_chunk[qi] = c;
-    q.head_pos[qi] = 1; q.tail_pos[qi] = 1;
-  } else if (q.tail_pos[qi] == kSqChunk) {
-    const uint32_t c = sq_alloc(q, a);
-    if ((threadIdx.x & 63) == 0) a.arena[(size_t)q.tail_chunk[qi] * kSqChunk] = c;
+  const uint32_t idx = q.tail[qi];
+  if ((idx % kSqChunk) == 0) {
+    if (q.bump >= a.n_chunks) { q.err = 1; return; }  // arena exhausted: the entry is dropped, the host reports VBX_ERR_CAPACITY
+    const uint32_t c = q.bump;
+    q.bump = c + 1;
+    if ((threadIdx.x & 63) == 0) a.chunk_tab[(size_t)qi * a.n_chunks + idx / kSqChunk] = c;
     q.tail_chunk[qi] = c;
-    q.tail_pos[qi] = 1;
+    if (idx == q.head[qi]) q.head_chunk[qi] = c;
   }
-  if (q.err) return;
-  const uint32_t p = q.tail_pos[qi];
-  if ((threadIdx.x & 63) == 0) a.arena[(size_t)q.tail_chunk[qi] * kSqChunk + p] = gid;
-  q.tail_pos[qi] = p + 1;
-  q.count[qi] = q.count[qi] + 1;
+  if ((threadIdx.x & 63) == 0) a.arena[(size_t)q.tail_chunk[qi] * kSqChunk + idx % kSqChunk] = gid;
+  q.tail[qi] = idx + 1;
 }
+__device__ inline uint32_t sq_count(const StrictQueues& q, int qi) { return q.tail[qi] - q.head[qi]; }
 __device__ inline uint32_t sq_pop(StrictQueues& q, const StrictArgs& a, int qi) {
   drain_stores();
-  if (q.head_pos[qi] == kSqChunk) {
-    const uint32_t old = q.head_chunk[qi];
-    const uint32_t next = ld_u32(&a.arena[(size_t)old * kSqChunk]);
-    sq_free(q, a, old);
-    q.head_chunk[qi] = next;
-    q.head_pos[qi] = 1;
-  }
-  const uint32_t p = q.head_pos[qi];
-  const uint32_t gid = ld_u32(&a.arena[(size_t)q.head_chunk[qi] * kSqChunk + p]);
-  q.head_pos[qi] = p + 1;
-  const uint32_t n = q.count[qi] - 1;
-  q.count[qi] = n;
-  if (n == 0) {
-    sq_free(q, a, q.head_chunk[qi]);
-    q.head_chunk[qi] = kSqNone;
-    q.tail_chunk[qi] = kSqNone;
-  }
+  const uint32_t idx = q.head[qi];
+  if ((idx % kSqChunk) == 0 && idx != 0) q.head_chunk[qi] = ld_u32(&a.chunk_tab[(size_t)qi * a.n_chunks + idx / kSqChunk]);
+  const uint32_t gid = ld_u32(&a.arena[(size_t)q.head_chunk[qi] * kSqChunk + idx % kSqChunk]);
+  q.head[qi] = idx + 1;
   return gid;
 }
 // BucketQueue::push (bucket_queue.h:41-56): the bucket of a value
@@ -137,7 +104,7 @@ __device__ inline void open_push(StrictQueues& q, const StrictArgs& a, uint32_t 
 // BucketQueue::front + pop (:58-80)
 __device__ inline uint32_t open_pop(StrictQueues& q, const StrictArgs& a) {
   int lb = q.last_bucket;
-  while (lb < a.num_buckets && q.count[lb] == 0) ++lb;
+  while (lb < a.num_buckets && sq_count(q, lb) == 0) ++lb;
   q.last_bucket = lb;
   q.n_open = q.n_open - 1;
   return sq_pop(q, a, lb);
@@ -188,9 +155,9 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   const int lane = threadIdx.x & 63;
   const int RQ = a.num_buckets;  // the raise queue's slot
   for (int i = lane; i <= a.num_buckets; i += 64) {
-    q.head_chunk[i] = kSqNone; q.tail_chunk[i] = kSqNone; q.head_pos[i] = 1; q.tail_pos[i] = 1; q.count[i] = 0;
+    q.head[i] = 0; q.tail[i] = 0; q.head_chunk[i] = 0; q.tail_chunk[i] = 0;
   }
-  q.free_top = 0; q.bump = 0; q.err = 0; q.last_bucket = 0; q.n_open = 0;
+  q.bump = 0; q.err = 0; q.last_bucket = 0; q.n_open = 0;
   __syncthreads();
   const MapDev& m = a.m;
   const EsdfDev& e = a.e;
@@ -330,7 +297,7 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   }
 
   // ---- processRaiseSet, :305-369 -----------------------------------------------------------------------
-  while (q.count[RQ] != 0 && !q.err && n_raised + n_pops < a.max_pops) {
+  while (sq_count(q, RQ) != 0 && !q.err && n_raised + n_pops < a.max_pops) {
     const uint32_t g = sq_pop(q, a, RQ);
     const uint32_t slot = g / m.nvox, lin = g % m.nvox;
     const int lx = (int)(lin % vps), ly = (int)((lin / vps) % vps), lz = (int)(lin / (vps * vps));
@@ -375,8 +342,19 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
     ++n_raised;
   }
 
+  if (a.stop_before_open) {
+    // open_ goes to the parallel replay: FIFO indices and the arena's fill level into its control block
+    drain_stores();
+    for (int i = lane; i < a.num_buckets; i += 64) {
+      a.rctl->head[i] = q.head[i];
+      a.rctl->tail[i] = q.tail[i];
+      a.rctl->reserved[i] = (q.tail[i] + kSqChunk - 1) / kSqChunk;
+      a.rctl->k_cur[i] = 0;
+    }
+    if (lane == 0) a.rctl->chunk_top = q.bump;
+  }
   // ---- processOpenSet, :371-496 ------------------------------------------------------------------------
-  while (q.n_open != 0 && !q.err && n_raised + n_pops < a.max_pops) {
+  while (!a.stop_before_open && q.n_open != 0 && !q.err && n_raised + n_pops < a.max_pops) {
     const uint32_t g = open_pop(q, a);
     ++n_pops;
     uint32_t vs = ld_u32(&e.state[g]);
@@ -447,7 +425,7 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   if (lane == 0) {
     a.stats[0] = n_lower; a.stats[1] = n_raise; a.stats[2] = n_new; a.stats[3] = n_raised; a.stats[4] = n_pops;
     a.stats[5] = n_relax; a.stats[6] = n_blocks;
-    a.stats[7] = q.err ? 1ull : ((q.count[RQ] != 0 || q.n_open != 0) ? 2ull : 0ull);
+    a.stats[7] = q.err ? 1ull : ((sq_count(q, RQ) != 0 || (q.n_open != 0 && !a.stop_before_open)) ? 2ull : 0ull);
   }
 }
 
