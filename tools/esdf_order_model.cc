@@ -29,6 +29,7 @@
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
@@ -108,7 +109,7 @@ class ModelEsdf : public EsdfIntegrator {
     bq_.assign(config_.num_buckets, {});
     n_open_ = 0;
     classify(tsdf_blocks);
-    raiseSet();
+    if (mode != 2) raiseSet();   // (the emulated device code pops raise_ itself)
     if (mode == 0) openSet(); else if (mode == 1) openSetParallel(); else openSetEmul();
   }
 
@@ -559,7 +560,7 @@ class ModelEsdf : public EsdfIntegrator {
       return slot_of.at(b) * nvox + (uint32_t)(l.x + vps * (l.y + vps * l.z));
     };
     Args a{};
-    a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_;
+    a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;
     Ctl& c = emul_ctl;
@@ -574,6 +575,13 @@ class ModelEsdf : public EsdfIntegrator {
       for (size_t i = 0; i < bq_[b].size(); ++i) rp_queue_store(a, b, (uint32_t)i, gidOf(bq_[b][i]));
       c.tail[b] = (uint32_t)bq_[b].size();
       bq_[b].clear();
+    }
+    {
+      const int RQ = config_.num_buckets;
+      rp_queue_reserve(a, RQ, (uint32_t)raise_q_.size());
+      for (size_t i = 0; i < raise_q_.size(); ++i) rp_queue_store(a, RQ, (uint32_t)i, gidOf(raise_q_[i]));
+      c.tail[RQ] = (uint32_t)raise_q_.size();
+      raise_q_.clear();
     }
     n_open_ = 0;
     const uint32_t rec_cap = a.c.kmax * 8 + 65536, tgt_cap = rec_cap * 4;
@@ -628,6 +636,7 @@ class ModelEsdf : public EsdfIntegrator {
             case PH_COMMIT_FOLD: rp_phase_commit_fold(a, tid); break;
             case PH_RANK_WRITE: rp_phase_rank_write(a, tid); break;
             case PH_CLEANUP: rp_phase_cleanup(a, tid); break;
+            case PH_RAISE_FOLD: rp_phase_raise_fold(a, tid); break;
             default: std::fprintf(stderr, "bad phase %u\n", c.phase); std::abort();
           }
         }
@@ -816,12 +825,12 @@ long eom_update_parallel(void* h, size_t kmax, size_t smax, int max_iters) {
   }
   if (m->e2->mode == 2) {
     const rp::Ctl& c = m->e2->emul_ctl;
-    std::printf("  emul: pops %llu relax %llu supersteps %llu iters %llu folds %llu exc %llu cuts(iters %llu smax %llu) steps %llu error %u | voxels %ld DIFF %ld\n",
-                c.st_pops, c.st_relax, c.st_supersteps, c.st_iters, c.st_folds, c.st_exc, c.st_cut_iters, c.st_cut_smax, c.st_steps, c.error, n, diff);
-    static const char* names[] = {"done", "begin", "place", "fold", "apply", "sim", "mincut", "cfold", "rank", "rwrite", "push", "cleanup"};
+    std::printf("  emul: raise pops %llu in %llu steps | pops %llu relax %llu supersteps %llu iters %llu folds %llu exc %llu cuts(iters %llu smax %llu) steps %llu error %u | voxels %ld DIFF %ld\n",
+                c.st_raise_pops, c.st_raise_steps, c.st_pops, c.st_relax, c.st_supersteps, c.st_iters, c.st_folds, c.st_exc, c.st_cut_iters, c.st_cut_smax, c.st_steps, c.error, n, diff);
+    static const char* names[] = {"done", "begin", "place", "fold", "apply", "sim", "mincut", "cfold", "rank", "rwrite", "push", "cleanup", "raise"};
     std::printf("  poison %llu trunc_q %llu trunc_rank %llu\n", c.st_poison, c.st_trunc_q, c.st_trunc_rank);
     std::printf("  steps:");
-    for (int k = 1; k < 12; ++k) std::printf(" %s %llu(%llu)", names[k], c.st_phase_steps[k], c.st_phase_threads[k]);
+    for (int k = 1; k < 13; ++k) std::printf(" %s %llu(%llu)", names[k], c.st_phase_steps[k], c.st_phase_threads[k]);
     std::printf("\n");
     return diff;
   }

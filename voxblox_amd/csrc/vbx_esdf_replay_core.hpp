@@ -60,13 +60,14 @@ enum Phase : uint32_t {
   PH_RANK_WRITE,   // thread per record
   PH_PUSH,         // SCAN over committed records in pop order, up to four buckets at a time: FIFO positions, entries written
   PH_CLEANUP,      // thread per target / record
+  PH_RAISE_FOLD,   // processRaiseSet: thread per target, one pass (no guessing: a raise pop reads nothing of its own voxel)
 };
 // A SCAN phase is collective and lives outside this file: for i = 0 .. n_threads - 1 in order, c = rp_scan_count(i),
 // rp_scan_apply(i, running sums), running sums += c; the totals go to Ctl::scan_tot.
 struct Cnt4 { uint32_t v[4]; };
 
 struct Cfg {
-  float max_distance, min_diff, voxel_size;
+  float max_distance, min_diff, voxel_size, default_distance;
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
 };
@@ -79,6 +80,7 @@ struct Ctl {
   uint32_t phase, done;
   uint32_t n_threads;                        // threads (items) the current phase needs
   uint32_t bucket, K, base_head;             // super-step: bucket b, base records, FIFO index of base record 0
+  uint32_t raise;                            // 1: the super-step pops raise_ (queue num_buckets) instead of a bucket of open_
   uint32_t n_rec, iter;
   uint32_t read;                             // dirty target lists: FOLD reads list `read`, marks go to 1 - read
   uint32_t a_chg, a_born, a_tgt;             // copies of n_chg / n_born / n_tgt as the last phase left them
@@ -100,8 +102,8 @@ struct Ctl {
   uint32_t push_cnt[kMaxBuckets + 1];        // pushes per bucket seen by COMMIT_FOLD (upper bound of what gets queued)
   uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
   // statistics
-  unsigned long long st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank;
-  unsigned long long st_phase_steps[16], st_phase_threads[16];
+  unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank;
+  unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16], t_prev;
 };
 
 struct Args {
@@ -153,6 +155,11 @@ struct Args {
   uint32_t* sub_slot;       // [kmax] slot + 1 of the base record's list in sub_list
   uint32_t* sub_list;       // [slots][smax] ranked records of the last ranking
   uint32_t* sub_slots_used;
+  // (device only, may be null) members of every excursion in birth order, for the wave-cooperative ranking
+  uint32_t* sub_mem;        // [slots][smax]
+  uint32_t* sub_mem_n;      // [kmax]
+  uint32_t* rec_local;      // [rec] 1 + index in its excursion's member list (0: the base record)
+  uint32_t* sub_restart;    // [kmax] smallest rank at which the excursion's structure changed since its last ranking
   unsigned long long* sim_q;  // [slots][smax] scratch of the ranking
   uint32_t sub_slots_cap;
   // commit
@@ -333,7 +340,6 @@ struct FoldEv {
   uint32_t code;  // record << 5 | lut
 };
 
-constexpr uint32_t kFast = 24;   // events a fold sorts in registers; longer lists are walked by repeated selection
 constexpr uint32_t kLp = 16;     // pushes below b one fold can see (one per pop of the voxel, plus one)
 
 RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool commit) {
@@ -343,16 +349,14 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
   const int b = (int)c.bucket;
   uint32_t n_all = a.tgt_cnt[t];
   if (n_all > kEv) n_all = kEv;
-  FoldEv ev[kFast];
+  FoldEv ev[kEv];
   uint32_t n = 0;
-  bool slow = false;
   for (uint32_t k = 0; k < n_all; ++k) {
     const uint32_t code = a.tgt_ev[(size_t)t * kEv + k];
     const uint32_t r = code >> 5;
     const uint32_t m = a.rec_meta[r];
     const unsigned long long T = a.rec_T[r];
     if (!rp_meta_live(m) || a.rec_poison[r] || !(T < limit)) continue;
-    if (n == kFast) { slow = true; break; }
     // insertion by T (events of one record on one target are unique, so are the T)
     uint32_t j = n++;
     while (j > 0 && ev[j - 1].T > T) { ev[j] = ev[j - 1]; --j; }
@@ -368,29 +372,8 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
   uint32_t lp_rec[kLp], lp_lb[kLp], lp_s[kLp];
   float lp_d[kLp];
   uint32_t n_lp = 0;
-  unsigned long long last_T = 0;
-  bool first = true;
-  for (uint32_t k = 0;; ++k) {
-    uint32_t code;
-    if (!slow) {
-      if (k >= n) break;
-      code = ev[k].code;
-    } else {
-      // the live event with the smallest T behind last_T
-      unsigned long long best = kNever;
-      code = 0;
-      for (uint32_t q = 0; q < n_all; ++q) {
-        const uint32_t cq = a.tgt_ev[(size_t)t * kEv + q];
-        const uint32_t rq = cq >> 5;
-        const unsigned long long T = a.rec_T[rq];
-        if (!(T < limit) || !(T < best) || (!first && !(T > last_T))) continue;
-        if (!rp_meta_live(a.rec_meta[rq]) || a.rec_poison[rq]) continue;
-        best = T; code = cq;
-      }
-      if (best == kNever) break;
-      last_T = best;
-      first = false;
-    }
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t code = ev[k].code;
     const uint32_t r = code >> 5, lut = code & 31;
     if (lut == kOwn) {
       // the pop: processOpenSet reads the voxel here (:381-392)
@@ -461,7 +444,7 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
       uint32_t bucket = rp_meta_bucket(m);
       for (uint32_t j = 0; j < n_lp; ++j)
         if (lp_rec[j] == a.rec_pusher[r] && (lp_lb[j] & 0xFF) == rp_meta_lut(m)) { found = true; bucket = lp_lb[j] >> 8; lp_rec[j] = kNone; }
-      mn = rp_meta(rp_meta_lut(m), bucket, found);
+      mn = rp_meta(rp_meta_lut(m), bucket, found) | (m & (1u << 18));
       if (mn != m) changed = true;
     }
     if (rp_meta_live(m) && a.rec_T[r] != kNever) {
@@ -488,6 +471,79 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// processRaiseSet (esdf_integrator.cc:305-369) for one generation of raise_: the target's events are the pops of its
+// neighbours in FIFO order; a pop whose direction is the voxel's parent resets and raises it, any other pop queues it in
+// open_ if it is not queued.  The popped voxel itself is not read, so one pass is exact.
+// ------------------------------------------------------------------------------------------------------------
+RP_FN bool rp_raise_event(const Cfg& c, float* d, uint32_t* s, int lut, bool* to_raise) {
+  if (!(*s & kObserved) || (*s & kFixed)) return false;          // :333-335
+  int dx, dy, dz, px, py, pz;
+  rp_lut_offset(lut, &dx, &dy, &dz);
+  rp_unpack_parent(*s, &px, &py, &pz);
+  bool is_parent = (px == -dx && py == -dy && pz == -dz);
+  if (c.full) {  // :340-348: the rounded normalised parent against the direction
+    const float n2 = (float)px * (float)px + ((float)py * (float)py + (float)pz * (float)pz);
+    float ux = (float)px, uy = (float)py, uz = (float)pz;
+    if (n2 > 0.f) {
+      const float nn = sqrtf(n2);
+      ux = ux / nn; uy = uy / nn; uz = uz / nn;
+    }
+    is_parent = ((int)roundf(ux) == -dx && (int)roundf(uy) == -dy && (int)roundf(uz) == -dz);
+  }
+  if (is_parent) {
+    *d = (float)rp_signum(*d) * c.default_distance;
+    *s &= 0xFFu;  // parent.setZero()
+    *to_raise = true;
+    return true;
+  }
+  if (!(*s & kInQueue)) {
+    *s |= kInQueue;
+    *to_raise = false;
+    return true;
+  }
+  return false;
+}
+
+RP_FN void rp_fold_raise(const Args& a, uint32_t t) {
+  Ctl& c = *a.ctl;
+  const uint32_t gid = a.tgt_gid[t];
+  if (gid == kNone) return;
+  uint32_t n_all = a.tgt_cnt[t];
+  if (n_all > kEv) n_all = kEv;
+  FoldEv ev[kEv];
+  uint32_t n = 0;
+  for (uint32_t k = 0; k < n_all; ++k) {
+    const uint32_t code = a.tgt_ev[(size_t)t * kEv + k];
+    if ((code & 31) == kOwn) continue;
+    const unsigned long long T = a.rec_T[code >> 5];
+    if (!(T < c.cut)) continue;   // (records behind an event-list overflow wait for the next super-step)
+    uint32_t j = n++;
+    while (j > 0 && ev[j - 1].T > T) { ev[j] = ev[j - 1]; --j; }
+    ev[j].T = T; ev[j].code = code;
+  }
+  const float d0 = a.dist[gid];
+  const uint32_t s0 = a.state[gid];
+  float d = d0;
+  uint32_t s = s0;
+  const int RQ = a.c.num_buckets;
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t r = ev[k].code >> 5, lut = ev[k].code & 31;
+    bool to_raise;
+    if (!rp_raise_event(a.c, &d, &s, (int)lut, &to_raise)) continue;
+    const int q = to_raise ? RQ : rp_bucket_of(a.c, d);
+    const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
+    atomicOr(&a.rec_push[w], (uint32_t)(q + 1) << sh);
+    atomicAdd(&c.push_cnt[q], 1u);
+  }
+  if (d != d0 || s != s0) {
+    a.dist[gid] = d;
+    a.state[gid] = s;
+    if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // phases
 // ------------------------------------------------------------------------------------------------------------
@@ -507,9 +563,11 @@ RP_FN void rp_phase_place_base(const Args& a, uint32_t tid) {
     a.rec_s[r] = a.state[gid];
     a.rec_d_n[r] = a.rec_d[r];
     a.rec_s_n[r] = a.rec_s[r];
+    a.ord[r] = r;   // (raise super-steps commit every record, in FIFO order)
     a.sub_dirty[r] = 0;
     a.sub_n[r] = 0;
     a.sub_slot[r] = 0;
+    if (a.sub_mem) { a.sub_mem_n[r] = 0; a.rec_local[r] = 0; a.sub_restart[r] = kNone; }
   }
   rp_place(a, r, gid, p);
 }
@@ -525,6 +583,11 @@ RP_FN void rp_phase_fold(const Args& a, uint32_t tid) {
 RP_FN void rp_mark_sub_dirty(const Args& a, uint32_t r) {
   Ctl& c = *a.ctl;
   const uint32_t base = a.rec_base[r];
+  if (a.sub_restart) {
+    // the excursion's pops up to r's stay as they are (an unranked r decides nothing yet: its children enter when it pops)
+    const unsigned long long T = a.rec_T[r];
+    if (T != kNever) atomicMin(&a.sub_restart[base], (uint32_t)(T & kRankMask));
+  }
   if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
 }
 
@@ -544,7 +607,10 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
       a.cp[atomicAdd(&c.n_cp, 1u)] = point;
       a.rec_d[r] = a.rec_d_n[r];
       a.rec_s[r] = a.rec_s_n[r];
-      a.rec_meta[r] = mn;
+      if (mn != m) {   // (bit 18 may be set by a birth in this very phase: change the other bits only)
+        atomicAnd(&a.rec_meta[r], (1u << 18));
+        atomicOr(&a.rec_meta[r], mn & ~(1u << 18));
+      }
     }
     rp_mark_dirty(a, a.rec_tgts[(size_t)r * 27 + p]);
     return;
@@ -568,6 +634,24 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     a.rec_kid[(size_t)pusher * 26 + lut] = r + 1;
     a.cp[atomicAdd(&c.n_cp, 1u)] = pusher;
     rp_mark_sub_dirty(a, pusher);
+    if (a.sub_mem) {
+      const uint32_t base = a.rec_base[pusher];
+      uint32_t slot = a.sub_slot[base];
+      if (slot == 0u) {
+        const uint32_t mine = atomicAdd(a.sub_slots_used, 1u) + 1u;
+        const uint32_t old = atomicCAS(&a.sub_slot[base], 0u, mine);
+        slot = old ? old : mine;
+      }
+      const uint32_t idx = atomicAdd(&a.sub_mem_n[base], 1u);
+      if (slot <= a.sub_slots_cap && idx < a.c.smax) {
+        a.sub_mem[(size_t)(slot - 1) * a.c.smax + idx] = r;
+        a.rec_local[r] = idx + 1;
+      } else {
+        // not in the list: the ranking stops where this record's pusher pops
+        a.rec_local[r] = 0;
+        atomicOr(&a.rec_meta[pusher], 1u << 18);
+      }
+    }
   }
   rp_place(a, r, gid, p);
 }
@@ -636,6 +720,11 @@ RP_FN void rp_phase_mincut(const Args& a, uint32_t tid) {
   atomicMin(&c.first_change, a.rec_T[a.cp[tid]]);
 }
 
+RP_FN void rp_phase_raise_fold(const Args& a, uint32_t tid) {
+  Ctl& c = *a.ctl;
+  if (tid >= c.a_tgt) return;
+  rp_fold_raise(a, tid);
+}
 RP_FN void rp_phase_commit_fold(const Args& a, uint32_t tid) {
   Ctl& c = *a.ctl;
   if (tid >= c.a_tgt) return;
@@ -725,9 +814,14 @@ RP_FN void rp_stop(Ctl& c) { c.phase = PH_DONE; c.done = 1; c.n_threads = 0; }
 
 RP_FN void rp_begin_superstep(const Args& a) {
   Ctl& c = *a.ctl;
-  int b = 0;
-  while (b < a.c.num_buckets && c.head[b] == c.tail[b]) ++b;
-  if (b == a.c.num_buckets) { rp_stop(c); return; }
+  int b = a.c.num_buckets;   // processRaiseSet runs to the end before processOpenSet starts (:293-298)
+  c.raise = 1;
+  if (c.head[b] == c.tail[b]) {
+    c.raise = 0;
+    b = 0;
+    while (b < a.c.num_buckets && c.head[b] == c.tail[b]) ++b;
+    if (b == a.c.num_buckets) { rp_stop(c); return; }
+  }
   c.bucket = (uint32_t)b;
   uint32_t K = c.tail[b] - c.head[b];
   if (c.k_cur[b] == 0 || c.k_cur[b] > a.c.kmax) c.k_cur[b] = a.c.kmax;
@@ -745,7 +839,7 @@ RP_FN void rp_begin_superstep(const Args& a) {
   c.smax_cut = kNever;
   c.cut = kNever;
   *a.sub_slots_used = 0;
-  ++c.st_supersteps;
+  if (c.raise) ++c.st_raise_steps; else ++c.st_supersteps;
   c.phase = PH_PLACE_BASE;
   c.n_threads = K * 27;
 }
@@ -773,7 +867,8 @@ RP_FN void rp_next_push_pass(const Args& a) {
   Ctl& c = *a.ctl;
   c.push_n = 0;
   int b = (int)c.push_next;
-  for (; b < a.c.num_buckets && c.push_n < 4; ++b) {
+  const int nq = a.c.num_buckets + (c.raise ? 1 : 0);
+  for (; b < nq && c.push_n < 4; ++b) {
     const uint32_t bound = RP_LD(c.push_cnt[b]);
     if (bound == 0) continue;
     if (!rp_queue_reserve(a, b, bound)) { rp_stop(c); return; }
@@ -800,6 +895,17 @@ RP_FN void rp_control(const Args& a) {
       rp_begin_superstep(a);
       break;
     case PH_PLACE_BASE:
+      if (c.raise) {
+        c.a_tgt = RP_LD(c.n_tgt);
+        const uint32_t kl = RP_LD(c.k_limit);
+        if (kl == 0) { c.error |= 16u; rp_stop(c); break; }
+        if (kl != kNone) c.cut = (unsigned long long)kl << kRankBits;   // an event list overflowed: the records behind wait
+        for (int k = 0; k <= a.c.num_buckets; ++k) c.push_cnt[k] = 0;
+        c.phase = PH_RAISE_FOLD;
+        c.n_threads = c.a_tgt;
+        break;
+      }
+      // fall through
     case PH_SIM:
     case PH_APPLY: {
       const uint32_t n_cp = RP_LD(c.n_cp);
@@ -836,6 +942,11 @@ RP_FN void rp_control(const Args& a) {
     case PH_MINCUT:
       rp_start_commit(a);
       break;
+    case PH_RAISE_FOLD:
+      c.n_commit = c.cut == kNever ? c.K : (uint32_t)(c.cut >> kRankBits);
+      c.push_next = 0;
+      rp_next_push_pass(a);
+      break;
     case PH_COMMIT_FOLD:
       c.phase = PH_RANK;
       c.n_threads = c.K;
@@ -859,9 +970,10 @@ RP_FN void rp_control(const Args& a) {
       if (c.cut == kNever || nb > c.K) nb = c.K;
       else if ((c.cut & kRankMask) != 0) nb += 1;   // the cut lies inside base record nb's excursion: it has popped
       c.head[c.bucket] += nb;
-      c.st_pops += c.n_commit;
+      if (c.raise) c.st_raise_pops += c.n_commit; else c.st_pops += c.n_commit;
       // a cut throws the work behind it away: take about as much as got through next time, ramp up after clean steps
-      if (c.cut != kNever) c.k_cur[c.bucket] = nb * 2 > 32 ? nb * 2 : 32;
+      if (c.raise) { /* raise super-steps never cut */ }
+      else if (c.cut != kNever) c.k_cur[c.bucket] = nb * 2 > 32 ? nb * 2 : 32;
       else c.k_cur[c.bucket] = c.k_cur[c.bucket] * 4 > a.c.kmax ? a.c.kmax : c.k_cur[c.bucket] * 4;
       rp_begin_superstep(a);
       break;

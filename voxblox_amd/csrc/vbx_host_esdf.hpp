@@ -372,7 +372,7 @@ static uint32_t rp_env_u32(const char* name, uint32_t dflt) {
 int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used) {
   hipStream_t s = ctx->stream;
   const MapDev& m = ctx->map;
-  const uint32_t kmax = rp_env_u32("VBX_RP_KMAX", 16384), smax = rp_env_u32("VBX_RP_SMAX", 256);
+  const uint32_t kmax = rp_env_u32("VBX_RP_KMAX", 16384), smax = std::min<uint32_t>(rp_env_u32("VBX_RP_SMAX", 1024), kSimMax);
   const uint32_t rec_cap = kmax * 8 + 65536, tgt_cap = rec_cap * 3;
   const bool fresh = !ctx->rp_ctl.p;
   HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl)));
@@ -388,8 +388,8 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(ctx->rp_tgt_ev.ensure((size_t)tgt_cap * rp::kEv * 4));
     HIP_TRY(ctx->rp_dl.ensure((size_t)tgt_cap * 4 * 2));
     HIP_TRY(ctx->rp_lists.ensure((size_t)rec_cap * 4 * (1 + 6 + 2) + (size_t)kmax * 4));
-    HIP_TRY(ctx->rp_sub.ensure((size_t)kmax * 4 * 4 + 64));
-    const uint32_t sub_slots = 8192;
+    HIP_TRY(ctx->rp_sub.ensure((size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4));
+    const uint32_t sub_slots = 4096;
     HIP_TRY(ctx->rp_sub_list.ensure((size_t)sub_slots * smax * 4));
     HIP_TRY(ctx->rp_sim_q.ensure((size_t)sub_slots * smax * 8));
     HIP_TRY(ctx->rp_ord.ensure((size_t)rec_cap * 4));
@@ -399,7 +399,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_kid.p, 0, (size_t)rec_cap * 26 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_push.p, 0, (size_t)rec_cap * 7 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0, (size_t)tgt_cap * 4 * 3, s));
-    HIP_TRY(hipMemsetAsync(ctx->rp_sub.p, 0, (size_t)kmax * 4 * 4 + 64, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_sub.p, 0, (size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_scan_desc.p, 0, ctx->rp_scan_desc.cap, s));
     ctx->rp_rec_cap = rec_cap;
     ctx->rp_tgt_cap = tgt_cap;
@@ -425,6 +425,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.c.max_distance = cfg->max_distance_m;
   a.c.min_diff = cfg->min_diff_m;
   a.c.voxel_size = m.voxel_size;
+  a.c.default_distance = cfg->default_distance_m;
   a.c.full = cfg->full_euclidean_distance != 0;
   a.c.multi_queue = cfg->multi_queue != 0;
   a.c.num_buckets = cfg->num_buckets;
@@ -463,9 +464,13 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   uint32_t* su = ctx->rp_sub.as<uint32_t>();
   a.sub_dirty = su; a.sub_n = su + (size_t)K; a.sub_slot = su + (size_t)2 * K; a.off0 = su + (size_t)3 * K;
   a.sub_slots_used = su + (size_t)4 * K;
+  a.sub_mem_n = su + (size_t)4 * K + 16;
+  a.sub_restart = su + (size_t)5 * K + 16;
+  a.rec_local = su + (size_t)6 * K + 16;
+  a.sub_mem = ctx->rp_sub_list.as<uint32_t>();   // (the device ranks from the member lists; sub_list is the serial form's)
   a.sub_list = ctx->rp_sub_list.as<uint32_t>();
   a.sim_q = ctx->rp_sim_q.as<unsigned long long>();
-  a.sub_slots_cap = 8192;
+  a.sub_slots_cap = 4096;
   a.ord = ctx->rp_ord.as<uint32_t>();
   return a;
 }
@@ -521,11 +526,12 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   HIP_TRY(hipMemcpyAsync(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (getenv("VBX_RP_STATS")) {
-    static const char* names[] = {"done", "begin", "place", "fold", "apply", "sim", "mincut", "cfold", "rank", "rwrite", "push", "cleanup"};
+    static const char* names[] = {"done", "begin", "place", "fold", "apply", "sim", "mincut", "cfold", "rank", "rwrite", "push", "cleanup", "raise"};
+    fprintf(stderr, "[rp] raise pops %llu in %llu steps\n", hc.st_raise_pops, hc.st_raise_steps);
     fprintf(stderr, "[rp] pops %llu relax %llu supersteps %llu iters %llu folds %llu exc %llu cuts(iters %llu smax %llu) steps %llu poison %llu error %u\n[rp] steps:",
             hc.st_pops, hc.st_relax, hc.st_supersteps, hc.st_iters, hc.st_folds, hc.st_exc, hc.st_cut_iters, hc.st_cut_smax, hc.st_steps,
             hc.st_poison, hc.error);
-    for (int k = 1; k < 12; ++k) fprintf(stderr, " %s %llu(%llu)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k]);
+    for (int k = 1; k < 13; ++k) fprintf(stderr, " %s %llu(%llu, %.2f ms)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k], hc.st_phase_ticks[k] * 1e-5);
     fprintf(stderr, "\n");
   }
   if (!hc.done) {
@@ -536,7 +542,7 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
     ctx->fail("ESDF reference order: replay error 0x%x (1 records, 2 targets, 4 queue arena, 8 no progress, 16 event list at the first record, 64 scan wait)", hc.error);
     return (hc.error & ~(8u | 64u)) ? VBX_ERR_CAPACITY : VBX_ERR_HIP;
   }
-  *pops = hc.st_pops;
+  *pops = hc.st_pops + hc.st_raise_pops;
   *relax = hc.st_relax;
   return VBX_OK;
 }
@@ -608,7 +614,7 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   const size_t n_chunks = std::max<size_t>(1024, (size_t)(cfg->multi_queue ? 16 : 4) * nv / kSqChunk + (size_t)4 * cfg->num_buckets + 64);
   HIP_TRY(ctx->b_keys0.ensure(n_chunks * kSqChunk * 4));
   HIP_TRY(ctx->b_vals0.ensure(64));
-  const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0;
+  const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0 && cfg->num_buckets <= 254;   // (a push table entry is one byte: bucket + 1, raise_ = num_buckets)
   rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(ctx->rp_ctl.p, 0, sizeof(rp::Ctl), s));

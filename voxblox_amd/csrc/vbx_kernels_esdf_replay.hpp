@@ -53,6 +53,416 @@ __device__ inline void rp_run_phase(const rp::Args& a, uint32_t phase, uint32_t 
   }
 }
 
+// rp_fold (vbx_esdf_replay_core.hpp, the form the CPU emulation runs) as ONE WAVE per target: a lane holds up to two of
+// the target's events with their records' pop times and pop-time states, the order of the events is a rank computed by
+// comparing pop times across lanes, and the replay itself — inherently sequential, event by event — runs wave-uniformly
+// on broadcast values.  A thread-per-target fold kept its event list in scratch memory and a target of a crowded
+// neighbourhood (a hundred events) cost milliseconds of dependent scratch round trips; the launch waits for its
+// slowest target.
+__device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long long limit, bool commit, int lane) {
+  using namespace rp;
+  Ctl& c = *a.ctl;
+  const uint32_t gid = a.tgt_gid[t];
+  if (gid == kNone) return;
+  const int b = (int)c.bucket;
+  uint32_t n_all = a.tgt_cnt[t];
+  if (n_all > kEv) n_all = kEv;
+  uint32_t code[2] = {0, 0}, es[2] = {0, 0}, emeta[2] = {0, 0};
+  unsigned long long eT[2] = {kNever, kNever};
+  float ed[2] = {0.f, 0.f};
+  bool valid[2] = {false, false}, have[2] = {false, false}, epoison[2] = {false, false};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t e = (uint32_t)lane + 64u * q;
+    if (e < n_all) {
+      have[q] = true;
+      code[q] = a.tgt_ev[(size_t)t * kEv + e];
+      const uint32_t r = code[q] >> 5;
+      emeta[q] = a.rec_meta[r];
+      eT[q] = a.rec_T[r];
+      epoison[q] = a.rec_poison[r] != 0u;
+      ed[q] = a.rec_d[r];
+      es[q] = a.rec_s[r];
+      valid[q] = rp_meta_live(emeta[q]) && !epoison[q] && eT[q] < limit;
+    }
+  }
+  // rank of every valid event = valid events with a smaller pop time (pop times of valid events are distinct)
+  uint32_t rank[2] = {0, 0};
+  const int slots = n_all > 64 ? 2 : 1;
+  for (int q2 = 0; q2 < slots; ++q2) {
+    unsigned long long vm = __ballot(valid[q2]);
+    while (vm) {
+      const int k = __ffsll((long long)vm) - 1;
+      vm &= vm - 1;
+      const unsigned long long Tk = __shfl(eT[q2], k);
+      rank[0] += (Tk < eT[0]) ? 1u : 0u;
+      rank[1] += (Tk < eT[1]) ? 1u : 0u;
+    }
+  }
+  const uint32_t n = (uint32_t)__popcll(__ballot(valid[0])) + (uint32_t)__popcll(__ballot(valid[1]));
+  const float d0 = a.dist[gid];
+  const uint32_t s0 = a.state[gid];
+  float d = d0;
+  uint32_t s = s0;
+  const bool usable = (s0 & kObserved) && !(s0 & kFixed);
+  uint32_t relax = 0;
+  // pushes below b seen in this fold: the j-th lives in lane j
+  uint32_t lp_rec = kNone, lp_lb = 0, lp_s = 0;
+  float lp_d = 0.f;
+  uint32_t n_lp = 0;
+  bool pop_moved[2] = {false, false};
+  for (uint32_t i = 0; i < n; ++i) {
+    const unsigned long long m0 = __ballot(valid[0] && rank[0] == i);
+    const unsigned long long m1 = __ballot(valid[1] && rank[1] == i);
+    uint32_t ecode, evs;
+    float evd;
+    int src, sq;
+    if (m0) {
+      src = __ffsll((long long)m0) - 1; sq = 0;
+      ecode = __shfl(code[0], src); evd = __shfl(ed[0], src); evs = __shfl(es[0], src);
+    } else if (m1) {
+      src = __ffsll((long long)m1) - 1; sq = 1;
+      ecode = __shfl(code[1], src); evd = __shfl(ed[1], src); evs = __shfl(es[1], src);
+    } else {
+      break;  // (cannot happen: ranks of valid events are 0 .. n - 1)
+    }
+    const uint32_t r = ecode >> 5, lut = ecode & 31;
+    if (lut == kOwn) {
+      // the pop: processOpenSet reads the voxel here (:381-392)
+      if (!commit) {
+        if (lane == 0) {
+          a.rec_d_n[r] = d;
+          a.rec_s_n[r] = s;
+        }
+        // did the record's pop-time state move? (kept by the lane that holds the event)
+        if (lane == src && (__float_as_uint(d) != __float_as_uint(evd) || s != evs)) pop_moved[sq] = true;
+      }
+      s &= ~kInQueue;                                            // :386
+      continue;
+    }
+    if (!(evs & kObserved) || evd >= a.c.max_distance || evd <= -a.c.max_distance) continue;  // :389-392
+    if (!usable) continue;                                       // :414-417
+    float nd;
+    uint32_t np;
+    if (!rp_relax(a.c, evd, evs, d, (int)lut, &nd, &np)) continue;
+    ++relax;
+    d = nd;
+    s = (s & 0xFFu) | np;
+    if (a.c.multi_queue || !(s & kInQueue)) {
+      s |= kInQueue;
+      const int nb = rp_bucket_of(a.c, nd);
+      if (commit) {
+        if (lane == 0) {
+          const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
+          atomicOr(&a.rec_push[w], (uint32_t)(nb + 1) << sh);
+          atomicAdd(&c.push_cnt[nb], 1u);
+        }
+      } else if (nb < b) {
+        if (n_lp == 64) {
+          // no room to describe this push: the pushing record leaves the super-step (the cut falls in front of it)
+          if (lane == 0 && atomicExch(&a.rec_poison[r], 1u) == 0u) {
+            atomicAdd(&c.st_poison, 1ull);
+            if (r < c.K) atomicMin(&c.k_limit, r);
+            const uint32_t base = a.rec_base[r];
+            const unsigned long long Tr = a.rec_T[r];
+            if (Tr != kNever && (Tr & kRankMask) != 0) atomicMin(&a.sub_restart[base], (uint32_t)(Tr & kRankMask) - 1u);
+            if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
+            a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+          }
+          continue;
+        }
+        if ((uint32_t)lane == n_lp) { lp_rec = r; lp_lb = lut | ((uint32_t)nb << 8); lp_d = d; lp_s = s; }
+        ++n_lp;
+      }
+    }
+  }
+  if (commit) {
+    if (lane == 0) {
+      if (d != d0 || s != s0) {
+        a.dist[gid] = d;
+        a.state[gid] = s;
+        if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+      }
+      if (relax) atomicAdd(&c.st_relax, (unsigned long long)relax);
+    }
+    return;
+  }
+  // ---- outputs of an iteration: the records on this voxel (their own-pop events, dead or alive)
+  bool own[2], chg[2] = {false, false};
+  uint32_t mn[2] = {0, 0}, pusher[2] = {kNone, kNone};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    own[q] = have[q] && (code[q] & 31) == kOwn && !epoison[q];
+    mn[q] = emeta[q];
+    if (own[q]) pusher[q] = a.rec_pusher[code[q] >> 5];
+  }
+  unsigned long long matched = 0;  // push j was matched by a record of mine
+  bool found[2] = {false, false};
+  uint32_t fbucket[2] = {rp_meta_bucket(emeta[0]), rp_meta_bucket(emeta[1])};
+  for (uint32_t j = 0; j < n_lp; ++j) {
+    const uint32_t lr = __shfl(lp_rec, (int)j), llb = __shfl(lp_lb, (int)j);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (own[q] && pusher[q] != kNone && lr == pusher[q] && (llb & 0xFF) == rp_meta_lut(emeta[q])) {
+        found[q] = true; fbucket[q] = llb >> 8; matched |= 1ull << j;
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (!own[q]) continue;
+    const uint32_t r = code[q] >> 5;
+    if (pusher[q] != kNone) {
+      // an excursion record lives iff this fold pushed it below b
+      mn[q] = rp_meta(rp_meta_lut(emeta[q]), fbucket[q], found[q]) | (emeta[q] & (1u << 18));
+      if (mn[q] != emeta[q]) chg[q] = true;
+    }
+    if (rp_meta_live(emeta[q]) && eT[q] != kNever) {
+      if (pop_moved[q]) chg[q] = true;   // it popped in this fold (lane 0 wrote its pop-time state)
+    } else {
+      a.rec_d_n[r] = ed[q];
+      a.rec_s_n[r] = es[q];
+    }
+    a.rec_meta_n[r] = mn[q];
+    if (chg[q]) a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+  }
+  // pushes below b that no record stands for yet
+  unsigned long long any_matched = 0;
+  for (uint32_t j = 0; j < n_lp; ++j)
+    if (__ballot((matched >> j) & 1ull)) any_matched |= 1ull << j;
+  if ((uint32_t)lane < n_lp && !((any_matched >> lane) & 1ull)) {
+    if (a.rec_kid[(size_t)lp_rec * 26 + (lp_lb & 0xFF)] == 0u) {
+      const uint32_t k = atomicAdd(&c.n_born, 1u);
+      a.born[(size_t)k * 6 + 0] = lp_rec;
+      a.born[(size_t)k * 6 + 1] = lp_lb & 0xFF;
+      a.born[(size_t)k * 6 + 2] = lp_lb >> 8;
+      a.born[(size_t)k * 6 + 3] = gid;
+      a.born[(size_t)k * 6 + 4] = __float_as_uint(lp_d);
+      a.born[(size_t)k * 6 + 5] = lp_s;
+    }
+  }
+}
+
+// rp_fold_raise as one wave per target (same layout as rp_fold_wave)
+__device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lane) {
+  using namespace rp;
+  Ctl& c = *a.ctl;
+  const uint32_t gid = a.tgt_gid[t];
+  if (gid == kNone) return;
+  uint32_t n_all = a.tgt_cnt[t];
+  if (n_all > kEv) n_all = kEv;
+  uint32_t code[2] = {0, 0};
+  unsigned long long eT[2] = {kNever, kNever};
+  bool valid[2] = {false, false};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t e = (uint32_t)lane + 64u * q;
+    if (e < n_all) {
+      code[q] = a.tgt_ev[(size_t)t * kEv + e];
+      eT[q] = a.rec_T[code[q] >> 5];
+      valid[q] = (code[q] & 31) != kOwn && eT[q] < c.cut;
+    }
+  }
+  uint32_t rank[2] = {0, 0};
+  const int slots = n_all > 64 ? 2 : 1;
+  for (int q2 = 0; q2 < slots; ++q2) {
+    unsigned long long vm = __ballot(valid[q2]);
+    while (vm) {
+      const int k = __ffsll((long long)vm) - 1;
+      vm &= vm - 1;
+      const unsigned long long Tk = __shfl(eT[q2], k);
+      rank[0] += (Tk < eT[0]) ? 1u : 0u;
+      rank[1] += (Tk < eT[1]) ? 1u : 0u;
+    }
+  }
+  const uint32_t n = (uint32_t)__popcll(__ballot(valid[0])) + (uint32_t)__popcll(__ballot(valid[1]));
+  const float d0 = a.dist[gid];
+  const uint32_t s0 = a.state[gid];
+  float d = d0;
+  uint32_t s = s0;
+  const int RQ = a.c.num_buckets;
+  for (uint32_t i = 0; i < n; ++i) {
+    const unsigned long long m0 = __ballot(valid[0] && rank[0] == i);
+    const unsigned long long m1 = __ballot(valid[1] && rank[1] == i);
+    uint32_t ecode;
+    if (m0) ecode = __shfl(code[0], __ffsll((long long)m0) - 1);
+    else if (m1) ecode = __shfl(code[1], __ffsll((long long)m1) - 1);
+    else break;
+    const uint32_t r = ecode >> 5, lut = ecode & 31;
+    bool to_raise;
+    if (!rp_raise_event(a.c, &d, &s, (int)lut, &to_raise)) continue;
+    if (lane == 0) {
+      const int q = to_raise ? RQ : rp_bucket_of(a.c, d);
+      const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
+      atomicOr(&a.rec_push[w], (uint32_t)(q + 1) << sh);
+      atomicAdd(&c.push_cnt[q], 1u);
+    }
+  }
+  if (lane == 0 && (d != d0 || s != s0)) {
+    a.dist[gid] = d;
+    a.state[gid] = s;
+    if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+  }
+}
+
+// PH_SIM on the device: one workgroup per excursion.  The excursion's records (member list kept by PH_APPLY) are loaded
+// into LDS in parallel — per record its pusher's position in the list, LUT index, bucket, liveness, its rank of the last
+// ranking — and the queue discipline (rp_phase_sim, the serial form the CPU emulation runs) is replayed by wave 0 on LDS
+// only: a pop costs a few hundred cycles instead of two dependent trips to L2.  The replay does not start from the base
+// record: PH_APPLY keeps, per excursion, the smallest rank at which something changed (a child that appeared, died or
+// moved to another bucket: Args::sub_restart); the pops up to that rank are as they were, the queue content at that point
+// is rebuilt from the ranks (every live record whose pusher has popped and that has not popped itself, in arrival order =
+// (pusher's rank, LUT index) per bucket) and only the pops behind it are replayed.  An excursion grows at its far end,
+// so a ranking costs what changed, not what exists.
+constexpr uint32_t kSimMax = 1024;   // records of one excursion the ranking handles (Cfg::smax <= this)
+struct SimLds {
+  unsigned short child[(kSimMax + 1) * 26];   // [position in the member list + 1 (0: the base record)][lut] -> member
+  uint32_t info[kSimMax];                     // lut | bucket << 8 | live << 16 | poisoned << 17 | has an unlisted child << 18
+  unsigned short next[kSimMax], rank[kSimMax];
+  uint32_t pend_key[kSimMax];                 // pending records at the restart point: bucket << 24 | pusher rank << 5 | lut
+  unsigned short pend_j[kSimMax], sorted[kSimMax];
+  unsigned short head[rp::kMaxBuckets + 1], tail[rp::kMaxBuckets + 1];
+  uint32_t n_pend, flag_rank, n_ranked, truncated;
+};
+__device__ inline void rp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L) {
+  rp::Ctl& c = *a.ctl;
+  const uint32_t smax = a.c.smax;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  const uint32_t slot = a.sub_slot[base];
+  uint32_t n = (slot != 0u && slot <= a.sub_slots_cap) ? a.sub_mem_n[base] : 0u;
+  if (n > smax) n = smax;
+  const uint32_t* mem = a.sub_mem + (size_t)(slot ? slot - 1 : 0) * smax;
+  const int nb = (int)c.bucket;
+  uint32_t p = a.sub_restart[base];          // ranks <= p stand
+  const uint32_t old_n = a.sub_n[base];
+  if (p > old_n) p = old_n;
+  __syncthreads();
+  for (uint32_t i = tid; i < (n + 1) * 26; i += kRpThreads) L.child[i] = 0xFFFF;
+  for (int i = tid; i < nb; i += kRpThreads) { L.head[i] = 0xFFFF; L.tail[i] = 0xFFFF; }
+  if (tid == 0) { L.n_pend = 0; L.flag_rank = 0xFFFFFFFFu; }
+  __syncthreads();
+  const uint32_t base_meta = a.rec_meta[base];
+  if (tid == 0 && (base_meta & (1u << 18))) L.flag_rank = 0;
+  // pass 1: records, their old ranks, the child table
+  for (uint32_t j = tid; j < n; j += kRpThreads) {
+    const uint32_t r = mem[j];
+    const uint32_t m = a.rec_meta[r];
+    const uint32_t pl = a.rec_local[a.rec_pusher[r]];
+    const unsigned long long T = a.rec_T[r];
+    uint32_t rk = 0xFFFF;
+    if (T != rp::kNever && (uint32_t)(T & rp::kRankMask) <= p) rk = (uint32_t)(T & rp::kRankMask);   // it popped in front of the restart point
+    L.info[j] = (m & 0x1FFFFu) | (a.rec_poison[r] ? (1u << 17) : 0u) | (m & (1u << 18)) | (pl << 19);
+    L.rank[j] = (unsigned short)rk;
+    if (rp::rp_meta_live(m)) L.child[pl * 26 + rp::rp_meta_lut(m)] = (unsigned short)j;
+    if (rk != 0xFFFF && (m & (1u << 18))) atomicMin(&L.flag_rank, rk);   // ranked, but a child of it is not in the list
+  }
+  __syncthreads();
+  // a record with an unlisted child in front of the restart point: the ranking ends behind it
+  uint32_t R = p;
+  bool truncated = false;
+  if (L.flag_rank <= p) { R = L.flag_rank; truncated = true; }
+  __syncthreads();
+  // pass 2: the queue at the restart point
+  if (!truncated) {
+    for (uint32_t j = tid; j < n; j += kRpThreads) {
+      const uint32_t inf = L.info[j];
+      if (!((inf >> 16) & 1u)) continue;                      // dead
+      if (L.rank[j] != 0xFFFF) continue;                      // popped already
+      const uint32_t pl = inf >> 19;
+      const uint32_t pr = pl == 0 ? 0u : (uint32_t)L.rank[pl - 1];
+      if (pl != 0 && (pr == 0xFFFF)) continue;                // its pusher has not popped
+      const uint32_t k = atomicAdd(&L.n_pend, 1u);
+      L.pend_key[k] = (((inf >> 8) & 0xFF) << 24) | (pr << 5) | (inf & 0x1F);
+      L.pend_j[k] = (unsigned short)j;
+    }
+  } else {
+    for (uint32_t j = tid; j < n; j += kRpThreads)
+      if (L.rank[j] != 0xFFFF && L.rank[j] > R) L.rank[j] = 0xFFFF;
+  }
+  __syncthreads();
+  const uint32_t P = L.n_pend;
+  for (uint32_t k = tid; k < P; k += kRpThreads) {
+    const uint32_t key = L.pend_key[k];
+    uint32_t pos = 0;
+    for (uint32_t q = 0; q < P; ++q) pos += (L.pend_key[q] < key) ? 1u : 0u;   // keys are distinct: (pusher, lut) is
+    L.sorted[pos] = L.pend_j[k];
+  }
+  __syncthreads();
+  for (uint32_t k = tid; k < P; k += kRpThreads) {
+    const uint32_t j = L.sorted[k];
+    const uint32_t kb = (L.info[j] >> 8) & 0xFF;
+    const bool first = k == 0 || ((L.info[L.sorted[k - 1]] >> 8) & 0xFF) != kb;
+    const bool last = k + 1 == P || ((L.info[L.sorted[k + 1]] >> 8) & 0xFF) != kb;
+    L.next[j] = last ? (unsigned short)0xFFFF : L.sorted[k + 1];
+    if (first) L.head[kb] = (unsigned short)j;
+    if (last) L.tail[kb] = (unsigned short)j;
+  }
+  __syncthreads();
+  if (tid < 64 && !truncated) {
+    // wave-uniform replay of the queue discipline from the restart point: every lane runs the same control flow, lanes
+    // 0..25 fetch the 26 child slots of a pop at once, the FIFO links are written by all lanes alike
+    uint32_t rank = R;
+    int lowest = 0;
+    for (;;) {
+      while (lowest < nb && L.head[lowest] == 0xFFFF) ++lowest;   // BucketQueue::front / pop
+      if (lowest >= nb) break;
+      const uint32_t j = L.head[lowest];
+      const uint32_t nx = L.next[j];
+      const uint32_t inf = L.info[j];
+      rp_wave_sync();
+      L.head[lowest] = (unsigned short)nx;
+      if (nx == 0xFFFF) L.tail[lowest] = 0xFFFF;
+      if (rank >= smax - 1 || (inf & (1u << 17))) { truncated = true; break; }
+      ++rank;
+      L.rank[j] = (unsigned short)rank;
+      rp_wave_sync();
+      if (inf & (1u << 18)) { truncated = true; break; }   // a child of it is not in the list: stop behind it
+      // its children enter their buckets in LUT order
+      uint32_t jv = 0xFFFF, jinfo = 0;
+      if (lane < 26) {
+        jv = L.child[(j + 1) * 26 + lane];
+        if (jv != 0xFFFF) jinfo = L.info[jv];
+      }
+      unsigned long long kids = __ballot(jv != 0xFFFF);
+      while (kids) {
+        const int src = __ffsll((long long)kids) - 1;
+        kids &= kids - 1;
+        const uint32_t cj = __shfl(jv, src);
+        const int kb = (int)((__shfl(jinfo, src) >> 8) & 0xFF);
+        const uint32_t tl = L.tail[kb];
+        L.next[cj] = 0xFFFF;
+        if (tl == 0xFFFF) L.head[kb] = (unsigned short)cj; else L.next[tl] = (unsigned short)cj;
+        L.tail[kb] = (unsigned short)cj;
+        if (kb < lowest) lowest = kb;
+        rp_wave_sync();
+      }
+    }
+    R = rank;
+  }
+  if (tid == 0) {
+    L.n_ranked = R;
+    L.truncated = truncated ? 1u : 0u;
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < n; j += kRpThreads) {
+    const uint32_t rk = L.rank[j];
+    a.rec_T[mem[j]] = rk == 0xFFFF ? rp::kNever : (((unsigned long long)base << rp::kRankBits) | rk);
+  }
+  if (tid == 0) {
+    a.sub_dirty[base] = 0;
+    a.sub_restart[base] = rp::kNone;
+    a.sub_n[base] = L.n_ranked;
+    if (L.truncated) {
+      atomicMin(&c.smax_cut, ((unsigned long long)base << rp::kRankBits) | (L.n_ranked + 1));
+      atomicAdd(&c.st_trunc_rank, 1ull);
+    }
+  }
+  __syncthreads();
+}
+
 // SCAN phase: tiles of kRpThreads items by ticket; exclusive prefix of the four counts per item
 __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32_t n) {
   __shared__ uint32_t s_tile;
@@ -132,29 +542,77 @@ __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32
 
 __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
   __shared__ uint32_t s_last;
+  __shared__ SimLds s_sim;
   rp::Ctl& c = *a.ctl;
   const uint32_t phase = c.phase;
   if (phase == rp::PH_DONE) return;
   const uint32_t n = c.n_threads;
+  // workgroups that have something to do (the others leave at once and are not waited for: 512 arrivals on one
+  // counter cost 6 us, a phase of a few hundred items should not pay for them)
+  const bool per_wave = phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD || phase == rp::PH_RAISE_FOLD;
+  const uint32_t unit = (phase == rp::PH_SIM && a.sub_mem) ? 1 : (per_wave ? kRpThreads / 64 : kRpThreads);
+  uint32_t active = (n + unit - 1) / unit;
+  if (active > gridDim.x) active = gridDim.x;
+  if (active == 0) active = 1;
+  if (blockIdx.x >= active) return;
   if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
     rp_scan_phase(a, sc, n);
+  } else if (phase == rp::PH_RAISE_FOLD) {
+    const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
+    for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves) rp_fold_raise_wave(a, w, threadIdx.x & 63);
+  } else if (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD) {
+    // one wave per target
+    const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves) {
+      if (phase == rp::PH_FOLD) {
+        const uint32_t t = a.dl[c.read][w];
+        if (lane == 0) a.tgt_dirty[t] = 0;
+        rp_fold_wave(a, t, rp::kNever, false, lane);
+      } else {
+        rp_fold_wave(a, w, c.cut, true, lane);
+      }
+    }
+  } else if (phase == rp::PH_SIM && a.sub_mem) {
+    for (uint32_t w = blockIdx.x; w < n; w += active) rp_sim_block(a, a.sd_list[w], s_sim);
   } else {
-    const uint32_t stride = gridDim.x * kRpThreads;
+    const uint32_t stride = active * kRpThreads;
     for (uint32_t tid = blockIdx.x * kRpThreads + threadIdx.x; tid < n; tid += stride) rp_run_phase(a, phase, tid);
   }
-  // the last workgroup to get here picks the next phase (its reads of what the others counted are atomic
-  // read-modify-writes, so every workgroup only has to have its own atomics performed before it says so)
+  // the last workgroup to get here picks the next phase.  Every workgroup only has to have its own atomics performed
+  // before it says so: the last one reads the control block through atomic read-modify-writes (the per-XCD L2s are not
+  // coherent) — all words at once, one per thread, into LDS; rp_control then runs on the LDS copy (a dozen dependent
+  // trips to memory otherwise, 10 - 20 us per step) and the copy is stored back.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(&c.arrive, 1u) == gridDim.x - 1) ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = (atomicAdd(&c.arrive, 1u) == active - 1) ? 1u : 0u;
   __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    c.arrive = 0;
+  if (!s_last) return;
+  __shared__ rp::Ctl s_ctl;
+  {
+    uint32_t* src = reinterpret_cast<uint32_t*>(a.ctl);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_ctl);
+    for (uint32_t i = threadIdx.x; i < sizeof(rp::Ctl) / 4; i += kRpThreads) dst[i] = atomicAdd(&src[i], 0u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_ctl.arrive = 0;
+    const unsigned long long now = wall_clock64();   // 100 MHz
+    if (s_ctl.t_prev) s_ctl.st_phase_ticks[phase & 15] += now - s_ctl.t_prev;
+    s_ctl.t_prev = now;
     if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
       sc.ticket[0] = 0;
       sc.ticket[1] = sc.ticket[1] + 1;
     }
-    rp::rp_control(a);
+    rp::Args a2 = a;
+    a2.ctl = &s_ctl;
+    rp::rp_control(a2);
+  }
+  __syncthreads();
+  {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.ctl);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_ctl);
+    for (uint32_t i = threadIdx.x; i < sizeof(rp::Ctl) / 4; i += kRpThreads) dst[i] = src[i];
   }
 }
 

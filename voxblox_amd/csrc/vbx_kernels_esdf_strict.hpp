@@ -17,8 +17,8 @@
 // Queues: FIFOs of voxel ids (pool slot * vps^3 + linear index) in the chunked arena the parallel replay uses
 // (vbx_esdf_replay_core.hpp: a FIFO index i of queue q lives in arena[chunk_tab[q][i / 1024] * 1024 + i % 1024], chunks
 // are handed out by a bump counter and never reused inside an update); queue num_buckets is raise_, 0 .. num_buckets - 1
-// are the buckets of open_.  With stop_before_open this kernel runs updateFromTsdfBlocks' voxel loop and
-// processRaiseSet only and leaves open_ to the replay; otherwise it also pops open_ one voxel at a time (the round-3
+// are the buckets of open_.  With stop_before_open this kernel runs updateFromTsdfBlocks' voxel loop only and leaves
+// raise_ and open_ to the replay; otherwise it also pops open_ one voxel at a time (the round-3
 // form, kept for A/B checks: VBX_ESDF_REPLAY=0).
 
 namespace {
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   }
 
   // ---- processRaiseSet, :305-369 -----------------------------------------------------------------------
-  while (sq_count(q, RQ) != 0 && !q.err && n_raised + n_pops < a.max_pops) {
+  while (!a.stop_before_open && sq_count(q, RQ) != 0 && !q.err && n_raised + n_pops < a.max_pops) {
     const uint32_t g = sq_pop(q, a, RQ);
     const uint32_t slot = g / m.nvox, lin = g % m.nvox;
     const int lx = (int)(lin % vps), ly = (int)((lin / vps) % vps), lz = (int)(lin / (vps * vps));
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   if (a.stop_before_open) {
     // open_ goes to the parallel replay: FIFO indices and the arena's fill level into its control block
     drain_stores();
-    for (int i = lane; i < a.num_buckets; i += 64) {
+    for (int i = lane; i <= a.num_buckets; i += 64) {   // open_'s buckets and (index num_buckets) raise_
       a.rctl->head[i] = q.head[i];
       a.rctl->tail[i] = q.tail[i];
       a.rctl->reserved[i] = (q.tail[i] + kSqChunk - 1) / kSqChunk;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   if (lane == 0) {
     a.stats[0] = n_lower; a.stats[1] = n_raise; a.stats[2] = n_new; a.stats[3] = n_raised; a.stats[4] = n_pops;
     a.stats[5] = n_relax; a.stats[6] = n_blocks;
-    a.stats[7] = q.err ? 1ull : ((sq_count(q, RQ) != 0 || (q.n_open != 0 && !a.stop_before_open)) ? 2ull : 0ull);
+    a.stats[7] = q.err ? 1ull : ((!a.stop_before_open && (sq_count(q, RQ) != 0 || q.n_open != 0)) ? 2ull : 0ull);
   }
 }
 
