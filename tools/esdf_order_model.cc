@@ -35,6 +35,7 @@ template <typename T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 #define RP_FN static inline
+static int g_filter_level = 3;
 #define RP_LD(x) (x)
 #define RP_LD64(x) (x)
 #include "../voxblox_amd/csrc/vbx_esdf_replay_core.hpp"
@@ -57,6 +58,8 @@ class ModelEsdf : public EsdfIntegrator {
   using EsdfIntegrator::EsdfIntegrator;
   Stats st;
   rp::Ctl emul_ctl;
+  bool seq_watch = false;
+  LIdx3 seq_watch_g{0, 0, 0};
   bool emul_shuffle = true;
   int mode = 0;  // 0: the reference's sequential wavefront (instrumented), 1: the batched event-fold replay
   size_t kmax = 1u << 20, smax = 256;
@@ -109,6 +112,12 @@ class ModelEsdf : public EsdfIntegrator {
     bq_.assign(config_.num_buckets, {});
     n_open_ = 0;
     classify(tsdf_blocks);
+    if (std::getenv("EOM_WATCH")) {
+      int bx, by, bz, lin;
+      std::sscanf(std::getenv("EOM_WATCH"), "%d,%d,%d,%d", &bx, &by, &bz, &lin);
+      seq_watch = true;
+      seq_watch_g = globalVoxelIndexFromBlockAndVoxelIndex(Idx3{bx, by, bz}, Idx3{lin % 16, (lin / 16) % 16, lin / 256}, 16);
+    }
     if (mode != 2) raiseSet();   // (the emulated device code pops raise_ itself)
     if (mode == 0) openSet(); else if (mode == 1) openSetParallel(); else openSetEmul();
   }
@@ -559,7 +568,24 @@ class ModelEsdf : public EsdfIntegrator {
       const Idx3 l = localFromGlobalVoxelIndex(g, vps);
       return slot_of.at(b) * nvox + (uint32_t)(l.x + vps * (l.y + vps * l.z));
     };
+    // Args::hazard: a neighbour of the other sign class exists
+    std::vector<uint8_t> hazard(nv, 0);
+    if (!std::getenv("EOM_NO_FILTER")) {
+      for (size_t sl = 0; sl < blocks.size(); ++sl)
+        for (uint32_t i = 0; i < nvox; ++i) {
+          const LIdx3 g = globalVoxelIndexFromBlockAndVoxelIndex(blocks[sl], esdf_layer_->block_map[blocks[sl]]->voxelIndexFromLinear(i), vps);
+          const bool pos = dist[sl * nvox + i] > 0;
+          for (int k = 0; k < 26; ++k) {
+            const Idx3 o = NeighborhoodLut::offset(k);
+            EsdfVoxel* nvx = esdf_layer_->getVoxelPtrByGlobalIndex({g.x + o.x, g.y + o.y, g.z + o.z});
+            if (nvx && nvx->observed && ((nvx->distance > 0) != pos)) { hazard[sl * nvox + i] = 1; break; }
+          }
+        }
+    }
+    if (std::getenv("EOM_FILTER_LEVEL")) g_filter_level = std::atoi(std::getenv("EOM_FILTER_LEVEL"));
     Args a{};
+    a.hazard = std::getenv("EOM_NO_FILTER") ? nullptr : hazard.data();
+    a.c.filter = (uint32_t)g_filter_level;
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;
@@ -584,7 +610,8 @@ class ModelEsdf : public EsdfIntegrator {
       raise_q_.clear();
     }
     n_open_ = 0;
-    const uint32_t rec_cap = a.c.kmax * 8 + 65536, tgt_cap = rec_cap * 4;
+    const uint32_t rec_cap = std::getenv("EOM_REC_CAP") ? (uint32_t)std::atoi(std::getenv("EOM_REC_CAP")) : a.c.kmax * 8 + 65536;
+    const uint32_t tgt_cap = std::getenv("EOM_TGT_CAP") ? (uint32_t)std::atoi(std::getenv("EOM_TGT_CAP")) : rec_cap * 4;
     a.rec_cap = rec_cap; a.tgt_cap = tgt_cap;
     std::vector<uint32_t> rec_vox(rec_cap), rec_pusher(rec_cap), rec_base(rec_cap), rec_meta(rec_cap), rec_meta_n(rec_cap), rec_poison(rec_cap),
         rec_s(rec_cap), rec_s_n(rec_cap), rec_kid((size_t)rec_cap * 26), rec_tgts((size_t)rec_cap * 27), rec_push((size_t)rec_cap * 7);
@@ -605,6 +632,8 @@ class ModelEsdf : public EsdfIntegrator {
     a.sub_slot = sub_slot.data(); a.sub_list = sub_list.data(); a.sub_slots_used = &sub_slots_used; a.sim_q = sim_q.data(); a.sub_slots_cap = sub_slots_cap;
     a.ord = ord.data(); a.off0 = off0.data();
 
+    uint32_t watch = kNone;
+    if (std::getenv("EOM_WATCH")) { int bx, by, bz, lin; std::sscanf(std::getenv("EOM_WATCH"), "%d,%d,%d,%d", &bx, &by, &bz, &lin); watch = slot_of.at(Idx3{bx, by, bz}) * nvox + (uint32_t)lin; }
     std::mt19937 rng(12345);
     std::vector<uint32_t> order;
     c.phase = PH_BEGIN;
@@ -639,6 +668,33 @@ class ModelEsdf : public EsdfIntegrator {
             case PH_RAISE_FOLD: rp_phase_raise_fold(a, tid); break;
             default: std::fprintf(stderr, "bad phase %u\n", c.phase); std::abort();
           }
+        }
+      }
+      if (watch != kNone) {
+        static uint32_t last_s = 0xdeadbeef; static float last_d = -1e9f;
+        if (state[watch] != last_s || dist[watch] != last_d) {
+          std::fprintf(stderr, "[watch] after phase %u (superstep %llu b=%u K=%u cut=%llx iter=%u): d=%.9g s=%08x\n", c.phase, c.st_supersteps, c.bucket, c.K, c.cut, c.iter, dist[watch], state[watch]);
+          last_s = state[watch]; last_d = dist[watch];
+        }
+        if (c.phase == PH_COMMIT_FOLD && a.vox2tgt[watch]) {
+          const uint32_t t = a.vox2tgt[watch] - 1;
+          std::fprintf(stderr, "[watch] commit of superstep %llu: target %u events %u\n", c.st_supersteps, t, a.tgt_cnt[t]);
+          for (uint32_t k = 0; k < a.tgt_cnt[t] && k < kEv; ++k) {
+            const uint32_t code = a.tgt_ev[(size_t)t * kEv + k], r = code >> 5, lut = code & 31;
+            uint32_t pv = lut < 26 ? ((a.rec_push[r * 7 + lut / 4] >> ((lut % 4) * 8)) & 0xFF) : 0;
+            const uint32_t rg = a.rec_vox[r];
+            const Idx3 rb = blocks[rg / nvox];
+            const uint32_t rl = rg % nvox;
+            std::fprintf(stderr, "[watch]   ev rec %u vox (%d %d %d) lut %u T=%llx live=%d poison=%u d=%.9g s=%08x push=%u kid=%u\n", r, rb.x * 16 + (int)(rl % 16), rb.y * 16 + (int)(rl / 16 % 16), rb.z * 16 + (int)(rl / 256), lut, a.rec_T[r], (int)rp_meta_live(a.rec_meta[r]), a.rec_poison[r],
+                         a.rec_d[r], a.rec_s[r], pv, lut < 26 ? a.rec_kid[(size_t)r * 26 + lut] : 0);
+          }
+        }
+        if (c.phase == PH_PLACE_BASE)
+          for (uint32_t r = 0; r < c.K; ++r) if (a.rec_vox[r] == watch) std::fprintf(stderr, "[watch] base record %u of superstep %llu b=%u\n", r, c.st_supersteps, c.bucket);
+        if (c.phase == PH_CLEANUP) {
+          for (uint32_t r = 0; r < c.n_rec; ++r) if (a.rec_vox[r] == watch) std::fprintf(stderr, "[watch] record %u (pusher %u) T=%llx live=%d poison=%u cut=%llx\n", r, a.rec_pusher[r], a.rec_T[r], (int)rp_meta_live(a.rec_meta[r]), a.rec_poison[r], c.cut);
+          for (int q = 0; q <= config_.num_buckets; ++q)
+            for (uint32_t i = c.head[q]; i < c.tail[q]; ++i) if (rp_queue_entry(a, q, i) == watch) std::fprintf(stderr, "[watch] queued in %d at %u (head %u tail %u)\n", q, i, c.head[q], c.tail[q]);
         }
       }
       if (std::getenv("EOM_TRACE2")) std::fprintf(stderr, "phase %u n=%u iter=%u rec=%u tgt=%u\n", c.phase, n, c.iter, c.n_rec, c.n_tgt);
@@ -732,6 +788,7 @@ class ModelEsdf : public EsdfIntegrator {
         }
         if (upd) {
           ++st.relax;
+          if (seq_watch && n == seq_watch_g) std::fprintf(stderr, "[seq] pop #%llu (%lld %lld %lld) d=%.9g bucket %d -> watch %.9g -> %.9g lut %d inq=%d\n", (unsigned long long)st.pops, (long long)g.x, (long long)g.y, (long long)g.z, voxel->distance, b, nv->distance, nd, idx, (int)nv->in_queue);
           nv->distance = nd;
           nv->parent = new_parent;
           if (config_.multi_queue || !nv->in_queue) {
@@ -763,7 +820,7 @@ void* eom_create(float voxel) {
   auto* m = new Model(voxel);
   TsdfConfig c;
   c.default_truncation_distance = 4 * voxel;
-  c.integrator_threads = 8;
+  c.integrator_threads = std::getenv("EOM_THREADS") ? std::atoi(std::getenv("EOM_THREADS")) : 8;
   m->fast.reset(new FastTsdfIntegrator(c, &m->tsdf));
   EsdfConfig ec;
   ec.min_distance_m = 2 * voxel;
@@ -819,8 +876,12 @@ long eom_update_parallel(void* h, size_t kmax, size_t smax, int max_iters) {
       const EsdfVoxel& c = it->second->voxels[i];
       ++n;
       if (std::memcmp(&a.distance, &c.distance, 4) != 0 || a.observed != c.observed || a.in_queue != c.in_queue ||
-          a.fixed != c.fixed || !(a.parent == c.parent) || a.hallucinated != c.hallucinated)
+          a.fixed != c.fixed || !(a.parent == c.parent) || a.hallucinated != c.hallucinated) {
         ++diff;
+        if (std::getenv("EOM_DUMP") && diff <= 20)
+          std::printf("    diff blk (%d %d %d) lin %zu: seq d=%.9g q=%d par=(%d %d %d) fixed=%d | par d=%.9g q=%d par=(%d %d %d)\n", kv.first.x, kv.first.y, kv.first.z, i,
+                      a.distance, a.in_queue, a.parent.x, a.parent.y, a.parent.z, a.fixed, c.distance, c.in_queue, c.parent.x, c.parent.y, c.parent.z);
+      }
     }
   }
   if (m->e2->mode == 2) {

@@ -37,6 +37,7 @@ namespace rp {
 
 constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
 constexpr uint32_t kEv = 128;              // events a target can hold
 constexpr uint32_t kOwn = 31;              // event code of a record's own pop (LUT indices are 0..25)
@@ -70,6 +71,7 @@ struct Cfg {
   float max_distance, min_diff, voxel_size, default_distance;
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
+  uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
 };
 
 // control block (device memory, one instance).  Part A is written by rp_control only (every workgroup reads it at
@@ -84,14 +86,12 @@ struct Ctl {
   uint32_t n_rec, iter;
   uint32_t read;                             // dirty target lists: FOLD reads list `read`, marks go to 1 - read
   uint32_t a_chg, a_born, a_tgt;             // copies of n_chg / n_born / n_tgt as the last phase left them
+  uint32_t cap_stop;                         // 1: the records (or their list) are full — no births any more, the super-step commits what stands
   unsigned long long cut;
   uint32_t n_commit;                         // committed records
   uint32_t scan_tot[4];
   uint32_t push_b[4], push_n;                // buckets of the current PH_PUSH pass
   uint32_t push_next;                        // first bucket not yet handled by a PH_PUSH pass
-  uint32_t head[kMaxBuckets + 1], tail[kMaxBuckets + 1];  // FIFO indices per bucket (entries ever popped / pushed)
-  uint32_t reserved[kMaxBuckets + 1];        // chunks of the bucket's FIFO that are backed by the arena
-  uint32_t k_cur[kMaxBuckets + 1];           // base records the bucket's next super-step may take (slow start after a cut)
   uint32_t chunk_top;
   // ---- B
   uint32_t error;                            // 1 record capacity, 2 target capacity, 4 queue arena, 8 no progress, 16 event overflow at base record 0
@@ -99,11 +99,15 @@ struct Ctl {
   uint32_t n_chg, n_born, n_sd, n_cp;
   uint32_t k_limit;                          // base records from here on cannot take part (event list overflow)
   unsigned long long first_change, smax_cut;
-  uint32_t push_cnt[kMaxBuckets + 1];        // pushes per bucket seen by COMMIT_FOLD (upper bound of what gets queued)
   uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
   // statistics
   unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank;
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16], t_prev;
+  // ---- per queue (bucket 0 .. num_buckets - 1, raise_ = num_buckets); the device wrapper moves the first num_buckets + 1 of each
+  uint32_t head[kMaxBuckets + 1], tail[kMaxBuckets + 1];  // A: FIFO indices (entries ever popped / pushed)
+  uint32_t reserved[kMaxBuckets + 1];        // A: chunks of the queue's FIFO that are backed by the arena
+  uint32_t k_cur[kMaxBuckets + 1];           // A: base records the bucket's next super-step may take (slow start after a cut)
+  uint32_t push_cnt[kMaxBuckets + 1];        // B: pushes per queue seen by COMMIT_FOLD (upper bound of what gets queued)
 };
 
 struct Args {
@@ -113,6 +117,7 @@ struct Args {
   float* dist;
   uint32_t* state;
   const uint32_t* nbslot;   // [slot][27]: pool slot of the ESDF block at offset (dx,dy,dz) = ((k%3)-1, (k/3%3)-1, (k/9)-1), kNone if the ESDF layer has none
+  const uint8_t* hazard;    // per voxel: a neighbour of the other sign class exists (null: no offer is ever left out)
   uint32_t* blk_dirty;      // per slot word that gets `dirty_bit` or-ed in when a voxel of the block changes (may be null)
   uint32_t dirty_bit;
   uint32_t nvox;
@@ -252,7 +257,7 @@ RP_FN bool rp_meta_live(uint32_t m) { return (m >> 16) & 1; }
 RP_FN uint32_t rp_meta(uint32_t lut, uint32_t bucket, bool live) { return lut | (bucket << 8) | ((uint32_t)live << 16); }
 
 RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
-  if (t == kNone) return;
+  if (t >= kSkip) return;
   if (atomicExch(&a.tgt_dirty[t], 1u) == 0u) {
     Ctl& c = *a.ctl;
     const uint32_t w = 1u - c.read;
@@ -266,8 +271,9 @@ RP_FN uint32_t rp_target(const Args& a, uint32_t gid) {
   Ctl& c = *a.ctl;
   const uint32_t v = a.vox2tgt[gid];
   if (v != 0u) return v - 1u;
+  if (c.n_tgt >= a.tgt_cap) return kNone;   // (racy look, the exact test follows; keeps the counter from running away)
   const uint32_t id = atomicAdd(&c.n_tgt, 1u);
-  if (id >= a.tgt_cap) { atomicOr(&c.error, 2u); return kNone; }
+  if (id >= a.tgt_cap) return kNone;
   const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, id + 1u);
   if (old != 0u) {  // somebody else made it: `id` stays an empty hole
     a.tgt_gid[id] = kNone;
@@ -277,22 +283,58 @@ RP_FN uint32_t rp_target(const Args& a, uint32_t gid) {
   return id;
 }
 
-// record `r` (voxel gid) announces itself to the target at position p (0..25 LUT neighbour, 26 the voxel itself)
-RP_FN void rp_place(const Args& a, uint32_t r, uint32_t gid, uint32_t p) {
+// Can the offer of a record whose voxel stands at (vd, vs) when it pops change neighbour ngid at all?  Leaving out
+// offers that cannot keeps two thirds of the targets from existing.  A neighbour that is unobserved or fixed is never
+// written (:414-417).  The sign class of a voxel (d > 0 or not) never changes inside processOpenSet (every branch of
+// :431-491 writes a distance of the neighbour's own class), so for a neighbour of the record's class with no neighbour
+// of the other class anywhere around it (Args::hazard) only the two same-sign branches can ever fire, they only move
+// the neighbour towards zero, and an offer that does not beat the neighbour's distance at the start of the super-step
+// cannot beat a later one.  The test is repeated whenever the record's guessed state changes (rp_phase_apply).
+RP_FN bool rp_offer_possible(const Args& a, float vd, uint32_t vs, uint32_t ngid, int lut) {
+  if (a.c.filter < 1) return true;
+  const uint32_t sn = a.state[ngid];
+  if (!(sn & kObserved) || (sn & kFixed)) return false;
+  if (a.ctl->raise || a.c.full || !a.hazard || a.c.filter < 2) return true;
+  if (!(vs & kObserved) || vd >= a.c.max_distance || vd <= -a.c.max_distance) return false;   // the pop offers nothing (:389-392)
+  if (a.c.filter < 3) return true;
+  const float nd = a.dist[ngid];
+  if ((vd > 0) != (nd > 0)) return true;
+  if (a.hazard[ngid]) return true;
+  const float distance = rp_lut_distance(lut) * a.c.voxel_size;
+  return vd > 0 ? (vd + distance + a.c.min_diff < nd) : (vd - distance - a.c.min_diff > nd);
+}
+
+// record `r` (voxel gid, guessed pop-time state vd / vs) announces itself to the target at position p (0..25 LUT
+// neighbour, 26 the voxel itself)
+RP_FN void rp_place(const Args& a, uint32_t r, uint32_t base, uint32_t gid, uint32_t p, float vd, uint32_t vs) {
   Ctl& c = *a.ctl;
   const uint32_t ngid = p == 26 ? gid : rp_neighbour(a, gid, (int)p);
   uint32_t t = kNone;
-  if (ngid != kNone) t = rp_target(a, ngid);
+  if (ngid != kNone) {
+    if (p != 26 && !rp_offer_possible(a, vd, vs, ngid, (int)p)) {
+      a.rec_tgts[(size_t)r * 27 + p] = kSkip;
+      return;
+    }
+    t = rp_target(a, ngid);
+  }
   a.rec_tgts[(size_t)r * 27 + p] = t;
-  if (t == kNone) return;
-  const uint32_t k = atomicAdd(&a.tgt_cnt[t], 1u);
+  if (ngid == kNone) return;
+  const uint32_t k = t == kNone ? kEv : atomicAdd(&a.tgt_cnt[t], 1u);   // (no target to be had: as if its list were full)
   if (k < kEv) {
     a.tgt_ev[(size_t)t * kEv + k] = (r << 5) | (p == 26 ? kOwn : p);
-  } else {
-    // the target cannot hear this record: the record must stay out of the super-step
-    a.rec_poison[r] = 1u;
+  } else if (atomicExch(&a.rec_poison[r], 1u) == 0u) {
+    // the target cannot hear this record: the record must stay out of the super-step.  A base record stops the
+    // super-step in front of itself; an excursion record that has a rank already (its offer is placed late, after its
+    // guessed state moved) is ranked again — the ranking ends in front of a poisoned record.
     atomicAdd(&c.st_poison, 1ull);
-    if (r < c.K) atomicMin(&c.k_limit, r);
+    if (r < c.K) {
+      atomicMin(&c.k_limit, r);
+    } else {
+      // (base: the caller's — a record's own fields may still be on their way when a sibling thread gets here)
+      const unsigned long long T = a.rec_T[r];
+      if (a.sub_restart && T != kNever && (T & kRankMask) != 0) atomicMin(&a.sub_restart[base], (uint32_t)(T & kRankMask) - 1u);
+      if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
+    }
   }
   rp_mark_dirty(a, t);
 }
@@ -462,6 +504,7 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
     // a push below b without a record yet (an existing record for (pusher, lut) sits on THIS voxel and was matched above)
     if (a.rec_kid[(size_t)lp_rec[j] * 26 + (lp_lb[j] & 0xFF)] != 0u) continue;  // (dead record that is not on this list cannot happen; be safe)
     const uint32_t k = atomicAdd(&c.n_born, 1u);
+    if (k >= a.rec_cap) { atomicMin(&c.first_change, a.rec_T[lp_rec[j]]); continue; }   // no room even to note it: the cut falls in front of its pusher
     a.born[(size_t)k * 6 + 0] = lp_rec[j];
     a.born[(size_t)k * 6 + 1] = lp_lb[j] & 0xFF;
     a.born[(size_t)k * 6 + 2] = lp_lb[j] >> 8;
@@ -569,7 +612,7 @@ RP_FN void rp_phase_place_base(const Args& a, uint32_t tid) {
     a.sub_slot[r] = 0;
     if (a.sub_mem) { a.sub_mem_n[r] = 0; a.rec_local[r] = 0; a.sub_restart[r] = kNone; }
   }
-  rp_place(a, r, gid, p);
+  rp_place(a, r, r, gid, p, a.dist[gid], a.state[gid]);
 }
 
 RP_FN void rp_phase_fold(const Args& a, uint32_t tid) {
@@ -612,13 +655,21 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
         atomicOr(&a.rec_meta[r], mn & ~(1u << 18));
       }
     }
-    rp_mark_dirty(a, a.rec_tgts[(size_t)r * 27 + p]);
+    const uint32_t t = a.rec_tgts[(size_t)r * 27 + p];
+    // (rec_d_n / rec_s_n: the new guess; thread 26 of this record is copying it over the old one right now)
+    if (t == kSkip) rp_place(a, r, a.rec_base[r], a.rec_vox[r], p, a.rec_d_n[r], a.rec_s_n[r]);   // an offer left out so far may count now
+    else rp_mark_dirty(a, t);
     return;
   }
   const uint32_t j = item - c.a_chg;
   if (j >= c.a_born) return;
   const uint32_t r = c.n_rec + j;   // (control checked the capacity)
   const uint32_t pusher = a.born[(size_t)j * 6], lut = a.born[(size_t)j * 6 + 1], bucket = a.born[(size_t)j * 6 + 2];
+  if (c.cap_stop) {
+    // no record for this push: the super-step ends in front of the pop that made it
+    if (p == 26) atomicMin(&c.first_change, a.rec_T[pusher]);
+    return;
+  }
   const uint32_t gid = a.born[(size_t)j * 6 + 3];
   if (p == 26) {
     a.rec_vox[r] = gid;
@@ -653,7 +704,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
       }
     }
   }
-  rp_place(a, r, gid, p);
+  rp_place(a, r, a.rec_base[pusher], gid, p, __uint_as_float(a.born[(size_t)j * 6 + 4]), a.born[(size_t)j * 6 + 5]);
 }
 
 // pop times of the excursion of base record `base`: the reference's queue discipline (lowest bucket first, FIFO
@@ -834,6 +885,7 @@ RP_FN void rp_begin_superstep(const Args& a) {
   c.read = 1;            // PLACE_BASE marks into list 0
   c.n_dirty[0] = c.n_dirty[1] = 0;
   c.n_chg = c.n_born = c.n_sd = c.n_cp = 0;
+  c.cap_stop = 0;
   c.k_limit = kNone;
   c.first_change = kNever;
   c.smax_cut = kNever;
@@ -857,6 +909,7 @@ RP_FN void rp_start_commit(const Args& a) {
   if (cut == 0) { c.error |= (k_limit == 0 ? 16u : 8u); rp_stop(c); return; }
   c.cut = cut;
   c.a_tgt = RP_LD(c.n_tgt);
+  if (c.a_tgt > a.tgt_cap) c.a_tgt = a.tgt_cap;
   for (int k = 0; k < a.c.num_buckets; ++k) c.push_cnt[k] = 0;
   c.phase = PH_COMMIT_FOLD;
   c.n_threads = c.a_tgt;
@@ -897,6 +950,7 @@ RP_FN void rp_control(const Args& a) {
     case PH_PLACE_BASE:
       if (c.raise) {
         c.a_tgt = RP_LD(c.n_tgt);
+        if (c.a_tgt > a.tgt_cap) c.a_tgt = a.tgt_cap;
         const uint32_t kl = RP_LD(c.k_limit);
         if (kl == 0) { c.error |= 16u; rp_stop(c); break; }
         if (kl != kNone) c.cut = (unsigned long long)kl << kRankBits;   // an event list overflowed: the records behind wait
@@ -910,8 +964,10 @@ RP_FN void rp_control(const Args& a) {
     case PH_APPLY: {
       const uint32_t n_cp = RP_LD(c.n_cp);
       if (c.phase == PH_APPLY) {
-        c.n_rec += c.a_born;
-        c.st_exc += c.a_born;
+        if (!c.cap_stop) {
+          c.n_rec += c.a_born;
+          c.st_exc += c.a_born;
+        }
         c.n_chg = c.n_born = 0;
         const uint32_t n_sd = RP_LD(c.n_sd);
         if (n_sd) { c.phase = PH_SIM; c.n_threads = n_sd; break; }
@@ -919,7 +975,7 @@ RP_FN void rp_control(const Args& a) {
       if (c.phase == PH_SIM) c.n_sd = 0;
       // next iteration, or stop
       if (c.phase != PH_PLACE_BASE && n_cp == 0) { rp_start_commit(a); break; }   // (cannot happen: APPLY always leaves a change point)
-      if (c.iter >= a.c.max_iters) { c.phase = PH_MINCUT; c.n_threads = n_cp; break; }
+      if (c.iter >= a.c.max_iters || c.cap_stop) { c.phase = PH_MINCUT; c.n_threads = n_cp; break; }
       c.n_cp = 0;
       c.read = 1u - c.read;
       c.n_dirty[1u - c.read] = 0;
@@ -934,7 +990,10 @@ RP_FN void rp_control(const Args& a) {
       c.a_chg = RP_LD(c.n_chg);
       c.a_born = RP_LD(c.n_born);
       if (c.a_chg == 0 && c.a_born == 0) { c.n_cp = 0; rp_start_commit(a); break; }   // fixed point
-      if (c.n_rec + c.a_born > a.rec_cap) { c.error |= 1u; rp_stop(c); break; }
+      if (c.a_born > a.rec_cap || c.n_rec + c.a_born > a.rec_cap) {
+        c.cap_stop = 1;   // PH_APPLY applies the changes, notes the pushers of the births it cannot make, and the prefix commits
+        if (c.a_born > a.rec_cap) c.a_born = a.rec_cap;
+      }
       c.phase = PH_APPLY;
       c.n_threads = (c.a_chg + c.a_born) * 27;
       break;

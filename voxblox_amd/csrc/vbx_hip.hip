@@ -49,6 +49,7 @@ using namespace vbx;
 #include "vbx_kernels_esdf.hpp"
 #include "vbx_kernels_esdf_replay.hpp"
 #include "vbx_kernels_esdf_strict.hpp"
+#include "vbx_kernels_esdf_classify.hpp"
 #include "vbx_kernels_mesh.hpp"
 #include "vbx_ctx.hpp"
 #include "vbx_sort.hpp"

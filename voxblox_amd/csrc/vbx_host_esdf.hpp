@@ -361,7 +361,7 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
 
 // ---- the parallel open set of reference_order (vbx_esdf_replay_core.hpp) ------------------------------------------
 constexpr int kRpGraphSteps = 48;   // launches per captured graph; the host looks at Ctl::done between graphs
-constexpr int kRpGrid = 512;        // workgroups of k_rp_step (grid-stride over the phase's items)
+constexpr int kRpGrid = 2048;       // workgroups of k_rp_step (grid-stride over the phase's items)
 
 static uint32_t rp_env_u32(const char* name, uint32_t dflt) {
   const char* v = getenv(name);
@@ -373,10 +373,11 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   hipStream_t s = ctx->stream;
   const MapDev& m = ctx->map;
   const uint32_t kmax = rp_env_u32("VBX_RP_KMAX", 16384), smax = std::min<uint32_t>(rp_env_u32("VBX_RP_SMAX", 1024), kSimMax);
-  const uint32_t rec_cap = kmax * 8 + 65536, tgt_cap = rec_cap * 3;
+  const uint32_t rec_cap = kmax * 12 + 65536, tgt_cap = rec_cap * 2;
   const bool fresh = !ctx->rp_ctl.p;
   HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl)));
   HIP_TRY(ctx->rp_nbslot.ensure((size_t)std::max<uint32_t>(used, 1) * 27 * 4));
+  HIP_TRY(ctx->rp_hazard.ensure((size_t)std::max<uint32_t>(used, 1) * m.nvox));
   HIP_TRY(ctx->rp_chunk_tab.ensure((size_t)(num_buckets + 1) * n_chunks * 4));
   if (fresh || ctx->rp_rec_cap != rec_cap || ctx->rp_tgt_cap != tgt_cap || ctx->rp_smax != smax) {
     HIP_TRY(ctx->rp_rec_u32.ensure((size_t)rec_cap * 4 * 10));
@@ -393,18 +394,29 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(ctx->rp_sub_list.ensure((size_t)sub_slots * smax * 4));
     HIP_TRY(ctx->rp_sim_q.ensure((size_t)sub_slots * smax * 8));
     HIP_TRY(ctx->rp_ord.ensure((size_t)rec_cap * 4));
-    HIP_TRY(ctx->rp_scan_desc.ensure((size_t)(rec_cap / kRpThreads + 2) * 4 * 8 + 64));
+
     // what the phases expect to be zero between super-steps
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_u32.p, 0, (size_t)rec_cap * 4 * 10, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_kid.p, 0, (size_t)rec_cap * 26 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_push.p, 0, (size_t)rec_cap * 7 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0, (size_t)tgt_cap * 4 * 3, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_sub.p, 0, (size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4, s));
-    HIP_TRY(hipMemsetAsync(ctx->rp_scan_desc.p, 0, ctx->rp_scan_desc.cap, s));
     ctx->rp_rec_cap = rec_cap;
     ctx->rp_tgt_cap = tgt_cap;
     ctx->rp_kmax = kmax;
     ctx->rp_smax = smax;
+  }
+  {
+    // chained-scan descriptors: one per tile of the longest scan (the voxel walk of the classification); ticket = 0, generation = 1
+    const size_t items = std::max<size_t>(rec_cap, (size_t)std::max<uint32_t>(used, 1) * m.nvox);
+    const size_t bytes = (items / kRpThreads + 2) * 4 * 8 + 64;
+    if (ctx->rp_scan_desc.cap < bytes) {
+      HIP_TRY(ctx->rp_scan_desc.ensure(bytes));
+      HIP_TRY(hipMemsetAsync(ctx->rp_scan_desc.p, 0, ctx->rp_scan_desc.cap, s));
+      const uint32_t t01[2] = {0u, 1u};
+      HIP_TRY(hipMemcpyAsync(ctx->rp_scan_desc.p, t01, 8, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
   }
   // voxel -> target map over the whole pool (zero between super-steps; a pool that grew gets a zeroed tail)
   const size_t vbytes = (size_t)m.cap_blocks * m.nvox * 4;
@@ -436,6 +448,8 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.dist = e.dist;
   a.state = e.state;
   a.nbslot = ctx->rp_nbslot.as<uint32_t>();
+  a.hazard = ctx->rp_hazard.as<uint8_t>();
+  a.c.filter = rp_env_u32("VBX_RP_FILTER", 3);
   a.blk_dirty = m.blk_flags;
   a.dirty_bit = kFlagEsdfDirty;
   a.nvox = m.nvox;
@@ -488,25 +502,19 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   memcpy(key.data(), &a, sizeof(rp::Args));
   key[key.size() - 1] = (uint64_t)(uintptr_t)sc.desc;
   key[key.size() - 2] = (uint64_t)(uintptr_t)s;
-  const bool use_graph = rp_env_u32("VBX_RP_GRAPH", 1) != 0;
+  const bool serial = rp_env_u32("VBX_RP_SERIAL", 0) != 0;   // debug: the emulated thread-per-item phases on the device
+  const bool use_graph = rp_env_u32("VBX_RP_GRAPH", 1) != 0 && !serial;
   if (use_graph && (!ctx->rp_graph_exec || key != ctx->rp_graph_key)) {
     if (ctx->rp_graph_exec) { (void)hipGraphExecDestroy(ctx->rp_graph_exec); ctx->rp_graph_exec = nullptr; }
     if (ctx->rp_graph) { (void)hipGraphDestroy(ctx->rp_graph); ctx->rp_graph = nullptr; }
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < kRpGraphSteps; ++i) hipLaunchKernelGGL(k_rp_step, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc);
+    for (int i = 0; i < kRpGraphSteps; ++i) hipLaunchKernelGGL(k_rp_step<false>, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc);
     HIP_TRY(hipStreamEndCapture(s, &ctx->rp_graph));
     HIP_TRY(hipGraphInstantiate(&ctx->rp_graph_exec, ctx->rp_graph, nullptr, nullptr, 0));
     ctx->rp_graph_key = key;
   }
-  // Ctl::sc.ticket: [0] = 0, [1] = generation >= 1 (descriptors of older scans read as "not there")
-  uint32_t h_ticket[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(h_ticket, sc.ticket, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (h_ticket[1] == 0 || h_ticket[0] != 0) {
-    h_ticket[0] = 0;
-    h_ticket[1] = std::max<uint32_t>(h_ticket[1], 1u);
-    HIP_TRY(hipMemcpyAsync(sc.ticket, h_ticket, 8, hipMemcpyHostToDevice, s));
-  }
+  rp::Args as = a;   // (serial form: no member lists, ranking from the child table)
+  as.sub_mem = nullptr; as.sub_restart = nullptr;
   KLAUNCH(k_rp_begin, dim3(1), dim3(1), 0, s, a);
   uint32_t h_done[2] = {0, 0};
   const uint64_t max_graphs = 1u << 20;
@@ -516,7 +524,17 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
       HIP_TRY(hipGraphLaunch(ctx->rp_graph_exec, s));
       prof_end(ctx);
     } else {
-      for (int i = 0; i < kRpGraphSteps; ++i) KLAUNCH(k_rp_step, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc);
+      for (int i = 0; i < kRpGraphSteps; ++i) {
+        if (getenv("VBX_RP_SYNC")) {   // debug: which phase faults
+          rp::Ctl hc;
+          (void)hipMemcpy(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost);
+          fprintf(stderr, "[rp-sync] step %llu phase %u n %u K %u b %u n_rec %u n_tgt %u n_chg %u n_born %u n_sd %u n_cp %u iter %u\n", hc.st_steps, hc.phase, hc.n_threads, hc.K,
+                  hc.bucket, hc.n_rec, hc.n_tgt, hc.n_chg, hc.n_born, hc.n_sd, hc.n_cp, hc.iter);
+        }
+        if (serial) KLAUNCH(k_rp_step<true>, dim3(kRpGrid), dim3(kRpThreads), 0, s, as, sc);
+        else KLAUNCH(k_rp_step<false>, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc);
+        if (getenv("VBX_RP_SYNC") && hipStreamSynchronize(s) != hipSuccess) { fprintf(stderr, "[rp-sync] fault\n"); }
+      }
     }
     HIP_TRY(hipMemcpyAsync(h_done, &a.ctl->phase, 8, hipMemcpyDeviceToHost, s));   // phase, done
     HIP_TRY(hipStreamSynchronize(s));
@@ -545,6 +563,63 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   *pops = hc.st_pops + hc.st_raise_pops;
   *relax = hc.st_relax;
   return VBX_OK;
+}
+
+// updateFromTsdfBlocks' voxel loop in parallel (vbx_kernels_esdf_classify.hpp).  Returns 1 when it has filled the queues,
+// 0 when the list names a block twice or the neighbour looks did not settle (the one-wave form takes over; nothing has
+// been written to the layer then), < 0 on error.
+int esdf_classify_parallel(vbx_ctx* ctx, const EsdfCfgDev& c, const EsdfDev& e, int incremental, int batch_crust, int num_buckets,
+                           const uint32_t* list_slots, uint32_t n_list, uint32_t used, const rp::Args& ra, unsigned long long* n_blocks) {
+  hipStream_t s = ctx->stream;
+  const MapDev& m = ctx->map;
+  *n_blocks = 0;
+  const size_t nv = (size_t)std::max<uint32_t>(n_list, 1) * m.nvox;
+  HIP_TRY(ctx->cls_pos.ensure((size_t)std::max<uint32_t>(used, 1) * 4));
+  HIP_TRY(ctx->cls_nb27.ensure((size_t)std::max<uint32_t>(n_list, 1) * 27 * 4));
+  HIP_TRY(ctx->cls_shadow.ensure(nv * 10));
+  HIP_TRY(ctx->cls_counters.ensure(4 * 512));
+  HIP_TRY(hipMemsetAsync(ctx->cls_pos.p, 0xFF, (size_t)std::max<uint32_t>(used, 1) * 4, s));
+  HIP_TRY(hipMemsetAsync(ctx->cls_counters.p, 0, 4 * 512, s));
+  ClsArgs a{};
+  a.m = m; a.e = e; a.c = c;
+  a.incremental = incremental; a.batch_crust = batch_crust; a.num_buckets = num_buckets;
+  a.list_slots = list_slots; a.n_list = n_list;
+  a.slot_pos = ctx->cls_pos.as<uint32_t>();
+  a.nb27 = ctx->cls_nb27.as<uint32_t>();
+  a.sh_d = ctx->cls_shadow.as<float>();
+  a.sh_s = reinterpret_cast<uint32_t*>(a.sh_d + nv);
+  a.sh_f = reinterpret_cast<uint8_t*>(a.sh_s + nv);
+  a.sh_q = a.sh_f + nv;
+  a.counters = ctx->cls_counters.as<uint32_t>();
+  uint32_t h[4] = {0, 0, 0, 0};
+  if (n_list) {
+    KLAUNCH(k_cls_positions, grid_for(n_list), dim3(256), 0, s, a);
+    KLAUNCH(k_cls_neighbours, grid_for((size_t)n_list * 27), dim3(256), 0, s, a);
+    KLAUNCH(k_cls_base, grid_for((size_t)n_list * m.nvox), dim3(256), 0, s, a);
+    int rounds = 0;
+    for (;; ++rounds) {
+      if (incremental) KLAUNCH(k_cls_nb, grid_for((size_t)n_list * m.nvox), dim3(256), 0, s, a);
+      HIP_TRY(hipMemcpyAsync(h, a.counters, 16, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (h[0] != 0) return 0;             // a block listed twice
+      if (!incremental || h[1] == 0) break;
+      if (rounds >= 64) return 0;          // (a chain of neighbour looks longer than anything a Config produces)
+      HIP_TRY(hipMemsetAsync(a.counters + 1, 0, 4, s));
+    }
+    KLAUNCH(k_cls_commit, grid_for((size_t)n_list * m.nvox), dim3(256), 0, s, a);
+  }
+  KLAUNCH(k_cls_reserve, dim3(1), dim3(1), 0, s, a, ra);
+  if (n_list) {
+    RpScan sc;
+    sc.desc = ctx->rp_scan_desc.as<unsigned long long>() + 8;
+    sc.ticket = ctx->rp_scan_desc.as<uint32_t>();
+    sc.max_tiles = 0;
+    const uint32_t tiles = (uint32_t)(((size_t)n_list * m.nvox + kRpThreads - 1) / kRpThreads);
+    for (int q0 = 0; q0 <= num_buckets; q0 += 4)
+      KLAUNCH(k_cls_push, dim3(std::min<uint32_t>(tiles, 1024u)), dim3(kRpThreads), 0, s, a, ra, sc, q0);
+  }
+  *n_blocks = h[2];
+  return 1;
 }
 
 // cfg->reference_order: the whole update as ONE sequential replay on the device (vbx_kernels_esdf_strict.hpp).
@@ -642,12 +717,19 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   a.stop_before_open = replay ? 1 : 0;
   a.stats = ctx->b_vals0.as<unsigned long long>();
   a.max_pops = 1ull << 40;
-  KLAUNCH(k_esdf_strict, dim3(1), dim3(64), 0, s, a);
-  unsigned long long rp_pops = 0, rp_relax = 0;
+  unsigned long long rp_pops = 0, rp_relax = 0, cls_blocks = 0;
+  int front_done = 0;
+  if (replay && rp_env_u32("VBX_RP_CLASSIFY", 1)) {
+    const rp::Args ra0 = rp_args(ctx, cfg, e, a.n_chunks);
+    front_done = esdf_classify_parallel(ctx, a.c, e, a.incremental, a.batch_crust, a.num_buckets, a.list_slots, a.n_list, used, ra0, &cls_blocks);
+    if (front_done < 0) return front_done;
+  }
+  if (!front_done) KLAUNCH(k_esdf_strict, dim3(1), dim3(64), 0, s, a);
   if (replay) {
     // processOpenSet: the parallel replay over the queue the kernel above filled
     KLAUNCH(k_rp_nbslot, grid_for((size_t)used * 27), dim3(256), 0, s, m, used, ctx->rp_nbslot.as<uint32_t>());
     const rp::Args ra = rp_args(ctx, cfg, e, a.n_chunks);
+    KLAUNCH(k_rp_hazard, grid_for((size_t)used * m.nvox), dim3(256), 0, s, ra, m.blk_flags, used, ctx->rp_hazard.as<uint8_t>());
     rc = rp_run(ctx, ra, &rp_pops, &rp_relax);
     if (rc) return rc;
   }
@@ -655,8 +737,12 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     KLAUNCH(k_esdf_strict_clear_tsdf_bit, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n);
   tmark(ctx, 7);
   unsigned long long st[8] = {0};
-  HIP_TRY(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (!front_done) {
+    HIP_TRY(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    st[6] = cls_blocks;
+  }
   if (st[7] == 1) {
     ctx->fail("ESDF reference order: queue arena exhausted (%zu chunks)", n_chunks);
     return VBX_ERR_CAPACITY;

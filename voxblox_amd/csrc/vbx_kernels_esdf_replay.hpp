@@ -15,6 +15,13 @@
 
 namespace {
 
+// broadcast of lane `src` (wave-uniform): v_readlane instead of a trip through the LDS crossbar
+__device__ inline uint32_t rl_u32(uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, __builtin_amdgcn_readfirstlane(src)); }
+__device__ inline float rl_f32(float x, int src) { return __uint_as_float(rl_u32(__float_as_uint(x), src)); }
+__device__ inline unsigned long long rl_u64(unsigned long long x, int src) {
+  return (unsigned long long)rl_u32((uint32_t)x, src) | ((unsigned long long)rl_u32((uint32_t)(x >> 32), src) << 32);
+}
+
 constexpr int kRpThreads = 256;
 constexpr uint32_t kRpSpinMax = 1u << 22;
 
@@ -39,14 +46,40 @@ __global__ void k_rp_nbslot(MapDev m, uint32_t used, uint32_t* __restrict__ nbsl
   nbslot[i] = out;
 }
 
+// Args::hazard: does the voxel have an observed neighbour of the other sign class (d > 0 or not)?  Classes are fixed for the
+// whole of processRaiseSet / processOpenSet, so this is computed once per update, after the voxel loop of updateFromTsdfBlocks.
+__global__ void k_rp_hazard(rp::Args a, const uint32_t* __restrict__ blk_flags, uint32_t used, uint8_t* __restrict__ hazard) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)used * a.nvox) return;
+  const uint32_t f = blk_flags[gid / a.nvox];
+  uint8_t h = 0;
+  if (!(f & kFlagFree) && (f & kFlagEsdfAlloc)) {
+    const bool pos = a.dist[gid] > 0;
+    for (int k = 0; k < 26; ++k) {
+      const uint32_t n = rp::rp_neighbour(a, (uint32_t)gid, k);
+      if (n == rp::kNone) continue;
+      if ((a.state[n] & rp::kObserved) && ((a.dist[n] > 0) != pos)) { h = 1; break; }
+    }
+  }
+  hazard[gid] = h;
+}
+
+template <bool SERIAL>
 __device__ inline void rp_run_phase(const rp::Args& a, uint32_t phase, uint32_t tid) {
+  if (SERIAL) {
+    // (debug form, VBX_RP_SERIAL=1: the thread-per-item folds and ranking the CPU emulation runs)
+    switch (phase) {
+      case rp::PH_FOLD: rp::rp_phase_fold(a, tid); return;
+      case rp::PH_SIM: rp::rp_phase_sim(a, tid); return;
+      case rp::PH_COMMIT_FOLD: rp::rp_phase_commit_fold(a, tid); return;
+      case rp::PH_RAISE_FOLD: rp::rp_phase_raise_fold(a, tid); return;
+      default: break;
+    }
+  }
   switch (phase) {
     case rp::PH_PLACE_BASE: rp::rp_phase_place_base(a, tid); break;
-    case rp::PH_FOLD: rp::rp_phase_fold(a, tid); break;
     case rp::PH_APPLY: rp::rp_phase_apply(a, tid); break;
-    case rp::PH_SIM: rp::rp_phase_sim(a, tid); break;
     case rp::PH_MINCUT: rp::rp_phase_mincut(a, tid); break;
-    case rp::PH_COMMIT_FOLD: rp::rp_phase_commit_fold(a, tid); break;
     case rp::PH_RANK_WRITE: rp::rp_phase_rank_write(a, tid); break;
     case rp::PH_CLEANUP: rp::rp_phase_cleanup(a, tid); break;
     default: break;
@@ -67,6 +100,8 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
   const int b = (int)c.bucket;
   uint32_t n_all = a.tgt_cnt[t];
   if (n_all > kEv) n_all = kEv;
+  const float d0 = a.dist[gid];          // (issued with the event loads, used after the ranking)
+  const uint32_t s0 = a.state[gid];
   uint32_t code[2] = {0, 0}, es[2] = {0, 0}, emeta[2] = {0, 0};
   unsigned long long eT[2] = {kNever, kNever};
   float ed[2] = {0.f, 0.f};
@@ -94,14 +129,12 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     while (vm) {
       const int k = __ffsll((long long)vm) - 1;
       vm &= vm - 1;
-      const unsigned long long Tk = __shfl(eT[q2], k);
+      const unsigned long long Tk = rl_u64(eT[q2], k);
       rank[0] += (Tk < eT[0]) ? 1u : 0u;
       rank[1] += (Tk < eT[1]) ? 1u : 0u;
     }
   }
   const uint32_t n = (uint32_t)__popcll(__ballot(valid[0])) + (uint32_t)__popcll(__ballot(valid[1]));
-  const float d0 = a.dist[gid];
-  const uint32_t s0 = a.state[gid];
   float d = d0;
   uint32_t s = s0;
   const bool usable = (s0 & kObserved) && !(s0 & kFixed);
@@ -119,10 +152,10 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     int src, sq;
     if (m0) {
       src = __ffsll((long long)m0) - 1; sq = 0;
-      ecode = __shfl(code[0], src); evd = __shfl(ed[0], src); evs = __shfl(es[0], src);
+      ecode = rl_u32(code[0], src); evd = rl_f32(ed[0], src); evs = rl_u32(es[0], src);
     } else if (m1) {
       src = __ffsll((long long)m1) - 1; sq = 1;
-      ecode = __shfl(code[1], src); evd = __shfl(ed[1], src); evs = __shfl(es[1], src);
+      ecode = rl_u32(code[1], src); evd = rl_f32(ed[1], src); evs = rl_u32(es[1], src);
     } else {
       break;  // (cannot happen: ranks of valid events are 0 .. n - 1)
     }
@@ -200,7 +233,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
   bool found[2] = {false, false};
   uint32_t fbucket[2] = {rp_meta_bucket(emeta[0]), rp_meta_bucket(emeta[1])};
   for (uint32_t j = 0; j < n_lp; ++j) {
-    const uint32_t lr = __shfl(lp_rec, (int)j), llb = __shfl(lp_lb, (int)j);
+    const uint32_t lr = rl_u32(lp_rec, (int)j), llb = rl_u32(lp_lb, (int)j);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       if (own[q] && pusher[q] != kNone && lr == pusher[q] && (llb & 0xFF) == rp_meta_lut(emeta[q])) {
@@ -232,12 +265,16 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
   if ((uint32_t)lane < n_lp && !((any_matched >> lane) & 1ull)) {
     if (a.rec_kid[(size_t)lp_rec * 26 + (lp_lb & 0xFF)] == 0u) {
       const uint32_t k = atomicAdd(&c.n_born, 1u);
+      if (k >= a.rec_cap) {
+        atomicMin(&c.first_change, a.rec_T[lp_rec]);   // no room even to note it: the cut falls in front of its pusher
+      } else {
       a.born[(size_t)k * 6 + 0] = lp_rec;
       a.born[(size_t)k * 6 + 1] = lp_lb & 0xFF;
       a.born[(size_t)k * 6 + 2] = lp_lb >> 8;
       a.born[(size_t)k * 6 + 3] = gid;
       a.born[(size_t)k * 6 + 4] = __float_as_uint(lp_d);
       a.born[(size_t)k * 6 + 5] = lp_s;
+      }
     }
   }
 }
@@ -269,7 +306,7 @@ __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lan
     while (vm) {
       const int k = __ffsll((long long)vm) - 1;
       vm &= vm - 1;
-      const unsigned long long Tk = __shfl(eT[q2], k);
+      const unsigned long long Tk = rl_u64(eT[q2], k);
       rank[0] += (Tk < eT[0]) ? 1u : 0u;
       rank[1] += (Tk < eT[1]) ? 1u : 0u;
     }
@@ -284,8 +321,8 @@ __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lan
     const unsigned long long m0 = __ballot(valid[0] && rank[0] == i);
     const unsigned long long m1 = __ballot(valid[1] && rank[1] == i);
     uint32_t ecode;
-    if (m0) ecode = __shfl(code[0], __ffsll((long long)m0) - 1);
-    else if (m1) ecode = __shfl(code[1], __ffsll((long long)m1) - 1);
+    if (m0) ecode = rl_u32(code[0], __ffsll((long long)m0) - 1);
+    else if (m1) ecode = rl_u32(code[1], __ffsll((long long)m1) - 1);
     else break;
     const uint32_t r = ecode >> 5, lut = ecode & 31;
     bool to_raise;
@@ -315,8 +352,12 @@ __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lan
 // so a ranking costs what changed, not what exists.
 constexpr uint32_t kSimMax = 1024;   // records of one excursion the ranking handles (Cfg::smax <= this)
 struct SimLds {
-  unsigned short child[(kSimMax + 1) * 26];   // [position in the member list + 1 (0: the base record)][lut] -> member
-  uint32_t info[kSimMax];                     // lut | bucket << 8 | live << 16 | poisoned << 17 | has an unlisted child << 18
+  // the live children of every record as CSR: kids[first[pl] .. first[pl + 1]) in LUT order, pl = position of the pusher in
+  // the member list + 1 (0: the base record)
+  uint32_t cnt[kSimMax + 2];
+  unsigned short first[kSimMax + 2], kids[kSimMax];
+  uint32_t wave_tot[kRpThreads / 64];
+  uint32_t info[kSimMax];                     // lut | bucket << 8 | live << 16 | poisoned << 17 | has an unlisted child << 18 | pusher's position << 19
   unsigned short next[kSimMax], rank[kSimMax];
   uint32_t pend_key[kSimMax];                 // pending records at the restart point: bucket << 24 | pusher rank << 5 | lut
   unsigned short pend_j[kSimMax], sorted[kSimMax];
@@ -340,7 +381,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   const uint32_t old_n = a.sub_n[base];
   if (p > old_n) p = old_n;
   __syncthreads();
-  for (uint32_t i = tid; i < (n + 1) * 26; i += kRpThreads) L.child[i] = 0xFFFF;
+  for (uint32_t i = tid; i < n + 2; i += kRpThreads) L.cnt[i] = 0;
   for (int i = tid; i < nb; i += kRpThreads) { L.head[i] = 0xFFFF; L.tail[i] = 0xFFFF; }
   if (tid == 0) { L.n_pend = 0; L.flag_rank = 0xFFFFFFFFu; }
   __syncthreads();
@@ -356,8 +397,52 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     if (T != rp::kNever && (uint32_t)(T & rp::kRankMask) <= p) rk = (uint32_t)(T & rp::kRankMask);   // it popped in front of the restart point
     L.info[j] = (m & 0x1FFFFu) | (a.rec_poison[r] ? (1u << 17) : 0u) | (m & (1u << 18)) | (pl << 19);
     L.rank[j] = (unsigned short)rk;
-    if (rp::rp_meta_live(m)) L.child[pl * 26 + rp::rp_meta_lut(m)] = (unsigned short)j;
+    if (rp::rp_meta_live(m)) atomicAdd(&L.cnt[pl], 1u);
     if (rk != 0xFFFF && (m & (1u << 18))) atomicMin(&L.flag_rank, rk);   // ranked, but a child of it is not in the list
+  }
+  __syncthreads();
+  {
+    // first[] = exclusive prefix of cnt[0 .. n]: five consecutive entries per thread, wave scan, wave totals
+    constexpr int kPer = (kSimMax + 2 + kRpThreads - 1) / kRpThreads;
+    uint32_t v[kPer], sum = 0;
+    for (int k = 0; k < kPer; ++k) {
+      const uint32_t i = tid * kPer + k;
+      v[k] = i <= n ? L.cnt[i] : 0u;
+      sum += v[k];
+    }
+    uint32_t inc = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) L.wave_tot[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < (tid >> 6); ++w) before += L.wave_tot[w];
+    uint32_t run = before + inc - sum;
+    for (int k = 0; k < kPer; ++k) {
+      const uint32_t i = tid * kPer + k;
+      if (i <= n + 1) L.first[i] = (unsigned short)run;
+      run += v[k];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n + 2; i += kRpThreads) L.cnt[i] = 0;
+  __syncthreads();
+  for (uint32_t j = tid; j < n; j += kRpThreads) {
+    const uint32_t inf = L.info[j];
+    if ((inf >> 16) & 1u) L.kids[L.first[inf >> 19] + atomicAdd(&L.cnt[inf >> 19], 1u)] = (unsigned short)j;
+  }
+  __syncthreads();
+  for (uint32_t pl = tid; pl <= n; pl += kRpThreads) {   // a record's children in LUT order (26 at most)
+    const uint32_t f = L.first[pl], e = L.first[pl + 1];
+    for (uint32_t x = f + 1; x < e; ++x) {
+      const unsigned short jj = L.kids[x];
+      const uint32_t key = L.info[jj] & 0x1F;
+      uint32_t y = x;
+      while (y > f && (L.info[L.kids[y - 1]] & 0x1F) > key) { L.kids[y] = L.kids[y - 1]; --y; }
+      L.kids[y] = jj;
+    }
   }
   __syncthreads();
   // a record with an unlisted child in front of the restart point: the ranking ends behind it
@@ -422,9 +507,12 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       if (inf & (1u << 18)) { truncated = true; break; }   // a child of it is not in the list: stop behind it
       // its children enter their buckets in LUT order
       uint32_t jv = 0xFFFF, jinfo = 0;
-      if (lane < 26) {
-        jv = L.child[(j + 1) * 26 + lane];
-        if (jv != 0xFFFF) jinfo = L.info[jv];
+      {
+        const uint32_t f = L.first[j + 1], e = L.first[j + 2];
+        if ((uint32_t)lane < e - f) {
+          jv = L.kids[f + lane];
+          jinfo = L.info[jv];
+        }
       }
       unsigned long long kids = __ballot(jv != 0xFFFF);
       while (kids) {
@@ -463,12 +551,13 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   __syncthreads();
 }
 
-// SCAN phase: tiles of kRpThreads items by ticket; exclusive prefix of the four counts per item
-__device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32_t n) {
+// SCAN: tiles of kRpThreads items by ticket; exclusive prefix of the four counts per item, F::count / F::apply per item,
+// totals -> tot[0..3] (atomic stores), a wait that does not end -> *err |= 64
+template <class F>
+__device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, uint32_t* tot, uint32_t* err) {
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_wave[kRpThreads / 64][4];
   __shared__ uint32_t s_prefix[4];
-  rp::Ctl& c = *a.ctl;
   const uint32_t tiles = (n + kRpThreads - 1) / kRpThreads;
   const uint32_t gen = sc.ticket[1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -480,7 +569,7 @@ __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32
     if (tile >= tiles) break;
     const uint32_t i = tile * kRpThreads + threadIdx.x;
     rp::Cnt4 cnt = {{0, 0, 0, 0}};
-    if (i < n) cnt = rp::rp_scan_count(a, i);
+    if (i < n) cnt = f.count(i);
     // exclusive scan inside the tile: wave scan by shuffles, wave totals through LDS
     rp::Cnt4 ex;
     for (int k = 0; k < 4; ++k) {
@@ -518,7 +607,7 @@ __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32
           const unsigned long long w = __hip_atomic_load(sc.desc + (size_t)(t - 1) * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint32_t tag = (uint32_t)(w >> 32);
           if ((tag >> 2) != gen || (tag & 3u) == 0u) {
-            if (++spins > kRpSpinMax) { atomicOr(&c.error, 64u); break; }
+            if (++spins > kRpSpinMax) { atomicOr(err, 64u); break; }
             __builtin_amdgcn_s_sleep(1);
             continue;
           }
@@ -529,17 +618,27 @@ __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32
         __hip_atomic_store(d, ((unsigned long long)((gen << 2) | 2u) << 32) | (prefix + agg[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       s_prefix[k] = prefix;
-      if (tile == tiles - 1) atomicExch(&c.scan_tot[k], prefix + agg[k]);
+      if (tile == tiles - 1) atomicExch(&tot[k], prefix + agg[k]);
     }
     __syncthreads();
     if (i < n) {
       for (int k = 0; k < 4; ++k) ex.v[k] += s_prefix[k];
-      rp::rp_scan_apply(a, i, ex);
+      f.apply(i, ex);
     }
   }
-  if (n == 0 && blockIdx.x == 0 && threadIdx.x < 4) atomicExch(&c.scan_tot[threadIdx.x], 0u);
+  if (n == 0 && blockIdx.x == 0 && threadIdx.x < 4) atomicExch(&tot[threadIdx.x], 0u);
+}
+struct RpPhaseScan {   // PH_RANK / PH_PUSH
+  const rp::Args& a;
+  __device__ rp::Cnt4 count(uint32_t i) const { return rp::rp_scan_count(a, i); }
+  __device__ void apply(uint32_t i, const rp::Cnt4& ex) const { rp::rp_scan_apply(a, i, ex); }
+};
+__device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32_t n) {
+  RpPhaseScan f{a};
+  rp_scan_tiles(f, sc, n, a.ctl->scan_tot, &a.ctl->error);
 }
 
+template <bool SERIAL>
 __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
   __shared__ uint32_t s_last;
   __shared__ SimLds s_sim;
@@ -549,18 +648,18 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
   const uint32_t n = c.n_threads;
   // workgroups that have something to do (the others leave at once and are not waited for: 512 arrivals on one
   // counter cost 6 us, a phase of a few hundred items should not pay for them)
-  const bool per_wave = phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD || phase == rp::PH_RAISE_FOLD;
-  const uint32_t unit = (phase == rp::PH_SIM && a.sub_mem) ? 1 : (per_wave ? kRpThreads / 64 : kRpThreads);
+  const bool per_wave = !SERIAL && (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD || phase == rp::PH_RAISE_FOLD);
+  const uint32_t unit = (!SERIAL && phase == rp::PH_SIM) ? 1 : (per_wave ? kRpThreads / 64 : kRpThreads);
   uint32_t active = (n + unit - 1) / unit;
   if (active > gridDim.x) active = gridDim.x;
   if (active == 0) active = 1;
   if (blockIdx.x >= active) return;
   if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
     rp_scan_phase(a, sc, n);
-  } else if (phase == rp::PH_RAISE_FOLD) {
+  } else if (!SERIAL && phase == rp::PH_RAISE_FOLD) {
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
     for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves) rp_fold_raise_wave(a, w, threadIdx.x & 63);
-  } else if (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD) {
+  } else if (!SERIAL && (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD)) {
     // one wave per target
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
     const int lane = threadIdx.x & 63;
@@ -573,11 +672,11 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
         rp_fold_wave(a, w, c.cut, true, lane);
       }
     }
-  } else if (phase == rp::PH_SIM && a.sub_mem) {
+  } else if (!SERIAL && phase == rp::PH_SIM) {
     for (uint32_t w = blockIdx.x; w < n; w += active) rp_sim_block(a, a.sd_list[w], s_sim);
   } else {
     const uint32_t stride = active * kRpThreads;
-    for (uint32_t tid = blockIdx.x * kRpThreads + threadIdx.x; tid < n; tid += stride) rp_run_phase(a, phase, tid);
+    for (uint32_t tid = blockIdx.x * kRpThreads + threadIdx.x; tid < n; tid += stride) rp_run_phase<SERIAL>(a, phase, tid);
   }
   // the last workgroup to get here picks the next phase.  Every workgroup only has to have its own atomics performed
   // before it says so: the last one reads the control block through atomic read-modify-writes (the per-XCD L2s are not
@@ -589,10 +688,15 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
   __syncthreads();
   if (!s_last) return;
   __shared__ rp::Ctl s_ctl;
+  // (the scalar part and the first num_buckets + 1 entries of the five per-queue arrays)
+  const uint32_t n_scalar = offsetof(rp::Ctl, head) / 4, nq = (uint32_t)a.c.num_buckets + 1u, n_copy = n_scalar + 5u * nq;
   {
     uint32_t* src = reinterpret_cast<uint32_t*>(a.ctl);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_ctl);
-    for (uint32_t i = threadIdx.x; i < sizeof(rp::Ctl) / 4; i += kRpThreads) dst[i] = atomicAdd(&src[i], 0u);
+    for (uint32_t i = threadIdx.x; i < n_copy; i += kRpThreads) {
+      const uint32_t w = i < n_scalar ? i : n_scalar + ((i - n_scalar) / nq) * (rp::kMaxBuckets + 1) + (i - n_scalar) % nq;
+      dst[w] = atomicAdd(&src[w], 0u);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -612,7 +716,10 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
   {
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.ctl);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_ctl);
-    for (uint32_t i = threadIdx.x; i < sizeof(rp::Ctl) / 4; i += kRpThreads) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < n_copy; i += kRpThreads) {
+      const uint32_t w = i < n_scalar ? i : n_scalar + ((i - n_scalar) / nq) * (rp::kMaxBuckets + 1) + (i - n_scalar) % nq;
+      dst[w] = src[w];
+    }
   }
 }
 
