@@ -177,3 +177,71 @@ def test_reference_order_refuses_pending_robot_work():
     gm.esdf_add_new_robot_position(cfg, pose[0])
     with pytest.raises(capi.VbxError):
         gm.esdf_update(cfg, batch=False, clear_updated_flag=True)
+
+
+def _full_resolution_lockstep(n_frames, env=None):
+    """BASELINE configs[3] at full size: 640x480 room stream, 0.05 m voxels, Fast integration + incremental ESDF update
+    after every frame, reference_order = 1, block list in the iteration order of the reference's own container; the
+    whole layer (distances bit for bit, flags, parents) is compared after the last frame and half way."""
+    from voxblox_amd import capi, scenes
+    import oracle_py as O
+    L = O.lib()
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        voxel = 0.05
+        L.orc_fast_reset_counter_set(0)
+        om = O.OracleMap(voxel, 16)
+        oi = om.tsdf_integrator("fast", O.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+        oe = om.esdf_integrator(O.esdf_cfg(min_distance_m=2 * voxel))
+        gm = capi.Map(voxel, 16, max_blocks=8192)
+        gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+        ge = capi.esdf_cfg(min_distance_m=2 * voxel, reference_order=1)
+        pops = 0
+        for f in range(n_frames):
+            pose, pts, col = scenes.room_frame(f, 100)
+            L.orc_fast_reset_counter_set(0)
+            oi.integrate(pose[0], pose[1], pts, col)
+            gm.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+            lst = _updated_esdf_blocks_in_container_order(om)
+            oe.update_from_tsdf_layer(True)
+            gm.esdf_update_blocks(ge, lst, incremental=True)
+            gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
+            pops += gm.counters()["esdf_sweeps"]
+            if f == n_frames // 2 or f == n_frames - 1:
+                _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")
+        st = oe.stats()
+        return pops, st
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_reference_order_full_resolution_stream_bit_exact(oracle):
+    """The BASELINE-size check (round-3 verdict: it lived in bench.py only): 8 full-resolution frames, ~600 k observed
+    voxels, every one identical to the reference's incremental layer; the replay pops exactly as often as the reference."""
+    pops, st = _full_resolution_lockstep(8)
+    assert pops == st["open_pops"] + st["raised"], (pops, st)
+
+
+def test_reference_order_small_super_steps_and_capacities(oracle):
+    """The same stream with the replay's knobs turned down so that every early-stop path runs on the device: 512 base
+    records per super-step, excursions cut at 64 records, 6 iterations per super-step."""
+    pops, st = _full_resolution_lockstep(3, env={"VBX_RP_KMAX": "512", "VBX_RP_SMAX": "64", "VBX_RP_MAX_ITERS": "6"})
+    assert pops == st["open_pops"] + st["raised"], (pops, st)
+
+
+def test_reference_order_one_wave_form_still_agrees(oracle):
+    """VBX_ESDF_REPLAY=0 selects the round-3 form (one wave pops open_ voxel by voxel): kept as the cross-check of the
+    parallel replay, so it has to stay bit-exact too."""
+    os.environ["VBX_ESDF_REPLAY"] = "0"
+    try:
+        sc = dict(kind="fast", voxel=0.1, n=3, cfg={})
+        _lockstep(oracle, sc, dict())
+    finally:
+        os.environ.pop("VBX_ESDF_REPLAY", None)

@@ -582,7 +582,7 @@ class ModelEsdf : public EsdfIntegrator {
           }
         }
     }
-    if (std::getenv("EOM_FILTER_LEVEL")) g_filter_level = std::atoi(std::getenv("EOM_FILTER_LEVEL"));
+    g_filter_level = std::getenv("EOM_FILTER_LEVEL") ? std::atoi(std::getenv("EOM_FILTER_LEVEL")) : 3;
     Args a{};
     a.hazard = std::getenv("EOM_NO_FILTER") ? nullptr : hazard.data();
     a.c.filter = (uint32_t)g_filter_level;

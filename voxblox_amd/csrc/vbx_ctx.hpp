@@ -68,9 +68,6 @@ struct vbx_ctx {
       rp_lists, rp_sub, rp_sub_list, rp_sim_q, rp_ord, rp_scan_desc, rp_hazard, cls_pos, cls_nb27, cls_shadow, cls_counters;
   size_t rp_vox2tgt_zeroed = 0;   // bytes of rp_vox2tgt known to be zero
   uint32_t rp_rec_cap = 0, rp_tgt_cap = 0, rp_kmax = 0, rp_smax = 0;
-  hipGraph_t rp_graph = nullptr;
-  hipGraphExec_t rp_graph_exec = nullptr;
-  std::vector<uint64_t> rp_graph_key;  // the kernel arguments the graph was captured with
   bool esdf_init = false;
   bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
   int esdf_spec_raise = 0, esdf_spec_lower = 0;  // sweeps queued ahead of the read-back (esdf_update_t)

@@ -2,8 +2,8 @@
 // Part of libvbx_hip.so's single translation unit (included by vbx_hip.hip, in order).
 //
 // k_rp_step runs ONE phase of the replay over the whole grid and lets the last workgroup to finish run rp_control,
-// which writes the next phase into the control block.  The host launches the same kernel back to back (a captured
-// graph of kRpGraphSteps launches) and looks at Ctl::done now and then: a kernel boundary is the grid-wide barrier
+// which writes the next phase into the control block.  The host launches the same kernel back to back and looks at
+// Ctl::done now and then: a kernel boundary is the grid-wide barrier
 // (1.5 - 2 us, MI355X_MICROARCH.md "boundary"), every phase gets the whole chip, no workgroup ever waits for
 // another inside a launch except in the two SCAN phases, where a tile waits for tiles with smaller tickets only
 // (chained scan with decoupled look-back: those tiles are running or done, so the wait ends).
@@ -592,33 +592,44 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
       ex.v[k] += before;
       agg[k] = total;
     }
-    // publish the aggregate, look back (one lane per component)
-    if (threadIdx.x < 4) {
-      const int k = threadIdx.x;
+    // publish the aggregates, look back: wave k owns component k and reads 64 predecessors at a time (a tile's wait is
+    // for aggregates only, which every tile publishes before it looks back — no chain of waits through the tiles)
+    if (wave < 4) {
+      const int k = wave;
       unsigned long long* d = sc.desc + (size_t)tile * 4 + k;
       uint32_t prefix = 0;
-      if (tile == 0) {
-        __hip_atomic_store(d, ((unsigned long long)((gen << 2) | 2u) << 32) | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __hip_atomic_store(d, ((unsigned long long)((gen << 2) | 1u) << 32) | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t t = tile;
-        uint32_t spins = 0;
-        while (t > 0) {
-          const unsigned long long w = __hip_atomic_load(sc.desc + (size_t)(t - 1) * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t tag = (uint32_t)(w >> 32);
-          if ((tag >> 2) != gen || (tag & 3u) == 0u) {
-            if (++spins > kRpSpinMax) { atomicOr(err, 64u); break; }
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          prefix += (uint32_t)w;
-          if ((tag & 3u) == 2u) break;
-          --t;
+      if (lane == 0)
+        __hip_atomic_store(d, ((unsigned long long)((gen << 2) | (tile == 0 ? 2u : 1u)) << 32) | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t t = tile;   // tiles [0, t) are still to be summed
+      uint32_t spins = 0;
+      while (t > 0) {
+        const bool mine = (uint32_t)lane < t;
+        unsigned long long w = 0;
+        if (mine) w = __hip_atomic_load(sc.desc + (size_t)(t - 1 - lane) * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tag = (uint32_t)(w >> 32);
+        const bool ready = mine && (tag >> 2) == gen && (tag & 3u) != 0u;
+        const bool incl = ready && (tag & 3u) == 2u;
+        const unsigned long long m_incl = __ballot(incl), m_ready = __ballot(ready), m_mine = __ballot(mine);
+        // lanes up to the first inclusive prefix (or all of mine) must be there
+        const int stop = m_incl ? (__ffsll((long long)m_incl) - 1) : 63;
+        const unsigned long long need = (stop == 63 ? ~0ull : ((2ull << stop) - 1ull)) & m_mine;
+        if ((m_ready & need) != need) {
+          if (++spins > kRpSpinMax) { if (lane == 0) atomicOr(err, 64u); break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
         }
-        __hip_atomic_store(d, ((unsigned long long)((gen << 2) | 2u) << 32) | (prefix + agg[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t v = ((need >> lane) & 1ull) ? (uint32_t)w : 0u;
+        for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_xor(v, dd);
+        prefix += v;
+        if (m_incl) break;
+        t -= (uint32_t)__popcll(m_mine);
       }
-      s_prefix[k] = prefix;
-      if (tile == tiles - 1) atomicExch(&tot[k], prefix + agg[k]);
+      if (lane == 0) {
+        if (tile != 0)
+          __hip_atomic_store(d, ((unsigned long long)((gen << 2) | 2u) << 32) | (prefix + agg[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix[k] = prefix;
+        if (tile == tiles - 1) atomicExch(&tot[k], prefix + agg[k]);
+      }
     }
     __syncthreads();
     if (i < n) {
