@@ -127,16 +127,18 @@ def cpu_baseline_frames(voxel):
     return (2, 10) if voxel >= 0.049 else (2, 4)
 
 
-def cpu_baseline(frames, kind, voxel, seconds=None):
+def cpu_baseline(frames, kind, voxel, seconds=None, window=None):
     """integratePointCloud of the reference on a FIXED sample of the same stream — the same frame list for every
     thread count in {1,2,4,...,nproc} (its own spawn-per-call threading) and for every leg of a run, so that the
-    figures are comparable: frames[0:2] untimed, median over the next frames.  `seconds` is ignored (kept for
-    callers that still pass a budget): the sample is bounded by its frame count."""
+    figures are comparable.  window = (n_warm, n_timed): frames[0:n_warm] untimed (they build the map the timed
+    frames land in), median over the next n_timed — the caller passes the GPU leg's own warm-up / timed split so
+    that both sides are timed on the SAME frames; without it 2 + 10 (2 + 4 below 0.05 m).  `seconds` is ignored
+    (kept for callers that still pass a budget): the sample is bounded by its frame count."""
     import ctypes
     O, L, use_ref = _oracle()
     cores = os.cpu_count() or 1
     counts = _thread_counts(cores)
-    n_warm, n_timed = cpu_baseline_frames(voxel)
+    n_warm, n_timed = window or cpu_baseline_frames(voxel)
     sample = frames[:n_warm + n_timed]
     by = {}
     t_all = time.time()
@@ -162,8 +164,10 @@ def cpu_baseline(frames, kind, voxel, seconds=None):
     return {"value": by[best]["value"], "unit": "Mpoints/s", "cores": int(best),
             "kind": "reference" if use_ref else "port", "host_hw_threads": cores, "by_threads": by,
             "cpu_seconds_spent": round(time.time() - t_all, 1),
+            "frames_timed": [n_warm, len(sample) - 1],
             "sample": f"{kind} integrator, {voxel:g} m voxels, frames 0..{len(sample) - 1} of the same stream for EVERY thread count "
-                      f"(the first {n_warm} untimed, median of the other {len(sample) - n_warm}), "
+                      f"(the first {n_warm} untimed, median of the other {len(sample) - n_warm}"
+                      + (" = the frames `value` is timed on" if window else "") + "), "
                       + ("reference sources compiled over dependency shims (oracle/_ref)" if use_ref
                          else "oracle restatement")}
 
@@ -286,7 +290,8 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
             batch[str(i + 1)] = compare(g, mb.esdf_dict())
     strict = compare(gpu_layer(gs), mi.esdf_dict())
     strict["ms_per_update"] = round(float(np.median(strict_ms)), 3)
-    strict["note"] = ("vbx_esdf_cfg.reference_order = 1 (the reference's queue order replayed by one wave, DESIGN 4.4), same stream, "
+    strict["note"] = ("vbx_esdf_cfg.reference_order = 1 (the reference's queue order replayed in parallel, DESIGN 4.4c), same stream, block list "
+                      "in the iteration order of the reference's own container, host wall clock of vbx_esdf_update_blocks incl. the list upload; "
                       "final layer against the reference's incremental layer: frac_differing must be 0")
     gm.close()
     gs.close()
@@ -296,6 +301,79 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
             "note": "GPU incremental stream (updateFromTsdfLayer(true) after every frame, default Config, min_diff_m 1e-3) "
                     "against the reference's own incremental stream and against its batch update of the same TSDF at the "
                     "checkpoints; distances in metres over voxels both sides observe"}
+
+
+def esdf_reference_order_leg(args, d_frames, kind, cfg, voxel, trunc, max_blocks, local_rank, warmup, steps):
+    """configs[3] with the reference's OWN result: the same frames as the timed region on a map of its own, Fast integration +
+    vbx_esdf_update(reference_order = 1) after every frame (the blocks carrying Update::kEsdf in ascending (z,y,x)); the
+    ESDF call is timed with events (device) and the host clock (wall)."""
+    import torch
+    from voxblox_amd import capi
+    gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+    gm.set_stream(torch.cuda.current_stream().cuda_stream)
+    ecfg = capi.esdf_cfg(min_distance_m=trunc / 2, reference_order=1)
+    gm.enable_timing(True)
+    ev, wall, pops, relax = [], [], 0, 0
+    for i in range(warmup + steps):
+        pose, dp, dc, n = d_frames[i % len(d_frames)]
+        gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+        t1 = time.perf_counter()
+        if i >= warmup:
+            ev.append(gm.timing()["total_ms"])
+            wall.append((t1 - t0) * 1e3)
+            c = gm.counters()
+            pops += c["esdf_sweeps"]
+            relax += c["esdf_relaxations"]
+    gm.close()
+    return {"ms_per_update": round(float(np.mean(ev)), 3), "median_ms": round(float(np.median(ev)), 3), "wall_ms_per_update": round(float(np.mean(wall)), 3),
+            "queue_pops_per_update": round(pops / steps, 1), "relaxations_per_update": round(relax / steps, 1),
+            "frames": [warmup, warmup + steps - 1],
+            "path": "vbx_esdf_cfg.reference_order = 1: updateFromTsdfBlocks' voxel walk, processRaiseSet and processOpenSet replayed in the reference's "
+                    "order by the parallel replay (DESIGN.md 4.4c); bit-identical to the reference (fidelity.reference_order_mode_vs_reference_incremental)"}
+
+
+def dropin_leg(frames, kind, voxel, warmup, steps):
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    L = O.ref_hip_lib()
+    L.orc_fast_reset_counter_set(0)
+    if hasattr(L, "orc_timing_reset"):
+        L.orc_timing_reset()
+    m = O.OracleMap(voxel, 16, L=L)
+    c = O.TsdfCfg()
+    L.orc_tsdf_cfg_default(ctypes.byref(c))
+    c.default_truncation_distance = 4 * voxel
+    it = m.tsdf_integrator(kind, c)
+    ts = []
+    tags = ("hip/tsdf_reconcile_from_host", "hip/tsdf_integrate_device", "hip/tsdf_mirror_to_host", "integrate/" + kind)
+    before = {}
+    for i in range(warmup + steps):
+        pose, pts, col = frames[i % len(frames)]
+        if i == warmup and hasattr(L, "orc_timing_get"):
+            before = {t: O.timing_get(L, t) for t in tags}
+        t0 = time.perf_counter()
+        it.integrate(pose[0], pose[1], pts, col)
+        ts.append(time.perf_counter() - t0)
+    used = ts[warmup:]
+    out = {"value": round(frames[0][1].shape[0] * len(used) / sum(used) / 1e6, 3), "unit": "Mpoints/s",
+           "ms_per_step": round(sum(used) / len(used) * 1e3, 4), "frames": [warmup, warmup + steps - 1],
+           "host_blocks_at_end": int(m.num_blocks(0)) if hasattr(m, "num_blocks") else None,
+           "note": "wall time inside " + kind.capitalize() + "TsdfIntegrator::integratePointCloud of voxblox's own class over the C-ABI (SURVEY 8(d)'s "
+                   "definition of the metric): reconcile of the host Layer, H2D of points + colours, device integration, touched blocks "
+                   "mirrored back into the host Layer; same frames as `value`"}
+    if before:
+        split = {}
+        for t in tags:
+            n1, s1 = O.timing_get(L, t)
+            n0, s0 = before[t]
+            if n1 > n0:
+                split[t] = round((s1 - s0) / (n1 - n0) * 1e3, 4)
+        out["ms_by_timer_tag"] = split
+    return out
 
 
 def cpu_mesh_baseline(frames, kind, voxel):
@@ -390,7 +468,7 @@ def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
             "step_frac": round(alg_bytes_per_step / max(device_ms_per_step * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBPS, 6),
             "device_ms_per_step": round(device_ms_per_step, 4), "all_kernels_us_per_step": round(total_us, 1),
             "note": "durations from HIP events around every launch on the launch stream (a profiled pass over the "
-                    "same stream right after the timed region; events add ~2-4 us per launch, so short kernels read "
+                    "SAME frame indices as the timed region, on a second map brought to the same state by the same warm-up; events add ~2-4 us per launch, so short kernels read "
                     "high against rocprofv3 — profiles/ holds the matching rocprofv3 --kernel-trace --stats summary); "
                     "traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of this kernel from the committed PMC passes of the "
                     "driver-shaped command (traffic_detail.source; null when that file is absent), against "
@@ -786,44 +864,64 @@ def main():
     out["stage_ms"] = stage
     out["counters_per_step"] = {k: round(v / K, 1) for k, v in acc["counters"].items() if not k.startswith("esdf")}
 
-    # ---- per-kernel profile pass over the next frames of the same stream (outside the clock)
+    # ---- per-kernel profile pass (outside the clock) over the SAME frames the clock ran over: a second map, the
+    # warm-up frames unprofiled, then the timed frame indices with an event pair around every launch
     if args.profile_frames > 0:
-        P = args.profile_frames
-        gm.enable_timing(False)
-        gm.profile(True, reset=True)
+        P = steps
+        gp = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+        gp.set_stream(torch.cuda.current_stream().cuda_stream)
+        gp.enable_timing(False)
+        for i in range(warmup):
+            pose, dp, dc, n = d_frames[i % len(d_frames)]
+            gp.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+        gp.profile(True, reset=True)
         upd = 0
         pts_prof = 0
-        for i in range(total, total + P):
+        for i in range(warmup, total):
             pose, dp, dc, n = d_frames[i % len(d_frames)]
-            gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
-            upd += gm.counters()["voxels_touched"]
+            gp.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+            upd += gp.counters()["voxels_touched"]
             pts_prof += n
-        gm.profile(False)
-        rows, _ = kernel_table(gm, 1.0)
+        gp.profile(False)
+        rows, _ = kernel_table(gp, 1.0)
+        gp.close()
+        del gp
         alg_bytes = 16.0 * pts_prof / P + 24.0 * upd / P
         out["roofline"] = roofline_from(rows, alg_bytes, stage.get("total_ms", 0.0),
                                         "16 B x points + 24 B x distinct voxels updated per frame (SURVEY 8(d))")
+        out["roofline"]["frames_profiled"] = [warmup, total - 1]
         out["kernels"] = rows[:16]
         if args.esdf:
-            gm.profile(True, reset=True)
+            ge = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+            ge.set_stream(torch.cuda.current_stream().cuda_stream)
+            ge.enable_timing(False)
             blocks = relax = 0
-            for i in range(total + P, total + 2 * P):
+            for i in range(total):
                 pose, dp, dc, n = d_frames[i % len(d_frames)]
-                gm.profile(False)
-                gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
-                gm.profile(True)
-                gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
-                c = gm.counters()
-                blocks += c["esdf_blocks"]
-                relax += c["esdf_relaxations"]
-            gm.profile(False)
-            erows, _ = kernel_table(gm, 1.0)
+                ge.profile(False)
+                ge.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+                if i == warmup:
+                    ge.profile(True, reset=True)
+                elif i > warmup:
+                    ge.profile(True)
+                ge.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+                if i >= warmup:
+                    c = ge.counters()
+                    blocks += c["esdf_blocks"]
+                    relax += c["esdf_relaxations"]
+            ge.profile(False)
+            erows, _ = kernel_table(ge, 1.0)
+            ge.close()
+            del ge
             ealg = (52.0 * 4096 * blocks + 40.0 * relax) / P
             esdf_ms = acc["esdf_ms"] / K
             out["esdf"] = {"ms_per_update": round(esdf_ms, 4),
                            "counters_per_update": {k: round(v / K, 1) for k, v in acc["esdf_cnt"].items()},
                            "roofline": roofline_from(erows, ealg, esdf_ms, "52 B x 4096 x updated blocks + 40 B x successful relaxations (SURVEY 8(d))"),
-                           "kernels": erows[:8]}
+                           "kernels": erows[:8],
+                           "path": "vbx_esdf_cfg.reference_order = 0: the order-free fixed point (masks and fixed band equal to the reference's, "
+                                   "distances inside its min_diff_m envelope: fidelity.vs_reference_*); the reference's own result on the same "
+                                   "frames: esdf.reference_order"}
     elif args.esdf:
         out["esdf"] = {"ms_per_update": round(acc["esdf_ms"] / K, 4)}
     gm.enable_timing(True)
@@ -886,10 +984,21 @@ def main():
         gh.close()
         del gh
 
+    # ---- the drop-in itself: FastTsdfIntegrator::integratePointCloud of voxblox's own class with the HIP translation
+    # units linked in (oracle/_ref/libvbxref_hip.so = the reference's headers + voxblox_amd/host/dropin/*.cc): host
+    # Layer reconciled, points copied in, integrated on the device, touched blocks mirrored back into the host Layer
+    if not args.esdf and not args.mesh and not args.no_host_path and not args.no_cpu_baseline:
+        try:
+            out["dropin_path"] = dropin_leg(frames, args.integrator, voxel, warmup, steps)
+        except Exception as e:  # a secondary leg must never take the headline line down
+            out["dropin_path"] = {"error": repr(e)[:300]}
+
     # ---- CPU reference on the same box
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(frames[:60], args.integrator, voxel, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(frames[:total], args.integrator, voxel, args.cpu_seconds,
+                                           window=(warmup, steps) if voxel >= 0.049 else None)
         if args.esdf:
+            out["esdf"]["reference_order"] = esdf_reference_order_leg(args, d_frames, kind, cfg, voxel, trunc, max_blocks, local_rank, warmup, steps)
             out["esdf"]["cpu_baseline"] = cpu_esdf_baseline(frames[:40], voxel, min(args.cpu_seconds, 12.0))
             if args.esdf_fidelity_frames > 0:
                 nf = min(args.esdf_fidelity_frames, len(frames))

@@ -176,7 +176,20 @@ def _bind(L):
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    # voxblox::timing queries: only the libraries built from the reference's sources have them
+    for name, (res, args) in {"orc_timing_get": (None, [C.c_char_p, C.POINTER(C.c_double)]), "orc_timing_reset": (None, [])}.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
     return L
+
+
+def timing_get(L, tag):
+    """(samples, total seconds) of a voxblox::timing tag in a reference-sources library (libvbxref*.so)."""
+    out = (C.c_double * 2)()
+    L.orc_timing_get(tag.encode(), out)
+    return int(out[0]), float(out[1])
 
 
 def _p(a, ct):

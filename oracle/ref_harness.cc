@@ -21,6 +21,7 @@
 #include "voxblox/utils/neighbor_tools.h"
 
 #include "vbx_oracle.h"
+#include "voxblox/utils/timing.h"
 
 using namespace voxblox;  // NOLINT
 
@@ -288,6 +289,16 @@ void orc_remove_distant_blocks(orc_map* m, int layer, const float c[3], double m
   else m->esdf.removeDistantBlocks(Point(c[0], c[1], c[2]), max_distance);
 }
 void orc_clear(orc_map* m, int layer) { if (layer == 0) m->tsdf.removeAllBlocks(); else m->esdf.removeAllBlocks(); }
+// voxblox::timing (utils/timing.h:132-194): samples and total seconds of a tag; count 0 when the tag does not exist
+void orc_timing_get(const char* tag, double out[2]) {
+  out[0] = out[1] = 0.0;
+  try {
+    out[0] = (double)voxblox::timing::Timing::GetNumSamples(std::string(tag));
+    out[1] = voxblox::timing::Timing::GetTotalSeconds(std::string(tag));
+  } catch (...) {
+  }
+}
+void orc_timing_reset() { voxblox::timing::Timing::Reset(); }
 void orc_dropin_stats(orc_map* m, uint64_t out[2]) {
   out[0] = out[1] = 0;
 #ifdef VBX_DROPIN

@@ -14,6 +14,7 @@
 #ifndef VOXBLOX_HIP_DEVICE_MIRROR_H_
 #define VOXBLOX_HIP_DEVICE_MIRROR_H_
 
+#include <atomic>
 #include <cstdint>
 #include <vector>
 
@@ -76,6 +77,10 @@ void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* esdf_layer);
 
 /// Reconcile counters of a layer's mirror (0 if none): blocks uploaded to / removed from the device so far.
 void mirrorStats(const Layer<TsdfVoxel>* tsdf_layer, uint64_t* uploaded_blocks, uint64_t* removed_blocks);
+
+/// 1 (default): EsdfIntegrator computes the reference's own result (queue order replayed on the device); 0: the order-free
+/// fixed point.  Process-wide; also exported from the drop-in as extern "C" vbx_dropin_set_esdf_reference_order(int).
+std::atomic<int>& esdfReferenceOrder();
 
 /// Sampled fingerprint of a block's voxel array: `lines` 64-byte lines spread evenly over the array
 /// (VBX_DROPIN_FINGERPRINT_LINES, default 8; 0 = every line).

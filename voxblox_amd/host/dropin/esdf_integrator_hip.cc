@@ -12,7 +12,10 @@
 
 #include <cstdlib>
 
+#include <atomic>
+
 #include "device_mirror.h"
+#include "voxblox/utils/timing.h"
 
 namespace voxblox {
 namespace hip {
@@ -51,7 +54,16 @@ void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
   CHECK_EQ(vbx_clear_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_MAP | VBX_UPDATE_DIRTY), VBX_OK) << vbx_last_error(dev.ctx);
 }
 
+std::atomic<int>& esdfReferenceOrder() {
+  static std::atomic<int> v([] {
+    const char* e = getenv("VBX_ESDF_REFERENCE_ORDER");
+    return (e && e[0]) ? (e[0] != '0' ? 1 : 0) : 1;
+  }());
+  return v;
+}
+
 namespace {
+
 vbx_esdf_cfg toC(const EsdfIntegrator::Config& c) {
   vbx_esdf_cfg o;
   vbx_esdf_cfg_default(&o);
@@ -66,13 +78,10 @@ vbx_esdf_cfg toC(const EsdfIntegrator::Config& c) {
   o.add_occupied_crust = c.add_occupied_crust;
   o.clear_sphere_radius = c.clear_sphere_radius;
   o.occupied_sphere_radius = c.occupied_sphere_radius;
-  // EsdfIntegrator::Config is the reference's struct: the switch for the reference-order replay (vbx_hip.h,
-  // vbx_esdf_cfg::reference_order) comes from the environment of the process that links the drop-in
-  static const bool reference_order = [] {
-    const char* e = getenv("VBX_ESDF_REFERENCE_ORDER");
-    return e && e[0] && e[0] != '0';
-  }();
-  o.reference_order = reference_order ? 1 : 0;
+  // EsdfIntegrator::Config is the reference's struct and has no such field: the drop-in computes the reference's own
+  // result (vbx_esdf_cfg::reference_order = 1, the queue order replayed on the device) unless the process asks for the
+  // order-free fixed point — vbx_dropin_set_esdf_reference_order(0), or VBX_ESDF_REFERENCE_ORDER=0 in its environment
+  o.reference_order = esdfReferenceOrder().load() ? 1 : 0;
   return o;
 }
 
@@ -142,11 +151,18 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
   hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);
   hip::reconcileEsdfFromHost(dev, esdf_layer_);
-  const vbx_esdf_cfg cfg = hip::toC(config_);
+  vbx_esdf_cfg cfg = hip::toC(config_);
   if (dev.esdf_pending && updated_blocks_.empty())  // clear() since addNewRobotPosition
     CHECK_EQ(vbx_esdf_integrator_clear(dev.ctx), VBX_OK) << vbx_last_error(dev.ctx);
+  if (cfg.reference_order && dev.esdf_pending) {
+    // the replay of the reference's queue order does not cover the marks addNewRobotPosition left on the device: this one
+    // update runs as the order-free fixed point (same rules, envelope of the reference's result)
+    LOG_FIRST_N(WARNING, 1) << "voxblox HIP drop-in: addNewRobotPosition work is pending; this ESDF update uses the order-free "
+                               "wavefront instead of the reference-order replay";
+    cfg.reference_order = 0;
+  }
+  timing::Timer esdf_timer("esdf");  // esdf_integrator.cc:127
   if (cfg.reference_order) {
-    CHECK(!dev.esdf_pending) << "VBX_ESDF_REFERENCE_ORDER does not cover addNewRobotPosition";
     BlockIndexList tsdf_blocks;
     tsdf_layer_->getAllUpdatedBlocks(Update::kEsdf, &tsdf_blocks);  // :105-106, in the host container's order
     const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
@@ -166,7 +182,10 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
     for (const BlockIndex& block_index : tsdf_blocks)
       if (tsdf_layer_->hasBlock(block_index)) tsdf_layer_->getBlockByIndex(block_index).updated().reset(Update::kEsdf);
   }
+  esdf_timer.Stop();
+  timing::Timer mirror_timer("hip/esdf_mirror_to_host");
   hip::mirrorEsdfToHost(dev, esdf_layer_);
+  mirror_timer.Stop();
 }
 
 void EsdfIntegrator::updateFromTsdfBlocks(const BlockIndexList& tsdf_blocks, bool incremental) {
@@ -186,6 +205,13 @@ void EsdfIntegrator::updateFromTsdfBlocks(const BlockIndexList& tsdf_blocks, boo
       << vbx_last_error(dev.ctx);
   hip::mirrorEsdfToHost(dev, esdf_layer_);
 }
+
+}  // namespace voxblox
+
+extern "C" void vbx_dropin_set_esdf_reference_order(int on) { voxblox::hip::esdfReferenceOrder().store(on ? 1 : 0); }
+extern "C" int vbx_dropin_get_esdf_reference_order() { return voxblox::hip::esdfReferenceOrder().load(); }
+
+namespace voxblox {
 
 // The wavefront runs on the device inside the update calls; the queue-level entry points of the class are
 // kept for link compatibility and have nothing left to process.
