@@ -177,7 +177,9 @@ def _bind(L):
         fn.restype = res
         fn.argtypes = args
     # voxblox::timing queries: only the libraries built from the reference's sources have them
-    for name, (res, args) in {"orc_timing_get": (None, [C.c_char_p, C.POINTER(C.c_double)]), "orc_timing_reset": (None, [])}.items():
+    for name, (res, args) in {"orc_timing_get": (None, [C.c_char_p, C.POINTER(C.c_double)]), "orc_timing_reset": (None, []),
+                              "vbx_dropin_set_esdf_reference_order": (None, [C.c_int]),
+                              "vbx_dropin_get_esdf_reference_order": (C.c_int, [])}.items():
         if hasattr(L, name):
             fn = getattr(L, name)
             fn.restype = res

@@ -85,10 +85,19 @@ def _loaded_pair(oracle, n_frames=3):
     return dst, src
 
 
+def _same_esdf_bits(g, o):
+    assert set(g) == set(o) and len(g) > 20
+    for k in o:
+        assert np.array_equal(g[k][1], o[k][1]) and g[k][3] == o[k][3], k                      # flags, updated bits
+        assert np.array_equal(g[k][0].view(np.uint32), o[k][0].view(np.uint32)), k            # distances, bit for bit
+        assert np.array_equal(g[k][2], o[k][2]), k                                             # parents
+
+
 def test_esdf_batch_over_a_loaded_tsdf_layer(oracle):
     """esdf_server / tsdf_to_esdf: the TSDF layer comes from a file, no integrator ever ran on it.  The ESDF drop-in
-    must see it (it used to see an empty device map): flags and updated bits equal to the CPU build's, distances
-    bit-exact against the order-free form of the sign-mismatch rule (as in test_real_voxblox_esdf_class_over_hip)."""
+    must see it (it used to see an empty device map).  Drop-in default (the reference's own order, blocks visited in the
+    iteration order of the host Layer's container): the host Layer<EsdfVoxel> is IDENTICAL to what the CPU build leaves
+    in a Layer filled the same way — distances bit for bit, flags, parents, updated bits."""
     dst, src = _loaded_pair(oracle)
     n_blocks = dst.num_blocks(0)
 
@@ -99,22 +108,51 @@ def test_esdf_batch_over_a_loaded_tsdf_layer(oracle):
         c.min_diff_m = 0.0
         return c
 
-    e = dst.esdf_integrator(esdf_cfg(oracle.ref_hip_lib()))
-    e.update_from_tsdf_layer_batch()
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    assert H.vbx_dropin_get_esdf_reference_order() == 1
+    dst.esdf_integrator(esdf_cfg(H)).update_from_tsdf_layer_batch()
     st = dst.dropin_stats()
     assert st["uploaded_blocks"] == n_blocks > 20, (st, n_blocks)
-    # checker: the restatement with the order-free sign-mismatch switch, on the same TSDF
-    chk = oracle.OracleMap(VOXEL, 16)
+    # the reference's result depends on the order in which getAllAllocatedBlocks lists the blocks, i.e. on how the
+    # Layer's unordered_map was filled: the CPU-build Layer is filled exactly like dst (same keys, same sequence)
+    ref = oracle.OracleMap(VOXEL, 16, L=R)
     for k, (d, w, c, _) in src.tsdf_dict().items():
-        chk.tsdf_block_set(k, d, w, c, 7)
-    oc = esdf_cfg(oracle.lib())
-    oc.oracle_orderfree_sign_mismatch = 1
-    chk.esdf_integrator(oc).update_from_tsdf_layer_batch()
-    g, o = dst.esdf_dict(), chk.esdf_dict()
-    assert set(g) == set(o) and len(g) > 20
-    for k in o:
-        assert np.array_equal(g[k][1], o[k][1]) and g[k][3] == o[k][3], k
-        assert np.array_equal(g[k][0].view(np.uint32), o[k][0].view(np.uint32)), k
+        ref.tsdf_block_set(k, d, w, c, 7)
+    ref.esdf_integrator(esdf_cfg(R)).update_from_tsdf_layer_batch()
+    _same_esdf_bits(dst.esdf_dict(), ref.esdf_dict())
+
+
+def test_esdf_batch_order_free_switch(oracle):
+    """vbx_dropin_set_esdf_reference_order(0): the order-free fixed point instead — flags and updated bits equal to the CPU
+    build's, distances bit-exact against the order-free form of the sign-mismatch rule (as in
+    test_real_voxblox_esdf_class_over_hip)."""
+    H = oracle.ref_hip_lib()
+    H.vbx_dropin_set_esdf_reference_order(0)
+    try:
+        dst, src = _loaded_pair(oracle)
+
+        def esdf_cfg(L):
+            c = oracle.EsdfCfg()
+            L.orc_esdf_cfg_default(C.byref(c))
+            c.min_distance_m = 2 * VOXEL
+            c.min_diff_m = 0.0
+            return c
+
+        dst.esdf_integrator(esdf_cfg(H)).update_from_tsdf_layer_batch()
+        # checker: the restatement with the order-free sign-mismatch switch, on the same TSDF
+        chk = oracle.OracleMap(VOXEL, 16)
+        for k, (d, w, c, _) in src.tsdf_dict().items():
+            chk.tsdf_block_set(k, d, w, c, 7)
+        oc = esdf_cfg(oracle.lib())
+        oc.oracle_orderfree_sign_mismatch = 1
+        chk.esdf_integrator(oc).update_from_tsdf_layer_batch()
+        g, o = dst.esdf_dict(), chk.esdf_dict()
+        assert set(g) == set(o) and len(g) > 20
+        for k in o:
+            assert np.array_equal(g[k][1], o[k][1]) and g[k][3] == o[k][3], k
+            assert np.array_equal(g[k][0].view(np.uint32), o[k][0].view(np.uint32)), k
+    finally:
+        H.vbx_dropin_set_esdf_reference_order(1)
 
 
 def test_integration_continues_on_a_loaded_layer(oracle):
@@ -231,4 +269,6 @@ def test_loaded_esdf_layer_is_uploaded_and_updated_incrementally(oracle):
         obs = (r[k][1] & 1).astype(bool)
         se += float(((g[k][0][obs] - r[k][0][obs]) ** 2).sum())
         n += int(obs.sum())
+    # (not the same bits: the frames insert new blocks into the two host Layers in different sequences — the mirror's vs the
+    # CPU integrator's — so getAllUpdatedBlocks walks them in different orders, and the reference's result depends on that walk)
     assert n > 10000 and (se / n) ** 0.5 < 1e-2, (n, (se / max(n, 1)) ** 0.5)
