@@ -689,6 +689,9 @@ int vbx_clear_keep_slots(vbx_ctx* ctx) {
   if (rc) return rc;
   const uint32_t used = ctx->h_state.pool_used;
   if (used == 0) return VBX_OK;
+  // Keeping the slots keeps every block the map ever touched: a delta map that follows a moving sensor would grow towards the
+  // whole map (no reclaim runs here).  Once the pool holds far more than the last call published, the blocks go back for real.
+  if (used > 2u * ctx->h_state.blocks_published + 256u) return vbx_clear(ctx, VBX_LAYER_TSDF);
   hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map, (float*)nullptr, (uint32_t*)nullptr,
                      VBX_LAYER_TSDF, f3{0.f, 0.f, 0.f}, -1.0, 0.0f);  // squared distance > -1: every block
   return VBX_OK;
@@ -855,7 +858,9 @@ int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n
     hipLaunchKernelGGL(k_deserialize_esdf, dim3((unsigned)n), dim3(256), 0, s, m.nvox, ctx->b_edist.as<float>(),
                        ctx->b_estate.as<uint32_t>(), ctx->b_rank.as<uint32_t>(), ctx->b_keys0.as<uint32_t>());
     hipLaunchKernelGGL(k_set_block_flags, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n,
-                       kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift), (const uint8_t*)nullptr, 0u);
+                       // voxels written from outside: not a fixed point of this map's wavefront (the next order-free update relaxes the
+                       // whole block, not its shell) and news for the host mirror (VBX_UPDATE_DIRTY)
+                       kFlagEsdfAlloc | (kFlagUpdMask << kFlagEsdfUpdShift) | kFlagEsdfUnsettled | kFlagEsdfDirty, (const uint8_t*)nullptr, 0u);
   }
   rc = sync_state(ctx);
   if (rc) return rc;

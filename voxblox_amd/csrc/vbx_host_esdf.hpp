@@ -719,6 +719,7 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     rc = rp_run(ctx, ra, &rp_pops, &rp_relax);
     if (rc) return rc;
   }
+  KLAUNCH(k_esdf_mark_unsettled, grid_for(used), dim3(256), 0, s, m, used);
   if (clear_updated_flag && !batch && !list && n)
     KLAUNCH(k_esdf_strict_clear_tsdf_bit, grid_for(n), dim3(256), 0, s, m, ctx->b_rank.as<uint32_t>(), (uint32_t)n);
   tmark(ctx, 7);

@@ -429,6 +429,15 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   }
 }
 
+// The layer a reference-order (or full-Euclidean) update leaves is not a fixed point of the order-free relaxation: if the next
+// update runs order-free, every ESDF block has to be relaxed as a whole, not only its shell (k_esdf_tile's shell_only pass)
+__global__ void k_esdf_mark_unsettled(MapDev m, uint32_t used) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= used) return;
+  const uint32_t f = m.blk_flags[s];
+  if (!(f & kFlagFree) && (f & kFlagEsdfAlloc) && !(f & kFlagEsdfUnsettled)) atomicOr(&m.blk_flags[s], kFlagEsdfUnsettled);
+}
+
 // Update::kEsdf off on the listed TSDF blocks (updateFromTsdfLayer(clear_updated_flag = true), :113-121)
 __global__ void k_esdf_strict_clear_tsdf_bit(MapDev m, const uint32_t* __restrict__ slots, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -422,7 +422,8 @@ __global__ void k_fast_seed_claims(const uint32_t* __restrict__ off, const uint3
   }
   if (r >= R) return;
   const uint32_t beg = off[r], len = off[r + 1] - beg;
-  const uint32_t t = min(len, (uint32_t)max_consecutive + 1u);
+  // (a negative max_consecutive_ray_collisions: the reference breaks at the first probe of every ray)
+  const uint32_t t = max_consecutive < 0 ? min(len, 1u) : min(len, (uint32_t)max_consecutive + 1u);
   const uint32_t cl_val = (tag_cl << s_bits) | r;
   for (uint32_t k = 0; k < t; ++k) {
     const uint32_t gid = vox[beg + k];

@@ -27,6 +27,7 @@ struct vbx_shard {
   bool worker_running = false;
   int rank = 0, world = 1, device = 0;
   ncclComm_t comm = nullptr;
+  bool dead = false;  // the communicator was aborted (world > 1): no step may run any more
   hipStream_t stream = nullptr;
   size_t nvox = 4096;
   float* d_send = nullptr;
@@ -196,6 +197,7 @@ int vbx_shard_wait(vbx_shard* s) {
 
 int vbx_shard_begin_step(vbx_shard* s) {
   if (!s) return VBX_ERR_INVALID;
+  if (s->dead) { s->err = "the shard's communicator was aborted after an allocation failure: no further step can run"; return VBX_ERR_HIP; }
   // pipelined: the exchange of the previous step may still read the OTHER set; the one that used THIS set (two steps
   // ago) was joined by the end_step in between
   for (size_t u = 0; u < set_size(s); ++u) VBXS(delta_of(s, s->cur_set, u), vbx_clear_keep_slots(delta_of(s, s->cur_set, u)));
@@ -305,6 +307,7 @@ static int exchange_and_merge(vbx_shard* s, int set, size_t used, int apply_caps
 
 int vbx_shard_end_step(vbx_shard* s, int apply_caps, float truncation_distance, float max_weight) {
   if (!s) return VBX_ERR_INVALID;
+  if (s->dead) { s->err = "the shard's communicator was aborted after an allocation failure: no further step can run"; return VBX_ERR_HIP; }
   // the exchange of the step before this one (pipelined mode) must be through: collectives are issued in step order
   int rc = join_worker(s);
   if (rc) return rc;
@@ -371,6 +374,7 @@ static int exchange_and_merge(vbx_shard* s, int set, size_t used, int apply_caps
     if (rc) {
       (void)ncclCommAbort(s->comm);
       s->comm = nullptr;
+      s->dead = true;   // every later step of this shard fails: without its communicator it must not merge other owners' blocks
       return rc;
     }
     if (n) HIPS(hipMemcpyAsync(s->d_keys_send, send_keys.data(), n * 12, hipMemcpyHostToDevice, s->stream));
