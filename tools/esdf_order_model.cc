@@ -36,6 +36,7 @@ static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 #define RP_FN static inline
 static int g_filter_level = 3;
+#define RP_INC(p) atomicAdd((p), 1u)
 #define RP_LD(x) (x)
 #define RP_LD64(x) (x)
 #include "../voxblox_amd/csrc/vbx_esdf_replay_core.hpp"

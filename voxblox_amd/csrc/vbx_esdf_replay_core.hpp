@@ -29,7 +29,8 @@
 // and rp_control, run by one thread after every phase, which picks the next.  The two SCAN phases (PH_RANK, PH_PUSH) are
 // collective: this file gives their per-item count / apply functions, the prefix sum itself lives outside.
 //
-// The includer defines RP_FN (function qualifiers), RP_LD / RP_LD64 (coherent read of a word other workgroups updated
+// The includer defines RP_FN (function qualifiers), RP_INC (returning increment of a counter that every caller in a wave
+// shares: the device sends one atomic per wave), RP_LD / RP_LD64 (coherent read of a word other workgroups updated
 // with atomics) and provides atomicAdd / atomicCAS / atomicMin / atomicOr / atomicExch on uint32_t and unsigned long long.
 #pragma once
 
@@ -261,7 +262,7 @@ RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
   if (atomicExch(&a.tgt_dirty[t], 1u) == 0u) {
     Ctl& c = *a.ctl;
     const uint32_t w = 1u - c.read;
-    const uint32_t k = atomicAdd(&c.n_dirty[w], 1u);
+    const uint32_t k = RP_INC(&c.n_dirty[w]);
     a.dl[w][k] = t;   // k < tgt_cap: a target is listed at most once per list
   }
 }
@@ -272,7 +273,7 @@ RP_FN uint32_t rp_target(const Args& a, uint32_t gid) {
   const uint32_t v = a.vox2tgt[gid];
   if (v != 0u) return v - 1u;
   if (c.n_tgt >= a.tgt_cap) return kNone;   // (racy look, the exact test follows; keeps the counter from running away)
-  const uint32_t id = atomicAdd(&c.n_tgt, 1u);
+  const uint32_t id = RP_INC(&c.n_tgt);
   if (id >= a.tgt_cap) return kNone;
   const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, id + 1u);
   if (old != 0u) {  // somebody else made it: `id` stays an empty hole
@@ -497,7 +498,7 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
       a.rec_s_n[r] = a.rec_s[r];
     }
     a.rec_meta_n[r] = mn;
-    if (changed) a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+    if (changed) a.chg[RP_INC(&c.n_chg)] = r;
   }
   for (uint32_t j = 0; j < n_lp; ++j) {
     if (lp_rec[j] == kNone) continue;  // matched an existing record
@@ -647,7 +648,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
         point = a.rec_pusher[r];
         rp_mark_sub_dirty(a, point);
       }
-      a.cp[atomicAdd(&c.n_cp, 1u)] = point;
+      a.cp[RP_INC(&c.n_cp)] = point;
       a.rec_d[r] = a.rec_d_n[r];
       a.rec_s[r] = a.rec_s_n[r];
       if (mn != m) {   // (bit 18 may be set by a birth in this very phase: change the other bits only)
@@ -683,7 +684,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     a.rec_d_n[r] = a.rec_d[r];
     a.rec_s_n[r] = a.rec_s[r];
     a.rec_kid[(size_t)pusher * 26 + lut] = r + 1;
-    a.cp[atomicAdd(&c.n_cp, 1u)] = pusher;
+    a.cp[RP_INC(&c.n_cp)] = pusher;
     rp_mark_sub_dirty(a, pusher);
     if (a.sub_mem) {
       const uint32_t base = a.rec_base[pusher];

@@ -584,12 +584,19 @@ int esdf_classify_parallel(vbx_ctx* ctx, const EsdfCfgDev& c, const EsdfDev& e, 
     KLAUNCH(k_cls_base, grid_for((size_t)n_list * m.nvox), dim3(256), 0, s, a);
     int rounds = 0;
     for (;; ++rounds) {
-      if (incremental) KLAUNCH(k_cls_nb, grid_for((size_t)n_list * m.nvox), dim3(256), 0, s, a);
+      if (incremental) {
+        switch (m.vps) {
+          case 8: KLAUNCH(k_cls_nb_block<8>, dim3(n_list), dim3(64), 0, s, a); break;
+          case 16: KLAUNCH(k_cls_nb_block<16>, dim3(n_list), dim3(256), 0, s, a); break;
+          default: return 0;   // (other block sizes: the one-wave walk)
+        }
+      }
       HIP_TRY(hipMemcpyAsync(h, a.counters, 16, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
+      if (getenv("VBX_RP_STATS")) fprintf(stderr, "[cls] round %d: moved %u (dup %u, blocks %u)\n", rounds, h[1], h[0], h[2]);
       if (h[0] != 0) return 0;             // a block listed twice
       if (!incremental || h[1] == 0) break;
-      if (rounds >= 64) return 0;          // (a chain of neighbour looks longer than anything a Config produces)
+      if (rounds >= 256) return 0;         // (values crossing block faces for longer than any map's walk)
       HIP_TRY(hipMemsetAsync(a.counters + 1, 0, 4, s));
     }
     KLAUNCH(k_cls_commit, grid_for((size_t)n_list * m.nvox), dim3(256), 0, s, a);

@@ -9,10 +9,10 @@
 // its own sign that is closer — with the LUT distance NOT scaled by the voxel size (:508, Q9).  Here:
 //   k_cls_base     thread per voxel of the listed blocks: the rule tree without the neighbour look, into shadow arrays
 //                  (the layer itself stays as it was so that "not yet classified" can still be read)
-//   k_cls_nb       the voxels that look at neighbours, again and again until nothing moves: a neighbour in front of the
-//                  voxel in the walk is read from the shadow, one behind it from the layer.  A voxel only depends on voxels
-//                  in front of it, so this is a fixed point of a cycle-free system (the unscaled LUT distance makes chains two
-//                  voxels long at the default Config); every round recomputes every such voxel from scratch.
+//   k_cls_nb_block the voxels that look at neighbours: a neighbour in front of the voxel in the walk is read from the shadow, one
+//                  behind it from the layer.  A voxel only depends on voxels in front of it (a cycle-free system); inside a
+//                  block the sweep follows that order (hyperplanes), across block faces the launch is repeated until nothing
+//                  moves.
 //   k_cls_commit   shadow -> layer, block flags, queue of every push (raise_ / bucket of open_) and the totals per queue
 //   k_cls_reserve  one thread: arena chunks for the totals, FIFO heads / tails into the replay's control block
 //   k_cls_push     chained scans over the walk order: the pushes land in their FIFOs in the order the reference made them
@@ -138,57 +138,99 @@ __global__ void k_cls_base(ClsArgs a) {
   a.sh_f[i] = f;
 }
 
-// updateVoxelFromNeighbors (:498-530) for the voxels that call it, against the walk's state at their moment
-__global__ void k_cls_nb(ClsArgs a) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)a.n_list * a.m.nvox) return;
-  const uint8_t f = a.sh_f[i];
-  if (!(f & kClsNb)) return;
-  const uint32_t p = (uint32_t)(i / a.m.nvox), lin = (uint32_t)(i % a.m.nvox);
-  const int vps = a.m.vps;
-  const int lx = (int)(lin % vps), ly = (int)((lin / vps) % vps), lz = (int)(lin / (vps * vps));
+// updateVoxelFromNeighbors (:498-530) for the voxels that call it, against the walk's state at their moment.
+// One workgroup per listed block.  A voxel depends on voxels IN FRONT of it in the walk only; inside a block those are the 13
+// neighbours with a smaller linear index, and t = x + 2 y + 4 z is smaller for every one of them (vps <= 16 ... 32: the
+// weights only have to exceed 1 and 1 + 2), so the block is swept in hyperplanes of equal t — thread (y, z) owns the one voxel
+// of its row on the plane — with the block's shadow distances in LDS: one launch settles everything inside the blocks, and a
+// launch is repeated only while values still cross block faces (chains along the walk are long: a row alternates between
+// "took the estimate of its -x neighbour" and "that one is beyond max_distance now", and per-voxel Jacobi rounds needed 25 - 200).
+template <int VPS>
+__global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
+  constexpr int NV = VPS * VPS * VPS;
+  __shared__ float s_d[NV];
+  __shared__ uint8_t s_f[NV];
+  __shared__ uint32_t s_moved;
+  const uint32_t p = blockIdx.x;
   const uint32_t slot = a.list_slots[p];
+  if (!cls_valid(a, slot)) return;
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)p * NV;
+  for (int i = tid; i < NV; i += VPS * VPS) { s_d[i] = a.sh_d[base + i]; s_f[i] = a.sh_f[base + i]; }
+  if (tid == 0) s_moved = 0;
+  __syncthreads();
   const EsdfCfgDev& c = a.c;
-  // the voxel as k_cls_base left it: sign * default, not fixed
-  const float td = a.m.dist[slot * a.m.nvox + lin];
-  const float vd = (float)signum(td) * c.default_distance;
-  float new_d = vd;
-  bool hit = false;
-  for (int idx = 0; idx < 26 && !hit; ++idx) {
-    int nx = lx + c_nb_off[idx][0], ny = ly + c_nb_off[idx][1], nz = lz + c_nb_off[idx][2];
-    int cx = 1, cy = 1, cz = 1;
-    if (nx < 0) { nx += vps; cx = 0; } else if (nx >= vps) { nx -= vps; cx = 2; }
-    if (ny < 0) { ny += vps; cy = 0; } else if (ny >= vps) { ny -= vps; cy = 2; }
-    if (nz < 0) { nz += vps; cz = 0; } else if (nz >= vps) { nz -= vps; cz = 2; }
-    const uint32_t s2 = a.nb27[(size_t)p * 27 + (cx + 3 * cy + 9 * cz)];
-    if (s2 == kInvalidSlot) continue;
-    const uint32_t nlin = (uint32_t)(nx + vps * (ny + vps * nz));
-    const uint32_t p2 = a.slot_pos[s2];
-    const bool walked = p2 != kInvalidSlot && cls_valid(a, s2);              // the walk visits the neighbour's block ...
-    const bool in_front = walked && (p2 < p || (p2 == p && nlin < lin));      // ... and has passed the neighbour
-    // getVoxelPtrByGlobalIndex: the ESDF block exists if it did before the update or the walk has reached it (:145)
-    if (!(a.m.blk_flags[s2] & kFlagEsdfAlloc) && !(walked && p2 <= p)) continue;
-    float nd;
-    uint32_t ns;
-    if (in_front) {
-      nd = a.sh_d[(size_t)p2 * a.m.nvox + nlin];
-      ns = a.sh_s[(size_t)p2 * a.m.nvox + nlin];
-    } else {
-      nd = a.e.dist[s2 * a.m.nvox + nlin];
-      ns = a.e.state[s2 * a.m.nvox + nlin];
+  const int y = tid % VPS, z = tid / VPS;
+  uint32_t moved = 0;
+  for (int t = 0; t <= 7 * (VPS - 1); ++t) {
+    const int x = t - 2 * y - 4 * z;
+    if (x >= 0 && x < VPS) {
+      const uint32_t lin = (uint32_t)(x + VPS * (y + VPS * z));
+      const uint8_t f = s_f[lin];
+      if (f & kClsNb) {
+        // the voxel as k_cls_base left it: sign * default, not fixed
+        const float td = a.m.dist[slot * NV + lin];
+        const float vd = (float)signum(td) * c.default_distance;
+        float new_d = vd;
+        bool hit = false;
+        for (int idx = 0; idx < 26 && !hit; ++idx) {
+          int nx = x + c_nb_off[idx][0], ny = y + c_nb_off[idx][1], nz = z + c_nb_off[idx][2];
+          int cx = 1, cy = 1, cz = 1;
+          if (nx < 0) { nx += VPS; cx = 0; } else if (nx >= VPS) { nx -= VPS; cx = 2; }
+          if (ny < 0) { ny += VPS; cy = 0; } else if (ny >= VPS) { ny -= VPS; cy = 2; }
+          if (nz < 0) { nz += VPS; cz = 0; } else if (nz >= VPS) { nz -= VPS; cz = 2; }
+          const uint32_t nlin = (uint32_t)(nx + VPS * (ny + VPS * nz));
+          float nd;
+          uint32_t ns;
+          if (cx == 1 && cy == 1 && cz == 1) {
+            // same block: in front of the voxel -> the shadow (LDS: this sweep's values), behind it -> the layer
+            if (nlin < lin) {
+              nd = s_d[nlin];
+              ns = a.sh_s[base + nlin];
+            } else {
+              if (!(a.m.blk_flags[slot] & kFlagEsdfAlloc)) { /* the block exists since the walk reached it (:145): zeros */ }
+              nd = a.e.dist[slot * NV + nlin];
+              ns = a.e.state[slot * NV + nlin];
+            }
+          } else {
+            const uint32_t s2 = a.nb27[(size_t)p * 27 + (cx + 3 * cy + 9 * cz)];
+            if (s2 == kInvalidSlot) continue;
+            const uint32_t p2 = a.slot_pos[s2];
+            const bool walked = p2 != kInvalidSlot && cls_valid(a, s2);   // the walk visits the neighbour's block ...
+            const bool in_front = walked && p2 < p;                       // ... and has passed it
+            // getVoxelPtrByGlobalIndex: the ESDF block exists if it did before the update or the walk has reached it (:145)
+            if (!(a.m.blk_flags[s2] & kFlagEsdfAlloc) && !in_front) continue;
+            if (in_front) {
+              nd = a.sh_d[(size_t)p2 * NV + nlin];
+              ns = a.sh_s[(size_t)p2 * NV + nlin];
+            } else {
+              nd = a.e.dist[s2 * NV + nlin];
+              ns = a.e.state[s2 * NV + nlin];
+            }
+          }
+          if (!(ns & kEsdfObserved) || nd >= c.max_distance || nd <= -c.max_distance) continue;
+          if (signum(nd) == signum(vd) && fabsf(nd) < fabsf(vd)) {
+            new_d = nd + (float)signum(vd) * (idx < 6 ? 1.0f : (idx < 18 ? (float)1.4142135623730951 : (float)1.7320508075688772));   // NOT scaled by the voxel size (:508, :522)
+            hit = true;
+          }
+        }
+        // (the state word stays as k_cls_base left it: a hit sets in_queue when the voxel is committed, :187-190; the parent is zeroed right after, :197)
+        const uint8_t f_new = hit ? (uint8_t)(f | kClsOpen | kClsHit) : (uint8_t)(f & ~(kClsOpen | kClsHit));
+        if (__float_as_uint(s_d[lin]) != __float_as_uint(new_d) || f_new != f) {
+          s_d[lin] = new_d;
+          s_f[lin] = f_new;
+          ++moved;
+        }
+      }
     }
-    if (!(ns & kEsdfObserved) || nd >= c.max_distance || nd <= -c.max_distance) continue;
-    if (signum(nd) == signum(vd) && fabsf(nd) < fabsf(vd)) {
-      new_d = nd + (float)signum(vd) * (idx < 6 ? 1.0f : (idx < 18 ? (float)1.4142135623730951 : (float)1.7320508075688772));   // NOT scaled by the voxel size (:508, :522)
-      hit = true;
-    }
+    __syncthreads();
   }
-  // (the state word stays as k_cls_base left it: a hit sets in_queue when the voxel is committed, :187-190; the parent is zeroed right after, :197)
-  const uint8_t f_new = hit ? (uint8_t)(f | kClsOpen | kClsHit) : (uint8_t)(f & ~(kClsOpen | kClsHit));
-  if (__float_as_uint(a.sh_d[i]) != __float_as_uint(new_d) || f_new != f) {
-    a.sh_d[i] = new_d;
-    a.sh_f[i] = f_new;
-    atomicAdd(&a.counters[1], 1u);
+  if (moved) atomicAdd(&s_moved, moved);
+  __syncthreads();
+  if (s_moved) {   // (a block that did not move leaves its shadow alone: readers of other blocks see the same bits)
+    for (int i = tid; i < NV; i += VPS * VPS)
+      if (s_f[i] & kClsNb) { a.sh_d[base + i] = s_d[i]; a.sh_f[base + i] = s_f[i]; }
+    if (tid == 0) atomicAdd(&a.counters[1], s_moved);
   }
 }
 

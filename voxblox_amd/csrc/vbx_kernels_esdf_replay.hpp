@@ -9,6 +9,18 @@
 // (chained scan with decoupled look-back: those tiles are running or done, so the wait ends).
 
 #define RP_FN __device__ inline
+// returning increment of a counter shared by every lane that gets here together: one atomic per wave (a single address
+// takes ~90 atomics per microsecond; a PLACE phase asks for tens of thousands of target / dirty-list slots)
+__device__ inline uint32_t rp_wave_inc(uint32_t* ctr) {
+  const unsigned long long mask = __ballot(1);
+  const int lane = (int)(threadIdx.x & 63);
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(ctr, (uint32_t)__popcll(mask));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+#define RP_INC(p) rp_wave_inc(p)
 #define RP_LD(x) atomicAdd(&(x), 0u)
 #define RP_LD64(x) atomicAdd(&(x), 0ull)
 #include "vbx_esdf_replay_core.hpp"
