@@ -100,6 +100,10 @@ struct Ctl {
   uint32_t n_chg, n_born, n_sd, n_cp;
   uint32_t k_limit;                          // base records from here on cannot take part (event list overflow)
   unsigned long long first_change, smax_cut;
+  // (device wrapper) n_threads | phase << 32 | launch number mod 64 << 40 of the step the NEXT launch runs, stored and read
+  // as one word: a workgroup the dispatcher starts after its own launch's control step already ran must not take the next
+  // step's phase for its own
+  unsigned long long hdr;
   uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
   // statistics
   unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank;
@@ -641,7 +645,9 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
   if (item < c.a_chg) {
     const uint32_t r = a.chg[item];
     if (p == 26) {
-      const uint32_t m = a.rec_meta[r], mn = a.rec_meta_n[r];
+      // (bit 18 of rec_meta may be set by a birth in this very phase, after FOLD copied the word to rec_meta_n: it is not
+      // part of the comparison — a base record, whose other bits never change, would be sent to its pusher otherwise)
+      const uint32_t mn = a.rec_meta_n[r] & ~(1u << 18), m = a.rec_meta[r] & ~(1u << 18);
       uint32_t point = r;
       if (mn != m) {
         // liveness / bucket of an excursion record: the change happened at its pusher's pop
@@ -651,9 +657,9 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
       a.cp[RP_INC(&c.n_cp)] = point;
       a.rec_d[r] = a.rec_d_n[r];
       a.rec_s[r] = a.rec_s_n[r];
-      if (mn != m) {   // (bit 18 may be set by a birth in this very phase: change the other bits only)
+      if (mn != m) {   // (change the other bits only)
         atomicAnd(&a.rec_meta[r], (1u << 18));
-        atomicOr(&a.rec_meta[r], mn & ~(1u << 18));
+        atomicOr(&a.rec_meta[r], mn);
       }
     }
     const uint32_t t = a.rec_tgts[(size_t)r * 27 + p];

@@ -204,6 +204,11 @@ void vbx_destroy(vbx_ctx* ctx) {
                   &ctx->b_eraised, &ctx->b_eactive, &ctx->b_mesh_list, &ctx->b_mesh_cnt, &ctx->b_mesh_off,
                   &ctx->b_mesh_tab, &ctx->b_mesh_verts, &ctx->b_mesh_normals, &ctx->b_mesh_colors, &ctx->b_bstart, &ctx->b_mgather, &ctx->b_fin};
   for (DBuf* b : bufs) b->release();
+  DBuf* rp_bufs[] = {&ctx->rp_ctl, &ctx->rp_nbslot, &ctx->rp_chunk_tab, &ctx->rp_rec_u32, &ctx->rp_rec_T, &ctx->rp_rec_kid,
+                     &ctx->rp_rec_tgts, &ctx->rp_rec_push, &ctx->rp_vox2tgt, &ctx->rp_tgt_u32, &ctx->rp_tgt_ev, &ctx->rp_dl,
+                     &ctx->rp_lists, &ctx->rp_sub, &ctx->rp_sub_list, &ctx->rp_sim_q, &ctx->rp_ord, &ctx->rp_scan_desc,
+                     &ctx->rp_hazard, &ctx->cls_pos, &ctx->cls_nb27, &ctx->cls_shadow, &ctx->cls_counters};
+  for (DBuf* b : rp_bufs) b->release();
   ctx->h_mkeys.release();
   ctx->h_mperm.release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);

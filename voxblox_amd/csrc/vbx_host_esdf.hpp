@@ -360,7 +360,6 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
 }
 
 // ---- the parallel open set of reference_order (vbx_esdf_replay_core.hpp) ------------------------------------------
-constexpr int kRpGraphSteps = 64;   // launches per batch; the host looks at Ctl::done after some batches
 constexpr int kRpGrid = 2048;       // workgroups of k_rp_step (grid-stride over the phase's items)
 
 static uint32_t rp_env_u32(const char* name, uint32_t dflt) {
@@ -401,6 +400,10 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_push.p, 0, (size_t)rec_cap * 7 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0, (size_t)tgt_cap * 4 * 3, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_sub.p, 0, (size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4, s));
+    if (getenv("VBX_RP_POISON")) {   // debug: nothing may depend on what a fresh allocation happens to hold
+      DBuf* junk[] = {&ctx->rp_rec_T, &ctx->rp_rec_tgts, &ctx->rp_tgt_ev, &ctx->rp_dl, &ctx->rp_lists, &ctx->rp_sub_list, &ctx->rp_sim_q, &ctx->rp_ord};
+      for (DBuf* b : junk) HIP_TRY(hipMemsetAsync(b->p, 0xCD, b->cap, s));
+    }
     ctx->rp_rec_cap = rec_cap;
     ctx->rp_tgt_cap = tgt_cap;
     ctx->rp_kmax = kmax;
@@ -497,8 +500,6 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   sc.desc = ctx->rp_scan_desc.as<unsigned long long>() + 8;
   sc.ticket = ctx->rp_scan_desc.as<uint32_t>();
   sc.max_tiles = ctx->rp_rec_cap / kRpThreads + 1;
-  // (plain launches: a step lasts 5 - 60 us, the host queues one in 3 - 4 us, so the stream never runs dry; a captured
-  // graph of steps bought nothing and faulted on this ROCm when it was re-captured every update)
   const bool serial = rp_env_u32("VBX_RP_SERIAL", 0) != 0;   // debug: the emulated thread-per-item phases on the device
   rp::Args as = a;   // (serial form: no member lists, ranking from the child table)
   as.sub_mem = nullptr; as.sub_restart = nullptr;
@@ -509,15 +510,15 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
     // (a look at Ctl::done is a drain of the stream: the first ones after 4 batches of launches, later ones after 8)
     const bool look = (g % (g < 32 ? 4 : 8)) == (g < 32 ? 3u : 7u);
     {
-      for (int i = 0; i < kRpGraphSteps; ++i) {
+      for (uint32_t i = 0; i < kRpGraphSteps; ++i) {
         if (getenv("VBX_RP_SYNC")) {   // debug: which phase faults
           rp::Ctl hc;
           (void)hipMemcpy(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost);
           fprintf(stderr, "[rp-sync] step %llu phase %u n %u K %u b %u n_rec %u n_tgt %u n_chg %u n_born %u n_sd %u n_cp %u iter %u\n", hc.st_steps, hc.phase, hc.n_threads, hc.K,
                   hc.bucket, hc.n_rec, hc.n_tgt, hc.n_chg, hc.n_born, hc.n_sd, hc.n_cp, hc.iter);
         }
-        if (serial) KLAUNCH(k_rp_step<true>, dim3(kRpGrid), dim3(kRpThreads), 0, s, as, sc);
-        else KLAUNCH(k_rp_step<false>, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc);
+        if (serial) KLAUNCH(k_rp_step<true>, dim3(kRpGrid), dim3(kRpThreads), 0, s, as, sc, i);
+        else KLAUNCH(k_rp_step<false>, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc, i);
         if (getenv("VBX_RP_SYNC") && hipStreamSynchronize(s) != hipSuccess) { fprintf(stderr, "[rp-sync] fault\n"); }
       }
     }

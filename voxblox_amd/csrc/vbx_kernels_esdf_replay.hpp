@@ -35,6 +35,7 @@ __device__ inline unsigned long long rl_u64(unsigned long long x, int src) {
 }
 
 constexpr int kRpThreads = 256;
+constexpr uint32_t kRpGraphSteps = 64;   // launches per batch (a power of two; Ctl::hdr numbers the launches modulo it)
 constexpr uint32_t kRpSpinMax = 1u << 22;
 
 struct RpScan {
@@ -661,14 +662,23 @@ __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32
   rp_scan_tiles(f, sc, n, a.ctl->scan_tot, &a.ctl->error);
 }
 
+__host__ __device__ inline unsigned long long rp_hdr(uint32_t seq, uint32_t phase, uint32_t n) {
+  return (unsigned long long)n | (unsigned long long)(phase & 0xFFu) << 32 | (unsigned long long)(seq & (kRpGraphSteps - 1)) << 40;
+}
+__host__ __device__ inline uint32_t rp_hdr_seq(unsigned long long h) { return (uint32_t)(h >> 40) & 0xFFu; }
+__host__ __device__ inline uint32_t rp_hdr_phase(unsigned long long h) { return (uint32_t)(h >> 32) & 0xFFu; }
 template <bool SERIAL>
-__global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
+__global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, uint32_t seq) {
   __shared__ uint32_t s_last;
   __shared__ SimLds s_sim;
   rp::Ctl& c = *a.ctl;
-  const uint32_t phase = c.phase;
+  // Only the workgroups with work are waited for, so the control step of this launch can run before the dispatcher has
+  // started the rest of the grid; those find the header of the next launch and leave.
+  const unsigned long long hdr = __hip_atomic_load(&c.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  if (rp_hdr_seq(hdr) != seq) return;
+  const uint32_t phase = rp_hdr_phase(hdr);
   if (phase == rp::PH_DONE) return;
-  const uint32_t n = c.n_threads;
+  const uint32_t n = (uint32_t)hdr;
   // workgroups that have something to do (the others leave at once and are not waited for: 512 arrivals on one
   // counter cost 6 us, a phase of a few hundred items should not pay for them)
   const bool per_wave = !SERIAL && (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD || phase == rp::PH_RAISE_FOLD);
@@ -711,6 +721,7 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
   __syncthreads();
   if (!s_last) return;
   __shared__ rp::Ctl s_ctl;
+  __shared__ rp::Args s_args;
   // (the scalar part and the first num_buckets + 1 entries of the five per-queue arrays)
   const uint32_t n_scalar = offsetof(rp::Ctl, head) / 4, nq = (uint32_t)a.c.num_buckets + 1u, n_copy = n_scalar + 5u * nq;
   {
@@ -731,19 +742,23 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc) {
       sc.ticket[0] = 0;
       sc.ticket[1] = sc.ticket[1] + 1;
     }
-    rp::Args a2 = a;
-    a2.ctl = &s_ctl;
-    rp::rp_control(a2);
+    s_args = a;
+    s_args.ctl = &s_ctl;
+    rp::rp_control(s_args);
+    s_ctl.hdr = rp_hdr(seq + 1, s_ctl.phase, s_ctl.n_threads);
   }
   __syncthreads();
   {
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.ctl);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_ctl);
+    const uint32_t w_hdr = offsetof(rp::Ctl, hdr) / 4;
     for (uint32_t i = threadIdx.x; i < n_copy; i += kRpThreads) {
       const uint32_t w = i < n_scalar ? i : n_scalar + ((i - n_scalar) / nq) * (rp::kMaxBuckets + 1) + (i - n_scalar) % nq;
-      dst[w] = src[w];
+      if (w != w_hdr && w != w_hdr + 1) dst[w] = src[w];
     }
   }
+  // the header in one piece (a workgroup that is late only ever reads this word)
+  if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned long long*>(&a.ctl->hdr) = s_ctl.hdr;
 }
 
 // first control step of an update (PH_BEGIN), one thread
@@ -751,6 +766,7 @@ __global__ void k_rp_begin(rp::Args a) {
   a.ctl->phase = rp::PH_BEGIN;
   a.ctl->done = 0;
   rp::rp_control(a);
+  a.ctl->hdr = rp_hdr(0, a.ctl->phase, a.ctl->n_threads);
 }
 
 }  // namespace
