@@ -721,7 +721,6 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   __syncthreads();
   if (!s_last) return;
   __shared__ rp::Ctl s_ctl;
-  __shared__ rp::Args s_args;
   // (the scalar part and the first num_buckets + 1 entries of the five per-queue arrays)
   const uint32_t n_scalar = offsetof(rp::Ctl, head) / 4, nq = (uint32_t)a.c.num_buckets + 1u, n_copy = n_scalar + 5u * nq;
   {
@@ -742,9 +741,9 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
       sc.ticket[0] = 0;
       sc.ticket[1] = sc.ticket[1] + 1;
     }
-    s_args = a;
-    s_args.ctl = &s_ctl;
-    rp::rp_control(s_args);
+    rp::Args a2 = a;
+    a2.ctl = &s_ctl;
+    rp::rp_control(a2);
     s_ctl.hdr = rp_hdr(seq + 1, s_ctl.phase, s_ctl.n_threads);
   }
   __syncthreads();
