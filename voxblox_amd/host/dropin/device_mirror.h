@@ -45,6 +45,9 @@ struct DeviceMirror {
   const Layer<EsdfVoxel>* esdf_layer = nullptr;  // set by the EsdfIntegrator that shares the map
   bool esdf_pending = false;                     // addNewRobotPosition since the last update
   uint64_t last_use = 0;                         // LRU stamp of the association table
+  std::atomic<int> pins{0};                      // drop-in calls in flight on this mirror (MirrorRef); never evicted while > 0
+  uint64_t frames_integrated = 0;                // > 0: the device holds integrator state the host layer does not
+                                                 // (FastTsdfIntegrator's approximate sets and frame counter)
   HostBlockRecords tsdf_known, esdf_known;       // the blocks the device holds, as the host last saw them
   std::vector<TsdfVoxel> tsdf_staging;
   std::vector<EsdfVoxel> esdf_staging;
@@ -54,10 +57,28 @@ struct DeviceMirror {
   uint64_t uploaded_blocks = 0, removed_blocks = 0;
 };
 
-/// The device map of a host TSDF layer (created on first use).  The association table is keyed by the layer's
-/// address and bounded: beyond kMaxMirrors live entries the least recently used one is dropped — safe, because
-/// the host layer is coherent after every call and a layer that comes back is uploaded again by reconcile*().
-DeviceMirror& mirrorOf(Layer<TsdfVoxel>* tsdf_layer);
+/// A pinned reference to a mirror: while one exists the association table will not drop the mirror (a call on
+/// another thread that creates the ninth live mirror would otherwise destroy a map this call is still using).
+class MirrorRef {
+ public:
+  explicit MirrorRef(DeviceMirror* m) : m_(m) { m_->pins.fetch_add(1, std::memory_order_relaxed); }
+  MirrorRef(MirrorRef&& o) noexcept : m_(o.m_) { o.m_ = nullptr; }
+  MirrorRef(const MirrorRef&) = delete;
+  MirrorRef& operator=(const MirrorRef&) = delete;
+  ~MirrorRef() { if (m_) m_->pins.fetch_sub(1, std::memory_order_release); }
+  DeviceMirror& operator*() const { return *m_; }
+  DeviceMirror* operator->() const { return m_; }
+
+ private:
+  DeviceMirror* m_;
+};
+
+/// The device map of a host TSDF layer (created on first use), pinned for the lifetime of the returned reference.
+/// The association table is keyed by the layer's address and bounded: beyond kMaxMirrors live entries the least
+/// recently used one that is neither pinned nor waiting for an ESDF update is dropped (mirrors without integrator
+/// state of their own first) — safe, because the host layer is coherent after every call and a layer that comes back
+/// is uploaded again by reconcile*().  (If every entry is exempt the table simply grows.)
+MirrorRef mirrorOf(Layer<TsdfVoxel>* tsdf_layer);
 /// Drops the association and frees the device map (a Layer has no destructor hook the drop-in could use).
 void releaseMirror(const Layer<TsdfVoxel>* tsdf_layer);
 

@@ -113,7 +113,8 @@ EsdfIntegrator::EsdfIntegrator(const Config& config, Layer<TsdfVoxel>* tsdf_laye
 }
 
 void EsdfIntegrator::addNewRobotPosition(const Point& position) {
-  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::MirrorRef pinned = hip::mirrorOf(tsdf_layer_);
+  hip::DeviceMirror& dev = *pinned;
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);
   hip::reconcileEsdfFromHost(dev, esdf_layer_);
   const vbx_esdf_cfg cfg = hip::toC(config_);
@@ -126,7 +127,8 @@ void EsdfIntegrator::addNewRobotPosition(const Point& position) {
 }
 
 void EsdfIntegrator::updateFromTsdfLayerBatch() {
-  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::MirrorRef pinned = hip::mirrorOf(tsdf_layer_);
+  hip::DeviceMirror& dev = *pinned;
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);  // a TSDF layer that was LOADED, not integrated (esdf_server, tsdf_to_esdf)
   const vbx_esdf_cfg cfg = hip::toC(config_);
   esdf_layer_->removeAllBlocks();  // esdf_integrator.cc:95
@@ -148,7 +150,8 @@ void EsdfIntegrator::updateFromTsdfLayerBatch() {
 }
 
 void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
-  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::MirrorRef pinned = hip::mirrorOf(tsdf_layer_);
+  hip::DeviceMirror& dev = *pinned;
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);
   hip::reconcileEsdfFromHost(dev, esdf_layer_);
   vbx_esdf_cfg cfg = hip::toC(config_);
@@ -189,7 +192,8 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
 }
 
 void EsdfIntegrator::updateFromTsdfBlocks(const BlockIndexList& tsdf_blocks, bool incremental) {
-  hip::DeviceMirror& dev = hip::mirrorOf(tsdf_layer_);
+  hip::MirrorRef pinned = hip::mirrorOf(tsdf_layer_);
+  hip::DeviceMirror& dev = *pinned;
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);
   hip::reconcileEsdfFromHost(dev, esdf_layer_);
   const vbx_esdf_cfg cfg = hip::toC(config_);

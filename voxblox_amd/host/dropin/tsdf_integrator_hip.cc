@@ -70,7 +70,7 @@ uint64_t voxelFingerprint(const void* voxels, size_t bytes) {
   return h;
 }
 
-DeviceMirror& mirrorOf(Layer<TsdfVoxel>* layer) {
+MirrorRef mirrorOf(Layer<TsdfVoxel>* layer) {
   CHECK_NOTNULL(layer);
   std::lock_guard<std::mutex> lock(g_mu);
   DeviceMirror*& m = table()[layer];
@@ -78,6 +78,7 @@ DeviceMirror& mirrorOf(Layer<TsdfVoxel>* layer) {
     vbx_map_cfg have;
     CHECK_EQ(vbx_get_map_cfg(m->ctx, &have), VBX_OK) << vbx_last_error(m->ctx);
     if (have.voxel_size != layer->voxel_size() || have.voxels_per_side != layer->voxels_per_side()) {
+      CHECK_EQ(m->pins.load(), 0) << "a Layer was replaced at the same address while a drop-in call on it is running";
       destroyMirror(m);
       m = nullptr;
     }
@@ -91,28 +92,38 @@ DeviceMirror& mirrorOf(Layer<TsdfVoxel>* layer) {
     m->ctx = vbx_create(&cfg, /*device=*/0);
     CHECK(m->ctx != nullptr) << vbx_last_error(nullptr);
     if (table().size() > kMaxMirrors) {  // bound the table: drop the least recently used association
+      // never a pinned one or one with an ESDF update pending; one without integrator state of its own before one with
+      // (the Fast integrator's approximate sets and frame counter live on the device only: losing them is what the
+      // reference's own periodic reset does, tsdf_integrator.cc:564-573, but it is not free)
       const void* victim = nullptr;
       uint64_t oldest = ~0ull;
-      for (auto& kv : table())
-        if (kv.first != layer && kv.second && !kv.second->esdf_pending && kv.second->last_use < oldest) {
-          oldest = kv.second->last_use;
+      bool victim_stateful = true;
+      for (auto& kv : table()) {
+        const DeviceMirror* c = kv.second;
+        if (kv.first == layer || !c || c->esdf_pending || c->pins.load(std::memory_order_acquire) != 0) continue;
+        const bool stateful = c->frames_integrated != 0;
+        if ((victim_stateful && !stateful) || (stateful == victim_stateful && c->last_use < oldest)) {
+          oldest = c->last_use;
           victim = kv.first;
+          victim_stateful = stateful;
         }
+      }
       if (victim) {
         destroyMirror(table()[victim]);
         table().erase(victim);
       }
     }
   }
-  DeviceMirror& dev = *table()[layer];
-  dev.last_use = ++g_tick;
-  return dev;
+  DeviceMirror* dev = table()[layer];
+  dev->last_use = ++g_tick;
+  return MirrorRef(dev);   // (pinned under g_mu: an eviction on another thread sees the pin)
 }
 
 void releaseMirror(const Layer<TsdfVoxel>* layer) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = table().find(layer);
   if (it == table().end()) return;
+  CHECK_EQ(it->second->pins.load(), 0) << "releaseMirror() while a drop-in call on the layer is running";
   destroyMirror(it->second);
   table().erase(it);
 }
@@ -284,7 +295,8 @@ void integrateOnDevice(int kind, const TsdfIntegratorBase::Config& config, Layer
   // the reference's own tags (tsdf_integrator.cc:246, :311, :559), so that timing::Timing::Print() of an unmodified
   // voxblox_ros keeps its integrate/* rows; hip/* split the call into its three parts
   timing::Timer integrate_timer(kind == VBX_TSDF_SIMPLE ? "integrate/simple" : kind == VBX_TSDF_MERGED ? "integrate/merged" : "integrate/fast");
-  DeviceMirror& dev = mirrorOf(layer);
+  MirrorRef pinned = mirrorOf(layer);
+  DeviceMirror& dev = *pinned;
   timing::Timer reconcile_timer("hip/tsdf_reconcile_from_host");
   reconcileTsdfFromHost(dev, layer);  // removeDistantBlocks / loadMap / tsdfMapCallback since the last call
   reconcile_timer.Stop();
@@ -299,6 +311,7 @@ void integrateOnDevice(int kind, const TsdfIntegratorBase::Config& config, Layer
                               colors.empty() ? nullptr : &colors[0].r, points_C.size(), freespace_points ? 1 : 0),
            VBX_OK)
       << vbx_last_error(dev.ctx);
+  if (kind == VBX_TSDF_FAST) ++dev.frames_integrated;
   device_timer.Stop();
   timing::Timer mirror_timer("hip/tsdf_mirror_to_host");
   mirrorTsdfToHost(dev, layer);
