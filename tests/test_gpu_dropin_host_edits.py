@@ -272,3 +272,32 @@ def test_loaded_esdf_layer_is_uploaded_and_updated_incrementally(oracle):
     # (not the same bits: the frames insert new blocks into the two host Layers in different sequences — the mirror's vs the
     # CPU integrator's — so getAllUpdatedBlocks walks them in different orders, and the reference's result depends on that walk)
     assert n > 10000 and (se / n) ** 0.5 < 1e-2, (n, (se / max(n, 1)) ** 0.5)
+
+
+def test_more_live_layers_than_the_mirror_table_holds(oracle):
+    """The association table keeps 8 device maps (device_mirror.h).  Eleven layers are alive at once here; the first
+    one loses its device map on the way and gets it back from the host Layer (which is coherent after every call)
+    when it is used again: the result is the CPU build's, and the re-upload shows in the mirror's counters."""
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    frames = S.frames(2)
+    maps = []
+    for i in range(11):
+        m = oracle.OracleMap(VOXEL, 16, L=H)
+        it = m.tsdf_integrator("simple", _cfg(oracle, H))
+        it.integrate(frames[0][0][0], frames[0][0][1], frames[0][1], frames[0][2])
+        maps.append((m, it))
+    assert maps[0][0].dropin_stats()["uploaded_blocks"] == 0
+    m0, it0 = maps[0]
+    it0.integrate(frames[1][0][0], frames[1][0][1], frames[1][1], frames[1][2])
+    ref = oracle.OracleMap(VOXEL, 16, L=R)
+    rit = ref.tsdf_integrator("simple", _cfg(oracle, R))
+    for pose, pts, col in frames:
+        rit.integrate(pose[0], pose[1], pts, col)
+    n = _same_tsdf(m0, ref)
+    assert n > 10
+    assert m0.dropin_stats()["uploaded_blocks"] > 10, m0.dropin_stats()   # the first frame came back from the host
+    # the last map never left the table
+    m10, it10 = maps[10]
+    it10.integrate(frames[1][0][0], frames[1][0][1], frames[1][1], frames[1][2])
+    assert _same_tsdf(m10, ref) == n
+    assert m10.dropin_stats()["uploaded_blocks"] == 0
