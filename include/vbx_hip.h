@@ -103,7 +103,9 @@ typedef struct vbx_esdf_cfg {
    * 0.05 m stream where the reference needs ~58 ms on one core and the order-free default 0.3 ms).  The blocks are visited in the order
    * of the list given to vbx_esdf_update_blocks; vbx_esdf_update visits them in ascending (z,y,x) order (the
    * reference's order there is the iteration order of the caller's std::unordered_map — the drop-in passes it down).
-   * Not available while addNewRobotPosition work is pending (VBX_ERR_UNSUPPORTED). */
+   * vbx_esdf_add_new_robot_position reads the field too: with 1 its raise_ / open_ pushes and updated_blocks_
+   * insertions are kept in the reference's order for the next update, which must then run with 1 as well (and the
+   * other way round: VBX_ERR_UNSUPPORTED when the two calls disagree). */
   int32_t reference_order;
 } vbx_esdf_cfg;
 
@@ -190,8 +192,20 @@ int vbx_mesh_device_ptrs(vbx_ctx* ctx, const float** d_vertices, const float** d
  * esdf_server.cc:219-226): unknown or hallucinated voxels within cfg->clear_sphere_radius become
  * free, remaining unknown voxels within cfg->occupied_sphere_radius occupied (both
  * "hallucinated"); ESDF blocks are allocated as needed.  The wavefront work it queues is done by
- * the next vbx_esdf_update(batch == 0); a batch update discards it with the layer. */
+ * the next vbx_esdf_update(batch == 0); a batch update discards it with the layer.
+ * cfg->reference_order = 1: the entries the reference pushes into raise_ (:48) and open_ (:84) are kept, in its
+ * order — the iteration order of getSphereAroundPoint's HierarchicalIndexMap (planning_utils_inl.h:13-50,
+ * common.h:97-99: an unordered_map with AnyIndexHash, block_hash.h:20-32, reproduced on the host with the same
+ * insertions and the libstdc++ this library is built with) — and the next reference-order update starts from queues
+ * that hold them; the blocks of updated_blocks_ (:54, :80) follow that update's TSDF blocks like in :107-109. */
 int vbx_esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const float position[3]);
+/* EsdfIntegrator::updated_blocks_ as the reference-order calls of vbx_esdf_add_new_robot_position left it:
+ * order 0 = the sequence of first insertions (a caller that keeps its own IndexSet inserts them one by one),
+ * order 1 = the iteration order of the reference's IndexSet.  Up to `cap` block indices (x, y, z) are written to
+ * out_xyz (may be NULL), *n_out gets the size of the set; clear != 0 empties it (a caller that composes the list of
+ * vbx_esdf_update_blocks itself, like updateFromTsdfLayer does :105-109; vbx_esdf_update appends and empties it on
+ * its own). */
+int vbx_esdf_robot_updated_blocks(vbx_ctx* ctx, int order, int32_t* out_xyz, size_t cap, size_t* n_out, int clear);
 
 /* ---- host <-> HBM coherence for the callers that read/modify the Layer directly
  *      (mesher, publishers, removeDistantBlocks, load_map) ---- */

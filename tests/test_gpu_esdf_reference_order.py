@@ -168,15 +168,93 @@ def test_reference_order_batch_with_crust_at_finer_voxels(oracle):
     _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), "batch crust")
 
 
-def test_reference_order_refuses_pending_robot_work():
+def test_robot_position_and_update_must_agree_on_the_order():
+    """addNewRobotPosition leaves its work either as order-free marks or as ordered queue entries, depending on the
+    cfg it was called with; the update that consumes it must be of the same kind."""
     from voxblox_amd import capi
-    gm = capi.Map(0.1, 16, max_blocks=1024)
     pose, pts, col = S.frames(1)[0]
-    gm.integrate(capi.TSDF_FAST, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
-    cfg = capi.esdf_cfg(min_distance_m=0.2, clear_sphere_radius=0.5, occupied_sphere_radius=1.0, reference_order=1)
-    gm.esdf_add_new_robot_position(cfg, pose[0])
-    with pytest.raises(capi.VbxError):
-        gm.esdf_update(cfg, batch=False, clear_updated_flag=True)
+    sph = dict(min_distance_m=0.2, clear_sphere_radius=0.5, occupied_sphere_radius=1.0)
+    for first, second in ((0, 1), (1, 0)):
+        gm = capi.Map(0.1, 16, max_blocks=1024)
+        gm.integrate(capi.TSDF_FAST, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
+        gm.esdf_add_new_robot_position(capi.esdf_cfg(reference_order=first, **sph), pose[0])
+        with pytest.raises(capi.VbxError):
+            gm.esdf_update(capi.esdf_cfg(reference_order=second, **sph), batch=False, clear_updated_flag=True)
+        with pytest.raises(capi.VbxError):
+            gm.esdf_add_new_robot_position(capi.esdf_cfg(reference_order=second, **sph), pose[0])
+        gm.esdf_update(capi.esdf_cfg(reference_order=first, **sph), batch=False, clear_updated_flag=True)   # the right kind works
+
+
+@pytest.mark.parametrize("esdf_kw", [dict(), dict(multi_queue=1, num_buckets=5)])
+def test_reference_order_robot_position_stream_bit_exact(oracle, esdf_kw):
+    """EsdfServer's loop with clear_sphere_for_planning (esdf_server.cc:219-230): integrate, addNewRobotPosition,
+    updateFromTsdfLayer(true).  The spheres push into raise_ / open_ BEFORE the update (esdf_integrator.cc:48, :84) in
+    the iteration order of an unordered_map of blocks, and their blocks join the update's list through updated_blocks_
+    (:107-109); the second and later positions find hallucinated voxels (raise_ entries) and blocks that are listed
+    twice.  Every voxel of the layer must carry the reference's bits after every frame."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    sph = dict(min_distance_m=2 * voxel, clear_sphere_radius=0.6, occupied_sphere_radius=1.5, **esdf_kw)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    oe = om.esdf_integrator(oracle.esdf_cfg(**sph))
+    gm = capi.Map(voxel, 16, max_blocks=4096)
+    gt = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    ge = capi.esdf_cfg(reference_order=1, **sph)
+    n_robot_blocks = 0
+    for f, (pose, pts, col) in enumerate(S.frames(4)):
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
+        oe.add_new_robot_position(pose[0])
+        gm.esdf_add_new_robot_position(ge, pose[0])
+        if f == 2:   # two positions before one update
+            p2 = np.asarray(pose[0], np.float32) + np.float32([0.35, -0.2, 0.1])
+            oe.add_new_robot_position(p2)
+            gm.esdf_add_new_robot_position(ge, p2)
+        _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"spheres of frame {f}")
+        lst = _updated_esdf_blocks_in_container_order(om)
+        rb = gm.esdf_robot_updated_blocks(order=1, clear=True)
+        seq = gm.esdf_robot_updated_blocks(order=0)
+        assert len(seq) == 0                                  # cleared
+        n_robot_blocks += len(rb)
+        oe.update_from_tsdf_layer(True)
+        gm.esdf_update_blocks(ge, np.concatenate([lst, rb]) if len(rb) else lst, incremental=True)
+        gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
+        _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")
+    assert n_robot_blocks > 8
+    r = om.esdf_dict()
+    assert sum(int((v[1] & 2).astype(bool).sum()) for v in r.values()) > 1000   # hallucinated voxels are in play
+
+
+def test_reference_order_robot_position_through_the_plain_update(oracle):
+    """vbx_esdf_update composes the list itself: its TSDF blocks in ascending (z,y,x) order, then updated_blocks_ in the
+    IndexSet's iteration order; the oracle gets that list through updateFromTsdfBlocks."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    sph = dict(min_distance_m=2 * voxel, clear_sphere_radius=0.6, occupied_sphere_radius=1.5)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    oe = om.esdf_integrator(oracle.esdf_cfg(**sph))
+    gm = capi.Map(voxel, 16, max_blocks=4096)
+    gt = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    ge = capi.esdf_cfg(reference_order=1, **sph)
+    for f, (pose, pts, col) in enumerate(S.frames(3)):
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
+        oe.add_new_robot_position(pose[0])
+        gm.esdf_add_new_robot_position(ge, pose[0])
+        lst = _updated_esdf_blocks_in_container_order(om)
+        lst = lst[np.lexsort((lst[:, 0], lst[:, 1], lst[:, 2]))]
+        rb = gm.esdf_robot_updated_blocks(order=1)            # (left in place: the update takes it)
+        oe.update_from_tsdf_blocks(np.concatenate([lst, rb]) if len(rb) else lst, incremental=True)
+        for i in lst:   # updateFromTsdfBlocks clears nothing (:124-302): clear Update::kEsdf by hand
+            d, w, c, bits = om.tsdf_block(i)
+            om.tsdf_block_set(i, d, w, c, bits & ~4)
+        gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+        assert len(gm.esdf_robot_updated_blocks(order=1)) == 0
+        _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")
 
 
 def _full_resolution_lockstep(n_frames, env=None):

@@ -22,7 +22,7 @@ UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
 EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_get_map_cfg", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
-    "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
+    "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_esdf_robot_updated_blocks", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_blocks_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_keep_slots", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
@@ -120,6 +120,7 @@ def lib():
         "vbx_esdf_update": (C.c_int, [vp, C.POINTER(EsdfCfg), C.c_int, C.c_int]),
         "vbx_esdf_add_new_robot_position": (C.c_int, [vp, C.POINTER(EsdfCfg), f32p]),
         "vbx_esdf_update_blocks": (C.c_int, [vp, C.POINTER(EsdfCfg), i32p, C.c_size_t, C.c_int]),
+        "vbx_esdf_robot_updated_blocks": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp, C.c_int]),
         "vbx_esdf_integrator_clear": (C.c_int, [vp]),
         "vbx_selftest_unordered_order": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32]),
         "vbx_mesh_cfg_default": (None, [C.POINTER(MeshCfg)]),
@@ -301,6 +302,16 @@ class Map:
         """EsdfIntegrator::addNewRobotPosition (esdf_integrator.cc:25-92)."""
         p = np.ascontiguousarray(position, np.float32)
         self._chk(self.L.vbx_esdf_add_new_robot_position(self.h, C.byref(cfg), p.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def esdf_robot_updated_blocks(self, order=1, clear=False):
+        """updated_blocks_ as the reference-order addNewRobotPosition calls left it: (n, 3) block indices, order 0 =
+        insertion sequence, 1 = iteration order of the reference's IndexSet."""
+        n = C.c_size_t(0)
+        self._chk(self.L.vbx_esdf_robot_updated_blocks(self.h, order, None, 0, C.byref(n), 0))
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        self._chk(self.L.vbx_esdf_robot_updated_blocks(self.h, order, out.ctypes.data_as(C.POINTER(C.c_int32)), n.value,
+                                                       C.byref(n), 1 if clear else 0))
+        return out[:n.value]
 
     def num_blocks(self, layer=LAYER_TSDF):
         n = C.c_size_t(0)

@@ -4,6 +4,19 @@
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+// BlockIndex keyed like the reference's AnyIndexHash (block_hash.h:20-32): containers of these iterate in the order the
+// reference's HierarchicalIndexMap / IndexSet do, given the same insertions and the same libstdc++
+struct HostBlockIdx {
+  int32_t x, y, z;
+  bool operator==(const HostBlockIdx& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct HostAnyIndexHash {
+  size_t operator()(const HostBlockIdx& i) const {
+    const size_t sl = 17191, sl2 = sl * sl;
+    return static_cast<unsigned int>(static_cast<size_t>(i.x) + static_cast<size_t>(i.y) * sl + static_cast<size_t>(i.z) * sl2);
+  }
+};
+
 struct vbx_ctx {
   int device = 0;
   vbx_map_cfg mcfg{};
@@ -70,6 +83,25 @@ struct vbx_ctx {
   uint32_t rp_rec_cap = 0, rp_tgt_cap = 0, rp_kmax = 0, rp_smax = 0;
   bool esdf_init = false;
   bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
+  // addNewRobotPosition under reference_order: what the call left in the integrator's containers, in the reference's order
+  // (raise_ and open_ are members that survive the call, esdf_integrator.cc:48, :84; updated_blocks_ :54, :80)
+  bool esdf_robot_ordered = false;              // the pending work is in these lists (not in the order-free marks)
+  int esdf_robot_buckets = 0;                   // num_buckets the open_ entries were binned with
+  float esdf_robot_max_distance = 0.0f;
+  std::vector<uint32_t> esdf_seed_raise;        // pool voxel ids, push order
+  std::vector<uint32_t> esdf_seed_open;         // pool voxel ids, push order
+  std::vector<uint8_t> esdf_seed_open_bucket;   // bucket of every open_ entry (the distance at push time decides)
+  std::vector<HostBlockIdx> esdf_updated_seq;   // updated_blocks_: first insertions, in sequence
+  std::unordered_set<HostBlockIdx, HostAnyIndexHash> esdf_updated_set;   // the same as the reference's IndexSet (iteration order)
+  void esdf_robot_forget() {   // EsdfIntegrator::clear() (esdf_integrator.h), or the voxels the entries name are gone
+    esdf_robot_pending = false;
+    esdf_robot_ordered = false;
+    esdf_seed_raise.clear();
+    esdf_seed_open.clear();
+    esdf_seed_open_bucket.clear();
+    esdf_updated_seq.clear();
+    esdf_updated_set.clear();
+  }
   int esdf_spec_raise = 0, esdf_spec_lower = 0;  // sweeps queued ahead of the read-back (esdf_update_t)
   // mesher output of the last vbx_mesh_generate call (vbx_host_mesh.hpp)
   DBuf b_mesh_list, b_mesh_cnt, b_mesh_off, b_mesh_tab, b_mesh_verts, b_mesh_normals, b_mesh_colors;

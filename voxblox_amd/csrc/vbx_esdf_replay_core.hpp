@@ -106,7 +106,7 @@ struct Ctl {
   unsigned long long hdr;
   uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
   // statistics
-  unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank;
+  unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16], t_prev;
   // ---- per queue (bucket 0 .. num_buckets - 1, raise_ = num_buckets); the device wrapper moves the first num_buckets + 1 of each
   uint32_t head[kMaxBuckets + 1], tail[kMaxBuckets + 1];  // A: FIFO indices (entries ever popped / pushed)
@@ -903,6 +903,22 @@ RP_FN void rp_begin_superstep(const Args& a) {
   c.n_threads = K * 27;
 }
 
+// The FIRST base record could not be heard by one of its targets: event lists fill up first come, first served, and with
+// multi_queue a bucket holds the same voxels many times over, so a prefix of the bucket may well fit where all of it does
+// not.  Nothing has been committed; the super-step is taken apart and started again with a quarter of the records
+// (PH_CLEANUP sees cut == 0).  A single record that does not fit is the one hard case.
+RP_FN void rp_retry_smaller(const Args& a) {
+  Ctl& c = *a.ctl;
+  if (c.K <= 1) { c.error |= 16u; rp_stop(c); return; }
+  c.a_tgt = RP_LD(c.n_tgt);
+  if (c.a_tgt > a.tgt_cap) c.a_tgt = a.tgt_cap;
+  c.cut = 0;
+  c.n_commit = 0;
+  ++c.st_retries;
+  c.phase = PH_CLEANUP;
+  c.n_threads = c.a_tgt > c.n_rec ? c.a_tgt : c.n_rec;
+}
+
 RP_FN void rp_start_commit(const Args& a) {
   Ctl& c = *a.ctl;
   const unsigned long long first_change = RP_LD64(c.first_change), smax_cut = RP_LD64(c.smax_cut);
@@ -913,7 +929,12 @@ RP_FN void rp_start_commit(const Args& a) {
     if (kl < cut) cut = kl;
   }
   if (cut != kNever) { if (smax_cut <= first_change) ++c.st_cut_smax; else ++c.st_cut_iters; }
-  if (cut == 0) { c.error |= (k_limit == 0 ? 16u : 8u); rp_stop(c); return; }
+  if (cut == 0) {
+    if (k_limit == 0) { rp_retry_smaller(a); return; }
+    c.error |= 8u;
+    rp_stop(c);
+    return;
+  }
   c.cut = cut;
   c.a_tgt = RP_LD(c.n_tgt);
   if (c.a_tgt > a.tgt_cap) c.a_tgt = a.tgt_cap;
@@ -955,11 +976,11 @@ RP_FN void rp_control(const Args& a) {
       rp_begin_superstep(a);
       break;
     case PH_PLACE_BASE:
+      if (RP_LD(c.k_limit) == 0) { rp_retry_smaller(a); break; }
       if (c.raise) {
         c.a_tgt = RP_LD(c.n_tgt);
         if (c.a_tgt > a.tgt_cap) c.a_tgt = a.tgt_cap;
         const uint32_t kl = RP_LD(c.k_limit);
-        if (kl == 0) { c.error |= 16u; rp_stop(c); break; }
         if (kl != kNone) c.cut = (unsigned long long)kl << kRankBits;   // an event list overflowed: the records behind wait
         for (int k = 0; k <= a.c.num_buckets; ++k) c.push_cnt[k] = 0;
         c.phase = PH_RAISE_FOLD;
@@ -1038,7 +1059,8 @@ RP_FN void rp_control(const Args& a) {
       c.head[c.bucket] += nb;
       if (c.raise) c.st_raise_pops += c.n_commit; else c.st_pops += c.n_commit;
       // a cut throws the work behind it away: take about as much as got through next time, ramp up after clean steps
-      if (c.raise) { /* raise super-steps never cut */ }
+      if (c.cut == 0) c.k_cur[c.bucket] = c.K / 4 > 1 ? c.K / 4 : 1;   // rp_retry_smaller
+      else if (c.raise) c.k_cur[c.bucket] = c.k_cur[c.bucket] * 4 > a.c.kmax ? a.c.kmax : c.k_cur[c.bucket] * 4;   // (raise super-steps only cut at a full event list)
       else if (c.cut != kNever) c.k_cur[c.bucket] = nb * 2 > 32 ? nb * 2 : 32;
       else c.k_cur[c.bucket] = c.k_cur[c.bucket] * 4 > a.c.kmax ? a.c.kmax : c.k_cur[c.bucket] * 4;
       rp_begin_superstep(a);

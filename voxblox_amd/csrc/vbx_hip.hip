@@ -33,6 +33,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 
@@ -285,7 +286,7 @@ int vbx_esdf_update_blocks(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const int32_t*
 int vbx_esdf_integrator_clear(vbx_ctx* ctx) {
   if (!ctx) return VBX_ERR_INVALID;
   HIP_TRY(hipSetDevice(ctx->device));
-  ctx->esdf_robot_pending = false;
+  ctx->esdf_robot_forget();
   if (!ctx->esdf_init) return VBX_OK;
   int rc = sync_state(ctx);
   if (rc) return rc;
@@ -294,6 +295,25 @@ int vbx_esdf_integrator_clear(vbx_ctx* ctx) {
   HIP_TRY(hipMemsetAsync(ctx->b_eraised.p, 0, (size_t)used * ctx->map.nvox, ctx->stream));
   hipLaunchKernelGGL(k_clear_update_bits, grid_for(used), dim3(256), 0, ctx->stream, ctx->map, used, ~0u,
                      kFlagEsdfPendClassify | kFlagEsdfPendOpen);
+  return VBX_OK;
+}
+
+int vbx_esdf_robot_updated_blocks(vbx_ctx* ctx, int order, int32_t* out_xyz, size_t cap, size_t* n_out, int clear) {
+  if (!ctx || !n_out || (order != 0 && order != 1)) return VBX_ERR_INVALID;
+  *n_out = ctx->esdf_updated_set.size();
+  if (out_xyz) {
+    size_t k = 0;
+    auto put = [&](const HostBlockIdx& b) {
+      if (k < cap) { out_xyz[3 * k] = b.x; out_xyz[3 * k + 1] = b.y; out_xyz[3 * k + 2] = b.z; }
+      ++k;
+    };
+    if (order == 0) for (const HostBlockIdx& b : ctx->esdf_updated_seq) put(b);
+    else for (const HostBlockIdx& b : ctx->esdf_updated_set) put(b);
+  }
+  if (clear) {
+    ctx->esdf_updated_set.clear();
+    ctx->esdf_updated_seq.clear();
+  }
   return VBX_OK;
 }
 
@@ -671,6 +691,7 @@ int vbx_clear(vbx_ctx* ctx, int layer) {
     int rc = sync_state(ctx);
     if (rc) return rc;
     const uint32_t used = ctx->h_state.pool_used;
+    if (layer == VBX_LAYER_ESDF) ctx->esdf_robot_forget();  // (queue entries name voxels of the layer that goes)
     if (used == 0) return VBX_OK;
     hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map,
                        ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,

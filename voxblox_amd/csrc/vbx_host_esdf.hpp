@@ -314,6 +314,24 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
   HIP_TRY(hipMemsetAsync(&ctx->d_state->new_count, 0, 4, s));
   HIP_TRY(hipMemsetAsync(&ctx->d_state->error, 0, 4, s));
   const float radii[2] = {cfg->clear_sphere_radius, cfg->occupied_sphere_radius};
+  const bool ordered = cfg->reference_order != 0;
+  if (ordered) {
+    if (cfg->num_buckets < 1 || cfg->num_buckets > 254) {
+      ctx->fail("addNewRobotPosition (reference order): num_buckets must be in 1..254");
+      return VBX_ERR_INVALID;
+    }
+    if (ctx->esdf_robot_pending && !ctx->esdf_robot_ordered) {
+      ctx->fail("addNewRobotPosition: work of an earlier call with reference_order = 0 is pending; update first");
+      return VBX_ERR_UNSUPPORTED;
+    }
+    if (ctx->esdf_robot_pending && (ctx->esdf_robot_buckets != cfg->num_buckets || ctx->esdf_robot_max_distance != cfg->max_distance_m)) {
+      ctx->fail("addNewRobotPosition (reference order): num_buckets / max_distance_m changed while entries are queued");
+      return VBX_ERR_INVALID;
+    }
+  } else if (ctx->esdf_robot_pending && ctx->esdf_robot_ordered) {
+    ctx->fail("addNewRobotPosition: work of an earlier call with reference_order = 1 is pending; update first");
+    return VBX_ERR_UNSUPPORTED;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     SphereDev sp;
     // planning_utils_inl.h:18-26: the float loop variable, stepped exactly like the reference's
@@ -351,9 +369,59 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
       if (rc) return rc;
       e = esdf_dev(ctx);  // the ESDF arrays moved with the pool
     }
-    KLAUNCH(k_sphere_apply, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, pass);
+    if (!ordered) {
+      KLAUNCH(k_sphere_apply, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, pass);
+      continue;
+    }
+    // reference_order: the voxel changes on the device, the containers' order on the host.  block_voxel_list
+    // (esdf_integrator.cc:29-34, :60-66) is an unordered_map from block index to the block's voxels in the order of the
+    // x / y / z loops of getSphereAroundPoint (planning_utils_inl.h:25-50); a block enters the map when its first voxel
+    // comes up.  Walking the cube in that order and inserting into a map with the reference's hash gives its iteration order.
+    HIP_TRY(ctx->b_order.ensure(cube * 4));
+    HIP_TRY(ctx->b_obs.ensure(cube * 2));
+    KLAUNCH(k_sphere_apply_ordered, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, cfg->max_distance_m,
+            cfg->num_buckets, pass, ctx->b_order.as<uint32_t>(), ctx->b_obs.as<uint16_t>());
+    rc = sync_state(ctx);
+    if (rc) return rc;
+    if (ctx->h_state.error) return check_state_error(ctx);
+    const uint32_t used = ctx->h_state.pool_used;
+    std::vector<uint32_t> gids(cube);
+    std::vector<uint16_t> codes(cube);
+    std::vector<int32_t> bidx((size_t)used * 3);
+    HIP_TRY(hipMemcpy(gids.data(), ctx->b_order.p, cube * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(codes.data(), ctx->b_obs.p, cube * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(bidx.data(), m.blk_idx, (size_t)used * 12, hipMemcpyDeviceToHost));
+    std::unordered_map<HostBlockIdx, std::vector<uint32_t>, HostAnyIndexHash> block_voxel_list;
+    uint32_t last_slot = kInvalidSlot;
+    std::vector<uint32_t>* last_list = nullptr;
+    for (size_t t = 0; t < cube; ++t) {
+      if (gids[t] == kInvalidSlot) continue;
+      const uint32_t slot = gids[t] / m.nvox;
+      if (slot != last_slot) {
+        last_slot = slot;
+        last_list = &block_voxel_list[HostBlockIdx{bidx[3 * slot], bidx[3 * slot + 1], bidx[3 * slot + 2]}];
+      }
+      last_list->push_back((uint32_t)t);
+    }
+    for (const auto& kv : block_voxel_list) {
+      for (const uint32_t t : kv.second) {
+        const uint32_t code = codes[t];
+        if (code & 2u) ctx->esdf_seed_raise.push_back(gids[t]);   // :48 (before the voxel is rewritten; the order is all that matters)
+        if (code & 1u) {                                          // :54, :80
+          if (ctx->esdf_updated_set.insert(kv.first).second) ctx->esdf_updated_seq.push_back(kv.first);
+        } else if (code & 4u) {                                   // :84
+          ctx->esdf_seed_open.push_back(gids[t]);
+          ctx->esdf_seed_open_bucket.push_back((uint8_t)(code >> 8));
+        }
+      }
+    }
   }
   ctx->esdf_robot_pending = true;
+  if (ordered) {
+    ctx->esdf_robot_ordered = true;
+    ctx->esdf_robot_buckets = cfg->num_buckets;
+    ctx->esdf_robot_max_distance = cfg->max_distance_m;
+  }
   rc = sync_state(ctx);
   if (rc) return rc;
   return check_state_error(ctx);
@@ -564,9 +632,9 @@ int esdf_classify_parallel(vbx_ctx* ctx, const EsdfCfgDev& c, const EsdfDev& e, 
   HIP_TRY(ctx->cls_pos.ensure((size_t)std::max<uint32_t>(used, 1) * 4));
   HIP_TRY(ctx->cls_nb27.ensure((size_t)std::max<uint32_t>(n_list, 1) * 27 * 4));
   HIP_TRY(ctx->cls_shadow.ensure(nv * 10));
-  HIP_TRY(ctx->cls_counters.ensure(4 * 512));
+  HIP_TRY(ctx->cls_counters.ensure(4 * kClsCounters));
   HIP_TRY(hipMemsetAsync(ctx->cls_pos.p, 0xFF, (size_t)std::max<uint32_t>(used, 1) * 4, s));
-  HIP_TRY(hipMemsetAsync(ctx->cls_counters.p, 0, 4 * 512, s));
+  HIP_TRY(hipMemsetAsync(ctx->cls_counters.p, 0, 4 * kClsCounters, s));
   ClsArgs a{};
   a.m = m; a.e = e; a.c = c;
   a.incremental = incremental; a.batch_crust = batch_crust; a.num_buckets = num_buckets;
@@ -632,11 +700,46 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   const uint32_t used = ctx->h_state.pool_used;
   ctx->counters = vbx_counters{};
   if (used == 0) return VBX_OK;
-  if (ctx->esdf_robot_pending && !batch) {
-    ctx->fail("ESDF reference order: addNewRobotPosition work is pending; run that update with reference_order = 0");
+  if (ctx->esdf_robot_pending && !ctx->esdf_robot_ordered && !batch) {
+    ctx->fail("ESDF reference order: addNewRobotPosition left its work as order-free marks (that call had reference_order = 0); "
+              "run this update with reference_order = 0 too");
     return VBX_ERR_UNSUPPORTED;
   }
+  // what addNewRobotPosition left in raise_ / open_ (esdf_integrator.cc:48, :84) is in front of everything this update
+  // pushes.  A batch update drops the ESDF layer the entries point into (the reference would die on them,
+  // esdf_integrator.cc:379-381 CHECK_NOTNULL): they are dropped with it.
+  const int NB = cfg->num_buckets;
+  std::vector<std::vector<uint32_t>> seeds;
+  size_t n_seed = 0;
+  if (ctx->esdf_robot_pending && ctx->esdf_robot_ordered && !batch && (!ctx->esdf_seed_raise.empty() || !ctx->esdf_seed_open.empty())) {
+    if (ctx->esdf_robot_buckets != NB || ctx->esdf_robot_max_distance != cfg->max_distance_m) {
+      ctx->fail("ESDF reference order: num_buckets / max_distance_m differ from the ones addNewRobotPosition queued its entries with");
+      return VBX_ERR_INVALID;
+    }
+    // (an ESDF block removed since — vbx_blocks_remove, vbx_remove_distant_blocks — takes its entries along)
+    std::vector<uint32_t> flags(used);
+    HIP_TRY(hipMemcpy(flags.data(), m.blk_flags, (size_t)used * 4, hipMemcpyDeviceToHost));
+    auto alive = [&](uint32_t gid) { const uint32_t sl = gid / m.nvox; return sl < used && !(flags[sl] & kFlagFree) && (flags[sl] & kFlagEsdfAlloc); };
+    seeds.resize((size_t)NB + 1);
+    for (size_t i = 0; i < ctx->esdf_seed_open.size(); ++i)
+      if (alive(ctx->esdf_seed_open[i])) seeds[std::min<int>(ctx->esdf_seed_open_bucket[i], NB - 1)].push_back(ctx->esdf_seed_open[i]);
+    for (const uint32_t g : ctx->esdf_seed_raise)
+      if (alive(g)) seeds[NB].push_back(g);
+    for (const auto& v : seeds) n_seed += v.size();
+  }
+  // updated_blocks_ goes behind the TSDF blocks of the update (:98-100, :107-109), in the set's iteration order;
+  // updateFromTsdfBlocks(list) leaves the set alone (the caller composes the list: vbx_esdf_robot_updated_blocks)
+  std::vector<HostBlockIdx> robot_blocks;
+  if (!list) {
+    robot_blocks.assign(ctx->esdf_updated_set.begin(), ctx->esdf_updated_set.end());
+    ctx->esdf_updated_set.clear();
+    ctx->esdf_updated_seq.clear();
+  }
   ctx->esdf_robot_pending = false;
+  ctx->esdf_robot_ordered = false;
+  ctx->esdf_seed_raise.clear();
+  ctx->esdf_seed_open.clear();
+  ctx->esdf_seed_open_bucket.clear();
   EsdfDev e = esdf_dev(ctx);
   const size_t nv = (size_t)used * m.nvox;
   for (int i = 0; i < 9; ++i) ctx->ev_hit[i] = false;
@@ -674,19 +777,55 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     std::sort(v.begin(), v.end());
     h_slots.resize(v.size());
     for (size_t i = 0; i < v.size(); ++i) h_slots[i] = v[i].second;
+    if (!robot_blocks.empty()) {
+      std::unordered_map<uint64_t, uint32_t> slot_of;
+      for (uint32_t sl = 0; sl < used; ++sl)
+        if (!(flags[sl] & kFlagFree)) slot_of[pack_block_key(idx[3 * sl], idx[3 * sl + 1], idx[3 * sl + 2])] = sl;
+      for (const HostBlockIdx& b : robot_blocks) {
+        const auto it = slot_of.find(pack_block_key(b.x, b.y, b.z));
+        h_slots.push_back(it == slot_of.end() ? kInvalidSlot : it->second);   // (:139-143 skips a block the TSDF layer does not have)
+      }
+      HIP_TRY(ctx->b_rank.ensure(h_slots.size() * 4));
+    }
     n = h_slots.size();
     if (n) HIP_TRY(hipMemcpyAsync(ctx->b_rank.p, h_slots.data(), n * 4, hipMemcpyHostToDevice, s));
   }
   // queue arena: a voxel sits in open_ at most once at a time without multi_queue and in raise_ at most once per
   // update, so 2 x voxels bounds what is queued at once; multi_queue can hold more (loud failure if it does)
   // (chunks are not reused inside an update: the arena holds every push of the update)
-  const size_t n_chunks = std::max<size_t>(1024, (size_t)(cfg->multi_queue ? 16 : 4) * nv / kSqChunk + (size_t)4 * cfg->num_buckets + 64);
+  const size_t n_chunks = std::max<size_t>(1024, (size_t)(cfg->multi_queue ? 16 : 4) * nv / kSqChunk + (size_t)4 * cfg->num_buckets + 64) +
+                          n_seed / kSqChunk + (size_t)NB + 2;
   HIP_TRY(ctx->b_keys0.ensure(n_chunks * kSqChunk * 4));
   HIP_TRY(ctx->b_vals0.ensure(64));
   const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0 && cfg->num_buckets <= 254;   // (a push table entry is one byte: bucket + 1, raise_ = num_buckets)
   rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(ctx->rp_ctl.p, 0, sizeof(rp::Ctl), s));
+  if (n_seed) {
+    // the queues as addNewRobotPosition left them: chunk table rows, arena image, FIFO tails (both forms of the voxel
+    // walk start from the control block's tails / chunk_top instead of empty queues)
+    std::vector<uint32_t> image, tails((size_t)NB + 1, 0), reserved((size_t)NB + 1, 0), row;
+    uint32_t top = 0;
+    rp::Ctl* dctl = ctx->rp_ctl.as<rp::Ctl>();
+    for (int q = 0; q <= NB; ++q) {
+      const std::vector<uint32_t>& v = seeds[q];
+      if (v.empty()) continue;
+      const uint32_t chunks = (uint32_t)((v.size() + kSqChunk - 1) / kSqChunk);
+      row.resize(chunks);
+      for (uint32_t j = 0; j < chunks; ++j) row[j] = top + j;
+      image.resize((size_t)(top + chunks) * kSqChunk, 0u);
+      std::memcpy(image.data() + (size_t)top * kSqChunk, v.data(), v.size() * 4);
+      HIP_TRY(hipMemcpy(ctx->rp_chunk_tab.as<uint32_t>() + (size_t)q * n_chunks, row.data(), (size_t)chunks * 4, hipMemcpyHostToDevice));
+      top += chunks;
+      tails[q] = (uint32_t)v.size();
+      reserved[q] = chunks;
+    }
+    HIP_TRY(hipStreamSynchronize(s));   // (the memset of the control block above)
+    HIP_TRY(hipMemcpy(ctx->b_keys0.p, image.data(), image.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&dctl->tail[0], tails.data(), tails.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&dctl->reserved[0], reserved.data(), reserved.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&dctl->chunk_top, &top, 4, hipMemcpyHostToDevice));
+  }
   StrictArgs a{};
   a.m = m;
   a.e = e;
@@ -771,6 +910,14 @@ int esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_upda
       return VBX_ERR_UNSUPPORTED;
     }
     return esdf_update_strict(ctx, cfg, batch, clear_updated_flag, list, n_list, list_incremental);
+  }
+  if (ctx->esdf_robot_pending && ctx->esdf_robot_ordered) {
+    if (!batch) {
+      ctx->fail("ESDF: addNewRobotPosition queued its work in the reference's order (that call had reference_order = 1); "
+                "run this update with reference_order = 1 too");
+      return VBX_ERR_UNSUPPORTED;
+    }
+    ctx->esdf_robot_forget();   // the batch update drops the layer the entries point into
   }
   const bool full = cfg->full_euclidean_distance != 0;
   if (full && !(cfg->max_distance_m / ctx->map.voxel_size < 120.0f)) {

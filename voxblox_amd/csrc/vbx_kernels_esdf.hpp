@@ -208,6 +208,59 @@ __global__ void k_sphere_apply(MapDev m, EsdfDev e, SphereDev sp, float default_
   if ((cur & want) != want) atomicOr(&m.blk_flags[slot], want);
 }
 
+// The same two passes for reference_order: the voxel changes are applied here, but what the reference pushes into raise_ /
+// open_ and inserts into updated_blocks_ goes back to the host per cube cell (gid, or kInvalidSlot outside the sphere;
+// code: bit 0 the voxel changed (:54, :80), bit 1 raise_.push (:48), bit 2 open_.push (:84) with its bucket in bits 8-15):
+// the host puts the entries in the iteration order of the reference's HierarchicalIndexMap (esdf_add_new_robot_position).
+__global__ void k_sphere_apply_ordered(MapDev m, EsdfDev e, SphereDev sp, float default_distance, float max_distance, int num_buckets,
+                                       int mode, uint32_t* __restrict__ out_gid, uint16_t* __restrict__ out_code) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)sp.n;
+  if (t >= n * n * n) return;
+  uint64_t key;
+  uint32_t lin;
+  uint32_t gid = kInvalidSlot;
+  uint32_t code = 0;
+  if (sphere_voxel(sp, m, t, &key, &lin)) {
+    const uint32_t slot = map_find(m, key);
+    if (slot != kInvalidSlot) {  // (pool exhausted otherwise: reported through DevState::error)
+      gid = slot * m.nvox + lin;
+      const uint32_t es = e.state[gid];
+      bool changed = false;
+      if (mode == 0) {
+        if (!(es & kEsdfObserved) || (es & kEsdfHallucinated)) {
+          if (es & kEsdfHallucinated) code |= 2u;
+          e.dist[gid] = default_distance;
+          changed = true;
+        }
+      } else {
+        if (!(es & kEsdfObserved)) {
+          e.dist[gid] = -default_distance;
+          changed = true;
+        } else if (!(es & kEsdfInQueue)) {
+          // BucketQueue::push (bucket_queue.h:41-56)
+          double value = (double)e.dist[gid];
+          const double max_val = (double)max_distance;
+          if (value > max_val) value = max_val;
+          int b = (int)floor(fabs(value) / max_val * (double)(num_buckets - 1));
+          if (b >= num_buckets) b = num_buckets - 1;
+          if (b < 0) b = 0;
+          code |= 4u | ((uint32_t)b << 8);
+        }
+      }
+      if (changed) {
+        e.state[gid] = (es & 0xFFu) | kEsdfObserved | kEsdfHallucinated;  // parent.setZero()
+        code |= 1u;
+        const uint32_t want = kFlagEsdfAlloc | kFlagEsdfDirty | kFlagEsdfUnsettled;
+        const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur & want) != want) atomicOr(&m.blk_flags[slot], want);
+      }
+    }
+  }
+  out_gid[t] = gid;
+  out_code[t] = (uint16_t)code;
+}
+
 // updateFromTsdfBlocks(list): mark the listed blocks for classification
 __global__ void k_esdf_mark_listed(MapDev m, EsdfDev e, const int32_t* __restrict__ idx, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

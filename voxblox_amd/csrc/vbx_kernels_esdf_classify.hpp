@@ -20,6 +20,7 @@
 
 namespace {
 
+constexpr uint32_t kClsCounters = 1024, kClsBase = 600;   // words of ClsArgs::counters; [kClsBase + q]: entries queue q held before the walk
 constexpr uint32_t kClsWrite = 1, kClsOpen = 2, kClsRaise = 4, kClsNb = 8, kClsHit = 16;
 
 struct ClsArgs {
@@ -35,7 +36,7 @@ struct ClsArgs {
   uint32_t* sh_s;
   uint8_t* sh_f;
   uint8_t* sh_q;
-  uint32_t* counters;           // [0] duplicate list entries, [1] voxels whose neighbour look moved this round, [2] blocks walked, [8 ..] pushes per queue
+  uint32_t* counters;           // [0] duplicate list entries, [1] voxels whose neighbour look moved this round, [2] blocks walked, [8 ..] pushes per queue, [kClsBase ..] FIFO index of the walk's first push per queue
 };
 
 // a listed block that the walk really visits (:139-143)
@@ -272,18 +273,21 @@ __global__ void __launch_bounds__(256) k_cls_commit(ClsArgs a) {
 
 // arena chunks for every queue's entries; FIFO indices into the replay's control block (one thread)
 __global__ void k_cls_reserve(ClsArgs a, rp::Args ra) {
+  // (behind what addNewRobotPosition left in the queues: tails, reserved chunks and chunk_top are zero otherwise)
   rp::Ctl& c = *ra.ctl;
-  uint32_t top = 0;
+  uint32_t top = c.chunk_top;
   for (int q = 0; q <= a.num_buckets; ++q) {
-    const uint32_t n = a.counters[8 + q];
+    const uint32_t base = c.tail[q];
+    const uint32_t n = base + a.counters[8 + q];
     const uint32_t chunks = (n + rp::kChunk - 1) / rp::kChunk;
-    for (uint32_t j = 0; j < chunks; ++j) {
+    for (uint32_t j = c.reserved[q]; j < chunks; ++j) {
       if (top >= ra.max_chunks) { c.error |= 4u; break; }
       ra.chunk_tab[(size_t)q * ra.max_chunks + j] = top++;
     }
+    a.counters[kClsBase + q] = base;
     c.head[q] = 0;
     c.tail[q] = n;
-    c.reserved[q] = chunks;
+    if (chunks > c.reserved[q]) c.reserved[q] = chunks;
     c.k_cur[q] = 0;
   }
   c.chunk_top = top;
@@ -317,7 +321,7 @@ struct ClsPushScan {
     if (!m) return;
     const uint32_t gid = a.list_slots[i / a.m.nvox] * a.m.nvox + i % a.m.nvox;
     for (int k = 0; k < 4; ++k)
-      if ((m >> k) & 1u) rp::rp_queue_store(ra, q0 + k, ex.v[k], gid);
+      if ((m >> k) & 1u) rp::rp_queue_store(ra, q0 + k, a.counters[kClsBase + q0 + k] + ex.v[k], gid);
   }
 };
 __global__ void __launch_bounds__(kRpThreads) k_cls_push(ClsArgs a, rp::Args ra, RpScan sc, int q0) {

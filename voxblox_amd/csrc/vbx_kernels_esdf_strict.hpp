@@ -154,10 +154,20 @@ __global__ void __launch_bounds__(64) k_esdf_strict(StrictArgs a) {
   __shared__ StrictQueues q;
   const int lane = threadIdx.x & 63;
   const int RQ = a.num_buckets;  // the raise queue's slot
+  // the queues start with what addNewRobotPosition left in them (the host put the entries, the chunk table rows and the
+  // tails in place; all zero otherwise)
   for (int i = lane; i <= a.num_buckets; i += 64) {
-    q.head[i] = 0; q.tail[i] = 0; q.head_chunk[i] = 0; q.tail_chunk[i] = 0;
+    const uint32_t t0 = a.rctl->tail[i];
+    q.head[i] = 0; q.tail[i] = t0;
+    q.head_chunk[i] = t0 ? a.chunk_tab[(size_t)i * a.n_chunks] : 0;
+    q.tail_chunk[i] = t0 ? a.chunk_tab[(size_t)i * a.n_chunks + (t0 - 1) / kSqChunk] : 0;
   }
-  q.bump = 0; q.err = 0; q.last_bucket = 0; q.n_open = 0;
+  __syncthreads();
+  if (lane == 0) {
+    unsigned long long n0 = 0;
+    for (int i = 0; i < a.num_buckets; ++i) n0 += q.tail[i];
+    q.bump = a.rctl->chunk_top; q.err = 0; q.last_bucket = 0; q.n_open = n0;
+  }
   __syncthreads();
   const MapDev& m = a.m;
   const EsdfDev& e = a.e;
