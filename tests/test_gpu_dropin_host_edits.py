@@ -85,8 +85,8 @@ def _loaded_pair(oracle, n_frames=3):
     return dst, src
 
 
-def _same_esdf_bits(g, o):
-    assert set(g) == set(o) and len(g) > 20
+def _same_esdf_bits(g, o, min_blocks=20):
+    assert set(g) == set(o) and len(g) > min_blocks
     for k in o:
         assert np.array_equal(g[k][1], o[k][1]) and g[k][3] == o[k][3], k                      # flags, updated bits
         assert np.array_equal(g[k][0].view(np.uint32), o[k][0].view(np.uint32)), k            # distances, bit for bit
@@ -301,3 +301,41 @@ def test_more_live_layers_than_the_mirror_table_holds(oracle):
     it10.integrate(frames[1][0][0], frames[1][0][1], frames[1][1], frames[1][2])
     assert _same_tsdf(m10, ref) == n
     assert m10.dropin_stats()["uploaded_blocks"] == 0
+
+
+def test_robot_position_spheres_in_reference_order_through_voxblox_classes(oracle):
+    """EsdfIntegrator::addNewRobotPosition + updateFromTsdfLayer through voxblox's real classes (esdf_server.cc:219-230)
+    with the drop-in's default, the reference's order: the sphere pushes wait in raise_ / open_ in the iteration order
+    of the reference's HierarchicalIndexMap, updated_blocks_ is the class's own IndexSet.  Two Layers filled the same
+    way give the same bits, twice in a row (the second position meets hallucinated voxels), and clear() forgets the
+    queued work on the device like it does on the host."""
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    assert H.vbx_dropin_get_esdf_reference_order() == 1
+    dst, src = _loaded_pair(oracle)
+    ref = oracle.OracleMap(VOXEL, 16, L=R)
+    for k, (d, w, c, _) in src.tsdf_dict().items():
+        ref.tsdf_block_set(k, d, w, c, 7)
+
+    def esdf_cfg(L):
+        c = oracle.EsdfCfg()
+        L.orc_esdf_cfg_default(C.byref(c))
+        c.min_distance_m = 2 * VOXEL
+        c.clear_sphere_radius = 0.6
+        c.occupied_sphere_radius = 1.5
+        return c
+
+    ge, re_ = dst.esdf_integrator(esdf_cfg(H)), ref.esdf_integrator(esdf_cfg(R))
+    p0 = np.float32(S.frames(1)[0][0][0])
+    for step, p in enumerate((p0, p0 + np.float32([0.3, 0.1, 0.0]))):
+        for e in (ge, re_):
+            e.add_new_robot_position(p)
+        _same_esdf_bits(dst.esdf_dict(), ref.esdf_dict(), min_blocks=8)
+        for e in (ge, re_):
+            e.update_from_tsdf_layer(True)
+        _same_esdf_bits(dst.esdf_dict(), ref.esdf_dict())
+    # clear() between the spheres and the update: the voxel changes stay, the queued work is gone
+    for e in (ge, re_):
+        e.add_new_robot_position(p0 + np.float32([-0.4, 0.2, 0.1]))
+        e.clear()
+        e.update_from_tsdf_layer(True)
+    _same_esdf_bits(dst.esdf_dict(), ref.esdf_dict())

@@ -44,6 +44,7 @@ struct DeviceMirror {
   vbx_ctx* ctx = nullptr;
   const Layer<EsdfVoxel>* esdf_layer = nullptr;  // set by the EsdfIntegrator that shares the map
   bool esdf_pending = false;                     // addNewRobotPosition since the last update
+  bool esdf_pending_ordered = false;             // ... queued in the reference's order (vbx_esdf_cfg::reference_order of that call)
   uint64_t last_use = 0;                         // LRU stamp of the association table
   std::atomic<int> pins{0};                      // drop-in calls in flight on this mirror (MirrorRef); never evicted while > 0
   uint64_t frames_integrated = 0;                // > 0: the device holds integrator state the host layer does not

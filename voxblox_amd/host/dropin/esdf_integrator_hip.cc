@@ -117,14 +117,37 @@ void EsdfIntegrator::addNewRobotPosition(const Point& position) {
   hip::DeviceMirror& dev = *pinned;
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);
   hip::reconcileEsdfFromHost(dev, esdf_layer_);
-  const vbx_esdf_cfg cfg = hip::toC(config_);
+  vbx_esdf_cfg cfg = hip::toC(config_);
+  if (dev.esdf_pending && raise_.empty())  // clear() since the last addNewRobotPosition (see below)
+    CHECK_EQ(vbx_esdf_integrator_clear(dev.ctx), VBX_OK) << vbx_last_error(dev.ctx);
+  else if (dev.esdf_pending)
+    cfg.reference_order = dev.esdf_pending_ordered ? 1 : 0;  // (the switch moved between two positions: stay with the first)
   CHECK_EQ(vbx_esdf_add_new_robot_position(dev.ctx, &cfg, position.data()), VBX_OK) << vbx_last_error(dev.ctx);
   dev.esdf_pending = true;
-  // EsdfIntegrator::clear() is inline in the header and only empties the host containers; a non-empty
-  // updated_blocks_ is how the next update tells "robot spheres pending" from "clear() was called"
-  updated_blocks_.insert(BlockIndex(0, 0, 0));
+  dev.esdf_pending_ordered = cfg.reference_order != 0;
+  if (cfg.reference_order) {
+    // updated_blocks_ (esdf_integrator.cc:54, :80) is this class's own IndexSet: the blocks go in one by one, in the
+    // sequence the reference inserts them, and the set's iteration order is the reference's by construction
+    size_t n = 0;
+    CHECK_EQ(vbx_esdf_robot_updated_blocks(dev.ctx, 0, nullptr, 0, &n, 0), VBX_OK) << vbx_last_error(dev.ctx);
+    std::vector<int32_t> idx(3 * n + 3);
+    CHECK_EQ(vbx_esdf_robot_updated_blocks(dev.ctx, 0, idx.data(), n, &n, /*clear=*/1), VBX_OK) << vbx_last_error(dev.ctx);
+    for (size_t i = 0; i < n; ++i) updated_blocks_.insert(BlockIndex(idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]));
+  }
+  // EsdfIntegrator::clear() is inline in the header and only empties the host containers (esdf_integrator.h:138-142); the
+  // queues themselves live on the device, so one placeholder entry in the host's raise_ is how the next call tells
+  // "robot spheres pending" from "clear() was called in between"
+  if (raise_.empty()) raise_.push(GlobalIndex::Zero());
   hip::mirrorEsdfToHost(dev, esdf_layer_);
 }
+
+namespace {
+// the integrator's containers after an update: empty (esdf_integrator.cc:100, :109; the queues drain)
+template <typename Queue>
+void dropPlaceholder(Queue* raise) {
+  while (!raise->empty()) raise->pop();
+}
+}  // namespace
 
 void EsdfIntegrator::updateFromTsdfLayerBatch() {
   hip::MirrorRef pinned = hip::mirrorOf(tsdf_layer_);
@@ -136,8 +159,9 @@ void EsdfIntegrator::updateFromTsdfLayerBatch() {
   if (cfg.reference_order) {
     BlockIndexList tsdf_blocks;
     tsdf_layer_->getAllAllocatedBlocks(&tsdf_blocks);  // :96-97, in the host container's order
+    tsdf_blocks.insert(tsdf_blocks.end(), updated_blocks_.begin(), updated_blocks_.end());  // :98-99
     const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
-    CHECK_EQ(vbx_clear(dev.ctx, VBX_LAYER_ESDF), VBX_OK) << vbx_last_error(dev.ctx);
+    CHECK_EQ(vbx_clear(dev.ctx, VBX_LAYER_ESDF), VBX_OK) << vbx_last_error(dev.ctx);  // (forgets queued sphere entries too)
     CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), /*incremental=*/0),
              VBX_OK)
         << vbx_last_error(dev.ctx);
@@ -146,6 +170,7 @@ void EsdfIntegrator::updateFromTsdfLayerBatch() {
   }
   dev.esdf_pending = false;
   updated_blocks_.clear();
+  dropPlaceholder(&raise_);
   hip::mirrorEsdfToHost(dev, esdf_layer_);
 }
 
@@ -155,19 +180,21 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);
   hip::reconcileEsdfFromHost(dev, esdf_layer_);
   vbx_esdf_cfg cfg = hip::toC(config_);
-  if (dev.esdf_pending && updated_blocks_.empty())  // clear() since addNewRobotPosition
+  if (dev.esdf_pending && raise_.empty()) {  // clear() since addNewRobotPosition
     CHECK_EQ(vbx_esdf_integrator_clear(dev.ctx), VBX_OK) << vbx_last_error(dev.ctx);
-  if (cfg.reference_order && dev.esdf_pending) {
-    // the replay of the reference's queue order does not cover the marks addNewRobotPosition left on the device: this one
-    // update runs as the order-free fixed point (same rules, envelope of the reference's result)
-    LOG_FIRST_N(WARNING, 1) << "voxblox HIP drop-in: addNewRobotPosition work is pending; this ESDF update uses the order-free "
-                               "wavefront instead of the reference-order replay";
-    cfg.reference_order = 0;
+    dev.esdf_pending = false;
+  }
+  if (dev.esdf_pending && (cfg.reference_order != 0) != dev.esdf_pending_ordered) {
+    // the sphere work was queued in the other form: this one update follows it
+    LOG_FIRST_N(WARNING, 1) << "voxblox HIP drop-in: the ESDF order switch moved between addNewRobotPosition and the update; "
+                               "this update runs in the form the sphere work was queued in";
+    cfg.reference_order = dev.esdf_pending_ordered ? 1 : 0;
   }
   timing::Timer esdf_timer("esdf");  // esdf_integrator.cc:127
   if (cfg.reference_order) {
     BlockIndexList tsdf_blocks;
     tsdf_layer_->getAllUpdatedBlocks(Update::kEsdf, &tsdf_blocks);  // :105-106, in the host container's order
+    tsdf_blocks.insert(tsdf_blocks.end(), updated_blocks_.begin(), updated_blocks_.end());  // :107-108
     const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
     CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), /*incremental=*/1),
              VBX_OK)
@@ -179,6 +206,7 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
   }
   dev.esdf_pending = false;
   updated_blocks_.clear();
+  dropPlaceholder(&raise_);
   if (clear_updated_flag) {  // esdf_integrator.cc:113-121, on the host copies of the TSDF blocks
     BlockIndexList tsdf_blocks;
     tsdf_layer_->getAllUpdatedBlocks(Update::kEsdf, &tsdf_blocks);
