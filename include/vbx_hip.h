@@ -62,8 +62,11 @@ typedef struct vbx_tsdf_cfg {
   int32_t max_consecutive_ray_collisions;
   int32_t clear_checks_every_n_frames;
   float max_integration_time_s; /* Fast only (tsdf_integrator.cc:496-499): <= 0 integrates nothing, like the
-                                   reference; a positive budget cannot cut a frame short on the device — a
-                                   call that ran past it sets vbx_counters.time_budget_exceeded and warns once */
+                                   reference.  A positive budget: the device cannot look at the clock inside a
+                                   frame, so the call takes the prefix of the reference's taking order
+                                   (ThreadSafeIndex) that the budget pays for at the time per point measured on
+                                   the handle's earlier calls (the first call takes everything);
+                                   vbx_counters.points_taken / time_budget_exceeded say what was done */
   /* Not in the reference Config.  MergedTsdfIntegrator visits its ray bundles in the iteration
    * order of a std::unordered_map (tsdf_integrator.cc:440-456), which the clamped fold makes
    * observable.  0 (default): that order, reconstructed from libstdc++'s bucket-count schedule and
@@ -318,9 +321,11 @@ typedef struct vbx_counters {
   uint64_t esdf_sweeps;     /* ESDF: wavefront sweeps */
   uint64_t replay_rounds;   /* Fast, fast_observed_set = 0: rounds of the observed-set replay */
   uint64_t replay_block_rounds; /* ... of which: rounds run on blocks of consecutive rays (fine voxels) */
-  uint64_t time_budget_exceeded; /* Fast: 1 if the last call outran cfg->max_integration_time_s (see there) */
+  uint64_t time_budget_exceeded; /* Fast: 1 if the last call outran cfg->max_integration_time_s or was cut short for it */
   uint64_t esdf_respeculated; /* ESDF: 1 if a phase needed more sweeps than were queued ahead of the read-back and the
                                  update was finished sweep by sweep (VBX_ESDF_RAISE_SWEEPS / VBX_ESDF_LOWER_SWEEPS) */
+  uint64_t points_taken;    /* Fast: points of the taking order the last call took (= points unless
+                               cfg->max_integration_time_s cut the frame short) */
 } vbx_counters;
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
 

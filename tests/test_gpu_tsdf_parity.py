@@ -420,3 +420,60 @@ def test_long_full_resolution_streams_bit_exact(oracle, kind, scene, n_frames):
     if digest(g) != digest(r):
         compare_tsdf(g, r, exact=True)   # names the first differing block
         raise AssertionError("digests differ")
+
+
+def _mixed_taking_order(n):
+    """MixedThreadSafeIndex::getNextIndexImpl (integrator_utils.cc:54-63): point index for every place in the order."""
+    s = np.arange(n)
+    groups = n // 1024
+    if groups == 0:
+        return s
+    out = (s % groups) * 1024 + s // groups
+    out[s >= groups * 1024] = s[s >= groups * 1024]
+    return out
+
+
+@pytest.mark.parametrize("order_mode", [0, 1])
+def test_fast_positive_time_budget_takes_a_prefix_of_the_order(oracle, order_mode):
+    """max_integration_time_s > 0 (tsdf_integrator.cc:496-499): the threads stop TAKING points when the budget is spent.
+    The device decides before the frame how many points the budget pays for (time per point of the earlier calls) and
+    takes that prefix of the taking order.  Checked against the oracle fed the same cloud with every point the device
+    did not take made invalid (a zero-length ray: isPointValid drops it, tsdf_integrator.cc:84-99) — same order, same
+    sets, bit-exact."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    # (sorted order: frames without two points of equal squared norm — std::sort leaves ties unspecified)
+    frames = [_small_room(k) for k in range(4)] if order_mode == 0 else [_unique_norm_frame(k) for k in (1, 6, 11)]
+    ocfg, gcfg = _cfgs(oracle, 4 * voxel, integration_order_mode=order_mode)
+    gcfg.max_integration_time_s = 2e-4          # 200 us: less than a frame costs
+    oracle.lib().orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("fast", ocfg)
+    gm = capi.Map(voxel, 16, max_blocks=4096)
+    cut = 0
+    for f, (pose, pts, col) in enumerate(frames):
+        gm.integrate(capi.TSDF_FAST, gcfg, pose[0], pose[1], pts, col)
+        c = gm.counters()
+        n, taken = len(pts), c["points_taken"]
+        assert c["points"] == n and taken <= n
+        if f == 0:
+            assert taken == n and c["time_budget_exceeded"] == 1      # nothing measured yet: everything, and it says so
+        if order_mode == 0:
+            order = _mixed_taking_order(n)
+        else:   # SortedThreadSafeIndex: ascending float squaredNorm (Eigen: x*x + (y*y + z*z)), ties by index here
+            q = pts.astype(np.float32)
+            order = np.argsort(q[:, 0] * q[:, 0] + (q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2]), kind="stable")
+        p2 = pts.copy()
+        p2[order[taken:]] = 0.0
+        cut += n - taken
+        oi.integrate(pose[0], pose[1], p2, col)
+        compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    assert cut > 0                                # the budget did cut frames short
+
+
+def test_fast_generous_time_budget_changes_nothing(oracle):
+    from voxblox_amd import capi
+    frames = [_small_room(k) for k in range(3)]
+    om, oi, gm = _run(oracle, "fast", 0.1, frames, max_integration_time_s=10.0)
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    assert gm.counters()["points_taken"] == len(frames[-1][1]) and gm.counters()["time_budget_exceeded"] == 0

@@ -68,7 +68,7 @@ class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("points", "rays_cast", "voxel_updates", "voxels_touched", "blocks_allocated",
                  "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps", "replay_rounds",
-                 "replay_block_rounds", "time_budget_exceeded", "esdf_respeculated")]
+                 "replay_block_rounds", "time_budget_exceeded", "esdf_respeculated", "points_taken")]
 
 
 class Timing(C.Structure):

@@ -168,6 +168,8 @@ struct CastCfg {  // by-value kernel argument: TsdfIntegratorBase::Config + deri
   int anti_grazing;
   int max_consecutive;
   float start_factor_times_inv;  // start_voxel_subsampling_factor * voxel_size_inv_
+  uint32_t take_limit;           // Fast: points whose place in the taking order (ThreadSafeIndex) is at or beyond this are not taken
+                                 // (max_integration_time_s, tsdf_integrator.cc:496-499); ~0u otherwise
 };
 
 // Merged: bundle keys are the endpoint voxel index RELATIVE to the cloud's bounding box, packed in as many

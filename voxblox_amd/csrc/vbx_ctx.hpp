@@ -25,6 +25,8 @@ struct vbx_ctx {
   uint32_t pool_limit = 0;   // vbx_set_pool_limit: the pool never grows beyond this many blocks (0: no limit)
   uint32_t pool_grown = 0;   // times the pool doubled
   bool warned_time_budget = false;  // Fast: max_integration_time_s overrun reported once
+  double fast_us_per_point = 0.0;   // Fast with a finite max_integration_time_s: wall time per taken point of the earlier calls
+  uint32_t fast_take_limit = ~0u;   // ... points of the taking order the current call takes
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   DevState* d_state = nullptr;

@@ -440,6 +440,7 @@ CastCfg make_cast_cfg(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const float pos[3])
   c.anti_grazing = cfg->enable_anti_grazing != 0;
   c.max_consecutive = cfg->max_consecutive_ray_collisions;
   c.start_factor_times_inv = cfg->start_voxel_subsampling_factor * ctx->map.voxel_size_inv;
+  c.take_limit = ~0u;
   return c;
 }
 

@@ -425,6 +425,7 @@ int fast_frame_tick(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg) {
 int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const float* d_pts,
                    const uint32_t* d_rgba, size_t n, int freespace) {
   CastCfg c = make_cast_cfg(ctx, cfg, &T.t.x);
+  c.take_limit = ctx->fast_take_limit;
   const uint32_t* order = nullptr;
   {
     int orc_ = visiting_order(ctx, cfg, d_pts, n, &order);
@@ -906,11 +907,28 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   if (n == 0) return kind == VBX_TSDF_FAST ? fast_frame_tick(ctx, cfg) : VBX_OK;
   // FastTsdfIntegrator stops taking points once max_integration_time_s of wall clock are used up
   // (tsdf_integrator.cc:496-499; Simple and Merged have no such check).  A budget that is already spent at the
-  // first point (<= 0, NaN) integrates nothing, exactly like the reference; a positive one is compared with
-  // the call's wall time afterwards: the device path cannot stop half way through a frame, so a call that ran
-  // past its budget says so (counters.time_budget_exceeded, one warning per handle) instead of pretending.
+  // first point (<= 0, NaN) integrates nothing, exactly like the reference.  A positive one: the device path cannot
+  // look at the clock half way through a frame, so it decides BEFORE the frame how many points the budget pays for,
+  // from the time per taken point of this handle's earlier calls, and takes that prefix of the reference's taking
+  // order (ThreadSafeIndex: mixed or sorted) — the points a single-threaded reference would have got to.  The first
+  // call of a handle has no measurement and integrates everything; counters.points_taken / time_budget_exceeded report
+  // what happened.
   const bool has_budget = kind == VBX_TSDF_FAST && cfg->max_integration_time_s < 1.0e30f;
   if (kind == VBX_TSDF_FAST && !(cfg->max_integration_time_s * 1000000.0f > 0.0f)) return fast_frame_tick(ctx, cfg);
+  ctx->fast_take_limit = ~0u;
+  ctx->counters.points_taken = n;
+  if (has_budget && ctx->fast_us_per_point > 0.0) {
+    const double can = (double)cfg->max_integration_time_s * 1000000.0 / ctx->fast_us_per_point;
+    if (can < (double)n) {
+      ctx->fast_take_limit = (uint32_t)can;
+      ctx->counters.points_taken = ctx->fast_take_limit;
+      ctx->counters.time_budget_exceeded = 1;
+      if (ctx->fast_take_limit == 0) {   // (the estimate decays so that a later frame gets another try)
+        ctx->fast_us_per_point *= 0.75;
+        return fast_frame_tick(ctx, cfg);
+      }
+    }
+  }
   const auto t_call0 = std::chrono::steady_clock::now();
   // per-call device counters
   KLAUNCH(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
@@ -938,13 +956,15 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
   if (has_budget) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
+    const double per = us / (double)std::max<uint64_t>(ctx->counters.points_taken, 1);
+    ctx->fast_us_per_point = ctx->fast_us_per_point > 0.0 ? 0.5 * ctx->fast_us_per_point + 0.5 * per : per;
     if (!(us < (double)cfg->max_integration_time_s * 1000000.0)) {
       ctx->counters.time_budget_exceeded = 1;
       if (!ctx->warned_time_budget) {
         ctx->warned_time_budget = true;
-        fprintf(stderr, "[vbx] FastTsdfIntegrator: the frame took %.0f us, max_integration_time_s allows %.0f us; the "
-                        "reference would have dropped the rest of the cloud, the device path integrated all of it "
-                        "(reported once; see vbx_counters.time_budget_exceeded)\n", us,
+        fprintf(stderr, "[vbx] FastTsdfIntegrator: the frame took %.0f us, max_integration_time_s allows %.0f us; later "
+                        "frames take as many points as the budget pays for at the measured rate "
+                        "(reported once; see vbx_counters.points_taken / time_budget_exceeded)\n", us,
                 (double)cfg->max_integration_time_s * 1000000.0);
       }
     }

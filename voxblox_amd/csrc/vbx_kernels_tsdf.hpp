@@ -96,7 +96,7 @@ __global__ void k_prep_points(const float* __restrict__ pts, const uint32_t* __r
   const size_t s = s_of_p ? (size_t)s_of_p[p] : mixed_index_inverse(p, n);
   const f3 pc{pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
   bool clearing = false;
-  const bool valid = point_valid(c, pc, freespace != 0, &clearing);
+  const bool valid = point_valid(c, pc, freespace != 0, &clearing) && s < (size_t)c.take_limit;
   const f3 pg = pose_transform(T, pc);
   tab.px[s] = pg.x;
   tab.py[s] = pg.y;

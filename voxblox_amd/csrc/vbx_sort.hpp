@@ -145,7 +145,9 @@ constexpr int kFsGroupBig = 64;                 // ... of a sort with more tiles
                                                 // 511 predecessors were 4 x the key traffic of a 37 M key pass)
 constexpr int kFsMaxBits = 10;                  // one digit per thread
 constexpr int kFsMaxPasses = 3;
-constexpr uint32_t kFsSpinMax = 1u << 20;
+constexpr uint32_t kFsSpinMax = 1u << 20;         // polls of an agent-scope load (>= 0.5 us each) + s_sleep: more than half a second
+                                                // of waiting for a tile that holds an EARLIER ticket, i.e. one that is resident or
+                                                // done — a hang detector, not a scheduling race (a preempted queue comes back in ms)
 struct FsPasses {
   int np;
   int shift[kFsMaxPasses];
