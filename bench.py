@@ -373,6 +373,14 @@ def dropin_leg(frames, kind, voxel, warmup, steps):
             if n1 > n0:
                 split[t] = round((s1 - s0) / (n1 - n0) * 1e3, 4)
         out["ms_by_timer_tag"] = split
+        inside = split.get("integrate/" + kind)
+        if inside:
+            # the metric's own definition: the timing::Timer the reference itself puts around the body of integratePointCloud
+            # (tsdf_integrator.cc:559 / :311 / :246); the perf_counter figure also holds the harness' conversion of the numpy
+            # cloud into voxblox's Pointcloud / Colors containers, which a voxblox caller has already
+            out["harness_wall_ms_per_step"] = out["ms_per_step"]
+            out["ms_per_step"] = inside
+            out["value"] = round(frames[0][1].shape[0] / inside / 1e3, 3)
     return out
 
 

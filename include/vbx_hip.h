@@ -102,8 +102,8 @@ typedef struct vbx_esdf_cfg {
    * 1: the reference's own order — updateFromTsdfBlocks' voxel walk, the FIFO raise queue, BucketQueue pop order
    * with num_buckets / multi_queue, min_diff_m gating, updateVoxelFromNeighbors incl. its unscaled LUT distance,
    * the sign-mismatch rule as written (esdf_integrator.cc:124-530, bucket_queue.h:41-80) — replayed in parallel with
-   * the reference's bits as the result (thousands of pops at a time; ~50 ms per update on the 640x480 /
-   * 0.05 m stream where the reference needs ~58 ms on one core and the order-free default 0.3 ms).  The blocks are visited in the order
+   * the reference's bits as the result (thousands of pops at a time; ~53 ms per update on the 640x480 /
+   * 0.05 m stream where the reference needs ~59 ms on one core and the order-free default 0.3 ms).  The blocks are visited in the order
    * of the list given to vbx_esdf_update_blocks; vbx_esdf_update visits them in ascending (z,y,x) order (the
    * reference's order there is the iteration order of the caller's std::unordered_map — the drop-in passes it down).
    * vbx_esdf_add_new_robot_position reads the field too: with 1 its raise_ / open_ pushes and updated_blocks_
