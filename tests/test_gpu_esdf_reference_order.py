@@ -197,15 +197,21 @@ def test_reference_order_robot_position_stream_bit_exact(oracle, esdf_kw):
     sph = dict(min_distance_m=2 * voxel, clear_sphere_radius=0.6, occupied_sphere_radius=1.5, **esdf_kw)
     oracle.lib().orc_fast_reset_counter_set(0)
     om = oracle.OracleMap(voxel, 16)
-    oi = om.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    # (the second case integrates with the Fast integrator's exact observed set: its per-voxel stamps live on the device
+    # between frames and must survive the sphere calls' scratch use)
+    fast = bool(esdf_kw)
+    okw = dict(oracle_fast_exact_observed_set=1) if fast else {}
+    gkw = dict(fast_observed_set=1) if fast else {}
+    oi = om.tsdf_integrator("fast" if fast else "simple",
+                            oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1, **okw))
     oe = om.esdf_integrator(oracle.esdf_cfg(**sph))
     gm = capi.Map(voxel, 16, max_blocks=4096)
-    gt = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    gt = capi.tsdf_cfg(default_truncation_distance=4 * voxel, **gkw)
     ge = capi.esdf_cfg(reference_order=1, **sph)
     n_robot_blocks = 0
     for f, (pose, pts, col) in enumerate(S.frames(4)):
         oi.integrate(pose[0], pose[1], pts, col)
-        gm.integrate(capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_FAST if fast else capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
         oe.add_new_robot_position(pose[0])
         gm.esdf_add_new_robot_position(ge, pose[0])
         if f == 2:   # two positions before one update
@@ -223,6 +229,8 @@ def test_reference_order_robot_position_stream_bit_exact(oracle, esdf_kw):
         gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
         _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")
     assert n_robot_blocks > 8
+    from parity_utils import compare_tsdf
+    compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
     r = om.esdf_dict()
     assert sum(int((v[1] & 2).astype(bool).sum()) for v in r.values()) > 1000   # hallucinated voxels are in play
 

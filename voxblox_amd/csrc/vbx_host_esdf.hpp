@@ -377,10 +377,11 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
     // (esdf_integrator.cc:29-34, :60-66) is an unordered_map from block index to the block's voxels in the order of the
     // x / y / z loops of getSphereAroundPoint (planning_utils_inl.h:25-50); a block enters the map when its first voxel
     // comes up.  Walking the cube in that order and inserting into a map with the reference's hash gives its iteration order.
-    HIP_TRY(ctx->b_order.ensure(cube * 4));
-    HIP_TRY(ctx->b_obs.ensure(cube * 2));
+    // (per-call scratch of the sorts: nothing else owns these between calls)
+    HIP_TRY(ctx->b_vals1.ensure(cube * 4));
+    HIP_TRY(ctx->b_keys1.ensure(cube * 2));
     KLAUNCH(k_sphere_apply_ordered, grid_for(cube), dim3(256), 0, s, m, e, sp, cfg->default_distance_m, cfg->max_distance_m,
-            cfg->num_buckets, pass, ctx->b_order.as<uint32_t>(), ctx->b_obs.as<uint16_t>());
+            cfg->num_buckets, pass, ctx->b_vals1.as<uint32_t>(), ctx->b_keys1.as<uint16_t>());
     rc = sync_state(ctx);
     if (rc) return rc;
     if (ctx->h_state.error) return check_state_error(ctx);
@@ -388,8 +389,8 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
     std::vector<uint32_t> gids(cube);
     std::vector<uint16_t> codes(cube);
     std::vector<int32_t> bidx((size_t)used * 3);
-    HIP_TRY(hipMemcpy(gids.data(), ctx->b_order.p, cube * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(codes.data(), ctx->b_obs.p, cube * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(gids.data(), ctx->b_vals1.p, cube * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(codes.data(), ctx->b_keys1.p, cube * 2, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(bidx.data(), m.blk_idx, (size_t)used * 12, hipMemcpyDeviceToHost));
     std::unordered_map<HostBlockIdx, std::vector<uint32_t>, HostAnyIndexHash> block_voxel_list;
     uint32_t last_slot = kInvalidSlot;
