@@ -341,6 +341,11 @@ int vbx_selftest_scan(vbx_ctx* ctx, uint32_t n, uint32_t seed, uint32_t repeats)
  * std::unordered_map iteration order (tsdf_integrator.cc:440-456, see vbx_host_tsdf.hpp) against the
  * container itself, on n distinct keys with pseudo-random hashes & hash_mask. */
 int vbx_selftest_unordered_order(uint32_t n, uint32_t seed, uint32_t hash_mask);
+/* Self-test hook, host only: the iteration order of the library's stand-in for the reference's IndexSet /
+ * HierarchicalIndexMap (block_hash.h:20-48; reference-order addNewRobotPosition) after inserting the n block indices
+ * of idx_xyz in sequence.  Writes the distinct indices in iteration order to out_xyz (room for n) and returns how
+ * many there are (< 0 on bad arguments); tests compare it with the oracle's containers. */
+int64_t vbx_selftest_index_set_order(const int32_t* idx_xyz, size_t n, int32_t* out_xyz);
 
 /* HIP-event timing of the last integrate / esdf call on the handle's stream, in ms. */
 typedef struct vbx_timing {

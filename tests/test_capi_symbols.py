@@ -109,3 +109,29 @@ def test_unordered_map_order_reconstruction_matches_libstdcxx(n, mask):
     from voxblox_amd import capi
     for seed in (1, 2, 3):
         assert capi.lib().vbx_selftest_unordered_order(n, seed, mask) == 0
+
+
+@pytest.mark.parametrize("n,span", [(1, 4), (12, 3), (200, 6), (3000, 12), (20000, 40)])
+def test_index_set_order_is_the_oracles_container_order(n, span):
+    """Host-only (no GPU): the library's stand-in for the reference's IndexSet / HierarchicalIndexMap (reference-order
+    addNewRobotPosition: raise_ / open_ pushes and updated_blocks_ come out in the iteration order of an unordered
+    container keyed with AnyIndexHash) iterates like the oracle's Layer block map — the same hash in the same libstdc++
+    container — after the same sequence of insertions, negative indices and duplicates included."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import oracle_py as O
+    from voxblox_amd import capi
+    rng = np.random.default_rng(n)
+    idx = rng.integers(-span, span, size=(n, 3)).astype(np.int32)
+    out = np.zeros((n, 3), np.int32)
+    k = capi.lib().vbx_selftest_index_set_order(idx.ctypes.data_as(C.POINTER(C.c_int32)), n,
+                                                out.ctypes.data_as(C.POINTER(C.c_int32)))
+    om = O.OracleMap(0.1, 8)
+    z = np.zeros(512, np.float32)
+    c = np.zeros((512, 4), np.uint8)
+    for i in idx:     # Layer::allocateBlockPtrByIndex in sequence (a second insertion of a key changes nothing)
+        om.tsdf_block_set(tuple(int(v) for v in i), z, z, c, 0)
+    ref = om.block_indices(0)
+    assert k == len(ref) == len({tuple(i) for i in idx.tolist()})
+    assert np.array_equal(out[:k], ref)

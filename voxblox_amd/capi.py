@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_blocks_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_keep_slots", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
-    "vbx_selftest_unordered_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
+    "vbx_selftest_unordered_order", "vbx_selftest_index_set_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
 
 
 class MapCfg(C.Structure):
@@ -123,6 +123,7 @@ def lib():
         "vbx_esdf_robot_updated_blocks": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp, C.c_int]),
         "vbx_esdf_integrator_clear": (C.c_int, [vp]),
         "vbx_selftest_unordered_order": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32]),
+        "vbx_selftest_index_set_order": (C.c_int64, [i32p, C.c_size_t, i32p]),
         "vbx_mesh_cfg_default": (None, [C.POINTER(MeshCfg)]),
         "vbx_mesh_generate": (C.c_int, [vp, C.POINTER(MeshCfg), C.c_int, C.c_int, szp, szp]),
         "vbx_mesh_blocks": (C.c_int, [vp, i32p, C.POINTER(C.c_uint64), C.c_size_t, szp]),

@@ -298,6 +298,18 @@ int vbx_esdf_integrator_clear(vbx_ctx* ctx) {
   return VBX_OK;
 }
 
+int64_t vbx_selftest_index_set_order(const int32_t* idx_xyz, size_t n, int32_t* out_xyz) {
+  if ((n && !idx_xyz) || !out_xyz) return -1;
+  std::unordered_set<HostBlockIdx, HostAnyIndexHash> set;
+  for (size_t i = 0; i < n; ++i) set.insert(HostBlockIdx{idx_xyz[3 * i], idx_xyz[3 * i + 1], idx_xyz[3 * i + 2]});
+  size_t k = 0;
+  for (const HostBlockIdx& b : set) {
+    out_xyz[3 * k] = b.x; out_xyz[3 * k + 1] = b.y; out_xyz[3 * k + 2] = b.z;
+    ++k;
+  }
+  return (int64_t)k;
+}
+
 int vbx_esdf_robot_updated_blocks(vbx_ctx* ctx, int order, int32_t* out_xyz, size_t cap, size_t* n_out, int clear) {
   if (!ctx || !n_out || (order != 0 && order != 1)) return VBX_ERR_INVALID;
   *n_out = ctx->esdf_updated_set.size();
