@@ -35,10 +35,11 @@ def model():
     L.eom_set_mode.argtypes = [C.c_void_p, C.c_int]
     L.eom_update_parallel.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
     L.eom_update_parallel.restype = C.c_long
+    L.eom_robot.argtypes = [C.c_void_p, fp]
     return L
 
 
-def _run(L, n_frames, voxel, sub, kmax, smax, max_iters, env=None):
+def _run(L, n_frames, voxel, sub, kmax, smax, max_iters, env=None, robot=False):
     sys.path.insert(0, ROOT)
     from voxblox_amd import scenes
     fp = C.POINTER(C.c_float)
@@ -59,6 +60,8 @@ def _run(L, n_frames, voxel, sub, kmax, smax, max_iters, env=None):
             col = np.ascontiguousarray(col[::sub], np.uint8)
             L.eom_integrate(h, pos.ctypes.data_as(fp), q.ctypes.data_as(fp), pts.ctypes.data_as(fp),
                             col.ctypes.data_as(C.POINTER(C.c_uint8)), pts.shape[0])
+            if robot:                 # EsdfIntegrator::addNewRobotPosition on both layers before the update
+                L.eom_robot(h, pos.ctypes.data_as(fp))
             L.eom_update(h, 0)        # the oracle's sequential update on the first ESDF layer
             diffs.append(L.eom_update_parallel(h, kmax, smax, max_iters))
         return diffs
@@ -86,3 +89,14 @@ def test_emulated_replay_with_every_early_stop(model):
 def test_emulated_replay_without_the_offer_filter(model):
     """Every offer an event (Cfg::filter = 0): the unfiltered form is the definition the filter has to agree with."""
     assert _run(model, 2, 0.1, 64, 8192, 256, 64, env={"EOM_FILTER_LEVEL": "0"}) == [0, 0]
+
+
+@pytest.mark.parametrize("env", [{}, {"EOM_MULTI_QUEUE": "1", "EOM_BUCKETS": "5"}])
+def test_emulated_replay_starts_from_queues_that_hold_robot_sphere_entries(model, env):
+    """addNewRobotPosition before every update (esdf_server.cc:219-230): raise_ and open_ are not empty when the voxel walk
+    starts, open_ holds voxels whose in_queue flag is clear (esdf_integrator.cc:84 does not set it) and, from the second
+    frame on, blocks are listed twice.  With multi_queue and five buckets a bucket holds the same neighbourhoods many
+    times over: the case in which the first record of a super-step may find a target's event list full and the
+    super-step is retried with fewer records (rp_retry_smaller)."""
+    e = dict(env, EOM_SPHERES="0.6,1.5")
+    assert _run(model, 3, 0.1, 16, 8192, 256, 64, env=e, robot=True) == [0, 0, 0]

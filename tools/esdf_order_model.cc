@@ -83,6 +83,8 @@ class ModelEsdf : public EsdfIntegrator {
   void update(bool clear_updated_flag) {
     std::vector<Idx3> tsdf_blocks;
     tsdf_layer_->getAllUpdatedBlocks(kEsdf, &tsdf_blocks);
+    tsdf_blocks.insert(tsdf_blocks.end(), updated_blocks_.begin(), updated_blocks_.end());   // esdf_integrator.cc:107-109
+    updated_blocks_.clear();
     // classification through the base class with its own queues; we then drain them into ours.  The base class
     // calls processRaiseSet / processOpenSet itself, so replicate updateFromTsdfBlocks' tail here instead:
     // run the base with the real thing on a COPY?  Simpler: the base's methods are reused, the open set is replayed
@@ -112,6 +114,15 @@ class ModelEsdf : public EsdfIntegrator {
     // To do that without running the base wavefront, call a trimmed copy of the loop.
     bq_.assign(config_.num_buckets, {});
     n_open_ = 0;
+    // what addNewRobotPosition (the base class' own, esdf_integrator.cc:25-92) left in raise_ / open_ comes first.  open_
+    // hands its entries out lowest bucket first, FIFO inside; an entry's bucket is that of its voxel's distance (pushed
+    // with it at :84, and nothing has touched the voxel since — one position per update here)
+    while (!raise_.empty()) { raise_q_.push_back(raise_.front()); raise_.pop(); }
+    while (!open_.empty()) {
+      const LIdx3 g = open_.front();
+      open_.pop();
+      qpush(g, esdf_layer_->getVoxelPtrByGlobalIndex(g)->distance);
+    }
     classify(tsdf_blocks);
     if (std::getenv("EOM_WATCH")) {
       int bx, by, bz, lin;
@@ -825,10 +836,23 @@ void* eom_create(float voxel) {
   m->fast.reset(new FastTsdfIntegrator(c, &m->tsdf));
   EsdfConfig ec;
   ec.min_distance_m = 2 * voxel;
+  if (std::getenv("EOM_MULTI_QUEUE")) ec.multi_queue = std::atoi(std::getenv("EOM_MULTI_QUEUE")) != 0;
+  if (std::getenv("EOM_BUCKETS")) ec.num_buckets = std::atoi(std::getenv("EOM_BUCKETS"));
+  if (std::getenv("EOM_SPHERES")) {   // "clear,occupied" radii in metres
+    float c = 0, o = 0;
+    std::sscanf(std::getenv("EOM_SPHERES"), "%f,%f", &c, &o);
+    ec.clear_sphere_radius = c;
+    ec.occupied_sphere_radius = o;
+  }
   m->e.reset(new ModelEsdf(ec, &m->tsdf, &m->esdf));
   m->e2.reset(new ModelEsdf(ec, &m->tsdf, &m->esdf2));
   m->e2->mode = 1;
   return m;
+}
+void eom_robot(void* h, const float* pos) {
+  auto* m = static_cast<Model*>(h);
+  m->e->addNewRobotPosition(Vec3f{pos[0], pos[1], pos[2]});
+  m->e2->addNewRobotPosition(Vec3f{pos[0], pos[1], pos[2]});
 }
 void eom_integrate(void* h, const float* pos, const float* q, const float* pts, const uint8_t* rgba, size_t n) {
   auto* m = static_cast<Model*>(h);
@@ -890,7 +914,7 @@ long eom_update_parallel(void* h, size_t kmax, size_t smax, int max_iters) {
     std::printf("  emul: raise pops %llu in %llu steps | pops %llu relax %llu supersteps %llu iters %llu folds %llu exc %llu cuts(iters %llu smax %llu) steps %llu error %u | voxels %ld DIFF %ld\n",
                 c.st_raise_pops, c.st_raise_steps, c.st_pops, c.st_relax, c.st_supersteps, c.st_iters, c.st_folds, c.st_exc, c.st_cut_iters, c.st_cut_smax, c.st_steps, c.error, n, diff);
     static const char* names[] = {"done", "begin", "place", "fold", "apply", "sim", "mincut", "cfold", "rank", "rwrite", "push", "cleanup", "raise"};
-    std::printf("  poison %llu trunc_q %llu trunc_rank %llu\n", c.st_poison, c.st_trunc_q, c.st_trunc_rank);
+    std::printf("  poison %llu trunc_q %llu trunc_rank %llu retries %llu\n", c.st_poison, c.st_trunc_q, c.st_trunc_rank, c.st_retries);
     std::printf("  steps:");
     for (int k = 1; k < 13; ++k) std::printf(" %s %llu(%llu)", names[k], c.st_phase_steps[k], c.st_phase_threads[k]);
     std::printf("\n");
