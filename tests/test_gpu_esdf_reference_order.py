@@ -58,7 +58,7 @@ def _updated_esdf_blocks_in_container_order(om):
     return np.array(out, np.int32).reshape(-1, 3)
 
 
-def _lockstep(oracle, sc, esdf_kw, n_frames=None, list_mode="container", check_every_frame=True):
+def _lockstep(oracle, sc, esdf_kw, n_frames=None, list_mode="container", check_every_frame=True, robot=False):
     """TSDF integration + incremental ESDF update after every frame on both sides; returns the two maps."""
     import ctypes as C
     from voxblox_amd import capi
@@ -74,8 +74,14 @@ def _lockstep(oracle, sc, esdf_kw, n_frames=None, list_mode="container", check_e
     for f, (pose, pts, col) in enumerate(S.frames(n_frames or sc["n"])):
         oi.integrate(pose[0], pose[1], pts, col)
         gm.integrate(KIND[sc["kind"]], gc, pose[0], pose[1], pts, col)
+        if robot:   # esdf_server.cc:224: addNewRobotPosition(T_G_C position) before the update
+            oe.add_new_robot_position(pose[0])
+            gm.esdf_add_new_robot_position(ge, pose[0])
         if list_mode == "container":
             lst = _updated_esdf_blocks_in_container_order(om)
+            if robot:   # + updated_blocks_ (esdf_integrator.cc:107-109)
+                rb = gm.esdf_robot_updated_blocks(order=1, clear=True)
+                lst = np.concatenate([lst, rb]) if len(rb) else lst
             oe.update_from_tsdf_layer(True)
             gm.esdf_update_blocks(ge, lst, incremental=True)
             gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
@@ -103,6 +109,16 @@ def test_reference_order_reproduces_the_golden_incremental_digest(oracle):
     assert S.digest_esdf(_gpu_esdf_dict(gm)) == GOLD[name]["esdf"]
     c = gm.counters()
     assert c["esdf_relaxations"] > 0 and c["esdf_sweeps"] > 0
+
+
+def test_reference_order_reproduces_the_golden_robot_spheres_digest(oracle):
+    """The reference build's `esdf_robot_spheres` scenario (Merged integrator, addNewRobotPosition with 0.6 / 1.6 m spheres
+    before every updateFromTsdfLayer(true)): the HIP layer hashes to the digest the reference's own sources produced."""
+    name = "esdf_robot_spheres"
+    sc = S.SCENARIOS[name]
+    gm, om = _lockstep(oracle, sc, sc["esdf"]["cfg"], robot=True)
+    assert S.digest_esdf(om.esdf_dict()) == GOLD[name]["esdf"]          # the checker itself reproduces the reference
+    assert S.digest_esdf(_gpu_esdf_dict(gm)) == GOLD[name]["esdf"]
 
 
 def test_reference_order_reproduces_the_golden_batch_digest(oracle):
