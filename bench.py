@@ -80,6 +80,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-reference sample")
     ap.add_argument("--esdf-fidelity-frames", type=int, default=24,
                     help="--esdf: frames of the lockstep GPU-vs-reference ESDF comparison (0 = skip)")
+    ap.add_argument("--esdf-mode", default="reference", choices=["reference", "order_free"],
+                    help="--esdf: what the timed region runs.  reference = vbx_esdf_cfg.reference_order = 1, the reference's own "
+                         "result (checked voxel by voxel against the reference build after the clock stops); order_free = the "
+                         "order-free fixed point (fast, NOT bit-exact)")
+    ap.add_argument("--bands", type=int, default=0,
+                    help="sensors4: ray bundles per sensor frame (default 1 = whole sensors, the only layout that reproduces the "
+                         "reference's map; 4 = the quarter-frame bundles of rounds 3-4, a different map)")
+    ap.add_argument("--detail-out", default="", help="where the full result goes (default bench_detail.json next to this file)")
     return ap.parse_args()
 
 
@@ -303,36 +311,69 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
                     "checkpoints; distances in metres over voxels both sides observe"}
 
 
-def esdf_reference_order_leg(args, d_frames, kind, cfg, voxel, trunc, max_blocks, local_rank, warmup, steps):
-    """configs[3] with the reference's OWN result: the same frames as the timed region on a map of its own, Fast integration +
-    vbx_esdf_update(reference_order = 1) after every frame (the blocks carrying Update::kEsdf in ascending (z,y,x)); the
-    ESDF call is timed with events (device) and the host clock (wall)."""
-    import torch
-    from voxblox_amd import capi
-    gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
-    gm.set_stream(torch.cuda.current_stream().cuda_stream)
-    ecfg = capi.esdf_cfg(min_distance_m=trunc / 2, reference_order=1)
-    gm.enable_timing(True)
-    ev, wall, pops, relax = [], [], 0, 0
-    for i in range(warmup + steps):
-        pose, dp, dc, n = d_frames[i % len(d_frames)]
-        gm.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
-        torch.cuda.synchronize()
+def esdf_reference_run(frames, voxel, n_frames):
+    """configs[3] on the reference build (oracle/_ref, the checker): FastTsdfIntegrator with ONE thread (the deterministic
+    reference the parity statement is about) + EsdfIntegrator::updateFromTsdfLayer(true) after every frame.  Returns the
+    per-frame times of both calls, the block list every update walked (Layer::getAllUpdatedBlocks(Update::kEsdf), layer.h:194-203,
+    in the container's own order) and the maps, so that the GPU leg can be compared voxel by voxel afterwards."""
+    import ctypes
+    O, L, use_ref = _oracle()
+    L.orc_fast_reset_counter_set(0)
+    m = O.OracleMap(voxel, 16, L=L)
+    c = O.TsdfCfg()
+    L.orc_tsdf_cfg_default(ctypes.byref(c))
+    c.default_truncation_distance = 4 * voxel
+    c.integrator_threads = 1
+    it = m.tsdf_integrator("fast", c)
+    ec = O.EsdfCfg()
+    L.orc_esdf_cfg_default(ctypes.byref(ec))
+    ec.min_distance_m = 2 * voxel
+    e = m.esdf_integrator(ec)
+    lists, t_tsdf, t_esdf = [], [], []
+    for pose, pts, col in frames[:n_frames]:
         t0 = time.perf_counter()
-        gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+        it.integrate(pose[0], pose[1], pts, col)
         t1 = time.perf_counter()
-        if i >= warmup:
-            ev.append(gm.timing()["total_ms"])
-            wall.append((t1 - t0) * 1e3)
-            c = gm.counters()
-            pops += c["esdf_sweeps"]
-            relax += c["esdf_relaxations"]
-    gm.close()
-    return {"ms_per_update": round(float(np.mean(ev)), 3), "median_ms": round(float(np.median(ev)), 3), "wall_ms_per_update": round(float(np.mean(wall)), 3),
-            "queue_pops_per_update": round(pops / steps, 1), "relaxations_per_update": round(relax / steps, 1),
-            "frames": [warmup, warmup + steps - 1],
-            "path": "vbx_esdf_cfg.reference_order = 1: updateFromTsdfBlocks' voxel walk, processRaiseSet and processOpenSet replayed in the reference's "
-                    "order by the parallel replay (DESIGN.md 4.4c); bit-identical to the reference (fidelity.reference_order_mode_vs_reference_incremental)"}
+        lists.append(np.array([b for b in m.block_indices(0) if m.tsdf_block(b)[3] & 4], np.int32).reshape(-1, 3))
+        t2 = time.perf_counter()
+        e.update_from_tsdf_layer(True)
+        t3 = time.perf_counter()
+        t_tsdf.append((t1 - t0) * 1e3)
+        t_esdf.append((t3 - t2) * 1e3)
+    return {"map": m, "tsdf": it, "esdf": e, "lists": lists, "tsdf_ms": t_tsdf, "esdf_ms": t_esdf, "kind": "reference" if use_ref else "port",
+            "all_blocks": m.block_indices(0)}
+
+
+def esdf_layer_diff(gm, ref_esdf_dict):
+    """Voxel-by-voxel comparison of the device's ESDF layer with the reference's: blocks, observed flags and distance BITS."""
+    from voxblox_amd import capi
+    idx = gm.block_indices(capi.LAYER_ESDF)
+    v, _, _ = gm.blocks_download(idx, capi.LAYER_ESDF)
+    g = {tuple(int(x) for x in i): k for k, i in enumerate(idx)}
+    n = diff = worst_n = 0
+    worst = 0.0
+    se = 0.0
+    n4 = 0
+    for key, (rd, rf, _rp, _u) in ref_esdf_dict.items():
+        obs = (rf & 1).astype(bool)
+        n += int(obs.sum())
+        if key not in g:
+            diff += int(obs.sum())
+            continue
+        gd = v[g[key]]["distance"]
+        go = v[g[key]]["observed"].astype(bool)
+        bad = (go != obs) | (obs & (gd.view(np.uint32) != rd.view(np.uint32)))
+        diff += int(bad.sum())
+        both = obs & go
+        d = np.abs(gd[both].astype(np.float64) - rd[both])
+        if d.size:
+            worst = max(worst, float(d.max()))
+            se += float((d ** 2).sum())
+            n4 += int((d > 1e-4).sum())
+            worst_n += d.size
+    extra = sum(int(v[k]["observed"].astype(bool).sum()) for key, k in g.items() if key not in ref_esdf_dict)
+    return {"voxels_compared": n, "voxels_differing_from_reference": diff + extra, "max_abs_m": round(worst, 6),
+            "rmse_m": round((se / max(worst_n, 1)) ** 0.5, 6), "frac_gt_1e-4_m": round(n4 / max(worst_n, 1), 5)}
 
 
 def dropin_leg(frames, kind, voxel, warmup, steps):
@@ -500,12 +541,17 @@ def to_device(frames, dev):
     return [(pose, torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev), pts.shape[0]) for pose, pts, col in frames]
 
 
-def run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, esdf_cfg=None, mesh_cfg=None):
-    """W warm-up + K timed steps on one map; returns dt, per-stage ms, counters, esdf/mesh accumulators."""
+def run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, esdf_cfg=None, mesh_cfg=None, esdf_lists=None):
+    """W warm-up + K timed steps on one map; returns dt, per-stage ms, counters, esdf/mesh accumulators.
+    esdf_lists[i] (optional): the block list update i walks, for vbx_esdf_update_blocks — the order of the reference's own
+    container; without it vbx_esdf_update lists the blocks itself."""
     from voxblox_amd import capi  # noqa: F401
-    acc = {"stage": {}, "counters": {}, "esdf_ms": 0.0, "esdf_cnt": {}, "mesh_s": 0.0, "mesh_blocks": 0, "mesh_vertices": 0}
+    acc = {"stage": {}, "counters": {}, "esdf_ms": 0.0, "esdf_cnt": {}, "mesh_s": 0.0, "mesh_blocks": 0, "mesh_vertices": 0,
+           "esdf_each_ms": []}
     total = warmup + steps
     timed = [False]
+    if esdf_cfg is not None:
+        gm.enable_timing(True)      # per-update device times of the warm-up frames too (the first update of a map)
 
     def step(i):
         pose, dp, dc, n = d_frames[i % len(d_frames)]
@@ -516,9 +562,15 @@ def run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, esdf_cfg=N
             for k, v in gm.counters().items():
                 acc["counters"][k] = acc["counters"].get(k, 0) + v
         if esdf_cfg is not None:
-            gm.esdf_update(esdf_cfg, batch=False, clear_updated_flag=True)
+            if esdf_lists is not None:
+                gm.esdf_update_blocks(esdf_cfg, esdf_lists[i], incremental=True)
+                acc["esdf_each_ms"].append(gm.timing()["total_ms"])
+                gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
+            else:
+                gm.esdf_update(esdf_cfg, batch=False, clear_updated_flag=True)
+                acc["esdf_each_ms"].append(gm.timing()["total_ms"])
             if timed[0]:
-                acc["esdf_ms"] += gm.timing()["total_ms"]
+                acc["esdf_ms"] += acc["esdf_each_ms"][-1]
                 for k, v in gm.counters().items():
                     if k.startswith("esdf"):
                         acc["esdf_cnt"][k] = acc["esdf_cnt"].get(k, 0) + v
@@ -545,13 +597,20 @@ def run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, esdf_cfg=N
     return dt, pts, acc, step
 
 
+SENSOR_BANDS = [1]   # ray bundles per sensor frame (--bands); whole sensors reproduce the reference's map
+
+
+def _bands(world):
+    return max(SENSOR_BANDS[0], (max(world, 1) + 3) // 4)
+
+
 def sensors4_shards(step, rank, world, dev, cache):
     """This rank's ray shards of one time step: 4 sensors x B bands, B = max(1, world / 4), dealt out in
     order (sensor-major), so world 1 holds everything, world 4 one sensor each, world 8 half a sensor each."""
     import torch
     from voxblox_amd import multi_gpu, scenes
     out = []
-    for s, b, bands in multi_gpu.deal_sensor_units(world)[rank]:
+    for s, b, bands in multi_gpu.deal_sensor_units(world, bands=_bands(world))[rank]:
         key = (s, step % 25)
         if key not in cache:
             pose, pts, col = scenes.room_sensor_frame(s, step % 25)
@@ -571,7 +630,7 @@ def run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
     pm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
     # one delta map per ray shard of this rank (x 2: the exchange of step k runs behind the integration of step k + 1):
     # the shards of a step are integrated concurrently, one host thread and one HIP stream each
-    n_units = max(1, len(multi_gpu.deal_sensor_units(world)[rank]))
+    n_units = max(1, len(multi_gpu.deal_sensor_units(world, bands=_bands(world))[rank]))
     delta_sets = [[capi.Map(voxel, 16, max_blocks=max(2048, max_blocks // n_units), device=local_rank) for _ in range(n_units)]
                   for _ in range(2)]
     deltas = [delta_sets[0][0], delta_sets[1][0]]
@@ -669,6 +728,149 @@ def calls_per_step_of(gm, n_steps):
 
 
 # ------------------------------------------------------------------------------------------------
+# the ONE line the driver parses: numbers only, < 4 KB; everything else goes to bench_detail.json
+# ------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    o = _pick(r, ("bound", "achieved", "peak", "unit", "frac"))
+    o["traffic"] = r.get("traffic")
+    o.update(_pick(r, ("kernel", "launches_per_step", "avg_launch_us", "kernel_us_per_step", "algorithmic_bytes_per_step",
+                       "step_frac", "device_ms_per_step")))
+    td = r.get("traffic_detail")
+    if isinstance(td, dict):
+        o["traffic_all_kernels_per_step"] = td.get("all_kernels_bytes_per_step")
+        o["traffic_source"] = td.get("source")
+    return o
+
+
+def _short_cpu(c):
+    if not isinstance(c, dict):
+        return None
+    o = _pick(c, ("value", "unit", "cores", "kind", "host_hw_threads", "ms_per_update", "ms_per_step"))
+    if isinstance(c.get("by_threads"), dict):
+        o["by_threads"] = {k: (v.get("value") if isinstance(v, dict) else v) for k, v in c["by_threads"].items()}
+    if c.get("sample"):
+        o["sample"] = str(c["sample"])[:100]
+    return o
+
+
+def _short_esdf(e):
+    if not isinstance(e, dict):
+        return None
+    o = _pick(e, ("mode", "ms_per_update", "median_ms", "voxels_compared", "voxels_differing_from_reference",
+                  "first_update_ms", "batch_update_ms"))
+    if isinstance(e.get("cpu_baseline"), dict):
+        o["cpu_1core"] = _pick(e["cpu_baseline"], ("ms_per_update", "first_update_ms", "batch_update_ms", "tsdf_ms_per_frame", "kind"))
+    if isinstance(e.get("roofline"), dict):
+        o["roofline"] = _pick(e["roofline"], ("achieved", "frac", "kernel", "kernel_us_per_step", "launches_per_step",
+                                              "algorithmic_bytes_per_step", "traffic"))
+    if isinstance(e.get("order_free"), dict):
+        o["order_free_not_bit_exact"] = _pick(e["order_free"], ("ms_per_update", "value", "rmse_m_vs_reference", "max_m_vs_reference",
+                                                                "frac_gt_1e-4_m"))
+    return o
+
+
+def _short_leg(j):
+    if not isinstance(j, dict):
+        return j
+    if "error" in j:
+        return {"error": str(j["error"])[:120]}
+    o = _pick(j, ("value", "unit", "ms_per_step", "steps"))
+    cfgd = j.get("config") or {}
+    o.update(_pick(cfgd, ("ray_bundles_per_step", "semantics")))
+    if "semantics" in o:
+        o["semantics"] = str(o["semantics"])[:90]
+    if isinstance(j.get("roofline"), dict):
+        o["roofline"] = _pick(j["roofline"], ("achieved", "frac", "kernel", "kernel_us_per_step"))
+    if isinstance(j.get("cpu_baseline"), dict):
+        o["cpu_baseline"] = _pick(j["cpu_baseline"], ("value", "cores", "kind"))
+    if isinstance(j.get("esdf"), dict):
+        o["esdf"] = _short_esdf(j["esdf"])
+    if isinstance(j.get("exchange"), dict):
+        o["exchange"] = _pick(j["exchange"], ("payload_bytes_per_step", "sent_blocks_per_step"))
+    for k in ("different_map_16_bundles", "whole_sensor_bundles"):
+        if isinstance(j.get(k), dict):
+            o[k] = _pick(j[k], ("value", "ms_per_step", "ray_bundles_per_step", "payload_bytes_per_step"))
+    return o
+
+
+def compact_line(out, detail_name):
+    """The driver-facing line: BASELINE's metric with `roofline` and `cpu_baseline`, one `value` per secondary leg."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    cfgd = out.get("config") or {}
+    line["config"] = _pick(cfgd, ("workload", "points_per_step", "points_per_step_per_gpu", "voxel_size", "voxels_per_side",
+                                  "ray_bundles_per_step", "parallelism"))
+    for k in ("workload", "parallelism"):
+        if k in line["config"]:
+            line["config"][k] = str(line["config"][k])[:160]
+    line["roofline"] = _short_roofline(out.get("roofline"))
+    line["cpu_baseline"] = _short_cpu(out.get("cpu_baseline"))
+    for k in ("host_pointer_path", "dropin_path"):
+        if isinstance(out.get(k), dict):
+            line[k] = _pick(out[k], ("value", "unit", "ms_per_step", "error"))
+            if isinstance(out[k].get("ms_by_timer_tag"), dict):
+                line[k]["ms_by_timer_tag"] = out[k]["ms_by_timer_tag"]
+    if isinstance(out.get("esdf"), dict):
+        line["esdf"] = _short_esdf(out["esdf"])
+    if isinstance(out.get("exchange"), dict):
+        line["exchange"] = _pick(out["exchange"], ("payload_bytes_per_step", "sent_blocks_per_step", "exchange_ms_per_step",
+                                                   "wait_ms_per_step"))
+    for k in ("different_map_16_bundles",):
+        if isinstance(out.get(k), dict):
+            line[k] = _pick(out[k], ("value", "ms_per_step", "ray_bundles_per_step", "payload_bytes_per_step"))
+    if isinstance(out.get("other_configs"), dict):
+        line["legs"] = {str(k)[:40]: _short_leg(v) for k, v in out["other_configs"].items()}
+    line["detail"] = detail_name
+    text = json.dumps(line, separators=(",", ":"))
+    # belt and braces: shed the optional parts, least important first, until the line fits
+    def legs_drop(key):
+        for leg in (line.get("legs") or {}).values():
+            if isinstance(leg, dict):
+                leg.pop(key, None)
+
+    def legs_bare():
+        line["legs"] = {k: _pick(v, ("value", "ms_per_step", "error")) for k, v in (line.get("legs") or {}).items()}
+
+    shed = [lambda: legs_drop("roofline"), lambda: (line.get("dropin_path") or {}).pop("ms_by_timer_tag", None),
+            lambda: legs_drop("cpu_baseline"), lambda: line.pop("host_pointer_path", None),
+            lambda: (line.get("cpu_baseline") or {}).pop("by_threads", None), lambda: legs_drop("esdf"), legs_bare,
+            lambda: line.pop("esdf", None), lambda: line.pop("exchange", None), lambda: line.pop("legs", None)]
+    for f in shed:
+        if len(text) < LINE_LIMIT:
+            break
+        f()
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(out, args):
+    """Full result -> bench_detail.json (and gpurun_out/ when that exists); the compact line -> stdout, LAST."""
+    path = args.detail_out or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        scratch = os.path.join(ROOT, "gpurun_out")
+        if not args.detail_out and os.path.isdir(scratch):
+            with open(os.path.join(scratch, "bench_detail.json"), "w") as f:
+                json.dump(out, f, indent=1)
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not write {path}: {e}\n")
+    sys.stderr.flush()
+    print(compact_line(out, os.path.basename(path)), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -717,7 +919,7 @@ def main():
 
     def finish(out):
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out, args)
         if world > 1 or force_sharded:
             dist.barrier()
             dist.destroy_process_group()
@@ -728,6 +930,8 @@ def main():
 
     # ---------------------------------------------------------------------------- configs[4]
     if workload == "sensors4":
+        SENSOR_BANDS[0] = max(1, args.bands or 1)
+        nb = 4 * _bands(world)
         dt, exch, rows, alg, _maps = run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup,
                                                   lambda: barrier())
         if world > 1:
@@ -740,25 +944,21 @@ def main():
                     "config": {"workload": "BASELINE configs[4]: FastTsdfIntegrator, 4 concurrent 640x480 synthetic room sensors, "
                                            "%g m voxels / 16^3 blocks, trunc %g m; one step = all four frames (1,228,800 points)" % (voxel, trunc),
                                "points_per_step": pts_step, "voxel_size": voxel, "voxels_per_side": 16, "world_size_seen": world,
-                               "semantics": "shard + merge: each ray shard (a sensor, or a band of one) integrated into a zeroed delta "
-                                            "map of its own (bit-exact Fast integrator per shard, the shards of a rank concurrently), "
-                                            "deltas merged in shard order with mergeVoxelAIntoVoxelB semantics — the merged map "
-                                            "depends on the shard layout, not on the number of ranks",
-                               "ray_bundles_per_step": 16,
-                               "parallelism": ("4 ray bands per sensor = 16 bundles per step (the same layout for every number of GPUs); " +
+                               "semantics": ("whole-sensor ray bundles: the layout that reproduces the reference's map in the first step and stays "
+                                             "within 2 % of the voxels afterwards (profiles/r04_shard_divergence_0p02.json)" if nb == 4 else
+                                             "%d bundles per sensor: A DIFFERENT MAP than the reference integrates (every band restarts the "
+                                             "Fast integrator's lossy sets); bit-exact only against an oracle doing the same shard + merge" % (nb // 4)),
+                               "ray_bundles_per_step": nb,
+                               "parallelism": ("%d ray bundle(s) per sensor = %d per step; " % (nb // 4, nb) +
                                                ("1 GPU integrates all of them concurrently (same shard + merge, no collective)" if world == 1 else
-                                                f"{world} ranks, {16 // world if world <= 16 else 1} bundle(s) each, sparse RCCL all-to-all of touched "
-                                                "blocks to their owners pipelined behind the next step's integration, map distributed by block owner"))},
+                                                f"{world} ranks, sparse RCCL all-to-all-v of touched blocks to their owners pipelined behind the next "
+                                                "step's integration, map distributed by block owner"))},
                     "exchange": exch})
         if world > 1:
             # the driver's N = 1 run of `bench.py` is configs[1] (the metric's own configuration), a different workload:
             # the one-GPU point of THIS curve is the same shard + merge on one GPU
-            out["n1_same_workload"] = {"command": "python bench.py --gpus 1 --workload sensors4",
-                                       "measured": "profiles/r03_bench_sensors4_1gpu.json: 32.5 Mpoints/s, 37.8 ms per step "
-                                                   "(MI355X, round 3; the same sixteen ray bundles, all on one GPU, libvbx_shard.so host path; "
-                                                   "43-55 ms through the Python host path the N > 1 runs use)",
-                                       "note": "strong-scaling efficiency at N = value / (N x that value); do not divide by the "
-                                               "configs[1] line"}
+            out["n1_same_workload"] = {"command": "python bench.py --gpus 1 --workload sensors4" + (" --bands %d" % args.bands if args.bands else ""),
+                                       "note": "strong-scaling efficiency at N = value / (N x that command's value); do not divide by the configs[1] line"}
         if rank == 0 and rows:
             alg_bytes = 16.0 * alg["points"] + 24.0 * alg["voxels_touched"]
             dev_ms = sum(r["us_per_step"] for r in rows) / 1e3
@@ -768,6 +968,18 @@ def main():
             from voxblox_amd import scenes
             fr = [scenes.room_sensor_frame(0, k) for k in range(8)]
             out["cpu_baseline"] = cpu_baseline(fr, "fast", voxel, args.cpu_seconds)
+        if world == 1 and nb == 4 and not args.bands and rank == 0:
+            # rounds 3-4 quoted this layout; it integrates ANOTHER map than the reference, so it is a secondary figure
+            try:
+                del _maps
+                torch.cuda.empty_cache()
+                SENSOR_BANDS[0] = 4
+                dt16, exch16, _r, _a, _m = run_sensors4(args, voxel, world, rank, local_rank, dist, dev, steps, warmup, lambda: barrier(), profile=False)
+                out["different_map_16_bundles"] = {"value": round(pts_step * steps / dt16 / 1e6, 3), "ms_per_step": round(dt16 / steps * 1e3, 4),
+                                                   "ray_bundles_per_step": 16, "payload_bytes_per_step": exch16.get("payload_bytes_per_step"),
+                                                   "note": "four bands per sensor: not the reference's map (12 % of voxels > 1e-4 m, half the weight missing)"}
+            except Exception as e:
+                out["different_map_16_bundles"] = {"error": repr(e)[:200]}
         finish(out)
         return
 
@@ -851,7 +1063,18 @@ def main():
 
     gm = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
     gm.set_stream(torch.cuda.current_stream().cuda_stream)
-    dt, pts_timed, acc, step = run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, ecfg, mcfg)
+    esdf_ref = None
+    esdf_parity = args.esdf and args.esdf_mode == "reference"
+    if esdf_parity:
+        # the timed region runs the reference's OWN result (vbx_esdf_cfg.reference_order = 1).  The reference build walks the
+        # same frames first (outside the clock): its times are the CPU figures of this leg, its final layer is what the device's
+        # layer is compared with afterwards.
+        ecfg = capi.esdf_cfg(min_distance_m=trunc / 2, reference_order=1)
+        if not args.no_cpu_baseline:
+            esdf_ref = esdf_reference_run(frames, voxel, total)
+    use_lists = esdf_ref is not None and os.environ.get("VBX_BENCH_ESDF_LISTS", "0") == "1"
+    dt, pts_timed, acc, step = run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, ecfg, mcfg,
+                                          esdf_lists=esdf_ref["lists"] if use_lists else None)
     K = steps
     workload_name = {("fast", "room"): "BASELINE configs[1]", ("merged", "cow"): "BASELINE configs[2]"}.get((args.integrator, args.scene), "variant")
     if args.esdf and args.integrator == "fast" and args.scene == "room":
@@ -865,8 +1088,10 @@ def main():
                                        + ", %g m voxels / 16^3 blocks, trunc %g m" % (voxel, trunc),
                            "points_per_step": n_pts, "voxel_size": voxel, "voxels_per_side": 16, "world_size_seen": world,
                            "scene": args.scene, "esdf_after_each_frame": bool(args.esdf), "mesh_after_each_frame": bool(args.mesh),
-                           "semantics": "bit-exact vs the 1-thread reference" if (args.merged_order == 0 and args.fast_set == 0)
-                                        else "fast mode (merged_bundle_order=%d, fast_observed_set=%d)" % (args.merged_order, args.fast_set),
+                           "semantics": ("fast mode (merged_bundle_order=%d, fast_observed_set=%d)" % (args.merged_order, args.fast_set)
+                                         if (args.merged_order or args.fast_set) else
+                                         "TSDF bit-exact vs the 1-thread reference; ESDF order-free fixed point, NOT bit-exact" if (args.esdf and not esdf_parity)
+                                         else "bit-exact vs the 1-thread reference"),
                            "parallelism": "1 GPU, whole cloud"}})
     stage = {k: round(v / K, 4) for k, v in acc["stage"].items()}
     out["stage_ms"] = stage
@@ -912,7 +1137,11 @@ def main():
                     ge.profile(True, reset=True)
                 elif i > warmup:
                     ge.profile(True)
-                ge.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+                if use_lists:
+                    ge.esdf_update_blocks(ecfg, esdf_ref["lists"][i], incremental=True)
+                    ge.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
+                else:
+                    ge.esdf_update(ecfg, batch=False, clear_updated_flag=True)
                 if i >= warmup:
                     c = ge.counters()
                     blocks += c["esdf_blocks"]
@@ -923,13 +1152,15 @@ def main():
             del ge
             ealg = (52.0 * 4096 * blocks + 40.0 * relax) / P
             esdf_ms = acc["esdf_ms"] / K
-            out["esdf"] = {"ms_per_update": round(esdf_ms, 4),
+            each = acc["esdf_each_ms"]
+            out["esdf"] = {"mode": "reference_order=1 (the reference's own result)" if esdf_parity else "order-free fixed point, NOT bit-exact",
+                           "ms_per_update": round(esdf_ms, 4), "median_ms": round(float(np.median(each[warmup:])), 4),
+                           "first_update_ms": round(each[0], 3) if each else None,
                            "counters_per_update": {k: round(v / K, 1) for k, v in acc["esdf_cnt"].items()},
                            "roofline": roofline_from(erows, ealg, esdf_ms, "52 B x 4096 x updated blocks + 40 B x successful relaxations (SURVEY 8(d))"),
                            "kernels": erows[:8],
-                           "path": "vbx_esdf_cfg.reference_order = 0: the order-free fixed point (masks and fixed band equal to the reference's, "
-                                   "distances inside its min_diff_m envelope: fidelity.vs_reference_*); the reference's own result on the same "
-                                   "frames: esdf.reference_order"}
+                           "block_list": ("the reference container's own order, handed to vbx_esdf_update_blocks" if use_lists else
+                                          "vbx_esdf_update lists the blocks itself" + (" in the order the reference's Layer would hold them" if esdf_parity else ""))}
     elif args.esdf:
         out["esdf"] = {"ms_per_update": round(acc["esdf_ms"] / K, 4)}
     gm.enable_timing(True)
@@ -1005,8 +1236,47 @@ def main():
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(frames[:total], args.integrator, voxel, args.cpu_seconds,
                                            window=(warmup, steps) if voxel >= 0.049 else None)
-        if args.esdf:
-            out["esdf"]["reference_order"] = esdf_reference_order_leg(args, d_frames, kind, cfg, voxel, trunc, max_blocks, local_rank, warmup, steps)
+        if args.esdf and esdf_ref is not None:
+            # parity of the timed region itself: the device layer after the last timed frame against the reference's
+            out["esdf"].update(esdf_layer_diff(gm, esdf_ref["map"].esdf_dict()))
+            te, tt = esdf_ref["esdf_ms"], esdf_ref["tsdf_ms"]
+            out["esdf"]["cpu_baseline"] = {"ms_per_update": round(float(np.median(te[warmup:])), 3), "first_update_ms": round(te[0], 3),
+                                           "tsdf_ms_per_frame": round(float(np.median(tt[warmup:])), 3), "cores": 1, "kind": esdf_ref["kind"],
+                                           "sample": "the frames of the timed region, reference build, 1 integrator thread (the deterministic reference), "
+                                                     "updateFromTsdfLayer(true) after every frame"}
+            # updateFromTsdfLayerBatch (esdf_integrator.cc:94-102) of the final TSDF map, both sides
+            try:
+                t0 = time.perf_counter()
+                esdf_ref["esdf"].update_from_tsdf_layer_batch()
+                out["esdf"]["cpu_baseline"]["batch_update_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+                gm.enable_timing(True)
+                if use_lists:
+                    gm.clear(capi.LAYER_ESDF)
+                    gm.esdf_update_blocks(ecfg, esdf_ref["all_blocks"], incremental=False)
+                else:
+                    gm.esdf_update(ecfg, batch=True, clear_updated_flag=True)
+                out["esdf"]["batch_update_ms"] = round(gm.timing()["total_ms"], 2)
+                out["esdf"]["batch"] = esdf_layer_diff(gm, esdf_ref["map"].esdf_dict())
+            except Exception as e:  # a secondary measurement must never take the line down
+                out["esdf"]["batch"] = {"error": repr(e)[:200]}
+            # the order-free mode on the same frames: fast, another answer
+            try:
+                go = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
+                go.set_stream(torch.cuda.current_stream().cuda_stream)
+                ocfg = capi.esdf_cfg(min_distance_m=trunc / 2)
+                dto, ptso, acco, _ = run_stream(args, go, kind, cfg, d_frames, steps, warmup, barrier, ocfg, None)
+                # (the reference map went through the batch update above: compare with a fresh incremental run)
+                ref2 = esdf_reference_run(frames, voxel, total)
+                dd = esdf_layer_diff(go, ref2["map"].esdf_dict())
+                out["esdf"]["order_free"] = {"value": round(ptso / dto / 1e6, 3), "ms_per_update": round(acco["esdf_ms"] / K, 4),
+                                             "rmse_m_vs_reference": dd["rmse_m"], "max_m_vs_reference": dd["max_abs_m"],
+                                             "frac_gt_1e-4_m": dd["frac_gt_1e-4_m"], "voxels_differing_from_reference": dd["voxels_differing_from_reference"],
+                                             "note": "vbx_esdf_cfg.reference_order = 0; NOT the reference's result"}
+                go.close()
+                del go, ref2
+            except Exception as e:
+                out["esdf"]["order_free"] = {"error": repr(e)[:200]}
+        elif args.esdf:
             out["esdf"]["cpu_baseline"] = cpu_esdf_baseline(frames[:40], voxel, min(args.cpu_seconds, 12.0))
             if args.esdf_fidelity_frames > 0:
                 nf = min(args.esdf_fidelity_frames, len(frames))
@@ -1018,23 +1288,30 @@ def main():
     if default_run and not args.no_extras:
         extras = {}
         py = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-host-path", "--mirror-frames", "0"]
-        legs = {"configs[2] merged, cow-and-lady-like orbit": ["--integrator", "merged", "--scene", "cow", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
-                "configs[3] fast + esdf update per frame": ["--esdf", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
-                "configs[4] on one GPU (4 sensors, 0.02 m, shard + merge)": ["--workload", "sensors4", "--steps", "4", "--warmup", "2"]}
+        legs = {"configs[2] merged cow orbit": ["--integrator", "merged", "--scene", "cow", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
+                "configs[3] fast + esdf (reference order)": ["--esdf", "--steps", "20", "--warmup", "3", "--cpu-seconds", "6"],
+                "configs[4] 4 sensors 0.02 m, 1 GPU": ["--workload", "sensors4", "--steps", "4", "--warmup", "2"]}
         del gm
         torch.cuda.empty_cache()
+        if steps < 10:   # a short run (tests): the legs shorten themselves with it
+            for extra in legs.values():
+                if "--steps" in extra:
+                    extra[extra.index("--steps") + 1] = str(steps)
+                    extra[extra.index("--warmup") + 1] = str(min(warmup, 2))
+        import tempfile
         for name, extra in legs.items():
             try:
-                r = subprocess.run(py + extra, capture_output=True, text=True, timeout=600)
-                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                if r.returncode == 0 and line:
-                    j = json.loads(line[-1])
-                    keep = {k: j[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "cpu_baseline", "esdf", "exchange", "roofline") if k in j}
-                    if "cpu_baseline" in keep:
-                        keep["cpu_baseline"] = {k: v for k, v in keep["cpu_baseline"].items() if k != "sample"}
+                with tempfile.NamedTemporaryFile(suffix=".json", delete=False) as tf:
+                    leg_path = tf.name
+                r = subprocess.run(py + extra + ["--detail-out", leg_path], capture_output=True, text=True, timeout=900)
+                if r.returncode == 0 and os.path.getsize(leg_path) > 2:
+                    j = json.load(open(leg_path))
+                    keep = {k: j[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "cpu_baseline", "esdf", "exchange", "roofline",
+                                              "different_map_16_bundles") if k in j}
                     extras[name] = keep
                 else:
                     extras[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                os.unlink(leg_path)
             except Exception as e:  # a secondary leg must never take the headline line down
                 extras[name] = {"error": repr(e)}
         out["other_configs"] = extras

@@ -1,0 +1,78 @@
+"""bench.py's driver-facing line: ONE JSON object, under 4 KB, carrying `roofline` and `cpu_baseline`.
+
+Round 4's line had grown to 21 KB and the driver could not parse it (BENCH_r04.parsed = null); the full result now goes
+to bench_detail.json and the line is built by bench.compact_line.  CPU test: the builder on round 4's full result and on an
+inflated one.  GPU test: the driver's own command shape end to end.
+"""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _check_line(text):
+    assert "\n" not in text
+    assert len(text) < 4096, len(text)
+    j = json.loads(text)
+    for k in REQUIRED:
+        assert k in j, k
+    assert j["config"]["workload"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in j["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in j["cpu_baseline"], k
+    return j
+
+
+def test_compact_line_of_round_4s_full_result_fits_and_keeps_the_contract():
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    assert len(json.dumps(full)) > 15000          # the line the driver could not parse
+    j = _check_line(bench.compact_line(full, "bench_detail.json"))
+    assert j["value"] == full["value"] and j["ms_per_step"] == full["ms_per_step"]
+    assert j["roofline"]["frac"] == full["roofline"]["frac"]
+    assert set(j["cpu_baseline"]["by_threads"]) == set(full["cpu_baseline"]["by_threads"])
+    assert len(j["legs"]) == len(full["other_configs"])
+    for leg in j["legs"].values():
+        assert "value" in leg and "ms_per_step" in leg
+
+
+def test_compact_line_sheds_optional_parts_instead_of_overflowing():
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    fat = copy.deepcopy(full)
+    fat["other_configs"] = {"leg %d %s" % (i, "x" * 60): copy.deepcopy(v) for i in range(6) for v in full["other_configs"].values()}
+    fat["cpu_baseline"]["by_threads"] = {str(t): {"value": 1.0 + t} for t in range(1, 120)}
+    j = _check_line(bench.compact_line(fat, "bench_detail.json"))
+    assert j["value"] == full["value"]
+
+
+@pytest.mark.gpu
+def test_the_drivers_command_prints_one_parseable_line_under_4_kb(tmp_path):
+    """`python bench.py --gpus 1 --steps K --warmup W` as the driver runs it (short K so that the test stays short; the
+    secondary legs shorten themselves with it): the LAST stdout line is the result."""
+    detail = tmp_path / "detail.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                        "--detail-out", str(detail)], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    j = _check_line(lines[-1])
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 2
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    legs = j["legs"]
+    assert len(legs) == 3 and all("value" in v for v in legs.values()), legs
+    esdf = [v for k, v in legs.items() if "configs[3]" in k][0]["esdf"]
+    assert esdf["voxels_differing_from_reference"] == 0 and esdf["voxels_compared"] > 100000, esdf
+    sens = [v for k, v in legs.items() if "configs[4]" in k][0]
+    assert sens["ray_bundles_per_step"] == 4
+    full = json.load(open(detail))
+    assert full["value"] == j["value"] and "kernels" in full

@@ -347,3 +347,35 @@ def test_reference_order_one_wave_form_still_agrees(oracle):
         _lockstep(oracle, sc, dict())
     finally:
         os.environ.pop("VBX_ESDF_REPLAY", None)
+
+
+def test_reference_order_list_longer_than_the_pool_naming_absent_blocks(oracle):
+    """A caller's list may name blocks the TSDF layer does not hold (esdf_integrator.cc:139-143 skips them) — far more of
+    them than the map has blocks, so that the ordered-push scan of the voxel walk runs over more tiles than a pool-sized
+    descriptor array would hold (round-4 ADVICE: out-of-bounds descriptor stores).  Bit-exact against the oracle on the
+    same list, and the map must still be usable afterwards."""
+    from voxblox_amd import capi
+    L = oracle.lib()
+    L.orc_fast_reset_counter_set(0)
+    voxel = 0.1
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("fast", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    gm = capi.Map(voxel, 16, max_blocks=256)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    kw = dict(min_distance_m=2 * voxel)
+    oe = om.esdf_integrator(oracle.esdf_cfg(**kw))
+    ge = capi.esdf_cfg(reference_order=1, **kw)
+    rng = np.random.default_rng(5)
+    for f, (pose, pts, col) in enumerate(S.frames(2)):
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+        real = _updated_esdf_blocks_in_container_order(om)
+        ghosts = rng.integers(1000, 2000, size=(700, 3)).astype(np.int32)      # 700 absent blocks: 2.9 M walk items
+        lst = np.concatenate([ghosts[:350], real, ghosts[350:]])
+        oe.update_from_tsdf_blocks(lst, incremental=True)
+        for i in real:
+            d, w, c, bits = om.tsdf_block(i)
+            om.tsdf_block_set(i, d, w, c, bits & ~4)
+        gm.esdf_update_blocks(ge, lst, incremental=True)
+        gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
+        _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")

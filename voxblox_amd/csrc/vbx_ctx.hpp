@@ -82,7 +82,7 @@ struct vbx_ctx {
   DBuf rp_ctl, rp_nbslot, rp_chunk_tab, rp_rec_u32, rp_rec_T, rp_rec_kid, rp_rec_tgts, rp_rec_push, rp_vox2tgt, rp_tgt_u32, rp_tgt_ev, rp_dl,
       rp_lists, rp_sub, rp_sub_list, rp_sim_q, rp_ord, rp_scan_desc, rp_hazard, cls_pos, cls_nb27, cls_shadow, cls_counters;
   size_t rp_vox2tgt_zeroed = 0;   // bytes of rp_vox2tgt known to be zero
-  uint32_t rp_rec_cap = 0, rp_tgt_cap = 0, rp_kmax = 0, rp_smax = 0;
+  uint32_t rp_rec_cap = 0, rp_tgt_cap = 0, rp_kmax = 0, rp_smax = 0, rp_scan_tiles_cap = 0;
   bool esdf_init = false;
   bool esdf_robot_pending = false;  // addNewRobotPosition since the last update
   // addNewRobotPosition under reference_order: what the call left in the integrator's containers, in the reference's order

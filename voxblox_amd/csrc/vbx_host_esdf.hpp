@@ -437,7 +437,7 @@ static uint32_t rp_env_u32(const char* name, uint32_t dflt) {
 }
 
 // buffers of the replay, sized for kmax base records per super-step
-int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used) {
+int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used, size_t n_list) {
   hipStream_t s = ctx->stream;
   const MapDev& m = ctx->map;
   const uint32_t kmax = rp_env_u32("VBX_RP_KMAX", 16384), smax = std::min<uint32_t>(rp_env_u32("VBX_RP_SMAX", 1024), kSimMax);
@@ -480,8 +480,11 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   }
   {
     // chained-scan descriptors: one per tile of the longest scan (the voxel walk of the classification); ticket = 0, generation = 1
-    const size_t items = std::max<size_t>(rec_cap, (size_t)std::max<uint32_t>(used, 1) * m.nvox);
+    // (a caller's list may name blocks the map does not hold, esdf_integrator.cc:139-143, or a block twice: it can be
+    // longer than the pool, and k_cls_push scans n_list * nvox items)
+    const size_t items = std::max<size_t>(rec_cap, std::max<size_t>(std::max<uint32_t>(used, 1), n_list) * m.nvox);
     const size_t bytes = (items / kRpThreads + 2) * 4 * 8 + 64;
+    ctx->rp_scan_tiles_cap = (uint32_t)std::min<size_t>(items / kRpThreads + 2, 0xFFFFFFFFu);
     if (ctx->rp_scan_desc.cap < bytes) {
       HIP_TRY(ctx->rp_scan_desc.ensure(bytes));
       HIP_TRY(hipMemsetAsync(ctx->rp_scan_desc.p, 0, ctx->rp_scan_desc.cap, s));
@@ -568,7 +571,7 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   RpScan sc;
   sc.desc = ctx->rp_scan_desc.as<unsigned long long>() + 8;
   sc.ticket = ctx->rp_scan_desc.as<uint32_t>();
-  sc.max_tiles = ctx->rp_rec_cap / kRpThreads + 1;
+  sc.max_tiles = ctx->rp_scan_tiles_cap;
   const bool serial = rp_env_u32("VBX_RP_SERIAL", 0) != 0;   // debug: the emulated thread-per-item phases on the device
   rp::Args as = a;   // (serial form: no member lists, ranking from the child table)
   as.sub_mem = nullptr; as.sub_restart = nullptr;
@@ -676,7 +679,7 @@ int esdf_classify_parallel(vbx_ctx* ctx, const EsdfCfgDev& c, const EsdfDev& e, 
     RpScan sc;
     sc.desc = ctx->rp_scan_desc.as<unsigned long long>() + 8;
     sc.ticket = ctx->rp_scan_desc.as<uint32_t>();
-    sc.max_tiles = 0;
+    sc.max_tiles = ctx->rp_scan_tiles_cap;
     const uint32_t tiles = (uint32_t)(((size_t)n_list * m.nvox + kRpThreads - 1) / kRpThreads);
     for (int q0 = 0; q0 <= num_buckets; q0 += 4)
       KLAUNCH(k_cls_push, dim3(std::min<uint32_t>(tiles, 1024u)), dim3(kRpThreads), 0, s, a, ra, sc, q0);
@@ -799,7 +802,7 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   HIP_TRY(ctx->b_keys0.ensure(n_chunks * kSqChunk * 4));
   HIP_TRY(ctx->b_vals0.ensure(64));
   const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0 && cfg->num_buckets <= 254;   // (a push table entry is one byte: bucket + 1, raise_ = num_buckets)
-  rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used);
+  rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used, n);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(ctx->rp_ctl.p, 0, sizeof(rp::Ctl), s));
   if (n_seed) {

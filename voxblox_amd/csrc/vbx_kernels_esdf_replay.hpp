@@ -572,6 +572,10 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
   __shared__ uint32_t s_wave[kRpThreads / 64][4];
   __shared__ uint32_t s_prefix[4];
   const uint32_t tiles = (n + kRpThreads - 1) / kRpThreads;
+  if (tiles > sc.max_tiles) {   // more tiles than descriptors: fail loudly instead of indexing past the buffer
+    if (threadIdx.x == 0) atomicOr(err, 64u);
+    return;
+  }
   const uint32_t gen = sc.ticket[1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (;;) {
