@@ -809,7 +809,7 @@ def compact_line(out, detail_name):
     line["vs_baseline"] = out.get("vs_baseline")
     cfgd = out.get("config") or {}
     line["config"] = _pick(cfgd, ("workload", "points_per_step", "points_per_step_per_gpu", "voxel_size", "voxels_per_side",
-                                  "ray_bundles_per_step", "parallelism"))
+                                  "world_size_seen", "ray_bundles_per_step", "parallelism"))
     for k in ("workload", "parallelism"):
         if k in line["config"]:
             line["config"][k] = str(line["config"][k])[:160]
@@ -828,6 +828,8 @@ def compact_line(out, detail_name):
     for k in ("different_map_16_bundles",):
         if isinstance(out.get(k), dict):
             line[k] = _pick(out[k], ("value", "ms_per_step", "ray_bundles_per_step", "payload_bytes_per_step"))
+    if isinstance(out.get("n1_same_workload"), dict):
+        line["n1_same_workload"] = out["n1_same_workload"].get("command")
     if isinstance(out.get("other_configs"), dict):
         line["legs"] = {str(k)[:40]: _short_leg(v) for k, v in out["other_configs"].items()}
     line["detail"] = detail_name

@@ -231,6 +231,20 @@ int vbx_block_indices(vbx_ctx* ctx, int layer, int32_t* idx_xyz, size_t cap, siz
 /* Layer::getAllUpdatedBlocks(bit) (layer.h:194-203); update_mask = OR of VBX_UPDATE_*. */
 int vbx_blocks_updated(vbx_ctx* ctx, int layer, int update_mask, int32_t* idx_xyz, size_t cap,
                        size_t* n);
+/* The TSDF blocks the LAST vbx_tsdf_integrate[_device] call added to the Layer, in the sequence in which the reference's
+ * single-threaded integrator inserts them: allocateStorageAndGetVoxelPtr emplaces a missing block in temp_block_map_ the
+ * first time a ray reaches it (tsdf_integrator.cc:107-121) and updateLayerWithStoredBlocks walks that container into
+ * Layer::insertBlock (:137-147; the Merged integrator does so once per pass, :329-336).  The device records every new
+ * block's first touch in the reference's taking order; the host replays the container (same hash, same libstdc++, the
+ * bucket array clear() leaves behind included).  A host Layer that allocates its new blocks in this sequence iterates
+ * like the Layer of a CPU run (Layer::getAllUpdatedBlocks, layer.h:194-203) — which is what the ESDF's walk order, and
+ * with it its result, depends on (esdf_integrator.cc:104-143). */
+int vbx_blocks_new_ordered(vbx_ctx* ctx, int32_t* idx_xyz, size_t cap, size_t* n);
+/* Layer::getAllAllocatedBlocks (update_mask 0) / getAllUpdatedBlocks(bit) of the TSDF layer in the iteration order the
+ * reference's block_map_ would have, as far as the library saw the Layer being built (integrate calls in the sequence
+ * above, vbx_blocks_upload in list order, removals); *exact (optional) = 0 when blocks of unknown provenance had to be
+ * appended in ascending order.  vbx_esdf_update with cfg->reference_order walks this order. */
+int vbx_block_indices_layer_order(vbx_ctx* ctx, int update_mask, int32_t* idx_xyz, size_t cap, size_t* n, int* exact);
 /* Block<V> voxel array in the reference's AoS layout: TsdfVoxel = {float distance; float
  * weight; uint8 r,g,b,a} (12 B, voxel.h:12-16); EsdfVoxel = {float distance; uint8 observed,
  * hallucinated, in_queue, fixed; int32 parent[3]} (20 B, voxel.h:18-37).  Returns

@@ -1,0 +1,116 @@
+"""-m gpu: the sequence in which new blocks join the Layer.
+
+The reference's integrators emplace a missing block in temp_block_map_ the first time a ray reaches it
+(allocateStorageAndGetVoxelPtr, tsdf_integrator.cc:107-121) and updateLayerWithStoredBlocks walks that container into
+Layer::insertBlock (:137-147; Merged once per pass).  The Layer is a std::unordered_map, so the sequence of insertions
+decides the order in which getAllAllocatedBlocks / getAllUpdatedBlocks list the blocks (layer.h:184-203) — and the
+EsdfIntegrator's result depends on that order (esdf_integrator.cc:104-143).  The device records every new block's first
+touch in the 1-thread taking order; the library replays the two containers.  Checked here against the oracle's Layer
+(whose container order is pinned against the reference build by tests/test_oracle_vs_reference_build.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import scenarios as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+KIND = {"simple": 1, "merged": 2, "fast": 3}
+
+
+def _order(a):
+    return [tuple(int(x) for x in b) for b in a]
+
+
+@pytest.mark.parametrize("kind,voxel,cfg", [
+    ("fast", 0.1, {}), ("fast", 0.05, {}), ("simple", 0.1, {}), ("merged", 0.1, {}), ("merged", 0.1, dict(enable_anti_grazing=1)),
+    ("fast", 0.1, dict(voxel_carving_enabled=0)), ("simple", 0.1, dict(integration_order_mode=1, allow_clear=0)),
+], ids=["fast", "fast_0p05", "simple", "merged", "merged_anti_grazing", "fast_no_carving", "simple_sorted"])
+def test_layer_iteration_order_equals_the_references(oracle, kind, voxel, cfg):
+    from voxblox_amd import capi
+    L = oracle.lib()
+    L.orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator(kind, oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1, **cfg))
+    gm = capi.Map(voxel, 16, max_blocks=4096)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel, **cfg)
+    seen = []
+    for f, (pose, pts, col) in enumerate(S.frames(6)):
+        before = set(_order(om.block_indices(0)))
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(KIND[kind], gc, pose[0], pose[1], pts, col)
+        new = _order(gm.blocks_new_ordered())
+        assert set(new) == set(_order(om.block_indices(0))) - before, f
+        seen.append(len(new))
+        got, exact = gm.block_indices_layer_order()
+        assert exact
+        assert _order(got) == _order(om.block_indices(0)), (kind, f)
+        upd, _ = gm.block_indices_layer_order(capi.UPDATE_ESDF)
+        assert _order(upd) == [tuple(int(x) for x in b) for b in om.block_indices(0) if om.tsdf_block(b)[3] & 4]
+        for b in om.block_indices(0):     # both sides' consumers clear their bit
+            d, w, c, bits = om.tsdf_block(b)
+            om.tsdf_block_set(b, d, w, c, bits & ~4)
+        gm.clear_updated(capi.UPDATE_ESDF)
+    assert seen[0] > 20 and sum(seen[1:]) > 0, seen
+
+
+def test_order_survives_removals_and_a_sliding_window(oracle):
+    """removeDistantBlocks after every frame on both sides (tsdf_server.cc:315): erased keys leave the container, blocks that
+    come back later are inserted anew — the iteration orders must stay equal."""
+    from voxblox_amd import capi
+    L = oracle.lib()
+    L.orc_fast_reset_counter_set(0)
+    voxel = 0.1
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("fast", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    gm = capi.Map(voxel, 16, max_blocks=1024)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    removed = 0
+    for f, (pose, pts, col) in enumerate(S.frames(10, step=9)):
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+        n0 = om.num_blocks(0)
+        om.remove_distant_blocks(pose[0], 2.6)
+        gm.remove_distant_blocks(pose[0], 2.6)
+        removed += n0 - om.num_blocks(0)
+        got, exact = gm.block_indices_layer_order()
+        assert exact and _order(got) == _order(om.block_indices(0)), f
+    assert removed > 10
+
+
+def test_plain_reference_order_update_reproduces_the_golden_incremental_digest(oracle):
+    """vbx_esdf_update(reference_order = 1) WITHOUT a list: the library walks the blocks in the order the reference's Layer
+    would hold them, so the reference build's golden `esdf_incremental` digest comes out with no input from the checker."""
+    import json
+    from voxblox_amd import capi
+    from test_gpu_esdf_reference_order import _gpu_esdf_dict
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_digests.json")))["scenarios"]
+    name = "esdf_incremental"
+    sc = S.SCENARIOS[name]
+    gm = capi.Map(sc["voxel"], 16, max_blocks=2048)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * sc["voxel"], **sc["cfg"])
+    ge = capi.esdf_cfg(min_distance_m=2 * sc["voxel"], reference_order=1, **sc["esdf"]["cfg"])
+    for pose, pts, col in S.frames(sc["n"]):
+        gm.integrate(KIND[sc["kind"]], gc, pose[0], pose[1], pts, col)
+        gm.esdf_update(ge, batch=False, clear_updated_flag=True)
+    assert S.digest_esdf(_gpu_esdf_dict(gm)) == gold[name]["esdf"]
+    assert len(gm.blocks_updated(capi.UPDATE_ESDF)) == 0
+
+
+def test_uploaded_blocks_join_in_list_order_and_unknown_ones_are_reported():
+    from voxblox_amd import capi
+    gm = capi.Map(0.1, 16, max_blocks=256)
+    idx = np.array([[3, 1, 0], [-2, 0, 1], [0, 0, 0], [5, -4, 2], [1, 1, 1]], np.int32)
+    vox = np.zeros((len(idx), 4096), capi.TSDF_VOXEL_DTYPE)
+    gm.blocks_upload(idx, vox, np.full(len(idx), 7, np.uint8))
+    got, exact = gm.block_indices_layer_order()
+    assert exact
+    # the same insertions into the same container (vbx_selftest_index_set_order uses the reference's hash)
+    out = np.zeros_like(idx)
+    n = capi.lib().vbx_selftest_index_set_order(idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx),
+                                                out.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert n == len(idx) and _order(got) == _order(out)

@@ -85,13 +85,8 @@ def _lockstep(oracle, sc, esdf_kw, n_frames=None, list_mode="container", check_e
             oe.update_from_tsdf_layer(True)
             gm.esdf_update_blocks(ge, lst, incremental=True)
             gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
-        else:   # vbx_esdf_update's own order: ascending (z,y,x); the oracle gets the same list
-            lst = _updated_esdf_blocks_in_container_order(om)
-            lst = lst[np.lexsort((lst[:, 0], lst[:, 1], lst[:, 2]))]
-            oe.update_from_tsdf_blocks(lst, incremental=True)
-            for i in lst:   # updateFromTsdfBlocks clears nothing (:124-302): clear Update::kEsdf by hand
-                d, w, c, bits = om.tsdf_block(i)
-                om.tsdf_block_set(i, d, w, c, bits & ~4)
+        else:   # vbx_esdf_update's own order: the one the reference's Layer would have (replayed by the library, round 5)
+            oe.update_from_tsdf_layer(True)
             gm.esdf_update(ge, batch=False, clear_updated_flag=True)
         if check_every_frame:
             _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")
@@ -155,9 +150,9 @@ def test_reference_order_variants_bit_exact_vs_oracle(oracle, esdf_kw):
 
 
 def test_reference_order_own_block_order_and_clear_flag(oracle):
-    """vbx_esdf_update(reference_order = 1) without a list: ascending (z,y,x) over the blocks carrying Update::kEsdf,
-    which it clears (updateFromTsdfLayer(true), esdf_integrator.cc:113-121) — bit-exact against the oracle fed the
-    same list."""
+    """vbx_esdf_update(reference_order = 1) without a list: the blocks carrying Update::kEsdf in the order the reference's
+    own Layer lists them (Layer::getAllUpdatedBlocks, layer.h:194-203 — the library replays the container), which it
+    clears (updateFromTsdfLayer(true), esdf_integrator.cc:113-121) — bit-exact against the oracle's plain call."""
     from voxblox_amd import capi
     sc = dict(kind="merged", voxel=0.1, n=4, cfg={})
     gm, om = _lockstep(oracle, sc, dict(), list_mode="own")
@@ -252,8 +247,8 @@ def test_reference_order_robot_position_stream_bit_exact(oracle, esdf_kw):
 
 
 def test_reference_order_robot_position_through_the_plain_update(oracle):
-    """vbx_esdf_update composes the list itself: its TSDF blocks in ascending (z,y,x) order, then updated_blocks_ in the
-    IndexSet's iteration order; the oracle gets that list through updateFromTsdfBlocks."""
+    """vbx_esdf_update composes the list itself: its TSDF blocks in the order the reference's Layer lists them, then
+    updated_blocks_ in the IndexSet's iteration order — the oracle's plain updateFromTsdfLayer(true) does the same."""
     from voxblox_amd import capi
     voxel = 0.1
     sph = dict(min_distance_m=2 * voxel, clear_sphere_radius=0.6, occupied_sphere_radius=1.5)
@@ -269,13 +264,7 @@ def test_reference_order_robot_position_through_the_plain_update(oracle):
         gm.integrate(capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
         oe.add_new_robot_position(pose[0])
         gm.esdf_add_new_robot_position(ge, pose[0])
-        lst = _updated_esdf_blocks_in_container_order(om)
-        lst = lst[np.lexsort((lst[:, 0], lst[:, 1], lst[:, 2]))]
-        rb = gm.esdf_robot_updated_blocks(order=1)            # (left in place: the update takes it)
-        oe.update_from_tsdf_blocks(np.concatenate([lst, rb]) if len(rb) else lst, incremental=True)
-        for i in lst:   # updateFromTsdfBlocks clears nothing (:124-302): clear Update::kEsdf by hand
-            d, w, c, bits = om.tsdf_block(i)
-            om.tsdf_block_set(i, d, w, c, bits & ~4)
+        oe.update_from_tsdf_layer(True)
         gm.esdf_update(ge, batch=False, clear_updated_flag=True)
         assert len(gm.esdf_robot_updated_blocks(order=1)) == 0
         _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")

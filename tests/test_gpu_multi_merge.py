@@ -243,7 +243,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert out["config"]["world_size_seen"] == 2 and out["config"]["points_per_step"] == 2 * 307200
     assert out["exchange"]["payload_bytes_per_step"] > 0
     # ... with configs[4] dealt out over the ranks as a secondary leg of the same launch
-    leg = list(out["other_configs"].values())[0]
+    leg = list(out["legs"].values())[0]
     assert "error" not in leg and leg["value"] > 0 and leg["exchange"]["payload_bytes_per_step"] > 0
     # and configs[4] as the workload proper
     r = subprocess.run(cmd + ["--workload", "sensors4"], env=env, cwd=root, capture_output=True, text=True, timeout=900)

@@ -118,6 +118,8 @@ struct DevState {
   int32_t bbox_max[3];
   uint32_t bbox_wide;        // a point whose voxel index is not usable for the box: absolute keys this frame
   uint32_t live_slots;       // k_reclaim: slots that still hold a block of either layer
+  uint32_t newlog_count;     // entries of the new-block log (k_collect_new) the host has not drained yet
+  uint32_t newlog_overflow;  // ... entries that did not fit
   unsigned long long total_keys;
   unsigned long long voxels_touched[64];  // distinct voxels updated, striped by workgroup for the same reason
   unsigned long long rays_cast;
@@ -143,6 +145,7 @@ struct MapDev {  // by-value kernel argument
   uint32_t* rgba;
   int32_t* blk_idx;     // 3 per slot
   uint32_t* blk_flags;  // 1 per slot
+  unsigned long long* blk_first;  // 1 per slot: first-touch rank of a block published by the call in flight, ~0 otherwise
   uint32_t* free_list;
   uint32_t cap_blocks;
   uint32_t nvox;
@@ -258,15 +261,28 @@ __device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* n
 // common case — block already published and flagged this frame — is a plain L2 read: only
 // the first toucher pays for the atomic, so hundreds of thousands of rays crossing ~200
 // blocks do not serialise on ~200 addresses.
-__device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* st) {
+//
+// `rank` (the integrators' emit kernels): position of this touch in the reference's single-threaded order —
+// (ray order << 24) | step along the ray, Merged's clearing pass above bit 62.  The smallest rank a NEW block sees
+// is the moment allocateStorageAndGetVoxelPtr emplaces it in temp_block_map_ (tsdf_integrator.cc:107-121); the
+// sequence of those moments decides the container's iteration order and with it the order in which
+// updateLayerWithStoredBlocks inserts the blocks into the Layer (:137-147).  kFlagNewThisCall is set in the same
+// atomic as kFlagPublished, so a block that shows Published without it was part of the Layer before this call.
+constexpr unsigned long long kNoRank = ~0ull;
+__device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* st, unsigned long long rank = kNoRank) {
   const uint32_t want = kFlagPublished | kFlagUpdMask;
   const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if ((cur & want) == want) return;
-  const uint32_t old = atomicOr(&m.blk_flags[slot], want);
-  if (!(old & kFlagPublished)) {
-    atomicOr(&m.blk_flags[slot], kFlagNewThisCall);
-    atomicAdd(&st->blocks_published, 1u);
+  if ((cur & want) == want && !(cur & kFlagNewThisCall)) return;
+  if (rank == kNoRank || ((cur & kFlagPublished) && !(cur & kFlagNewThisCall))) {
+    const uint32_t old = atomicOr(&m.blk_flags[slot], want);
+    if (!(old & kFlagPublished)) atomicAdd(&st->blocks_published, 1u);
+    return;
   }
+  if ((cur & (want | kFlagNewThisCall)) != (want | kFlagNewThisCall)) {
+    const uint32_t old = atomicOr(&m.blk_flags[slot], want | kFlagNewThisCall);
+    if (!(old & kFlagPublished)) atomicAdd(&st->blocks_published, 1u);
+  }
+  if (__hip_atomic_load(&m.blk_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > rank) atomicMin(&m.blk_first[slot], rank);
 }
 
 __device__ inline void unpack_parent_bits(uint32_t s, int* x, int* y, int* z) {

@@ -36,6 +36,19 @@ struct vbx_ctx {
   uint32_t sync_seq = 0;
   std::string err;
 
+  // The order in which the reference's single-threaded integrators hand new blocks to the Layer (tsdf_integrator.cc:91-147):
+  // first-touch ranks per block on the device (MapDev::blk_first), a device log of the blocks every call published, and
+  // host containers keyed like the reference's that turn the log into iteration orders.
+  DBuf b_blkfirst, b_newlog;
+  unsigned long long call_seq = 1, last_call_seq = 0, last_new_seq = 0;
+  uint32_t newlog_pending = 0;        // log entries not read back yet
+  uint32_t published_since_clear = 0; // blocks the integrate calls published since the map was last cleared (vbx_clear_keep_slots)
+  bool new_flags_live = false;        // kFlagNewThisCall may be set on some block
+  bool layer_order_exact = true;      // every block of the map went through layer_order in the reference's sequence
+  std::unordered_map<HostBlockIdx, int, HostAnyIndexHash> temp_block_map;       // TsdfIntegratorBase::temp_block_map_
+  std::unordered_map<HostBlockIdx, uint32_t, HostAnyIndexHash> layer_order;     // Layer<TsdfVoxel>::block_map_ (keys only)
+  std::vector<HostBlockIdx> last_new;   // the last integrate call's new blocks in Layer::insertBlock sequence
+
   // pool / map storage
   DBuf b_hkeys, b_hvals, b_dist, b_weight, b_rgba, b_blkidx, b_blkflags, b_freelist, b_newlist;
   // per-call scratch

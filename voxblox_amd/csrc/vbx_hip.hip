@@ -148,7 +148,7 @@ vbx_ctx* vbx_create(const vbx_map_cfg* cfg, int device) {
   if (!ok(ctx->b_hkeys.ensure((size_t)hcap * 8)) || !ok(ctx->b_hvals.ensure((size_t)hcap * 4)) ||
       !ok(ctx->b_dist.ensure(nv * 4)) || !ok(ctx->b_weight.ensure(nv * 4)) ||
       !ok(ctx->b_rgba.ensure(nv * 4)) || !ok(ctx->b_blkidx.ensure((size_t)m.cap_blocks * 12)) ||
-      !ok(ctx->b_blkflags.ensure((size_t)m.cap_blocks * 4)) ||
+      !ok(ctx->b_blkflags.ensure((size_t)m.cap_blocks * 4)) || !ok(ctx->b_blkfirst.ensure((size_t)m.cap_blocks * 8)) ||
       !ok(ctx->b_freelist.ensure((size_t)m.cap_blocks * 4)) ||
       !ok(ctx->b_newlist.ensure((size_t)m.cap_blocks * 4)) ||
       !ok(hipMalloc((void**)&ctx->d_state, sizeof(DevState))))
@@ -175,6 +175,7 @@ vbx_ctx* vbx_create(const vbx_map_cfg* cfg, int device) {
   m.rgba = ctx->b_rgba.as<uint32_t>();
   m.blk_idx = ctx->b_blkidx.as<int32_t>();
   m.blk_flags = ctx->b_blkflags.as<uint32_t>();
+  m.blk_first = ctx->b_blkfirst.as<unsigned long long>();
   m.free_list = ctx->b_freelist.as<uint32_t>();
   hipStream_t s = ctx->stream;
   bool good = ok(hipMemsetAsync(m.hkeys, 0xFF, (size_t)hcap * 8, s)) &&
@@ -182,6 +183,7 @@ vbx_ctx* vbx_create(const vbx_map_cfg* cfg, int device) {
               ok(hipMemsetAsync(m.dist, 0, nv * 4, s)) && ok(hipMemsetAsync(m.weight, 0, nv * 4, s)) &&
               ok(hipMemsetAsync(m.rgba, 0, nv * 4, s)) &&
               ok(hipMemsetAsync(m.blk_flags, 0, (size_t)m.cap_blocks * 4, s)) &&
+              ok(hipMemsetAsync(m.blk_first, 0xFF, (size_t)m.cap_blocks * 8, s)) &&
               ok(hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), s));
   for (int i = 0; i < 9 && good; ++i) good = ok(hipEventCreate(&ctx->ev[i]));
   good = good && ok(hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
@@ -195,7 +197,7 @@ void vbx_destroy(vbx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   DBuf* bufs[] = {&ctx->b_hkeys, &ctx->b_hvals, &ctx->b_dist, &ctx->b_weight, &ctx->b_rgba,
-                  &ctx->b_blkidx, &ctx->b_blkflags, &ctx->b_freelist, &ctx->b_newlist, &ctx->b_pts,
+                  &ctx->b_blkidx, &ctx->b_blkflags, &ctx->b_blkfirst, &ctx->b_newlog, &ctx->b_freelist, &ctx->b_newlist, &ctx->b_pts,
                   &ctx->b_cols, &ctx->t_px, &ctx->t_py, &ctx->t_pz, &ctx->t_rgba, &ctx->t_w,
                   &ctx->t_flags, &ctx->t_bkey, &ctx->u_px, &ctx->u_py, &ctx->u_pz, &ctx->u_rgba,
                   &ctx->u_w, &ctx->u_flags, &ctx->u_bkey, &ctx->b_pcx, &ctx->b_pcy, &ctx->b_pcz,
@@ -403,6 +405,31 @@ int vbx_blocks_updated(vbx_ctx* ctx, int layer, int update_mask, int32_t* idx, s
   return emit_list(v, idx, cap, n);
 }
 
+int vbx_blocks_new_ordered(vbx_ctx* ctx, int32_t* idx, size_t cap, size_t* n) {
+  if (!ctx || !n || (cap && !idx)) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = drain_new_blocks(ctx);
+  if (rc) return rc;
+  if (ctx->last_new_seq != ctx->last_call_seq) ctx->last_new.clear();   // the last call published nothing
+  *n = ctx->last_new.size();
+  for (size_t i = 0; i < ctx->last_new.size() && i < cap; ++i) {
+    idx[3 * i] = ctx->last_new[i].x; idx[3 * i + 1] = ctx->last_new[i].y; idx[3 * i + 2] = ctx->last_new[i].z;
+  }
+  return VBX_OK;
+}
+
+int vbx_block_indices_layer_order(vbx_ctx* ctx, int update_mask, int32_t* idx, size_t cap, size_t* n, int* exact) {
+  if (!ctx || !n || (cap && !idx)) return VBX_ERR_INVALID;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  int rc = list_blocks(ctx, VBX_LAYER_TSDF, (uint32_t)update_mask & kFlagUpdMask, &v);
+  if (rc) return rc;
+  bool ex = true;
+  rc = order_like_layer(ctx, &v, &ex);
+  if (rc) return rc;
+  if (exact) *exact = ex ? 1 : 0;
+  return emit_list(v, idx, cap, n);
+}
+
 static int find_slot_host(vbx_ctx* ctx, const int32_t idx[3], uint32_t* slot, uint32_t* hpos) {
   // host-side probe of the device hash map (small D2H reads; not on the hot path)
   const uint64_t key = pack_block_key(idx[0], idx[1], idx[2]);
@@ -606,7 +633,15 @@ int vbx_blocks_upload(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n, con
   }
   rc = sync_state(ctx);  // the caller's host buffers are free again
   if (rc) return rc;
-  return check_state_error(ctx);
+  rc = check_state_error(ctx);
+  if (rc) return rc;
+  if (layer == VBX_LAYER_TSDF) {
+    // Layer::allocateBlockPtrByIndex in the caller's sequence (layer.h:133-160): blocks the Layer did not hold join it in list order
+    rc = drain_new_blocks(ctx);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) ctx->layer_order.emplace(HostBlockIdx{idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]}, 0u);
+  }
+  return VBX_OK;
 }
 
 int vbx_block_upload(vbx_ctx* ctx, int layer, const int32_t idx[3], const void* aos, uint8_t updated_bits,
@@ -656,6 +691,11 @@ int vbx_blocks_remove(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n) {
   if (layer == VBX_LAYER_ESDF && !ctx->esdf_init) return VBX_OK;  // no ESDF block exists
   int rc = upload_idx(ctx, idx, n);
   if (rc) return rc;
+  if (layer == VBX_LAYER_TSDF) {
+    rc = drain_new_blocks(ctx);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) ctx->layer_order.erase(HostBlockIdx{idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]});
+  }
   hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(k_lookup_slots, grid_for(n), dim3(256), 0, s, ctx->map, ctx->b_head.as<int32_t>(), (uint32_t)n, 0,
                      ctx->b_rank.as<uint32_t>());
@@ -679,6 +719,10 @@ int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], do
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = sync_state(ctx);
   if (rc) return rc;
+  if (layer == VBX_LAYER_TSDF) {   // (which blocks go is decided on the device: ordered_block_list drops the stale keys)
+    rc = drain_new_blocks(ctx);
+    if (rc) return rc;
+  }
   const uint32_t used = ctx->h_state.pool_used;
   if (used == 0) return VBX_OK;
   const float block_size = ctx->map.voxel_size * (float)ctx->map.vps;
@@ -686,7 +730,22 @@ int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], do
                      ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,
                      ctx->esdf_init ? ctx->b_estate.as<uint32_t>() : (uint32_t*)nullptr, layer,
                      f3{center[0], center[1], center[2]}, max_distance * max_distance, block_size);
-  return reclaim_slots(ctx);
+  rc = reclaim_slots(ctx);
+  if (rc || layer != VBX_LAYER_TSDF) return rc;
+  // block_map_.erase(it) for every block that went (layer.h:170-182): which ones was decided on the device, so the keys
+  // that are not published any more leave the replayed container (an erased key frees its bucket: it matters for where
+  // later insertions land)
+  std::vector<std::pair<uint64_t, uint32_t>> alive;
+  rc = list_blocks(ctx, VBX_LAYER_TSDF, 0, &alive);
+  if (rc) return rc;
+  std::unordered_set<uint64_t> keys;
+  keys.reserve(alive.size() * 2);
+  for (const auto& kv : alive) keys.insert(kv.first);
+  for (auto it = ctx->layer_order.begin(); it != ctx->layer_order.end();) {
+    if (keys.count(pack_block_key(it->first.x, it->first.y, it->first.z))) ++it;
+    else it = ctx->layer_order.erase(it);
+  }
+  return VBX_OK;
 }
 
 int vbx_clear(vbx_ctx* ctx, int layer) {
@@ -704,6 +763,13 @@ int vbx_clear(vbx_ctx* ctx, int layer) {
     if (rc) return rc;
     const uint32_t used = ctx->h_state.pool_used;
     if (layer == VBX_LAYER_ESDF) ctx->esdf_robot_forget();  // (queue entries name voxels of the layer that goes)
+    if (layer == VBX_LAYER_TSDF) {   // block_map_.clear() (layer.h:168): the keys go, the bucket array stays
+      ctx->published_since_clear = 0;
+      rc = drain_new_blocks(ctx);
+      if (rc) return rc;
+      ctx->layer_order.clear();
+      ctx->last_new.clear();
+    }
     if (used == 0) return VBX_OK;
     hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map,
                        ctx->esdf_init ? ctx->b_edist.as<float>() : (float*)nullptr,
@@ -729,7 +795,14 @@ int vbx_clear_keep_slots(vbx_ctx* ctx) {
   if (used == 0) return VBX_OK;
   // Keeping the slots keeps every block the map ever touched: a delta map that follows a moving sensor would grow towards the
   // whole map (no reclaim runs here).  Once the pool holds far more than the last call published, the blocks go back for real.
-  if (used > 2u * ctx->h_state.blocks_published + 256u) return vbx_clear(ctx, VBX_LAYER_TSDF);
+  // (published_since_clear: every integrate call since the last clear — a step may integrate several clouds into one delta map)
+  const uint32_t published = ctx->published_since_clear;
+  ctx->published_since_clear = 0;
+  if (used > 2u * published + 256u) return vbx_clear(ctx, VBX_LAYER_TSDF);
+  rc = drain_new_blocks(ctx);
+  if (rc) return rc;
+  ctx->layer_order.clear();
+  ctx->last_new.clear();
   hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map, (float*)nullptr, (uint32_t*)nullptr,
                      VBX_LAYER_TSDF, f3{0.f, 0.f, 0.f}, -1.0, 0.0f);  // squared distance > -1: every block
   return VBX_OK;

@@ -121,6 +121,7 @@ int grow_pool(vbx_ctx* ctx) {
               ok(grow_buf(ctx->b_rgba, nv_new * 4, nv_old * 4, 0, s)) &&
               ok(grow_buf(ctx->b_blkidx, (size_t)new_cap * 12, (size_t)used * 12, 0, s)) &&
               ok(grow_buf(ctx->b_blkflags, (size_t)new_cap * 4, (size_t)used * 4, 0, s)) &&
+              ok(grow_buf(ctx->b_blkfirst, (size_t)new_cap * 8, (size_t)used * 8, 0xFF, s)) &&
               ok(grow_buf(ctx->b_freelist, (size_t)new_cap * 4, (size_t)std::min(ctx->h_state.free_count, m.cap_blocks) * 4, 0, s)) &&
               ok(grow_buf(ctx->b_newlist, (size_t)new_cap * 4, 0, 0, s)) &&
               ok(grow_buf(ctx->b_hkeys, (size_t)hcap * 8, 0, 0xFF, s)) && ok(grow_buf(ctx->b_hvals, (size_t)hcap * 4, 0, 0xFF, s));
@@ -149,6 +150,7 @@ int grow_pool(vbx_ctx* ctx) {
   m.rgba = ctx->b_rgba.as<uint32_t>();
   m.blk_idx = ctx->b_blkidx.as<int32_t>();
   m.blk_flags = ctx->b_blkflags.as<uint32_t>();
+  m.blk_first = ctx->b_blkfirst.as<unsigned long long>();
   m.free_list = ctx->b_freelist.as<uint32_t>();
   // pool_used may have been pushed to the old capacity by the failed commit: the blocks that exist are `used`
   HIP_TRY(hipMemcpyAsync(&ctx->d_state->pool_used, &used, 4, hipMemcpyHostToDevice, s));

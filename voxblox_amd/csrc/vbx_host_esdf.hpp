@@ -779,6 +779,10 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
       v.emplace_back(pack_block_key(idx[3 * sl], idx[3 * sl + 1], idx[3 * sl + 2]), sl);
     }
     std::sort(v.begin(), v.end());
+    // the iteration order of the reference's block_map_, as far as the library saw the Layer being built (integrate calls,
+    // uploads); blocks of unknown provenance follow in ascending (z,y,x)
+    rc = order_like_layer(ctx, &v, nullptr);
+    if (rc) return rc;
     h_slots.resize(v.size());
     for (size_t i = 0; i < v.size(); ++i) h_slots[i] = v[i].second;
     if (!robot_blocks.empty()) {

@@ -71,7 +71,7 @@ int sort_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, uint32_t to
 // keys, sort, fold.  `limit` (optional) bounds the number of voxels each ray visits.
 int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_origin,
                    const uint32_t* limit, bool blocks_already_marked, const uint64_t* graze_keys,
-                   uint32_t n_graze) {
+                   uint32_t n_graze, bool two_pass = false) {
   const uint32_t R = tab.R;
   if (R == 0) return VBX_OK;
   MapDev& m = ctx->map;
@@ -117,7 +117,7 @@ int march_and_fold(vbx_ctx* ctx, const RayTab& tab, const CastCfg& c, bool from_
   HIP_TRY(ctx->b_keys0.ensure((size_t)total * 8));
   HIP_TRY(ctx->b_keys1.ensure((size_t)total * 8));
   KLAUNCH(k_ray_emit, grid_for(R), dim3(256), 0, s, tab, c, m, from_origin ? 1 : 0, limit,
-                     ctx->b_off.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), graze_keys, n_graze,
+                     ctx->b_off.as<uint32_t>(), ctx->b_keys0.as<uint64_t>(), graze_keys, n_graze, two_pass ? 1 : 0,
                      ctx->d_state);
   tmark(ctx, 4);
   return sort_and_fold(ctx, tab, c, total);
@@ -396,7 +396,7 @@ int integrate_merged(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const
   // Non-clearing bundles sort before clearing ones (bit 63), so the graze key list is the
   // sorted prefix of non-clearing bundle keys; entries of clearing bundles stay ~0 (sorted last).
   const uint64_t* graze = c.anti_grazing ? ctx->b_graze.as<uint64_t>() : nullptr;
-  return march_and_fold(ctx, bt, c, /*from_origin=*/true, nullptr, false, graze, nb);
+  return march_and_fold(ctx, bt, c, /*from_origin=*/true, nullptr, false, graze, nb, /*two_pass=*/true);
 }
 
 constexpr uint32_t kFastSetSize = (1u << 20) + 10000u;  // ApproxHashSet<20, 10000>
@@ -882,6 +882,105 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
   return sort_and_fold(ctx, kt, c, total, /*giant_runs=*/false);
 }
 
+// ---- the order in which the reference's Layer receives its blocks -------------------------------------------------------
+// k_collect_new appends the blocks a call published to a device log; nothing is read back until somebody needs the order.
+int drain_new_blocks(vbx_ctx* ctx);
+int collect_new_blocks(vbx_ctx* ctx) {
+  hipStream_t s = ctx->stream;
+  const uint32_t used = std::min(ctx->h_state.pool_used, ctx->map.cap_blocks);
+  const size_t cap = (size_t)ctx->map.cap_blocks + 1024;
+  if (ctx->b_newlog.cap < cap * sizeof(NewLogEntry)) {
+    int rc = drain_new_blocks(ctx);   // (the log moves: take what it holds first)
+    if (rc) return rc;
+    HIP_TRY(ctx->b_newlog.ensure(cap * sizeof(NewLogEntry)));
+  }
+  const uint32_t log_cap = (uint32_t)(ctx->b_newlog.cap / sizeof(NewLogEntry));
+  if ((size_t)ctx->newlog_pending + ctx->h_state.blocks_published > log_cap) {
+    int rc = drain_new_blocks(ctx);
+    if (rc) return rc;
+  }
+  if (used) KLAUNCH(k_collect_new, grid_for(used), dim3(256), 0, s, ctx->map, used, ctx->b_newlog.as<NewLogEntry>(), log_cap, ctx->call_seq, ctx->d_state);
+  ctx->newlog_pending += ctx->h_state.blocks_published;
+  ctx->new_flags_live = false;
+  ++ctx->call_seq;
+  return VBX_OK;
+}
+
+// Log -> temp_block_map_ -> Layer: per call (and per pass of the Merged integrator) the new blocks are emplaced in first-touch
+// order into a container keyed like the reference's (same hash, same libstdc++: same iteration order, including the bucket
+// array clear() leaves behind, tsdf_integrator.cc:146), and that container's iteration order is the sequence of
+// Layer::insertBlock calls (:141-144).
+int drain_new_blocks(vbx_ctx* ctx) {
+  if (ctx->newlog_pending == 0) return VBX_OK;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipStreamSynchronize(s));
+  uint32_t cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpy(cnt, &ctx->d_state->newlog_count, 8, hipMemcpyDeviceToHost));
+  const uint32_t log_cap = (uint32_t)(ctx->b_newlog.cap / sizeof(NewLogEntry));
+  const uint32_t n = std::min(cnt[0], log_cap);
+  std::vector<NewLogEntry> log(n);
+  if (n) HIP_TRY(hipMemcpy(log.data(), ctx->b_newlog.p, (size_t)n * sizeof(NewLogEntry), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemsetAsync(&ctx->d_state->newlog_count, 0, 8, s));
+  ctx->newlog_pending = 0;
+  if (cnt[1]) ctx->layer_order_exact = false;   // (entries were dropped: those blocks are listed behind the known ones)
+  std::sort(log.begin(), log.end(), [](const NewLogEntry& a, const NewLogEntry& b) {
+    return a.seq != b.seq ? a.seq < b.seq : a.rank < b.rank;
+  });
+  size_t i = 0;
+  while (i < log.size()) {
+    // one batch = one updateLayerWithStoredBlocks: a call, or one of the Merged integrator's two passes
+    const unsigned long long seq = log[i].seq, pass = log[i].rank >> 62;
+    const bool last_call = seq == ctx->last_call_seq;
+    if (last_call && (i == 0 || log[i - 1].seq != seq)) ctx->last_new.clear();
+    size_t j = i;
+    for (; j < log.size() && log[j].seq == seq && (log[j].rank >> 62) == pass; ++j) {
+      int x, y, z;
+      unpack_block_key(log[j].key, &x, &y, &z);
+      ctx->temp_block_map.emplace(HostBlockIdx{x, y, z}, 0);
+      ctx->layer_order.erase(HostBlockIdx{x, y, z});   // (published anew: whatever the key meant before was removed since)
+    }
+    for (const auto& kv : ctx->temp_block_map) {
+      ctx->layer_order.emplace(kv.first, 0u);
+      if (last_call) ctx->last_new.push_back(kv.first);
+    }
+    ctx->temp_block_map.clear();
+    i = j;
+  }
+  ctx->last_new_seq = ctx->last_call_seq;
+  return VBX_OK;
+}
+
+// A list of (key, slot) pairs of published TSDF blocks -> the sequence in which the reference's Layer would iterate
+// over them (Layer::getAllAllocatedBlocks / getAllUpdatedBlocks walk block_map_, layer.h:184-203).  Blocks whose insertion
+// the library did not see in the reference's sequence (merged in from another map, a log that overflowed) follow in
+// ascending key order and *exact turns false.
+int order_like_layer(vbx_ctx* ctx, std::vector<std::pair<uint64_t, uint32_t>>* v, bool* exact) {
+  int rc = drain_new_blocks(ctx);
+  if (rc) return rc;
+  std::unordered_map<uint64_t, uint32_t> slot_of;
+  slot_of.reserve(v->size() * 2);
+  for (const auto& kv : *v) slot_of.emplace(kv.first, kv.second);
+  std::vector<std::pair<uint64_t, uint32_t>> out;
+  out.reserve(v->size());
+  for (const auto& kv : ctx->layer_order) {
+    const uint64_t key = pack_block_key(kv.first.x, kv.first.y, kv.first.z);
+    const auto it = slot_of.find(key);
+    if (it == slot_of.end()) continue;
+    out.emplace_back(key, it->second);
+    slot_of.erase(it);
+  }
+  bool ex = ctx->layer_order_exact;
+  if (!slot_of.empty()) {
+    ex = false;
+    std::vector<std::pair<uint64_t, uint32_t>> rest(slot_of.begin(), slot_of.end());
+    std::sort(rest.begin(), rest.end());
+    out.insert(out.end(), rest.begin(), rest.end());
+  }
+  v->swap(out);
+  if (exact) *exact = ex;
+  return VBX_OK;
+}
+
 int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const float pos[3],
                      const float quat[4], const float* d_pts, const uint8_t* d_rgba, size_t n,
                      int freespace) {
@@ -930,6 +1029,11 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
     }
   }
   const auto t_call0 = std::chrono::steady_clock::now();
+  if (ctx->new_flags_live) {   // an earlier call failed half way: its new-block marks must not count for this one
+    int rcn = collect_new_blocks(ctx);
+    if (rcn) return rcn;
+  }
+  ctx->new_flags_live = true;
   // per-call device counters
   KLAUNCH(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
   Pose T;
@@ -954,6 +1058,16 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->counters.voxels_touched = 0;
   for (int i = 0; i < 64; ++i) ctx->counters.voxels_touched += ctx->h_state.voxels_touched[i];
   ctx->counters.blocks_allocated = ctx->h_state.blocks_published;
+  // the blocks this call added to the Layer, with their first-touch ranks -> the new-block log (no read-back here)
+  ctx->last_call_seq = ctx->call_seq;
+  ctx->published_since_clear += ctx->h_state.blocks_published;
+  if (ctx->h_state.blocks_published > 0) {
+    rc = collect_new_blocks(ctx);
+    if (rc) return rc;
+  } else {
+    ctx->new_flags_live = false;
+    ++ctx->call_seq;
+  }
   if (has_budget) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
     const double per = us / (double)std::max<uint64_t>(ctx->counters.points_taken, 1);

@@ -659,7 +659,7 @@ __global__ void k_fast_emit(const uint32_t* __restrict__ off_full, const uint32_
   // tsdf_integrator.cc:128: block->updated().set() on every visited voxel's block
   const uint32_t slot = gid / m.nvox;
   const bool first_of_block = (k == 0) || (vox[off_full[r] + k - 1] / m.nvox != slot);
-  if (first_of_block) publish_block(m, slot, st);
+  if (first_of_block) publish_block(m, slot, st, ((unsigned long long)r << 24) | (unsigned long long)(k & 0xFFFFFFu));
 }
 
 

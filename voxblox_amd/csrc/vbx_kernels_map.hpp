@@ -79,7 +79,35 @@ __global__ void k_assign_slots(MapDev m, const uint32_t* new_list, DevState* st)
   m.blk_idx[3 * slot + 1] = y;
   m.blk_idx[3 * slot + 2] = z;
   m.blk_flags[slot] = 0;
+  m.blk_first[slot] = kNoRank;
   __hip_atomic_store(&m.hvals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The blocks the call published (kFlagNewThisCall) -> the new-block log: {first-touch rank, packed BlockIndex, call
+// number}; the flag and the rank go back to their idle values.  The host drains the log when somebody asks for the
+// order (vbx_blocks_new_ordered, a reference-order ESDF update).
+struct NewLogEntry {
+  unsigned long long rank;
+  unsigned long long key;
+  unsigned long long seq;
+};
+__global__ void k_collect_new(MapDev m, uint32_t used, NewLogEntry* log, uint32_t log_cap, unsigned long long seq, DevState* st) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= used) return;
+  const uint32_t f = m.blk_flags[slot];
+  if (!(f & kFlagNewThisCall)) return;
+  m.blk_flags[slot] = f & ~kFlagNewThisCall;
+  const unsigned long long rank = m.blk_first[slot];
+  m.blk_first[slot] = kNoRank;
+  if (f & kFlagFree) return;
+  const uint32_t i = atomicAdd(&st->newlog_count, 1u);
+  if (i >= log_cap) {
+    atomicAdd(&st->newlog_overflow, 1u);
+    return;
+  }
+  log[i].rank = rank;
+  log[i].key = pack_block_key(m.blk_idx[3 * slot], m.blk_idx[3 * slot + 1], m.blk_idx[3 * slot + 2]);
+  log[i].seq = seq;
 }
 
 __global__ void k_commit_alloc(MapDev m, DevState* st) {

@@ -217,7 +217,7 @@ __global__ void k_ray_mark_blocks(RayTab tab, CastCfg c, MapDev m, int from_orig
 __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
                            const uint32_t* __restrict__ limit, const uint32_t* __restrict__ off,
                            uint64_t* keys, const uint64_t* __restrict__ graze_keys,
-                           uint32_t n_graze, DevState* st) {
+                           uint32_t n_graze, int two_pass, DevState* st) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= tab.R) return;
   RayCaster rc;
@@ -225,6 +225,8 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
   if (rc.cur != 0) return;
   const uint32_t n = min(limit ? limit[o] : 0xFFFFFFFFu, rc.steps + 1);
   const bool clearing = (tab.flags[o] & 2) != 0;
+  // Merged runs its clearing bundles as a second pass with its own updateLayerWithStoredBlocks (tsdf_integrator.cc:329-336)
+  const unsigned long long rank_hi = ((unsigned long long)o << 24) | ((two_pass && clearing) ? 1ull << 62 : 0ull);
   BlockWalk bw;
   bw.start(rc, m.vps, m.vps_inv);
   bool need_lookup = false;
@@ -258,7 +260,7 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
         if (slot == kInvalidSlot) {
           atomicOr(&st->error, 2u);
         } else {
-          publish_block(m, slot, st);
+          publish_block(m, slot, st, rank_hi | (unsigned long long)(k & 0xFFFFFFu));
         }
       }
       if (slot != kInvalidSlot) out = ((uint64_t)(slot * m.nvox + bw.lin) << 32) | o;

@@ -16,6 +16,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include <vbx_hip.h>
@@ -40,6 +41,15 @@ struct HostBlockRecord {
 };
 typedef AnyIndexHashMapType<HostBlockRecord>::type HostBlockRecords;  // block_hash.h:33-41
 
+/// Page-locked staging for the device-to-host copies of the mirror (grows, never shrinks; plain memory if pinning fails).
+struct PinnedStaging {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  void* ensure(size_t bytes);
+  ~PinnedStaging();
+};
+
 struct DeviceMirror {
   vbx_ctx* ctx = nullptr;
   const Layer<EsdfVoxel>* esdf_layer = nullptr;  // set by the EsdfIntegrator that shares the map
@@ -50,9 +60,11 @@ struct DeviceMirror {
   uint64_t frames_integrated = 0;                // > 0: the device holds integrator state the host layer does not
                                                  // (FastTsdfIntegrator's approximate sets and frame counter)
   HostBlockRecords tsdf_known, esdf_known;       // the blocks the device holds, as the host last saw them
-  std::vector<TsdfVoxel> tsdf_staging;
+  std::vector<TsdfVoxel> tsdf_staging;           // host -> device (reconcile)
   std::vector<EsdfVoxel> esdf_staging;
+  PinnedStaging down_staging;                    // device -> host (mirror)
   std::vector<int32_t> idx;
+  std::vector<int32_t> new_idx;   // vbx_blocks_new_ordered: the blocks a call added, in the reference's insertion sequence
   std::vector<uint8_t> bits, has_data;
   // reconcile statistics (tests, INTEGRATION.md figures)
   uint64_t uploaded_blocks = 0, removed_blocks = 0;
@@ -104,9 +116,16 @@ void mirrorStats(const Layer<TsdfVoxel>* tsdf_layer, uint64_t* uploaded_blocks, 
 /// fixed point.  Process-wide; also exported from the drop-in as extern "C" vbx_dropin_set_esdf_reference_order(int).
 std::atomic<int>& esdfReferenceOrder();
 
-/// Sampled fingerprint of a block's voxel array: `lines` 64-byte lines spread evenly over the array
-/// (VBX_DROPIN_FINGERPRINT_LINES, default 8; 0 = every line).
+/// Fingerprint of a block's voxel array.  Default: EVERY 64-byte line (a single-voxel poke anywhere in the block moves it:
+/// each line is folded with odd multipliers — a change of one word changes the line's value — and passed through a
+/// bijective finaliser before the lines are summed, so lines can be hashed independently and in any order).
+/// VBX_DROPIN_FINGERPRINT_LINES = n > 0 samples n evenly spread lines instead (cheaper, blind between the samples).
 uint64_t voxelFingerprint(const void* voxels, size_t bytes);
+
+/// f(0) .. f(n-1) on the calling thread plus a few persistent helpers (VBX_DROPIN_THREADS, default min(8, hardware));
+/// returns when all are done.  The per-call passes over whole blocks (fingerprints, voxel copies) are memory-bound.
+void parallelFor(size_t n, const std::function<void(size_t)>& f);
+
 
 }  // namespace hip
 }  // namespace voxblox

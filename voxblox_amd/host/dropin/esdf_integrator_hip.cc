@@ -11,6 +11,7 @@
 #include "voxblox/integrator/esdf_integrator.h"
 
 #include <cstdlib>
+#include <cstring>
 
 #include <atomic>
 
@@ -30,23 +31,28 @@ void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
   CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_ESDF, VBX_UPDATE_DIRTY, dev.idx.data(), n, &n), VBX_OK)
       << vbx_last_error(dev.ctx);
   const size_t nv = layer->voxels_per_side() * layer->voxels_per_side() * layer->voxels_per_side();
-  dev.esdf_staging.resize(n * nv);
+  EsdfVoxel* staging = static_cast<EsdfVoxel*>(dev.down_staging.ensure(n * nv * sizeof(EsdfVoxel)));   // page-locked
   dev.bits.resize(n);
   dev.has_data.resize(n);
-  CHECK_EQ(vbx_blocks_download(dev.ctx, VBX_LAYER_ESDF, dev.idx.data(), n, dev.esdf_staging.data(), dev.bits.data(),
-                               dev.has_data.data()),
-           VBX_OK)
+  CHECK_EQ(vbx_blocks_download(dev.ctx, VBX_LAYER_ESDF, dev.idx.data(), n, staging, dev.bits.data(), dev.has_data.data()), VBX_OK)
       << vbx_last_error(dev.ctx);
+  std::vector<Block<EsdfVoxel>::Ptr> blocks(n);
+  std::vector<uint64_t> fps(n);
+  for (size_t i = 0; i < n; ++i)
+    blocks[i] = layer->allocateBlockPtrByIndex(BlockIndex(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]));
+  parallelFor(n, [&](size_t i) {
+    const EsdfVoxel* src = staging + i * nv;
+    std::memcpy(static_cast<void*>(&blocks[i]->getVoxelByLinearIndex(0)), src, nv * sizeof(EsdfVoxel));
+    fps[i] = voxelFingerprint(src, nv * sizeof(EsdfVoxel));
+  });
   for (size_t i = 0; i < n; ++i) {
     const BlockIndex bi(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]);
-    Block<EsdfVoxel>::Ptr block = layer->allocateBlockPtrByIndex(bi);
-    const EsdfVoxel* src = dev.esdf_staging.data() + i * nv;
-    for (size_t v = 0; v < nv; ++v) block->getVoxelByLinearIndex(v) = src[v];
+    Block<EsdfVoxel>::Ptr& block = blocks[i];
     block->updated() |= std::bitset<Update::kCount>(dev.bits[i]);  // set_updated(true): kMap only (:147)
     HostBlockRecord& rec = dev.esdf_known[bi];
     rec.block = block.get();
     rec.bits = static_cast<uint8_t>(block->updated().to_ulong());
-    rec.fingerprint = voxelFingerprint(&block->getVoxelByLinearIndex(0), nv * sizeof(EsdfVoxel));
+    rec.fingerprint = fps[i];
   }
   // the device's copy of the block's Update bits is only a carrier towards the host (nothing on the device reads an
   // ESDF block's bits): clear it with the dirty mark, so that a block the wavefront touches later does not bring a

@@ -10,11 +10,14 @@
 // (abort), the reference's own error convention.
 #include "voxblox/integrator/tsdf_integrator.h"
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "device_mirror.h"
 #include "voxblox/utils/timing.h"
@@ -42,16 +45,106 @@ void destroyMirror(DeviceMirror* m) {
 int fingerprintLines() {
   static const int lines = [] {
     const char* e = getenv("VBX_DROPIN_FINGERPRINT_LINES");
-    return e ? atoi(e) : 8;
+    return e ? atoi(e) : 0;   // 0 = every line (round 5; rounds 3-4 sampled 8 of a block's 768 lines by default)
   }();
   return lines;
 }
+
+// ---- a handful of persistent helper threads for the per-call passes over whole blocks ---------------------------------
+class Helpers {
+ public:
+  static Helpers& get() {
+    static Helpers* h = new Helpers;   // (never destroyed: joining threads from a static destructor is asking for trouble)
+    return *h;
+  }
+  void run(size_t n, const std::function<void(size_t)>& f) {
+    if (n == 0) return;
+    if (threads_.empty() || n < 4) {
+      for (size_t i = 0; i < n; ++i) f(i);
+      return;
+    }
+    std::unique_lock<std::mutex> call_lock(call_mu_);   // one parallelFor at a time
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      fn_ = &f;
+      n_ = n;
+      next_.store(0, std::memory_order_relaxed);
+      busy_ = threads_.size();
+      ++generation_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lock(mu_);
+    done_cv_.wait(lock, [this] { return busy_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  Helpers() {
+    const char* e = getenv("VBX_DROPIN_THREADS");
+    const unsigned hw = std::thread::hardware_concurrency();
+    int want = e ? atoi(e) : static_cast<int>(std::min(8u, hw ? hw : 1u));
+    for (int i = 1; i < want; ++i) threads_.emplace_back([this] { loop(); });
+    for (std::thread& t : threads_) t.detach();
+  }
+  void work() {
+    for (;;) {
+      const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n_) break;
+      (*fn_)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        --busy_;
+      }
+      done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(size_t)>* fn_ = nullptr;
+  size_t n_ = 0, busy_ = 0;
+  std::atomic<size_t> next_{0};
+  uint64_t generation_ = 0;
+};
 }  // namespace
 
+void parallelFor(size_t n, const std::function<void(size_t)>& f) { Helpers::get().run(n, f); }
+
+void* PinnedStaging::ensure(size_t bytes) {
+  if (bytes <= cap) return p;
+  if (p) {
+    if (pinned) vbx_host_free(p); else free(p);
+  }
+  cap = bytes + bytes / 4;
+  p = vbx_host_alloc(cap);
+  pinned = p != nullptr;
+  if (!p) p = malloc(cap);
+  CHECK(p != nullptr) << "out of host memory for the mirror's staging buffer";
+  return p;
+}
+PinnedStaging::~PinnedStaging() {
+  if (!p) return;
+  if (pinned) vbx_host_free(p); else free(p);
+}
+
 uint64_t voxelFingerprint(const void* voxels, size_t bytes) {
-  // 64-byte lines at evenly spread positions, eight 8-byte words each, folded with a multiply-xorshift.  A
-  // whole-block overwrite (deserializeFromIntegers, mergeBlock) moves it with near certainty; a single-voxel
-  // poke between two sampled lines does not — VBX_DROPIN_FINGERPRINT_LINES=0 reads every line.
+  // Per 64-byte line: the eight 8-byte words folded with odd multipliers (a change of any one word changes the sum), the
+  // line number mixed in, a bijective finaliser (murmur3's fmix64) on top; the block's fingerprint is the SUM of its lines'
+  // values — independent per line, so the pass is eight multiply chains wide and memory-bound.
+  static const uint64_t K[8] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0xD6E8FEB86659FD93ull,
+                                0xFF51AFD7ED558CCDull, 0xC4CEB9FE1A85EC53ull, 0x2545F4914F6CDD1Dull, 0x9FB21C651E98DF25ull};
   const size_t n_lines = bytes / 64;
   const int want = fingerprintLines();
   const size_t lines = (want <= 0 || (size_t)want > n_lines) ? n_lines : (size_t)want;
@@ -61,12 +154,16 @@ uint64_t voxelFingerprint(const void* voxels, size_t bytes) {
     const size_t line = (lines == n_lines) ? k : (k * n_lines) / lines + (n_lines / lines) / 2;
     uint64_t w[8];
     std::memcpy(w, base + line * 64, 64);
-    for (int j = 0; j < 8; ++j) {
-      h ^= w[j] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-      h *= 0xFF51AFD7ED558CCDull;
-      h ^= h >> 29;
-    }
+    uint64_t v = line * 0xD1B54A32D192ED03ull;
+    for (int j = 0; j < 8; ++j) v += (w[j] + j + 1) * K[j];
+    v ^= v >> 33;
+    v *= 0xFF51AFD7ED558CCDull;
+    v ^= v >> 33;
+    v *= 0xC4CEB9FE1A85EC53ull;
+    v ^= v >> 33;
+    h += v;
   }
+  // (the tail beyond the last whole line: 12 B and 20 B voxels times 4096 are multiples of 64)
   return h;
 }
 
@@ -169,16 +266,24 @@ void reconcileFromHost(DeviceMirror& dev, Layer<VoxelType>* layer, int vbx_layer
       dev.removed_blocks += gone.size() / 3;
     }
   }
-  // 2. blocks the host created, replaced or wrote to
+  // 2. blocks the host created, replaced or wrote to: every block's voxel array is fingerprinted in full (helper threads)
   dev.idx.clear();
   dev.bits.clear();
   dev.has_data.clear();
+  std::vector<typename Block<VoxelType>::Ptr> all(host_blocks.size());
+  std::vector<uint64_t> all_fp(host_blocks.size());
+  {
+    size_t k = 0;
+    for (const BlockIndex& bi : host_blocks) all[k++] = layer->getBlockPtrByIndex(bi);
+  }
+  parallelFor(all.size(), [&](size_t i) { all_fp[i] = voxelFingerprint(&all[i]->getVoxelByLinearIndex(0), nv * sizeof(VoxelType)); });
   std::vector<typename Block<VoxelType>::Ptr> up;
   std::vector<uint64_t> up_fp;
+  size_t k_block = 0;
   for (const BlockIndex& bi : host_blocks) {
-    typename Block<VoxelType>::Ptr block = layer->getBlockPtrByIndex(bi);
+    typename Block<VoxelType>::Ptr& block = all[k_block];
+    const uint64_t fp = all_fp[k_block++];
     const uint8_t bits = static_cast<uint8_t>(block->updated().to_ulong());
-    const uint64_t fp = voxelFingerprint(&block->getVoxelByLinearIndex(0), nv * sizeof(VoxelType));
     auto it = known->find(bi);
     if (it != known->end() && it->second.block == block.get() && (bits & ~it->second.bits) == 0 &&
         it->second.fingerprint == fp) {
@@ -231,18 +336,37 @@ void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
   CHECK_EQ(vbx_blocks_updated(dev.ctx, VBX_LAYER_TSDF, VBX_UPDATE_MAP, dev.idx.data(), n, &n), VBX_OK)
       << vbx_last_error(dev.ctx);
   const size_t nv = layer->voxels_per_side() * layer->voxels_per_side() * layer->voxels_per_side();
-  dev.tsdf_staging.resize(n * nv);
+  {
+    // updateLayerWithStoredBlocks (tsdf_integrator.cc:137-147): the blocks the call added join the host Layer in the
+    // sequence the reference's single-threaded integrator inserts them — temp_block_map_'s iteration order, replayed by
+    // the library from the first touch of every new block — so that the Layer's own unordered_map, and with it
+    // getAllUpdatedBlocks and the ESDF's walk (layer.h:194-203, esdf_integrator.cc:104-143), iterate like in a CPU run
+    size_t n_new = 0;
+    CHECK_EQ(vbx_blocks_new_ordered(dev.ctx, nullptr, 0, &n_new), VBX_OK) << vbx_last_error(dev.ctx);
+    if (n_new) {
+      dev.new_idx.resize(3 * n_new);
+      CHECK_EQ(vbx_blocks_new_ordered(dev.ctx, dev.new_idx.data(), n_new, &n_new), VBX_OK) << vbx_last_error(dev.ctx);
+      for (size_t i = 0; i < n_new; ++i)
+        layer->allocateBlockPtrByIndex(BlockIndex(dev.new_idx[3 * i], dev.new_idx[3 * i + 1], dev.new_idx[3 * i + 2]));
+    }
+  }
+  TsdfVoxel* staging = static_cast<TsdfVoxel*>(dev.down_staging.ensure(n * nv * sizeof(TsdfVoxel)));   // page-locked
   dev.bits.resize(n);
   dev.has_data.resize(n);
-  CHECK_EQ(vbx_blocks_download(dev.ctx, VBX_LAYER_TSDF, dev.idx.data(), n, dev.tsdf_staging.data(), dev.bits.data(),
-                               dev.has_data.data()),
-           VBX_OK)
+  CHECK_EQ(vbx_blocks_download(dev.ctx, VBX_LAYER_TSDF, dev.idx.data(), n, staging, dev.bits.data(), dev.has_data.data()), VBX_OK)
       << vbx_last_error(dev.ctx);
+  std::vector<Block<TsdfVoxel>::Ptr> blocks(n);
+  std::vector<uint64_t> fps(n);
+  for (size_t i = 0; i < n; ++i)   // (the Layer's container is not thread-safe: allocation stays on this thread)
+    blocks[i] = layer->allocateBlockPtrByIndex(BlockIndex(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]));
+  parallelFor(n, [&](size_t i) {
+    const TsdfVoxel* src = staging + i * nv;
+    std::memcpy(static_cast<void*>(&blocks[i]->getVoxelByLinearIndex(0)), src, nv * sizeof(TsdfVoxel));
+    fps[i] = voxelFingerprint(src, nv * sizeof(TsdfVoxel));
+  });
   for (size_t i = 0; i < n; ++i) {
     const BlockIndex bi(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]);
-    Block<TsdfVoxel>::Ptr block = layer->allocateBlockPtrByIndex(bi);
-    const TsdfVoxel* src = dev.tsdf_staging.data() + i * nv;
-    for (size_t v = 0; v < nv; ++v) block->getVoxelByLinearIndex(v) = src[v];
+    Block<TsdfVoxel>::Ptr& block = blocks[i];
     // block->updated().set() on every touched block (tsdf_integrator.cc:128); bits a host consumer has
     // cleared since (mesher: kMesh, ESDF: kEsdf) come back only if the device set them again
     block->updated() |= std::bitset<Update::kCount>(dev.bits[i]);
@@ -250,7 +374,7 @@ void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
     HostBlockRecord& rec = dev.tsdf_known[bi];
     rec.block = block.get();
     rec.bits = static_cast<uint8_t>(block->updated().to_ulong());
-    rec.fingerprint = voxelFingerprint(&block->getVoxelByLinearIndex(0), nv * sizeof(TsdfVoxel));
+    rec.fingerprint = fps[i];
   }
   // kMap doubles as the mirror's dirty bit on the device; kMesh / kEsdf stay for the device-side
   // mesher / ESDF
