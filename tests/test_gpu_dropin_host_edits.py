@@ -9,7 +9,7 @@ doing the same edits:
     further integration                                      (io::LoadBlocksFromFile, tsdf_server.cc:566-578;
                                                               esdf_server / tsdf_to_esdf)
   * an in-place overwrite of an existing block without any marker (deserializeMsgToLayer kUpdate,
-    conversions_inl.h:80-88): caught by the sampled voxel fingerprint
+    conversions_inl.h:80-88), down to a single voxel: caught by the full fingerprint of the voxel array
   * Update bits set by the host on an existing block (Block::mergeBlock, block_inl.h:120)
 """
 import ctypes as C
@@ -194,6 +194,36 @@ def test_in_place_overwrite_of_an_existing_block_is_seen(oracle):
     assert _same_tsdf(maps[0], maps[1]) > 10
     st = maps[0].dropin_stats()
     assert st["uploaded_blocks"] == 3, st
+
+
+def test_a_single_voxel_poke_without_any_marker_is_seen(oracle):
+    """The round-3/4 hole: the fingerprint sampled 8 of a block's 768 lines, so a write into ONE voxel between two sampled
+    lines, with no Update bit, was overwritten by the next mirror.  The default fingerprint now covers every line: a poke
+    into a single voxel (here: one whose 12 bytes lie in a line the old sampling never read) is uploaded before the next
+    frame integrates, and both sides fold the next frames into the poked value."""
+    H, R = oracle.ref_hip_lib(), _cpu_lib(oracle)
+    frames = S.frames(4)
+    maps = []
+    for L in (H, R):
+        L.orc_fast_reset_counter_set(0)
+        m = oracle.OracleMap(VOXEL, 16, L=L)
+        it = m.tsdf_integrator("merged", _cfg(oracle, L))
+        for pose, pts, col in frames[:2]:
+            it.integrate(pose[0], pose[1], pts, col)
+        d = m.tsdf_dict()
+        victim = sorted(k for k in d if (d[k][1] > 0).sum() > 3000)[0]
+        dist, w, c, bits = d[victim]
+        sampled = {(k * 768) // 8 + 48 for k in range(8)}                      # the lines rounds 3-4 looked at
+        v = next(i for i in range(100, 4096) if w[i] > 0 and (12 * i) // 64 not in sampled and (12 * i + 11) // 64 not in sampled)
+        dist = dist.copy(); w = w.copy()
+        dist[v] = np.float32(-0.123); w[v] = np.float32(7.5)
+        m.tsdf_block_set(victim, dist, w, c, bits)                              # bits untouched
+        for pose, pts, col in frames[2:]:
+            it.integrate(pose[0], pose[1], pts, col)
+        maps.append(m)
+    assert _same_tsdf(maps[0], maps[1]) > 10
+    st = maps[0].dropin_stats()
+    assert st["uploaded_blocks"] == 1, st
 
 
 def test_update_bits_set_by_the_host_trigger_an_upload(oracle):

@@ -94,6 +94,13 @@ vbx_esdf_cfg toC(const EsdfIntegrator::Config& c) {
 // The reference visits the blocks in the iteration order of the CALLER'S containers (Layer::getAllUpdatedBlocks /
 // getAllAllocatedBlocks over std::unordered_map, then updated_blocks_; esdf_integrator.cc:96-101, :105-109): in
 // reference-order mode that order is taken from the host layer and handed down with the call.
+// esdf_integrator.cc:139-145: the walk allocates the ESDF block of every listed TSDF block the layer holds, in list order —
+// the host ESDF Layer receives its new blocks in that sequence (its container then iterates like a CPU run's)
+void allocateEsdfBlocksInWalkOrder(const BlockIndexList& tsdf_blocks, const Layer<TsdfVoxel>& tsdf_layer, Layer<EsdfVoxel>* esdf_layer) {
+  for (const BlockIndex& block_index : tsdf_blocks)
+    if (tsdf_layer.hasBlock(block_index)) esdf_layer->allocateBlockPtrByIndex(block_index);
+}
+
 std::vector<int32_t> flatten(const BlockIndexList& l) {
   std::vector<int32_t> idx;
   idx.reserve(3 * l.size());
@@ -167,6 +174,7 @@ void EsdfIntegrator::updateFromTsdfLayerBatch() {
     tsdf_layer_->getAllAllocatedBlocks(&tsdf_blocks);  // :96-97, in the host container's order
     tsdf_blocks.insert(tsdf_blocks.end(), updated_blocks_.begin(), updated_blocks_.end());  // :98-99
     const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
+    hip::allocateEsdfBlocksInWalkOrder(tsdf_blocks, *tsdf_layer_, esdf_layer_);
     CHECK_EQ(vbx_clear(dev.ctx, VBX_LAYER_ESDF), VBX_OK) << vbx_last_error(dev.ctx);  // (forgets queued sphere entries too)
     CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), /*incremental=*/0),
              VBX_OK)
@@ -202,6 +210,7 @@ void EsdfIntegrator::updateFromTsdfLayer(bool clear_updated_flag) {
     tsdf_layer_->getAllUpdatedBlocks(Update::kEsdf, &tsdf_blocks);  // :105-106, in the host container's order
     tsdf_blocks.insert(tsdf_blocks.end(), updated_blocks_.begin(), updated_blocks_.end());  // :107-108
     const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
+    hip::allocateEsdfBlocksInWalkOrder(tsdf_blocks, *tsdf_layer_, esdf_layer_);
     CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), /*incremental=*/1),
              VBX_OK)
         << vbx_last_error(dev.ctx);
@@ -230,17 +239,23 @@ void EsdfIntegrator::updateFromTsdfBlocks(const BlockIndexList& tsdf_blocks, boo
   hip::DeviceMirror& dev = *pinned;
   hip::reconcileTsdfFromHost(dev, tsdf_layer_);
   hip::reconcileEsdfFromHost(dev, esdf_layer_);
-  const vbx_esdf_cfg cfg = hip::toC(config_);
-  std::vector<int32_t> idx;
-  idx.reserve(3 * tsdf_blocks.size());
-  for (const BlockIndex& b : tsdf_blocks) {
-    idx.push_back(b.x());
-    idx.push_back(b.y());
-    idx.push_back(b.z());
+  vbx_esdf_cfg cfg = hip::toC(config_);
+  // the same bookkeeping as updateFromTsdfLayer: clear() since addNewRobotPosition (placeholder in raise_ gone), sphere work
+  // queued in the other form than the process-wide switch says now
+  if (dev.esdf_pending && raise_.empty()) {
+    CHECK_EQ(vbx_esdf_integrator_clear(dev.ctx), VBX_OK) << vbx_last_error(dev.ctx);
+    dev.esdf_pending = false;
   }
+  if (dev.esdf_pending) cfg.reference_order = dev.esdf_pending_ordered ? 1 : 0;
+  const std::vector<int32_t> idx = hip::flatten(tsdf_blocks);
+  if (cfg.reference_order) hip::allocateEsdfBlocksInWalkOrder(tsdf_blocks, *tsdf_layer_, esdf_layer_);
   CHECK_EQ(vbx_esdf_update_blocks(dev.ctx, &cfg, idx.empty() ? nullptr : idx.data(), tsdf_blocks.size(), incremental ? 1 : 0),
            VBX_OK)
       << vbx_last_error(dev.ctx);
+  // the queues drained (esdf_integrator.cc:296-301); updated_blocks_ is the caller's to compose into the list and is left
+  // alone, like in the reference
+  dev.esdf_pending = false;
+  dropPlaceholder(&raise_);
   hip::mirrorEsdfToHost(dev, esdf_layer_);
 }
 
