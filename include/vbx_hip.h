@@ -308,12 +308,15 @@ int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx_xyz, size
  * the rank that owns the block (a sparse RCCL all-to-all-v of the touched blocks only, grouped by owner; a
  * reduce-scatter over the union of touched blocks would move the same sums N times), and the owner adds
  * the senders' rows up and folds them into its shard of the persistent map. */
-/* For each listed block writes six float planes of nvox = vps^3 values each,
- *   [w*d, w, w*r, w*g, w*b, w*a],  layout d_out[(i*6 + plane)*nvox + linear_index],
- * zeros for blocks this map does not hold.  idx_xyz is a host array, d_out a device pointer. */
+/* For each listed block writes one ROW of three planes of nvox = vps^3 32-bit words each — distance (float), weight
+ * (float), colour (the four bytes r,g,b,a as one word) — layout d_out[(i*3 + plane)*nvox + linear_index], zeros for
+ * blocks this map does not hold: the delta voxels themselves, 48 KiB per block at vps 16, what mergeVoxelAIntoVoxelB reads of
+ * voxel A (voxel_utils.cc:10-22).  (Rounds 1-4 exported the six products [w*d, w, w*r, w*g, w*b, w*a], 96 KiB; the
+ * products are now formed by vbx_blocks_merge_sums with the same float operations — the merged map is bit for bit the
+ * same.)  idx_xyz is a host array, d_out a device pointer. */
 int vbx_blocks_export_sums(vbx_ctx* ctx, const int32_t* idx_xyz, size_t n, float* d_out);
-/* Folds sums (same layout, device pointer) into this map.  A BlockIndex may be listed more than once (several
- * senders touched the block): its rows are added up first, in row order.  Then A = {d = Swd/Sw, w = Sw,
+/* Folds rows (same layout, device pointer) into this map.  A BlockIndex may be listed more than once (several
+ * senders touched the block): the weighted sums of its rows are added up first, in row order.  Then A = {d = Swd/Sw, w = Sw,
  * colour = round(Swc/Sw)} merged into the stored voxel B exactly as mergeVoxelAIntoVoxelB does
  * (d = (dA*wA + dB*wB)/(wA+wB), colour = blendTwoColors(A,wA,B,wB), w = wA+wB; nothing when
  * wA+wB <= 0).  Blocks are allocated as needed and get all Update bits.  If apply_caps != 0

@@ -4,10 +4,10 @@
  * updates are combined over RCCL with the reference's own merge semantics — Block::mergeBlock /
  * mergeVoxelAIntoVoxelB (core/block_inl.h:112-129, src/utils/voxel_utils.cc:10-22) is a weighted sum.
  * One process per GPU.  Per time step every rank integrates ITS ray shards (whole sensors, or contiguous
- * bands of a cloud) into a zeroed per-step delta map; vbx_shard_end_step then sends the partial sums
- * (w*d, w, w*r, w*g, w*b, w*a) of every touched block to the block's owner rank
- * (owner = hash(BlockIndex) mod world) with ONE sparse all-to-all-v — only touched blocks travel, 96 KiB each
- * at vps 16 — and the owner adds the rows of equal BlockIndex in (sender rank, key) order and folds the
+ * bands of a cloud) into a zeroed per-step delta map; vbx_shard_end_step then sends every touched block of the
+ * delta (distance, weight, colour: 48 KiB at vps 16) to the block's owner rank
+ * (owner = hash(BlockIndex) mod world) with ONE sparse all-to-all-v — only touched blocks travel — and the owner
+ * forms the partial sums (w*d, w, w*r, w*g, w*b, w*a), adds the rows of equal BlockIndex in (sender rank, key) order and folds the
  * result into its shard of the persistent map (vbx_blocks_merge_sums).  The persistent map is distributed
  * by block ownership; no rank holds all of it.
  *
@@ -74,7 +74,7 @@ typedef struct vbx_shard_stats {
   uint64_t steps;
   uint64_t sent_blocks;      /* blocks this rank's deltas touched (= rows sent, own ones included) */
   uint64_t received_blocks;  /* rows this rank received as owner */
-  uint64_t payload_bytes;    /* bytes of sums sent */
+  uint64_t payload_bytes;    /* bytes of block rows sent */
 } vbx_shard_stats;
 int vbx_shard_get_stats(vbx_shard* s, vbx_shard_stats* out);
 

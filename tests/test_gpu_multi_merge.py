@@ -47,7 +47,7 @@ def test_export_merge_matches_reference_merge(oracle):
         assert np.allclose(gw, rw, rtol=1e-6, atol=1e-7)
         assert np.abs(gd - rd).max() <= 1e-6
         assert np.abs(gc.astype(np.int32) - rc.astype(np.int32)).max() <= 1
-    assert sm.last["sent_blocks"] > 0 and sm.last["payload_bytes"] == sm.last["sent_blocks"] * 6 * 4096 * 4
+    assert sm.last["sent_blocks"] > 0 and sm.last["payload_bytes"] == sm.last["sent_blocks"] * 3 * 4096 * 4
 
 
 def test_clear_is_complete():

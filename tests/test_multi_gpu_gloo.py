@@ -49,20 +49,28 @@ class OracleBackend:
         return self._torch.zeros(shape, dtype=self._torch.float32)
 
     def export_sums(self, keys, out_view):
+        # a row = the delta block itself: distance, weight, colour bytes (vbx_blocks_export_sums, 3 planes)
         o = out_view.numpy()
         for i, k in enumerate(keys):
             blk = self.m.tsdf_block(k)
             if blk is None:
                 continue
             d, w, c, _ = blk
-            o[i, 0] = w * d
+            o[i, 0] = d
             o[i, 1] = w
-            for ch in range(4):
-                o[i, 2 + ch] = w * c[:, ch].astype(np.float32)
+            o[i, 2] = np.ascontiguousarray(c, np.uint8).view(np.uint32).reshape(-1).view(np.float32)
 
     def merge_sums(self, keys, sums, apply_caps, trunc, max_weight):
-        # rows of one block are added in row order first (vbx_blocks_merge_sums)
-        rows = sums.numpy()
+        # the owner forms the six weighted sums per row and adds the rows of one block in row order (vbx_blocks_merge_sums)
+        raw = sums.numpy()
+        rows = np.zeros((raw.shape[0], 6, raw.shape[2]), np.float32)
+        for i in range(raw.shape[0]):
+            w = raw[i, 1]
+            c = np.ascontiguousarray(raw[i, 2]).view(np.uint32).view(np.uint8).reshape(-1, 4)
+            rows[i, 0] = w * raw[i, 0]
+            rows[i, 1] = w
+            for ch in range(4):
+                rows[i, 2 + ch] = w * c[:, ch].astype(np.float32)
         first = {}
         acc = []
         for i, k in enumerate(keys):
@@ -170,7 +178,7 @@ def test_two_rank_shard_and_merge_matches_serial_reference_merge(oracle, pipelin
         assert not (set(owned) & set(merged)), "a block is owned by two ranks"
         merged.update(owned)
         # sparse exchange: a rank sends exactly the blocks its delta touched, 96 KiB of sums each
-        assert last["sent_blocks"] > 0 and last["payload_bytes"] == last["sent_blocks"] * 6 * 4096 * 4
+        assert last["sent_blocks"] > 0 and last["payload_bytes"] == last["sent_blocks"] * 3 * 4096 * 4
         assert last["received_blocks"] >= last["owned_blocks"] > 0
 
     # serial restatement: per frame, per rank delta (fresh map), merged in rank order with the

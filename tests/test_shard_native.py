@@ -63,5 +63,5 @@ def test_native_shard_equals_python_shard(with_rccl):
         assert np.array_equal(a[k][2], b[k][2]) and a[k][3] == b[k][3]
     st = ns.stats()
     assert st["steps"] == len(frames) and st["sent_blocks"] == st["received_blocks"] > 0
-    assert st["payload_bytes"] == st["sent_blocks"] * 6 * 4096 * 4
+    assert st["payload_bytes"] == st["sent_blocks"] * 3 * 4096 * 4
     ns.close()

@@ -461,7 +461,7 @@ class Map:
                                                 None if hd is None else hd.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     def export_sums(self, idx_xyz, d_out_ptr):
-        """vbx_blocks_export_sums: six float planes [w*d, w, w*r, w*g, w*b, w*a] per listed block."""
+        """vbx_blocks_export_sums: three planes (distance, weight, colour word) per listed block."""
         idx = np.ascontiguousarray(idx_xyz, np.int32).reshape(-1, 3)
         self._chk(self.L.vbx_blocks_export_sums(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.shape[0],
                                                 C.c_void_p(d_out_ptr)))

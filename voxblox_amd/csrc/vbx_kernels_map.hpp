@@ -244,22 +244,25 @@ __global__ void k_set_block_flags(MapDev m, const uint32_t* __restrict__ slots, 
 // ---------------------------------------------------------------------------
 // kernels: multi-GPU block merge (mergeVoxelAIntoVoxelB as weighted sums)
 // ---------------------------------------------------------------------------
+// One row per listed block: three planes of nvox 32-bit words — distance, weight, the colour's four bytes — i.e. the
+// delta voxel itself (12 B, what mergeVoxelAIntoVoxelB reads of voxel A, voxel_utils.cc:10-22).  The weighted sums
+// w*d and w*channel are formed by the OWNER (k_merge_sums) with the same float operations the sender used to run, so
+// the merged map is bit for bit what the six-plane rows of rounds 1-4 gave at half the bytes.
+constexpr uint32_t kRowPlanes = 3;
 __global__ void k_export_sums(MapDev m, const uint32_t* __restrict__ slots, float* out) {
   const uint32_t b = blockIdx.x;
   const uint32_t slot = slots[b];
-  float* o = out + (size_t)b * 6 * m.nvox;
+  float* o = out + (size_t)b * kRowPlanes * m.nvox;
   for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
-    float wd = 0.f, w = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f;
+    float d = 0.f, w = 0.f;
+    uint32_t c = 0u;
     if (slot != kInvalidSlot) {
       const uint32_t gid = slot * m.nvox + v;
       w = m.weight[gid];
-      wd = w * m.dist[gid];
-      const uint32_t c = m.rgba[gid];
-      cr = w * (float)(c & 0xFF); cg = w * (float)((c >> 8) & 0xFF);
-      cb = w * (float)((c >> 16) & 0xFF); ca = w * (float)((c >> 24) & 0xFF);
+      d = m.dist[gid];
+      c = m.rgba[gid];
     }
-    o[v] = wd; o[m.nvox + v] = w; o[2 * m.nvox + v] = cr; o[3 * m.nvox + v] = cg;
-    o[4 * m.nvox + v] = cb; o[5 * m.nvox + v] = ca;
+    o[v] = d; o[m.nvox + v] = w; o[2 * m.nvox + v] = __uint_as_float(c);
   }
 }
 
@@ -347,9 +350,15 @@ __global__ void k_merge_sums(MapDev m, const uint32_t* __restrict__ slots, const
   for (uint32_t v = threadIdx.x; v < m.nvox; v += blockDim.x) {
     float acc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (uint32_t q = r0; q < r1; ++q) {
-      const float* a = in + (size_t)rows[q] * 6 * m.nvox;
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) acc[pl] += a[pl * m.nvox + v];
+      const float* a = in + (size_t)rows[q] * kRowPlanes * m.nvox;
+      const float w = a[m.nvox + v];
+      const uint32_t c = __float_as_uint(a[2 * m.nvox + v]);
+      acc[0] += w * a[v];
+      acc[1] += w;
+      acc[2] += w * (float)(c & 0xFF);
+      acc[3] += w * (float)((c >> 8) & 0xFF);
+      acc[4] += w * (float)((c >> 16) & 0xFF);
+      acc[5] += w * (float)((c >> 24) & 0xFF);
     }
     const float wA = acc[1];
     if (!(wA > 0.0f)) continue;

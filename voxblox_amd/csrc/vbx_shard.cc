@@ -89,6 +89,9 @@ int grow(vbx_shard* s, T** p, size_t* cap, size_t want, size_t elems_per_row) {
 }
 }  // namespace
 
+// a row = the delta block itself: distance, weight and colour planes (vbx_blocks_export_sums); 48 KiB at vps 16
+static constexpr size_t kRowPlanes = 3;
+
 extern "C" {
 
 int vbx_shard_owner_of(const int32_t idx[3], int world) {
@@ -287,7 +290,7 @@ static int prepare_step(vbx_shard* s, int set, size_t used, std::vector<int32_t>
     }
   }
   // 2. their weighted sums, in the same order: one export per (delta, owner) segment (one per delta when there is one)
-  int rc = grow(s, &s->d_send, &s->send_cap, n_total, 6 * s->nvox);
+  int rc = grow(s, &s->d_send, &s->send_cap, n_total, kRowPlanes * s->nvox);
   if (rc) return rc;
   for (size_t u = 0; u < used; ++u) {
     vbx_ctx* d = delta_of(s, set, u);
@@ -297,7 +300,7 @@ static int prepare_step(vbx_shard* s, int set, size_t used, std::vector<int32_t>
     }
     for (int o = 0; o < W; ++o)
       if (cnt[u][o])
-        VBXS(d, vbx_blocks_export_sums(d, &send_keys[3 * seg[u][o]], cnt[u][o], s->d_send + seg[u][o] * 6 * s->nvox));
+        VBXS(d, vbx_blocks_export_sums(d, &send_keys[3 * seg[u][o]], cnt[u][o], s->d_send + seg[u][o] * kRowPlanes * s->nvox));
   }
   *n_out = n_total;
   return VBX_OK;
@@ -370,7 +373,7 @@ static int exchange_and_merge(vbx_shard* s, int set, size_t used, int apply_caps
     //    communicator, so that the others' collectives return an error instead of waiting for it.
     int rc = grow(s, &s->d_keys_send, &s->ks_cap, n, 3);
     if (!rc) rc = grow(s, &s->d_keys_recv, &s->kr_cap, n_recv, 3);
-    if (!rc) rc = grow(s, &s->d_recv, &s->recv_cap, n_recv, 6 * nvox);
+    if (!rc) rc = grow(s, &s->d_recv, &s->recv_cap, n_recv, kRowPlanes * nvox);
     if (rc) {
       (void)ncclCommAbort(s->comm);
       s->comm = nullptr;
@@ -381,7 +384,7 @@ static int exchange_and_merge(vbx_shard* s, int set, size_t used, int apply_caps
     std::vector<size_t> sc(W), sd(W), rcn(W), rd(W);
     for (int r = 0; r < W; ++r) { sc[r] = send_counts[r] * 3; sd[r] = sdispl[r] * 3; rcn[r] = recv_counts[r] * 3; rd[r] = rdispl[r] * 3; }
     NCCLS(ncclAllToAllv(s->d_keys_send, sc.data(), sd.data(), s->d_keys_recv, rcn.data(), rd.data(), ncclInt32, s->comm, s->stream));
-    const size_t row_f = 6 * nvox;
+    const size_t row_f = kRowPlanes * nvox;
     for (int r = 0; r < W; ++r) { sc[r] = send_counts[r] * row_f; sd[r] = sdispl[r] * row_f; rcn[r] = recv_counts[r] * row_f; rd[r] = rdispl[r] * row_f; }
     NCCLS(ncclAllToAllv(s->d_send, sc.data(), sd.data(), s->d_recv, rcn.data(), rd.data(), ncclFloat32, s->comm, s->stream));
     recv_keys.resize(3 * std::max<size_t>(n_recv, 1));
@@ -394,7 +397,7 @@ static int exchange_and_merge(vbx_shard* s, int set, size_t used, int apply_caps
   ++s->stats.steps;
   s->stats.sent_blocks += n;
   s->stats.received_blocks += n_recv;
-  s->stats.payload_bytes += (uint64_t)n * 6 * nvox * 4;
+  s->stats.payload_bytes += (uint64_t)n * kRowPlanes * nvox * 4;
   return VBX_OK;
 }
 

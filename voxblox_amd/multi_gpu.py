@@ -4,14 +4,16 @@ SURVEY.md §8(e).  One process per GPU.  Per frame every rank integrates ITS sha
 rays (whole sensors, or contiguous bands of a cloud) into a zero-initialised per-frame delta
 map; overlapping block updates are then combined with the reference's own merge semantics —
 Block::mergeBlock / mergeVoxelAIntoVoxelB (core/block_inl.h:112-129,
-src/utils/voxel_utils.cc:10-22) is a weighted sum, so the partial sums (w*d, w, w*r, w*g, w*b,
-w*a) of every touched block travel to the block's OWNER (owner = hash(BlockIndex) mod world),
-which adds them up and folds them into its shard of the persistent map:
+src/utils/voxel_utils.cc:10-22) is a weighted sum, so every touched block of the delta map travels
+to the block's OWNER (owner = hash(BlockIndex) mod world), which forms the partial sums (w*d, w, w*r, w*g,
+w*b, w*a), adds them up and folds them into its shard of the persistent map:
 
   1. every rank lists the blocks its delta touched, grouped by owner            (host, tiny)
   2. all-to-all of the group sizes, then of the BlockIndex rows                 (world ints, 12 B / block)
-  3. vbx_blocks_export_sums writes the touched blocks' six float planes in the same order, one
-     all-to-all-v moves each group to its owner: ONLY touched blocks travel, 96 KiB each at vps 16
+  3. vbx_blocks_export_sums writes the touched blocks' rows in the same order — three planes of 32-bit words:
+     distance, weight, colour, i.e. the delta voxels themselves, 48 KiB per block at vps 16 (rounds 1-4 sent the
+     six products, 96 KiB; the owner now forms them with the same float operations, so the merged map is bit for
+     bit the same) — and one all-to-all-v moves each group to its owner: ONLY touched blocks travel
   4. the owner sums the rows of equal BlockIndex in (sender rank, key) order and merges the
      result into the stored voxels                                              (vbx_blocks_merge_sums)
 
@@ -60,6 +62,7 @@ def group_by_owner(keys, world):
     return np.ascontiguousarray(k[order]), counts
 
 
+ROW_PLANES = 3        # a row of the exchange = the delta block itself: distance, weight, colour planes (48 KiB at vps 16)
 BANDS_PER_SENSOR = 4   # ray bundles per 640x480 frame (76,800 rays each)
 
 
@@ -178,13 +181,13 @@ class ShardedTsdfMap:
         n_send = int(send_counts.sum())
         if len(per) == 1:
             send_keys = per[0][0]
-            send = self.d.zeros((max(n_send, 1), 6, nvox))
+            send = self.d.zeros((max(n_send, 1), ROW_PLANES, nvox))
             if n_send:
                 self.d.export_sums(send_keys, send[:n_send])
         else:
             tmp = []
             for (k, c), d in zip(per, self.deltas):
-                t = d.zeros((max(int(k.shape[0]), 1), 6, nvox))
+                t = d.zeros((max(int(k.shape[0]), 1), ROW_PLANES, nvox))
                 if k.shape[0]:
                     d.export_sums(k, t[:k.shape[0]])
                 tmp.append(t)
@@ -197,7 +200,7 @@ class ShardedTsdfMap:
                         key_parts.append(k[a:b])
                         row_parts.append(tmp[u][a:b])
             send_keys = np.ascontiguousarray(np.concatenate(key_parts)) if key_parts else np.zeros((0, 3), np.int32)
-            send = torch.cat(row_parts) if row_parts else self.d.zeros((1, 6, nvox))
+            send = torch.cat(row_parts) if row_parts else self.d.zeros((1, ROW_PLANES, nvox))
         if not self._collective():
             recv_keys, recv = send_keys, send[:n_send]
             recv_counts = send_counts
@@ -213,13 +216,13 @@ class ShardedTsdfMap:
             self.dist.all_to_all_single(rk, kt, output_split_sizes=[int(c) * 3 for c in recv_counts],
                                         input_split_sizes=[int(c) * 3 for c in send_counts])
             recv_keys = rk.cpu().numpy().reshape(-1, 3)
-            payload = send[:n_send].reshape(n_send, 6 * nvox)
+            payload = send[:n_send].reshape(n_send, ROW_PLANES * nvox)
             if payload.device != dev:
                 payload = payload.to(dev)
-            recv = torch.empty((n_recv, 6 * nvox), dtype=torch.float32, device=dev)
+            recv = torch.empty((n_recv, ROW_PLANES * nvox), dtype=torch.float32, device=dev)
             self.dist.all_to_all_single(recv, payload, output_split_sizes=[int(c) for c in recv_counts],
                                         input_split_sizes=[int(c) for c in send_counts])
-            recv = recv.reshape(n_recv, 6, nvox)
+            recv = recv.reshape(n_recv, ROW_PLANES, nvox)
             if recv.device != self.p.device:
                 recv = recv.to(self.p.device)
         if recv_keys.shape[0]:
@@ -228,8 +231,8 @@ class ShardedTsdfMap:
             self.p.merge_sums(recv_keys, recv, self.apply_caps, self.trunc, self.max_weight)
         self.last = dict(sent_blocks=n_send, received_blocks=int(recv_keys.shape[0]),
                          owned_blocks=int(np.unique(recv_keys, axis=0).shape[0]) if recv_keys.shape[0] else 0,
-                         payload_bytes=int(n_send * 6 * nvox * 4),
-                         kept_local_bytes=int(send_counts[self.rank] * 6 * nvox * 4) if self.rank < len(send_counts) else 0)
+                         payload_bytes=int(n_send * ROW_PLANES * nvox * 4),
+                         kept_local_bytes=int(send_counts[self.rank] * ROW_PLANES * nvox * 4) if self.rank < len(send_counts) else 0)
 
 
 class PipelinedShardedTsdfMap:
