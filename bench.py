@@ -240,7 +240,7 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
     gm = capi.Map(voxel, 16, max_blocks=8192)
     gs = capi.Map(voxel, 16, max_blocks=8192)   # the same stream with the ESDF in the reference's own order
     gcfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
-    ecfg = capi.esdf_cfg(min_distance_m=2 * voxel)
+    ecfg = capi.esdf_cfg(min_distance_m=2 * voxel, reference_order=0)
     scfg = capi.esdf_cfg(min_distance_m=2 * voxel, reference_order=1)
     strict_ms = []
 
@@ -470,7 +470,7 @@ def kernel_table(gm, calls_per_step=1.0):
     return rows, calls
 
 
-def pmc_traffic(kernel, tag_files=("r03_pmc_hbm_traffic.json",)):
+def pmc_traffic(kernel, tag_files=("r05_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json")):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate runs with --kernel-trace only, the driver-shaped command; tools/collect_profiles.sh +
     tools/summarize_profiles.py).  Counters cannot be read from inside this process, so the figure comes from the
@@ -507,7 +507,7 @@ def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
     achieved = alg_bytes_per_step / t / 1e9 if t > 0 else 0.0
     total_us = sum(r["us_per_step"] for r in rows)
     tr = (pmc_traffic(dom["kernel"]) if "distinct voxels updated per frame" in what else
-          pmc_traffic(dom["kernel"], ("r03_pmc_esdf_traffic.json",)) if "updated blocks" in what else None)
+          pmc_traffic(dom["kernel"], ("r05_pmc_esdf_ref_order.json", "r03_pmc_esdf_traffic.json")) if "updated blocks" in what else None)
     return {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": (tr["bytes_per_launch"] if tr else None),
             "traffic_detail": tr,
@@ -993,7 +993,7 @@ def main():
     n_pts = frames[0][1].shape[0]
     max_blocks = args.max_blocks or int(8192 * max(1.0, (VOXEL / voxel) ** 3))
     cfg = capi.tsdf_cfg(default_truncation_distance=trunc, merged_bundle_order=args.merged_order, fast_observed_set=args.fast_set)
-    ecfg = capi.esdf_cfg(min_distance_m=trunc / 2) if args.esdf else None  # ros_params.h:136-137
+    ecfg = capi.esdf_cfg(min_distance_m=trunc / 2, reference_order=0) if args.esdf else None  # ros_params.h:136-137 (order_free mode)
     mcfg = capi.mesh_cfg() if args.mesh else None
 
     sharded = None
@@ -1265,7 +1265,7 @@ def main():
             try:
                 go = capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank)
                 go.set_stream(torch.cuda.current_stream().cuda_stream)
-                ocfg = capi.esdf_cfg(min_distance_m=trunc / 2)
+                ocfg = capi.esdf_cfg(min_distance_m=trunc / 2, reference_order=0)
                 dto, ptso, acco, _ = run_stream(args, go, kind, cfg, d_frames, steps, warmup, barrier, ocfg, None)
                 # (the reference map went through the batch update above: compare with a fresh incremental run)
                 ref2 = esdf_reference_run(frames, voxel, total)

@@ -57,9 +57,9 @@ def test_oracle_and_capi_defaults_agree(oracle):
     oe, ge = oracle.esdf_cfg(), capi.esdf_cfg()
     for name, _ in capi.EsdfCfg._fields_:
         if name == "reference_order":
-            continue   # HIP-only field; 0 = the order-free default path
+            continue   # HIP-only field; 1 (default) = the reference's own queue order, 0 = the order-free fast mode
         assert getattr(oe, name) == getattr(ge, name), name
-    assert ge.reference_order == 0
+    assert ge.reference_order == 1
     assert oe.oracle_orderfree_sign_mismatch == 0  # oracle-only switch defaults to the reference
 
 

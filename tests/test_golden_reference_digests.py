@@ -92,7 +92,7 @@ def test_hip_esdf_batch_against_reference_golden(oracle):
     for pose, pts, col in S.frames(sc["n"]):
         gm.integrate({"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED, "fast": capi.TSDF_FAST}[sc["kind"]], cfg,
                      pose[0], pose[1], pts, col)
-    ecfg = capi.esdf_cfg(min_distance_m=2 * sc["voxel"], **sc["esdf"]["cfg"])
+    ecfg = capi.esdf_cfg(reference_order=0, min_distance_m=2 * sc["voxel"], **sc["esdf"]["cfg"])
     gm.esdf_update(ecfg, batch=True, clear_updated_flag=True)
     g = {}
     for i in gm.block_indices(capi.LAYER_ESDF):

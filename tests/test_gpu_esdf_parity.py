@@ -30,7 +30,7 @@ def _pair(oracle, frames, kind="simple", esdf_each_frame=False, ocfg=None, gcfg=
     gm = capi.Map(VOXEL, 16, max_blocks=4096)
     k = {"simple": capi.TSDF_SIMPLE, "merged": capi.TSDF_MERGED}[kind]
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, **gcfg)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2, **gcfg)
     for pose, pts, col in frames:
         oi.integrate(pose[0], pose[1], pts, col)
         gm.integrate(k, gt, pose[0], pose[1], pts, col)
@@ -139,7 +139,7 @@ def test_esdf_default_min_diff_envelope_vs_reference_incremental(oracle):
     oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2))
     gm = capi.Map(VOXEL, 16, max_blocks=4096)
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2)
     for pose, pts, col in frames:
         oi.integrate(pose[0], pose[1], pts, col)
         oe.update_from_tsdf_layer(True)
@@ -208,7 +208,7 @@ def test_esdf_add_new_robot_position_bit_exact(oracle):
                                             oracle_orderfree_sign_mismatch=1, **sph))
     gm = capi.Map(VOXEL, 16, max_blocks=4096)
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC, max_ray_length_m=3.2)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0, **sph)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2, min_diff_m=0.0, **sph)
     for pose, pts, col in frames:
         oi.integrate(pose[0], pose[1], pts, col)
         gm.integrate(capi.TSDF_SIMPLE, gt, pose[0], pose[1], pts, col)
@@ -241,7 +241,7 @@ def test_esdf_robot_position_stream_envelope_vs_reference(oracle):
     oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, **sph))
     gm = capi.Map(VOXEL, 16, max_blocks=4096)
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, **sph)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2, **sph)
     for pose, pts, col in frames:
         oi.integrate(pose[0], pose[1], pts, col)
         oe.add_new_robot_position(pose[0])
@@ -264,7 +264,7 @@ def test_clear_spheres_reference_test_on_gpu(oracle, voxel):
                clear_sphere_radius=1.0, occupied_sphere_radius=4.0)
     gm = capi.Map(voxel, 16, max_blocks=4096)
     gt = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
-    ge = capi.esdf_cfg(**sph)
+    ge = capi.esdf_cfg(reference_order=0, **sph)
     oracle.lib().orc_fast_reset_counter_set(0)
     om = oracle.OracleMap(voxel, 16)
     oi = om.tsdf_integrator("merged", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
@@ -297,7 +297,7 @@ def test_esdf_update_from_tsdf_blocks_subsets(oracle):
     om, oe, gm = _pair(oracle, frames, ocfg=dict(min_diff_m=0.0, oracle_orderfree_sign_mismatch=1),
                        gcfg=dict(min_diff_m=0.0), batch_gpu=True)
     gm.clear(capi.LAYER_ESDF)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2, min_diff_m=0.0)
     blocks = gm.block_indices()
     gm.esdf_update_blocks(ge, blocks[::2], incremental=False)
     oe.update_from_tsdf_blocks(blocks[::2], False)
@@ -334,7 +334,7 @@ def test_esdf_integrator_clear_forgets_robot_spheres(oracle):
     om, oe, gm = _pair(oracle, frames, ocfg=dict(min_diff_m=0.0, oracle_orderfree_sign_mismatch=1, **sph),
                        gcfg=dict(min_diff_m=0.0, **sph), batch_gpu=True)
     oe.update_from_tsdf_layer_batch()
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0, **sph)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2, min_diff_m=0.0, **sph)
     p = frames[0][0][0]
     gm.esdf_add_new_robot_position(ge, p)
     gm.esdf_integrator_clear()
@@ -450,7 +450,7 @@ def test_esdf_full_euclidean_incremental_stream_envelope(oracle):
     oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=TRUNC / 2, **kw))
     gm = capi.Map(VOXEL, 16, max_blocks=4096)
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, **kw)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2, **kw)
     for pose, pts, col in frames:
         oi.integrate(pose[0], pose[1], pts, col)
         oe.update_from_tsdf_layer(True)
@@ -465,7 +465,7 @@ def test_esdf_full_euclidean_range_guard():
     from voxblox_amd import capi
     gm = capi.Map(0.01, 16, max_blocks=64)
     with pytest.raises(RuntimeError, match="int8 parent"):
-        gm.esdf_update(capi.esdf_cfg(full_euclidean_distance=1, max_distance_m=2.0))
+        gm.esdf_update(capi.esdf_cfg(reference_order=0, full_euclidean_distance=1, max_distance_m=2.0))
 
 
 def test_esdf_and_mesh_long_full_resolution_stream(oracle):
@@ -491,7 +491,7 @@ def test_esdf_and_mesh_long_full_resolution_stream(oracle):
     ml = om.mesh_layer()
     gm = capi.Map(VOXEL, 16, max_blocks=8192)
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2, min_diff_m=0.0)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2, min_diff_m=0.0)
     meshes = {}
     for i in range(12):
         pose, pts, col = scenes.room_frame(2 * i, 100)
@@ -573,7 +573,7 @@ def test_esdf_update_finished_sweep_by_sweep_gives_the_same_layer(monkeypatch):
     from voxblox_amd import capi
     frames = [scenes.room_frame(2 * k, 100, f=160.0, width=320, height=240) for k in range(5)]
     gt = capi.tsdf_cfg(default_truncation_distance=TRUNC)
-    ge = capi.esdf_cfg(min_distance_m=TRUNC / 2)
+    ge = capi.esdf_cfg(reference_order=0, min_distance_m=TRUNC / 2)
     def run(expect_requeued):
         gm = capi.Map(VOXEL, 16, max_blocks=4096)   # reads the environment at its first update
         snaps, requeued = [], 0

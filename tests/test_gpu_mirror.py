@@ -15,9 +15,9 @@ def test_blocks_download_equals_per_block():
     for k in (0, 5):
         pose, pts, col = scenes.room_frame(k, 100, f=80.0, width=160, height=120)
         gm.integrate(capi.TSDF_MERGED, cfg, pose[0], pose[1], pts, col)
-    ecfg = capi.esdf_cfg(min_distance_m=0.1)
+    ecfg = capi.esdf_cfg(reference_order=0, min_distance_m=0.1)
     gm.esdf_update(ecfg, batch=False, clear_updated_flag=False)
-    gm.esdf_add_new_robot_position(capi.esdf_cfg(min_distance_m=0.1, clear_sphere_radius=0.5, occupied_sphere_radius=1.0),
+    gm.esdf_add_new_robot_position(capi.esdf_cfg(reference_order=0, min_distance_m=0.1, clear_sphere_radius=0.5, occupied_sphere_radius=1.0),
                                    np.zeros(3, np.float32))
     for layer in (capi.LAYER_TSDF, capi.LAYER_ESDF):
         idx = gm.block_indices(layer)
@@ -58,7 +58,7 @@ def test_remove_distant_blocks_matches_reference(oracle):
     for pose, pts, col in frames[:2]:
         gm.integrate(capi.TSDF_SIMPLE, gcfg, pose[0], pose[1], pts, col)
         oi.integrate(pose[0], pose[1], pts, col)
-    ecfg = capi.esdf_cfg(min_distance_m=2 * voxel)
+    ecfg = capi.esdf_cfg(reference_order=0, min_distance_m=2 * voxel)
     gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
     oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=2 * voxel))
     oe.update_from_tsdf_layer(True)
@@ -95,7 +95,7 @@ def test_block_upload_round_trip_both_layers():
     cfg = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
     pose, pts, col = scenes.room_frame(3, 100, f=40.0, width=80, height=60)
     src.integrate(capi.TSDF_MERGED, cfg, pose[0], pose[1], pts, col)
-    src.esdf_update(capi.esdf_cfg(min_distance_m=2 * voxel), batch=True, clear_updated_flag=False)
+    src.esdf_update(capi.esdf_cfg(reference_order=0, min_distance_m=2 * voxel), batch=True, clear_updated_flag=False)
     dst = capi.Map(voxel, 16, max_blocks=1024)
     idx = src.block_indices(capi.LAYER_ESDF)
     ev, eu, _ = src.blocks_download(idx, capi.LAYER_ESDF)
@@ -213,7 +213,7 @@ def test_batched_block_upload_round_trip():
     pose, pts, col = scenes.room_frame(2, 100, f=40.0, width=80, height=60)
     src = capi.Map(0.1, 16, max_blocks=1024)
     src.integrate(capi.TSDF_FAST, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
-    src.esdf_update(capi.esdf_cfg(min_distance_m=0.2), batch=True, clear_updated_flag=False)
+    src.esdf_update(capi.esdf_cfg(reference_order=0, min_distance_m=0.2), batch=True, clear_updated_flag=False)
     idx = src.block_indices()
     tv, tu, th = src.blocks_download(idx, capi.LAYER_TSDF)
     eidx = src.block_indices(capi.LAYER_ESDF)

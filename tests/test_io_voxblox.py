@@ -139,7 +139,7 @@ def test_gpu_words_and_file_round_trip(oracle, tmp_path):
         pose, pts, col = scenes.room_frame(9 * k, 100, f=40.0, width=80, height=60)
         gm.integrate(capi.TSDF_SIMPLE, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
         oi.integrate(pose[0], pose[1], pts, col)
-    gm.esdf_update(capi.esdf_cfg(min_distance_m=0.2, min_diff_m=0.0), batch=True)
+    gm.esdf_update(capi.esdf_cfg(reference_order=0, min_distance_m=0.2, min_diff_m=0.0), batch=True)
     oe.update_from_tsdf_layer_batch()
     # 1. word streams bit-identical to the oracle's (== reference build's) for TSDF; for ESDF
     #    distance + flag bits identical, parents may differ on ties -> compare after masking

@@ -98,7 +98,7 @@ void vbx_esdf_cfg_default(vbx_esdf_cfg* c) {  // esdf_integrator.h:37-77
   c->add_occupied_crust = 0;
   c->clear_sphere_radius = 1.5f;
   c->occupied_sphere_radius = 5.0f;
-  c->reference_order = 0;
+  c->reference_order = 1;   // the reference's own result by default (round 5); 0 = the order-free fast mode
 }
 
 const char* vbx_last_error(vbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
