@@ -268,18 +268,28 @@ __device__ inline void map_insert_key(const MapDev& m, uint64_t key, uint32_t* n
 // sequence of those moments decides the container's iteration order and with it the order in which
 // updateLayerWithStoredBlocks inserts the blocks into the Layer (:137-147).  kFlagNewThisCall is set in the same
 // atomic as kFlagPublished, so a block that shows Published without it was part of the Layer before this call.
+// (A block that is published between the reading of `cur` and the atomic by a non-ranked publisher cannot happen: inside an
+// integrate call only the emit kernel publishes before the fold runs.)
 constexpr unsigned long long kNoRank = ~0ull;
-__device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* st, unsigned long long rank = kNoRank) {
+// Every toucher of a block may call this: one plain L2 read in the common case (block published and flagged).
+__device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* st) {
   const uint32_t want = kFlagPublished | kFlagUpdMask;
   const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if ((cur & want) == want && !(cur & kFlagNewThisCall)) return;
-  if (rank == kNoRank || ((cur & kFlagPublished) && !(cur & kFlagNewThisCall))) {
+  if ((cur & want) == want) return;
+  const uint32_t old = atomicOr(&m.blk_flags[slot], want);
+  if (!(old & kFlagPublished)) atomicAdd(&st->blocks_published, 1u);
+}
+// The integrators' emit kernels, once per (ray, block it enters): acts on blocks that were NOT part of the Layer when the call
+// began — publishes them and keeps the smallest rank.  Blocks the Layer already held are left alone here: their Update
+// bits are set by the fold, where the keys are sorted by voxel and exactly one thread per touched block does it
+// (publish_block above) — thousands of rays re-flagging the same ~100 blocks from the emit kernel, every frame a consumer
+// had cleared a bit, was a same-address atomic storm (k_fast_emit 18 -> 62 us whenever an ESDF update ran in between).
+__device__ inline void publish_new_block_ranked(const MapDev& m, uint32_t slot, DevState* st, unsigned long long rank) {
+  const uint32_t want = kFlagPublished | kFlagUpdMask | kFlagNewThisCall;
+  const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((cur & kFlagPublished) && !(cur & kFlagNewThisCall)) return;   // part of the Layer before this call
+  if ((cur & want) != want) {
     const uint32_t old = atomicOr(&m.blk_flags[slot], want);
-    if (!(old & kFlagPublished)) atomicAdd(&st->blocks_published, 1u);
-    return;
-  }
-  if ((cur & (want | kFlagNewThisCall)) != (want | kFlagNewThisCall)) {
-    const uint32_t old = atomicOr(&m.blk_flags[slot], want | kFlagNewThisCall);
     if (!(old & kFlagPublished)) atomicAdd(&st->blocks_published, 1u);
   }
   if (__hip_atomic_load(&m.blk_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > rank) atomicMin(&m.blk_first[slot], rank);

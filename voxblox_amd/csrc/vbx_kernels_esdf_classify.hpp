@@ -157,13 +157,25 @@ __global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
   if (!cls_valid(a, slot)) return;
   const int tid = threadIdx.x;
   const size_t base = (size_t)p * NV;
-  for (int i = tid; i < NV; i += VPS * VPS) { s_d[i] = a.sh_d[base + i]; s_f[i] = a.sh_f[base + i]; }
+  // hyperplanes that hold a voxel which looks at its neighbours: the others are skipped (in a steady frame the lookers are
+  // the new voxels along the frontier — a few planes per block; the loop over all 7 (VPS - 1) + 1 planes, each a chain of
+  // dependent neighbour reads, was 0.66 ms per launch)
+  __shared__ uint8_t s_plane[7 * (VPS - 1) + 1];
+  for (int i = tid; i <= 7 * (VPS - 1); i += VPS * VPS) s_plane[i] = 0;
   if (tid == 0) s_moved = 0;
+  __syncthreads();
+  for (int i = tid; i < NV; i += VPS * VPS) {
+    const uint8_t f = a.sh_f[base + i];
+    s_d[i] = a.sh_d[base + i];
+    s_f[i] = f;
+    if (f & kClsNb) s_plane[(i % VPS) + 2 * ((i / VPS) % VPS) + 4 * (i / (VPS * VPS))] = 1;
+  }
   __syncthreads();
   const EsdfCfgDev& c = a.c;
   const int y = tid % VPS, z = tid / VPS;
   uint32_t moved = 0;
   for (int t = 0; t <= 7 * (VPS - 1); ++t) {
+    if (!s_plane[t]) continue;   // (uniform over the workgroup: no barrier is skipped by a part of it)
     const int x = t - 2 * y - 4 * z;
     if (x >= 0 && x < VPS) {
       const uint32_t lin = (uint32_t)(x + VPS * (y + VPS * z));
@@ -174,42 +186,53 @@ __global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
         const float vd = (float)signum(td) * c.default_distance;
         float new_d = vd;
         bool hit = false;
-        for (int idx = 0; idx < 26 && !hit; ++idx) {
+        // the 26 neighbours' (distance, state) first — independent loads, all in flight together — then the first neighbour
+        // in LUT order that qualifies (:505-527); an absent / unusable neighbour reads as state 0
+        float nbd[26];
+        uint32_t nbs[26];
+#pragma unroll
+        for (int idx = 0; idx < 26; ++idx) {
           int nx = x + c_nb_off[idx][0], ny = y + c_nb_off[idx][1], nz = z + c_nb_off[idx][2];
           int cx = 1, cy = 1, cz = 1;
           if (nx < 0) { nx += VPS; cx = 0; } else if (nx >= VPS) { nx -= VPS; cx = 2; }
           if (ny < 0) { ny += VPS; cy = 0; } else if (ny >= VPS) { ny -= VPS; cy = 2; }
           if (nz < 0) { nz += VPS; cz = 0; } else if (nz >= VPS) { nz -= VPS; cz = 2; }
           const uint32_t nlin = (uint32_t)(nx + VPS * (ny + VPS * nz));
-          float nd;
-          uint32_t ns;
+          float nd = 0.f;
+          uint32_t ns = 0u;
           if (cx == 1 && cy == 1 && cz == 1) {
             // same block: in front of the voxel -> the shadow (LDS: this sweep's values), behind it -> the layer
+            // (the block exists since the walk reached it, :145: a block without ESDF voxels reads zeros)
             if (nlin < lin) {
               nd = s_d[nlin];
               ns = a.sh_s[base + nlin];
             } else {
-              if (!(a.m.blk_flags[slot] & kFlagEsdfAlloc)) { /* the block exists since the walk reached it (:145): zeros */ }
               nd = a.e.dist[slot * NV + nlin];
               ns = a.e.state[slot * NV + nlin];
             }
           } else {
             const uint32_t s2 = a.nb27[(size_t)p * 27 + (cx + 3 * cy + 9 * cz)];
-            if (s2 == kInvalidSlot) continue;
-            const uint32_t p2 = a.slot_pos[s2];
-            const bool walked = p2 != kInvalidSlot && cls_valid(a, s2);   // the walk visits the neighbour's block ...
-            const bool in_front = walked && p2 < p;                       // ... and has passed it
-            // getVoxelPtrByGlobalIndex: the ESDF block exists if it did before the update or the walk has reached it (:145)
-            if (!(a.m.blk_flags[s2] & kFlagEsdfAlloc) && !in_front) continue;
-            if (in_front) {
-              nd = a.sh_d[(size_t)p2 * NV + nlin];
-              ns = a.sh_s[(size_t)p2 * NV + nlin];
-            } else {
-              nd = a.e.dist[s2 * NV + nlin];
-              ns = a.e.state[s2 * NV + nlin];
+            if (s2 != kInvalidSlot) {
+              const uint32_t p2 = a.slot_pos[s2];
+              const bool walked = p2 != kInvalidSlot && cls_valid(a, s2);   // the walk visits the neighbour's block ...
+              const bool in_front = walked && p2 < p;                       // ... and has passed it
+              // getVoxelPtrByGlobalIndex: the ESDF block exists if it did before the update or the walk has reached it (:145)
+              if (in_front) {
+                nd = a.sh_d[(size_t)p2 * NV + nlin];
+                ns = a.sh_s[(size_t)p2 * NV + nlin];
+              } else if (a.m.blk_flags[s2] & kFlagEsdfAlloc) {
+                nd = a.e.dist[s2 * NV + nlin];
+                ns = a.e.state[s2 * NV + nlin];
+              }
             }
           }
-          if (!(ns & kEsdfObserved) || nd >= c.max_distance || nd <= -c.max_distance) continue;
+          nbd[idx] = nd;
+          nbs[idx] = ns;
+        }
+#pragma unroll
+        for (int idx = 0; idx < 26; ++idx) {
+          const float nd = nbd[idx];
+          if (hit || !(nbs[idx] & kEsdfObserved) || nd >= c.max_distance || nd <= -c.max_distance) continue;
           if (signum(nd) == signum(vd) && fabsf(nd) < fabsf(vd)) {
             new_d = nd + (float)signum(vd) * (idx < 6 ? 1.0f : (idx < 18 ? (float)1.4142135623730951 : (float)1.7320508075688772));   // NOT scaled by the voxel size (:508, :522)
             hit = true;

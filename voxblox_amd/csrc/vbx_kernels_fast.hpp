@@ -656,10 +656,11 @@ __global__ void k_fast_emit(const uint32_t* __restrict__ off_full, const uint32_
     return;
   }
   keys[i] = ((uint64_t)gid << 32) | r;
-  // tsdf_integrator.cc:128: block->updated().set() on every visited voxel's block
+  // new blocks join the Layer here (with their first-touch rank); block->updated().set() (tsdf_integrator.cc:128) for every
+  // touched block is done by the fold, one thread per block
   const uint32_t slot = gid / m.nvox;
   const bool first_of_block = (k == 0) || (vox[off_full[r] + k - 1] / m.nvox != slot);
-  if (first_of_block) publish_block(m, slot, st, ((unsigned long long)r << 24) | (unsigned long long)(k & 0xFFFFFFu));
+  if (first_of_block) publish_new_block_ranked(m, slot, st, ((unsigned long long)r << 24) | (unsigned long long)(k & 0xFFFFFFu));
 }
 
 

@@ -260,7 +260,7 @@ __global__ void k_ray_emit(RayTab tab, CastCfg c, MapDev m, int from_origin,
         if (slot == kInvalidSlot) {
           atomicOr(&st->error, 2u);
         } else {
-          publish_block(m, slot, st, rank_hi | (unsigned long long)(k & 0xFFFFFFu));
+          publish_new_block_ranked(m, slot, st, rank_hi | (unsigned long long)(k & 0xFFFFFFu));
         }
       }
       if (slot != kInvalidSlot) out = ((uint64_t)(slot * m.nvox + bw.lin) << 32) | o;
@@ -381,10 +381,13 @@ __global__ void __launch_bounds__(256) k_fold_direct(const uint64_t* __restrict_
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = (i < n) ? keys[i] : ~0ull;
   const uint32_t gid = (uint32_t)(key >> 32);
-  const bool head = key != ~0ull && !(i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid);
+  const uint32_t prev_gid = i > 0 ? (uint32_t)(keys[i - 1] >> 32) : 0xFFFFFFFFu;
+  const bool head = key != ~0ull && !(i > 0 && prev_gid == gid);
   const int nheads = __syncthreads_count(head);
   if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched[blockIdx.x & 63u], (unsigned long long)nheads);
   if (!head) return;
+  // block->updated().set() (tsdf_integrator.cc:128): the keys are sorted by voxel, so the first key of a block is one thread
+  if (i == 0 || prev_gid / m.nvox != gid / m.nvox) publish_block(m, gid / m.nvox, st);
   const l3 g = voxel_of_gid(m, gid);
   float d = m.dist[gid];
   float W = m.weight[gid];
@@ -428,8 +431,11 @@ __global__ void __launch_bounds__(256) k_fold(const uint64_t* __restrict__ keys,
     if (i >= n) break;
     const uint64_t key = keys[i];
     const uint32_t gid = (uint32_t)(key >> 32);
-    if (key == ~0ull || (i > 0 && (uint32_t)(keys[i - 1] >> 32) == gid)) continue;  // not a head
+    const uint32_t prev_gid = i > 0 ? (uint32_t)(keys[i - 1] >> 32) : 0xFFFFFFFFu;
+    if (key == ~0ull || (i > 0 && prev_gid == gid)) continue;  // not a head
     ++nheads;
+    // block->updated().set() (tsdf_integrator.cc:128): the first key of a block in sorted order is one thread
+    if (i == 0 || prev_gid / m.nvox != gid / m.nvox) publish_block(m, gid / m.nvox, st);
     if (i + kFoldShort < n && (uint32_t)(keys[i + kFoldShort] >> 32) == gid) {
       if (giant_list && i + kFoldGiant < n && (uint32_t)(keys[i + kFoldGiant] >> 32) == gid) {
         const uint32_t idx = atomicAdd(&st->fold_giant_count, 1u);  // a hundred per frame
