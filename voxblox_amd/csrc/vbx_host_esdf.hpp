@@ -862,8 +862,42 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   int front_done = 0;
   if (replay && rp_env_u32("VBX_RP_CLASSIFY", 1)) {
     const rp::Args ra0 = rp_args(ctx, cfg, e, a.n_chunks);
-    front_done = esdf_classify_parallel(ctx, a.c, e, a.incremental, a.batch_crust, a.num_buckets, a.list_slots, a.n_list, used, ra0, &cls_blocks);
-    if (front_done < 0) return front_done;
+    // A list may name a block twice — esdf_server calls addNewRobotPosition before every update (esdf_server.cc:219-230) and
+    // a sphere block that is also an updated TSDF block is listed by both (:105-109) — and the reference then walks the
+    // block a second time over what the first visit left.  The parallel walk handles a list WITHOUT repeats, so the list is
+    // cut into maximal repeat-free segments that run one after the other: a segment commits to the layer and appends its
+    // pushes behind the queues' tails before the next one starts, which is what the sequential loop does.  (Rounds 3-4 sent
+    // any list with a repeat through the one-wave walk: every update of such a server.)
+    std::vector<uint32_t> seg_slots;
+    if (list) {
+      seg_slots.resize(n);
+      if (n) HIP_TRY(hipMemcpy(seg_slots.data(), ctx->b_rank.p, n * 4, hipMemcpyDeviceToHost));   // (the stream was drained after the lookup)
+    } else {
+      seg_slots = h_slots;
+    }
+    std::unordered_set<uint32_t> in_seg;
+    const uint32_t* all_slots = a.list_slots;
+    size_t pos = 0;
+    front_done = 1;
+    do {
+      in_seg.clear();
+      size_t end = pos;
+      for (; end < n; ++end) {
+        const uint32_t sl = seg_slots[end];
+        if (sl != kInvalidSlot && !in_seg.insert(sl).second) break;   // (absent blocks may repeat: the walk skips them, :139-143)
+      }
+      unsigned long long seg_blocks = 0;
+      const int r = esdf_classify_parallel(ctx, a.c, e, a.incremental, a.batch_crust, a.num_buckets, all_slots + pos, (uint32_t)(end - pos), used, ra0, &seg_blocks);
+      if (r < 0) return r;
+      if (r == 0) {   // not this segment's voxel walk in parallel (block size, unsettled looks): the one-wave form walks the rest of the list
+        a.list_slots = all_slots + pos;
+        a.n_list = (uint32_t)(n - pos);
+        front_done = 0;
+        break;
+      }
+      cls_blocks += seg_blocks;
+      pos = end;
+    } while (pos < n);
   }
   if (!front_done) KLAUNCH(k_esdf_strict, dim3(1), dim3(64), 0, s, a);
   if (replay) {
@@ -882,6 +916,7 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   if (!front_done) {
     HIP_TRY(hipMemcpyAsync(st, a.stats, sizeof(st), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    st[6] += cls_blocks;   // (segments the parallel walk handled before the one-wave form took over)
   } else {
     st[6] = cls_blocks;
   }
