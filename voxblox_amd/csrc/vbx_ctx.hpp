@@ -27,6 +27,8 @@ struct vbx_ctx {
   bool warned_time_budget = false;  // Fast: max_integration_time_s overrun reported once
   double fast_us_per_point = 0.0;   // Fast with a finite max_integration_time_s: wall time per taken point of the earlier calls
   uint32_t fast_take_limit = ~0u;   // ... points of the taking order the current call takes
+  uint32_t fast_prev_taken = 0;     // ... points the previous budgeted call took (the limit moves by at most 2x per frame)
+  uint64_t fast_budget_calls = 0;   // budgeted calls so far (the first one is left out of the estimate)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   DevState* d_state = nullptr;

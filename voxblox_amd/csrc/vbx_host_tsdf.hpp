@@ -1017,7 +1017,10 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   ctx->fast_take_limit = ~0u;
   ctx->counters.points_taken = n;
   if (has_budget && ctx->fast_us_per_point > 0.0) {
-    const double can = (double)cfg->max_integration_time_s * 1000000.0 / ctx->fast_us_per_point;
+    double can = (double)cfg->max_integration_time_s * 1000000.0 / ctx->fast_us_per_point;
+    // (the estimate is a wall-time average: the number of points taken moves by at most a factor of two from one frame
+    // to the next, so that one slow frame — a host hiccup — does not cut the next one to a sliver)
+    if (ctx->fast_prev_taken > 0) can = std::min(std::max(can, 0.5 * (double)ctx->fast_prev_taken), 2.0 * (double)ctx->fast_prev_taken);
     if (can < (double)n) {
       ctx->fast_take_limit = (uint32_t)can;
       ctx->counters.points_taken = ctx->fast_take_limit;
@@ -1029,6 +1032,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
     }
   }
   const auto t_call0 = std::chrono::steady_clock::now();
+  const uint32_t pool_grown_before = ctx->pool_grown;
   if (ctx->new_flags_live) {   // an earlier call failed half way: its new-block marks must not count for this one
     int rcn = collect_new_blocks(ctx);
     if (rcn) return rcn;
@@ -1071,7 +1075,11 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   if (has_budget) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call0).count();
     const double per = us / (double)std::max<uint64_t>(ctx->counters.points_taken, 1);
-    ctx->fast_us_per_point = ctx->fast_us_per_point > 0.0 ? 0.5 * ctx->fast_us_per_point + 0.5 * per : per;
+    // the handle's first integrate call and any call that grew the pool pay one-off costs (allocations, code objects,
+    // the pool copy): they are no measure of what a point costs, and the calls after them take everything again
+    const bool one_off = ctx->fast_budget_calls++ == 0 || ctx->pool_grown != pool_grown_before;
+    ctx->fast_prev_taken = (uint32_t)std::min<uint64_t>(ctx->counters.points_taken, 0xFFFFFFFFu);
+    if (!one_off) ctx->fast_us_per_point = ctx->fast_us_per_point > 0.0 ? 0.5 * ctx->fast_us_per_point + 0.5 * per : per;
     if (!(us < (double)cfg->max_integration_time_s * 1000000.0)) {
       ctx->counters.time_budget_exceeded = 1;
       if (!ctx->warned_time_budget) {
