@@ -249,6 +249,12 @@ int vbx_blocks_new_ordered(vbx_ctx* ctx, int32_t* idx_xyz, size_t cap, size_t* n
  * above, vbx_blocks_upload in list order, removals); *exact (optional) = 0 when blocks of unknown provenance had to be
  * appended in ascending order.  vbx_esdf_update with cfg->reference_order walks this order. */
 int vbx_block_indices_layer_order(vbx_ctx* ctx, int update_mask, int32_t* idx_xyz, size_t cap, size_t* n, int* exact);
+/* on = 0: the map stops following the reference's insertion order (no first-touch ranks, no log; the integrators' emit
+ * kernels then issue no atomics at all — the fold publishes a touched block from one thread).  For scratch maps whose block
+ * order nobody asks for: the per-step delta maps of the sharding, where every block is new in every step
+ * (libvbx_shard.so and voxblox_amd.multi_gpu switch it off for their deltas).  Default on.  Call it on a map without
+ * blocks if vbx_block_indices_layer_order is to stay exact. */
+int vbx_set_block_order_tracking(vbx_ctx* ctx, int on);
 /* Block<V> voxel array in the reference's AoS layout: TsdfVoxel = {float distance; float
  * weight; uint8 r,g,b,a} (12 B, voxel.h:12-16); EsdfVoxel = {float distance; uint8 observed,
  * hallucinated, in_queue, fixed; int32 parent[3]} (20 B, voxel.h:18-37).  Returns

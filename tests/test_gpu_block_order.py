@@ -114,3 +114,31 @@ def test_uploaded_blocks_join_in_list_order_and_unknown_ones_are_reported():
     n = capi.lib().vbx_selftest_index_set_order(idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx),
                                                 out.ctypes.data_as(C.POINTER(C.c_int32)))
     assert n == len(idx) and _order(got) == _order(out)
+
+
+def test_tracking_switched_off_changes_nothing_but_the_order_service(oracle):
+    """vbx_set_block_order_tracking(0) — what the sharding does for its per-step delta maps: no ranks, no log, the fold publishes
+    the blocks.  The map itself must come out bit for bit as before (blocks, voxels, Update bits), clears included."""
+    from voxblox_amd import capi
+    sys.path.insert(0, HERE)
+    from parity_utils import compare_tsdf
+    L = oracle.lib()
+    voxel = 0.1
+    for kind in ("fast", "merged"):
+        L.orc_fast_reset_counter_set(0)
+        om = oracle.OracleMap(voxel, 16)
+        oi = om.tsdf_integrator(kind, oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+        gm = capi.Map(voxel, 16, max_blocks=2048)
+        gm.set_block_order_tracking(False)
+        gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+        for f, (pose, pts, col) in enumerate(S.frames(4)):
+            oi.integrate(pose[0], pose[1], pts, col)
+            gm.integrate(KIND[kind], gc, pose[0], pose[1], pts, col)
+            assert len(gm.blocks_new_ordered()) == 0
+            if f == 1:      # a delta map's life: cleared, its slots kept, filled again
+                om.clear(0)
+                gm.clear_keep_slots()
+        compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+        got, exact = gm.block_indices_layer_order()
+        assert not exact and len(got) == om.num_blocks(0)
+        gm.close()

@@ -22,7 +22,7 @@ UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
 EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_get_map_cfg", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
-    "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_esdf_robot_updated_blocks", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated", "vbx_blocks_new_ordered", "vbx_block_indices_layer_order",
+    "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_esdf_robot_updated_blocks", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated", "vbx_blocks_new_ordered", "vbx_block_indices_layer_order", "vbx_set_block_order_tracking",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_blocks_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_keep_slots", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
@@ -135,6 +135,7 @@ def lib():
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_new_ordered": (C.c_int, [vp, i32p, C.c_size_t, szp]),
+        "vbx_set_block_order_tracking": (C.c_int, [vp, C.c_int]),
         "vbx_block_indices_layer_order": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp, C.POINTER(C.c_int)]),
         "vbx_block_download": (C.c_int, [vp, C.c_int, i32p, vp, u8p, u8p]),
         "vbx_blocks_download": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, vp, u8p, u8p]),
@@ -336,6 +337,9 @@ class Map:
         self._chk(self.L.vbx_blocks_updated(self.h, layer, mask, out.ctypes.data_as(C.POINTER(C.c_int32)),
                                             n.value, C.byref(n)))
         return out[:n.value]
+
+    def set_block_order_tracking(self, on):
+        self._chk(self.L.vbx_set_block_order_tracking(self.h, int(on)))
 
     def blocks_new_ordered(self):
         """The last integrate call's new TSDF blocks in the reference's Layer::insertBlock sequence."""

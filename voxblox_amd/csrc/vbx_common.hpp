@@ -285,6 +285,7 @@ __device__ inline void publish_block(const MapDev& m, uint32_t slot, DevState* s
 // (publish_block above) — thousands of rays re-flagging the same ~100 blocks from the emit kernel, every frame a consumer
 // had cleared a bit, was a same-address atomic storm (k_fast_emit 18 -> 62 us whenever an ESDF update ran in between).
 __device__ inline void publish_new_block_ranked(const MapDev& m, uint32_t slot, DevState* st, unsigned long long rank) {
+  if (!m.blk_first) return;   // order tracking off (vbx_set_block_order_tracking: delta maps of the sharding): the fold publishes
   const uint32_t want = kFlagPublished | kFlagUpdMask | kFlagNewThisCall;
   const uint32_t cur = __hip_atomic_load(&m.blk_flags[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if ((cur & kFlagPublished) && !(cur & kFlagNewThisCall)) return;   // part of the Layer before this call

@@ -46,6 +46,7 @@ struct vbx_ctx {
   uint32_t newlog_pending = 0;        // log entries not read back yet
   uint32_t published_since_clear = 0; // blocks the integrate calls published since the map was last cleared (vbx_clear_keep_slots)
   bool new_flags_live = false;        // kFlagNewThisCall may be set on some block
+  bool track_block_order = true;      // vbx_set_block_order_tracking (off: MapDev::blk_first is null, nothing is ranked or logged)
   bool layer_order_exact = true;      // every block of the map went through layer_order in the reference's sequence
   std::unordered_map<HostBlockIdx, int, HostAnyIndexHash> temp_block_map;       // TsdfIntegratorBase::temp_block_map_
   std::unordered_map<HostBlockIdx, uint32_t, HostAnyIndexHash> layer_order;     // Layer<TsdfVoxel>::block_map_ (keys only)

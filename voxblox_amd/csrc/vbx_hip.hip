@@ -418,6 +418,23 @@ int vbx_blocks_new_ordered(vbx_ctx* ctx, int32_t* idx, size_t cap, size_t* n) {
   return VBX_OK;
 }
 
+int vbx_set_block_order_tracking(vbx_ctx* ctx, int on) {
+  if (!ctx) return VBX_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = sync_state(ctx);
+  if (rc) return rc;
+  if (ctx->new_flags_live) {
+    rc = collect_new_blocks(ctx);
+    if (rc) return rc;
+  }
+  rc = discard_new_blocks(ctx);   // (what the library knows about the Layer's order ends here)
+  if (rc) return rc;
+  ctx->track_block_order = on != 0;
+  ctx->layer_order_exact = ctx->track_block_order && ctx->h_state.pool_used == 0;   // blocks already in the map were not followed
+  ctx->map.blk_first = ctx->track_block_order ? ctx->b_blkfirst.as<unsigned long long>() : nullptr;
+  return VBX_OK;
+}
+
 int vbx_block_indices_layer_order(vbx_ctx* ctx, int update_mask, int32_t* idx, size_t cap, size_t* n, int* exact) {
   if (!ctx || !n || (cap && !idx)) return VBX_ERR_INVALID;
   std::vector<std::pair<uint64_t, uint32_t>> v;
@@ -765,10 +782,8 @@ int vbx_clear(vbx_ctx* ctx, int layer) {
     if (layer == VBX_LAYER_ESDF) ctx->esdf_robot_forget();  // (queue entries name voxels of the layer that goes)
     if (layer == VBX_LAYER_TSDF) {   // block_map_.clear() (layer.h:168): the keys go, the bucket array stays
       ctx->published_since_clear = 0;
-      rc = drain_new_blocks(ctx);
+      rc = discard_new_blocks(ctx);
       if (rc) return rc;
-      ctx->layer_order.clear();
-      ctx->last_new.clear();
     }
     if (used == 0) return VBX_OK;
     hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map,
@@ -799,10 +814,8 @@ int vbx_clear_keep_slots(vbx_ctx* ctx) {
   const uint32_t published = ctx->published_since_clear;
   ctx->published_since_clear = 0;
   if (used > 2u * published + 256u) return vbx_clear(ctx, VBX_LAYER_TSDF);
-  rc = drain_new_blocks(ctx);
+  rc = discard_new_blocks(ctx);
   if (rc) return rc;
-  ctx->layer_order.clear();
-  ctx->last_new.clear();
   hipLaunchKernelGGL(k_remove_distant, dim3(used), dim3(256), 0, ctx->stream, ctx->map, (float*)nullptr, (uint32_t*)nullptr,
                      VBX_LAYER_TSDF, f3{0.f, 0.f, 0.f}, -1.0, 0.0f);  // squared distance > -1: every block
   return VBX_OK;

@@ -150,7 +150,7 @@ int grow_pool(vbx_ctx* ctx) {
   m.rgba = ctx->b_rgba.as<uint32_t>();
   m.blk_idx = ctx->b_blkidx.as<int32_t>();
   m.blk_flags = ctx->b_blkflags.as<uint32_t>();
-  m.blk_first = ctx->b_blkfirst.as<unsigned long long>();
+  m.blk_first = ctx->track_block_order ? ctx->b_blkfirst.as<unsigned long long>() : nullptr;
   m.free_list = ctx->b_freelist.as<uint32_t>();
   // pool_used may have been pushed to the old capacity by the failed commit: the blocks that exist are `used`
   HIP_TRY(hipMemcpyAsync(&ctx->d_state->pool_used, &used, 4, hipMemcpyHostToDevice, s));

@@ -950,6 +950,16 @@ int drain_new_blocks(vbx_ctx* ctx) {
   return VBX_OK;
 }
 
+// Every block of the layer goes (vbx_clear, vbx_clear_keep_slots): whatever the log still holds names blocks that go too —
+// dropped on the device, nothing is read back (a delta map of the sharding is cleared every step).
+int discard_new_blocks(vbx_ctx* ctx) {
+  if (ctx->newlog_pending) HIP_TRY(hipMemsetAsync(&ctx->d_state->newlog_count, 0, 8, ctx->stream));
+  ctx->newlog_pending = 0;
+  ctx->layer_order.clear();   // block_map_.clear() (layer.h:168): the keys go, the bucket array stays
+  ctx->last_new.clear();
+  return VBX_OK;
+}
+
 // A list of (key, slot) pairs of published TSDF blocks -> the sequence in which the reference's Layer would iterate
 // over them (Layer::getAllAllocatedBlocks / getAllUpdatedBlocks walk block_map_, layer.h:184-203).  Blocks whose insertion
 // the library did not see in the reference's sequence (merged in from another map, a log that overflowed) follow in
@@ -1037,7 +1047,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
     int rcn = collect_new_blocks(ctx);
     if (rcn) return rcn;
   }
-  ctx->new_flags_live = true;
+  ctx->new_flags_live = ctx->track_block_order;
   // per-call device counters
   KLAUNCH(k_reset_call_state, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state);
   Pose T;
@@ -1065,7 +1075,7 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   // the blocks this call added to the Layer, with their first-touch ranks -> the new-block log (no read-back here)
   ctx->last_call_seq = ctx->call_seq;
   ctx->published_since_clear += ctx->h_state.blocks_published;
-  if (ctx->h_state.blocks_published > 0) {
+  if (ctx->h_state.blocks_published > 0 && ctx->track_block_order) {
     rc = collect_new_blocks(ctx);
     if (rc) return rc;
   } else {

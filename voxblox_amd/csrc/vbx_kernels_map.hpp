@@ -79,7 +79,7 @@ __global__ void k_assign_slots(MapDev m, const uint32_t* new_list, DevState* st)
   m.blk_idx[3 * slot + 1] = y;
   m.blk_idx[3 * slot + 2] = z;
   m.blk_flags[slot] = 0;
-  m.blk_first[slot] = kNoRank;
+  if (m.blk_first) m.blk_first[slot] = kNoRank;
   __hip_atomic_store(&m.hvals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -142,6 +142,7 @@ vbx_shard* vbx_shard_create(vbx_ctx* persistent, vbx_ctx* delta, int rank, int w
     return nullptr;
   }
   s->nvox = (size_t)cp.voxels_per_side * cp.voxels_per_side * cp.voxels_per_side;
+  (void)vbx_set_block_order_tracking(delta, 0);   // a delta map is rebuilt every step; nobody asks for its Layer order
   return s;
 }
 
@@ -177,6 +178,7 @@ int vbx_shard_add_delta(vbx_shard* s, vbx_ctx* delta) {
     return VBX_ERR_INVALID;
   }
   s->deltas.push_back(delta);
+  (void)vbx_set_block_order_tracking(delta, 0);
   return VBX_OK;
 }
 

@@ -104,6 +104,10 @@ class ShardedTsdfMap:
         self.p = persistent
         self.deltas = list(delta) if isinstance(delta, (list, tuple)) else [delta]
         self.d = self.deltas[0]
+        for d in self.deltas:   # a delta map is rebuilt every step and nobody asks for its Layer order: no first-touch ranks
+            off = getattr(getattr(d, "m", None), "set_block_order_tracking", None)
+            if off is not None:
+                off(False)
         self.rank, self.world = int(rank), int(world)
         self.dist = dist
         self.apply_caps, self.trunc, self.max_weight = apply_caps, truncation, max_weight
