@@ -142,3 +142,19 @@ def test_tracking_switched_off_changes_nothing_but_the_order_service(oracle):
         got, exact = gm.block_indices_layer_order()
         assert not exact and len(got) == om.num_blocks(0)
         gm.close()
+
+
+def test_new_blocks_of_a_call_that_published_nothing_are_none():
+    """The log is read lazily: a call that added blocks followed, without any question in between, by a call that added none —
+    vbx_blocks_new_ordered then answers for the LAST call (nothing), and the Layer order still holds the earlier blocks."""
+    from voxblox_amd import capi
+    gm = capi.Map(0.1, 16, max_blocks=1024)
+    gc = capi.tsdf_cfg(default_truncation_distance=0.4)
+    pose, pts, col = S.frames(1)[0]
+    gm.integrate(capi.TSDF_SIMPLE, gc, pose[0], pose[1], pts, col)
+    n_first = gm.counters()["blocks_allocated"]
+    gm.integrate(capi.TSDF_SIMPLE, gc, pose[0], pose[1], pts, col)      # the same cloud again: every block exists
+    assert n_first > 20 and gm.counters()["blocks_allocated"] == 0
+    assert len(gm.blocks_new_ordered()) == 0
+    got, exact = gm.block_indices_layer_order()
+    assert exact and len(got) == n_first

@@ -42,7 +42,8 @@ struct vbx_ctx {
   // first-touch ranks per block on the device (MapDev::blk_first), a device log of the blocks every call published, and
   // host containers keyed like the reference's that turn the log into iteration orders.
   DBuf b_blkfirst, b_newlog;
-  unsigned long long call_seq = 1, last_call_seq = 0, last_new_seq = 0;
+  unsigned long long call_seq = 1, last_call_seq = 0;
+  unsigned long long last_new_seq = 0;   // the call whose new blocks `last_new` holds
   uint32_t newlog_pending = 0;        // log entries not read back yet
   uint32_t published_since_clear = 0; // blocks the integrate calls published since the map was last cleared (vbx_clear_keep_slots)
   bool new_flags_live = false;        // kFlagNewThisCall may be set on some block

@@ -931,7 +931,10 @@ int drain_new_blocks(vbx_ctx* ctx) {
     // one batch = one updateLayerWithStoredBlocks: a call, or one of the Merged integrator's two passes
     const unsigned long long seq = log[i].seq, pass = log[i].rank >> 62;
     const bool last_call = seq == ctx->last_call_seq;
-    if (last_call && (i == 0 || log[i - 1].seq != seq)) ctx->last_new.clear();
+    if (last_call && ctx->last_new_seq != seq) {   // the first batch of the last call: last_new starts over
+      ctx->last_new.clear();
+      ctx->last_new_seq = seq;
+    }
     size_t j = i;
     for (; j < log.size() && log[j].seq == seq && (log[j].rank >> 62) == pass; ++j) {
       int x, y, z;
@@ -946,7 +949,6 @@ int drain_new_blocks(vbx_ctx* ctx) {
     ctx->temp_block_map.clear();
     i = j;
   }
-  ctx->last_new_seq = ctx->last_call_seq;
   return VBX_OK;
 }
 
