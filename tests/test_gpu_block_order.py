@@ -158,3 +158,24 @@ def test_new_blocks_of_a_call_that_published_nothing_are_none():
     assert len(gm.blocks_new_ordered()) == 0
     got, exact = gm.block_indices_layer_order()
     assert exact and len(got) == n_first
+
+
+@pytest.mark.parametrize("voxel,n_frames", [(0.05, 6), (0.02, 2)], ids=["0p05_stream", "0p02_sensor_frames"])
+def test_layer_order_at_baseline_size(oracle, voxel, n_frames):
+    """Full 640x480 frames — BASELINE configs[1]'s stream at 0.05 m, configs[4]'s sensor frames at 0.02 m (where the observed-set
+    replay runs in blocks of rays) — through the Fast integrator: the Layer's iteration order equals the oracle's after every
+    frame (hundreds to thousands of new blocks per call, ranks from 300 k rays)."""
+    from voxblox_amd import capi, scenes
+    L = oracle.lib()
+    L.orc_fast_reset_counter_set(0)
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("fast", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    gm = capi.Map(voxel, 16, max_blocks=8192 if voxel > 0.03 else 16384)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    for f in range(n_frames):
+        pose, pts, col = scenes.room_frame(3 * f, 100) if voxel > 0.03 else scenes.room_sensor_frame(0, f)
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+        got, exact = gm.block_indices_layer_order()
+        assert exact and _order(got) == _order(om.block_indices(0)), f
+    assert om.num_blocks(0) > (200 if voxel > 0.03 else 1000)

@@ -655,13 +655,13 @@ class ModelEsdf : public EsdfIntegrator {
       ++steps;
       const uint32_t n = c.n_threads;
       if (c.phase == PH_RANK || c.phase == PH_PUSH) {
-        Cnt4 run = {{0, 0, 0, 0}};
+        Cnt4 run{};
         for (uint32_t i = 0; i < n; ++i) {
           const Cnt4 cnt = rp_scan_count(a, i);
           rp_scan_apply(a, i, run);
-          for (int k = 0; k < 4; ++k) run.v[k] += cnt.v[k];
+          for (int k = 0; k < kScanC; ++k) run.v[k] += cnt.v[k];
         }
-        for (int k = 0; k < 4; ++k) c.scan_tot[k] = run.v[k];
+        for (int k = 0; k < kScanC; ++k) c.scan_tot[k] = run.v[k];
       } else {
         order.resize(n);
         for (uint32_t i = 0; i < n; ++i) order[i] = i;

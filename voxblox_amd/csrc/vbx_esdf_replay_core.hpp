@@ -66,7 +66,8 @@ enum Phase : uint32_t {
 };
 // A SCAN phase is collective and lives outside this file: for i = 0 .. n_threads - 1 in order, c = rp_scan_count(i),
 // rp_scan_apply(i, running sums), running sums += c; the totals go to Ctl::scan_tot.
-struct Cnt4 { uint32_t v[4]; };
+constexpr int kScanC = 8;   // components a SCAN phase carries per item: bucket FIFOs filled by one PH_PUSH pass (four until round 5)
+struct Cnt4 { uint32_t v[kScanC]; };
 
 struct Cfg {
   float max_distance, min_diff, voxel_size, default_distance;
@@ -90,8 +91,8 @@ struct Ctl {
   uint32_t cap_stop;                         // 1: the records (or their list) are full — no births any more, the super-step commits what stands
   unsigned long long cut;
   uint32_t n_commit;                         // committed records
-  uint32_t scan_tot[4];
-  uint32_t push_b[4], push_n;                // buckets of the current PH_PUSH pass
+  uint32_t scan_tot[kScanC];
+  uint32_t push_b[kScanC], push_n;                // buckets of the current PH_PUSH pass
   uint32_t push_next;                        // first bucket not yet handled by a PH_PUSH pass
   uint32_t chunk_top;
   // ---- B
@@ -792,24 +793,32 @@ RP_FN void rp_phase_commit_fold(const Args& a, uint32_t tid) {
 // SCAN counts / applies.  PH_RANK: item = base record i, count = its committed records (itself included), apply =
 // dense pop rank of base record i.  PH_PUSH: item = j-th committed record in pop order, count[k] = its entries for
 // bucket push_b[k], apply = they are written behind the bucket's tail in LUT order.
-RP_FN uint32_t rp_push_bits(const Args& a, uint32_t r, uint32_t bucket, unsigned long long cut) {
-  uint32_t bits = 0;
-  for (uint32_t lut = 0; lut < 26; ++lut) {
-    const uint32_t v = (a.rec_push[r * 7 + lut / 4] >> ((lut % 4) * 8)) & 0xFF;
-    if (v != bucket + 1) continue;
-    // an entry that was popped inside this super-step is not queued
-    const uint32_t kid = a.rec_kid[(size_t)r * 26 + lut];
-    if (kid != 0u) {
-      const uint32_t k = kid - 1;
-      if (rp_meta_live(a.rec_meta[k]) && a.rec_T[k] < cut) continue;
+// the committed pushes of record r, one LUT index at a time: f(lut, component k of the current PH_PUSH pass)
+template <class F>
+RP_FN void rp_for_pushes(const Args& a, uint32_t r, const F& f) {
+  const Ctl& c = *a.ctl;
+  for (uint32_t w = 0; w < 7; ++w) {
+    uint32_t word = a.rec_push[r * 7 + w];
+    for (uint32_t j = 0; word != 0u && j < 4; ++j, word >>= 8) {
+      const uint32_t v = word & 0xFF;
+      if (v == 0u) continue;
+      const uint32_t lut = w * 4 + j;
+      uint32_t k = 0;
+      while (k < c.push_n && c.push_b[k] != v - 1u) ++k;
+      if (k == c.push_n) continue;                            // a bucket of another pass
+      // an entry that was popped inside this super-step is not queued
+      const uint32_t kid = a.rec_kid[(size_t)r * 26 + lut];
+      if (kid != 0u) {
+        const uint32_t kr = kid - 1;
+        if (rp_meta_live(a.rec_meta[kr]) && a.rec_T[kr] < c.cut) continue;
+      }
+      f(lut, k);
     }
-    bits |= 1u << lut;
   }
-  return bits;
 }
 RP_FN Cnt4 rp_scan_count(const Args& a, uint32_t i) {
   const Ctl& c = *a.ctl;
-  Cnt4 n = {{0, 0, 0, 0}};
+  Cnt4 n{};
   if (c.phase == PH_RANK) {
     const unsigned long long T0 = (unsigned long long)i << kRankBits;
     if (T0 < c.cut) {
@@ -817,12 +826,7 @@ RP_FN Cnt4 rp_scan_count(const Args& a, uint32_t i) {
       if ((c.cut >> kRankBits) == i) n.v[0] = (uint32_t)(c.cut & kRankMask);  // ranks in front of the cut's, plus the base record
     }
   } else {
-    const uint32_t r = a.ord[i];
-    for (uint32_t k = 0; k < c.push_n; ++k) {
-      uint32_t x = rp_push_bits(a, r, c.push_b[k], c.cut), cnt = 0;
-      for (; x; x &= x - 1) ++cnt;
-      n.v[k] = cnt;
-    }
+    rp_for_pushes(a, a.ord[i], [&](uint32_t, uint32_t k) { ++n.v[k]; });
   }
   return n;
 }
@@ -834,12 +838,10 @@ RP_FN void rp_scan_apply(const Args& a, uint32_t i, const Cnt4& prefix) {
   }
   const uint32_t r = a.ord[i];
   const uint32_t gid = a.rec_vox[r];
-  for (uint32_t k = 0; k < c.push_n; ++k) {
-    const uint32_t bits = rp_push_bits(a, r, c.push_b[k], c.cut);
-    uint32_t pos = c.tail[c.push_b[k]] + prefix.v[k];
-    for (uint32_t lut = 0; lut < 26; ++lut)
-      if ((bits >> lut) & 1u) rp_queue_store(a, (int)c.push_b[k], pos++, rp_neighbour(a, gid, (int)lut));
-  }
+  Cnt4 pos = prefix;   // (LUT indices come in ascending order: the entries of a bucket land in LUT order)
+  rp_for_pushes(a, r, [&](uint32_t lut, uint32_t k) {
+    rp_queue_store(a, (int)c.push_b[k], c.tail[c.push_b[k]] + pos.v[k]++, rp_neighbour(a, gid, (int)lut));
+  });
 }
 RP_FN void rp_phase_rank_write(const Args& a, uint32_t tid) {
   Ctl& c = *a.ctl;
@@ -943,13 +945,13 @@ RP_FN void rp_start_commit(const Args& a) {
   c.n_threads = c.a_tgt;
 }
 
-// the next (up to four) buckets that receive entries from this commit, chunks reserved for the most they can get
+// the next (up to kScanC) buckets that receive entries from this commit, chunks reserved for the most they can get
 RP_FN void rp_next_push_pass(const Args& a) {
   Ctl& c = *a.ctl;
   c.push_n = 0;
   int b = (int)c.push_next;
   const int nq = a.c.num_buckets + (c.raise ? 1 : 0);
-  for (; b < nq && c.push_n < 4; ++b) {
+  for (; b < nq && c.push_n < (uint32_t)kScanC; ++b) {
     const uint32_t bound = RP_LD(c.push_cnt[b]);
     if (bound == 0) continue;
     if (!rp_queue_reserve(a, b, bound)) { rp_stop(c); return; }
@@ -1035,6 +1037,15 @@ RP_FN void rp_control(const Args& a) {
       rp_next_push_pass(a);
       break;
     case PH_COMMIT_FOLD:
+      if (c.n_rec == c.K) {
+        // no excursion records: the committed records are the base records in front of the cut, in FIFO order — which is
+        // what ord[] holds since PLACE_BASE (ord[r] = r); the dense ranking and its write pass have nothing to add
+        unsigned long long nb = c.cut >> kRankBits;
+        c.n_commit = (c.cut == kNever || nb > c.K) ? c.K : (uint32_t)nb;
+        c.push_next = 0;
+        rp_next_push_pass(a);
+        break;
+      }
       c.phase = PH_RANK;
       c.n_threads = c.K;
       break;

@@ -483,7 +483,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     // (a caller's list may name blocks the map does not hold, esdf_integrator.cc:139-143, or a block twice: it can be
     // longer than the pool, and k_cls_push scans n_list * nvox items)
     const size_t items = std::max<size_t>(rec_cap, std::max<size_t>(std::max<uint32_t>(used, 1), n_list) * m.nvox);
-    const size_t bytes = (items / kRpThreads + 2) * 4 * 8 + 64;
+    const size_t bytes = (items / kRpThreads + 2) * rp::kScanC * 8 + 64;
     ctx->rp_scan_tiles_cap = (uint32_t)std::min<size_t>(items / kRpThreads + 2, 0xFFFFFFFFu);
     if (ctx->rp_scan_desc.cap < bytes) {
       HIP_TRY(ctx->rp_scan_desc.ensure(bytes));
@@ -681,7 +681,7 @@ int esdf_classify_parallel(vbx_ctx* ctx, const EsdfCfgDev& c, const EsdfDev& e, 
     sc.ticket = ctx->rp_scan_desc.as<uint32_t>();
     sc.max_tiles = ctx->rp_scan_tiles_cap;
     const uint32_t tiles = (uint32_t)(((size_t)n_list * m.nvox + kRpThreads - 1) / kRpThreads);
-    for (int q0 = 0; q0 <= num_buckets; q0 += 4)
+    for (int q0 = 0; q0 <= num_buckets; q0 += rp::kScanC)
       KLAUNCH(k_cls_push, dim3(std::min<uint32_t>(tiles, 1024u)), dim3(kRpThreads), 0, s, a, ra, sc, q0);
   }
   *n_blocks = h[2];

@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr uint32_t kClsCounters = 1024, kClsBase = 600;   // words of ClsArgs::counters; [kClsBase + q]: entries queue q held before the walk
+constexpr uint32_t kClsCounters = 1024, kClsBase = 600, kClsScanTot = 1000;   // words of ClsArgs::counters; [kClsBase + q]: entries queue q held before the walk
 constexpr uint32_t kClsWrite = 1, kClsOpen = 2, kClsRaise = 4, kClsNb = 8, kClsHit = 16;
 
 struct ClsArgs {
@@ -316,7 +316,7 @@ __global__ void k_cls_reserve(ClsArgs a, rp::Args ra) {
   c.chunk_top = top;
 }
 
-// the pushes of queues q0 .. q0 + 3 in walk order
+// the pushes of queues q0 .. q0 + rp::kScanC - 1 in walk order
 struct ClsPushScan {
   const ClsArgs& a;
   const rp::Args& ra;
@@ -327,34 +327,36 @@ struct ClsPushScan {
     if (!(f & kClsWrite)) return 0;
     if (f & kClsOpen) {
       const int k = (int)a.sh_q[i] - q0;
-      if (k >= 0 && k < 4) m |= 1u << k;
+      if (k >= 0 && k < rp::kScanC) m |= 1u << k;
     }
     if (f & kClsRaise) {
       const int k = a.num_buckets - q0;
-      if (k >= 0 && k < 4) m |= 1u << k;
+      if (k >= 0 && k < rp::kScanC) m |= 1u << k;
     }
     return m;
   }
   __device__ rp::Cnt4 count(uint32_t i) const {
     const uint32_t m = mask(i);
-    return rp::Cnt4{{m & 1u, (m >> 1) & 1u, (m >> 2) & 1u, (m >> 3) & 1u}};
+    rp::Cnt4 c{};
+    for (int k = 0; k < rp::kScanC; ++k) c.v[k] = (m >> k) & 1u;
+    return c;
   }
   __device__ void apply(uint32_t i, const rp::Cnt4& ex) const {
     const uint32_t m = mask(i);
     if (!m) return;
     const uint32_t gid = a.list_slots[i / a.m.nvox] * a.m.nvox + i % a.m.nvox;
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < rp::kScanC; ++k)
       if ((m >> k) & 1u) rp::rp_queue_store(ra, q0 + k, a.counters[kClsBase + q0 + k] + ex.v[k], gid);
   }
 };
 __global__ void __launch_bounds__(kRpThreads) k_cls_push(ClsArgs a, rp::Args ra, RpScan sc, int q0) {
   __shared__ uint32_t s_last;
-  // (nothing to do for these four queues: leave the scan's ticket / generation alone)
+  // (nothing to do for these queues: leave the scan's ticket / generation alone)
   uint32_t any = 0;
-  for (int k = 0; k < 4 && q0 + k <= a.num_buckets; ++k) any |= a.counters[8 + q0 + k];
+  for (int k = 0; k < rp::kScanC && q0 + k <= a.num_buckets; ++k) any |= a.counters[8 + q0 + k];
   if (!any) return;
   ClsPushScan f{a, ra, q0};
-  rp_scan_tiles(f, sc, a.n_list * a.m.nvox, a.counters + 4, &ra.ctl->error);
+  rp_scan_tiles(f, sc, a.n_list * a.m.nvox, a.counters + kClsScanTot, &ra.ctl->error);   // (the totals are not used: [8 + q] holds them already)
   // the last workgroup resets the ticket and moves the generation on for the next scan
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

@@ -564,13 +564,13 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   __syncthreads();
 }
 
-// SCAN: tiles of kRpThreads items by ticket; exclusive prefix of the four counts per item, F::count / F::apply per item,
+// SCAN: tiles of kRpThreads items by ticket; exclusive prefix of the first nc (<= rp::kScanC) counts per item, F::count / F::apply per item,
 // totals -> tot[0..3] (atomic stores), a wait that does not end -> *err |= 64
 template <class F>
-__device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, uint32_t* tot, uint32_t* err) {
+__device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, uint32_t* tot, uint32_t* err, int nc = rp::kScanC) {
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wave[kRpThreads / 64][4];
-  __shared__ uint32_t s_prefix[4];
+  __shared__ uint32_t s_wave[kRpThreads / 64][rp::kScanC];
+  __shared__ uint32_t s_prefix[rp::kScanC];
   const uint32_t tiles = (n + kRpThreads - 1) / kRpThreads;
   if (tiles > sc.max_tiles) {   // more tiles than descriptors: fail loudly instead of indexing past the buffer
     if (threadIdx.x == 0) atomicOr(err, 64u);
@@ -585,11 +585,11 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
     const uint32_t tile = s_tile;
     if (tile >= tiles) break;
     const uint32_t i = tile * kRpThreads + threadIdx.x;
-    rp::Cnt4 cnt = {{0, 0, 0, 0}};
+    rp::Cnt4 cnt{};
     if (i < n) cnt = f.count(i);
     // exclusive scan inside the tile: wave scan by shuffles, wave totals through LDS
-    rp::Cnt4 ex;
-    for (int k = 0; k < 4; ++k) {
+    rp::Cnt4 ex{};
+    for (int k = 0; k < nc; ++k) {
       uint32_t v = cnt.v[k];
       for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(v, d);
@@ -599,8 +599,8 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
       ex.v[k] = v - cnt.v[k];
     }
     __syncthreads();
-    uint32_t agg[4];
-    for (int k = 0; k < 4; ++k) {
+    uint32_t agg[rp::kScanC];
+    for (int k = 0; k < nc; ++k) {
       uint32_t before = 0, total = 0;
       for (int w = 0; w < kRpThreads / 64; ++w) {
         if (w < wave) before += s_wave[w][k];
@@ -609,20 +609,22 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
       ex.v[k] += before;
       agg[k] = total;
     }
-    // publish the aggregates, look back: wave k owns component k and reads 64 predecessors at a time (a tile's wait is
+    // publish the aggregates, look back: wave k owns components k, k + 4 and reads 64 predecessors at a time (a tile's wait is
     // for aggregates only, which every tile publishes before it looks back — no chain of waits through the tiles)
-    if (wave < 4) {
-      const int k = wave;
-      unsigned long long* d = sc.desc + (size_t)tile * 4 + k;
-      uint32_t prefix = 0;
+    // (four waves, up to eight components: a wave owns k and k + 4; all of a tile's aggregates go out before it waits for anybody)
+    for (int k = wave; k < nc; k += kRpThreads / 64)
       if (lane == 0)
-        __hip_atomic_store(d, ((unsigned long long)((gen << 2) | (tile == 0 ? 2u : 1u)) << 32) | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k, ((unsigned long long)((gen << 2) | (tile == 0 ? 2u : 1u)) << 32) | agg[k], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = wave; k < nc; k += kRpThreads / 64) {
+      unsigned long long* d = sc.desc + (size_t)tile * rp::kScanC + k;
+      uint32_t prefix = 0;
       uint32_t t = tile;   // tiles [0, t) are still to be summed
       uint32_t spins = 0;
       while (t > 0) {
         const bool mine = (uint32_t)lane < t;
         unsigned long long w = 0;
-        if (mine) w = __hip_atomic_load(sc.desc + (size_t)(t - 1 - lane) * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mine) w = __hip_atomic_load(sc.desc + (size_t)(t - 1 - lane) * rp::kScanC + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t tag = (uint32_t)(w >> 32);
         const bool ready = mine && (tag >> 2) == gen && (tag & 3u) != 0u;
         const bool incl = ready && (tag & 3u) == 2u;
@@ -650,20 +652,25 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
     }
     __syncthreads();
     if (i < n) {
-      for (int k = 0; k < 4; ++k) ex.v[k] += s_prefix[k];
+      for (int k = 0; k < nc; ++k) ex.v[k] += s_prefix[k];
       f.apply(i, ex);
     }
   }
-  if (n == 0 && blockIdx.x == 0 && threadIdx.x < 4) atomicExch(&tot[threadIdx.x], 0u);
+  if (n == 0 && blockIdx.x == 0 && (int)threadIdx.x < nc) atomicExch(&tot[threadIdx.x], 0u);
 }
 struct RpPhaseScan {   // PH_RANK / PH_PUSH
   const rp::Args& a;
   __device__ rp::Cnt4 count(uint32_t i) const { return rp::rp_scan_count(a, i); }
   __device__ void apply(uint32_t i, const rp::Cnt4& ex) const { rp::rp_scan_apply(a, i, ex); }
 };
-__device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32_t n) {
+__device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32_t n, uint32_t phase) {
   RpPhaseScan f{a};
-  rp_scan_tiles(f, sc, n, a.ctl->scan_tot, &a.ctl->error);
+  // PH_RANK counts one thing per item, a PH_PUSH pass one per bucket it fills (Ctl::push_n: part A, written by the control
+  // step of an earlier launch)
+  int nc = phase == rp::PH_RANK ? 1 : (int)a.ctl->push_n;
+  if (nc < 1) nc = 1;
+  if (nc > rp::kScanC) nc = rp::kScanC;
+  rp_scan_tiles(f, sc, n, a.ctl->scan_tot, &a.ctl->error, nc);
 }
 
 __host__ __device__ inline unsigned long long rp_hdr(uint32_t seq, uint32_t phase, uint32_t n) {
@@ -692,7 +699,7 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   if (active == 0) active = 1;
   if (blockIdx.x >= active) return;
   if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
-    rp_scan_phase(a, sc, n);
+    rp_scan_phase(a, sc, n, phase);
   } else if (!SERIAL && phase == rp::PH_RAISE_FOLD) {
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
     for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves) rp_fold_raise_wave(a, w, threadIdx.x & 63);
