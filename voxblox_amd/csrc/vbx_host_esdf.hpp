@@ -429,7 +429,7 @@ int esdf_add_new_robot_position(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const flo
 }
 
 // ---- the parallel open set of reference_order (vbx_esdf_replay_core.hpp) ------------------------------------------
-constexpr int kRpGrid = 2048;       // workgroups of k_rp_step (grid-stride over the phase's items)
+constexpr int kRpGrid = 1024;       // workgroups of k_rp_step (grid-stride over the phase's items; VBX_RP_GRID: 256 / 512 / 1024 / 2048 / 4096 measured 47.9 / 47.0 / 46.2 / 48.6 / 52.9 ms on frame 11 of the stream)
 
 static uint32_t rp_env_u32(const char* name, uint32_t dflt) {
   const char* v = getenv(name);
@@ -576,6 +576,7 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   rp::Args as = a;   // (serial form: no member lists, ranking from the child table)
   as.sub_mem = nullptr; as.sub_restart = nullptr;
   KLAUNCH(k_rp_begin, dim3(1), dim3(1), 0, s, a);
+  const uint32_t rp_grid = std::max<uint32_t>(64u, rp_env_u32("VBX_RP_GRID", kRpGrid));   // (measurement switch)
   uint32_t h_done[2] = {0, 0};
   const uint64_t max_graphs = 1u << 20;
   for (uint64_t g = 0; g < max_graphs; ++g) {
@@ -589,8 +590,8 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
           fprintf(stderr, "[rp-sync] step %llu phase %u n %u K %u b %u n_rec %u n_tgt %u n_chg %u n_born %u n_sd %u n_cp %u iter %u\n", hc.st_steps, hc.phase, hc.n_threads, hc.K,
                   hc.bucket, hc.n_rec, hc.n_tgt, hc.n_chg, hc.n_born, hc.n_sd, hc.n_cp, hc.iter);
         }
-        if (serial) KLAUNCH(k_rp_step<true>, dim3(kRpGrid), dim3(kRpThreads), 0, s, as, sc, i);
-        else KLAUNCH(k_rp_step<false>, dim3(kRpGrid), dim3(kRpThreads), 0, s, a, sc, i);
+        if (serial) KLAUNCH(k_rp_step<true>, dim3(rp_grid), dim3(kRpThreads), 0, s, as, sc, i);
+        else KLAUNCH(k_rp_step<false>, dim3(rp_grid), dim3(kRpThreads), 0, s, a, sc, i);
         if (getenv("VBX_RP_SYNC") && hipStreamSynchronize(s) != hipSuccess) { fprintf(stderr, "[rp-sync] fault\n"); }
       }
     }
