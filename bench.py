@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--bands", type=int, default=0,
                     help="sensors4: ray bundles per sensor frame (default 1 = whole sensors, the only layout that reproduces the "
                          "reference's map; 4 = the quarter-frame bundles of rounds 3-4, a different map)")
+    ap.add_argument("--cpu-threads", default="", help="comma list of integrator_threads values the CPU reference is timed with (default: 1, 2, 4, ... nproc)")
     ap.add_argument("--detail-out", default="", help="where the full result goes (default bench_detail.json next to this file)")
     return ap.parse_args()
 
@@ -125,7 +126,12 @@ def _oracle():
     return O, (O.ref_lib() if use_ref else O.lib()), use_ref
 
 
+CPU_THREADS = []   # --cpu-threads (empty: the full ladder)
+
+
 def _thread_counts(cores):
+    if CPU_THREADS:
+        return sorted({t for t in CPU_THREADS if 1 <= t <= cores}) or [1]
     return sorted({t for t in (1, 2, 4, 8, 16, 32, 64, cores) if t <= cores})
 
 
@@ -875,6 +881,8 @@ def emit(out, args):
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.cpu_threads:
+        CPU_THREADS[:] = [int(x) for x in args.cpu_threads.split(",") if x.strip()]
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn(args)
     import torch
@@ -1295,6 +1303,8 @@ def main():
                 "configs[4] 4 sensors 0.02 m, 1 GPU": ["--workload", "sensors4", "--steps", "4", "--warmup", "2"]}
         del gm
         torch.cuda.empty_cache()
+        if args.cpu_threads:
+            py += ["--cpu-threads", args.cpu_threads]
         if steps < 10:   # a short run (tests): the legs shorten themselves with it
             for extra in legs.values():
                 if "--steps" in extra:

@@ -62,7 +62,7 @@ def test_the_drivers_command_prints_one_parseable_line_under_4_kb(tmp_path):
     secondary legs shorten themselves with it): the LAST stdout line is the result."""
     detail = tmp_path / "detail.json"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                        "--detail-out", str(detail)], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+                        "--cpu-threads", "1,16", "--detail-out", str(detail)], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     j = _check_line(lines[-1])
