@@ -1049,6 +1049,30 @@ def main():
                                  "integrate_ms_per_step": round(sharded.stats["integrate_s"] / f * 1e3, 3),
                                  "wait_ms_per_step": round(sharded.stats["wait_s"] / f * 1e3, 3),
                                  "note": "this rank's figures; the exchange is hidden behind the next frame unless wait_ms > 0"}})
+        # per-kernel profile of THIS rank's integration (rank 0 only, outside the clock): its delta map 0 over the timed frame
+        # indices, an event pair around every launch -> the dominant kernel and its share of the HBM roof, like at N = 1
+        if rank == 0 and args.profile_frames > 0:
+            try:
+                sharded.flush()
+                gp = dl[0]
+                gp.enable_timing(False)
+                gp.profile(True, reset=True)
+                upd = pts_prof = 0
+                nprof = min(steps, max(4, args.profile_frames))
+                for i in range(warmup, warmup + nprof):
+                    pose, dp, dc, n = d_frames[i % len(d_frames)]
+                    gp.clear_keep_slots()
+                    gp.integrate_device(kind, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), n)
+                    upd += gp.counters()["voxels_touched"]
+                    pts_prof += n
+                gp.profile(False)
+                rows, _ = kernel_table(gp, 1.0)
+                alg_bytes = 16.0 * pts_prof / nprof + 24.0 * upd / nprof
+                dev_ms = sum(r["us_per_step"] for r in rows) / 1e3
+                out["roofline"] = roofline_from(rows, alg_bytes, dev_ms, "16 B x points + 24 B x distinct voxels updated per frame (SURVEY 8(d)), this rank's frames into its per-frame delta map")
+                out["kernels"] = rows[:16]
+            except Exception as e:  # a secondary measurement must never take the line down
+                out["roofline_error"] = repr(e)[:200]
         sharded.close()
         del sharded, pm, dl
         torch.cuda.empty_cache()

@@ -76,3 +76,27 @@ def test_the_drivers_command_prints_one_parseable_line_under_4_kb(tmp_path):
     assert sens["ray_bundles_per_step"] == 4
     full = json.load(open(detail))
     assert full["value"] == j["value"] and "kernels" in full
+
+
+def test_compact_line_of_a_multi_rank_result_and_of_a_failed_leg():
+    """The N > 1 shape (weak scaling, an `exchange` block, configs[4] as the only leg) and a leg that failed: the line keeps
+    the contract's keys, carries the leg's error text in short form and never the traceback."""
+    import bench
+    out = {"metric": "Mpoints/s integrated (640x480 frame, 0.05 m voxels) + achieved HBM GB/s", "unit": "Mpoints/s", "n_gpus": 8,
+           "steps": 20, "warmup": 5, "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "value": 1500.0, "ms_per_step": 1.64, "scaling": "weak",
+           "config": {"workload": "BASELINE configs[1] on every GPU: " + "x" * 400, "points_per_step": 8 * 307200,
+                      "points_per_step_per_gpu": 307200, "voxel_size": 0.05, "voxels_per_side": 16, "world_size_seen": 8,
+                      "semantics": "y" * 500, "parallelism": "z" * 300},
+           "exchange": {"payload_bytes_per_step": 6_000_000, "exchange_ms_per_step": 0.4, "integrate_ms_per_step": 1.5,
+                        "wait_ms_per_step": 0.0, "note": "n" * 300},
+           "other_configs": {"configs[4]": {"error": "Traceback (most recent call last):\n" + "frame\n" * 200}}}
+    text = bench.compact_line(out, "bench_detail.json")
+    assert len(text) < 4096 and "\n" not in text
+    j = json.loads(text)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["value"] == 1500.0
+    assert j["roofline"] is None and j["cpu_baseline"] is None          # ranks > 1 carry neither (rank 0 at N = 1 only)
+    assert j["exchange"]["payload_bytes_per_step"] == 6_000_000
+    assert len(j["config"]["workload"]) <= 160 and "semantics" not in j["config"]
+    leg = j["legs"]["configs[4]"]
+    assert set(leg) == {"error"} and len(leg["error"]) <= 120

@@ -174,6 +174,7 @@ def test_bench_sharded_path_over_rccl_single_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["scaling"] == "weak" and out["value"] > 0 and out["exchange"]["payload_bytes_per_step"] > 0
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["kernel"].startswith("k_")   # rank 0 profiles its own integration at N > 1 too
 
 
 def test_bench_refuses_more_ranks_than_gpus():
