@@ -36,10 +36,11 @@ def model():
     L.eom_update_parallel.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
     L.eom_update_parallel.restype = C.c_long
     L.eom_robot.argtypes = [C.c_void_p, fp]
+    L.eom_check_counts.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     return L
 
 
-def _run(L, n_frames, voxel, sub, kmax, smax, max_iters, env=None, robot=False):
+def _run(L, n_frames, voxel, sub, kmax, smax, max_iters, env=None, robot=False, checks=None):
     sys.path.insert(0, ROOT)
     from voxblox_amd import scenes
     fp = C.POINTER(C.c_float)
@@ -64,6 +65,10 @@ def _run(L, n_frames, voxel, sub, kmax, smax, max_iters, env=None, robot=False):
                 L.eom_robot(h, pos.ctypes.data_as(fp))
             L.eom_update(h, 0)        # the oracle's sequential update on the first ESDF layer
             diffs.append(L.eom_update_parallel(h, kmax, smax, max_iters))
+            if checks is not None:    # EOM_CHECK=1: fixed points refolded in full / inconsistent ones
+                out = (C.c_ulonglong * 2)()
+                L.eom_check_counts(h, out)
+                checks.append((int(out[0]), int(out[1])))
         return diffs
     finally:
         os.environ.pop("EOM_THREADS", None)
@@ -100,3 +105,21 @@ def test_emulated_replay_starts_from_queues_that_hold_robot_sphere_entries(model
     super-step is retried with fewer records (rp_retry_smaller)."""
     e = dict(env, EOM_SPHERES="0.6,1.5")
     assert _run(model, 3, 0.1, 16, 8192, 256, 64, env=e, robot=True) == [0, 0, 0]
+
+
+@pytest.mark.parametrize("caps", [False, True])
+def test_every_fixed_point_is_consistent_for_all_targets(model, caps):
+    """The iteration folds only the targets somebody marked dirty.  EOM_CHECK folds ALL targets once more at every fixed
+    point: nothing in front of the cut may change, i.e. no target was left with a stale order of its events (rankings
+    mark the targets of the records they move: rp_mark_rec_targets).  Also with the capacities that force every early
+    stop."""
+    checks = []
+    env = {"EOM_CHECK": "1"}
+    if caps:
+        env.update(EOM_REC_CAP="2500", EOM_TGT_CAP="2500")
+        d = _run(model, 3, 0.1, 64, 2048, 64, 8, env=env, checks=checks)
+    else:
+        d = _run(model, 3, 0.1, 16, 8192, 256, 64, env=env, checks=checks)
+    assert d == [0, 0, 0]
+    assert sum(r for r, _ in checks) > 20
+    assert [f for _, f in checks] == [0, 0, 0]

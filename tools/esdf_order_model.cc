@@ -59,6 +59,7 @@ class ModelEsdf : public EsdfIntegrator {
   using EsdfIntegrator::EsdfIntegrator;
   Stats st;
   rp::Ctl emul_ctl;
+  uint64_t emul_check_runs = 0, emul_check_failures = 0;   // EOM_CHECK: fixed points refolded in full / found inconsistent (last update)
   bool seq_watch = false;
   LIdx3 seq_watch_g{0, 0, 0};
   bool emul_shuffle = true;
@@ -598,6 +599,7 @@ class ModelEsdf : public EsdfIntegrator {
     Args a{};
     a.hazard = std::getenv("EOM_NO_FILTER") ? nullptr : hazard.data();
     a.c.filter = (uint32_t)g_filter_level;
+    a.c.mark_moved = std::getenv("EOM_NO_MARK_MOVED") ? 0u : 1u;
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;
@@ -646,6 +648,7 @@ class ModelEsdf : public EsdfIntegrator {
 
     uint32_t watch = kNone;
     if (std::getenv("EOM_WATCH")) { int bx, by, bz, lin; std::sscanf(std::getenv("EOM_WATCH"), "%d,%d,%d,%d", &bx, &by, &bz, &lin); watch = slot_of.at(Idx3{bx, by, bz}) * nvox + (uint32_t)lin; }
+    uint64_t check_failures = 0, check_runs = 0;
     std::mt19937 rng(12345);
     std::vector<uint32_t> order;
     c.phase = PH_BEGIN;
@@ -710,10 +713,35 @@ class ModelEsdf : public EsdfIntegrator {
         }
       }
       if (std::getenv("EOM_TRACE2")) std::fprintf(stderr, "phase %u n=%u iter=%u rec=%u tgt=%u\n", c.phase, n, c.iter, c.n_rec, c.n_tgt);
+      const bool was_fold = c.phase == PH_FOLD && c.n_chg == 0 && c.n_born == 0;
+
       if (std::getenv("EOM_TRACE") && c.phase == PH_CLEANUP) std::fprintf(stderr, "superstep b=%u K=%u recs=%u tgts=%u iters=%u cut=%llx commit=%u\n", c.bucket, c.K, c.n_rec, c.a_tgt, c.iter, c.cut, c.n_commit);
       rp_control(a);
+      // EOM_CHECK: at a fixed point (a FOLD phase that changed nothing, the cut is known now) a fold of EVERY target must change
+      // nothing in front of the cut either — a target whose events moved relative to each other without being marked dirty
+      // would show up here
+      if (was_fold && c.phase == PH_COMMIT_FOLD && std::getenv("EOM_CHECK")) {
+        const uint32_t nt = c.n_tgt < a.tgt_cap ? c.n_tgt : a.tgt_cap;
+        for (uint32_t t = 0; t < nt; ++t) rp_fold(a, t, kNever, false);
+        uint32_t bad_chg = 0, bad_born = 0;
+        for (uint32_t k = 0; k < c.n_chg; ++k) {
+          const uint32_t r = a.chg[k];
+          unsigned long long T = a.rec_T[r];
+          if (a.rec_pusher[r] != kNone && (a.rec_meta_n[r] & ~(1u << 18)) != (a.rec_meta[r] & ~(1u << 18))) T = a.rec_T[a.rec_pusher[r]];   // liveness: decided at the pusher's pop
+          if (T < c.cut) ++bad_chg;
+        }
+        for (uint32_t k = 0; k < c.n_born && k < a.rec_cap; ++k) if (a.rec_T[a.born[(size_t)k * 6]] < c.cut) ++bad_born;
+        if (bad_chg || bad_born)
+          std::fprintf(stderr, "[check] superstep %llu b=%u K=%u iter=%u cut=%llx: a full refold at the fixed point changes %u records, bears %u in front of the cut (%u / %u anywhere)\n", c.st_supersteps, c.bucket, c.K, c.iter, c.cut, bad_chg, bad_born, c.n_chg, c.n_born);
+        if (bad_chg || bad_born) ++check_failures;
+        ++check_runs;
+        c.n_chg = c.n_born = 0;
+      }
     }
     if (c.error) std::fprintf(stderr, "EMUL ERROR %u\n", c.error);
+    if (check_runs) std::fprintf(stderr, "[check] %llu fixed points refolded in full, %llu inconsistent\n", (unsigned long long)check_runs, (unsigned long long)check_failures);
+    emul_check_runs = check_runs;
+    emul_check_failures = check_failures;
     st.pops += c.st_pops;
     // back into the layer
     for (size_t sl = 0; sl < blocks.size(); ++sl) {
@@ -885,6 +913,11 @@ void eom_update(void* h, int verbose) {
   }
 }
 // the batched replay on the second ESDF layer, compared with the sequential one voxel by voxel
+void eom_check_counts(void* h, unsigned long long* out) {
+  auto* m = static_cast<Model*>(h);
+  out[0] = m->e2->emul_check_runs;
+  out[1] = m->e2->emul_check_failures;
+}
 void eom_set_mode(void* h, int mode) { static_cast<Model*>(h)->e2->mode = mode; }
 long eom_update_parallel(void* h, size_t kmax, size_t smax, int max_iters) {
   auto* m = static_cast<Model*>(h);

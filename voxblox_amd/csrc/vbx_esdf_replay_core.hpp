@@ -74,6 +74,7 @@ struct Cfg {
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
+  uint32_t mark_moved;   // 1: a ranking marks the targets of every record whose pop time it moved (rp_mark_rec_targets); 0: round 4's behaviour
 };
 
 // control block (device memory, one instance).  Part A is written by rp_control only (every workgroup reads it at
@@ -715,6 +716,18 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
   rp_place(a, r, a.rec_base[pusher], gid, p, __uint_as_float(a.born[(size_t)j * 6 + 4]), a.born[(size_t)j * 6 + 5]);
 }
 
+// A ranking that moves a record's pop time changes the ORDER of the events on the targets that record talks to.  PH_APPLY
+// marks the targets of the records whose state or liveness changed; the records behind them in the excursion move with
+// them, and when one of those overtakes a record of its own excursion on a target both talk to (a child that changed
+// its bucket takes its descendants along), or stops popping because the ranking now ends in front of it (smax, a poisoned
+// record), nobody told that target.  Found with the emulation's EOM_CHECK (tools/esdf_order_model.cc: at every fixed point
+// ALL targets are folded once more and must not change anything in front of the cut): one super-step of the first frame
+// of the configs[3] stream — 1 of 2 187 fixed points in six frames — was not consistent; the layer still came out right
+// (the missed event did not change the voxel), with this marking all are consistent.  6 % more folds.
+RP_FN void rp_mark_rec_targets(const Args& a, uint32_t r) {
+  for (uint32_t p = 0; p < 27; ++p) rp_mark_dirty(a, a.rec_tgts[(size_t)r * 27 + p]);
+}
+
 // pop times of the excursion of base record `base`: the reference's queue discipline (lowest bucket first, FIFO
 // inside, bucket_queue.h:58-80) over the live excursion records; children enter in LUT order when their pusher pops
 RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
@@ -730,7 +743,8 @@ RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
   }
   uint32_t* list = a.sub_list + (size_t)(slot - 1) * a.c.smax;
   unsigned long long* q = a.sim_q + (size_t)(slot - 1) * a.c.smax;   // pending entries: record | next entry << 32
-  for (uint32_t k = 0; k < a.sub_n[base]; ++k) a.rec_T[list[k]] = kNever;
+  const uint32_t old_n = a.sub_n[base];
+  for (uint32_t k = 0; k < old_n; ++k) a.rec_T[list[k]] = kNever;
   // one FIFO per bucket below b, linked through q; lowest = a lower bound of the lowest non-empty bucket
   unsigned short head[kMaxBuckets + 1], tail[kMaxBuckets + 1];
   const int nb = (int)c.bucket;
@@ -765,9 +779,16 @@ RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
     if (rank >= a.c.smax - 1 || a.rec_poison[r]) { truncated = true; atomicAdd(&c.st_trunc_rank, 1ull); break; }
     ++rank;
     a.rec_T[r] = ((unsigned long long)base << kRankBits) | rank;
+    if (a.c.mark_moved && (rank - 1 >= old_n || list[rank - 1] != r)) {
+      // its pop time moved (or it pops for the first time, or again): the targets it talks to fold again
+      rp_mark_rec_targets(a, r);
+      if (rank - 1 < old_n) rp_mark_rec_targets(a, list[rank - 1]);   // (the record that had this rank: it moves, or it does not pop any more)
+    }
     list[rank - 1] = r;
     cur = r;
   }
+  if (a.c.mark_moved)
+    for (uint32_t k = rank; k < old_n; ++k) rp_mark_rec_targets(a, list[k]);   // ranked before, not now (or marked already)
   a.sub_n[base] = rank;
   // an excursion that does not fit stops the super-step behind its last ranked record
   if (truncated) atomicMin(&c.smax_cut, ((unsigned long long)base << kRankBits) | (rank + 1));

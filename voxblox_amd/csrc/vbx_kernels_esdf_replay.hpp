@@ -550,7 +550,11 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   __syncthreads();
   for (uint32_t j = tid; j < n; j += kRpThreads) {
     const uint32_t rk = L.rank[j];
-    a.rec_T[mem[j]] = rk == 0xFFFF ? rp::kNever : (((unsigned long long)base << rp::kRankBits) | rk);
+    const uint32_t r = mem[j];
+    const unsigned long long Tn = rk == 0xFFFF ? rp::kNever : (((unsigned long long)base << rp::kRankBits) | rk);
+    // a pop time that moved reorders the events of the targets the record talks to (rp_mark_rec_targets)
+    if (a.c.mark_moved && a.rec_T[r] != Tn) rp::rp_mark_rec_targets(a, r);
+    a.rec_T[r] = Tn;
   }
   if (tid == 0) {
     a.sub_dirty[base] = 0;
