@@ -600,6 +600,7 @@ class ModelEsdf : public EsdfIntegrator {
     a.hazard = std::getenv("EOM_NO_FILTER") ? nullptr : hazard.data();
     a.c.filter = (uint32_t)g_filter_level;
     a.c.mark_moved = std::getenv("EOM_NO_MARK_MOVED") ? 0u : 1u;
+    a.c.fold_all = std::getenv("EOM_NO_FOLD_ALL") ? 0u : 1u;
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;

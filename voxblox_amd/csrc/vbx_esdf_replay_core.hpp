@@ -74,6 +74,7 @@ struct Cfg {
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
+  uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
   uint32_t mark_moved;   // 1: a ranking marks the targets of every record whose pop time it moved (rp_mark_rec_targets); 0: round 4's behaviour
 };
 
@@ -88,6 +89,7 @@ struct Ctl {
   uint32_t raise;                            // 1: the super-step pops raise_ (queue num_buckets) instead of a bucket of open_
   uint32_t n_rec, iter;
   uint32_t read;                             // dirty target lists: FOLD reads list `read`, marks go to 1 - read
+  uint32_t fold_all;                         // 1: the FOLD phase that follows PH_PLACE_BASE folds targets 0 .. n_threads - 1 (no list: PLACE_BASE does not mark)
   uint32_t a_chg, a_born, a_tgt;             // copies of n_chg / n_born / n_tgt as the last phase left them
   uint32_t cap_stop;                         // 1: the records (or their list) are full — no births any more, the super-step commits what stands
   unsigned long long cut;
@@ -265,8 +267,11 @@ RP_FN uint32_t rp_meta(uint32_t lut, uint32_t bucket, bool live) { return lut | 
 
 RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
   if (t >= kSkip) return;
+  Ctl& c = *a.ctl;
+  // every target PH_PLACE_BASE touches is new and will be folded: no flag, no list entry (a flag and a slot of one shared
+  // counter per placement — tens of thousands of atomics on one cache line in a super-step of 16 k base records)
+  if (c.phase == PH_PLACE_BASE && a.c.fold_all) return;
   if (atomicExch(&a.tgt_dirty[t], 1u) == 0u) {
-    Ctl& c = *a.ctl;
     const uint32_t w = 1u - c.read;
     const uint32_t k = RP_INC(&c.n_dirty[w]);
     a.dl[w][k] = t;   // k < tgt_cap: a target is listed at most once per list
@@ -625,7 +630,7 @@ RP_FN void rp_phase_place_base(const Args& a, uint32_t tid) {
 RP_FN void rp_phase_fold(const Args& a, uint32_t tid) {
   Ctl& c = *a.ctl;
   if (tid >= c.n_threads) return;
-  const uint32_t t = a.dl[c.read][tid];
+  const uint32_t t = c.fold_all ? tid : a.dl[c.read][tid];
   a.tgt_dirty[t] = 0;
   rp_fold(a, t, kNever, false);
 }
@@ -1033,6 +1038,12 @@ RP_FN void rp_control(const Args& a) {
       ++c.iter;
       ++c.st_iters;
       c.n_threads = RP_LD(c.n_dirty[c.read]);
+      c.fold_all = 0;
+      if (c.phase == PH_PLACE_BASE && a.c.fold_all) {
+        c.fold_all = 1;
+        c.n_threads = RP_LD(c.n_tgt);
+        if (c.n_threads > a.tgt_cap) c.n_threads = a.tgt_cap;
+      }
       c.st_folds += c.n_threads;
       c.phase = PH_FOLD;
       break;

@@ -525,6 +525,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.nbslot = ctx->rp_nbslot.as<uint32_t>();
   a.hazard = ctx->rp_hazard.as<uint8_t>();
   a.c.filter = rp_env_u32("VBX_RP_FILTER", 3);
+  a.c.fold_all = rp_env_u32("VBX_RP_FOLD_ALL", 1);       // (0: PH_PLACE_BASE fills the dirty list like every other phase)
   a.c.mark_moved = rp_env_u32("VBX_RP_MARK_MOVED", 1);   // (0: rankings do not mark the targets of the records they moved — rounds 4 / 5a)
   a.blk_dirty = m.blk_flags;
   a.dirty_bit = kFlagEsdfDirty;

@@ -375,7 +375,8 @@ struct SimLds {
   uint32_t pend_key[kSimMax];                 // pending records at the restart point: bucket << 24 | pusher rank << 5 | lut
   unsigned short pend_j[kSimMax], sorted[kSimMax];
   unsigned short head[rp::kMaxBuckets + 1], tail[rp::kMaxBuckets + 1];
-  uint32_t n_pend, flag_rank, n_ranked, truncated;
+  unsigned short moved[kSimMax];              // members whose pop time this ranking moved
+  uint32_t n_pend, flag_rank, n_ranked, truncated, n_moved;
 };
 __device__ inline void rp_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -548,14 +549,20 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     L.truncated = truncated ? 1u : 0u;
   }
   __syncthreads();
+  if (tid == 0) L.n_moved = 0;
+  __syncthreads();
   for (uint32_t j = tid; j < n; j += kRpThreads) {
     const uint32_t rk = L.rank[j];
     const uint32_t r = mem[j];
     const unsigned long long Tn = rk == 0xFFFF ? rp::kNever : (((unsigned long long)base << rp::kRankBits) | rk);
-    // a pop time that moved reorders the events of the targets the record talks to (rp_mark_rec_targets)
-    if (a.c.mark_moved && a.rec_T[r] != Tn) rp::rp_mark_rec_targets(a, r);
+    // a pop time that moved reorders the events of the targets the record talks to (rp::rp_mark_rec_targets)
+    if (a.c.mark_moved && a.rec_T[r] != Tn) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;
     a.rec_T[r] = Tn;
   }
+  __syncthreads();
+  // one (moved record, target) pair per thread: 27 dependent atomics in a row on one lane would be most of a small ranking's time
+  for (uint32_t i = tid; i < L.n_moved * 27u; i += kRpThreads)
+    rp::rp_mark_dirty(a, a.rec_tgts[(size_t)mem[L.moved[i / 27u]] * 27 + i % 27u]);
   if (tid == 0) {
     a.sub_dirty[base] = 0;
     a.sub_restart[base] = rp::kNone;
@@ -713,7 +720,7 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
     const int lane = threadIdx.x & 63;
     for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves) {
       if (phase == rp::PH_FOLD) {
-        const uint32_t t = a.dl[c.read][w];
+        const uint32_t t = c.fold_all ? w : a.dl[c.read][w];
         if (lane == 0) a.tgt_dirty[t] = 0;
         rp_fold_wave(a, t, rp::kNever, false, lane);
       } else {
