@@ -601,6 +601,7 @@ class ModelEsdf : public EsdfIntegrator {
     a.c.filter = (uint32_t)g_filter_level;
     a.c.mark_moved = std::getenv("EOM_NO_MARK_MOVED") ? 0u : 1u;
     a.c.fold_all = std::getenv("EOM_NO_FOLD_ALL") ? 0u : 1u;
+    a.c.tgt_claim = std::getenv("EOM_NO_TGT_CLAIM") ? 0u : 1u;
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;
@@ -646,6 +647,8 @@ class ModelEsdf : public EsdfIntegrator {
     a.chg = chg.data(); a.born = born.data(); a.cp = cp.data(); a.sd_list = sd_list.data(); a.sub_dirty = sub_dirty.data(); a.sub_n = sub_n.data();
     a.sub_slot = sub_slot.data(); a.sub_list = sub_list.data(); a.sub_slots_used = &sub_slots_used; a.sim_q = sim_q.data(); a.sub_slots_cap = sub_slots_cap;
     a.ord = ord.data(); a.off0 = off0.data();
+    std::vector<uint32_t> rec_born_it(rec_cap);
+    a.rec_born_it = std::getenv("EOM_NO_BORN_IT") ? nullptr : rec_born_it.data();
 
     uint32_t watch = kNone;
     if (std::getenv("EOM_WATCH")) { int bx, by, bz, lin; std::sscanf(std::getenv("EOM_WATCH"), "%d,%d,%d,%d", &bx, &by, &bz, &lin); watch = slot_of.at(Idx3{bx, by, bz}) * nvox + (uint32_t)lin; }

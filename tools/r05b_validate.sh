@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round 5, last GPU call (through gpurun, from the repo root): the full GPU suite at HEAD, the reference-order ESDF timed with
-# and without the two changes of this session (VBX_RP_MARK_MOVED, VBX_RP_FOLD_ALL), its phase counters, and the driver's
+# and without the two changes of this session (VBX_RP_MARK_MOVED, VBX_RP_FOLD_ALL, VBX_RP_TGT_CLAIM), its phase counters, and the driver's
 # command.  Everything lands in gpurun_out/r05b/.
 export TMPDIR=/tmp
-O=gpurun_out/r05b
+O=gpurun_out/${1:-r05b}
 mkdir -p $O
 timeout 700 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "rc=$?" >> $O/gpu_tests.log
-for v in "1 1" "0 0" "1 0" "0 1"; do
+for v in "1 1 1" "1 1 0" "0 0 0" "0 1 1"; do
   set -- $v
-  VBX_RP_MARK_MOVED=$1 VBX_RP_FOLD_ALL=$2 timeout 120 python tools/time_esdf_strict.py 14 > $O/esdf_time_mark$1_all$2.log 2>&1
+  VBX_RP_MARK_MOVED=$1 VBX_RP_FOLD_ALL=$2 VBX_RP_TGT_CLAIM=$3 timeout 120 python tools/time_esdf_strict.py 14 > $O/esdf_time_mark$1_all$2_claim$3.log 2>&1
 done
 VBX_RP_STATS=1 timeout 120 python tools/time_esdf_strict.py 12 > $O/esdf_ref_order_phases.txt 2>&1
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-threads 1,16 --detail-out $O/bench_detail.json > $O/bench_line.json 2> $O/bench_err.log

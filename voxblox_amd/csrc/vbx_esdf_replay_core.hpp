@@ -74,6 +74,7 @@ struct Cfg {
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
+  uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
   uint32_t mark_moved;   // 1: a ranking marks the targets of every record whose pop time it moved (rp_mark_rec_targets); 0: round 4's behaviour
 };
@@ -151,6 +152,8 @@ struct Args {
   uint32_t* rec_kid;        // [rec][26]: excursion record + 1 spawned by this record's push to LUT neighbour k
   uint32_t* rec_tgts;       // [rec][27]: targets of the 26 neighbours and (26) of the voxel itself
   uint32_t* rec_push;       // [rec][26] bytes packed in 7 words: bucket + 1 of the committed push to neighbour k
+  uint32_t* rec_born_it;    // (may be null) low word of Ctl::st_iters when PH_APPLY made the record: the ranking of that very iteration need not
+                            // mark its targets (rp_place just did)
   // targets
   uint32_t tgt_cap;
   uint32_t* vox2tgt;        // [pool voxels]: target + 1
@@ -279,11 +282,38 @@ RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
 }
 
 // the target of voxel gid (created on first use)
+//
+// Cfg::tgt_claim: the voxel is CLAIMED first (vox2tgt 0 -> kBusyTgt), only the claimant takes an id, writes it over the claim,
+// and whoever finds the claim looks again until the id is there.  The records of a super-step are neighbours of each other:
+// up to 27 lanes want the same new target at the same moment, and when each of them took an id before trying to publish it
+// (rounds 4 / 5a, tgt_claim = 0) more than half of all ids ended as holes — 1.14 M ids for 0.5 M targets per update of the
+// configs[3] stream — which every thread-per-target phase (first fold, commit fold, raise fold, clean-up) then walks.  Inside a
+// wave the claimant's branch runs to its end before the loop goes round again, so nobody waits for a lane that cannot move;
+// a wait that does not end (kTgtSpin looks) gives the target up like a full pool does (the record is poisoned).
+constexpr uint32_t kBusyTgt = 0xFFFFFFFFu;
+constexpr uint32_t kTgtSpin = 1u << 14;
 RP_FN uint32_t rp_target(const Args& a, uint32_t gid) {
   Ctl& c = *a.ctl;
   const uint32_t v = a.vox2tgt[gid];
-  if (v != 0u) return v - 1u;
+  if (v != 0u && v != kBusyTgt) return v - 1u;
   if (c.n_tgt >= a.tgt_cap) return kNone;   // (racy look, the exact test follows; keeps the counter from running away)
+  if (a.c.tgt_claim) {
+    for (uint32_t spin = 0; spin < kTgtSpin; ++spin) {
+      const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, kBusyTgt);
+      if (old == 0u) {
+        const uint32_t id = RP_INC(&c.n_tgt);
+        if (id >= a.tgt_cap) {
+          atomicExch(&a.vox2tgt[gid], 0u);
+          return kNone;
+        }
+        a.tgt_gid[id] = gid;
+        atomicExch(&a.vox2tgt[gid], id + 1u);
+        return id;
+      }
+      if (old != kBusyTgt) return old - 1u;
+    }
+    return kNone;
+  }
   const uint32_t id = RP_INC(&c.n_tgt);
   if (id >= a.tgt_cap) return kNone;
   const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, id + 1u);
@@ -697,6 +727,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     a.rec_d_n[r] = a.rec_d[r];
     a.rec_s_n[r] = a.rec_s[r];
     a.rec_kid[(size_t)pusher * 26 + lut] = r + 1;
+    if (a.rec_born_it) a.rec_born_it[r] = (uint32_t)c.st_iters;
     a.cp[RP_INC(&c.n_cp)] = pusher;
     rp_mark_sub_dirty(a, pusher);
     if (a.sub_mem) {
@@ -729,7 +760,13 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
 // ALL targets are folded once more and must not change anything in front of the cut): one super-step of the first frame
 // of the configs[3] stream — 1 of 2 187 fixed points in six frames — was not consistent; the layer still came out right
 // (the missed event did not change the voxel), with this marking all are consistent.  6 % more folds.
+// does a ranking of this iteration have to mark r's targets when it moves r's pop time?  Not those of a record PH_APPLY made in this
+// very iteration: every one of them is in the dirty list already
+RP_FN bool rp_moved_needs_mark(const Args& a, uint32_t r) {
+  return !(a.rec_born_it && a.rec_born_it[r] == (uint32_t)a.ctl->st_iters && a.rec_pusher[r] != kNone);
+}
 RP_FN void rp_mark_rec_targets(const Args& a, uint32_t r) {
+  if (!rp_moved_needs_mark(a, r)) return;
   for (uint32_t p = 0; p < 27; ++p) rp_mark_dirty(a, a.rec_tgts[(size_t)r * 27 + p]);
 }
 

@@ -448,7 +448,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   HIP_TRY(ctx->rp_hazard.ensure((size_t)std::max<uint32_t>(used, 1) * m.nvox));
   HIP_TRY(ctx->rp_chunk_tab.ensure((size_t)(num_buckets + 1) * n_chunks * 4));
   if (fresh || ctx->rp_rec_cap != rec_cap || ctx->rp_tgt_cap != tgt_cap || ctx->rp_smax != smax) {
-    HIP_TRY(ctx->rp_rec_u32.ensure((size_t)rec_cap * 4 * 10));
+    HIP_TRY(ctx->rp_rec_u32.ensure((size_t)rec_cap * 4 * 11));
     HIP_TRY(ctx->rp_rec_T.ensure((size_t)rec_cap * 8));
     HIP_TRY(ctx->rp_rec_kid.ensure((size_t)rec_cap * 26 * 4));
     HIP_TRY(ctx->rp_rec_tgts.ensure((size_t)rec_cap * 27 * 4));
@@ -464,7 +464,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(ctx->rp_ord.ensure((size_t)rec_cap * 4));
 
     // what the phases expect to be zero between super-steps
-    HIP_TRY(hipMemsetAsync(ctx->rp_rec_u32.p, 0, (size_t)rec_cap * 4 * 10, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_rec_u32.p, 0, (size_t)rec_cap * 4 * 11, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_kid.p, 0, (size_t)rec_cap * 26 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_push.p, 0, (size_t)rec_cap * 7 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0, (size_t)tgt_cap * 4 * 3, s));
@@ -525,6 +525,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.nbslot = ctx->rp_nbslot.as<uint32_t>();
   a.hazard = ctx->rp_hazard.as<uint8_t>();
   a.c.filter = rp_env_u32("VBX_RP_FILTER", 3);
+  a.c.tgt_claim = rp_env_u32("VBX_RP_TGT_CLAIM", 1);     // (0: a target id is taken before the voxel is known to be free: lost races leave holes)
   a.c.fold_all = rp_env_u32("VBX_RP_FOLD_ALL", 1);       // (0: PH_PLACE_BASE fills the dirty list like every other phase)
   a.c.mark_moved = rp_env_u32("VBX_RP_MARK_MOVED", 1);   // (0: rankings do not mark the targets of the records they moved — rounds 4 / 5a)
   a.blk_dirty = m.blk_flags;
@@ -540,6 +541,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.rec_vox = ru; a.rec_pusher = ru + (size_t)R; a.rec_base = ru + (size_t)2 * R; a.rec_meta = ru + (size_t)3 * R;
   a.rec_meta_n = ru + (size_t)4 * R; a.rec_poison = ru + (size_t)5 * R; a.rec_s = ru + (size_t)6 * R; a.rec_s_n = ru + (size_t)7 * R;
   a.rec_d = reinterpret_cast<float*>(ru + (size_t)8 * R); a.rec_d_n = reinterpret_cast<float*>(ru + (size_t)9 * R);
+  a.rec_born_it = ru + (size_t)10 * R;
   a.rec_T = ctx->rp_rec_T.as<unsigned long long>();
   a.rec_kid = ctx->rp_rec_kid.as<uint32_t>();
   a.rec_tgts = ctx->rp_rec_tgts.as<uint32_t>();

@@ -556,7 +556,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     const uint32_t r = mem[j];
     const unsigned long long Tn = rk == 0xFFFF ? rp::kNever : (((unsigned long long)base << rp::kRankBits) | rk);
     // a pop time that moved reorders the events of the targets the record talks to (rp::rp_mark_rec_targets)
-    if (a.c.mark_moved && a.rec_T[r] != Tn) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;
+    if (a.c.mark_moved && a.rec_T[r] != Tn && rp::rp_moved_needs_mark(a, r)) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;
     a.rec_T[r] = Tn;
   }
   __syncthreads();
