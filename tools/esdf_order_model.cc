@@ -601,6 +601,8 @@ class ModelEsdf : public EsdfIntegrator {
     a.c.filter = (uint32_t)g_filter_level;
     a.c.mark_moved = std::getenv("EOM_NO_MARK_MOVED") ? 0u : 1u;
     a.c.fold_all = std::getenv("EOM_NO_FOLD_ALL") ? 0u : 1u;
+    a.c.ev = std::getenv("EOM_EV") ? (uint32_t)std::atoi(std::getenv("EOM_EV")) : 256u;
+    if (a.c.ev > kEvMax) a.c.ev = kEvMax;
     a.c.tgt_claim = std::getenv("EOM_NO_TGT_CLAIM") ? 0u : 1u;
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
@@ -636,7 +638,7 @@ class ModelEsdf : public EsdfIntegrator {
     a.rec_vox = rec_vox.data(); a.rec_pusher = rec_pusher.data(); a.rec_base = rec_base.data(); a.rec_meta = rec_meta.data();
     a.rec_meta_n = rec_meta_n.data(); a.rec_poison = rec_poison.data(); a.rec_T = rec_T.data(); a.rec_d = rec_d.data(); a.rec_d_n = rec_d_n.data();
     a.rec_s = rec_s.data(); a.rec_s_n = rec_s_n.data(); a.rec_kid = rec_kid.data(); a.rec_tgts = rec_tgts.data(); a.rec_push = rec_push.data();
-    std::vector<uint32_t> vox2tgt(nv), tgt_gid(tgt_cap), tgt_cnt(tgt_cap), tgt_ev((size_t)tgt_cap * kEv), tgt_dirty(tgt_cap), dl0(tgt_cap), dl1(tgt_cap);
+    std::vector<uint32_t> vox2tgt(nv), tgt_gid(tgt_cap), tgt_cnt(tgt_cap), tgt_ev((size_t)tgt_cap * kEvMax), tgt_dirty(tgt_cap), dl0(tgt_cap), dl1(tgt_cap);
     a.vox2tgt = vox2tgt.data(); a.tgt_gid = tgt_gid.data(); a.tgt_cnt = tgt_cnt.data(); a.tgt_ev = tgt_ev.data(); a.tgt_dirty = tgt_dirty.data();
     a.dl[0] = dl0.data(); a.dl[1] = dl1.data();
     std::vector<uint32_t> chg(rec_cap), born((size_t)rec_cap * 6), cp(rec_cap * 2), sd_list(a.c.kmax), sub_dirty(a.c.kmax), sub_n(a.c.kmax), sub_slot(a.c.kmax);
@@ -698,8 +700,8 @@ class ModelEsdf : public EsdfIntegrator {
         if (c.phase == PH_COMMIT_FOLD && a.vox2tgt[watch]) {
           const uint32_t t = a.vox2tgt[watch] - 1;
           std::fprintf(stderr, "[watch] commit of superstep %llu: target %u events %u\n", c.st_supersteps, t, a.tgt_cnt[t]);
-          for (uint32_t k = 0; k < a.tgt_cnt[t] && k < kEv; ++k) {
-            const uint32_t code = a.tgt_ev[(size_t)t * kEv + k], r = code >> 5, lut = code & 31;
+          for (uint32_t k = 0; k < a.tgt_cnt[t] && k < a.c.ev; ++k) {
+            const uint32_t code = a.tgt_ev[(size_t)t * a.c.ev + k], r = code >> 5, lut = code & 31;
             uint32_t pv = lut < 26 ? ((a.rec_push[r * 7 + lut / 4] >> ((lut % 4) * 8)) & 0xFF) : 0;
             const uint32_t rg = a.rec_vox[r];
             const Idx3 rb = blocks[rg / nvox];

@@ -6,11 +6,10 @@ export TMPDIR=/tmp
 O=gpurun_out/${1:-r05b}
 mkdir -p $O
 timeout 700 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "rc=$?" >> $O/gpu_tests.log
-for v in "1 1 1" "1 1 0" "0 0 0" "0 1 1"; do
-  set -- $v
-  VBX_RP_MARK_MOVED=$1 VBX_RP_FOLD_ALL=$2 VBX_RP_TGT_CLAIM=$3 timeout 120 python tools/time_esdf_strict.py 14 > $O/esdf_time_mark$1_all$2_claim$3.log 2>&1
+for ev in 256 128; do
+  VBX_RP_EV=$ev timeout 120 python tools/time_esdf_strict.py 14 > $O/esdf_time_ev$ev.log 2>&1
 done
 VBX_RP_STATS=1 timeout 120 python tools/time_esdf_strict.py 12 > $O/esdf_ref_order_phases.txt 2>&1
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-threads 1,16 --detail-out $O/bench_detail.json > $O/bench_line.json 2> $O/bench_err.log
 echo "bench rc=$?" >> $O/gpu_tests.log
-tail -3 $O/gpu_tests.log; for f in $O/esdf_time_*.log; do echo $f; tail -1 $f; done; wc -c $O/bench_line.json
+tail -3 $O/gpu_tests.log; for f in $O/esdf_time_*.log; do echo $f; grep 'frame 0 ' $f; tail -1 $f; done; wc -c $O/bench_line.json

@@ -40,7 +40,11 @@ constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
-constexpr uint32_t kEv = 128;              // events a target can hold
+#ifndef RP_EVQ
+#define RP_EVQ 4
+#endif
+constexpr uint32_t kEvQ = RP_EVQ;          // events of a target one lane of the wave-per-target fold holds
+constexpr uint32_t kEvMax = 64 * kEvQ;     // most events a target can hold (Cfg::ev <= this: the capacity in use, and the stride of tgt_ev)
 constexpr uint32_t kOwn = 31;              // event code of a record's own pop (LUT indices are 0..25)
 constexpr unsigned long long kNever = ~0ull;
 constexpr uint32_t kRankBits = 24;
@@ -73,6 +77,7 @@ struct Cfg {
   float max_distance, min_diff, voxel_size, default_distance;
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
+  uint32_t ev;       // events a target can hold (<= kEvMax); a record whose event does not fit is poisoned and the super-step ends in front of it
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
@@ -159,7 +164,7 @@ struct Args {
   uint32_t* vox2tgt;        // [pool voxels]: target + 1
   uint32_t* tgt_gid;
   uint32_t* tgt_cnt;
-  uint32_t* tgt_ev;         // [tgt][kEv]: record << 5 | code
+  uint32_t* tgt_ev;         // [tgt][Cfg::ev]: record << 5 | code
   uint32_t* tgt_dirty;
   uint32_t* dl[2];          // dirty target lists
   // per-iteration lists
@@ -361,9 +366,9 @@ RP_FN void rp_place(const Args& a, uint32_t r, uint32_t base, uint32_t gid, uint
   }
   a.rec_tgts[(size_t)r * 27 + p] = t;
   if (ngid == kNone) return;
-  const uint32_t k = t == kNone ? kEv : atomicAdd(&a.tgt_cnt[t], 1u);   // (no target to be had: as if its list were full)
-  if (k < kEv) {
-    a.tgt_ev[(size_t)t * kEv + k] = (r << 5) | (p == 26 ? kOwn : p);
+  const uint32_t k = t == kNone ? a.c.ev : atomicAdd(&a.tgt_cnt[t], 1u);   // (no target to be had: as if its list were full)
+  if (k < a.c.ev) {
+    a.tgt_ev[(size_t)t * a.c.ev + k] = (r << 5) | (p == 26 ? kOwn : p);
   } else if (atomicExch(&a.rec_poison[r], 1u) == 0u) {
     // the target cannot hear this record: the record must stay out of the super-step.  A base record stops the
     // super-step in front of itself; an excursion record that has a rank already (its offer is placed late, after its
@@ -432,11 +437,11 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
   if (gid == kNone) return;
   const int b = (int)c.bucket;
   uint32_t n_all = a.tgt_cnt[t];
-  if (n_all > kEv) n_all = kEv;
-  FoldEv ev[kEv];
+  if (n_all > a.c.ev) n_all = a.c.ev;
+  FoldEv ev[kEvMax];
   uint32_t n = 0;
   for (uint32_t k = 0; k < n_all; ++k) {
-    const uint32_t code = a.tgt_ev[(size_t)t * kEv + k];
+    const uint32_t code = a.tgt_ev[(size_t)t * a.c.ev + k];
     const uint32_t r = code >> 5;
     const uint32_t m = a.rec_meta[r];
     const unsigned long long T = a.rec_T[r];
@@ -515,7 +520,7 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
   }
   // ---- outputs of an iteration
   for (uint32_t k = 0; k < n_all; ++k) {
-    const uint32_t code = a.tgt_ev[(size_t)t * kEv + k];
+    const uint32_t code = a.tgt_ev[(size_t)t * a.c.ev + k];
     if ((code & 31) != kOwn) continue;
     const uint32_t r = code >> 5;
     const uint32_t m = a.rec_meta[r];
@@ -596,11 +601,11 @@ RP_FN void rp_fold_raise(const Args& a, uint32_t t) {
   const uint32_t gid = a.tgt_gid[t];
   if (gid == kNone) return;
   uint32_t n_all = a.tgt_cnt[t];
-  if (n_all > kEv) n_all = kEv;
-  FoldEv ev[kEv];
+  if (n_all > a.c.ev) n_all = a.c.ev;
+  FoldEv ev[kEvMax];
   uint32_t n = 0;
   for (uint32_t k = 0; k < n_all; ++k) {
-    const uint32_t code = a.tgt_ev[(size_t)t * kEv + k];
+    const uint32_t code = a.tgt_ev[(size_t)t * a.c.ev + k];
     if ((code & 31) == kOwn) continue;
     const unsigned long long T = a.rec_T[code >> 5];
     if (!(T < c.cut)) continue;   // (records behind an event-list overflow wait for the next super-step)

@@ -454,7 +454,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(ctx->rp_rec_tgts.ensure((size_t)rec_cap * 27 * 4));
     HIP_TRY(ctx->rp_rec_push.ensure((size_t)rec_cap * 7 * 4));
     HIP_TRY(ctx->rp_tgt_u32.ensure((size_t)tgt_cap * 4 * 3));
-    HIP_TRY(ctx->rp_tgt_ev.ensure((size_t)tgt_cap * rp::kEv * 4));
+    HIP_TRY(ctx->rp_tgt_ev.ensure((size_t)tgt_cap * rp::kEvMax * 4));   // (sized for the largest Cfg::ev)
     HIP_TRY(ctx->rp_dl.ensure((size_t)tgt_cap * 4 * 2));
     HIP_TRY(ctx->rp_lists.ensure((size_t)rec_cap * 4 * (1 + 6 + 2) + (size_t)kmax * 4));
     HIP_TRY(ctx->rp_sub.ensure((size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4));
@@ -525,6 +525,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.nbslot = ctx->rp_nbslot.as<uint32_t>();
   a.hazard = ctx->rp_hazard.as<uint8_t>();
   a.c.filter = rp_env_u32("VBX_RP_FILTER", 3);
+  a.c.ev = std::min<uint32_t>(std::max<uint32_t>(rp_env_u32("VBX_RP_EV", 256), 32), rp::kEvMax);   // events per target (128 until round 5a)
   a.c.tgt_claim = rp_env_u32("VBX_RP_TGT_CLAIM", 1);     // (0: a target id is taken before the voxel is known to be free: lost races leave holes)
   a.c.fold_all = rp_env_u32("VBX_RP_FOLD_ALL", 1);       // (0: PH_PLACE_BASE fills the dirty list like every other phase)
   a.c.mark_moved = rp_env_u32("VBX_RP_MARK_MOVED", 1);   // (0: rankings do not mark the targets of the records they moved — rounds 4 / 5a)

@@ -99,32 +99,36 @@ __device__ inline void rp_run_phase(const rp::Args& a, uint32_t phase, uint32_t 
   }
 }
 
-// rp_fold (vbx_esdf_replay_core.hpp, the form the CPU emulation runs) as ONE WAVE per target: a lane holds up to two of
-// the target's events with their records' pop times and pop-time states, the order of the events is a rank computed by
+// rp_fold (vbx_esdf_replay_core.hpp, the form the CPU emulation runs) as ONE WAVE per target: a lane holds up to kEvQ of
+// the target's events (only the slots a target's list reaches are looked at: most lists have fewer than 64 entries) with their records' pop times and pop-time states, the order of the events is a rank computed by
 // comparing pop times across lanes, and the replay itself — inherently sequential, event by event — runs wave-uniformly
 // on broadcast values.  A thread-per-target fold kept its event list in scratch memory and a target of a crowded
 // neighbourhood (a hundred events) cost milliseconds of dependent scratch round trips; the launch waits for its
 // slowest target.
 __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long long limit, bool commit, int lane) {
   using namespace rp;
+  constexpr int Q = (int)kEvQ;     // events per lane: event e of the target lives in lane e % 64, slot e / 64
   Ctl& c = *a.ctl;
   const uint32_t gid = a.tgt_gid[t];
   if (gid == kNone) return;
   const int b = (int)c.bucket;
   uint32_t n_all = a.tgt_cnt[t];
-  if (n_all > kEv) n_all = kEv;
+  if (n_all > a.c.ev) n_all = a.c.ev;
+  const int slots = (int)((n_all + 63u) >> 6);   // slots in use (wave-uniform)
   const float d0 = a.dist[gid];          // (issued with the event loads, used after the ranking)
   const uint32_t s0 = a.state[gid];
-  uint32_t code[2] = {0, 0}, es[2] = {0, 0}, emeta[2] = {0, 0};
-  unsigned long long eT[2] = {kNever, kNever};
-  float ed[2] = {0.f, 0.f};
-  bool valid[2] = {false, false}, have[2] = {false, false}, epoison[2] = {false, false};
+  uint32_t code[Q], es[Q], emeta[Q];
+  unsigned long long eT[Q];
+  float ed[Q];
+  bool valid[Q], have[Q], epoison[Q];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < Q; ++q) {
+    code[q] = 0; es[q] = 0; emeta[q] = 0; eT[q] = kNever; ed[q] = 0.f;
+    valid[q] = false; have[q] = false; epoison[q] = false;
     const uint32_t e = (uint32_t)lane + 64u * q;
     if (e < n_all) {
       have[q] = true;
-      code[q] = a.tgt_ev[(size_t)t * kEv + e];
+      code[q] = a.tgt_ev[(size_t)t * a.c.ev + e];
       const uint32_t r = code[q] >> 5;
       emeta[q] = a.rec_meta[r];
       eT[q] = a.rec_T[r];
@@ -135,19 +139,23 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     }
   }
   // rank of every valid event = valid events with a smaller pop time (pop times of valid events are distinct)
-  uint32_t rank[2] = {0, 0};
-  const int slots = n_all > 64 ? 2 : 1;
-  for (int q2 = 0; q2 < slots; ++q2) {
+  uint32_t rank[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) rank[q] = 0;
+  uint32_t n = 0;
+#pragma unroll
+  for (int q2 = 0; q2 < Q; ++q2) {
+    if (q2 >= slots) break;
     unsigned long long vm = __ballot(valid[q2]);
+    n += (uint32_t)__popcll(vm);
     while (vm) {
       const int k = __ffsll((long long)vm) - 1;
       vm &= vm - 1;
       const unsigned long long Tk = rl_u64(eT[q2], k);
-      rank[0] += (Tk < eT[0]) ? 1u : 0u;
-      rank[1] += (Tk < eT[1]) ? 1u : 0u;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) rank[q] += (Tk < eT[q]) ? 1u : 0u;
     }
   }
-  const uint32_t n = (uint32_t)__popcll(__ballot(valid[0])) + (uint32_t)__popcll(__ballot(valid[1]));
   float d = d0;
   uint32_t s = s0;
   const bool usable = (s0 & kObserved) && !(s0 & kFixed);
@@ -156,22 +164,24 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
   uint32_t lp_rec = kNone, lp_lb = 0, lp_s = 0;
   float lp_d = 0.f;
   uint32_t n_lp = 0;
-  bool pop_moved[2] = {false, false};
+  bool pop_moved[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) pop_moved[q] = false;
   for (uint32_t i = 0; i < n; ++i) {
-    const unsigned long long m0 = __ballot(valid[0] && rank[0] == i);
-    const unsigned long long m1 = __ballot(valid[1] && rank[1] == i);
-    uint32_t ecode, evs;
-    float evd;
-    int src, sq;
-    if (m0) {
-      src = __ffsll((long long)m0) - 1; sq = 0;
-      ecode = rl_u32(code[0], src); evd = rl_f32(ed[0], src); evs = rl_u32(es[0], src);
-    } else if (m1) {
-      src = __ffsll((long long)m1) - 1; sq = 1;
-      ecode = rl_u32(code[1], src); evd = rl_f32(ed[1], src); evs = rl_u32(es[1], src);
-    } else {
-      break;  // (cannot happen: ranks of valid events are 0 .. n - 1)
+    // the event of rank i: which slot, which lane
+    uint32_t ecode = 0, evs = 0;
+    float evd = 0.f;
+    int src = -1, sq = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q >= slots || src >= 0) continue;
+      const unsigned long long m = __ballot(valid[q] && rank[q] == i);
+      if (m) {
+        src = __ffsll((long long)m) - 1; sq = q;
+        ecode = rl_u32(code[q], src); evd = rl_f32(ed[q], src); evs = rl_u32(es[q], src);
+      }
     }
+    if (src < 0) break;  // (cannot happen: ranks of valid events are 0 .. n - 1)
     const uint32_t r = ecode >> 5, lut = ecode & 31;
     if (lut == kOwn) {
       // the pop: processOpenSet reads the voxel here (:381-392)
@@ -181,7 +191,10 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
           a.rec_s_n[r] = s;
         }
         // did the record's pop-time state move? (kept by the lane that holds the event)
-        if (lane == src && (__float_as_uint(d) != __float_as_uint(evd) || s != evs)) pop_moved[sq] = true;
+        if (lane == src && (__float_as_uint(d) != __float_as_uint(evd) || s != evs)) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) if (q == sq) pop_moved[q] = true;
+        }
       }
       s &= ~kInQueue;                                            // :386
       continue;
@@ -234,27 +247,28 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     return;
   }
   // ---- outputs of an iteration: the records on this voxel (their own-pop events, dead or alive)
-  bool own[2], chg[2] = {false, false};
-  uint32_t mn[2] = {0, 0}, pusher[2] = {kNone, kNone};
+  bool own[Q], chg[Q], found[Q];
+  uint32_t mn[Q], pusher[Q], fbucket[Q];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < Q; ++q) {
     own[q] = have[q] && (code[q] & 31) == kOwn && !epoison[q];
+    chg[q] = false; found[q] = false;
     mn[q] = emeta[q];
+    pusher[q] = kNone;
+    fbucket[q] = rp_meta_bucket(emeta[q]);
     if (own[q]) pusher[q] = a.rec_pusher[code[q] >> 5];
   }
   unsigned long long matched = 0;  // push j was matched by a record of mine
-  bool found[2] = {false, false};
-  uint32_t fbucket[2] = {rp_meta_bucket(emeta[0]), rp_meta_bucket(emeta[1])};
   for (uint32_t j = 0; j < n_lp; ++j) {
     const uint32_t lr = rl_u32(lp_rec, (int)j), llb = rl_u32(lp_lb, (int)j);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < Q; ++q)
       if (own[q] && pusher[q] != kNone && lr == pusher[q] && (llb & 0xFF) == rp_meta_lut(emeta[q])) {
         found[q] = true; fbucket[q] = llb >> 8; matched |= 1ull << j;
       }
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < Q; ++q) {
     if (!own[q]) continue;
     const uint32_t r = code[q] >> 5;
     if (pusher[q] != kNone) {
@@ -295,48 +309,58 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
 // rp_fold_raise as one wave per target (same layout as rp_fold_wave)
 __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lane) {
   using namespace rp;
+  constexpr int Q = (int)kEvQ;
   Ctl& c = *a.ctl;
   const uint32_t gid = a.tgt_gid[t];
   if (gid == kNone) return;
   uint32_t n_all = a.tgt_cnt[t];
-  if (n_all > kEv) n_all = kEv;
-  uint32_t code[2] = {0, 0};
-  unsigned long long eT[2] = {kNever, kNever};
-  bool valid[2] = {false, false};
+  if (n_all > a.c.ev) n_all = a.c.ev;
+  const int slots = (int)((n_all + 63u) >> 6);
+  uint32_t code[Q];
+  unsigned long long eT[Q];
+  bool valid[Q];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < Q; ++q) {
+    code[q] = 0; eT[q] = kNever; valid[q] = false;
     const uint32_t e = (uint32_t)lane + 64u * q;
     if (e < n_all) {
-      code[q] = a.tgt_ev[(size_t)t * kEv + e];
+      code[q] = a.tgt_ev[(size_t)t * a.c.ev + e];
       eT[q] = a.rec_T[code[q] >> 5];
       valid[q] = (code[q] & 31) != kOwn && eT[q] < c.cut;
     }
   }
-  uint32_t rank[2] = {0, 0};
-  const int slots = n_all > 64 ? 2 : 1;
-  for (int q2 = 0; q2 < slots; ++q2) {
+  uint32_t rank[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) rank[q] = 0;
+  uint32_t n = 0;
+#pragma unroll
+  for (int q2 = 0; q2 < Q; ++q2) {
+    if (q2 >= slots) break;
     unsigned long long vm = __ballot(valid[q2]);
+    n += (uint32_t)__popcll(vm);
     while (vm) {
       const int k = __ffsll((long long)vm) - 1;
       vm &= vm - 1;
       const unsigned long long Tk = rl_u64(eT[q2], k);
-      rank[0] += (Tk < eT[0]) ? 1u : 0u;
-      rank[1] += (Tk < eT[1]) ? 1u : 0u;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) rank[q] += (Tk < eT[q]) ? 1u : 0u;
     }
   }
-  const uint32_t n = (uint32_t)__popcll(__ballot(valid[0])) + (uint32_t)__popcll(__ballot(valid[1]));
   const float d0 = a.dist[gid];
   const uint32_t s0 = a.state[gid];
   float d = d0;
   uint32_t s = s0;
   const int RQ = a.c.num_buckets;
   for (uint32_t i = 0; i < n; ++i) {
-    const unsigned long long m0 = __ballot(valid[0] && rank[0] == i);
-    const unsigned long long m1 = __ballot(valid[1] && rank[1] == i);
-    uint32_t ecode;
-    if (m0) ecode = rl_u32(code[0], __ffsll((long long)m0) - 1);
-    else if (m1) ecode = rl_u32(code[1], __ffsll((long long)m1) - 1);
-    else break;
+    uint32_t ecode = 0;
+    bool got = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q >= slots || got) continue;
+      const unsigned long long m = __ballot(valid[q] && rank[q] == i);
+      if (m) { ecode = rl_u32(code[q], __ffsll((long long)m) - 1); got = true; }
+    }
+    if (!got) break;
     const uint32_t r = ecode >> 5, lut = ecode & 31;
     bool to_raise;
     if (!rp_raise_event(a.c, &d, &s, (int)lut, &to_raise)) continue;
