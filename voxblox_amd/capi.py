@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvbx_hip.so")
+# (VBX_HIP_LIB: another build of the same library, e.g. one compiled with -DRP_EVQ=8 — tools/r05b_validate.sh)
+LIB_PATH = os.environ.get("VBX_HIP_LIB") or os.path.join(_HERE, "csrc", "libvbx_hip.so")
 
 VBX_OK = 0
 VBX_ERR_INVALID, VBX_ERR_HIP, VBX_ERR_CAPACITY, VBX_ERR_UNSUPPORTED = -1, -2, -3, -4   # include/vbx_hip.h:30-33
