@@ -599,7 +599,7 @@ class ModelEsdf : public EsdfIntegrator {
     Args a{};
     a.hazard = std::getenv("EOM_NO_FILTER") ? nullptr : hazard.data();
     a.c.filter = (uint32_t)g_filter_level;
-    a.c.mark_moved = std::getenv("EOM_NO_MARK_MOVED") ? 0u : 1u;
+    a.c.mark_moved = std::getenv("EOM_NO_MARK_MOVED") ? 0u : (std::getenv("EOM_MARK_MOVED") ? (uint32_t)std::atoi(std::getenv("EOM_MARK_MOVED")) : 2u);
     a.c.fold_all = std::getenv("EOM_NO_FOLD_ALL") ? 0u : 1u;
     a.c.ev = std::getenv("EOM_EV") ? (uint32_t)std::atoi(std::getenv("EOM_EV")) : 256u;
     if (a.c.ev > kEvMax) a.c.ev = kEvMax;
@@ -649,6 +649,8 @@ class ModelEsdf : public EsdfIntegrator {
     a.chg = chg.data(); a.born = born.data(); a.cp = cp.data(); a.sd_list = sd_list.data(); a.sub_dirty = sub_dirty.data(); a.sub_n = sub_n.data();
     a.sub_slot = sub_slot.data(); a.sub_list = sub_list.data(); a.sub_slots_used = &sub_slots_used; a.sim_q = sim_q.data(); a.sub_slots_cap = sub_slots_cap;
     a.ord = ord.data(); a.off0 = off0.data();
+    std::vector<uint32_t> sim_old((size_t)sub_slots_cap * a.c.smax);
+    a.sim_old = sim_old.data();
     std::vector<uint32_t> rec_born_it(rec_cap);
     a.rec_born_it = std::getenv("EOM_NO_BORN_IT") ? nullptr : rec_born_it.data();
 

@@ -6,8 +6,8 @@ export TMPDIR=/tmp
 O=gpurun_out/${1:-r05b}
 mkdir -p $O
 timeout 700 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "rc=$?" >> $O/gpu_tests.log
-for ev in 256 128; do
-  VBX_RP_EV=$ev timeout 120 python tools/time_esdf_strict.py 14 > $O/esdf_time_ev$ev.log 2>&1
+for mm in 2 1; do
+  VBX_RP_MARK_MOVED=$mm timeout 120 python tools/time_esdf_strict.py 14 > $O/esdf_time_mark$mm.log 2>&1
 done
 # the same library built with -DRP_EVQ=8 (tools/_evq8/, built by hand: hipcc ... -DRP_EVQ=8 voxblox_amd/csrc/vbx_hip.hip): 512 events per target
 if [ -f tools/_evq8/libvbx_hip.so ]; then

@@ -81,7 +81,7 @@ struct Cfg {
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
-  uint32_t mark_moved;   // 1: a ranking marks the targets of every record whose pop time it moved (rp_mark_rec_targets); 0: round 4's behaviour
+  uint32_t mark_moved;   // a ranking marks the targets of 2: the records whose order it changed, 1: every record whose pop time it moved (rp_mark_rec_targets); 0: nothing (round 4)
 };
 
 // control block (device memory, one instance).  Part A is written by rp_control only (every workgroup reads it at
@@ -177,6 +177,7 @@ struct Args {
   uint32_t* sub_slot;       // [kmax] slot + 1 of the base record's list in sub_list
   uint32_t* sub_list;       // [slots][smax] ranked records of the last ranking
   uint32_t* sub_slots_used;
+  uint32_t* sim_old;        // (serial form, may be null) [slots][smax] the list of the last ranking while the next one is made (Cfg::mark_moved = 2)
   // (device only, may be null) members of every excursion in birth order, for the wave-cooperative ranking
   uint32_t* sub_mem;        // [slots][smax]
   uint32_t* sub_mem_n;      // [kmax]
@@ -791,7 +792,15 @@ RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
   uint32_t* list = a.sub_list + (size_t)(slot - 1) * a.c.smax;
   unsigned long long* q = a.sim_q + (size_t)(slot - 1) * a.c.smax;   // pending entries: record | next entry << 32
   const uint32_t old_n = a.sub_n[base];
-  for (uint32_t k = 0; k < old_n; ++k) a.rec_T[list[k]] = kNever;
+  // Cfg::mark_moved = 2: only what changes the ORDER of events on some target is marked — a record that pops now and did not
+  // before (unless PH_APPLY made it in this iteration), one that popped and does not any more, and one that is overtaken: a
+  // record with a larger old rank pops in front of it now (every pair that swapped has such a member, and the targets the pair
+  // shares are among that member's).  Ranks that merely shift because something was inserted or removed in front of them move
+  // no order.  The old pop times stay in rec_T until the record pops again; the old list is kept aside (Args::sim_old).
+  uint32_t* oldl = (a.c.mark_moved >= 2 && a.sim_old) ? a.sim_old + (size_t)(slot - 1) * a.c.smax : nullptr;
+  uint32_t runmax = 0;
+  if (oldl) for (uint32_t k = 0; k < old_n; ++k) oldl[k] = list[k];
+  else for (uint32_t k = 0; k < old_n; ++k) a.rec_T[list[k]] = kNever;
   // one FIFO per bucket below b, linked through q; lowest = a lower bound of the lowest non-empty bucket
   unsigned short head[kMaxBuckets + 1], tail[kMaxBuckets + 1];
   const int nb = (int)c.bucket;
@@ -825,8 +834,14 @@ RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
     if (head[lowest] == 0xFFFF) tail[lowest] = 0xFFFF;
     if (rank >= a.c.smax - 1 || a.rec_poison[r]) { truncated = true; atomicAdd(&c.st_trunc_rank, 1ull); break; }
     ++rank;
+    if (oldl) {
+      const unsigned long long oT = a.rec_T[r];
+      const uint32_t o = oT == kNever ? 0u : (uint32_t)(oT & kRankMask);
+      if (o == 0u || o < runmax) rp_mark_rec_targets(a, r);
+      if (o > runmax) runmax = o;
+    }
     a.rec_T[r] = ((unsigned long long)base << kRankBits) | rank;
-    if (a.c.mark_moved && (rank - 1 >= old_n || list[rank - 1] != r)) {
+    if (!oldl && a.c.mark_moved && (rank - 1 >= old_n || list[rank - 1] != r)) {
       // its pop time moved (or it pops for the first time, or again): the targets it talks to fold again
       rp_mark_rec_targets(a, r);
       if (rank - 1 < old_n) rp_mark_rec_targets(a, list[rank - 1]);   // (the record that had this rank: it moves, or it does not pop any more)
@@ -834,8 +849,18 @@ RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
     list[rank - 1] = r;
     cur = r;
   }
-  if (a.c.mark_moved)
+  if (oldl) {
+    // ranked before and not now: its old pop time is still there and it is not where it was in the new list
+    for (uint32_t k = 0; k < old_n; ++k) {
+      const uint32_t r = oldl[k];
+      if (a.rec_T[r] == (((unsigned long long)base << kRankBits) | (k + 1)) && !(k < rank && list[k] == r)) {
+        a.rec_T[r] = kNever;
+        rp_mark_rec_targets(a, r);
+      }
+    }
+  } else if (a.c.mark_moved) {
     for (uint32_t k = rank; k < old_n; ++k) rp_mark_rec_targets(a, list[k]);   // ranked before, not now (or marked already)
+  }
   a.sub_n[base] = rank;
   // an excursion that does not fit stops the super-step behind its last ranked record
   if (truncated) atomicMin(&c.smax_cut, ((unsigned long long)base << kRankBits) | (rank + 1));

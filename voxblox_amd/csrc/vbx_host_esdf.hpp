@@ -528,7 +528,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.c.ev = std::min<uint32_t>(std::max<uint32_t>(rp_env_u32("VBX_RP_EV", 256), 32), rp::kEvMax);   // events per target (128 until round 5a)
   a.c.tgt_claim = rp_env_u32("VBX_RP_TGT_CLAIM", 1);     // (0: a target id is taken before the voxel is known to be free: lost races leave holes)
   a.c.fold_all = rp_env_u32("VBX_RP_FOLD_ALL", 1);       // (0: PH_PLACE_BASE fills the dirty list like every other phase)
-  a.c.mark_moved = rp_env_u32("VBX_RP_MARK_MOVED", 1);   // (0: rankings do not mark the targets of the records they moved — rounds 4 / 5a)
+  a.c.mark_moved = rp_env_u32("VBX_RP_MARK_MOVED", 2);   // (0: rankings do not mark the targets of the records they moved — rounds 4 / 5a)
   a.blk_dirty = m.blk_flags;
   a.dirty_bit = kFlagEsdfDirty;
   a.nvox = m.nvox;

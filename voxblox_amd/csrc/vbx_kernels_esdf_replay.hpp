@@ -400,6 +400,7 @@ struct SimLds {
   unsigned short pend_j[kSimMax], sorted[kSimMax];
   unsigned short head[rp::kMaxBuckets + 1], tail[rp::kMaxBuckets + 1];
   unsigned short moved[kSimMax];              // members whose pop time this ranking moved
+  unsigned short orank[kSimMax];              // rank of the last ranking (0: none) | 0x8000: this ranking changed its order (rp_phase_sim, mark_moved = 2)
   uint32_t n_pend, flag_rank, n_ranked, truncated, n_moved;
 };
 __device__ inline void rp_wave_sync() {
@@ -435,6 +436,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     if (T != rp::kNever && (uint32_t)(T & rp::kRankMask) <= p) rk = (uint32_t)(T & rp::kRankMask);   // it popped in front of the restart point
     L.info[j] = (m & 0x1FFFFu) | (a.rec_poison[r] ? (1u << 17) : 0u) | (m & (1u << 18)) | (pl << 19);
     L.rank[j] = (unsigned short)rk;
+    L.orank[j] = T != rp::kNever ? (unsigned short)(T & 0x7FFFu) : (unsigned short)0;   // (ranks stay below smax <= 1024)
     if (rp::rp_meta_live(m)) atomicAdd(&L.cnt[pl], 1u);
     if (rk != 0xFFFF && (m & (1u << 18))) atomicMin(&L.flag_rank, rk);   // ranked, but a child of it is not in the list
   }
@@ -528,6 +530,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     // wave-uniform replay of the queue discipline from the restart point: every lane runs the same control flow, lanes
     // 0..25 fetch the 26 child slots of a pop at once, the FIFO links are written by all lanes alike
     uint32_t rank = R;
+    uint32_t runmax = R;   // largest old rank among the records that have popped (the records up to the restart point kept theirs: 1 .. R)
     int lowest = 0;
     for (;;) {
       while (lowest < nb && L.head[lowest] == 0xFFFF) ++lowest;   // BucketQueue::front / pop
@@ -541,6 +544,12 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       if (rank >= smax - 1 || (inf & (1u << 17))) { truncated = true; break; }
       ++rank;
       L.rank[j] = (unsigned short)rank;
+      {
+        // it pops now and did not before, or a record that used to pop behind it has popped in front of it: its order moved
+        const uint32_t o = L.orank[j] & 0x7FFFu;
+        if (o == 0u || o < runmax) L.orank[j] = (unsigned short)(o | 0x8000u);
+        if (o > runmax) runmax = o;
+      }
       rp_wave_sync();
       if (inf & (1u << 18)) { truncated = true; break; }   // a child of it is not in the list: stop behind it
       // its children enter their buckets in LUT order
@@ -580,7 +589,10 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     const uint32_t r = mem[j];
     const unsigned long long Tn = rk == 0xFFFF ? rp::kNever : (((unsigned long long)base << rp::kRankBits) | rk);
     // a pop time that moved reorders the events of the targets the record talks to (rp::rp_mark_rec_targets)
-    if (a.c.mark_moved && a.rec_T[r] != Tn && rp::rp_moved_needs_mark(a, r)) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;
+    const unsigned long long To = a.rec_T[r];
+    bool moved = To != Tn;                                                      // mark_moved = 1: every pop time that moved
+    if (a.c.mark_moved >= 2) moved = rk == 0xFFFF ? (To != rp::kNever) : ((L.orank[j] & 0x8000u) != 0u);   // 2: order changes only (rp_phase_sim)
+    if (a.c.mark_moved && moved && rp::rp_moved_needs_mark(a, r)) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;
     a.rec_T[r] = Tn;
   }
   __syncthreads();
