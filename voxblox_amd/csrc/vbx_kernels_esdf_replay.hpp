@@ -105,7 +105,9 @@ __device__ inline void rp_run_phase(const rp::Args& a, uint32_t phase, uint32_t 
 // on broadcast values.  A thread-per-target fold kept its event list in scratch memory and a target of a crowded
 // neighbourhood (a hundred events) cost milliseconds of dependent scratch round trips; the launch waits for its
 // slowest target.
-__device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long long limit, bool commit, int lane) {
+// (commit: the pushes per queue go to push_acc — the workgroup's LDS counters in k_rp_step —, the relaxations to *relax_acc)
+__device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long long limit, bool commit, int lane, uint32_t* push_acc = nullptr,
+                                    uint32_t* relax_acc = nullptr) {
   using namespace rp;
   constexpr int Q = (int)kEvQ;     // events per lane: event e of the target lives in lane e % 64, slot e / 64
   Ctl& c = *a.ctl;
@@ -214,7 +216,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
         if (lane == 0) {
           const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
           atomicOr(&a.rec_push[w], (uint32_t)(nb + 1) << sh);
-          atomicAdd(&c.push_cnt[nb], 1u);
+          atomicAdd(push_acc ? &push_acc[nb] : &c.push_cnt[nb], 1u);
         }
       } else if (nb < b) {
         if (n_lp == 64) {
@@ -242,7 +244,10 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
         a.state[gid] = s;
         if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
       }
-      if (relax) atomicAdd(&c.st_relax, (unsigned long long)relax);
+      if (relax) {
+        if (relax_acc) *relax_acc += relax;
+        else atomicAdd(&c.st_relax, (unsigned long long)relax);
+      }
     }
     return;
   }
@@ -307,7 +312,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
 }
 
 // rp_fold_raise as one wave per target (same layout as rp_fold_wave)
-__device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lane) {
+__device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lane, uint32_t* push_acc = nullptr) {
   using namespace rp;
   constexpr int Q = (int)kEvQ;
   Ctl& c = *a.ctl;
@@ -368,7 +373,7 @@ __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lan
       const int q = to_raise ? RQ : rp_bucket_of(a.c, d);
       const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
       atomicOr(&a.rec_push[w], (uint32_t)(q + 1) << sh);
-      atomicAdd(&c.push_cnt[q], 1u);
+      atomicAdd(push_acc ? &push_acc[q] : &c.push_cnt[q], 1u);
     }
   }
   if (lane == 0 && (d != d0 || s != s0)) {
@@ -729,6 +734,11 @@ template <bool SERIAL>
 __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, uint32_t seq) {
   __shared__ uint32_t s_last;
   __shared__ SimLds s_sim;
+  // COMMIT_FOLD / RAISE_FOLD: pushes per queue and relaxations of this workgroup.  Ctl::push_cnt and Ctl::st_relax share a
+  // few cache lines and used to take one atomic per push and one per target — 15 k on the same lines in a launch over 7 k
+  // targets, which is what such a launch lasted (a line takes a few hundred atomics per microsecond at best)
+  __shared__ uint32_t s_push[rp::kMaxBuckets + 1];
+  __shared__ uint32_t s_relax;
   rp::Ctl& c = *a.ctl;
   // Only the workgroups with work are waited for, so the control step of this launch can run before the dispatcher has
   // started the rest of the grid; those find the header of the next launch and leave.
@@ -745,11 +755,18 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   if (active > gridDim.x) active = gridDim.x;
   if (active == 0) active = 1;
   if (blockIdx.x >= active) return;
+  const bool lds_counts = !SERIAL && a.c.lds_counts && (phase == rp::PH_COMMIT_FOLD || phase == rp::PH_RAISE_FOLD);
+  if (lds_counts) {
+    for (uint32_t i = threadIdx.x; i <= rp::kMaxBuckets; i += kRpThreads) s_push[i] = 0;
+    if (threadIdx.x == 0) s_relax = 0;
+    __syncthreads();
+  }
   if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
     rp_scan_phase(a, sc, n, phase);
   } else if (!SERIAL && phase == rp::PH_RAISE_FOLD) {
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
-    for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves) rp_fold_raise_wave(a, w, threadIdx.x & 63);
+    for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves)
+      rp_fold_raise_wave(a, w, threadIdx.x & 63, lds_counts ? s_push : nullptr);
   } else if (!SERIAL && (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD)) {
     // one wave per target
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
@@ -760,7 +777,9 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
         if (lane == 0) a.tgt_dirty[t] = 0;
         rp_fold_wave(a, t, rp::kNever, false, lane);
       } else {
-        rp_fold_wave(a, w, c.cut, true, lane);
+        uint32_t relax = 0;
+        rp_fold_wave(a, w, c.cut, true, lane, lds_counts ? s_push : nullptr, lds_counts ? &relax : nullptr);
+        if (lane == 0 && relax) atomicAdd(&s_relax, relax);
       }
     }
   } else if (!SERIAL && phase == rp::PH_SIM) {
@@ -773,6 +792,12 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   // before it says so: the last one reads the control block through atomic read-modify-writes (the per-XCD L2s are not
   // coherent) — all words at once, one per thread, into LDS; rp_control then runs on the LDS copy (a dozen dependent
   // trips to memory otherwise, 10 - 20 us per step) and the copy is stored back.
+  if (lds_counts) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= rp::kMaxBuckets; i += kRpThreads)
+      if (s_push[i]) atomicAdd(&c.push_cnt[i], s_push[i]);
+    if (threadIdx.x == 0 && s_relax) atomicAdd(&c.st_relax, (unsigned long long)s_relax);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) s_last = (atomicAdd(&c.arrive, 1u) == active - 1) ? 1u : 0u;
