@@ -23,9 +23,14 @@
 //   commit       targets write their state as of the cut; the committed records' pushes are appended to the bucket
 //                FIFOs in (T, LUT index) order = the order in which the reference pushed them.
 //
+// WHICH targets an iteration folds: the ones somebody marked dirty — PH_PLACE_BASE's are all new and are folded without a
+// list (Cfg::fold_all), PH_APPLY marks those of the records whose state or liveness changed, and a ranking marks those of
+// the records whose pop ORDER it changed (Cfg::mark_moved, rp_mark_rec_targets).  tools/esdf_order_model.cc with EOM_CHECK=1
+// folds every target once more at every fixed point and must find nothing to change in front of the cut.
+//
 // The code is a set of PHASES: plain functions of (arguments, thread id) with no synchronisation inside — a phase
 // runs to completion before the next starts (on the device a kernel boundary, vbx_kernels_esdf_replay.hpp; in
-// tools/esdf_replay_emul.cc a serial loop, which is how this file is checked against the oracle without a GPU) —
+// tools/esdf_order_model.cc (mode 2) a serial loop, which is how this file is checked against the oracle without a GPU) —
 // and rp_control, run by one thread after every phase, which picks the next.  The two SCAN phases (PH_RANK, PH_PUSH) are
 // collective: this file gives their per-item count / apply functions, the prefix sum itself lives outside.
 //
