@@ -604,6 +604,7 @@ class ModelEsdf : public EsdfIntegrator {
     a.c.ev = std::getenv("EOM_EV") ? (uint32_t)std::atoi(std::getenv("EOM_EV")) : 256u;
     if (a.c.ev > kEvMax) a.c.ev = kEvMax;
     a.c.tgt_claim = std::getenv("EOM_NO_TGT_CLAIM") ? 0u : 1u;
+    a.c.slot_by_base = std::getenv("EOM_NO_SLOT_BY_BASE") ? 0u : 1u;
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;
@@ -642,7 +643,7 @@ class ModelEsdf : public EsdfIntegrator {
     a.vox2tgt = vox2tgt.data(); a.tgt_gid = tgt_gid.data(); a.tgt_cnt = tgt_cnt.data(); a.tgt_ev = tgt_ev.data(); a.tgt_dirty = tgt_dirty.data();
     a.dl[0] = dl0.data(); a.dl[1] = dl1.data();
     std::vector<uint32_t> chg(rec_cap), born((size_t)rec_cap * 6), cp(rec_cap * 2), sd_list(a.c.kmax), sub_dirty(a.c.kmax), sub_n(a.c.kmax), sub_slot(a.c.kmax);
-    const uint32_t sub_slots_cap = 16384;
+    const uint32_t sub_slots_cap = std::max<uint32_t>(a.c.kmax, 4096);
     std::vector<uint32_t> sub_list((size_t)sub_slots_cap * a.c.smax), ord(rec_cap), off0(a.c.kmax);
     std::vector<unsigned long long> sim_q((size_t)sub_slots_cap * a.c.smax);
     uint32_t sub_slots_used = 0;
@@ -651,6 +652,10 @@ class ModelEsdf : public EsdfIntegrator {
     a.ord = ord.data(); a.off0 = off0.data();
     std::vector<uint32_t> sim_old((size_t)sub_slots_cap * a.c.smax);
     a.sim_old = sim_old.data();
+    // the member lists PH_APPLY keeps for the device's ranking (the serial ranking does not read them: kept here so that the
+    // code that fills them runs, and is bounds-checked, without a GPU)
+    std::vector<uint32_t> sub_mem((size_t)sub_slots_cap * a.c.smax), sub_mem_n(a.c.kmax), rec_local(rec_cap), sub_restart(a.c.kmax, kNone);
+    a.sub_mem = sub_mem.data(); a.sub_mem_n = sub_mem_n.data(); a.rec_local = rec_local.data(); a.sub_restart = sub_restart.data();
     std::vector<uint32_t> rec_born_it(rec_cap);
     a.rec_born_it = std::getenv("EOM_NO_BORN_IT") ? nullptr : rec_born_it.data();
 

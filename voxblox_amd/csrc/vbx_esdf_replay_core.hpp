@@ -85,6 +85,7 @@ struct Cfg {
   uint32_t ev;       // events a target can hold (<= kEvMax); a record whose event does not fit is poisoned and the super-step ends in front of it
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
   uint32_t lds_counts;   // (device) 1: COMMIT_FOLD / RAISE_FOLD count pushes and relaxations per workgroup in LDS, one atomic per queue and workgroup
+  uint32_t slot_by_base; // 1: the list of base record i's excursion is slot i + 1 (sub_slots_cap >= kmax); 0: slots are handed out as excursions appear
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
   uint32_t mark_moved;   // a ranking marks the targets of 2: the records whose order it changed, 1: every record whose pop time it moved (rp_mark_rec_targets); 0: nothing (round 4)
@@ -744,11 +745,20 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     rp_mark_sub_dirty(a, pusher);
     if (a.sub_mem) {
       const uint32_t base = a.rec_base[pusher];
+      // the excursion's list: slot base + 1 (Cfg::slot_by_base — one list per base record, nothing to allocate), or the next
+      // free one (until round 5a: 4,096 slots taken first come first served, and every lane that met an excursion without a
+      // slot took one before it knew whether it had won — a super-step of 16 k base records with 3,000 excursions ran out,
+      // the rankings behind the last slot stopped at their first record and the super-step was cut)
       uint32_t slot = a.sub_slot[base];
       if (slot == 0u) {
-        const uint32_t mine = atomicAdd(a.sub_slots_used, 1u) + 1u;
-        const uint32_t old = atomicCAS(&a.sub_slot[base], 0u, mine);
-        slot = old ? old : mine;
+        if (a.c.slot_by_base) {
+          slot = base + 1u;
+          a.sub_slot[base] = slot;
+        } else {
+          const uint32_t mine = atomicAdd(a.sub_slots_used, 1u) + 1u;
+          const uint32_t old = atomicCAS(&a.sub_slot[base], 0u, mine);
+          slot = old ? old : mine;
+        }
       }
       const uint32_t idx = atomicAdd(&a.sub_mem_n[base], 1u);
       if (slot <= a.sub_slots_cap && idx < a.c.smax) {
@@ -791,7 +801,7 @@ RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
   a.sub_dirty[base] = 0;
   uint32_t slot = a.sub_slot[base];
   if (slot == 0) {
-    slot = atomicAdd(a.sub_slots_used, 1u) + 1u;
+    slot = a.c.slot_by_base ? base + 1u : atomicAdd(a.sub_slots_used, 1u) + 1u;
     if (slot > a.sub_slots_cap) { atomicOr(&c.error, 1u); return; }
     a.sub_slot[base] = slot;
   }

@@ -436,6 +436,9 @@ static uint32_t rp_env_u32(const char* name, uint32_t dflt) {
   return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
+// lists of ranked excursions the buffers hold: one per base record of a super-step (at least the 4,096 of rounds 4 / 5a)
+static uint32_t rp_sub_slots(uint32_t kmax) { return std::max<uint32_t>(kmax, 4096); }
+
 // buffers of the replay, sized for kmax base records per super-step
 int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used, size_t n_list) {
   hipStream_t s = ctx->stream;
@@ -458,7 +461,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(ctx->rp_dl.ensure((size_t)tgt_cap * 4 * 2));
     HIP_TRY(ctx->rp_lists.ensure((size_t)rec_cap * 4 * (1 + 6 + 2) + (size_t)kmax * 4));
     HIP_TRY(ctx->rp_sub.ensure((size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4));
-    const uint32_t sub_slots = 4096;
+    const uint32_t sub_slots = rp_sub_slots(kmax);
     HIP_TRY(ctx->rp_sub_list.ensure((size_t)sub_slots * smax * 4));
     HIP_TRY(ctx->rp_sim_q.ensure((size_t)sub_slots * smax * 8));
     HIP_TRY(ctx->rp_ord.ensure((size_t)rec_cap * 4));
@@ -565,7 +568,9 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.sub_mem = ctx->rp_sub_list.as<uint32_t>();   // (the device ranks from the member lists; sub_list is the serial form's)
   a.sub_list = ctx->rp_sub_list.as<uint32_t>();
   a.sim_q = ctx->rp_sim_q.as<unsigned long long>();
-  a.sub_slots_cap = 4096;
+  // VBX_RP_SLOT_BY_BASE (default 1): base record i's excursion is ranked in list i + 1; 0: 4,096 lists handed out as excursions appear
+  a.c.slot_by_base = rp_env_u32("VBX_RP_SLOT_BY_BASE", 1);
+  a.sub_slots_cap = a.c.slot_by_base ? rp_sub_slots(ctx->rp_kmax) : 4096;
   a.ord = ctx->rp_ord.as<uint32_t>();
   return a;
 }
