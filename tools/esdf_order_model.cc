@@ -725,6 +725,11 @@ class ModelEsdf : public EsdfIntegrator {
             for (uint32_t i = c.head[q]; i < c.tail[q]; ++i) if (rp_queue_entry(a, q, i) == watch) std::fprintf(stderr, "[watch] queued in %d at %u (head %u tail %u)\n", q, i, c.head[q], c.tail[q]);
         }
       }
+      if (c.phase == PH_CLEANUP && std::getenv("EOM_SLOTS")) {   // excursions (base records with a ranking list) of the super-step
+        uint32_t n_exc = 0;
+        for (uint32_t i = 0; i < c.K; ++i) n_exc += a.sub_slot[i] != 0u;
+        if (n_exc > 1000) std::fprintf(stderr, "[slots] superstep %llu b=%u K=%u: %u excursions, %u records\n", c.st_supersteps, c.bucket, c.K, n_exc, c.n_rec);
+      }
       if (std::getenv("EOM_TRACE2")) std::fprintf(stderr, "phase %u n=%u iter=%u rec=%u tgt=%u\n", c.phase, n, c.iter, c.n_rec, c.n_tgt);
       const bool was_fold = c.phase == PH_FOLD && c.n_chg == 0 && c.n_born == 0;
 
