@@ -605,6 +605,7 @@ class ModelEsdf : public EsdfIntegrator {
     if (a.c.ev > kEvMax) a.c.ev = kEvMax;
     a.c.tgt_claim = std::getenv("EOM_NO_TGT_CLAIM") ? 0u : 1u;
     a.c.slot_by_base = std::getenv("EOM_NO_SLOT_BY_BASE") ? 0u : 1u;
+    a.c.member_limit = std::getenv("EOM_MEMBER_LIMIT") ? 1u : 0u;
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;

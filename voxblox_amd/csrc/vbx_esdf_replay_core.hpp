@@ -85,6 +85,7 @@ struct Cfg {
   uint32_t ev;       // events a target can hold (<= kEvMax); a record whose event does not fit is poisoned and the super-step ends in front of it
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
   uint32_t lds_counts;   // (device) 1: COMMIT_FOLD / RAISE_FOLD count pushes and relaxations per workgroup in LDS, one atomic per queue and workgroup
+  uint32_t member_limit; // (serial ranking) 1: stop behind a record one of whose children is not in the member list, as the device's ranking must
   uint32_t slot_by_base; // 1: the list of base record i's excursion is slot i + 1 (sub_slots_cap >= kmax); 0: slots are handed out as excursions appear
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
@@ -826,6 +827,10 @@ RP_FN void rp_phase_sim(const Args& a, uint32_t tid) {
   bool truncated = false;
   uint32_t cur = base;
   for (;;) {
+    // (Cfg::member_limit: the device ranks from the member lists PH_APPLY keeps — smax births per excursion, dead records
+    // included — and has to stop behind a record that has a child outside the list; the serial form can do the same, which
+    // is how the emulation reproduces the device's cuts)
+    if (a.c.member_limit && a.sub_mem && (a.rec_meta[cur] & (1u << 18))) { truncated = true; atomicAdd(&c.st_trunc_q, 1ull); break; }
     // the children of `cur` enter their buckets in LUT order
     for (int lut = 0; lut < 26 && !truncated; ++lut) {
       const uint32_t kid = a.rec_kid[(size_t)cur * 26 + lut];
