@@ -106,7 +106,17 @@ typedef struct vbx_esdf_cfg {
    * visited in the order of the list given to vbx_esdf_update_blocks; vbx_esdf_update visits them in the iteration order
    * the reference's Layer would have (Layer::getAllUpdatedBlocks over its unordered_map, layer.h:194-203): the library
    * replays that container from the sequence in which the integrators hand blocks to the Layer
-   * (vbx_block_indices_layer_order) — so the plain call reproduces a single-threaded reference run bit for bit.
+   * (vbx_block_indices_layer_order) — so the plain call reproduces a single-threaded reference run bit for bit AS LONG AS
+   * the library saw every block join the Layer (integrate calls, vbx_blocks_upload).  Blocks of unknown provenance
+   * (vbx_blocks_merge_sums on a sharded persistent map, vbx_blocks_deserialize, blocks integrated while
+   * vbx_set_block_order_tracking was off, a log that overflowed) are walked in ascending (z,y,x) order behind the others:
+   * the call then still succeeds, vbx_counters.esdf_order_inexact says how many blocks that concerned and stderr carries
+   * one line per handle; pass the order yourself (vbx_esdf_update_blocks) when it matters.
+   * COST OF THIS DEFAULT: latency ~100x the fast mode's (tens of ms per update instead of 0.3); device memory ~0.7 GB
+   * of replay pools per handle whatever the size of the map (0.5 GB of it the targets' event lists) + ~21 B per pool
+   * voxel for the queue arena and the target / hazard maps (64 B with multi_queue) = ~1.7 GB for a 20 k-block map,
+   * allocated at the first reference-order update and kept until vbx_destroy.  Handles that never run a
+   * reference-order update allocate none of it.
    * 0: the fast mode — order-free wavefronts run to their exact fixed points on the whole chip (0.3 ms per update; NOT
    * the reference's result where it depends on the queue order: bit-exact for batch updates with min_diff_m = 0, inside
    * the reference's own min_diff_m envelope otherwise).
@@ -353,8 +363,22 @@ typedef struct vbx_counters {
                                  update was finished sweep by sweep (VBX_ESDF_RAISE_SWEEPS / VBX_ESDF_LOWER_SWEEPS) */
   uint64_t points_taken;    /* Fast: points of the taking order the last call took (= points unless
                                cfg->max_integration_time_s cut the frame short) */
+  uint64_t esdf_order_inexact; /* ESDF, reference_order = 1, vbx_esdf_update: blocks the walk had to list in ascending
+                               (z,y,x) order behind the ones whose place in the reference Layer's iteration order the
+                               library knows (blocks merged in from another map, deserialised, integrated while
+                               vbx_set_block_order_tracking was off, or behind an overflowed log).  0: the update walked
+                               the blocks exactly like a single-threaded reference run */
 } vbx_counters;
 int vbx_get_counters(vbx_ctx* ctx, vbx_counters* out);
+
+/* `static int64_t reset_counter` of FastTsdfIntegrator::integratePointCloud (tsdf_integrator.cc:564-569): the reference
+ * counts the calls of ALL FastTsdfIntegrator instances of the process in one function-static and clears the two
+ * ApproxHashSets of the instance whose call makes it reach clear_checks_every_n_frames.  The library keeps the same ONE
+ * counter per process (per loaded libvbx_hip.so), shared by every handle on every device; with the default
+ * clear_checks_every_n_frames = 1 it is invisible.  The reference offers no access to it; these two exist so that a test
+ * (or a process that wants per-map behaviour) can put it into a known state. */
+int64_t vbx_fast_reset_counter_get(void);
+void vbx_fast_reset_counter_set(int64_t value);
 
 /* Self-test hook (no reference counterpart): checks the library's stable radix sort — the primitive
  * under the start-voxel replay, the observed-set replay and the ordered fold — against

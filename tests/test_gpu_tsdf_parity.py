@@ -29,6 +29,7 @@ def _run(oracle, kind, voxel, frames, max_blocks=4096, **kw):
     from voxblox_amd import capi
     ocfg, gcfg = _cfgs(oracle, 4 * voxel, **kw)
     oracle.lib().orc_fast_reset_counter_set(0)
+    capi.lib().vbx_fast_reset_counter_set(0)   # the library's process-wide counter (tsdf_integrator.cc:564), like the oracle's
     om = oracle.OracleMap(voxel, 16)
     oi = om.tsdf_integrator(kind, ocfg)
     gm = capi.Map(voxel, 16, max_blocks=max_blocks)
@@ -198,6 +199,58 @@ def test_sorted_integration_order(oracle, kind, extra):
         _, _, gm2 = _run(oracle, kind, 0.05, frames)
         a, b = gm.tsdf_dict(), gm2.tsdf_dict()
         assert any(not np.array_equal(a[k][0], b[k][0]) for k in a)
+
+
+@pytest.mark.parametrize("kind", ["simple", "merged", "fast"])
+def test_sparsity_compensation_factor_on_the_device(oracle, kind):
+    """use_sparsity_compensation_factor = 1 (tsdf_integrator.cc:173-182): the weight of every update whose |sdf| lies
+    inside the truncation band is multiplied by the factor — all three integrators, bit for bit against the oracle
+    (which test_oracle_vs_reference_build.py pins against the reference build with the same Config)."""
+    frames = [_small_room(k) for k in (0, 6, 12)]
+    om, oi, gm = _run(oracle, kind, 0.05, frames, use_sparsity_compensation_factor=1, sparsity_compensation_factor=3.0)
+    st = compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    assert st["observed_voxels"] > 10000
+    # and the switch does something: without it the weights inside the band are a third
+    _, _, g0 = _run(oracle, kind, 0.05, frames)
+    a, b = gm.tsdf_dict(), g0.tsdf_dict()
+    assert a.keys() == b.keys()
+    assert any(not np.array_equal(a[k][1], b[k][1]) for k in a)
+
+
+def test_fast_reset_counter_is_shared_by_all_integrators_of_the_process(oracle):
+    """`static int64_t reset_counter` (tsdf_integrator.cc:564-569) counts the calls of EVERY FastTsdfIntegrator of the
+    process: two integrators on two maps with clear_checks_every_n_frames = 3, called alternately, clear their sets when
+    the SHARED counter reaches 3 — i.e. on calls 3, 6, 9 of the interleaved sequence, whichever integrator makes them.
+    Per-handle counters would clear each map's sets on its own 3rd call instead: a different map."""
+    from voxblox_amd import capi
+    ocfg, gcfg = _cfgs(oracle, 0.2, clear_checks_every_n_frames=3)
+    oracle.lib().orc_fast_reset_counter_set(0)
+    capi.lib().vbx_fast_reset_counter_set(0)
+    oms = [oracle.OracleMap(0.05, 16) for _ in range(2)]
+    ois = [om.tsdf_integrator("fast", ocfg) for om in oms]
+    gms = [capi.Map(0.05, 16, max_blocks=4096) for _ in range(2)]
+    # (poses close together so that what a set still holds decides which rays are cast)
+    seq = [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (1, 3)]
+    for which, k in seq:
+        pose, pts, col = _small_room(k)
+        ois[which].integrate(pose[0], pose[1], pts, col)
+        gms[which].integrate(capi.TSDF_FAST, gcfg, pose[0], pose[1], pts, col)
+    assert capi.lib().vbx_fast_reset_counter_get() == len(seq) % 3
+    for om, gm in zip(oms, gms):
+        compare_tsdf(gm.tsdf_dict(), om.tsdf_dict(), exact=True)
+    # the same calls with a counter per map (each map alone in the process) give another layer for at least one of the two
+    differs = False
+    for which in range(2):
+        oracle.lib().orc_fast_reset_counter_set(0)
+        om1 = oracle.OracleMap(0.05, 16)
+        oi1 = om1.tsdf_integrator("fast", ocfg)
+        for w, k in seq:
+            if w == which:
+                pose, pts, col = _small_room(k)
+                oi1.integrate(pose[0], pose[1], pts, col)
+        a, b = om1.tsdf_dict(), oms[which].tsdf_dict()
+        differs |= a.keys() != b.keys() or any(not np.array_equal(a[k][0], b[k][0]) or not np.array_equal(a[k][1], b[k][1]) for k in a)
+    assert differs, "the scenario does not tell a shared counter from per-map counters"
 
 
 @pytest.mark.parametrize("n_frames", [2, 3])

@@ -128,18 +128,29 @@ def test_oracle_word_packing_vs_reference_build(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_words_and_file_round_trip(oracle, tmp_path):
+@pytest.mark.parametrize("reference_order", [1, 0])
+def test_gpu_words_and_file_round_trip(oracle, tmp_path, reference_order):
+    """reference_order = 1 (the C-ABI's default): the ESDF word stream — distance, flags AND parents (block.cc:112-137) —
+    equals the unswitched reference's word for word; 0: the order-free mode against the oracle's order-free switch, where
+    parents may differ on ties and are masked."""
     from voxblox_amd import capi
     voxel = 0.1
     gm = capi.Map(voxel, 16, max_blocks=2048)
     om = oracle.OracleMap(voxel, 16)
     oi = om.tsdf_integrator("simple", oracle.tsdf_cfg(default_truncation_distance=0.4, integrator_threads=1))
-    oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=0.2, min_diff_m=0.0, oracle_orderfree_sign_mismatch=1))
+    if reference_order:
+        oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=0.2))
+    else:
+        oe = om.esdf_integrator(oracle.esdf_cfg(min_distance_m=0.2, min_diff_m=0.0, oracle_orderfree_sign_mismatch=1))
     for k in range(2):
         pose, pts, col = scenes.room_frame(9 * k, 100, f=40.0, width=80, height=60)
         gm.integrate(capi.TSDF_SIMPLE, capi.tsdf_cfg(default_truncation_distance=0.4), pose[0], pose[1], pts, col)
         oi.integrate(pose[0], pose[1], pts, col)
-    gm.esdf_update(capi.esdf_cfg(reference_order=0, min_distance_m=0.2, min_diff_m=0.0), batch=True)
+    if reference_order:
+        gm.esdf_update(capi.esdf_cfg(reference_order=1, min_distance_m=0.2), batch=True)
+        assert gm.counters()["esdf_order_inexact"] == 0
+    else:
+        gm.esdf_update(capi.esdf_cfg(reference_order=0, min_distance_m=0.2, min_diff_m=0.0), batch=True)
     oe.update_from_tsdf_layer_batch()
     # 1. word streams bit-identical to the oracle's (== reference build's) for TSDF; for ESDF
     #    distance + flag bits identical, parents may differ on ties -> compare after masking
@@ -151,8 +162,11 @@ def test_gpu_words_and_file_round_trip(oracle, tmp_path):
     we, _ = gm.blocks_serialize(idx, capi.LAYER_ESDF)
     for i, b in enumerate(idx):
         ow = om.block_serialize(b, 1)
-        assert np.array_equal(we[i][0::2], ow[0::2])
-        assert np.array_equal(we[i][1::2] & 0xF, ow[1::2] & 0xF)
+        if reference_order:
+            assert np.array_equal(we[i], ow), f"ESDF words (distance, parents, flags) differ in block {tuple(b)}"
+        else:
+            assert np.array_equal(we[i][0::2], ow[0::2])
+            assert np.array_equal(we[i][1::2] & 0xF, ow[1::2] & 0xF)
     # 2. .voxblox file: TSDF + appended ESDF section, reloaded into a fresh map
     path = str(tmp_path / "map.voxblox")
     vio.save_layer(gm, path, capi.LAYER_TSDF, clear_file=True)

@@ -92,6 +92,8 @@ def test_tsdf_integrators_bit_identical(kind):
     ("simple", dict(voxel_carving_enabled=0)),
     ("simple", dict(use_const_weight=1, use_weight_dropoff=0)),
     ("simple", dict(use_sparsity_compensation_factor=1, sparsity_compensation_factor=3.0)),
+    ("merged", dict(use_sparsity_compensation_factor=1, sparsity_compensation_factor=3.0)),
+    ("fast", dict(use_sparsity_compensation_factor=1, sparsity_compensation_factor=3.0)),
     ("simple", dict(allow_clear=0, max_ray_length_m=3.0)),
     ("merged", dict(enable_anti_grazing=1)),
     ("merged", dict(max_ray_length_m=2.5, min_ray_length_m=1.5)),

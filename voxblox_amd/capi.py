@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "vbx_last_error", "vbx_get_map_cfg", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
     "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_esdf_robot_updated_blocks", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated", "vbx_blocks_new_ordered", "vbx_block_indices_layer_order", "vbx_set_block_order_tracking",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_blocks_remove", "vbx_remove_distant_blocks",
-    "vbx_clear", "vbx_clear_keep_slots", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_enable_timing", "vbx_get_timing",
+    "vbx_clear", "vbx_clear_keep_slots", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_fast_reset_counter_get", "vbx_fast_reset_counter_set", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
     "vbx_selftest_unordered_order", "vbx_selftest_index_set_order", "vbx_mesh_cfg_default", "vbx_mesh_generate", "vbx_mesh_blocks", "vbx_mesh_download", "vbx_mesh_device_ptrs")
 
@@ -69,7 +69,8 @@ class Counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("points", "rays_cast", "voxel_updates", "voxels_touched", "blocks_allocated",
                  "iterations", "esdf_blocks", "esdf_relaxations", "esdf_sweeps", "replay_rounds",
-                 "replay_block_rounds", "time_budget_exceeded", "esdf_respeculated", "points_taken")]
+                 "replay_block_rounds", "time_budget_exceeded", "esdf_respeculated", "points_taken",
+                 "esdf_order_inexact")]
 
 
 class Timing(C.Structure):
@@ -132,6 +133,8 @@ def lib():
         "vbx_mesh_device_ptrs": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "vbx_selftest_sort": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
         "vbx_selftest_scan": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "vbx_fast_reset_counter_get": (C.c_int64, []),
+        "vbx_fast_reset_counter_set": (None, [C.c_int64]),
         "vbx_num_blocks": (C.c_int, [vp, C.c_int, szp]),
         "vbx_block_indices": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp]),
         "vbx_blocks_updated": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_size_t, szp]),

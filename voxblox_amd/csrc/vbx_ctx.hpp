@@ -17,6 +17,12 @@ struct HostAnyIndexHash {
   }
 };
 
+// `static int64_t reset_counter` of FastTsdfIntegrator::integratePointCloud (tsdf_integrator.cc:564): ONE counter for every
+// FastTsdfIntegrator of the process, whichever Layer it integrates into — two integrators with clear_checks_every_n_frames > 1
+// advance each other's.  Calls on one handle come from one thread (the reference's integratePointCloud is documented not
+// thread safe); the atomic only keeps concurrent handles (the sharding's delta maps, one host thread each) from tearing it.
+static std::atomic<int64_t> g_fast_reset_counter{0};
+
 struct vbx_ctx {
   int device = 0;
   vbx_map_cfg mcfg{};
@@ -25,6 +31,7 @@ struct vbx_ctx {
   uint32_t pool_limit = 0;   // vbx_set_pool_limit: the pool never grows beyond this many blocks (0: no limit)
   uint32_t pool_grown = 0;   // times the pool doubled
   bool warned_time_budget = false;  // Fast: max_integration_time_s overrun reported once
+  bool warned_esdf_order = false;   // ESDF: a reference-order walk over blocks of unknown Layer order reported once
   double fast_us_per_point = 0.0;   // Fast with a finite max_integration_time_s: wall time per taken point of the earlier calls
   uint32_t fast_take_limit = ~0u;   // ... points of the taking order the current call takes
   uint32_t fast_prev_taken = 0;     // ... points the previous budgeted call took (the limit moves by at most 2x per frame)
@@ -91,7 +98,8 @@ struct vbx_ctx {
   uint32_t obsset_offset = 0;
   bool obsset_sentinel_live = true;
   bool obsset_init = false;
-  int64_t reset_counter = 0;  // tsdf_integrator.cc:564
+  // (FastTsdfIntegrator's reset counter is a function-static in the reference, shared by every instance of the process:
+  // g_fast_reset_counter below, not a member)
   DBuf b_own0, b_own1;
   // ESDF layer (allocated on first use)
   DBuf b_edist, b_estate, b_eraised, b_eactive;

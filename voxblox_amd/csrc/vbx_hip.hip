@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -749,6 +750,9 @@ int vbx_remove_distant_blocks(vbx_ctx* ctx, int layer, const float center[3], do
                      f3{center[0], center[1], center[2]}, max_distance * max_distance, block_size);
   rc = reclaim_slots(ctx);
   if (rc || layer != VBX_LAYER_TSDF) return rc;
+  // (a map that does not follow the order, or has no order yet, has nothing to reconcile: tsdf_server-style callers remove
+  // distant blocks after every frame)
+  if (!ctx->track_block_order || ctx->layer_order.empty()) return VBX_OK;
   // block_map_.erase(it) for every block that went (layer.h:170-182): which ones was decided on the device, so the keys
   // that are not published any more leave the replayed container (an erased key frees its bucket: it matters for where
   // later insertions land)
@@ -990,6 +994,10 @@ int vbx_blocks_deserialize(vbx_ctx* ctx, int layer, const int32_t* idx, size_t n
   if (rc) return rc;
   return check_state_error(ctx);
 }
+
+// FastTsdfIntegrator's process-wide reset counter (tsdf_integrator.cc:564)
+int64_t vbx_fast_reset_counter_get(void) { return g_fast_reset_counter.load(); }
+void vbx_fast_reset_counter_set(int64_t value) { g_fast_reset_counter.store(value); }
 
 // Self-test hook of the hand-written stable radix sort (vbx_sort.hpp): n pseudo-random keys,
 // sorted on bits [begin_bit, end_bit) on the device, compared with std::stable_sort on the host.

@@ -793,8 +793,23 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     std::sort(v.begin(), v.end());
     // the iteration order of the reference's block_map_, as far as the library saw the Layer being built (integrate calls,
     // uploads); blocks of unknown provenance follow in ascending (z,y,x)
-    rc = order_like_layer(ctx, &v, nullptr);
+    bool order_exact = true;
+    size_t n_unknown = 0;
+    rc = order_like_layer(ctx, &v, &order_exact, &n_unknown);
     if (rc) return rc;
+    if (!order_exact && !v.empty()) {
+      // not the reference Layer's order: say so instead of silently walking another sequence (vbx_counters.esdf_order_inexact;
+      // one line on stderr per handle)
+      ctx->counters.esdf_order_inexact = std::max<size_t>(n_unknown, 1);
+      if (!ctx->warned_esdf_order) {
+        ctx->warned_esdf_order = true;
+        fprintf(stderr, "[vbx] vbx_esdf_update(reference_order = 1): the place of %zu of %zu blocks in the reference Layer's iteration "
+                        "order is unknown to the library (merged in / deserialised / integrated with block-order tracking off / log "
+                        "overflow); they are walked in ascending (z,y,x) order behind the others, the result may differ from a "
+                        "single-threaded reference run (reported once; vbx_counters.esdf_order_inexact; pass the order with "
+                        "vbx_esdf_update_blocks)\n", n_unknown, v.size());
+      }
+    }
     h_slots.resize(v.size());
     for (size_t i = 0; i < v.size(); ++i) h_slots[i] = v[i].second;
     if (!robot_blocks.empty()) {
@@ -891,7 +906,22 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     const uint32_t* all_slots = a.list_slots;
     size_t pos = 0;
     front_done = 1;
-    do {
+    // every segment is a pass of its own (a memset over the pool, five launches or more, a stream sync per neighbour round):
+    // a list that alternates (A, B, A, B, ...) would take O(n) such passes where the one-wave walk takes the list in one —
+    // beyond a handful of segments the whole list goes through that form
+    static const uint32_t max_segments = rp_env_u32("VBX_RP_MAX_SEGMENTS", 8);
+    {
+      uint32_t n_seg = 0;
+      for (size_t p2 = 0; p2 < n && n_seg <= max_segments; ++n_seg) {
+        in_seg.clear();
+        for (; p2 < n; ++p2) {
+          const uint32_t sl = seg_slots[p2];
+          if (sl != kInvalidSlot && !in_seg.insert(sl).second) break;
+        }
+      }
+      if (n_seg > max_segments) front_done = 0;
+    }
+    if (front_done) do {
       in_seg.clear();
       size_t end = pos;
       for (; end < n; ++end) {

@@ -405,9 +405,10 @@ constexpr uint32_t kFastSetSize = (1u << 20) + 10000u;  // ApproxHashSet<20, 100
 // every clear_checks_every_n_frames-th call -- empty clouds included -- both ApproxHashSets move
 // on by one offset, and are zeroed when the offset wraps at 10000 (approx_hash_array.h:156-169).
 int fast_frame_tick(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg) {
-  if ((++ctx->reset_counter) < cfg->clear_checks_every_n_frames) return VBX_OK;
+  // (one counter per process, like the reference's function-static: ++counter >= n resets it and clears THIS integrator's sets)
+  if (g_fast_reset_counter.fetch_add(1) + 1 < (int64_t)cfg->clear_checks_every_n_frames) return VBX_OK;
   hipStream_t s = ctx->stream;
-  ctx->reset_counter = 0;
+  g_fast_reset_counter.store(0);
   ++ctx->obs_epoch;  // voxel_observed set cleared (exact-set form of resetApproxSet)
   if (++ctx->obsset_offset >= 10000u) {
     if (ctx->obsset_init) HIP_TRY(hipMemsetAsync(ctx->b_obsset.p, 0, (size_t)kFastSetSize * 4, s));
@@ -955,6 +956,13 @@ int drain_new_blocks(vbx_ctx* ctx) {
 // Every block of the layer goes (vbx_clear, vbx_clear_keep_slots): whatever the log still holds names blocks that go too —
 // dropped on the device, nothing is read back (a delta map of the sharding is cleared every step).
 int discard_new_blocks(vbx_ctx* ctx) {
+  // A map that follows the Layer's order replays the pending insertions first: temp_block_map_ and block_map_ keep the
+  // bucket arrays those insertions grew (clear() keeps the buckets, layer.h:164, tsdf_integrator.cc:146), and where later
+  // insertions land depends on them.  A map with tracking off (the sharding's delta maps) never has a pending log.
+  if (ctx->newlog_pending && ctx->track_block_order) {
+    int rc = drain_new_blocks(ctx);
+    if (rc) return rc;
+  }
   if (ctx->newlog_pending) HIP_TRY(hipMemsetAsync(&ctx->d_state->newlog_count, 0, 8, ctx->stream));
   ctx->newlog_pending = 0;
   ctx->layer_order.clear();   // block_map_.clear() (layer.h:168): the keys go, the bucket array stays
@@ -966,7 +974,7 @@ int discard_new_blocks(vbx_ctx* ctx) {
 // over them (Layer::getAllAllocatedBlocks / getAllUpdatedBlocks walk block_map_, layer.h:184-203).  Blocks whose insertion
 // the library did not see in the reference's sequence (merged in from another map, a log that overflowed) follow in
 // ascending key order and *exact turns false.
-int order_like_layer(vbx_ctx* ctx, std::vector<std::pair<uint64_t, uint32_t>>* v, bool* exact) {
+int order_like_layer(vbx_ctx* ctx, std::vector<std::pair<uint64_t, uint32_t>>* v, bool* exact, size_t* n_unknown = nullptr) {
   int rc = drain_new_blocks(ctx);
   if (rc) return rc;
   std::unordered_map<uint64_t, uint32_t> slot_of;
@@ -982,6 +990,7 @@ int order_like_layer(vbx_ctx* ctx, std::vector<std::pair<uint64_t, uint32_t>>* v
     slot_of.erase(it);
   }
   bool ex = ctx->layer_order_exact;
+  if (n_unknown) *n_unknown = slot_of.size();
   if (!slot_of.empty()) {
     ex = false;
     std::vector<std::pair<uint64_t, uint32_t>> rest(slot_of.begin(), slot_of.end());
@@ -1046,8 +1055,18 @@ int integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg, const floa
   const auto t_call0 = std::chrono::steady_clock::now();
   const uint32_t pool_grown_before = ctx->pool_grown;
   if (ctx->new_flags_live) {   // an earlier call failed half way: its new-block marks must not count for this one
-    int rcn = collect_new_blocks(ctx);
+    // (the host copy of the state is the failed call's last read-back: slots it allocated later would be missed, so the
+    // flush reads the state first and walks the whole pool; what the failed call published enters the order behind the
+    // known blocks, and the library says so: exact = 0)
+    int rcn = sync_state(ctx);
     if (rcn) return rcn;
+    ctx->h_state.pool_used = ctx->map.cap_blocks;
+    ctx->h_state.blocks_published = std::max(ctx->h_state.blocks_published, 1u);
+    rcn = collect_new_blocks(ctx);
+    if (rcn) return rcn;
+    rcn = sync_state(ctx);
+    if (rcn) return rcn;
+    ctx->layer_order_exact = false;
   }
   ctx->new_flags_live = ctx->track_block_order;
   // per-call device counters
