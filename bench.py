@@ -129,6 +129,44 @@ def _oracle():
 CPU_THREADS = []   # --cpu-threads (empty: the full ladder)
 
 
+def host_cpu_info():
+    """What the CPU figures were measured on: hardware threads the machine reports, the ones this process may run on, and the
+    cgroup's CPU quota (a throttled lease would otherwise look like an idle 256-thread host)."""
+    info = {"host_hw_threads": os.cpu_count() or 1}
+    try:
+        info["affinity_threads"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity_threads"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else round(float(txt[0]) / float(txt[1]), 2)
+            else:
+                q = float(txt[0])
+                period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+                quota = None if q < 0 else round(q / period, 2)
+            info["cgroup_cpu_quota_source"] = path
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    info["cgroup_cpu_quota_cores"] = quota   # None: unlimited (or no cgroup file readable)
+    try:
+        info["loadavg_1min"] = round(os.getloadavg()[0], 2)
+    except OSError:
+        pass
+    return info
+
+
+def _usable_cores():
+    i = host_cpu_info()
+    n = i.get("affinity_threads") or i["host_hw_threads"]
+    if i.get("cgroup_cpu_quota_cores"):
+        n = max(1, min(n, int(i["cgroup_cpu_quota_cores"])))
+    return n
+
+
 def _thread_counts(cores):
     if CPU_THREADS:
         return sorted({t for t in CPU_THREADS if 1 <= t <= cores}) or [1]
@@ -150,7 +188,7 @@ def cpu_baseline(frames, kind, voxel, seconds=None, window=None):
     (kept for callers that still pass a budget): the sample is bounded by its frame count."""
     import ctypes
     O, L, use_ref = _oracle()
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     counts = _thread_counts(cores)
     n_warm, n_timed = window or cpu_baseline_frames(voxel)
     sample = frames[:n_warm + n_timed]
@@ -176,7 +214,7 @@ def cpu_baseline(frames, kind, voxel, seconds=None, window=None):
         del it, m
     best = max(by, key=lambda k: by[k]["value"])
     return {"value": by[best]["value"], "unit": "Mpoints/s", "cores": int(best),
-            "kind": "reference" if use_ref else "port", "host_hw_threads": cores, "by_threads": by,
+            "kind": "reference" if use_ref else "port", "host_hw_threads": os.cpu_count() or 1, "host": host_cpu_info(), "by_threads": by,
             "cpu_seconds_spent": round(time.time() - t_all, 1),
             "frames_timed": [n_warm, len(sample) - 1],
             "sample": f"{kind} integrator, {voxel:g} m voxels, frames 0..{len(sample) - 1} of the same stream for EVERY thread count "
@@ -382,7 +420,10 @@ def esdf_layer_diff(gm, ref_esdf_dict):
             "rmse_m": round((se / max(worst_n, 1)) ** 0.5, 6), "frac_gt_1e-4_m": round(n4 / max(worst_n, 1), 5)}
 
 
-def dropin_leg(frames, kind, voxel, warmup, steps):
+DROPIN_EXTRA_BLOCKS = (5000, 20000)
+
+
+def dropin_leg(frames, kind, voxel, warmup, steps, extra_blocks=0):
     import ctypes
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
@@ -391,6 +432,21 @@ def dropin_leg(frames, kind, voxel, warmup, steps):
     if hasattr(L, "orc_timing_reset"):
         L.orc_timing_reset()
     m = O.OracleMap(voxel, 16, L=L)
+    if extra_blocks:
+        # `extra_blocks` LOADED blocks far from the scene (io::LoadBlocksFromFile's effect on the host Layer: voxels written,
+        # all Update bits set): they go to the device with the first call and are never touched again
+        rng = np.random.RandomState(7)
+        d = rng.uniform(-0.2, 0.2, 4096).astype(np.float32)
+        w = rng.uniform(0.5, 50.0, 4096).astype(np.float32)
+        col = rng.randint(0, 256, (4096, 4)).astype(np.uint8)
+        side = int(np.ceil(extra_blocks ** (1.0 / 3.0)))
+        k = 0
+        for z in range(side):
+            for y in range(side):
+                for x in range(side):
+                    if k < extra_blocks:
+                        m.tsdf_block_set((1000 + x, 1000 + y, 1000 + z), d, w, col, 7)
+                        k += 1
     c = O.TsdfCfg()
     L.orc_tsdf_cfg_default(ctypes.byref(c))
     c.default_truncation_distance = 4 * voxel
@@ -409,6 +465,7 @@ def dropin_leg(frames, kind, voxel, warmup, steps):
     out = {"value": round(frames[0][1].shape[0] * len(used) / sum(used) / 1e6, 3), "unit": "Mpoints/s",
            "ms_per_step": round(sum(used) / len(used) * 1e3, 4), "frames": [warmup, warmup + steps - 1],
            "host_blocks_at_end": int(m.num_blocks(0)) if hasattr(m, "num_blocks") else None,
+           "entry": "voxblox " + kind.capitalize() + "TsdfIntegrator::integratePointCloud (host Layer, host pointers) over the drop-in",
            "note": "wall time inside " + kind.capitalize() + "TsdfIntegrator::integratePointCloud of voxblox's own class over the C-ABI (SURVEY 8(d)'s "
                    "definition of the metric): reconcile of the host Layer, H2D of points + colours, device integration, touched blocks "
                    "mirrored back into the host Layer; same frames as `value`"}
@@ -476,7 +533,7 @@ def kernel_table(gm, calls_per_step=1.0):
     return rows, calls
 
 
-def pmc_traffic(kernel, tag_files=("r05_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json")):
+def pmc_traffic(kernel, tag_files=("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json")):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     separate runs with --kernel-trace only, the driver-shaped command; tools/collect_profiles.sh +
     tools/summarize_profiles.py).  Counters cannot be read from inside this process, so the figure comes from the
@@ -491,7 +548,8 @@ def pmc_traffic(kernel, tag_files=("r05_pmc_hbm_traffic.json", "r03_pmc_hbm_traf
             if not k or not k.get("launches_per_frame"):
                 continue
             per_launch = (k["fetch_bytes"] + k["write_bytes"]) / k["launches_per_frame"]
-            return {"bytes_per_launch": int(per_launch), "fetch_bytes_per_step": int(k["fetch_bytes"]),
+            return {"bytes_per_step": int(k["fetch_bytes"] + k["write_bytes"]),
+                    "bytes_per_launch": int(per_launch), "fetch_bytes_per_step": int(k["fetch_bytes"]),
                     "write_bytes_per_step": int(k["write_bytes"]), "launches_per_step": k["launches_per_frame"],
                     "all_kernels_bytes_per_step": int(j.get("total_bytes_per_frame", 0)),
                     "source": "profiles/" + f, "frames": j.get("frames_desc", j.get("frames")),
@@ -513,9 +571,18 @@ def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
     achieved = alg_bytes_per_step / t / 1e9 if t > 0 else 0.0
     total_us = sum(r["us_per_step"] for r in rows)
     tr = (pmc_traffic(dom["kernel"]) if "distinct voxels updated per frame" in what else
-          pmc_traffic(dom["kernel"], ("r05_pmc_esdf_ref_order.json", "r03_pmc_esdf_traffic.json")) if "updated blocks" in what else None)
+          pmc_traffic(dom["kernel"], ("r06_pmc_esdf_ref_order.json", "r05_pmc_esdf_ref_order.json", "r03_pmc_esdf_traffic.json")) if "updated blocks" in what else None)
     return {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": (tr["bytes_per_launch"] if tr else None),
+            "frac": round(achieved / HBM_PEAK_GBPS, 6),
+            # counter bytes PER STEP of the dominant kernel (all of its launches in a step), the same unit as
+            # algorithmic_bytes_per_step and as `achieved`'s numerator: traffic / algorithmic_bytes_per_step is how many times
+            # the compulsory bytes this kernel moves, traffic_all_kernels_per_step / algorithmic_bytes_per_step the whole step's
+            "traffic": (tr["bytes_per_step"] if tr else None),
+            "traffic_per_launch": (tr["bytes_per_launch"] if tr else None),
+            "traffic_all_kernels_per_step": (tr["all_kernels_bytes_per_step"] if tr else None),
+            "traffic_over_algorithmic": (round(tr["bytes_per_step"] / alg_bytes_per_step, 2) if tr and alg_bytes_per_step else None),
+            "traffic_all_kernels_over_algorithmic": (round(tr["all_kernels_bytes_per_step"] / alg_bytes_per_step, 2)
+                                                     if tr and alg_bytes_per_step and tr.get("all_kernels_bytes_per_step") else None),
             "traffic_detail": tr,
             "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
             "kernel_us_per_step": dom["us_per_step"], "algorithmic_bytes_per_step": int(alg_bytes_per_step),
@@ -525,10 +592,10 @@ def roofline_from(rows, alg_bytes_per_step, device_ms_per_step, what):
             "note": "durations from HIP events around every launch on the launch stream (a profiled pass over the "
                     "SAME frame indices as the timed region, on a second map brought to the same state by the same warm-up; events add ~2-4 us per launch, so short kernels read "
                     "high against rocprofv3 — profiles/ holds the matching rocprofv3 --kernel-trace --stats summary); "
-                    "traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of this kernel from the committed PMC passes of the "
-                    "driver-shaped command (traffic_detail.source; null when that file is absent), against "
-                    "algorithmic_bytes_per_step / launches_per_step per launch; latency / dependency bound path far "
-                    "below the HBM roofline (SURVEY 8(d))"}
+                    "traffic = FETCH_SIZE + WRITE_SIZE bytes PER STEP of this kernel (all of its launches in a step; "
+                    "traffic_per_launch beside it) from the committed PMC passes of the driver-shaped command "
+                    "(traffic_detail.source; null when that file is absent), to be read against algorithmic_bytes_per_step; "
+                    "latency / dependency bound path far below the HBM roofline (SURVEY 8(d))"}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -604,6 +671,33 @@ def run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, esdf_cfg=N
 
 
 SENSOR_BANDS = [1]   # ray bundles per sensor frame (--bands); whole sensors reproduce the reference's map
+
+
+def sharded_stream_timed(sharded, d_frames, kind, cfg, warmup, total, barrier, dist, world, reduce_device):
+    """The N > 1 timed region of the stream workload: W untimed frames per rank into the sharded map (delta map + pipelined
+    owner exchange), a flush, then EXACTLY total - W timed frames bracketed by barrier + synchronize on both sides, and the
+    MAX of the ranks' times (the contract's `value` = all ranks' points / that).  Every rank returns the same number.
+    A function of its own so that tests/test_multi_gpu_gloo.py can run it at world size 8 over gloo with a CPU-backed map
+    (deadlocks, ordering of the collectives, the MAX) where no 8-GPU box is at hand."""
+    import torch
+    for i in range(warmup):
+        pose, dp, dc, n = d_frames[i % len(d_frames)]
+        sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n)
+    sharded.flush()
+    for key in sharded.stats:
+        sharded.stats[key] = 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(warmup, total):
+        pose, dp, dc, n = d_frames[i % len(d_frames)]
+        sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n)
+    sharded.flush()
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=reduce_device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
 
 
 def _bands(world):
@@ -748,11 +842,11 @@ def _short_roofline(r):
         return None
     o = _pick(r, ("bound", "achieved", "peak", "unit", "frac"))
     o["traffic"] = r.get("traffic")
-    o.update(_pick(r, ("kernel", "launches_per_step", "avg_launch_us", "kernel_us_per_step", "algorithmic_bytes_per_step",
-                       "step_frac", "device_ms_per_step")))
+    o.update(_pick(r, ("traffic_per_launch", "traffic_all_kernels_per_step", "traffic_over_algorithmic",
+                       "traffic_all_kernels_over_algorithmic", "kernel", "launches_per_step", "avg_launch_us", "kernel_us_per_step",
+                       "algorithmic_bytes_per_step", "step_frac", "device_ms_per_step")))
     td = r.get("traffic_detail")
     if isinstance(td, dict):
-        o["traffic_all_kernels_per_step"] = td.get("all_kernels_bytes_per_step")
         o["traffic_source"] = td.get("source")
     return o
 
@@ -761,6 +855,9 @@ def _short_cpu(c):
     if not isinstance(c, dict):
         return None
     o = _pick(c, ("value", "unit", "cores", "kind", "host_hw_threads", "ms_per_update", "ms_per_step"))
+    if isinstance(c.get("host"), dict):
+        o.update(_pick(c["host"], ("affinity_threads", "cgroup_cpu_quota_cores")))
+        o["cgroup_cpu_quota_cores"] = c["host"].get("cgroup_cpu_quota_cores")   # (null = unlimited: say so)
     if isinstance(c.get("by_threads"), dict):
         o["by_threads"] = {k: (v.get("value") if isinstance(v, dict) else v) for k, v in c["by_threads"].items()}
     if c.get("sample"):
@@ -814,8 +911,10 @@ def compact_line(out, detail_name):
                        "vs_baseline", "dtype", "data"))
     line["vs_baseline"] = out.get("vs_baseline")
     cfgd = out.get("config") or {}
-    line["config"] = _pick(cfgd, ("workload", "points_per_step", "points_per_step_per_gpu", "voxel_size", "voxels_per_side",
+    line["config"] = _pick(cfgd, ("workload", "entry", "points_per_step", "points_per_step_per_gpu", "voxel_size", "voxels_per_side",
                                   "world_size_seen", "ray_bundles_per_step", "parallelism"))
+    if "entry" in line["config"]:
+        line["config"]["entry"] = str(line["config"]["entry"])[:64].rstrip(" :(") 
     for k in ("workload", "parallelism"):
         if k in line["config"]:
             line["config"][k] = str(line["config"][k])[:160]
@@ -823,9 +922,14 @@ def compact_line(out, detail_name):
     line["cpu_baseline"] = _short_cpu(out.get("cpu_baseline"))
     for k in ("host_pointer_path", "dropin_path"):
         if isinstance(out.get(k), dict):
-            line[k] = _pick(out[k], ("value", "unit", "ms_per_step", "error"))
+            line[k] = _pick(out[k], ("value", "unit", "ms_per_step", "error", "entry"))
+            if "entry" in line[k]:
+                line[k]["entry"] = str(line[k]["entry"])[:110]
             if isinstance(out[k].get("ms_by_timer_tag"), dict):
                 line[k]["ms_by_timer_tag"] = out[k]["ms_by_timer_tag"]
+            if isinstance(out[k].get("by_host_blocks"), dict):   # host blocks -> [Mpoints/s, reconcile ms]
+                line[k]["by_host_blocks"] = {hb: ([v.get("value"), (v.get("ms_by_timer_tag") or {}).get("hip/tsdf_reconcile_from_host")]
+                                                  if "error" not in v else v) for hb, v in out[k]["by_host_blocks"].items()}
     if isinstance(out.get("esdf"), dict):
         line["esdf"] = _short_esdf(out["esdf"])
     if isinstance(out.get("exchange"), dict):
@@ -850,6 +954,8 @@ def compact_line(out, detail_name):
         line["legs"] = {k: _pick(v, ("value", "ms_per_step", "error")) for k, v in (line.get("legs") or {}).items()}
 
     shed = [lambda: legs_drop("roofline"), lambda: (line.get("dropin_path") or {}).pop("ms_by_timer_tag", None),
+            lambda: [(line.get(k) or {}).pop("entry", None) for k in ("host_pointer_path", "dropin_path")],
+            lambda: (line.get("dropin_path") or {}).pop("by_host_blocks", None),
             lambda: legs_drop("cpu_baseline"), lambda: line.pop("host_pointer_path", None),
             lambda: (line.get("cpu_baseline") or {}).pop("by_threads", None), lambda: legs_drop("esdf"), legs_bare,
             lambda: line.pop("esdf", None), lambda: line.pop("exchange", None), lambda: line.pop("legs", None)]
@@ -1012,24 +1118,8 @@ def main():
         dl = [capi.Map(voxel, 16, max_blocks=max_blocks, device=local_rank) for _ in range(2)]
         sharded = multi_gpu.PipelinedShardedTsdfMap(multi_gpu.GpuBackend(pm, dev), [multi_gpu.GpuBackend(d, dev, keep_slots=True) for d in dl],
                                                     rank, world, dist, device=dev)
-        for i in range(warmup):
-            pose, dp, dc, n = d_frames[i % len(d_frames)]
-            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n)
-        sharded.flush()
-        for key in sharded.stats:
-            sharded.stats[key] = 0
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(warmup, total):
-            pose, dp, dc, n = d_frames[i % len(d_frames)]
-            sharded.integrate_shard(kind, cfg, pose[0], pose[1], dp, dc, n)
-        sharded.flush()
-        barrier()
-        dt = time.perf_counter() - t0
-        tt = torch.tensor([dt], device=("cpu" if dist.get_backend() == "gloo" else dev), dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = sharded_stream_timed(sharded, d_frames, kind, cfg, warmup, total, barrier, dist, world,
+                                  "cpu" if dist.get_backend() == "gloo" else dev)
         pts_timed = sum(d_frames[i % len(d_frames)][3] for i in range(warmup, total))
         f = max(sharded.stats["frames"], 1)
         out = dict(base)
@@ -1126,6 +1216,9 @@ def main():
                                          if (args.merged_order or args.fast_set) else
                                          "TSDF bit-exact vs the 1-thread reference; ESDF order-free fixed point, NOT bit-exact" if (args.esdf and not esdf_parity)
                                          else "bit-exact vs the 1-thread reference"),
+                           "entry": "vbx_tsdf_integrate_device: points and colours resident in HBM when the clock starts (the bench "
+                                    "contract); the same frames through voxblox's own FastTsdfIntegrator::integratePointCloud with the "
+                                    "drop-in linked in (host Layer, host pointers — SURVEY 8(d)'s definition of the metric) = dropin_path",
                            "parallelism": "1 GPU, whole cloud"}})
     stage = {k: round(v / K, 4) for k, v in acc["stage"].items()}
     out["stage_ms"] = stage
@@ -1252,6 +1345,7 @@ def main():
         torch.cuda.synchronize()
         dth = time.perf_counter() - t0
         out["host_pointer_path"] = {"value": round(pts_timed / dth / 1e6, 3), "unit": "Mpoints/s", "ms_per_step": round(dth / K * 1e3, 4),
+                                    "entry": "vbx_tsdf_integrate (host pointers)",
                                     "note": "vbx_tsdf_integrate (the drop-in's entry: pageable host points + colours copied to HBM "
                                             "inside the call), same frames and warm-up as `value`"}
         gh.close()
@@ -1263,6 +1357,16 @@ def main():
     if not args.esdf and not args.mesh and not args.no_host_path and not args.no_cpu_baseline:
         try:
             out["dropin_path"] = dropin_leg(frames, args.integrator, voxel, warmup, steps)
+            # the same call with a host Layer that also holds 5 k / 20 k blocks the frames never touch (a map that has been
+            # built for a while): what the call costs must follow the blocks a cloud touches, like the reference's, not the map
+            by = {str(out["dropin_path"].get("host_blocks_at_end")): _pick(out["dropin_path"], ("value", "ms_per_step", "ms_by_timer_tag"))}
+            for extra in DROPIN_EXTRA_BLOCKS:
+                try:
+                    j = dropin_leg(frames, args.integrator, voxel, warmup, steps, extra_blocks=extra)
+                    by[str(j.get("host_blocks_at_end"))] = _pick(j, ("value", "ms_per_step", "ms_by_timer_tag"))
+                except Exception as e:
+                    by["+%d" % extra] = {"error": repr(e)[:200]}
+            out["dropin_path"]["by_host_blocks"] = by
         except Exception as e:  # a secondary leg must never take the headline line down
             out["dropin_path"] = {"error": repr(e)[:300]}
 

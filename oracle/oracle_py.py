@@ -179,7 +179,11 @@ def _bind(L):
     # voxblox::timing queries: only the libraries built from the reference's sources have them
     for name, (res, args) in {"orc_timing_get": (None, [C.c_char_p, C.POINTER(C.c_double)]), "orc_timing_reset": (None, []),
                               "vbx_dropin_set_esdf_reference_order": (None, [C.c_int]),
-                              "vbx_dropin_get_esdf_reference_order": (C.c_int, [])}.items():
+                              "vbx_dropin_get_esdf_reference_order": (C.c_int, []),
+                              "vbx_dropin_set_reconcile_mode": (None, [C.c_int]),
+                              "vbx_dropin_get_reconcile_mode": (C.c_int, []),
+                              "orc_dropin_mark_edited": (None, [vp, C.c_int]),
+                              "orc_dropin_mesher": (C.c_int, [])}.items():
         if hasattr(L, name):
             fn = getattr(L, name)
             fn.restype = res
@@ -324,6 +328,11 @@ class OracleMap:
 
     def clear(self, layer=0):
         self.L.orc_clear(self.h, layer)
+
+    def dropin_mark_edited(self, layer=0):
+        """libvbxref_hip.so: hip::markLayerEdited — the caller wrote voxels of the layer in place without any marker."""
+        if hasattr(self.L, "orc_dropin_mark_edited"):
+            self.L.orc_dropin_mark_edited(self.h, int(layer))
 
     def dropin_stats(self):
         """libvbxref_hip.so: blocks the drop-in uploaded to / removed from the device while reconciling host edits."""

@@ -54,9 +54,14 @@ struct orc_approx_set { std::unique_ptr<ApproxSetIface> s; };
 struct orc_bucket_queue { BucketQueue<size_t> q; };
 
 #ifdef VBX_DROPIN
+// the mesher's drop-in: MeshIntegrator<TsdfVoxel>::generateMesh specialised for the device (a maintainer adds this include
+// at the end of voxblox/mesh/mesh_integrator.h)
+#include "mesh_integrator_hip.h"
 namespace voxblox { namespace hip {
 void releaseMirror(const Layer<TsdfVoxel>* tsdf_layer);
 void mirrorStats(const Layer<TsdfVoxel>* tsdf_layer, uint64_t* uploaded_blocks, uint64_t* removed_blocks);
+void markLayerEdited(const Layer<TsdfVoxel>* tsdf_layer);
+void markLayerEdited(const Layer<EsdfVoxel>* esdf_layer);
 } }
 #endif
 
@@ -305,6 +310,22 @@ void orc_dropin_stats(orc_map* m, uint64_t out[2]) {
   voxblox::hip::mirrorStats(&m->tsdf, &out[0], &out[1]);
 #else
   (void)m;
+#endif
+}
+// hip::markLayerEdited: the caller (a test) wrote voxels of the layer in place without touching Update bits
+void orc_dropin_mark_edited(orc_map* m, int layer) {
+#ifdef VBX_DROPIN
+  if (layer == 0) voxblox::hip::markLayerEdited(&m->tsdf); else voxblox::hip::markLayerEdited(&m->esdf);
+#else
+  (void)m; (void)layer;
+#endif
+}
+// 1: MeshIntegrator<TsdfVoxel>::generateMesh of this library is the HIP specialisation (mesh_integrator_hip.h)
+int orc_dropin_mesher() {
+#ifdef VBX_DROPIN
+  return 1;
+#else
+  return 0;
 #endif
 }
 uint64_t orc_tsdf_count_observed(orc_map* m) {

@@ -56,6 +56,41 @@ def test_compact_line_sheds_optional_parts_instead_of_overflowing():
     assert j["value"] == full["value"]
 
 
+def _pmc_ratio(roof):
+    """counter bytes per STEP of the line's dominant kernel, read from the PMC file the line names, over the line's
+    algorithmic bytes per step"""
+    pmc = json.load(open(os.path.join(ROOT, roof["traffic_source"])))
+    k = pmc["per_frame_bytes"][roof["kernel"]]
+    return (k["fetch_bytes"] + k["write_bytes"]) / roof["algorithmic_bytes_per_step"], pmc["total_bytes_per_frame"] / roof["algorithmic_bytes_per_step"]
+
+
+def test_roofline_traffic_is_counter_bytes_per_step_of_the_dominant_kernel():
+    """Round 5's line put bytes per LAUNCH in `traffic` next to algorithmic bytes per STEP (12.7 MB against 10.1 MB looked like
+    1.25x where the kernel moves 25x and the step 88x the compulsory bytes).  `traffic` is per step now: its ratio to
+    algorithmic_bytes_per_step equals the PMC file's, for the dominant kernel and for all kernels."""
+    import bench
+    rows = [{"kernel": "k_fast_sweep", "us_per_step": 469.3, "launches_per_step": 20.2, "avg_us": 23.23},
+            {"kernel": "k_rsort_fused", "us_per_step": 380.0, "launches_per_step": 19.6, "avg_us": 19.4}]
+    alg = 10143285
+    r = bench.roofline_from(rows, alg, 1.4226, "16 B x points + 24 B x distinct voxels updated per frame")
+    assert r["kernel"] == "k_fast_sweep" and r["traffic"] is not None
+    short = bench._short_roofline(r)
+    for roof in (r, short):
+        roof = dict(roof, traffic_source=(roof.get("traffic_source") or roof["traffic_detail"]["source"]))
+        dom, allk = _pmc_ratio(roof)
+        assert abs(roof["traffic"] / roof["algorithmic_bytes_per_step"] - dom) <= 0.01 * dom
+        assert abs(roof["traffic_all_kernels_per_step"] / roof["algorithmic_bytes_per_step"] - allk) <= 0.01 * allk
+        assert abs(roof["traffic_over_algorithmic"] - dom) <= 0.01 * dom + 0.01
+    assert abs(r["traffic"] - r["traffic_per_launch"] * 20.2) <= 0.01 * r["traffic"]
+
+
+def test_host_cpu_info_names_affinity_and_quota():
+    import bench
+    i = bench.host_cpu_info()
+    assert i["host_hw_threads"] >= 1 and "affinity_threads" in i and "cgroup_cpu_quota_cores" in i
+    assert 1 <= bench._usable_cores() <= i["host_hw_threads"]
+
+
 @pytest.mark.gpu
 def test_the_drivers_command_prints_one_parseable_line_under_4_kb(tmp_path):
     """`python bench.py --gpus 1 --steps K --warmup W` as the driver runs it (short K so that the test stays short; the
@@ -76,6 +111,18 @@ def test_the_drivers_command_prints_one_parseable_line_under_4_kb(tmp_path):
     assert sens["ray_bundles_per_step"] == 4
     full = json.load(open(detail))
     assert full["value"] == j["value"] and "kernels" in full
+    # the line says what it measures: which entry point `value` is, the same for the drop-in figure, counter traffic per step
+    assert "vbx_tsdf_integrate_device" in j["config"]["entry"]
+    assert "integratePointCloud" in j["dropin_path"]["entry"]
+    assert len(j["dropin_path"]["by_host_blocks"]) == 3, j["dropin_path"]
+    for hb, v in j["dropin_path"]["by_host_blocks"].items():
+        assert isinstance(v, list) and v[0] > 0 and v[1] is not None and v[1] < 1.0, (hb, v)   # [Mpoints/s, reconcile ms]
+    roof = j["roofline"]
+    if roof.get("traffic") is not None:
+        dom, allk = _pmc_ratio(roof)
+        assert abs(roof["traffic"] / roof["algorithmic_bytes_per_step"] - dom) <= 0.01 * dom
+        assert abs(roof["traffic_all_kernels_per_step"] / roof["algorithmic_bytes_per_step"] - allk) <= 0.01 * allk
+    assert "affinity_threads" in j["cpu_baseline"] and "cgroup_cpu_quota_cores" in j["cpu_baseline"]
 
 
 def test_compact_line_of_a_multi_rank_result_and_of_a_failed_leg():

@@ -27,6 +27,18 @@ pytestmark = pytest.mark.gpu
 VOXEL = 0.1
 
 
+@pytest.fixture(autouse=True, params=[-1, 0], ids=["reconcile_touched", "reconcile_every_line"])
+def reconcile_mode(request, oracle):
+    """Every test of this file runs in both reconcile modes of the drop-in (device_mirror.h): -1 = O(touched), the default
+    since round 6 (the mirror's own records + a rotating window; an in-place overwrite WITHOUT any marker has to be announced
+    with hip::markLayerEdited), 0 = every line of every host block on every call (round 5's default: sees a single-voxel
+    poke without being told)."""
+    H = oracle.ref_hip_lib()
+    H.vbx_dropin_set_reconcile_mode(request.param)
+    yield request.param
+    H.vbx_dropin_set_reconcile_mode(-1)
+
+
 def _cfg(oracle, L):
     c = oracle.TsdfCfg()
     L.orc_tsdf_cfg_default(C.byref(c))
@@ -169,7 +181,7 @@ def test_integration_continues_on_a_loaded_layer(oracle):
     assert _same_tsdf(dst, src) > 20
 
 
-def test_in_place_overwrite_of_an_existing_block_is_seen(oracle):
+def test_in_place_overwrite_of_an_existing_block_is_seen(oracle, reconcile_mode):
     """deserializeMsgToLayer(kUpdate) writes new voxels into a block the layer already has and marks nothing
     (conversions_inl.h:80-88).  The sampled fingerprint of the voxel array tells; the next frame then folds into
     the overwritten values on both sides."""
@@ -188,6 +200,8 @@ def test_in_place_overwrite_of_an_existing_block_is_seen(oracle):
         for k in victims:   # a different map's values for the same block: halve the distances, double the weights
             dist, w, c, bits = d[k]
             m.tsdf_block_set(k, dist * np.float32(0.5), w * np.float32(2.0), c[:, ::-1].copy(), bits)   # bits untouched
+        if reconcile_mode < 0:
+            m.dropin_mark_edited(0)   # hip::markLayerEdited: what a caller of deserializeMsgToLayer(kUpdate) adds in this mode
         for pose, pts, col in frames[2:]:
             it.integrate(pose[0], pose[1], pts, col)
         maps.append(m)
@@ -196,7 +210,7 @@ def test_in_place_overwrite_of_an_existing_block_is_seen(oracle):
     assert st["uploaded_blocks"] == 3, st
 
 
-def test_a_single_voxel_poke_without_any_marker_is_seen(oracle):
+def test_a_single_voxel_poke_without_any_marker_is_seen(oracle, reconcile_mode):
     """The round-3/4 hole: the fingerprint sampled 8 of a block's 768 lines, so a write into ONE voxel between two sampled
     lines, with no Update bit, was overwritten by the next mirror.  The default fingerprint now covers every line: a poke
     into a single voxel (here: one whose 12 bytes lie in a line the old sampling never read) is uploaded before the next
@@ -218,6 +232,8 @@ def test_a_single_voxel_poke_without_any_marker_is_seen(oracle):
         dist = dist.copy(); w = w.copy()
         dist[v] = np.float32(-0.123); w[v] = np.float32(7.5)
         m.tsdf_block_set(victim, dist, w, c, bits)                              # bits untouched
+        if reconcile_mode < 0:
+            m.dropin_mark_edited(0)   # O(touched) mode: the poke is announced (no marker at all: mode 0, the other run of this test)
         for pose, pts, col in frames[2:]:
             it.integrate(pose[0], pose[1], pts, col)
         maps.append(m)

@@ -4,9 +4,11 @@ esdf_integrator.h:80-107 — unchanged, over the dependency stand-ins of oracle/
 place of src/integrator/tsdf_integrator.cc / esdf_integrator.cc into oracle/_ref/libvbxref_hip.so, next
 to the reference's remaining sources (block.cc, integrator_utils.cc, marching_cubes.cc, ...).  The test
 harness (oracle/ref_harness.cc) then drives voxblox's real classes — TsdfIntegratorFactory::create,
-integratePointCloud on a host Layer<TsdfVoxel>, EsdfIntegrator, the reference's CPU MeshIntegrator reading
-the mirrored host layer — exactly as it drives the pure-CPU reference build, and the resulting HOST layers
-must hash to the golden digests the reference build produced (tests/golden/reference_digests.json).
+integratePointCloud on a host Layer<TsdfVoxel>, EsdfIntegrator, and voxblox's own MeshIntegrator<TsdfVoxel> whose
+generateMesh is the HIP specialisation of voxblox_amd/host/dropin/mesh_integrator_hip.h (mesh_integrator.h:142-195,
+:250-270; round 6 — until round 5 the reference's CPU mesher read the mirrored host layer) — exactly as it drives the
+pure-CPU reference build, and the resulting HOST layers and MeshLayers must hash to the golden digests the reference
+build produced (tests/golden/reference_digests.json).
 
 The library is built where /root/reference exists (__graft_entry__.build()) and travels to the GPU box
 like every other built .so; without it the test fails loudly instead of skipping."""
@@ -31,14 +33,50 @@ TSDF_BITEXACT = [n for n in sorted(S.SCENARIOS) if S.SCENARIOS[n].get("esdf") is
 
 @pytest.mark.parametrize("name", TSDF_BITEXACT)
 def test_real_voxblox_classes_over_hip_reproduce_reference_digest(oracle, name):
-    """TSDF integrators (and, in the mesh_* scenarios, the reference's own CPU mesher consuming the
-    mirrored host layer and its kMesh bits): host Layer after every scenario == the reference's, bit for
-    bit — distances, weights, colours, updated bits."""
+    """TSDF integrators (and, in the mesh_* scenarios, voxblox's own MeshIntegrator<TsdfVoxel> class with the device
+    mesher underneath — generateMesh(true, true) after every frame or one full pass, with and without colours — filling the
+    caller's MeshLayer): host Layer after every scenario == the reference's, bit for bit — distances, weights, colours,
+    updated bits (kMesh cleared by the mesher included) — and every Mesh of the MeshLayer == the reference's: vertices,
+    normals, colours, indices, the `updated` flag, the MeshLayer's own block order."""
     L = oracle.ref_hip_lib()
+    assert L.orc_dropin_mesher() == 1, "libvbxref_hip.so was built without the mesher's specialisation"
     m = S.run_on_oracle_api(oracle, L, S.SCENARIOS[name])
     assert S.digest_tsdf(m.tsdf_dict()) == GOLD[name]["tsdf"]
     if "mesh" in GOLD[name]:
         assert S.digest_mesh(m.mesh.as_dict()) == GOLD[name]["mesh"]
+        assert oracle.timing_get(L, "mesh/generate")[0] > 0      # the timer of generateMeshOnDevice: the HIP path ran
+
+
+def test_mesher_dropin_follows_host_side_kmesh_bits(oracle):
+    """The block list of generateMesh(only_mesh_updated_blocks = true) is the HOST layer's (mesh_integrator.h:147-152).
+    Somebody clears kMesh on the host between two calls (another consumer meshed those blocks): the device still carries
+    the bits, the drop-in must not re-mesh those blocks — their Mesh::updated stays false like in the CPU build."""
+    H, R = oracle.ref_hip_lib(), oracle.ref_lib()
+    sc = S.SCENARIOS["mesh_fast_0p05_incremental"]
+    frames = S.frames(sc["n"])
+    import ctypes as C
+    out = []
+    for L in (H, R):
+        L.orc_fast_reset_counter_set(0)
+        m = oracle.OracleMap(sc["voxel"], 16, L=L)
+        c = oracle.TsdfCfg()
+        L.orc_tsdf_cfg_default(C.byref(c))
+        c.default_truncation_distance = 4 * sc["voxel"]
+        c.integrator_threads = 1
+        it = m.tsdf_integrator("fast", c)
+        ml = m.mesh_layer()
+        for k, (pose, pts, col) in enumerate(frames):
+            it.integrate(pose[0], pose[1], pts, col)
+            if k == 1:   # the host clears kMesh (bit 1) on half of the updated blocks, voxels untouched
+                d = m.tsdf_dict()
+                for j, key in enumerate(sorted(d)):
+                    if j % 2 == 0 and (d[key][3] & 2):
+                        m.tsdf_block_set(key, d[key][0], d[key][1], d[key][2], d[key][3] & ~2)
+            ml.clear_updated()
+            ml.generate(only_mesh_updated_blocks=True, clear_updated_flag=True, use_color=True, min_weight=1e-4)
+        out.append((S.digest_tsdf(m.tsdf_dict()), S.digest_mesh(ml.as_dict()), {k: v["updated"] for k, v in ml.as_dict().items()}))
+    assert out[0][2] == out[1][2], "the set of re-meshed blocks differs from the CPU build's"
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
 
 
 def test_real_voxblox_esdf_class_over_hip(oracle):

@@ -139,6 +139,30 @@ def _rank_worker(rank, world, port, path, out_dir, n_steps, width, height, f, vo
             sm.end_step()
     if path == "native":
         sm.wait()
+    # self-diagnosis for the first box with several GPUs (the driver's scaling run is the first time RCCL runs with more than
+    # one rank): what every rank saw of the communicator and what it moved, gathered through the SAME RCCL group and printed once
+    st = sm.stats() if path == "native" else dict(sm.stats)
+    mine = {"rank": rank, "world_seen_by_torch": dist.get_world_size(), "backend": dist.get_backend(),
+            "device": torch.cuda.get_device_name(rank), "device_index": rank, "path": path,
+            "steps": int(st.get("steps", st.get("frames", 0))), "sent_blocks": int(st.get("sent_blocks", 0)),
+            "received_blocks": int(st.get("received_blocks", 0)), "payload_bytes": int(st.get("payload_bytes", 0))}
+    # an all-reduce over the device tensors: proves the RCCL ring itself spans `world` ranks (sum of ranks = world (world - 1) / 2)
+    t = torch.tensor([float(rank)], device=dev)
+    dist.all_reduce(t)
+    mine["rccl_allreduce_sum_of_ranks"] = float(t.item())
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank == 0:
+        print(f"[multi-GPU diagnosis] path={path} world={world} RCCL all-reduce of ranks = {mine['rccl_allreduce_sum_of_ranks']} "
+              f"(expected {world * (world - 1) / 2})", flush=True)
+        for e in everyone:
+            print("[multi-GPU diagnosis] rank %(rank)d on %(device)s (cuda:%(device_index)d): %(steps)d steps, sent %(sent_blocks)d blocks / "
+                  "%(payload_bytes)d B, received %(received_blocks)d rows as owner" % e, flush=True)
+        import json
+        scratch = os.path.join(ROOT, "gpurun_out")
+        with open(os.path.join(scratch if os.path.isdir(scratch) else out_dir, f"multi_gpu_diagnosis_{path}.json"), "w") as fh:
+            json.dump(everyone, fh, indent=1)
+    assert mine["rccl_allreduce_sum_of_ranks"] == world * (world - 1) / 2
     sm.close()
     torch.cuda.synchronize()
     owned = pm.tsdf_dict()

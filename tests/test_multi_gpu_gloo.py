@@ -299,3 +299,102 @@ def test_ray_bundle_layout_is_the_same_for_every_world_size():
     assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(3))
     # explicit layouts for the parity tests
     assert [u for units in multi_gpu.deal_sensor_units(1, bands=1) for u in units] == [(s, 0, 1) for s in range(4)]
+
+
+def _worker_bench_loop(rank, world, port, out_q):
+    """One rank of bench.py's N > 1 timed region (bench.sharded_stream_timed: warm-up, flush, barrier-bracketed timed frames,
+    MAX over ranks) over gloo with the oracle-backed map — the real world size of the driver's scaling run, no GPU."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import oracle_py as O
+    import bench
+    from voxblox_amd import multi_gpu, scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    voxel = 0.1
+    cfg = O.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
+    sm = multi_gpu.PipelinedShardedTsdfMap(OracleBackend(O, voxel), [OracleBackend(O, voxel), OracleBackend(O, voxel)], rank, world, dist)
+    # bench.stream_frames: every rank its own sensor along the same trajectory (weak scaling); small frames keep eight CPU ranks short
+    frames = []
+    for k in range(5):
+        pose, pts, col = scenes.room_frame((k + rank * 100 // world) % 100, 100, f=40.0, width=80, height=60)
+        frames.append((pose, pts, col, pts.shape[0]))
+    n_barriers = [0]
+
+    def barrier():
+        n_barriers[0] += 1
+        dist.barrier()
+
+    warmup, total = 2, 5
+    dt = bench.sharded_stream_timed(sm, frames, "fast", cfg, warmup, total, barrier, dist, world, "cpu")
+    stats = dict(sm.stats)
+    sm.close()
+    owned = {tuple(int(v) for v in i): sm.p.m.tsdf_block(i) for i in sm.p.block_indices()}
+    out_q.put((rank, dt, stats, n_barriers[0], owned))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_at_world_size_8_over_gloo(oracle):
+    """The driver's scaling run is the first time more than one RCCL rank ever executes (one GPU per development box).  What
+    can be checked without the hardware is everything around the collectives at the REAL world size: eight ranks run bench.py's
+    own timed region (bench.sharded_stream_timed) over gloo — nobody deadlocks (the pipelined exchange issues its collectives
+    from a worker thread), every rank ends on the same MAX-over-ranks time, two barriers bracket the timed frames, every rank
+    sent blocks, the owners partition the union of the blocks, and the merged map equals the serial oracle shard + merge."""
+    import torch.multiprocessing as mp
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_loop, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    results.sort(key=lambda t: t[0])
+    dts = [r[1] for r in results]
+    assert all(d == dts[0] for d in dts) and dts[0] > 0, dts            # the all_reduce(MAX): one number on every rank
+    merged = {}
+    for rank, dt, stats, n_barriers, owned in results:
+        assert n_barriers == 2                                           # barrier + sync on both sides of the timed frames
+        assert stats["frames"] == 3 and stats["payload_bytes"] > 0      # the counters cover exactly the timed frames
+        assert not (set(owned) & set(merged)), "a block is owned by two ranks"
+        merged.update(owned)
+    from voxblox_amd import multi_gpu, scenes
+    for rank, _, _, _, owned in results:
+        keys = np.array(list(owned.keys()), np.int32).reshape(-1, 3)
+        if keys.shape[0]:
+            assert np.all(multi_gpu.owner_of(keys, world) == rank)
+    # serial restatement of all five frames (warm-up frames land in the same persistent map): per frame, every rank's cloud
+    # into a fresh delta, merged in rank order
+    voxel = 0.1
+    cfg = oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1)
+    ref = {}
+    for k in range(5):
+        step = {}   # the owner adds the rows of one block in sender order, then folds the sum in ONCE (vbx_blocks_merge_sums)
+        for rank in range(world):
+            pose, pts, col = scenes.room_frame((k + rank * 100 // world) % 100, 100, f=40.0, width=80, height=60)
+            oracle.lib().orc_fast_reset_counter_set(0)
+            m = oracle.OracleMap(voxel, 16)
+            m.tsdf_integrator("fast", cfg).integrate(pose[0], pose[1], pts, col)
+            for key, (d, w, c, _) in m.tsdf_dict().items():
+                sA = np.stack([w * d, w] + [w * c[:, ch].astype(np.float32) for ch in range(4)])
+                step[key] = step[key] + sA if key in step else sA
+        for key, sA in step.items():
+            if not (sA[1] > 0).any():
+                continue
+            dB, wB, cB = ref.get(key, (np.zeros(4096, np.float32), np.zeros(4096, np.float32), np.zeros((4096, 4), np.uint8)))
+            ref[key] = merge_A_into_B(sA, dB, wB, cB)
+    assert set(merged) == set(ref), (len(merged), len(ref))
+    for key in ref:
+        gd, gw, gc, _ = merged[key]
+        rd, rw, rc = ref[key]
+        assert np.array_equal(gw > 0, rw > 0)
+        assert np.allclose(gw, rw, rtol=1e-5, atol=1e-6)
+        assert np.abs(gd - rd).max() <= 1e-5
+        assert np.abs(gc.astype(np.int32) - rc.astype(np.int32)).max() <= 1
+    assert len({multi_gpu.owner_of(np.array([k], np.int32), world)[0] for k in merged}) == world   # every rank owns something

@@ -28,18 +28,55 @@
 namespace voxblox {
 namespace hip {
 
-/// What the mirror last left in (or last took from) one host block: the Block object's address (kReplace /
-/// removeBlock + re-allocate put a NEW object under the same BlockIndex, layer_inl.h:203-210), its Update bits
-/// (consumers only ever clear bits: mesh_integrator.h:181, esdf_integrator.cc:116-118; bits that appear were set
-/// by the host — Block::mergeBlock block_inl.h:120, Layer::addBlockFromProto layer_inl.h:227) and a sampled
-/// fingerprint of the voxel array (in-place writes without any marker: deserializeMsgToLayer's kUpdate,
-/// conversions_inl.h:80-88).
+/// What the mirror last left in (or last took from) one host block: the Block object itself — a shared reference, so that
+/// the object stays readable even after the Layer dropped it and `use_count() == 1` says exactly that (removeBlock,
+/// removeDistantBlocks; kReplace / removeBlock + re-allocate put a NEW object under the same BlockIndex,
+/// layer_inl.h:203-210) —, its Update bits (consumers only ever clear bits: mesh_integrator.h:181,
+/// esdf_integrator.cc:116-118; bits that appear were set by the host — Block::mergeBlock block_inl.h:120,
+/// Layer::addBlockFromProto layer_inl.h:227) and two fingerprints of the voxel array (in-place writes without any marker:
+/// deserializeMsgToLayer's kUpdate, conversions_inl.h:80-88): every 64-byte line, and kSampledLines spread lines.
+template <typename VoxelType>
 struct HostBlockRecord {
-  const void* block = nullptr;
+  BlockIndex index = BlockIndex::Zero();
+  typename Block<VoxelType>::Ptr block;
   uint8_t bits = 0;
-  uint64_t fingerprint = 0;
+  uint64_t fingerprint = 0;   // every line
+  uint64_t sampled = 0;       // kSampledLines lines
 };
-typedef AnyIndexHashMapType<HostBlockRecord>::type HostBlockRecords;  // block_hash.h:33-41
+constexpr int kSampledLines = 8;
+
+/// The blocks the device holds, as the host last saw them: a dense array (the per-call scan walks it with prefetches, on
+/// helper threads when it is long) + BlockIndex -> position.
+template <typename VoxelType>
+struct KnownBlocks {
+  typedef HostBlockRecord<VoxelType> Rec;
+  std::vector<Rec> recs;
+  typename AnyIndexHashMapType<size_t>::type pos;   // block_hash.h:33-41
+  size_t cursor = 0;                                // rotating window of the touched-only reconcile
+  size_t size() const { return recs.size(); }
+  bool empty() const { return recs.empty(); }
+  void clear() { recs.clear(); pos.clear(); cursor = 0; }
+  Rec* find(const BlockIndex& bi) {
+    auto it = pos.find(bi);
+    return it == pos.end() ? nullptr : &recs[it->second];
+  }
+  Rec& operator[](const BlockIndex& bi) {
+    auto it = pos.find(bi);
+    if (it != pos.end()) return recs[it->second];
+    pos.emplace(bi, recs.size());
+    recs.emplace_back();
+    recs.back().index = bi;
+    return recs.back();
+  }
+  void erase(size_t i) {   // swap with the last
+    pos.erase(recs[i].index);
+    if (i + 1 != recs.size()) {
+      recs[i] = std::move(recs.back());
+      pos[recs[i].index] = i;
+    }
+    recs.pop_back();
+  }
+};
 
 /// Page-locked staging for the device-to-host copies of the mirror (grows, never shrinks; plain memory if pinning fails).
 struct PinnedStaging {
@@ -59,7 +96,9 @@ struct DeviceMirror {
   std::atomic<int> pins{0};                      // drop-in calls in flight on this mirror (MirrorRef); never evicted while > 0
   uint64_t frames_integrated = 0;                // > 0: the device holds integrator state the host layer does not
                                                  // (FastTsdfIntegrator's approximate sets and frame counter)
-  HostBlockRecords tsdf_known, esdf_known;       // the blocks the device holds, as the host last saw them
+  KnownBlocks<TsdfVoxel> tsdf_known;             // the blocks the device holds, as the host last saw them
+  KnownBlocks<EsdfVoxel> esdf_known;
+  bool tsdf_check_all = false, esdf_check_all = false;   // markLayerEdited: the next reconcile fingerprints every line of every block
   std::vector<TsdfVoxel> tsdf_staging;           // host -> device (reconcile)
   std::vector<EsdfVoxel> esdf_staging;
   PinnedStaging down_staging;                    // device -> host (mirror)
@@ -98,8 +137,21 @@ void releaseMirror(const Layer<TsdfVoxel>* tsdf_layer);
 /// HOST -> DEVICE, on entry to every drop-in call.  The host Layer is the source of truth between calls: its
 /// callers edit it directly (Layer::removeDistantBlocks tsdf_server.cc:315, removeAllBlocks, io::LoadBlocksFromFile
 /// :566-578, deserializeMsgToLayer :639-653).  Blocks the host no longer has are removed on the device
-/// (vbx_blocks_remove), blocks that are new, replaced, carry Update bits the mirror did not leave, or whose
-/// sampled voxel fingerprint moved are uploaded (vbx_blocks_upload) — one batched call each.
+/// (vbx_blocks_remove), blocks that are new, replaced, carry Update bits the mirror did not leave, or whose voxel
+/// fingerprint moved are uploaded (vbx_blocks_upload) — one batched call each.
+///
+/// What a call looks at (reconcileMode()):
+///   -1 (default) O(touched), the reference's own cost model (its integrators only ever visit the blocks a cloud
+///      touches): a pass over the mirror's OWN records — is the Block object still the Layer's (use_count), did Update
+///      bits appear — which finds removals, replacements, merges and loads without a hash lookup or a voxel read, plus a
+///      rotating window of kWindowBlocks blocks per call that are looked up in the Layer and compared by their sampled
+///      fingerprint (so small maps are checked whole every call and big ones in turn), plus a membership scan when the
+///      Layer's block count differs from the mirror's.  An IN-PLACE overwrite without any marker outside the window is the
+///      one edit this mode does not see at once: announce it (markLayerEdited / markBlockEdited), or run mode 0;
+///    0 every 64-byte line of every host block on every call (round 5's default; O(map): 12 MB per 251 blocks);
+///   >0 the sampled fingerprint of every host block on every call (rounds 3-4).
+/// VBX_DROPIN_FINGERPRINT_LINES in the environment sets the start value (unset = -1), vbx_dropin_set_reconcile_mode(int)
+/// changes it.
 void reconcileTsdfFromHost(DeviceMirror& dev, Layer<TsdfVoxel>* tsdf_layer);
 void reconcileEsdfFromHost(DeviceMirror& dev, Layer<EsdfVoxel>* esdf_layer);
 
@@ -116,11 +168,23 @@ void mirrorStats(const Layer<TsdfVoxel>* tsdf_layer, uint64_t* uploaded_blocks, 
 /// fixed point.  Process-wide; also exported from the drop-in as extern "C" vbx_dropin_set_esdf_reference_order(int).
 std::atomic<int>& esdfReferenceOrder();
 
-/// Fingerprint of a block's voxel array.  Default: EVERY 64-byte line (a single-voxel poke anywhere in the block moves it:
-/// each line is folded with odd multipliers — a change of one word changes the line's value — and passed through a
-/// bijective finaliser before the lines are summed, so lines can be hashed independently and in any order).
-/// VBX_DROPIN_FINGERPRINT_LINES = n > 0 samples n evenly spread lines instead (cheaper, blind between the samples).
-uint64_t voxelFingerprint(const void* voxels, size_t bytes);
+/// The reconcile mode (see above), process-wide.
+std::atomic<int>& reconcileMode();
+constexpr size_t kWindowBlocks = 256;
+/// The caller wrote voxels of `layer` in place without touching Update bits (deserializeMsgToLayer's kUpdate): the next
+/// drop-in call on the layer compares every line of every block (markLayerEdited) / uploads the named block
+/// (markBlockEdited).  Not needed for removeBlock / removeDistantBlocks / removeAllBlocks / LoadBlocksFromFile /
+/// mergeBlock / addBlockFromProto — those change the Block object, the block count or the Update bits — nor in mode 0.
+/// Also exported as extern "C" vbx_dropin_mark_layer_edited(const void* tsdf_or_esdf_layer).
+void markLayerEdited(const Layer<TsdfVoxel>* tsdf_layer);
+void markLayerEdited(const Layer<EsdfVoxel>* esdf_layer);
+void markBlockEdited(const Layer<TsdfVoxel>* tsdf_layer, const BlockIndex& block_index);
+
+/// Fingerprint of a block's voxel array over `lines` evenly spread 64-byte lines (0: EVERY line — a single-voxel poke
+/// anywhere in the block moves it: each line is folded with odd multipliers — a change of one word changes the line's
+/// value — and passed through a bijective finaliser before the lines are summed, so lines can be hashed independently
+/// and in any order).
+uint64_t voxelFingerprint(const void* voxels, size_t bytes, int lines = 0);
 
 /// f(0) .. f(n-1) on the calling thread plus a few persistent helpers (VBX_DROPIN_THREADS, default min(8, hardware));
 /// returns when all are done.  The per-call passes over whole blocks (fingerprints, voxel copies) are memory-bound.

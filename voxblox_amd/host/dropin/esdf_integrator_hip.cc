@@ -37,22 +37,24 @@ void mirrorEsdfToHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
   CHECK_EQ(vbx_blocks_download(dev.ctx, VBX_LAYER_ESDF, dev.idx.data(), n, staging, dev.bits.data(), dev.has_data.data()), VBX_OK)
       << vbx_last_error(dev.ctx);
   std::vector<Block<EsdfVoxel>::Ptr> blocks(n);
-  std::vector<uint64_t> fps(n);
+  std::vector<uint64_t> fps(n), fps_s(n);
   for (size_t i = 0; i < n; ++i)
     blocks[i] = layer->allocateBlockPtrByIndex(BlockIndex(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]));
   parallelFor(n, [&](size_t i) {
     const EsdfVoxel* src = staging + i * nv;
     std::memcpy(static_cast<void*>(&blocks[i]->getVoxelByLinearIndex(0)), src, nv * sizeof(EsdfVoxel));
-    fps[i] = voxelFingerprint(src, nv * sizeof(EsdfVoxel));
+    fps[i] = voxelFingerprint(src, nv * sizeof(EsdfVoxel), 0);
+    fps_s[i] = voxelFingerprint(src, nv * sizeof(EsdfVoxel), kSampledLines);
   });
   for (size_t i = 0; i < n; ++i) {
     const BlockIndex bi(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]);
     Block<EsdfVoxel>::Ptr& block = blocks[i];
     block->updated() |= std::bitset<Update::kCount>(dev.bits[i]);  // set_updated(true): kMap only (:147)
-    HostBlockRecord& rec = dev.esdf_known[bi];
-    rec.block = block.get();
+    HostBlockRecord<EsdfVoxel>& rec = dev.esdf_known[bi];
+    rec.block = block;
     rec.bits = static_cast<uint8_t>(block->updated().to_ulong());
     rec.fingerprint = fps[i];
+    rec.sampled = fps_s[i];
   }
   // the device's copy of the block's Update bits is only a carrier towards the host (nothing on the device reads an
   // ESDF block's bits): clear it with the dirty mark, so that a block the wavefront touches later does not bring a

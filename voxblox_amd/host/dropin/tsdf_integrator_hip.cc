@@ -42,14 +42,6 @@ void destroyMirror(DeviceMirror* m) {
 // (No cleanup at process exit: the HIP runtime may already be gone when static destructors run; the driver frees
 // a dying process's device memory.  Long-lived processes drop maps through releaseMirror() or the LRU bound.)
 
-int fingerprintLines() {
-  static const int lines = [] {
-    const char* e = getenv("VBX_DROPIN_FINGERPRINT_LINES");
-    return e ? atoi(e) : 0;   // 0 = every line (round 5; rounds 3-4 sampled 8 of a block's 768 lines by default)
-  }();
-  return lines;
-}
-
 // ---- a handful of persistent helper threads for the per-call passes over whole blocks ---------------------------------
 class Helpers {
  public:
@@ -139,14 +131,21 @@ PinnedStaging::~PinnedStaging() {
   if (pinned) vbx_host_free(p); else free(p);
 }
 
-uint64_t voxelFingerprint(const void* voxels, size_t bytes) {
+std::atomic<int>& reconcileMode() {
+  static std::atomic<int> v([] {
+    const char* e = getenv("VBX_DROPIN_FINGERPRINT_LINES");
+    return (e && e[0]) ? atoi(e) : -1;   // unset: the O(touched) reconcile (round 6); 0: every line of every block (round 5); n: sampled (rounds 3-4)
+  }());
+  return v;
+}
+
+uint64_t voxelFingerprint(const void* voxels, size_t bytes, int want) {
   // Per 64-byte line: the eight 8-byte words folded with odd multipliers (a change of any one word changes the sum), the
   // line number mixed in, a bijective finaliser (murmur3's fmix64) on top; the block's fingerprint is the SUM of its lines'
   // values — independent per line, so the pass is eight multiply chains wide and memory-bound.
   static const uint64_t K[8] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0xD6E8FEB86659FD93ull,
                                 0xFF51AFD7ED558CCDull, 0xC4CEB9FE1A85EC53ull, 0x2545F4914F6CDD1Dull, 0x9FB21C651E98DF25ull};
   const size_t n_lines = bytes / 64;
-  const int want = fingerprintLines();
   const size_t lines = (want <= 0 || (size_t)want > n_lines) ? n_lines : (size_t)want;
   const unsigned char* base = static_cast<const unsigned char*>(voxels);
   uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
@@ -232,82 +231,191 @@ void mirrorStats(const Layer<TsdfVoxel>* layer, uint64_t* uploaded_blocks, uint6
   if (removed_blocks) *removed_blocks = it == table().end() ? 0 : it->second->removed_blocks;
 }
 
+void markLayerEdited(const Layer<TsdfVoxel>* layer) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = table().find(layer);
+  if (it != table().end()) it->second->tsdf_check_all = true;   // (no mirror yet: everything is uploaded at the first call anyway)
+}
+void markLayerEdited(const Layer<EsdfVoxel>* layer) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  for (auto& kv : table())
+    if (kv.second && kv.second->esdf_layer == layer) kv.second->esdf_check_all = true;
+}
+void markBlockEdited(const Layer<TsdfVoxel>* layer, const BlockIndex& block_index) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = table().find(layer);
+  if (it == table().end()) return;
+  // a fingerprint that cannot match: the block goes up at the next call's window / scan — the record is put where the
+  // rotating window starts, so the very next reconcile looks at it
+  KnownBlocks<TsdfVoxel>& known = it->second->tsdf_known;
+  HostBlockRecord<TsdfVoxel>* rec = known.find(block_index);
+  if (!rec) return;   // unknown to the mirror: found as a new block anyway
+  rec->block.reset();   // "replaced": the scan's use_count test sends it through the upload path
+}
+
 namespace {
 // Shared by the two layers: which host blocks must go up, which device blocks must go.
 template <typename VoxelType>
-void reconcileFromHost(DeviceMirror& dev, Layer<VoxelType>* layer, int vbx_layer, HostBlockRecords* known,
-                       std::vector<VoxelType>* staging) {
+void reconcileFromHost(DeviceMirror& dev, Layer<VoxelType>* layer, int vbx_layer, KnownBlocks<VoxelType>* known,
+                       std::vector<VoxelType>* staging, bool* check_all) {
+  typedef HostBlockRecord<VoxelType> Rec;
   const size_t nv = layer->voxels_per_side() * layer->voxels_per_side() * layer->voxels_per_side();
-  if (layer->getNumberOfAllocatedBlocks() == 0u) {  // removeAllBlocks(), or a new Layer at a recycled address
+  const size_t bytes = nv * sizeof(VoxelType);
+  const size_t host_n = layer->getNumberOfAllocatedBlocks();
+  if (host_n == 0u) {  // removeAllBlocks(), or a new Layer at a recycled address
     if (!known->empty()) {
       CHECK_EQ(vbx_clear(dev.ctx, vbx_layer), VBX_OK) << vbx_last_error(dev.ctx);
       dev.removed_blocks += known->size();
       known->clear();
     }
+    *check_all = false;
     return;
   }
-  BlockIndexList host_blocks;
-  layer->getAllAllocatedBlocks(&host_blocks);
-  // 1. blocks the host dropped (removeDistantBlocks, removeBlock)
-  if (known->size() > 0) {
-    std::vector<int32_t> gone;
-    for (auto it = known->begin(); it != known->end();) {
-      if (layer->hasBlock(it->first)) {
-        ++it;
+  int mode = reconcileMode().load(std::memory_order_relaxed);
+  if (*check_all) mode = 0;
+  *check_all = false;
+  std::vector<int32_t> gone;
+  std::vector<typename Block<VoxelType>::Ptr> up;   // blocks to upload, with their indices in dev.idx
+  std::vector<BlockIndex> up_idx;
+  auto note_gone = [&](const BlockIndex& bi) {
+    gone.push_back(bi.x());
+    gone.push_back(bi.y());
+    gone.push_back(bi.z());
+  };
+  if (mode < 0) {
+    // ---- O(touched).  1. the mirror's own records: is the object still the Layer's, did Update bits appear?  No hash
+    // lookup, no voxel read: one or two cache lines per block (the shared_ptr's control block sits in front of the Block it
+    // was made with), prefetched ahead, on the helper threads when the map is large.
+    std::vector<Rec>& recs = known->recs;
+    const size_t n = recs.size();
+    std::vector<uint8_t> suspect(n, 0);
+    auto scan = [&](size_t lo, size_t hi) {
+      constexpr size_t kAhead = 8;
+      for (size_t i = lo; i < hi; ++i) {
+        if (i + kAhead < hi && recs[i + kAhead].block) __builtin_prefetch(recs[i + kAhead].block.get());
+        Rec& r = recs[i];
+        if (!r.block || r.block.use_count() <= 1) { suspect[i] = 1; continue; }   // dropped or replaced (or markBlockEdited)
+        const uint8_t bits = static_cast<uint8_t>(r.block->updated().to_ulong());
+        if (bits & ~r.bits) suspect[i] = 1;   // the host set bits: merged / loaded into
+        else r.bits = bits;                   // consumers cleared bits: remember, so that a later set() shows
+      }
+    };
+    constexpr size_t kChunk = 2048;
+    if (n <= 2 * kChunk) scan(0, n);
+    else parallelFor((n + kChunk - 1) / kChunk, [&](size_t c) { scan(c * kChunk, std::min(n, (c + 1) * kChunk)); });
+    // 2. a rotating window: looked up in the Layer (identity) and compared by the sampled fingerprint
+    const size_t w = std::min(n, kWindowBlocks);
+    std::vector<size_t> win(w);
+    for (size_t k = 0; k < w; ++k) win[k] = (known->cursor + k) % n;
+    known->cursor = n ? (known->cursor + w) % n : 0;
+    std::vector<typename Block<VoxelType>::Ptr> win_block(w);
+    for (size_t k = 0; k < w; ++k)
+      if (!suspect[win[k]]) win_block[k] = layer->getBlockPtrByIndex(recs[win[k]].index);
+    parallelFor(w, [&](size_t k) {
+      const size_t i = win[k];
+      if (suspect[i]) return;
+      if (win_block[k].get() != recs[i].block.get() ||
+          voxelFingerprint(&win_block[k]->getVoxelByLinearIndex(0), bytes, kSampledLines) != recs[i].sampled)
+        suspect[i] = 1;
+    });
+    // 3. the suspects: what does the Layer hold under that index now?  (descending, so that erase()'s swap never moves an
+    // unvisited suspect)
+    for (size_t i = n; i-- > 0;) {
+      if (!suspect[i]) continue;
+      const BlockIndex bi = recs[i].index;
+      typename Block<VoxelType>::Ptr now = layer->getBlockPtrByIndex(bi);
+      if (!now) {
+        note_gone(bi);
+        known->erase(i);
+      } else {
+        up.push_back(now);
+        up_idx.push_back(bi);
+      }
+    }
+    // 4. blocks the mirror has never seen (created by the host: loadMap, tsdfMapCallback), or a removal the scan could not
+    // see because somebody else still holds the object: the counts tell, and only then is the Layer walked
+    if (known->size() != host_n) {
+      BlockIndexList host_blocks;
+      layer->getAllAllocatedBlocks(&host_blocks);
+      for (const BlockIndex& bi : host_blocks) {
+        if (known->find(bi)) continue;
+        up.push_back(layer->getBlockPtrByIndex(bi));
+        up_idx.push_back(bi);
+        (*known)[bi];   // (filled in below)
+      }
+      if (known->size() != host_n) {
+        for (size_t i = known->size(); i-- > 0;) {
+          if (layer->hasBlock(known->recs[i].index)) continue;
+          note_gone(known->recs[i].index);
+          known->erase(i);
+        }
+      }
+    }
+  } else {
+    // ---- every host block, every call: all lines (mode 0) or the sampled ones (mode > 0)
+    BlockIndexList host_blocks;
+    layer->getAllAllocatedBlocks(&host_blocks);
+    // 1. blocks the host dropped (removeDistantBlocks, removeBlock)
+    for (size_t i = known->size(); i-- > 0;) {
+      if (layer->hasBlock(known->recs[i].index)) continue;
+      note_gone(known->recs[i].index);
+      known->erase(i);
+    }
+    // 2. blocks the host created, replaced or wrote to
+    std::vector<typename Block<VoxelType>::Ptr> all(host_blocks.size());
+    std::vector<uint64_t> all_fp(host_blocks.size());
+    {
+      size_t k = 0;
+      for (const BlockIndex& bi : host_blocks) all[k++] = layer->getBlockPtrByIndex(bi);
+    }
+    const int lines = mode == 0 ? 0 : kSampledLines;
+    parallelFor(all.size(), [&](size_t i) { all_fp[i] = voxelFingerprint(&all[i]->getVoxelByLinearIndex(0), bytes, lines); });
+    size_t k_block = 0;
+    for (const BlockIndex& bi : host_blocks) {
+      typename Block<VoxelType>::Ptr& block = all[k_block];
+      const uint64_t fp = all_fp[k_block++];
+      const uint8_t bits = static_cast<uint8_t>(block->updated().to_ulong());
+      Rec* rec = known->find(bi);
+      if (rec && rec->block.get() == block.get() && (bits & ~rec->bits) == 0 && (mode == 0 ? rec->fingerprint : rec->sampled) == fp) {
+        rec->bits = bits;  // consumers cleared bits: remember, so that a later set() shows
         continue;
       }
-      gone.push_back(it->first.x());
-      gone.push_back(it->first.y());
-      gone.push_back(it->first.z());
-      it = known->erase(it);
-    }
-    if (!gone.empty()) {
-      CHECK_EQ(vbx_blocks_remove(dev.ctx, vbx_layer, gone.data(), gone.size() / 3), VBX_OK) << vbx_last_error(dev.ctx);
-      dev.removed_blocks += gone.size() / 3;
+      up.push_back(block);
+      up_idx.push_back(bi);
     }
   }
-  // 2. blocks the host created, replaced or wrote to: every block's voxel array is fingerprinted in full (helper threads)
+  if (!gone.empty()) {
+    CHECK_EQ(vbx_blocks_remove(dev.ctx, vbx_layer, gone.data(), gone.size() / 3), VBX_OK) << vbx_last_error(dev.ctx);
+    dev.removed_blocks += gone.size() / 3;
+  }
+  if (up.empty()) return;
   dev.idx.clear();
   dev.bits.clear();
   dev.has_data.clear();
-  std::vector<typename Block<VoxelType>::Ptr> all(host_blocks.size());
-  std::vector<uint64_t> all_fp(host_blocks.size());
-  {
-    size_t k = 0;
-    for (const BlockIndex& bi : host_blocks) all[k++] = layer->getBlockPtrByIndex(bi);
-  }
-  parallelFor(all.size(), [&](size_t i) { all_fp[i] = voxelFingerprint(&all[i]->getVoxelByLinearIndex(0), nv * sizeof(VoxelType)); });
-  std::vector<typename Block<VoxelType>::Ptr> up;
-  std::vector<uint64_t> up_fp;
-  size_t k_block = 0;
-  for (const BlockIndex& bi : host_blocks) {
-    typename Block<VoxelType>::Ptr& block = all[k_block];
-    const uint64_t fp = all_fp[k_block++];
-    const uint8_t bits = static_cast<uint8_t>(block->updated().to_ulong());
-    auto it = known->find(bi);
-    if (it != known->end() && it->second.block == block.get() && (bits & ~it->second.bits) == 0 &&
-        it->second.fingerprint == fp) {
-      it->second.bits = bits;  // consumers cleared bits: remember, so that a later set() shows
-      continue;
-    }
-    up.push_back(block);
-    up_fp.push_back(fp);
+  staging->resize(up.size() * nv);
+  std::vector<uint64_t> fp_all(up.size()), fp_s(up.size());
+  parallelFor(up.size(), [&](size_t i) {
+    const void* src = &up[i]->getVoxelByLinearIndex(0);
+    std::memcpy(static_cast<void*>(staging->data() + i * nv), src, bytes);
+    fp_all[i] = voxelFingerprint(src, bytes, 0);
+    fp_s[i] = voxelFingerprint(src, bytes, kSampledLines);
+  });
+  for (size_t i = 0; i < up.size(); ++i) {
+    const BlockIndex& bi = up_idx[i];
+    const uint8_t bits = static_cast<uint8_t>(up[i]->updated().to_ulong());
     dev.idx.push_back(bi.x());
     dev.idx.push_back(bi.y());
     dev.idx.push_back(bi.z());
     // kMap is the MIRROR's dirty bit on the device (a block uploaded from the host is not dirty); kMesh / kEsdf
     // travel: the device-side ESDF update must see a loaded block as updated (esdf_integrator.cc:104-110)
     dev.bits.push_back(static_cast<uint8_t>(bits & ~VBX_UPDATE_MAP));
-    dev.has_data.push_back(block->has_data() ? 1 : 0);
-    HostBlockRecord& rec = (*known)[bi];
-    rec.block = block.get();
+    dev.has_data.push_back(up[i]->has_data() ? 1 : 0);
+    Rec& rec = (*known)[bi];
+    rec.block = up[i];
     rec.bits = bits;
-    rec.fingerprint = fp;
+    rec.fingerprint = fp_all[i];
+    rec.sampled = fp_s[i];
   }
-  if (up.empty()) return;
-  staging->resize(up.size() * nv);
-  for (size_t i = 0; i < up.size(); ++i)
-    std::memcpy(static_cast<void*>(staging->data() + i * nv), &up[i]->getVoxelByLinearIndex(0), nv * sizeof(VoxelType));
   CHECK_EQ(vbx_blocks_upload(dev.ctx, vbx_layer, dev.idx.data(), up.size(), staging->data(), dev.bits.data(),
                              dev.has_data.data()),
            VBX_OK)
@@ -318,12 +426,12 @@ void reconcileFromHost(DeviceMirror& dev, Layer<VoxelType>* layer, int vbx_layer
 
 void reconcileTsdfFromHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
   static_assert(sizeof(TsdfVoxel) == 12, "TsdfVoxel is {float distance; float weight; Color color}");
-  reconcileFromHost<TsdfVoxel>(dev, layer, VBX_LAYER_TSDF, &dev.tsdf_known, &dev.tsdf_staging);
+  reconcileFromHost<TsdfVoxel>(dev, layer, VBX_LAYER_TSDF, &dev.tsdf_known, &dev.tsdf_staging, &dev.tsdf_check_all);
 }
 
 void reconcileEsdfFromHost(DeviceMirror& dev, Layer<EsdfVoxel>* layer) {
   static_assert(sizeof(EsdfVoxel) == 20, "EsdfVoxel is {float distance; bool observed, hallucinated, in_queue, fixed; Vector3i parent}");
-  reconcileFromHost<EsdfVoxel>(dev, layer, VBX_LAYER_ESDF, &dev.esdf_known, &dev.esdf_staging);
+  reconcileFromHost<EsdfVoxel>(dev, layer, VBX_LAYER_ESDF, &dev.esdf_known, &dev.esdf_staging, &dev.esdf_check_all);
 }
 
 void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
@@ -356,13 +464,14 @@ void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
   CHECK_EQ(vbx_blocks_download(dev.ctx, VBX_LAYER_TSDF, dev.idx.data(), n, staging, dev.bits.data(), dev.has_data.data()), VBX_OK)
       << vbx_last_error(dev.ctx);
   std::vector<Block<TsdfVoxel>::Ptr> blocks(n);
-  std::vector<uint64_t> fps(n);
+  std::vector<uint64_t> fps(n), fps_s(n);
   for (size_t i = 0; i < n; ++i)   // (the Layer's container is not thread-safe: allocation stays on this thread)
     blocks[i] = layer->allocateBlockPtrByIndex(BlockIndex(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]));
   parallelFor(n, [&](size_t i) {
     const TsdfVoxel* src = staging + i * nv;
     std::memcpy(static_cast<void*>(&blocks[i]->getVoxelByLinearIndex(0)), src, nv * sizeof(TsdfVoxel));
-    fps[i] = voxelFingerprint(src, nv * sizeof(TsdfVoxel));
+    fps[i] = voxelFingerprint(src, nv * sizeof(TsdfVoxel), 0);
+    fps_s[i] = voxelFingerprint(src, nv * sizeof(TsdfVoxel), kSampledLines);
   });
   for (size_t i = 0; i < n; ++i) {
     const BlockIndex bi(dev.idx[3 * i], dev.idx[3 * i + 1], dev.idx[3 * i + 2]);
@@ -371,10 +480,11 @@ void mirrorTsdfToHost(DeviceMirror& dev, Layer<TsdfVoxel>* layer) {
     // cleared since (mesher: kMesh, ESDF: kEsdf) come back only if the device set them again
     block->updated() |= std::bitset<Update::kCount>(dev.bits[i]);
     block->has_data() = dev.has_data[i] != 0;  // the integrators never set it
-    HostBlockRecord& rec = dev.tsdf_known[bi];
-    rec.block = block.get();
+    HostBlockRecord<TsdfVoxel>& rec = dev.tsdf_known[bi];
+    rec.block = block;
     rec.bits = static_cast<uint8_t>(block->updated().to_ulong());
     rec.fingerprint = fps[i];
+    rec.sampled = fps_s[i];
   }
   // kMap doubles as the mirror's dirty bit on the device; kMesh / kEsdf stay for the device-side
   // mesher / ESDF
@@ -444,6 +554,17 @@ void integrateOnDevice(int kind, const TsdfIntegratorBase::Config& config, Layer
 }
 }  // namespace
 }  // namespace hip
+
+}  // namespace voxblox
+extern "C" void vbx_dropin_set_reconcile_mode(int mode) { voxblox::hip::reconcileMode().store(mode); }
+extern "C" int vbx_dropin_get_reconcile_mode() { return voxblox::hip::reconcileMode().load(); }
+extern "C" void vbx_dropin_mark_tsdf_layer_edited(const void* tsdf_layer) {
+  voxblox::hip::markLayerEdited(static_cast<const voxblox::Layer<voxblox::TsdfVoxel>*>(tsdf_layer));
+}
+extern "C" void vbx_dropin_mark_esdf_layer_edited(const void* esdf_layer) {
+  voxblox::hip::markLayerEdited(static_cast<const voxblox::Layer<voxblox::EsdfVoxel>*>(esdf_layer));
+}
+namespace voxblox {
 
 TsdfIntegratorBase::Ptr TsdfIntegratorFactory::create(const std::string& integrator_type_name,
                                                       const TsdfIntegratorBase::Config& config,
