@@ -209,18 +209,16 @@ RP_FN void rp_unpack_parent(uint32_t s, int* x, int* y, int* z) {
   *x = (int)(int8_t)(s >> 8); *y = (int)(int8_t)(s >> 16); *z = (int)(int8_t)(s >> 24);
 }
 RP_FN void rp_lut_offset(int idx, int* dx, int* dy, int* dz) {  // neighbor_tools.cc:8-34, column order
-  // 6 faces, 12 edges, 8 corners — packed as 2-bit fields (value + 1) per axis
-  const unsigned char t[26] = {
-      // x | y << 2 | z << 4, each 0..2
-      0 | (1 << 2) | (1 << 4), 2 | (1 << 2) | (1 << 4), 1 | (0 << 2) | (1 << 4), 1 | (2 << 2) | (1 << 4),
-      1 | (1 << 2) | (0 << 4), 1 | (1 << 2) | (2 << 4), 0 | (0 << 2) | (1 << 4), 0 | (2 << 2) | (1 << 4),
-      2 | (0 << 2) | (1 << 4), 2 | (2 << 2) | (1 << 4), 1 | (0 << 2) | (0 << 4), 1 | (0 << 2) | (2 << 4),
-      1 | (2 << 2) | (0 << 4), 1 | (2 << 2) | (2 << 4), 0 | (1 << 2) | (0 << 4), 2 | (1 << 2) | (0 << 4),
-      0 | (1 << 2) | (2 << 4), 2 | (1 << 2) | (2 << 4), 0 | (0 << 2) | (0 << 4), 0 | (0 << 2) | (2 << 4),
-      0 | (2 << 2) | (0 << 4), 0 | (2 << 2) | (2 << 4), 2 | (0 << 2) | (0 << 4), 2 | (0 << 2) | (2 << 4),
-      2 | (2 << 2) | (0 << 4), 2 | (2 << 2) | (2 << 4)};
-  const int v = t[idx];
-  *dx = (v & 3) - 1; *dy = ((v >> 2) & 3) - 1; *dz = ((v >> 4) & 3) - 1;
+  // 6 faces, 12 edges, 8 corners: per axis the 26 offsets + 1 as 2-bit fields of one 64-bit literal (entry idx at bits
+  // 2 idx .. 2 idx + 1).  Pure ALU: the byte table this replaces was a global load followed by a wait in every iteration of the
+  // folds' event loops (one dependent trip to memory per event of a target).
+  //   idx:  0 1 2 3 4 5 | 6 7 8 9 10 11 12 13 14 15 16 17 | 18 .. 25
+  //   x+1:  0 2 1 1 1 1 | 0 0 2 2 1  1  1  1  0  2  0  2  | 0 0 0 0 2 2 2 2
+  //   y+1:  1 1 0 2 1 1 | 0 2 0 2 0  0  2  2  1  1  1  1  | 0 0 2 2 0 0 2 2
+  //   z+1:  1 1 1 1 0 2 | 1 1 1 1 0  2  0  2  0  0  2  2  | 0 2 0 2 0 2 0 2
+  const unsigned long long X = 0xaa008855a0558ull, Y = 0xa0a055a088585ull, Z = 0x8888a08855855ull;
+  const unsigned sh = 2u * (unsigned)idx;
+  *dx = (int)((X >> sh) & 3ull) - 1; *dy = (int)((Y >> sh) & 3ull) - 1; *dz = (int)((Z >> sh) & 3ull) - 1;
 }
 RP_FN float rp_lut_distance(int idx) {
   const float sq2 = (float)1.4142135623730951, sq3 = (float)1.7320508075688772;  // std::sqrt(2), std::sqrt(3) as float

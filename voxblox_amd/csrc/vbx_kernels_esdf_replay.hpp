@@ -34,6 +34,11 @@ __device__ inline unsigned long long rl_u64(unsigned long long x, int src) {
   return (unsigned long long)rl_u32((uint32_t)x, src) | ((unsigned long long)rl_u32((uint32_t)(x >> 32), src) << 32);
 }
 
+__device__ inline void rp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 constexpr int kRpThreads = 256;
 constexpr uint32_t kRpGraphSteps = 64;   // launches per batch (a power of two; Ctl::hdr numbers the launches modulo it)
 constexpr uint32_t kRpSpinMax = 1u << 22;
@@ -100,14 +105,22 @@ __device__ inline void rp_run_phase(const rp::Args& a, uint32_t phase, uint32_t 
 }
 
 // rp_fold (vbx_esdf_replay_core.hpp, the form the CPU emulation runs) as ONE WAVE per target: a lane holds up to kEvQ of
-// the target's events (only the slots a target's list reaches are looked at: most lists have fewer than 64 entries) with their records' pop times and pop-time states, the order of the events is a rank computed by
-// comparing pop times across lanes, and the replay itself — inherently sequential, event by event — runs wave-uniformly
-// on broadcast values.  A thread-per-target fold kept its event list in scratch memory and a target of a crowded
-// neighbourhood (a hundred events) cost milliseconds of dependent scratch round trips; the launch waits for its
-// slowest target.
+// the target's events (only the slots a target's list reaches are looked at: most lists have fewer than 64 entries) with their
+// records' pop times and pop-time states; the order of the events is a rank computed by comparing pop times across lanes.
+//
+// The replay itself (round 6).  Until round 5 it ran event by event, wave-uniformly, on broadcast values: a target of a crowded
+// neighbourhood (a list of 256 events) cost 256 trips through ~100 wave instructions, and a launch lasts as long as its slowest
+// target (first update of a map: 6,785 fold launches of 56 us).  But most events change nothing: an offer that does not beat the
+// voxel's distance leaves no trace.  So the events are put into pop order through the wave's LDS scratch (rank r -> lane r % 64,
+// slot r / 64) and taken 64 at a time: EVERY lane tests its own event against the voxel's current state (rp_relax with the
+// lane's own LUT index), the first lane whose event changes the state is found with a ballot, that one event is applied
+// wave-uniformly — the events in front of it were no-ops against exactly this state, so skipping them is the sequential
+// result — and the test is repeated from the event behind it.  A pop of the voxel itself (it records the state it finds)
+// always counts as a change.  Steps per target = events that change something + one per 64 events, instead of events.
 // (commit: the pushes per queue go to push_acc — the workgroup's LDS counters in k_rp_step —, the relaxations to *relax_acc)
-__device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long long limit, bool commit, int lane, uint32_t* push_acc = nullptr,
-                                    uint32_t* relax_acc = nullptr) {
+constexpr uint32_t kFoldLdsWords = rp::kEvMax * 4;   // per wave: {code, distance bits, state, pop-time state moved} per event
+__device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long long limit, bool commit, int lane, uint32_t* ws,
+                                    uint32_t* push_acc = nullptr, uint32_t* relax_acc = nullptr) {
   using namespace rp;
   constexpr int Q = (int)kEvQ;     // events per lane: event e of the target lives in lane e % 64, slot e / 64
   Ctl& c = *a.ctl;
@@ -158,6 +171,15 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
       for (int q = 0; q < Q; ++q) rank[q] += (Tk < eT[q]) ? 1u : 0u;
     }
   }
+  // the events in pop order: rank r -> ws[4 r ..] (the wave's own LDS scratch; DS operations of one wave execute in order)
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (q < slots && valid[q]) {
+      uint32_t* w = ws + 4u * rank[q];
+      w[0] = code[q]; w[1] = __float_as_uint(ed[q]); w[2] = es[q]; w[3] = 0u;
+    }
+  }
+  rp_wave_sync();
   float d = d0;
   uint32_t s = s0;
   const bool usable = (s0 & kObserved) && !(s0 & kFixed);
@@ -166,74 +188,79 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
   uint32_t lp_rec = kNone, lp_lb = 0, lp_s = 0;
   float lp_d = 0.f;
   uint32_t n_lp = 0;
-  bool pop_moved[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) pop_moved[q] = false;
-  for (uint32_t i = 0; i < n; ++i) {
-    // the event of rank i: which slot, which lane
-    uint32_t ecode = 0, evs = 0;
-    float evd = 0.f;
-    int src = -1, sq = 0;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      if (q >= slots || src >= 0) continue;
-      const unsigned long long m = __ballot(valid[q] && rank[q] == i);
-      if (m) {
-        src = __ffsll((long long)m) - 1; sq = q;
-        ecode = rl_u32(code[q], src); evd = rl_f32(ed[q], src); evs = rl_u32(es[q], src);
-      }
+  for (uint32_t base = 0; base < n; base += 64u) {
+    const uint32_t cnt = n - base < 64u ? n - base : 64u;
+    uint32_t mcode = 0, ms = 0;
+    float md = 0.f;
+    if ((uint32_t)lane < cnt) {
+      const uint32_t* w = ws + 4u * (base + (uint32_t)lane);
+      mcode = w[0]; md = __uint_as_float(w[1]); ms = w[2];
     }
-    if (src < 0) break;  // (cannot happen: ranks of valid events are 0 .. n - 1)
-    const uint32_t r = ecode >> 5, lut = ecode & 31;
-    if (lut == kOwn) {
-      // the pop: processOpenSet reads the voxel here (:381-392)
-      if (!commit) {
-        if (lane == 0) {
-          a.rec_d_n[r] = d;
-          a.rec_s_n[r] = s;
-        }
-        // did the record's pop-time state move? (kept by the lane that holds the event)
-        if (lane == src && (__float_as_uint(d) != __float_as_uint(evd) || s != evs)) {
-#pragma unroll
-          for (int q = 0; q < Q; ++q) if (q == sq) pop_moved[q] = true;
-        }
+    const uint32_t mlut = mcode & 31u;
+    const bool is_pop = mlut == kOwn;
+    // what does not depend on the voxel's state: the pop offers nothing (:389-392), the voxel cannot be written (:414-417)
+    const bool dead = !is_pop && (!(ms & kObserved) || md >= a.c.max_distance || md <= -a.c.max_distance || !usable);
+    uint32_t cur = 0;
+    for (;;) {
+      bool chg = false;
+      float nd = 0.f;
+      uint32_t np = 0;
+      if ((uint32_t)lane >= cur && (uint32_t)lane < cnt) {
+        if (is_pop) chg = true;
+        else if (!dead) chg = rp_relax(a.c, md, ms, d, (int)mlut, &nd, &np);
       }
-      s &= ~kInQueue;                                            // :386
-      continue;
-    }
-    if (!(evs & kObserved) || evd >= a.c.max_distance || evd <= -a.c.max_distance) continue;  // :389-392
-    if (!usable) continue;                                       // :414-417
-    float nd;
-    uint32_t np;
-    if (!rp_relax(a.c, evd, evs, d, (int)lut, &nd, &np)) continue;
-    ++relax;
-    d = nd;
-    s = (s & 0xFFu) | np;
-    if (a.c.multi_queue || !(s & kInQueue)) {
-      s |= kInQueue;
-      const int nb = rp_bucket_of(a.c, nd);
-      if (commit) {
-        if (lane == 0) {
-          const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
-          atomicOr(&a.rec_push[w], (uint32_t)(nb + 1) << sh);
-          atomicAdd(push_acc ? &push_acc[nb] : &c.push_cnt[nb], 1u);
-        }
-      } else if (nb < b) {
-        if (n_lp == 64) {
-          // no room to describe this push: the pushing record leaves the super-step (the cut falls in front of it)
-          if (lane == 0 && atomicExch(&a.rec_poison[r], 1u) == 0u) {
-            atomicAdd(&c.st_poison, 1ull);
-            if (r < c.K) atomicMin(&c.k_limit, r);
-            const uint32_t base = a.rec_base[r];
-            const unsigned long long Tr = a.rec_T[r];
-            if (Tr != kNever && (Tr & kRankMask) != 0) atomicMin(&a.sub_restart[base], (uint32_t)(Tr & kRankMask) - 1u);
-            if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
-            a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+      const unsigned long long cm = __ballot(chg);
+      if (!cm) break;
+      const int f = __ffsll((long long)cm) - 1;   // events cur .. f - 1 leave the state as it is
+      cur = (uint32_t)f + 1u;
+      const uint32_t fcode = rl_u32(mcode, f);
+      const uint32_t r = fcode >> 5, lut = fcode & 31u;
+      if (lut == kOwn) {
+        // the pop: processOpenSet reads the voxel here (:381-392)
+        if (!commit) {
+          const float evd = rl_f32(md, f);
+          const uint32_t evs = rl_u32(ms, f);
+          if (lane == 0) {
+            a.rec_d_n[r] = d;
+            a.rec_s_n[r] = s;
+            // did the record's pop-time state move? (read back by the lane that holds the event)
+            if (__float_as_uint(d) != __float_as_uint(evd) || s != evs) ws[4u * (base + (uint32_t)f) + 3u] = 1u;
           }
-          continue;
         }
-        if ((uint32_t)lane == n_lp) { lp_rec = r; lp_lb = lut | ((uint32_t)nb << 8); lp_d = d; lp_s = s; }
-        ++n_lp;
+        s &= ~kInQueue;                                            // :386
+        continue;
+      }
+      const float fnd = rl_f32(nd, f);
+      const uint32_t fnp = rl_u32(np, f);
+      ++relax;
+      d = fnd;
+      s = (s & 0xFFu) | fnp;
+      if (a.c.multi_queue || !(s & kInQueue)) {
+        s |= kInQueue;
+        const int nb = rp_bucket_of(a.c, fnd);
+        if (commit) {
+          if (lane == 0) {
+            const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
+            atomicOr(&a.rec_push[w], (uint32_t)(nb + 1) << sh);
+            atomicAdd(push_acc ? &push_acc[nb] : &c.push_cnt[nb], 1u);
+          }
+        } else if (nb < b) {
+          if (n_lp == 64) {
+            // no room to describe this push: the pushing record leaves the super-step (the cut falls in front of it)
+            if (lane == 0 && atomicExch(&a.rec_poison[r], 1u) == 0u) {
+              atomicAdd(&c.st_poison, 1ull);
+              if (r < c.K) atomicMin(&c.k_limit, r);
+              const uint32_t base_r = a.rec_base[r];
+              const unsigned long long Tr = a.rec_T[r];
+              if (Tr != kNever && (Tr & kRankMask) != 0) atomicMin(&a.sub_restart[base_r], (uint32_t)(Tr & kRankMask) - 1u);
+              if (atomicExch(&a.sub_dirty[base_r], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base_r;
+              a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+            }
+            continue;
+          }
+          if ((uint32_t)lane == n_lp) { lp_rec = r; lp_lb = lut | ((uint32_t)nb << 8); lp_d = d; lp_s = s; }
+          ++n_lp;
+        }
       }
     }
   }
@@ -251,6 +278,10 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     }
     return;
   }
+  rp_wave_sync();   // (lane 0's moved flags)
+  bool pop_moved[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) pop_moved[q] = (q < slots && valid[q] && (code[q] & 31u) == kOwn) ? ws[4u * rank[q] + 3u] != 0u : false;
   // ---- outputs of an iteration: the records on this voxel (their own-pop events, dead or alive)
   bool own[Q], chg[Q], found[Q];
   uint32_t mn[Q], pusher[Q], fbucket[Q];
@@ -398,6 +429,7 @@ struct SimLds {
   // the member list + 1 (0: the base record)
   uint32_t cnt[kSimMax + 2];
   unsigned short first[kSimMax + 2], kids[kSimMax];
+  unsigned short kidb[kSimMax];               // bucket of kids[x] (read with it: one LDS round trip less per pop)
   uint32_t wave_tot[kRpThreads / 64];
   uint32_t info[kSimMax];                     // lut | bucket << 8 | live << 16 | poisoned << 17 | has an unlisted child << 18 | pusher's position << 19
   unsigned short next[kSimMax], rank[kSimMax];
@@ -408,10 +440,6 @@ struct SimLds {
   unsigned short orank[kSimMax];              // rank of the last ranking (0: none) | 0x8000: this ranking changed its order (rp_phase_sim, mark_moved = 2)
   uint32_t n_pend, flag_rank, n_ranked, truncated, n_moved;
 };
-__device__ inline void rp_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L) {
   rp::Ctl& c = *a.ctl;
   const uint32_t smax = a.c.smax;
@@ -440,6 +468,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     uint32_t rk = 0xFFFF;
     if (T != rp::kNever && (uint32_t)(T & rp::kRankMask) <= p) rk = (uint32_t)(T & rp::kRankMask);   // it popped in front of the restart point
     L.info[j] = (m & 0x1FFFFu) | (a.rec_poison[r] ? (1u << 17) : 0u) | (m & (1u << 18)) | (pl << 19);
+    L.next[j] = (unsigned short)0xFFFF;
     L.rank[j] = (unsigned short)rk;
     L.orank[j] = T != rp::kNever ? (unsigned short)(T & 0x7FFFu) : (unsigned short)0;   // (ranks stay below smax <= 1024)
     if (rp::rp_meta_live(m)) atomicAdd(&L.cnt[pl], 1u);
@@ -490,6 +519,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     }
   }
   __syncthreads();
+  for (uint32_t x = tid; x < (uint32_t)L.first[n + 1]; x += kRpThreads) L.kidb[x] = (unsigned short)((L.info[L.kids[x]] >> 8) & 0xFF);
   // a record with an unlisted child in front of the restart point: the ranking ends behind it
   uint32_t R = p;
   bool truncated = false;
@@ -531,11 +561,57 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     if (last) L.tail[kb] = (unsigned short)j;
   }
   __syncthreads();
-  if (tid < 64 && !truncated) {
-    // wave-uniform replay of the queue discipline from the restart point: every lane runs the same control flow, lanes
-    // 0..25 fetch the 26 child slots of a pop at once, the FIFO links are written by all lanes alike
+  if (tid < 64 && !truncated && nb <= 64) {
+    // Replay of the queue discipline from the restart point by ONE wave, wave-uniformly.  Round 6: the heads and tails of the
+    // bucket FIFOs live in registers (lane b holds bucket b's: the lowest non-empty bucket is a ballot, not a walk over LDS), a
+    // pop fetches everything it needs about its record in one LDS round trip (the five reads are independent) and its children
+    // with their buckets in a second one; LDS operations of one wave execute in order, so the FIFO links written for a child
+    // are there when the child pops.  A pop cost six to eight dependent LDS round trips before (first update of a map: 5,354
+    // rankings of 93 us).
     uint32_t rank = R;
     uint32_t runmax = R;   // largest old rank among the records that have popped (the records up to the restart point kept theirs: 1 .. R)
+    uint32_t hd = lane < nb ? (uint32_t)L.head[lane] : 0xFFFFu, tl = lane < nb ? (uint32_t)L.tail[lane] : 0xFFFFu;
+    for (;;) {
+      const unsigned long long nonempty = __ballot(hd != 0xFFFFu);
+      if (!nonempty) break;                                      // BucketQueue::front / pop
+      const int lowest = __ffsll((long long)nonempty) - 1;
+      const uint32_t j = rl_u32(hd, lowest);
+      const uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.next[j]);
+      const uint32_t inf = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.info[j]);
+      const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.orank[j]) & 0x7FFFu;
+      const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.first[j + 1]);
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.first[j + 2]);
+      if (lane == lowest) {
+        hd = nx;
+        if (nx == 0xFFFFu) tl = 0xFFFFu;
+      }
+      if (rank >= smax - 1 || (inf & (1u << 17))) { truncated = true; break; }
+      ++rank;
+      if (lane == 0) {
+        L.rank[j] = (unsigned short)rank;
+        // it pops now and did not before, or a record that used to pop behind it has popped in front of it: its order moved
+        if (o == 0u || o < runmax) L.orank[j] = (unsigned short)(o | 0x8000u);
+      }
+      if (o > runmax) runmax = o;
+      if (inf & (1u << 18)) { truncated = true; break; }   // a child of it is not in the list: stop behind it
+      // its children enter their buckets in LUT order
+      const uint32_t nk = e - f;
+      uint32_t cj = 0xFFFFu, ckb = 0;
+      if ((uint32_t)lane < nk) { cj = L.kids[f + lane]; ckb = L.kidb[f + lane]; }
+      for (uint32_t k = 0; k < nk; ++k) {
+        const uint32_t kj = rl_u32(cj, (int)k);
+        const int kb = (int)rl_u32(ckb, (int)k);
+        const uint32_t told = rl_u32(tl, kb);
+        if (told == 0xFFFFu) { if (lane == kb) hd = kj; }
+        else if (lane == 0) L.next[told] = (unsigned short)kj;
+        if (lane == kb) tl = kj;
+      }
+    }
+    R = rank;
+  } else if (tid < 64 && !truncated) {
+    // (more than 64 buckets: heads and tails stay in LDS)
+    uint32_t rank = R;
+    uint32_t runmax = R;
     int lowest = 0;
     for (;;) {
       while (lowest < nb && L.head[lowest] == 0xFFFF) ++lowest;   // BucketQueue::front / pop
@@ -550,14 +626,12 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       ++rank;
       L.rank[j] = (unsigned short)rank;
       {
-        // it pops now and did not before, or a record that used to pop behind it has popped in front of it: its order moved
         const uint32_t o = L.orank[j] & 0x7FFFu;
         if (o == 0u || o < runmax) L.orank[j] = (unsigned short)(o | 0x8000u);
         if (o > runmax) runmax = o;
       }
       rp_wave_sync();
-      if (inf & (1u << 18)) { truncated = true; break; }   // a child of it is not in the list: stop behind it
-      // its children enter their buckets in LUT order
+      if (inf & (1u << 18)) { truncated = true; break; }
       uint32_t jv = 0xFFFF, jinfo = 0;
       {
         const uint32_t f = L.first[j + 1], e = L.first[j + 2];
@@ -733,7 +807,9 @@ __host__ __device__ inline uint32_t rp_hdr_phase(unsigned long long h) { return 
 template <bool SERIAL>
 __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, uint32_t seq) {
   __shared__ uint32_t s_last;
-  __shared__ SimLds s_sim;
+  // the ranking's tables and the folds' per-wave event scratch are never live in the same launch (a launch runs ONE phase)
+  __shared__ union { SimLds sim; uint32_t fold[kRpThreads / 64][kFoldLdsWords]; } s_u;
+  SimLds& s_sim = s_u.sim;
   // COMMIT_FOLD / RAISE_FOLD: pushes per queue and relaxations of this workgroup.  Ctl::push_cnt and Ctl::st_relax share a
   // few cache lines and used to take one atomic per push and one per target — 15 k on the same lines in a launch over 7 k
   // targets, which is what such a launch lasted (a line takes a few hundred atomics per microsecond at best)
@@ -775,10 +851,10 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
       if (phase == rp::PH_FOLD) {
         const uint32_t t = c.fold_all ? w : a.dl[c.read][w];
         if (lane == 0) a.tgt_dirty[t] = 0;
-        rp_fold_wave(a, t, rp::kNever, false, lane);
+        rp_fold_wave(a, t, rp::kNever, false, lane, s_u.fold[wave]);
       } else {
         uint32_t relax = 0;
-        rp_fold_wave(a, w, c.cut, true, lane, lds_counts ? s_push : nullptr, lds_counts ? &relax : nullptr);
+        rp_fold_wave(a, w, c.cut, true, lane, s_u.fold[wave], lds_counts ? s_push : nullptr, lds_counts ? &relax : nullptr);
         if (lane == 0 && relax) atomicAdd(&s_relax, relax);
       }
     }
