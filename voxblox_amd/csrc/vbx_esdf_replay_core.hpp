@@ -37,6 +37,7 @@
 // The includer defines RP_FN (function qualifiers), RP_INC (returning increment of a counter that every caller in a wave
 // shares: the device sends one atomic per wave), RP_LD / RP_LD64 (coherent read of a word other workgroups updated
 // with atomics) and provides atomicAdd / atomicCAS / atomicMin / atomicOr / atomicExch on uint32_t and unsigned long long.
+// Optional: RP_WG_DIRTY_PUSH(t) -> bool, a per-workgroup collector of dirty marks (true: taken, the includer files it later).
 #pragma once
 
 namespace rp {
@@ -125,6 +126,7 @@ struct Ctl {
   uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
   // statistics
   unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
+  unsigned long long st_sim_members, st_sim_pops, st_sim_hist[4], st_sim_ticks[3];   // (device ranking) members loaded, pops replayed, rankings by pops replayed: < 16, < 64, < 256, more
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16], t_prev;
   // ---- per queue (bucket 0 .. num_buckets - 1, raise_ = num_buckets); the device wrapper moves the first num_buckets + 1 of each
   uint32_t head[kMaxBuckets + 1], tail[kMaxBuckets + 1];  // A: FIFO indices (entries ever popped / pushed)
@@ -287,6 +289,12 @@ RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
   // counter per placement — tens of thousands of atomics on one cache line in a super-step of 16 k base records)
   if (c.phase == PH_PLACE_BASE && a.c.fold_all) return;
   if (atomicExch(&a.tgt_dirty[t], 1u) == 0u) {
+    // (device) the workgroup collects its marks and takes ONE range of the list for all of them when the phase ends
+    // (k_rp_step): Ctl::n_dirty is a single word that every wave with a mark used to increment — a hundred rankings per
+    // launch, eight increments each, on an address that takes ~90 atomics per microsecond: two thirds of a ranking's time
+#ifdef RP_WG_DIRTY_PUSH
+    if (RP_WG_DIRTY_PUSH(t)) return;
+#endif
     const uint32_t w = 1u - c.read;
     const uint32_t k = RP_INC(&c.n_dirty[w]);
     a.dl[w][k] = t;   // k < tgt_cap: a target is listed at most once per list

@@ -621,6 +621,10 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
             hc.st_pops, hc.st_relax, hc.st_supersteps, hc.st_iters, hc.st_folds, hc.st_exc, hc.st_cut_iters, hc.st_cut_smax, hc.st_steps,
             hc.st_poison, hc.error);
     for (int k = 1; k < 13; ++k) fprintf(stderr, " %s %llu(%llu, %.2f ms)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k], hc.st_phase_ticks[k] * 1e-5);
+    fprintf(stderr, "\n[rp] rankings: members loaded %llu, pops replayed %llu, by pops replayed <16: %llu <64: %llu <256: %llu more: %llu", hc.st_sim_members, hc.st_sim_pops,
+            hc.st_sim_hist[0], hc.st_sim_hist[1], hc.st_sim_hist[2], hc.st_sim_hist[3]);
+    fprintf(stderr, "; workgroup-ms summed over rankings: tables %.2f, queue replay %.2f, write-back %.2f", hc.st_sim_ticks[0] * 1e-5, hc.st_sim_ticks[1] * 1e-5,
+            hc.st_sim_ticks[2] * 1e-5);
     fprintf(stderr, "\n");
   }
   if (!hc.done) {

@@ -21,6 +21,10 @@ __device__ inline uint32_t rp_wave_inc(uint32_t* ctr) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 #define RP_INC(p) rp_wave_inc(p)
+// PH_APPLY collects its dirty marks per workgroup (k_rp_step files them with one atomic on Ctl::n_dirty): defined below the
+// LDS layout
+__device__ inline bool rp_wg_dirty_push(uint32_t t);
+#define RP_WG_DIRTY_PUSH(t) rp_wg_dirty_push(t)
 #define RP_LD(x) atomicAdd(&(x), 0u)
 #define RP_LD64(x) atomicAdd(&(x), 0ull)
 #include "vbx_esdf_replay_core.hpp"
@@ -40,6 +44,7 @@ __device__ inline void rp_wave_sync() {
 }
 
 constexpr int kRpThreads = 256;
+constexpr uint32_t kWgDirtyCap = 4000;   // dirty marks a workgroup collects in PH_APPLY before it falls back to the shared counter
 constexpr uint32_t kRpGraphSteps = 64;   // launches per batch (a power of two; Ctl::hdr numbers the launches modulo it)
 constexpr uint32_t kRpSpinMax = 1u << 22;
 
@@ -440,10 +445,35 @@ struct SimLds {
   unsigned short orank[kSimMax];              // rank of the last ranking (0: none) | 0x8000: this ranking changed its order (rp_phase_sim, mark_moved = 2)
   uint32_t n_pend, flag_rank, n_ranked, truncated, n_moved;
 };
+}  // namespace
+// The step kernel's LDS: a launch runs ONE phase, so the ranking's tables, the folds' per-wave event scratch, PH_APPLY's
+// collector of dirty marks and the control block's copy (the control step runs when the phase is over) share one region —
+// 34 KB, which with the counters below keeps four workgroups on a CU (the grid of 1,024 starts in one go: a launch with a
+// second round of workgroups costs every phase twice its floor).  File scope, so that the core's hook reaches it.
+struct RpWgDirty { uint32_t cnt, base; uint32_t list[kWgDirtyCap]; };
+union RpLds {
+  SimLds sim;
+  uint32_t fold[kRpThreads / 64][kFoldLdsWords];
+  RpWgDirty dirty;
+  rp::Ctl ctl;
+};
+__shared__ RpLds g_rp_lds;
+__shared__ uint32_t g_rp_collect;   // 1 while a phase runs whose marks are collected (outside the union: the hook reads it in every phase)
+__device__ inline bool rp_wg_dirty_push(uint32_t t) {
+  if (!g_rp_collect) return false;
+  const uint32_t k = atomicAdd(&g_rp_lds.dirty.cnt, 1u);
+  if (k >= kWgDirtyCap) return false;   // full: this mark goes to the shared list directly
+  g_rp_lds.dirty.list[k] = t;
+  return true;
+}
+namespace {
+
 __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L) {
   rp::Ctl& c = *a.ctl;
   const uint32_t smax = a.c.smax;
   const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  const unsigned long long tk0 = wall_clock64();   // (100 MHz; Ctl::st_sim_ticks: tables built / queue replayed / pop times written)
+  unsigned long long tk1 = tk0, tk2 = tk0;
   const uint32_t slot = a.sub_slot[base];
   uint32_t n = (slot != 0u && slot <= a.sub_slots_cap) ? a.sub_mem_n[base] : 0u;
   if (n > smax) n = smax;
@@ -561,6 +591,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     if (last) L.tail[kb] = (unsigned short)j;
   }
   __syncthreads();
+  tk1 = wall_clock64();
   if (tid < 64 && !truncated && nb <= 64) {
     // Replay of the queue discipline from the restart point by ONE wave, wave-uniformly.  Round 6: the heads and tails of the
     // bucket FIFOs live in registers (lane b holds bucket b's: the lowest non-empty bucket is a ballot, not a walk over LDS), a
@@ -656,7 +687,12 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     }
     R = rank;
   }
+  tk2 = wall_clock64();
   if (tid == 0) {
+    const uint32_t popped = R - (L.flag_rank <= p ? L.flag_rank : p);   // pops this ranking replayed (behind the restart point)
+    atomicAdd(&c.st_sim_members, (unsigned long long)n);
+    atomicAdd(&c.st_sim_pops, (unsigned long long)popped);
+    atomicAdd(&c.st_sim_hist[popped < 16u ? 0 : popped < 64u ? 1 : popped < 256u ? 2 : 3], 1ull);
     L.n_ranked = R;
     L.truncated = truncated ? 1u : 0u;
   }
@@ -675,9 +711,28 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     a.rec_T[r] = Tn;
   }
   __syncthreads();
-  // one (moved record, target) pair per thread: 27 dependent atomics in a row on one lane would be most of a small ranking's time
-  for (uint32_t i = tid; i < L.n_moved * 27u; i += kRpThreads)
-    rp::rp_mark_dirty(a, a.rec_tgts[(size_t)mem[L.moved[i / 27u]] * 27 + i % 27u]);
+  // one (moved record, target) pair per thread: 27 dependent atomics in a row on one lane would be most of a small ranking's time.
+  // The marks are collected in LDS (the pending-queue tables are dead by now) and filed with ONE atomic on Ctl::n_dirty per
+  // ranking: every wave with a mark used to increment that word — eight increments per ranking, a hundred rankings per launch,
+  // on an address that takes ~90 atomics per microsecond: two thirds of a ranking's time (st_sim_ticks).
+  if (tid == 0) L.n_pend = 0;
+  __syncthreads();
+  const uint32_t wl = 1u - c.read;
+  for (uint32_t i = tid; i < L.n_moved * 27u; i += kRpThreads) {
+    const uint32_t t = a.rec_tgts[(size_t)mem[L.moved[i / 27u]] * 27 + i % 27u];
+    if (t >= rp::kSkip) continue;
+    if (atomicExch(&a.tgt_dirty[t], 1u) != 0u) continue;
+    const uint32_t k = atomicAdd(&L.n_pend, 1u);
+    if (k < kSimMax) L.pend_key[k] = t;
+    else a.dl[wl][atomicAdd(&c.n_dirty[wl], 1u)] = t;
+  }
+  __syncthreads();
+  {
+    const uint32_t nd = L.n_pend < kSimMax ? L.n_pend : kSimMax;
+    if (tid == 0 && nd) L.flag_rank = atomicAdd(&c.n_dirty[wl], nd);
+    __syncthreads();
+    for (uint32_t i = tid; i < nd; i += kRpThreads) a.dl[wl][L.flag_rank + i] = L.pend_key[i];
+  }
   if (tid == 0) {
     a.sub_dirty[base] = 0;
     a.sub_restart[base] = rp::kNone;
@@ -686,6 +741,9 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       atomicMin(&c.smax_cut, ((unsigned long long)base << rp::kRankBits) | (L.n_ranked + 1));
       atomicAdd(&c.st_trunc_rank, 1ull);
     }
+    atomicAdd(&c.st_sim_ticks[0], tk1 - tk0);
+    atomicAdd(&c.st_sim_ticks[1], tk2 - tk1);
+    atomicAdd(&c.st_sim_ticks[2], wall_clock64() - tk2);
   }
   __syncthreads();
 }
@@ -807,8 +865,7 @@ __host__ __device__ inline uint32_t rp_hdr_phase(unsigned long long h) { return 
 template <bool SERIAL>
 __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, uint32_t seq) {
   __shared__ uint32_t s_last;
-  // the ranking's tables and the folds' per-wave event scratch are never live in the same launch (a launch runs ONE phase)
-  __shared__ union { SimLds sim; uint32_t fold[kRpThreads / 64][kFoldLdsWords]; } s_u;
+  RpLds& s_u = g_rp_lds;
   SimLds& s_sim = s_u.sim;
   // COMMIT_FOLD / RAISE_FOLD: pushes per queue and relaxations of this workgroup.  Ctl::push_cnt and Ctl::st_relax share a
   // few cache lines and used to take one atomic per push and one per target — 15 k on the same lines in a launch over 7 k
@@ -837,6 +894,13 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
     if (threadIdx.x == 0) s_relax = 0;
     __syncthreads();
   }
+  // PH_APPLY and PH_SIM mark dirty targets: collected per workgroup, one range of the list taken at the end
+  const bool collect = !SERIAL && phase == rp::PH_APPLY;   // (PH_SIM collects per ranking, inside rp_sim_block)
+  if (threadIdx.x == 0) {
+    g_rp_collect = collect ? 1u : 0u;
+    if (collect) s_u.dirty.cnt = 0;
+  }
+  __syncthreads();
   if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
     rp_scan_phase(a, sc, n, phase);
   } else if (!SERIAL && phase == rp::PH_RAISE_FOLD) {
@@ -874,12 +938,21 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
       if (s_push[i]) atomicAdd(&c.push_cnt[i], s_push[i]);
     if (threadIdx.x == 0 && s_relax) atomicAdd(&c.st_relax, (unsigned long long)s_relax);
   }
+  if (collect) {
+    __syncthreads();
+    const uint32_t nd = s_u.dirty.cnt < kWgDirtyCap ? s_u.dirty.cnt : kWgDirtyCap;
+    const uint32_t wl = 1u - c.read;
+    if (threadIdx.x == 0 && nd) s_u.dirty.base = atomicAdd(&c.n_dirty[wl], nd);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nd; i += kRpThreads) a.dl[wl][s_u.dirty.base + i] = s_u.dirty.list[i];   // (< tgt_cap: a target is listed once)
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) s_last = (atomicAdd(&c.arrive, 1u) == active - 1) ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  __shared__ rp::Ctl s_ctl;
+  __syncthreads();   // (everybody is done with the phase's part of the shared region)
+  rp::Ctl& s_ctl = s_u.ctl;
   // (the scalar part and the first num_buckets + 1 entries of the five per-queue arrays)
   const uint32_t n_scalar = offsetof(rp::Ctl, head) / 4, nq = (uint32_t)a.c.num_buckets + 1u, n_copy = n_scalar + 5u * nq;
   {
