@@ -90,6 +90,7 @@ struct Cfg {
   uint32_t slot_by_base; // 1: the list of base record i's excursion is slot i + 1 (sub_slots_cap >= kmax); 0: slots are handed out as excursions appear
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
+  uint32_t stats;        // (device) 1: the rankings keep their statistics (Ctl::st_sim_*: six atomics per ranking on a few words — measurement runs only)
   uint32_t mark_moved;   // a ranking marks the targets of 2: the records whose order it changed, 1: every record whose pop time it moved (rp_mark_rec_targets); 0: nothing (round 4)
 };
 
@@ -192,6 +193,7 @@ struct Args {
   uint32_t* sub_mem;        // [slots][smax]
   uint32_t* sub_mem_n;      // [kmax]
   uint32_t* rec_local;      // [rec] 1 + index in its excursion's member list (0: the base record)
+  uint32_t* rec_plocal;     // [rec] rec_local of the record's pusher, noted at birth (may be null: the ranking then asks rec_local[rec_pusher[r]] — one more dependent trip to memory per member)
   uint32_t* sub_restart;    // [kmax] smallest rank at which the excursion's structure changed since its last ranking
   unsigned long long* sim_q;  // [slots][smax] scratch of the ranking
   uint32_t sub_slots_cap;
@@ -767,6 +769,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
           slot = old ? old : mine;
         }
       }
+      if (a.rec_plocal) a.rec_plocal[r] = a.rec_local[pusher];   // (the pusher was born in an earlier iteration: its place in the list stands)
       const uint32_t idx = atomicAdd(&a.sub_mem_n[base], 1u);
       if (slot <= a.sub_slots_cap && idx < a.c.smax) {
         a.sub_mem[(size_t)(slot - 1) * a.c.smax + idx] = r;

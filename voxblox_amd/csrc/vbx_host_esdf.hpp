@@ -451,7 +451,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   HIP_TRY(ctx->rp_hazard.ensure((size_t)std::max<uint32_t>(used, 1) * m.nvox));
   HIP_TRY(ctx->rp_chunk_tab.ensure((size_t)(num_buckets + 1) * n_chunks * 4));
   if (fresh || ctx->rp_rec_cap != rec_cap || ctx->rp_tgt_cap != tgt_cap || ctx->rp_smax != smax) {
-    HIP_TRY(ctx->rp_rec_u32.ensure((size_t)rec_cap * 4 * 11));
+    HIP_TRY(ctx->rp_rec_u32.ensure((size_t)rec_cap * 4 * 12));
     HIP_TRY(ctx->rp_rec_T.ensure((size_t)rec_cap * 8));
     HIP_TRY(ctx->rp_rec_kid.ensure((size_t)rec_cap * 26 * 4));
     HIP_TRY(ctx->rp_rec_tgts.ensure((size_t)rec_cap * 27 * 4));
@@ -467,7 +467,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(ctx->rp_ord.ensure((size_t)rec_cap * 4));
 
     // what the phases expect to be zero between super-steps
-    HIP_TRY(hipMemsetAsync(ctx->rp_rec_u32.p, 0, (size_t)rec_cap * 4 * 11, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_rec_u32.p, 0, (size_t)rec_cap * 4 * 12, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_kid.p, 0, (size_t)rec_cap * 26 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_push.p, 0, (size_t)rec_cap * 7 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0, (size_t)tgt_cap * 4 * 3, s));
@@ -547,6 +547,8 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.rec_meta_n = ru + (size_t)4 * R; a.rec_poison = ru + (size_t)5 * R; a.rec_s = ru + (size_t)6 * R; a.rec_s_n = ru + (size_t)7 * R;
   a.rec_d = reinterpret_cast<float*>(ru + (size_t)8 * R); a.rec_d_n = reinterpret_cast<float*>(ru + (size_t)9 * R);
   a.rec_born_it = ru + (size_t)10 * R;
+  a.rec_plocal = ru + (size_t)11 * R;
+  a.c.stats = getenv("VBX_RP_STATS") ? 1u : 0u;
   a.rec_T = ctx->rp_rec_T.as<unsigned long long>();
   a.rec_kid = ctx->rp_rec_kid.as<uint32_t>();
   a.rec_tgts = ctx->rp_rec_tgts.as<uint32_t>();

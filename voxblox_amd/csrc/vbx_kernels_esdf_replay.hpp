@@ -443,6 +443,7 @@ struct SimLds {
   unsigned short head[rp::kMaxBuckets + 1], tail[rp::kMaxBuckets + 1];
   unsigned short moved[kSimMax];              // members whose pop time this ranking moved
   unsigned short orank[kSimMax];              // rank of the last ranking (0: none) | 0x8000: this ranking changed its order (rp_phase_sim, mark_moved = 2)
+  uint32_t memr[kSimMax];                     // the members' record numbers (read once in pass 1: the write-back needs them again)
   uint32_t n_pend, flag_rank, n_ranked, truncated, n_moved;
 };
 }  // namespace
@@ -492,8 +493,9 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   // pass 1: records, their old ranks, the child table
   for (uint32_t j = tid; j < n; j += kRpThreads) {
     const uint32_t r = mem[j];
+    L.memr[j] = r;
     const uint32_t m = a.rec_meta[r];
-    const uint32_t pl = a.rec_local[a.rec_pusher[r]];
+    const uint32_t pl = a.rec_plocal ? a.rec_plocal[r] : a.rec_local[a.rec_pusher[r]];
     const unsigned long long T = a.rec_T[r];
     uint32_t rk = 0xFFFF;
     if (T != rp::kNever && (uint32_t)(T & rp::kRankMask) <= p) rk = (uint32_t)(T & rp::kRankMask);   // it popped in front of the restart point
@@ -689,10 +691,12 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   }
   tk2 = wall_clock64();
   if (tid == 0) {
-    const uint32_t popped = R - (L.flag_rank <= p ? L.flag_rank : p);   // pops this ranking replayed (behind the restart point)
-    atomicAdd(&c.st_sim_members, (unsigned long long)n);
-    atomicAdd(&c.st_sim_pops, (unsigned long long)popped);
-    atomicAdd(&c.st_sim_hist[popped < 16u ? 0 : popped < 64u ? 1 : popped < 256u ? 2 : 3], 1ull);
+    if (a.c.stats) {
+      const uint32_t popped = R - (L.flag_rank <= p ? L.flag_rank : p);   // pops this ranking replayed (behind the restart point)
+      atomicAdd(&c.st_sim_members, (unsigned long long)n);
+      atomicAdd(&c.st_sim_pops, (unsigned long long)popped);
+      atomicAdd(&c.st_sim_hist[popped < 16u ? 0 : popped < 64u ? 1 : popped < 256u ? 2 : 3], 1ull);
+    }
     L.n_ranked = R;
     L.truncated = truncated ? 1u : 0u;
   }
@@ -701,14 +705,16 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   __syncthreads();
   for (uint32_t j = tid; j < n; j += kRpThreads) {
     const uint32_t rk = L.rank[j];
-    const uint32_t r = mem[j];
+    const uint32_t r = L.memr[j];
     const unsigned long long Tn = rk == 0xFFFF ? rp::kNever : (((unsigned long long)base << rp::kRankBits) | rk);
-    // a pop time that moved reorders the events of the targets the record talks to (rp::rp_mark_rec_targets)
-    const unsigned long long To = a.rec_T[r];
-    bool moved = To != Tn;                                                      // mark_moved = 1: every pop time that moved
-    if (a.c.mark_moved >= 2) moved = rk == 0xFFFF ? (To != rp::kNever) : ((L.orank[j] & 0x8000u) != 0u);   // 2: order changes only (rp_phase_sim)
+    // a pop time that moved reorders the events of the targets the record talks to (rp::rp_mark_rec_targets).  The old pop
+    // time is (base, old rank) — a record never leaves its excursion —, and the old rank is in the table since pass 1 (0: it
+    // had not popped): no second trip to rec_T
+    const uint32_t o_rk = L.orank[j] & 0x7FFFu, n_rk = rk == 0xFFFF ? 0u : rk;
+    bool moved = o_rk != n_rk;                                                  // mark_moved = 1: every pop time that moved
+    if (a.c.mark_moved >= 2) moved = rk == 0xFFFF ? (o_rk != 0u) : ((L.orank[j] & 0x8000u) != 0u);   // 2: order changes only (rp_phase_sim)
     if (a.c.mark_moved && moved && rp::rp_moved_needs_mark(a, r)) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;
-    a.rec_T[r] = Tn;
+    if (o_rk != n_rk) a.rec_T[r] = Tn;
   }
   __syncthreads();
   // one (moved record, target) pair per thread: 27 dependent atomics in a row on one lane would be most of a small ranking's time.
@@ -719,7 +725,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   __syncthreads();
   const uint32_t wl = 1u - c.read;
   for (uint32_t i = tid; i < L.n_moved * 27u; i += kRpThreads) {
-    const uint32_t t = a.rec_tgts[(size_t)mem[L.moved[i / 27u]] * 27 + i % 27u];
+    const uint32_t t = a.rec_tgts[(size_t)L.memr[L.moved[i / 27u]] * 27 + i % 27u];
     if (t >= rp::kSkip) continue;
     if (atomicExch(&a.tgt_dirty[t], 1u) != 0u) continue;
     const uint32_t k = atomicAdd(&L.n_pend, 1u);
@@ -741,9 +747,11 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       atomicMin(&c.smax_cut, ((unsigned long long)base << rp::kRankBits) | (L.n_ranked + 1));
       atomicAdd(&c.st_trunc_rank, 1ull);
     }
-    atomicAdd(&c.st_sim_ticks[0], tk1 - tk0);
-    atomicAdd(&c.st_sim_ticks[1], tk2 - tk1);
-    atomicAdd(&c.st_sim_ticks[2], wall_clock64() - tk2);
+    if (a.c.stats) {
+      atomicAdd(&c.st_sim_ticks[0], tk1 - tk0);
+      atomicAdd(&c.st_sim_ticks[1], tk2 - tk1);
+      atomicAdd(&c.st_sim_ticks[2], wall_clock64() - tk2);
+    }
   }
   __syncthreads();
 }
