@@ -146,11 +146,20 @@ __global__ void k_cls_base(ClsArgs a) {
 // of its row on the plane — with the block's shadow distances in LDS: one launch settles everything inside the blocks, and a
 // launch is repeated only while values still cross block faces (chains along the walk are long: a row alternates between
 // "took the estimate of its -x neighbour" and "that one is beyond max_distance now", and per-voxel Jacobi rounds needed 25 - 200).
+// Round 6: everything a sweep reads that does NOT change during the sweep is staged in LDS first — the block's own voxels as the
+// layer holds them (what a looker sees of a neighbour BEHIND it in the walk) and the one-voxel halo around the block (the 26
+// neighbouring blocks: their shadow values if the walk has passed them, their layer values otherwise; fixed for the launch:
+// other workgroups only write their shadows when they are done) as one padded (VPS + 2)^3 array of distances and one of
+// "observed" bytes.  A plane then costs 26 LDS reads per looker instead of a chain of four dependent global loads (block table
+// -> list position -> block flags -> voxel); the launch was 0.4 - 0.95 ms, four of them per update.
 template <int VPS>
 __global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
   constexpr int NV = VPS * VPS * VPS;
-  __shared__ float s_d[NV];
-  __shared__ uint8_t s_f[NV];
+  constexpr int P = VPS + 2, NP = P * P * P;
+  __shared__ float s_d[NV];        // the shadow distances of this sweep (what a looker sees of a neighbour IN FRONT of it)
+  __shared__ uint8_t s_f[NV];      // shadow flags | 0x80: the shadow state is observed
+  __shared__ float s_st[NP];       // static view: own voxels as the layer has them, halo voxels as described above
+  __shared__ uint8_t s_so[NP];     // ... their "observed" bit (an absent voxel: 0)
   __shared__ uint32_t s_moved;
   const uint32_t p = blockIdx.x;
   const uint32_t slot = a.list_slots[p];
@@ -158,17 +167,66 @@ __global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
   const int tid = threadIdx.x;
   const size_t base = (size_t)p * NV;
   // hyperplanes that hold a voxel which looks at its neighbours: the others are skipped (in a steady frame the lookers are
-  // the new voxels along the frontier — a few planes per block; the loop over all 7 (VPS - 1) + 1 planes, each a chain of
-  // dependent neighbour reads, was 0.66 ms per launch)
+  // the new voxels along the frontier — a few planes per block)
   __shared__ uint8_t s_plane[7 * (VPS - 1) + 1];
   for (int i = tid; i <= 7 * (VPS - 1); i += VPS * VPS) s_plane[i] = 0;
   if (tid == 0) s_moved = 0;
   __syncthreads();
+  // where the 27 neighbouring blocks' voxels are read from: kind (0 nothing there, 1 the shadow of list position idx, 2 the layer's
+  // pool slot idx) — a chain of three dependent loads (block table -> list position -> block flags) done ONCE per neighbour block,
+  // not once per halo voxel
+  __shared__ uint32_t s_src[27];
+  if (tid < 27) {
+    uint32_t src = 0;
+    const uint32_t s2 = tid == 13 ? slot : a.nb27[(size_t)p * 27 + tid];
+    if (tid == 13) {
+      src = 2u | (slot << 2);            // own block, behind the looker: the layer (zeros if it holds no ESDF voxels yet, :145)
+    } else if (s2 != kInvalidSlot) {
+      const uint32_t p2 = a.slot_pos[s2];
+      const bool walked = p2 != kInvalidSlot && cls_valid(a, s2);   // the walk visits the neighbour's block ...
+      const bool in_front = walked && p2 < p;                       // ... and has passed it
+      // getVoxelPtrByGlobalIndex: the ESDF block exists if it did before the update or the walk has reached it (:145)
+      if (in_front) src = 1u | (p2 << 2);
+      else if (a.m.blk_flags[s2] & kFlagEsdfAlloc) src = 2u | (s2 << 2);
+    }
+    s_src[tid] = src;
+  }
+#pragma unroll 4
   for (int i = tid; i < NV; i += VPS * VPS) {
     const uint8_t f = a.sh_f[base + i];
     s_d[i] = a.sh_d[base + i];
-    s_f[i] = f;
-    if (f & kClsNb) s_plane[(i % VPS) + 2 * ((i / VPS) % VPS) + 4 * (i / (VPS * VPS))] = 1;
+    uint8_t sg = 0;   // a looker's TSDF sign (its ESDF value before the look is sign * default): 0x40 positive, 0x20 negative
+    if (f & kClsNb) {
+      const float td = a.m.dist[slot * NV + i];
+      sg = td > 0.f ? 0x40u : (td < 0.f ? 0x20u : 0u);
+      s_plane[(i % VPS) + 2 * ((i / VPS) % VPS) + 4 * (i / (VPS * VPS))] = 1;
+    }
+    s_f[i] = (uint8_t)((f & 0x1Fu) | sg | ((a.sh_s[base + i] & kEsdfObserved) ? 0x80u : 0u));
+  }
+  __syncthreads();
+  // the static view, cell (px, py, pz) of the padded cube = voxel (px - 1, py - 1, pz - 1) relative to this block
+#pragma unroll 4
+  for (int i = tid; i < NP; i += VPS * VPS) {
+    const int px = i % P, py = (i / P) % P, pz = i / (P * P);
+    int nx = px - 1, ny = py - 1, nz = pz - 1;
+    int cx = 1, cy = 1, cz = 1;
+    if (nx < 0) { nx += VPS; cx = 0; } else if (nx >= VPS) { nx -= VPS; cx = 2; }
+    if (ny < 0) { ny += VPS; cy = 0; } else if (ny >= VPS) { ny -= VPS; cy = 2; }
+    if (nz < 0) { nz += VPS; cz = 0; } else if (nz >= VPS) { nz -= VPS; cz = 2; }
+    const uint32_t nlin = (uint32_t)(nx + VPS * (ny + VPS * nz));
+    const uint32_t src = s_src[cx + 3 * cy + 9 * cz];
+    const size_t at = (size_t)(src >> 2) * NV + nlin;
+    float nd = 0.f;
+    uint32_t ns = 0u;
+    if ((src & 3u) == 1u) {
+      nd = a.sh_d[at];
+      ns = a.sh_s[at];
+    } else if ((src & 3u) == 2u) {
+      nd = a.e.dist[at];
+      ns = a.e.state[at];
+    }
+    s_st[i] = nd;
+    s_so[i] = (ns & kEsdfObserved) ? 1 : 0;
   }
   __syncthreads();
   const EsdfCfgDev& c = a.c;
@@ -179,60 +237,29 @@ __global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
     const int x = t - 2 * y - 4 * z;
     if (x >= 0 && x < VPS) {
       const uint32_t lin = (uint32_t)(x + VPS * (y + VPS * z));
-      const uint8_t f = s_f[lin];
+      const uint8_t f = (uint8_t)(s_f[lin] & 0x1Fu);
       if (f & kClsNb) {
         // the voxel as k_cls_base left it: sign * default, not fixed
-        const float td = a.m.dist[slot * NV + lin];
-        const float vd = (float)signum(td) * c.default_distance;
+        const float vd = (float)((s_f[lin] & 0x40u) ? 1 : ((s_f[lin] & 0x20u) ? -1 : 0)) * c.default_distance;
         float new_d = vd;
         bool hit = false;
-        // the 26 neighbours' (distance, state) first — independent loads, all in flight together — then the first neighbour
-        // in LUT order that qualifies (:505-527); an absent / unusable neighbour reads as state 0
-        float nbd[26];
-        uint32_t nbs[26];
+        // the first neighbour in LUT order that qualifies (:505-527); an absent / unusable neighbour reads as not observed
 #pragma unroll
         for (int idx = 0; idx < 26; ++idx) {
-          int nx = x + c_nb_off[idx][0], ny = y + c_nb_off[idx][1], nz = z + c_nb_off[idx][2];
-          int cx = 1, cy = 1, cz = 1;
-          if (nx < 0) { nx += VPS; cx = 0; } else if (nx >= VPS) { nx -= VPS; cx = 2; }
-          if (ny < 0) { ny += VPS; cy = 0; } else if (ny >= VPS) { ny -= VPS; cy = 2; }
-          if (nz < 0) { nz += VPS; cz = 0; } else if (nz >= VPS) { nz -= VPS; cz = 2; }
+          const int nx = x + c_nb_off[idx][0], ny = y + c_nb_off[idx][1], nz = z + c_nb_off[idx][2];
+          const bool inside = nx >= 0 && nx < VPS && ny >= 0 && ny < VPS && nz >= 0 && nz < VPS;
           const uint32_t nlin = (uint32_t)(nx + VPS * (ny + VPS * nz));
-          float nd = 0.f;
-          uint32_t ns = 0u;
-          if (cx == 1 && cy == 1 && cz == 1) {
-            // same block: in front of the voxel -> the shadow (LDS: this sweep's values), behind it -> the layer
-            // (the block exists since the walk reached it, :145: a block without ESDF voxels reads zeros)
-            if (nlin < lin) {
-              nd = s_d[nlin];
-              ns = a.sh_s[base + nlin];
-            } else {
-              nd = a.e.dist[slot * NV + nlin];
-              ns = a.e.state[slot * NV + nlin];
-            }
+          float nd;
+          bool obs;
+          if (inside && nlin < lin) {   // same block, in front of the voxel: this sweep's shadow
+            nd = s_d[nlin];
+            obs = (s_f[nlin] & 0x80u) != 0;
           } else {
-            const uint32_t s2 = a.nb27[(size_t)p * 27 + (cx + 3 * cy + 9 * cz)];
-            if (s2 != kInvalidSlot) {
-              const uint32_t p2 = a.slot_pos[s2];
-              const bool walked = p2 != kInvalidSlot && cls_valid(a, s2);   // the walk visits the neighbour's block ...
-              const bool in_front = walked && p2 < p;                       // ... and has passed it
-              // getVoxelPtrByGlobalIndex: the ESDF block exists if it did before the update or the walk has reached it (:145)
-              if (in_front) {
-                nd = a.sh_d[(size_t)p2 * NV + nlin];
-                ns = a.sh_s[(size_t)p2 * NV + nlin];
-              } else if (a.m.blk_flags[s2] & kFlagEsdfAlloc) {
-                nd = a.e.dist[s2 * NV + nlin];
-                ns = a.e.state[s2 * NV + nlin];
-              }
-            }
+            const int pi = (nx + 1) + P * ((ny + 1) + P * (nz + 1));
+            nd = s_st[pi];
+            obs = s_so[pi] != 0;
           }
-          nbd[idx] = nd;
-          nbs[idx] = ns;
-        }
-#pragma unroll
-        for (int idx = 0; idx < 26; ++idx) {
-          const float nd = nbd[idx];
-          if (hit || !(nbs[idx] & kEsdfObserved) || nd >= c.max_distance || nd <= -c.max_distance) continue;
+          if (hit || !obs || nd >= c.max_distance || nd <= -c.max_distance) continue;
           if (signum(nd) == signum(vd) && fabsf(nd) < fabsf(vd)) {
             new_d = nd + (float)signum(vd) * (idx < 6 ? 1.0f : (idx < 18 ? (float)1.4142135623730951 : (float)1.7320508075688772));   // NOT scaled by the voxel size (:508, :522)
             hit = true;
@@ -242,7 +269,7 @@ __global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
         const uint8_t f_new = hit ? (uint8_t)(f | kClsOpen | kClsHit) : (uint8_t)(f & ~(kClsOpen | kClsHit));
         if (__float_as_uint(s_d[lin]) != __float_as_uint(new_d) || f_new != f) {
           s_d[lin] = new_d;
-          s_f[lin] = f_new;
+          s_f[lin] = (uint8_t)(f_new | (s_f[lin] & 0xE0u));
           ++moved;
         }
       }
@@ -253,7 +280,7 @@ __global__ void __launch_bounds__(VPS * VPS) k_cls_nb_block(ClsArgs a) {
   __syncthreads();
   if (s_moved) {   // (a block that did not move leaves its shadow alone: readers of other blocks see the same bits)
     for (int i = tid; i < NV; i += VPS * VPS)
-      if (s_f[i] & kClsNb) { a.sh_d[base + i] = s_d[i]; a.sh_f[base + i] = s_f[i]; }
+      if (s_f[i] & kClsNb) { a.sh_d[base + i] = s_d[i]; a.sh_f[base + i] = (uint8_t)(s_f[i] & 0x1Fu); }
     if (tid == 0) atomicAdd(&a.counters[1], s_moved);
   }
 }
