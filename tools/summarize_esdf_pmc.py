@@ -1,6 +1,7 @@
 """FETCH_SIZE / WRITE_SIZE passes of the reference-order ESDF leg (gpurun_out/profiles_new/pmc_esdf_*) ->
-profiles/r05_pmc_esdf_ref_order.json.  Run from the repo root (tools/collect_profiles_r05.sh, tools/collect_profiles_r05e.sh)."""
-import csv, json, re
+profiles/<tag>_pmc_esdf_ref_order.json (tag = argv[1], default r05).  Run from the repo root (tools/collect_profiles_r05.sh, tools/collect_profiles_r05e.sh)."""
+import csv, json, re, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 WARM, STEPS = 3, 10
 per = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -29,5 +30,5 @@ for k, d in sorted(per.items(), key=lambda kv: -(kv[1]['FETCH_SIZE'] + kv[1]['WR
     out["per_frame_bytes"][k] = {"launches_per_frame": round(d['launches'] / STEPS, 2), "fetch_bytes": round(d['FETCH_SIZE'] * 1024 / STEPS),
                                  "write_bytes": round(d['WRITE_SIZE'] * 1024 / STEPS)}
 out["total_bytes_per_frame"] = sum(v["fetch_bytes"] + v["write_bytes"] for v in out["per_frame_bytes"].values())
-json.dump(out, open('profiles/r05_pmc_esdf_ref_order.json', 'w'), indent=1)
+json.dump(out, open('profiles/%s_pmc_esdf_ref_order.json' % TAG, 'w'), indent=1)
 print(json.dumps(out["per_frame_bytes"], indent=1)[:1500], "total/update", out["total_bytes_per_frame"])

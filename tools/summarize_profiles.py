@@ -6,7 +6,7 @@ import collections, csv, json, os, re, shutil, sys
 src, tag = sys.argv[1], sys.argv[2]
 FRAMES = {"fast": 20, "esdf": 20, "merged_cow": 20, "simple": 6, "sensors4": 2}
 WHAT = {"fast": "BASELINE configs[1]: Fast integrator, 640x480 room stream, 0.05 m (the driver-shaped run: frames 5..24 timed after 5 warm-up frames)",
-        "esdf": "BASELINE configs[3]: Fast + EsdfIntegrator::updateFromTsdfLayer(true) per frame (round 5: reference_order = 1, the reference's own result)",
+        "esdf": "BASELINE configs[3]: Fast + EsdfIntegrator::updateFromTsdfLayer(true) per frame (reference_order = 1, the reference's own result)",
         "merged_cow": "BASELINE configs[2]: Merged integrator, cow-and-lady-like orbit",
         "simple": "Simple integrator on the room stream",
         "sensors4": "BASELINE configs[4] on one GPU: 4 sensors, 0.02 m, shard + merge (one step = 4 frames)"}
