@@ -342,7 +342,7 @@ def esdf_fidelity(frames, voxel, n_frames, checkpoints):
             batch[str(i + 1)] = compare(g, mb.esdf_dict())
     strict = compare(gpu_layer(gs), mi.esdf_dict())
     strict["ms_per_update"] = round(float(np.median(strict_ms)), 3)
-    strict["note"] = ("vbx_esdf_cfg.reference_order = 1 (the reference's queue order replayed in parallel, DESIGN 4.4c), same stream, block list "
+    strict["note"] = ("vbx_esdf_cfg.reference_order = 1 (the reference's queue order replayed in parallel, DESIGN 4.5), same stream, block list "
                       "in the iteration order of the reference's own container, host wall clock of vbx_esdf_update_blocks incl. the list upload; "
                       "final layer against the reference's incremental layer: frac_differing must be 0")
     gm.close()

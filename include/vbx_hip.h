@@ -101,8 +101,8 @@ typedef struct vbx_esdf_cfg {
    * depends on an implementation detail): the reference's OWN result — updateFromTsdfBlocks' voxel walk, the FIFO raise
    * queue, BucketQueue pop order with num_buckets / multi_queue, min_diff_m gating, updateVoxelFromNeighbors incl. its
    * unscaled LUT distance, the sign-mismatch rule as written (esdf_integrator.cc:124-530, bucket_queue.h:41-80) — replayed
-   * in parallel, thousands of pops at a time, with the reference's bits as the result (~47 ms per update on
-   * the 640x480 / 0.05 m stream where the reference build needs ~78 ms on one core of the same box).  The blocks are
+   * in parallel, thousands of pops at a time, with the reference's bits as the result (~34 ms per update on
+   * the 640x480 / 0.05 m stream where the reference build needs ~77 ms on one core of the same box).  The blocks are
    * visited in the order of the list given to vbx_esdf_update_blocks; vbx_esdf_update visits them in the iteration order
    * the reference's Layer would have (Layer::getAllUpdatedBlocks over its unordered_map, layer.h:194-203): the library
    * replays that container from the sequence in which the integrators hand blocks to the Layer
@@ -119,7 +119,7 @@ typedef struct vbx_esdf_cfg {
    * reference-order update allocate none of it.
    * 0: the fast mode — order-free wavefronts run to their exact fixed points on the whole chip (0.3 ms per update; NOT
    * the reference's result where it depends on the queue order: bit-exact for batch updates with min_diff_m = 0, inside
-   * the reference's own min_diff_m envelope otherwise, DESIGN 4.4).
+   * the reference's own min_diff_m envelope otherwise, DESIGN 4.5).
    * vbx_esdf_add_new_robot_position reads the field too: with 1 its raise_ / open_ pushes and updated_blocks_
    * insertions are kept in the reference's order for the next update, which must then run with 1 as well (and the
    * other way round: VBX_ERR_UNSUPPORTED when the two calls disagree). */

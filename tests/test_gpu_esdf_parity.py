@@ -1,6 +1,6 @@
 """-m gpu: ESDF integrator on the GPU vs the CPU oracle, through the C-ABI.
 
-Bar: allocated blocks, observed and fixed flags identical; fixed-band
+Bar (HISTORY.md §4.4): allocated blocks, observed and fixed flags identical; fixed-band
 distances bit-exact copies of the TSDF; with min_diff_m = 0 every distance is bit-exact
 against the oracle's updateFromTsdfLayerBatch (the wavefront's fixed point is order-free);
 with the reference's default min_diff_m the reference's own envelope (1e-2 rmse,
@@ -196,7 +196,7 @@ def test_esdf_add_new_robot_position_bit_exact(oracle):
     The occupied sphere covers every observed voxel, so the reference's wavefront (sources = the
     voxels it pushed) reaches the same fixed point as the GPU's unrestricted relaxation; with
     observed voxels outside the sphere the reference stops short at the sphere boundary
-     and only the envelope of the next test applies."""
+    (HISTORY.md §4.4) and only the envelope of the next test applies."""
     from voxblox_amd import capi
     frames = _frames(3)
     sph = dict(clear_sphere_radius=0.6, occupied_sphere_radius=3.8)
@@ -289,7 +289,7 @@ def test_esdf_update_from_tsdf_blocks_subsets(oracle):
     """EsdfIntegrator::updateFromTsdfBlocks(list, incremental=false) on two disjoint halves of the
     TSDF blocks (min_diff_m = 0).  First call (fresh ESDF layer, every source is queued): bit-exact
     against the oracle.  Second call: the reference only expands voxels it queued, so new voxels
-    bordering the first half's converged voxels stay under-relaxed there, while
+    bordering the first half's converged voxels stay under-relaxed there (HISTORY.md §4.4), while
     the pull relaxation here reaches the unrestricted fixed point = the reference's own batch
     result: same masks, |d_gpu| <= |d_ref| everywhere, and bit-exact against the oracle batch."""
     from voxblox_amd import capi

@@ -94,7 +94,7 @@ def test_configs4_full_size_step_equals_serial_oracle_shard_merge(oracle, path, 
     assert len(ref) > 3000            # thousands of 0.32 m blocks: this is the full-size map
     worst = assert_merged_equal(got, ref)
     if path == "native" and bands == 1:
-        assert replay_block_rounds > 0    # the fine-voxel replay of DESIGN 4.3 really ran (whole frames: millions of probes)
+        assert replay_block_rounds > 0    # the fine-voxel replay of DESIGN 4.4 really ran (whole frames: millions of probes)
     print(f"configs[4] {path}, {bands} bands per sensor: {len(ref)} blocks, max |dd| {worst[0]:.2e}, max rel dw {worst[1]:.2e}")
 
 

@@ -181,7 +181,7 @@ int esdf_update_t(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_up
   uint32_t sweeps = 0;
   uint32_t g_sweep = 0;  // sweep number across the phases of this update (the tile kernel's scheduling tag)
   // The wavefronts run to their exact fixed points: min_diff_m only gates the TSDF->ESDF copy
-  // of phase 1 (see DESIGN.md §ESDF for why the relaxation itself uses strict improvement).
+  // of phase 1 (see HISTORY.md §4.4 for why the relaxation itself uses strict improvement).
   EsdfCfgDev cr = c;
   cr.min_diff = 0.0f;
   if (!FULL && (m.nvox & 3u) == 0) {

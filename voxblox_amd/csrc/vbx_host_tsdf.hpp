@@ -782,7 +782,7 @@ int integrate_fast(vbx_ctx* ctx, const vbx_tsdf_cfg* cfg, const Pose& T, const f
         // measured: a check costs about as much as one idle round (the rounds are bound by their ~10
         // dependent kernels, not by the read-back), so batches stay short: 1, 1, 1, then pairs
         // a block of the fine-voxel replay needs a few dozen rounds (each fixes the next link of its dependency chains):
-        // there the checks are spread further (measured at 0.02 m: rounds 187 -> see DESIGN 4.3)
+        // there the checks are spread further (measured at 0.02 m: rounds 187 -> see HISTORY.md §4.3)
         static const uint32_t blk_batch = getenv("VBX_REPLAY_BATCH") ? (uint32_t)atoi(getenv("VBX_REPLAY_BATCH")) : 2u;
         if (a != 0 || b != R) batch = done >= 2 ? blk_batch : 1;
         else batch = done >= 3 ? 2 : 1;

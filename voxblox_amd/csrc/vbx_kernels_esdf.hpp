@@ -3,7 +3,7 @@
 
 namespace {
 // ===========================================================================
-// ESDF integrator (esdf_integrator.cc) — see DESIGN.md §ESDF.
+// ESDF integrator (esdf_integrator.cc) — see DESIGN.md §4.5, HISTORY.md §4.4.
 //
 // The reference runs three strictly sequential phases per update: (1) walk every voxel of the
 // updated TSDF blocks and classify it (new / lower / raise / sign flip), (2) a FIFO "raise"

@@ -75,7 +75,7 @@ __global__ void k_compact_rays(RayTab in, const uint32_t* __restrict__ keep,
 #ifndef VBX_LIST_RPW
 #define VBX_LIST_RPW 64
 #endif
-constexpr int kListRPW = VBX_LIST_RPW;  // rays per wave in k_fast_build_lists (32 and 16 measured: see DESIGN 4.3b)
+constexpr int kListRPW = VBX_LIST_RPW;  // rays per wave in k_fast_build_lists (32 and 16 measured: see HISTORY.md §4.3b)
 template <int RPW>
 __global__ void __launch_bounds__(256)
 k_fast_build_lists(RayTab tab, CastCfg c, MapDev m, const uint32_t* __restrict__ off,
