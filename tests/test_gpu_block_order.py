@@ -179,3 +179,62 @@ def test_layer_order_at_baseline_size(oracle, voxel, n_frames):
         got, exact = gm.block_indices_layer_order()
         assert exact and _order(got) == _order(om.block_indices(0)), f
     assert om.num_blocks(0) > (200 if voxel > 0.03 else 1000)
+
+
+def test_clear_with_a_pending_log_keeps_the_containers_bucket_arrays(oracle):
+    """ADVICE (round 5): integrate -> vbx_clear with nothing asking for the order in between.  The reference's
+    temp_block_map_ and Layer::block_map_ keep the bucket arrays those insertions grew (clear() keeps the buckets,
+    layer.h:164, tsdf_integrator.cc:146), and where LATER insertions land depends on them: the library must replay the
+    pending log into its two containers before it clears them, or the blocks integrated after the clear iterate in another
+    order while `exact` still says 1."""
+    from voxblox_amd import capi
+    L = oracle.lib()
+    L.orc_fast_reset_counter_set(0)
+    capi.lib().vbx_fast_reset_counter_set(0)
+    voxel = 0.1
+    om = oracle.OracleMap(voxel, 16)
+    oi = om.tsdf_integrator("fast", oracle.tsdf_cfg(default_truncation_distance=4 * voxel, integrator_threads=1))
+    gm = capi.Map(voxel, 16, max_blocks=4096)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    frames = S.frames(6)
+    for pose, pts, col in frames[:3]:          # the log of these calls is never drained ...
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+    assert om.num_blocks(0) > 60               # (enough insertions to have grown the bucket arrays several times)
+    om.clear(0)                                # Layer::removeAllBlocks
+    gm.clear(capi.LAYER_TSDF)                  # ... before the layer goes
+    for f, (pose, pts, col) in enumerate(frames[3:]):
+        oi.integrate(pose[0], pose[1], pts, col)
+        gm.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+        got, exact = gm.block_indices_layer_order()
+        assert exact
+        assert _order(got) == _order(om.block_indices(0)), f
+
+
+def test_blocks_of_unknown_provenance_are_reported_not_silently_reordered(oracle, capfd):
+    """ADVICE (round 5): vbx_esdf_update(reference_order = 1) over blocks whose place in the reference Layer's order the
+    library never saw (deserialised into the map) walks them in ascending key order behind the known ones — and SAYS so:
+    vbx_counters.esdf_order_inexact, one line on stderr per handle, exact = 0 from vbx_block_indices_layer_order."""
+    from voxblox_amd import capi
+    voxel = 0.1
+    src = capi.Map(voxel, 16, max_blocks=4096)
+    gc = capi.tsdf_cfg(default_truncation_distance=4 * voxel)
+    for pose, pts, col in S.frames(2):
+        src.integrate(capi.TSDF_FAST, gc, pose[0], pose[1], pts, col)
+    idx = src.block_indices()
+    words, has_data = src.blocks_serialize(idx, capi.LAYER_TSDF)
+    dst = capi.Map(voxel, 16, max_blocks=4096)
+    dst.blocks_deserialize(idx, words, has_data, capi.LAYER_TSDF)       # Layer::addBlockFromProto: no first-touch ranks
+    ecfg = capi.esdf_cfg(min_distance_m=2 * voxel, reference_order=1)
+    dst.esdf_update(ecfg, batch=True)
+    c = dst.counters()
+    assert c["esdf_order_inexact"] > 0 and c["esdf_blocks"] == len(idx)
+    _, exact = dst.block_indices_layer_order()
+    assert not exact
+    err = capfd.readouterr().err
+    assert "reference_order = 1" in err and "unknown to the library" in err
+    dst.esdf_update(ecfg, batch=True)                                   # reported once per handle
+    assert "unknown to the library" not in capfd.readouterr().err
+    # the source map, whose blocks the library followed from their first touch, is exact
+    src.esdf_update(ecfg, batch=True)
+    assert src.counters()["esdf_order_inexact"] == 0
