@@ -317,9 +317,10 @@ RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
 // a wait that does not end (kTgtSpin looks) gives the target up like a full pool does (the record is poisoned).
 constexpr uint32_t kBusyTgt = 0xFFFFFFFFu;
 constexpr uint32_t kTgtSpin = 1u << 14;
-RP_FN uint32_t rp_target(const Args& a, uint32_t gid) {
+// (v: what vox2tgt[gid] held when the caller looked — rp_place reads it together with the voxel's state, distance and hazard
+// byte, one trip to memory instead of four in a row)
+RP_FN uint32_t rp_target(const Args& a, uint32_t gid, uint32_t v) {
   Ctl& c = *a.ctl;
-  const uint32_t v = a.vox2tgt[gid];
   if (v != 0u && v != kBusyTgt) return v - 1u;
   if (c.n_tgt >= a.tgt_cap) return kNone;   // (racy look, the exact test follows; keeps the counter from running away)
   if (a.c.tgt_claim) {
@@ -357,16 +358,15 @@ RP_FN uint32_t rp_target(const Args& a, uint32_t gid) {
 // of the other class anywhere around it (Args::hazard) only the two same-sign branches can ever fire, they only move
 // the neighbour towards zero, and an offer that does not beat the neighbour's distance at the start of the super-step
 // cannot beat a later one.  The test is repeated whenever the record's guessed state changes (rp_phase_apply).
-RP_FN bool rp_offer_possible(const Args& a, float vd, uint32_t vs, uint32_t ngid, int lut) {
+// (sn, nd, hz: the neighbour's state word, distance and hazard byte, read by the caller in one go)
+RP_FN bool rp_offer_possible(const Args& a, float vd, uint32_t vs, uint32_t sn, float nd, bool hz, int lut) {
   if (a.c.filter < 1) return true;
-  const uint32_t sn = a.state[ngid];
   if (!(sn & kObserved) || (sn & kFixed)) return false;
   if (a.ctl->raise || a.c.full || !a.hazard || a.c.filter < 2) return true;
   if (!(vs & kObserved) || vd >= a.c.max_distance || vd <= -a.c.max_distance) return false;   // the pop offers nothing (:389-392)
   if (a.c.filter < 3) return true;
-  const float nd = a.dist[ngid];
   if ((vd > 0) != (nd > 0)) return true;
-  if (a.hazard[ngid]) return true;
+  if (hz) return true;
   const float distance = rp_lut_distance(lut) * a.c.voxel_size;
   return vd > 0 ? (vd + distance + a.c.min_diff < nd) : (vd - distance - a.c.min_diff > nd);
 }
@@ -378,11 +378,17 @@ RP_FN void rp_place(const Args& a, uint32_t r, uint32_t base, uint32_t gid, uint
   const uint32_t ngid = p == 26 ? gid : rp_neighbour(a, gid, (int)p);
   uint32_t t = kNone;
   if (ngid != kNone) {
-    if (p != 26 && !rp_offer_possible(a, vd, vs, ngid, (int)p)) {
+    // everything this thread will want to know about the voxel, asked for at once (the loads are independent; behind the
+    // early returns of the tests below they were four dependent trips)
+    const uint32_t v2t = a.vox2tgt[ngid];
+    const uint32_t sn = a.state[ngid];
+    const float nd = a.dist[ngid];
+    const bool hz = a.hazard ? a.hazard[ngid] != 0 : true;
+    if (p != 26 && !rp_offer_possible(a, vd, vs, sn, nd, hz, (int)p)) {
       a.rec_tgts[(size_t)r * 27 + p] = kSkip;
       return;
     }
-    t = rp_target(a, ngid);
+    t = rp_target(a, ngid, v2t);
   }
   a.rec_tgts[(size_t)r * 27 + p] = t;
   if (ngid == kNone) return;
