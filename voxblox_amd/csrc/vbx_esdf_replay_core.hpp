@@ -319,13 +319,25 @@ constexpr uint32_t kBusyTgt = 0xFFFFFFFFu;
 constexpr uint32_t kTgtSpin = 1u << 14;
 // (v: what vox2tgt[gid] held when the caller looked — rp_place reads it together with the voxel's state, distance and hazard
 // byte, one trip to memory instead of four in a row)
+#ifndef RP_LD_RO
+#define RP_LD_RO(x) RP_LD(x)
+#endif
 RP_FN uint32_t rp_target(const Args& a, uint32_t gid, uint32_t v) {
   Ctl& c = *a.ctl;
   if (v != 0u && v != kBusyTgt) return v - 1u;
   if (c.n_tgt >= a.tgt_cap) return kNone;   // (racy look, the exact test follows; keeps the counter from running away)
   if (a.c.tgt_claim) {
     for (uint32_t spin = 0; spin < kTgtSpin; ++spin) {
+      // (a voxel somebody else is busy with is WATCHED with reads — RP_LD_RO: a coherent load where the includer has one —
+      // and only asked for with a compare-and-swap again once it reads free: up to 26 lanes wait for the 27th here, and a
+      // swap per look is a read-modify-write at the memory side where a look costs a read)
+      if (v == kBusyTgt) {
+        v = RP_LD_RO(a.vox2tgt[gid]);
+        if (v == kBusyTgt) continue;
+        if (v != 0u) return v - 1u;
+      }
       const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, kBusyTgt);
+      v = old;
       if (old == 0u) {
         const uint32_t id = RP_INC(&c.n_tgt);
         if (id >= a.tgt_cap) {

@@ -27,6 +27,7 @@ __device__ inline bool rp_wg_dirty_push(uint32_t t);
 #define RP_WG_DIRTY_PUSH(t) rp_wg_dirty_push(t)
 #define RP_LD(x) atomicAdd(&(x), 0u)
 #define RP_LD64(x) atomicAdd(&(x), 0ull)
+#define RP_LD_RO(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // a coherent READ (no read-modify-write)
 #include "vbx_esdf_replay_core.hpp"
 
 namespace {
