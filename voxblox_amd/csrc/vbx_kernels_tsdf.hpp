@@ -378,29 +378,49 @@ __global__ void __launch_bounds__(256) k_fold_inputs(const uint64_t* __restrict_
 // frame than inputs / tiles / long runs, and no staging arrays.
 __global__ void __launch_bounds__(256) k_fold_direct(const uint64_t* __restrict__ keys, size_t n, RayTab tab, CastCfg c,
                                                      MapDev m, DevState* st) {
+  // Round 6: the state-independent half of EVERY update (projective sdf, drop-off weight: the gathers from the ray table, a
+  // square root and two divisions) is computed by the thread that holds the key — all lanes busy — and left in LDS; the run's
+  // head then only applies the two or three cheap state updates of its voxel.  Before, the head walked its run alone through
+  // key -> ray table -> arithmetic, one dependent chain per update, while two thirds of the lanes had left (64 us per frame).
+  __shared__ float s_sdf[256], s_uw[256];
+  __shared__ uint32_t s_rgba[256], s_gid[256];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = (i < n) ? keys[i] : ~0ull;
   const uint32_t gid = (uint32_t)(key >> 32);
   const uint32_t prev_gid = i > 0 ? (uint32_t)(keys[i - 1] >> 32) : 0xFFFFFFFFu;
   const bool head = key != ~0ull && !(i > 0 && prev_gid == gid);
+  l3 g{0, 0, 0};
+  s_gid[threadIdx.x] = gid;
+  if (key != ~0ull) {
+    g = voxel_of_gid(m, gid);
+    const uint32_t o = (uint32_t)(key & 0xFFFFFFFFu);
+    float sdf, uw;
+    tsdf_update_inputs(c, m.voxel_size, f3{tab.px[o], tab.py[o], tab.pz[o]}, g, tab.w[o], &sdf, &uw);
+    s_sdf[threadIdx.x] = sdf;
+    s_uw[threadIdx.x] = uw;
+    s_rgba[threadIdx.x] = tab.rgba[o];
+  }
   const int nheads = __syncthreads_count(head);
   if (threadIdx.x == 0 && nheads) atomicAdd(&st->voxels_touched[blockIdx.x & 63u], (unsigned long long)nheads);
   if (!head) return;
   // block->updated().set() (tsdf_integrator.cc:128): the keys are sorted by voxel, so the first key of a block is one thread
   if (i == 0 || prev_gid / m.nvox != gid / m.nvox) publish_block(m, gid / m.nvox, st);
-  const l3 g = voxel_of_gid(m, gid);
   float d = m.dist[gid];
   float W = m.weight[gid];
   uint32_t col = m.rgba[gid];
-  uint64_t k = key;
+  uint32_t t = threadIdx.x;
   for (size_t j = i;;) {
-    const uint32_t o = (uint32_t)(k & 0xFFFFFFFFu);
-    float sdf, uw;
-    tsdf_update_inputs(c, m.voxel_size, f3{tab.px[o], tab.py[o], tab.pz[o]}, g, tab.w[o], &sdf, &uw);
-    tsdf_update_state(c, sdf, uw, tab.rgba[o], d, W, col);
+    if (t < 256u) {   // the update's inputs wait in LDS
+      tsdf_update_state(c, s_sdf[t], s_uw[t], s_rgba[t], d, W, col);
+    } else {          // the run crosses the workgroup's last key: the old way for the rest of it
+      const uint32_t o = (uint32_t)(keys[j] & 0xFFFFFFFFu);
+      float sdf, uw;
+      tsdf_update_inputs(c, m.voxel_size, f3{tab.px[o], tab.py[o], tab.pz[o]}, g, tab.w[o], &sdf, &uw);
+      tsdf_update_state(c, sdf, uw, tab.rgba[o], d, W, col);
+    }
+    ++t;
     if (++j >= n) break;
-    k = keys[j];
-    if ((uint32_t)(k >> 32) != gid) break;
+    if (t < 256u ? s_gid[t] != gid : (uint32_t)(keys[j] >> 32) != gid) break;
   }
   m.dist[gid] = d;
   m.weight[gid] = W;
