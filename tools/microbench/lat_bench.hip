@@ -1,0 +1,138 @@
+// Latency price list of MI355X as the ESDF replay's rankings see it: one workgroup of 256 threads on an otherwise idle chip.
+// hipcc --offload-arch=gfx950 -O3 -o lat_bench lat_bench.hip ; ./lat_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <numeric>
+#include <algorithm>
+#include <random>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void k_chase(const uint32_t* next, uint32_t start, int steps, unsigned long long* out) {
+  uint32_t i = start;
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) i = next[i];
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = i; }
+}
+__global__ void k_chase_atomic(uint32_t* next, uint32_t start, int steps, unsigned long long* out) {
+  uint32_t i = start;
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) i = atomicAdd(&next[i], 0u);
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = i; }
+}
+__global__ void k_chase_exch(uint32_t* next, uint32_t* flags, uint32_t start, int steps, unsigned long long* out) {
+  uint32_t i = start;
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) { const uint32_t w = atomicExch(&flags[i], 1u); i = next[i] + w; }   // load + atomic in one trip (independent)
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = i; }
+}
+__global__ void k_barrier(int steps, unsigned long long* out) {
+  __shared__ uint32_t x;
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) { if (threadIdx.x == (s & 255)) x = s; __syncthreads(); }
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = x; }
+}
+__global__ void k_clock(int steps, unsigned long long* out) {
+  unsigned long long acc = 0;
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) acc += wall_clock64();
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = acc; }
+}
+// store then barrier (the fence of __syncthreads waits for the store's acknowledgement)
+__global__ void k_store_barrier(uint32_t* buf, int steps, unsigned long long* out) {
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) { buf[(size_t)s * 4096 + threadIdx.x * 16] = s; __syncthreads(); }
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; }
+}
+// every thread loads 1 / 4 / 8 independent random words per trip, then a barrier: what a "batched" pass costs
+template <int B>
+__global__ void k_batch(const uint32_t* next, int steps, unsigned long long* out) {
+  uint32_t i[B];
+  for (int b = 0; b < B; ++b) i[b] = (threadIdx.x * 977u + b * 131071u + blockIdx.x * 7919u) & 0xFFFFFu;
+  const unsigned long long t0 = wall_clock64();
+  for (int s = 0; s < steps; ++s) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) i[b] = next[i[b]];
+  }
+  const unsigned long long t1 = wall_clock64();
+  uint32_t acc = 0;
+  for (int b = 0; b < B; ++b) acc += i[b];
+  if (threadIdx.x == 0) { out[0] = t1 - t0; }
+  if (acc == 0xdeadbeef) out[1] = acc;
+}
+__global__ void k_busy(float* x, int iters) {   // background load: other workgroups spinning on ALU + memory
+  float v = x[blockIdx.x * blockDim.x + threadIdx.x];
+  for (int i = 0; i < iters; ++i) v = v * 1.0001f + 0.5f;
+  x[blockIdx.x * blockDim.x + threadIdx.x] = v;
+}
+
+static std::vector<uint32_t> cycle(size_t n, uint32_t seed) {
+  std::vector<uint32_t> perm(n), next(n);
+  std::iota(perm.begin(), perm.end(), 0u);
+  std::mt19937 g(seed);
+  std::shuffle(perm.begin(), perm.end(), g);
+  for (size_t k = 0; k < n; ++k) next[perm[k]] = perm[(k + 1) % n];
+  return next;
+}
+
+int main() {
+  unsigned long long* out; CK(hipMalloc(&out, 64));
+  unsigned long long h[2];
+  auto report = [&](const char* what, int steps) {
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost));
+    printf("%-64s %8.1f ns per step\n", what, h[0] * 10.0 / steps);
+  };
+  const int steps = 2000;
+  for (size_t words : {size_t(1) << 16, size_t(1) << 20, size_t(1) << 24, size_t(1) << 28}) {
+    auto nx = cycle(words, 7);
+    uint32_t *d, *fl; CK(hipMalloc(&d, words * 4)); CK(hipMalloc(&fl, words * 4));
+    CK(hipMemcpy(d, nx.data(), words * 4, hipMemcpyHostToDevice)); CK(hipMemset(fl, 0, words * 4));
+    char name[128];
+    for (int rep = 0; rep < 2; ++rep) {
+      snprintf(name, sizeof name, "dependent loads, 1 thread, %zu KB%s", words * 4 / 1024, rep ? " (again)" : "");
+      k_chase<<<1, 1>>>(d, 0, steps, out); report(name, steps);
+    }
+    snprintf(name, sizeof name, "dependent loads, 256 threads same address, %zu KB", words * 4 / 1024);
+    k_chase<<<1, 256>>>(d, 0, steps, out); report(name, steps);
+    snprintf(name, sizeof name, "dependent returning atomicAdd(+0), 1 thread, %zu KB", words * 4 / 1024);
+    k_chase_atomic<<<1, 1>>>(d, 0, steps, out); report(name, steps);
+    snprintf(name, sizeof name, "load + atomicExch per step, 1 thread, %zu KB", words * 4 / 1024);
+    k_chase_exch<<<1, 1>>>(d, fl, 0, steps, out); report(name, steps);
+    if (words >= (size_t(1) << 20)) {
+      snprintf(name, sizeof name, "256 threads x 1 random load per step, %zu KB", words * 4 / 1024);
+      k_batch<1><<<1, 256>>>(d, steps, out); report(name, steps);
+      snprintf(name, sizeof name, "256 threads x 4 random loads per step, %zu KB", words * 4 / 1024);
+      k_batch<4><<<1, 256>>>(d, steps, out); report(name, steps);
+      snprintf(name, sizeof name, "256 threads x 8 random loads per step, %zu KB", words * 4 / 1024);
+      k_batch<8><<<1, 256>>>(d, steps, out); report(name, steps);
+      snprintf(name, sizeof name, "... the same in 150 workgroups at once, x 8, %zu KB", words * 4 / 1024);
+      k_batch<8><<<150, 256>>>(d, steps, out); report(name, steps);
+    }
+    CK(hipFree(d)); CK(hipFree(fl));
+  }
+  k_barrier<<<1, 256>>>(20000, out); report("__syncthreads, 256 threads", 20000);
+  k_clock<<<1, 64>>>(20000, out); report("wall_clock64", 20000);
+  {
+    uint32_t* buf; CK(hipMalloc(&buf, size_t(2000) * 4096 * 4));
+    k_store_barrier<<<1, 256>>>(buf, 2000, out); report("store + __syncthreads, 256 threads", 2000);
+    CK(hipFree(buf));
+  }
+  // with the rest of the chip busy
+  {
+    float* x; CK(hipMalloc(&x, 1023 * 256 * 4)); CK(hipMemset(x, 0, 1023 * 256 * 4));
+    auto nx = cycle(size_t(1) << 24, 7);
+    uint32_t* d; CK(hipMalloc(&d, nx.size() * 4)); CK(hipMemcpy(d, nx.data(), nx.size() * 4, hipMemcpyHostToDevice));
+    hipStream_t s2; CK(hipStreamCreate(&s2));
+    k_busy<<<1023, 256, 0, s2>>>(x, 4000000);
+    k_chase<<<1, 1>>>(d, 0, steps, out); report("dependent loads, 1 thread, 64 MB, 1023 busy workgroups beside", steps);
+    CK(hipDeviceSynchronize());
+  }
+  return 0;
+}

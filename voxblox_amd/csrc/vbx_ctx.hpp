@@ -105,7 +105,7 @@ struct vbx_ctx {
   DBuf b_edist, b_estate, b_eraised, b_eactive;
   // parallel reference-order open set (vbx_kernels_esdf_replay.hpp): control block, records, targets, lists
   DBuf rp_ctl, rp_nbslot, rp_chunk_tab, rp_rec_u32, rp_rec_T, rp_rec_kid, rp_rec_tgts, rp_rec_push, rp_vox2tgt, rp_tgt_u32, rp_tgt_ev, rp_dl,
-      rp_lists, rp_sub, rp_sub_list, rp_sim_q, rp_ord, rp_scan_desc, rp_hazard, cls_pos, cls_nb27, cls_shadow, cls_counters;
+      rp_lists, rp_sub, rp_sub_list, rp_sim_q, rp_ord, rp_wg_stats, rp_scan_desc, rp_hazard, cls_pos, cls_nb27, cls_shadow, cls_counters;
   size_t rp_vox2tgt_zeroed = 0;   // bytes of rp_vox2tgt known to be zero
   uint32_t rp_rec_cap = 0, rp_tgt_cap = 0, rp_kmax = 0, rp_smax = 0, rp_scan_tiles_cap = 0;
   bool esdf_init = false;

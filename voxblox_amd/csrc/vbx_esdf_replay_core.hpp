@@ -44,6 +44,7 @@ namespace rp {
 
 constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kWgStats = 16;
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
 #ifndef RP_EVQ
@@ -130,7 +131,7 @@ struct Ctl {
   uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
   // statistics
   unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
-  unsigned long long st_sim_members, st_sim_pops, st_sim_hist[4], st_sim_ticks[3];   // (device ranking) members loaded, pops replayed, rankings by pops replayed: < 16, < 64, < 256, more
+  unsigned long long st_sim_members, st_sim_pops, st_sim_hist[4], st_sim_ticks[5];   // (device ranking) members loaded, pops replayed, rankings by pops replayed: < 16, < 64, < 256, more
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16], t_prev;
   // ---- per queue (bucket 0 .. num_buckets - 1, raise_ = num_buckets); the device wrapper moves the first num_buckets + 1 of each
   uint32_t head[kMaxBuckets + 1], tail[kMaxBuckets + 1];  // A: FIFO indices (entries ever popped / pushed)
@@ -196,6 +197,7 @@ struct Args {
   uint32_t* sub_mem;        // [slots][smax]
   uint32_t* sub_mem_n;      // [kmax]
   uint32_t* rec_local;      // [rec] 1 + index in its excursion's member list (0: the base record)
+  unsigned long long* wg_stats;   // (VBX_RP_STATS, may be null) [workgroup][kWgStats]: what a ranking cost, kept per workgroup — atomics on Ctl's lines slow down what they measure
   uint32_t* rec_plocal;     // [rec] rec_local of the record's pusher, noted at birth (may be null: the ranking then asks rec_local[rec_pusher[r]] — one more dependent trip to memory per member)
   uint32_t* sub_restart;    // [kmax] smallest rank at which the excursion's structure changed since its last ranking
   unsigned long long* sim_q;  // [slots][smax] scratch of the ranking

@@ -447,6 +447,10 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   const uint32_t rec_cap = kmax * 12 + 65536, tgt_cap = rec_cap * 2;
   const bool fresh = !ctx->rp_ctl.p;
   HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl)));
+  if (getenv("VBX_RP_STATS")) {   // what the rankings cost, per workgroup (rp::Args::wg_stats), zero at the start of an update
+    HIP_TRY(ctx->rp_wg_stats.ensure((size_t)4096 * rp::kWgStats * 8));
+    HIP_TRY(hipMemsetAsync(ctx->rp_wg_stats.p, 0, (size_t)4096 * rp::kWgStats * 8, s));
+  }
   HIP_TRY(ctx->rp_nbslot.ensure((size_t)std::max<uint32_t>(used, 1) * 27 * 4));
   HIP_TRY(ctx->rp_hazard.ensure((size_t)std::max<uint32_t>(used, 1) * m.nvox));
   HIP_TRY(ctx->rp_chunk_tab.ensure((size_t)(num_buckets + 1) * n_chunks * 4));
@@ -549,6 +553,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.rec_born_it = ru + (size_t)10 * R;
   a.rec_plocal = ru + (size_t)11 * R;
   a.c.stats = getenv("VBX_RP_STATS") ? 1u : 0u;
+  a.wg_stats = (a.c.stats && ctx->rp_wg_stats.p) ? ctx->rp_wg_stats.as<unsigned long long>() : nullptr;
   a.rec_T = ctx->rp_rec_T.as<unsigned long long>();
   a.rec_kid = ctx->rp_rec_kid.as<uint32_t>();
   a.rec_tgts = ctx->rp_rec_tgts.as<uint32_t>();
@@ -623,10 +628,15 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
             hc.st_pops, hc.st_relax, hc.st_supersteps, hc.st_iters, hc.st_folds, hc.st_exc, hc.st_cut_iters, hc.st_cut_smax, hc.st_steps,
             hc.st_poison, hc.error);
     for (int k = 1; k < 13; ++k) fprintf(stderr, " %s %llu(%llu, %.2f ms)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k], hc.st_phase_ticks[k] * 1e-5);
-    fprintf(stderr, "\n[rp] rankings: members loaded %llu, pops replayed %llu, by pops replayed <16: %llu <64: %llu <256: %llu more: %llu", hc.st_sim_members, hc.st_sim_pops,
-            hc.st_sim_hist[0], hc.st_sim_hist[1], hc.st_sim_hist[2], hc.st_sim_hist[3]);
-    fprintf(stderr, "; workgroup-ms summed over rankings: tables %.2f, queue replay %.2f, write-back %.2f", hc.st_sim_ticks[0] * 1e-5, hc.st_sim_ticks[1] * 1e-5,
-            hc.st_sim_ticks[2] * 1e-5);
+    if (a.wg_stats) {
+      std::vector<unsigned long long> ws((size_t)4096 * rp::kWgStats), tot(rp::kWgStats, 0);
+      HIP_TRY(hipMemcpy(ws.data(), a.wg_stats, ws.size() * 8, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ws.size(); ++i) tot[i % rp::kWgStats] += ws[i];
+      fprintf(stderr, "\n[rp] rankings: %llu, members loaded %llu, pops replayed %llu, by pops replayed <16: %llu <64: %llu <256: %llu more: %llu", tot[15], tot[0], tot[1],
+              tot[2], tot[3], tot[4], tot[5]);
+      fprintf(stderr, "; workgroup-ms summed over rankings: header %.2f, records %.2f, tables %.2f, queue at the restart point %.2f, queue replay %.2f, pop times written %.2f, "
+              "marks %.2f, filed %.2f, batches %llu", tot[6] * 1e-5, tot[7] * 1e-5, tot[8] * 1e-5, tot[9] * 1e-5, tot[10] * 1e-5, tot[11] * 1e-5, tot[12] * 1e-5, tot[13] * 1e-5, tot[14]);
+    }
     fprintf(stderr, "\n");
   }
   if (!hc.done) {

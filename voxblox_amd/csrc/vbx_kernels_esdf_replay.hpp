@@ -43,6 +43,27 @@ __device__ inline void rp_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// inclusive prefix sum / prefix maximum over the 64 lanes on the DPP data path (values >= 0: lanes without a source read 0)
+__device__ inline uint32_t rp_wave_scan_add(uint32_t x) {
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (uint32_t)v;
+}
+__device__ inline uint32_t rp_wave_scan_max(uint32_t x) {
+  int v = (int)x;
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+  return (uint32_t)v;
+}
 
 constexpr int kRpThreads = 256;
 constexpr uint32_t kWgDirtyCap = 4000;   // dirty marks a workgroup collects in PH_APPLY before it falls back to the shared counter
@@ -437,7 +458,7 @@ struct SimLds {
   unsigned short first[kSimMax + 2], kids[kSimMax];
   unsigned short kidb[kSimMax];               // bucket of kids[x] (read with it: one LDS round trip less per pop)
   uint32_t wave_tot[kRpThreads / 64];
-  uint32_t info[kSimMax];                     // lut | bucket << 8 | live << 16 | poisoned << 17 | has an unlisted child << 18 | pusher's position << 19
+  uint32_t info[kSimMax];                     // lut | bucket << 8 | live << 16 | poisoned << 17 | has an unlisted child << 18 | pusher's position << 19 (11 bits) | rp_moved_needs_mark << 30
   unsigned short next[kSimMax], rank[kSimMax];
   uint32_t pend_key[kSimMax];                 // pending records at the restart point: bucket << 24 | pusher rank << 5 | lut
   unsigned short pend_j[kSimMax], sorted[kSimMax];
@@ -476,31 +497,74 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   const int tid = threadIdx.x, lane = threadIdx.x & 63;
   const unsigned long long tk0 = wall_clock64();   // (100 MHz; Ctl::st_sim_ticks: tables built / queue replayed / pop times written)
   unsigned long long tk1 = tk0, tk2 = tk0;
+  uint32_t n_batches = 0;
+  // Every pass below issues ALL its loads before it uses one: a ranking is a chain of dependent trips to memory (~1.5 us each
+  // on a mostly idle chip), and a loop of "load, test, load" over 256 members at a time pays the chain once per 256 members —
+  // the launch waits for its LARGEST ranking (round 6: tables 7.8 + pop times 5.1 + marks 3.9 us for the average ranking of 25
+  // members; a ranking that moved 300 members spent as long on its marks as on replaying the queue).
+  constexpr int kPer1 = kSimMax / kRpThreads;
+  // trip 1: the excursion's header and — when the list's place follows from the base record (Cfg::slot_by_base) — the member list
+  const bool guess = a.c.slot_by_base && base < a.sub_slots_cap;
+  uint32_t rr[kPer1];
+  {
+    const uint32_t* mem_g = a.sub_mem + (size_t)base * smax;
+#pragma unroll
+    for (int k = 0; k < kPer1; ++k) {
+      const uint32_t j = tid + k * kRpThreads;
+      rr[k] = (guess && j < smax) ? mem_g[j] : 0u;
+    }
+  }
   const uint32_t slot = a.sub_slot[base];
-  uint32_t n = (slot != 0u && slot <= a.sub_slots_cap) ? a.sub_mem_n[base] : 0u;
-  if (n > smax) n = smax;
-  const uint32_t* mem = a.sub_mem + (size_t)(slot ? slot - 1 : 0) * smax;
-  const int nb = (int)c.bucket;
+  const uint32_t mem_n = a.sub_mem_n[base];
   uint32_t p = a.sub_restart[base];          // ranks <= p stand
   const uint32_t old_n = a.sub_n[base];
+  const uint32_t base_meta = a.rec_meta[base];
+  const uint32_t it_now = (uint32_t)c.st_iters;
+  uint32_t n = (slot != 0u && slot <= a.sub_slots_cap) ? mem_n : 0u;
+  if (n > smax) n = smax;
+  const int nb = (int)c.bucket;
   if (p > old_n) p = old_n;
+  if (!(guess && slot == base + 1u)) {
+    const uint32_t* mem = a.sub_mem + (size_t)(slot ? slot - 1 : 0) * smax;
+#pragma unroll
+    for (int k = 0; k < kPer1; ++k) {
+      const uint32_t j = tid + k * kRpThreads;
+      rr[k] = j < n ? mem[j] : 0u;
+    }
+  }
   __syncthreads();
+  const unsigned long long ta = wall_clock64();
   for (uint32_t i = tid; i < n + 2; i += kRpThreads) L.cnt[i] = 0;
   for (int i = tid; i < nb; i += kRpThreads) { L.head[i] = 0xFFFF; L.tail[i] = 0xFFFF; }
-  if (tid == 0) { L.n_pend = 0; L.flag_rank = 0xFFFFFFFFu; }
+  if (tid == 0) { L.n_pend = 0; L.flag_rank = (base_meta & (1u << 18)) ? 0u : 0xFFFFFFFFu; }
+  // trip 2: the members' records (a member always has a pusher — PH_APPLY made it —, so rp::rp_moved_needs_mark is its birth
+  // iteration alone: bit 30 of the table word, and the write-back does not go to memory for it)
+  uint32_t m4[kPer1], pl4[kPer1], po4[kPer1], bi4[kPer1];
+  unsigned long long T4[kPer1];
+#pragma unroll
+  for (int k = 0; k < kPer1; ++k) {
+    const uint32_t j = tid + k * kRpThreads;
+    const bool on = j < n;
+    const uint32_t r = rr[k];
+    m4[k] = on ? a.rec_meta[r] : 0u;
+    pl4[k] = on ? (a.rec_plocal ? a.rec_plocal[r] : a.rec_local[a.rec_pusher[r]]) : 0u;
+    T4[k] = on ? a.rec_T[r] : rp::kNever;
+    po4[k] = on ? a.rec_poison[r] : 0u;
+    bi4[k] = (on && a.rec_born_it) ? a.rec_born_it[r] : ~it_now;
+  }
   __syncthreads();
-  const uint32_t base_meta = a.rec_meta[base];
-  if (tid == 0 && (base_meta & (1u << 18))) L.flag_rank = 0;
+  const unsigned long long tb = wall_clock64();
   // pass 1: records, their old ranks, the child table
-  for (uint32_t j = tid; j < n; j += kRpThreads) {
-    const uint32_t r = mem[j];
-    L.memr[j] = r;
-    const uint32_t m = a.rec_meta[r];
-    const uint32_t pl = a.rec_plocal ? a.rec_plocal[r] : a.rec_local[a.rec_pusher[r]];
-    const unsigned long long T = a.rec_T[r];
+#pragma unroll
+  for (int k = 0; k < kPer1; ++k) {
+    const uint32_t j = tid + k * kRpThreads;
+    if (j >= n) continue;
+    const uint32_t m = m4[k], pl = pl4[k];
+    const unsigned long long T = T4[k];
+    L.memr[j] = rr[k];
     uint32_t rk = 0xFFFF;
     if (T != rp::kNever && (uint32_t)(T & rp::kRankMask) <= p) rk = (uint32_t)(T & rp::kRankMask);   // it popped in front of the restart point
-    L.info[j] = (m & 0x1FFFFu) | (a.rec_poison[r] ? (1u << 17) : 0u) | (m & (1u << 18)) | (pl << 19);
+    L.info[j] = (m & 0x1FFFFu) | (po4[k] ? (1u << 17) : 0u) | (m & (1u << 18)) | (pl << 19) | (bi4[k] == it_now ? 0u : (1u << 30));
     L.next[j] = (unsigned short)0xFFFF;
     L.rank[j] = (unsigned short)rk;
     L.orank[j] = T != rp::kNever ? (unsigned short)(T & 0x7FFFu) : (unsigned short)0;   // (ranks stay below smax <= 1024)
@@ -538,7 +602,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   __syncthreads();
   for (uint32_t j = tid; j < n; j += kRpThreads) {
     const uint32_t inf = L.info[j];
-    if ((inf >> 16) & 1u) L.kids[L.first[inf >> 19] + atomicAdd(&L.cnt[inf >> 19], 1u)] = (unsigned short)j;
+    if ((inf >> 16) & 1u) L.kids[L.first[(inf >> 19) & 0x7FFu] + atomicAdd(&L.cnt[(inf >> 19) & 0x7FFu], 1u)] = (unsigned short)j;
   }
   __syncthreads();
   for (uint32_t pl = tid; pl <= n; pl += kRpThreads) {   // a record's children in LUT order (26 at most)
@@ -553,18 +617,22 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   }
   __syncthreads();
   for (uint32_t x = tid; x < (uint32_t)L.first[n + 1]; x += kRpThreads) L.kidb[x] = (unsigned short)((L.info[L.kids[x]] >> 8) & 0xFF);
+  const bool arrays = nb <= 64;   // the bucket FIFOs as arrays (below); more buckets than lanes: linked lists, one pop at a time
+  if (arrays && tid < 64) { L.cnt[tid] = 0; L.tail[tid] = 0; L.moved[tid] = 0; }   // (cnt is free since the child table was filled)
   // a record with an unlisted child in front of the restart point: the ranking ends behind it
   uint32_t R = p;
   bool truncated = false;
   if (L.flag_rank <= p) { R = L.flag_rank; truncated = true; }
   __syncthreads();
+  const unsigned long long te = wall_clock64();
   // pass 2: the queue at the restart point
   if (!truncated) {
     for (uint32_t j = tid; j < n; j += kRpThreads) {
       const uint32_t inf = L.info[j];
       if (!((inf >> 16) & 1u)) continue;                      // dead
       if (L.rank[j] != 0xFFFF) continue;                      // popped already
-      const uint32_t pl = inf >> 19;
+      if (arrays && ((inf >> 8) & 0xFF) < 64u) atomicAdd(&L.cnt[(inf >> 8) & 0xFF], 1u);   // it may enter its bucket's FIFO in this replay: room for it
+      const uint32_t pl = (inf >> 19) & 0x7FFu;
       const uint32_t pr = pl == 0 ? 0u : (uint32_t)L.rank[pl - 1];
       if (pl != 0 && (pr == 0xFFFF)) continue;                // its pusher has not popped
       const uint32_t k = atomicAdd(&L.n_pend, 1u);
@@ -584,62 +652,125 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     L.sorted[pos] = L.pend_j[k];
   }
   __syncthreads();
-  for (uint32_t k = tid; k < P; k += kRpThreads) {
-    const uint32_t j = L.sorted[k];
-    const uint32_t kb = (L.info[j] >> 8) & 0xFF;
-    const bool first = k == 0 || ((L.info[L.sorted[k - 1]] >> 8) & 0xFF) != kb;
-    const bool last = k + 1 == P || ((L.info[L.sorted[k + 1]] >> 8) & 0xFF) != kb;
-    L.next[j] = last ? (unsigned short)0xFFFF : L.sorted[k + 1];
-    if (first) L.head[kb] = (unsigned short)j;
-    if (last) L.tail[kb] = (unsigned short)j;
+  if (arrays) {
+    // Bucket q's FIFO is the array L.next[L.head[q] ..): room for every live record of that bucket that has not popped (a record
+    // enters a FIFO once).  The pending records are sorted by (bucket, pusher's rank, LUT index): run q of `sorted` is the FIFO's
+    // content at the restart point — L.tail[q] / L.moved[q]: where the run starts / ends.
+    if (tid < 64) {
+      const uint32_t cq = tid < nb ? L.cnt[tid] : 0u;
+      L.head[tid] = (unsigned short)(rp_wave_scan_add(cq) - cq);
+    }
+    for (uint32_t k = tid; k < P; k += kRpThreads) {
+      const uint32_t kb = (L.info[L.sorted[k]] >> 8) & 0xFF;
+      if (k == 0 || ((L.info[L.sorted[k - 1]] >> 8) & 0xFF) != kb) L.tail[kb] = (unsigned short)k;
+      if (k + 1 == P || ((L.info[L.sorted[k + 1]] >> 8) & 0xFF) != kb) L.moved[kb] = (unsigned short)(k + 1);
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < P; k += kRpThreads) {
+      const uint32_t j = L.sorted[k];
+      const uint32_t kb = (L.info[j] >> 8) & 0xFF;
+      L.next[L.head[kb] + k - L.tail[kb]] = (unsigned short)j;
+    }
+  } else {
+    for (uint32_t k = tid; k < P; k += kRpThreads) {
+      const uint32_t j = L.sorted[k];
+      const uint32_t kb = (L.info[j] >> 8) & 0xFF;
+      const bool first = k == 0 || ((L.info[L.sorted[k - 1]] >> 8) & 0xFF) != kb;
+      const bool last = k + 1 == P || ((L.info[L.sorted[k + 1]] >> 8) & 0xFF) != kb;
+      L.next[j] = last ? (unsigned short)0xFFFF : L.sorted[k + 1];
+      if (first) L.head[kb] = (unsigned short)j;
+      if (last) L.tail[kb] = (unsigned short)j;
+    }
   }
   __syncthreads();
   tk1 = wall_clock64();
-  if (tid < 64 && !truncated && nb <= 64) {
-    // Replay of the queue discipline from the restart point by ONE wave, wave-uniformly.  Round 6: the heads and tails of the
-    // bucket FIFOs live in registers (lane b holds bucket b's: the lowest non-empty bucket is a ballot, not a walk over LDS), a
-    // pop fetches everything it needs about its record in one LDS round trip (the five reads are independent) and its children
-    // with their buckets in a second one; LDS operations of one wave execute in order, so the FIFO links written for a child
-    // are there when the child pops.  A pop cost six to eight dependent LDS round trips before (first update of a map: 5,354
-    // rankings of 93 us).
+  if (tid < 64 && !truncated && arrays) {
+    // Replay of the queue discipline from the restart point by ONE wave, A BATCH OF POPS AT A TIME.  Everything that sits in the
+    // lowest non-empty bucket pops before anything else does — children enter at the tail of their bucket, and a child's bucket
+    // is below its pusher's only when the pusher's distance fell after it was queued — so up to 64 entries of that FIFO pop
+    // together: lane k takes entry k, ranks are rank + k + 1, "was overtaken" is a prefix maximum over the old ranks, and the
+    // children of all of them are appended in (pusher, LUT) order by counting, per bucket, the children in front of each.  The
+    // batch is cut where the serial loop would behave differently: in front of a poisoned record / the rank limit (the ranking
+    // ends), behind a record with an unlisted child (it ends), behind a record with a child in a LOWER bucket (that child is
+    // next).  Until round 6 this was one pop per trip through the loop: 0.32 us per pop — 60 instructions of one wave, a dozen
+    // taken branches, two LDS waits —, and a launch waits for its largest ranking (first update of a map: 2,500 rankings of more
+    // than 256 pops); the stream's rankings pop 5.9 entries per batch on average.
+    // Lane q holds bucket q's FIFO: its place in L.next (qs), entries popped (hd) and entered (tl).
     uint32_t rank = R;
     uint32_t runmax = R;   // largest old rank among the records that have popped (the records up to the restart point kept theirs: 1 .. R)
-    uint32_t hd = lane < nb ? (uint32_t)L.head[lane] : 0xFFFFu, tl = lane < nb ? (uint32_t)L.tail[lane] : 0xFFFFu;
+    const uint32_t qs = lane < nb ? (uint32_t)L.head[lane] : 0u;
+    uint32_t hd = 0, tl = lane < nb ? (uint32_t)L.moved[lane] - (uint32_t)L.tail[lane] : 0u;
+    uint32_t* scr = L.pend_key;   // (the pending records' keys are dead) children of the batch: record | bucket << 16
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (;;) {
-      const unsigned long long nonempty = __ballot(hd != 0xFFFFu);
+      const unsigned long long nonempty = __ballot(hd < tl);
       if (!nonempty) break;                                      // BucketQueue::front / pop
-      const int lowest = __ffsll((long long)nonempty) - 1;
-      const uint32_t j = rl_u32(hd, lowest);
-      const uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.next[j]);
-      const uint32_t inf = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.info[j]);
-      const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.orank[j]) & 0x7FFFu;
-      const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.first[j + 1]);
-      const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.first[j + 2]);
-      if (lane == lowest) {
-        hd = nx;
-        if (nx == 0xFFFFu) tl = 0xFFFFu;
-      }
-      if (rank >= smax - 1 || (inf & (1u << 17))) { truncated = true; break; }
-      ++rank;
-      if (lane == 0) {
-        L.rank[j] = (unsigned short)rank;
-        // it pops now and did not before, or a record that used to pop behind it has popped in front of it: its order moved
-        if (o == 0u || o < runmax) L.orank[j] = (unsigned short)(o | 0x8000u);
-      }
-      if (o > runmax) runmax = o;
-      if (inf & (1u << 18)) { truncated = true; break; }   // a child of it is not in the list: stop behind it
-      // its children enter their buckets in LUT order
+      const int b = __ffsll((long long)nonempty) - 1;
+      const uint32_t at = rl_u32(qs + hd, b), m0 = rl_u32(tl - hd, b);
+      const uint32_t m = m0 < 64u ? m0 : 64u;
+      ++n_batches;
+      const bool in = (uint32_t)lane < m;
+      const uint32_t j = in ? (uint32_t)L.next[at + lane] : 0u;
+      uint32_t inf = 0, o = 0, f = 0, e = 0;
+      if (in) { inf = L.info[j]; o = (uint32_t)L.orank[j] & 0x7FFFu; f = L.first[j + 1]; e = L.first[j + 2]; }
       const uint32_t nk = e - f;
-      uint32_t cj = 0xFFFFu, ckb = 0;
-      if ((uint32_t)lane < nk) { cj = L.kids[f + lane]; ckb = L.kidb[f + lane]; }
-      for (uint32_t k = 0; k < nk; ++k) {
-        const uint32_t kj = rl_u32(cj, (int)k);
-        const int kb = (int)rl_u32(ckb, (int)k);
-        const uint32_t told = rl_u32(tl, kb);
-        if (told == 0xFFFFu) { if (lane == kb) hd = kj; }
-        else if (lane == 0) L.next[told] = (unsigned short)kj;
-        if (lane == kb) tl = kj;
+      const unsigned long long mA = __ballot(in && ((inf & (1u << 17)) || rank + (uint32_t)lane >= smax - 1));   // the ranking ends in front of it
+      const unsigned long long mB = __ballot(in && (inf & (1u << 18)));                                          // ... behind it
+      const uint32_t cutA = mA ? (uint32_t)__ffsll((long long)mA) - 1u : 65u, cutB = mB ? (uint32_t)__ffsll((long long)mB) : 65u;   // (65: none)
+      const uint32_t inc = rp_wave_scan_add(nk);
+      const unsigned long long mD = __ballot(in && inc > kSimMax);   // more children than the scratch holds: the batch ends in front of it
+      const uint32_t cutD = mD ? (uint32_t)__ffsll((long long)mD) - 1u : 65u;
+      uint32_t M = m < cutA ? m : cutA;
+      M = M < cutB ? M : cutB;
+      M = M < cutD ? M : cutD;
+      // the children of the batch, in (pusher, LUT) order
+      bool low = false;
+      const uint32_t off = inc - nk;
+      for (uint32_t ci = 0;; ++ci) {
+        const bool act = (uint32_t)lane < M && ci < nk;
+        if (!__ballot(act)) break;
+        if (act) {
+          const uint32_t kb = L.kidb[f + ci];
+          scr[off + ci] = (uint32_t)L.kids[f + ci] | (kb << 16);
+          low = low || kb < (uint32_t)b;
+        }
       }
+      const unsigned long long mC = __ballot(low);   // a child in a bucket below this one pops next
+      const uint32_t cutC = mC ? (uint32_t)__ffsll((long long)mC) : 65u;
+      M = M < cutC ? M : cutC;
+      // ranks; it pops now and did not before, or a record that used to pop behind it has popped in front of it: its order moved
+      const bool pops = (uint32_t)lane < M;
+      const uint32_t omax = rp_wave_scan_max(pops ? o : 0u);
+      uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)omax, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0: 0)
+      before = before > runmax ? before : runmax;
+      if (pops) {
+        L.rank[j] = (unsigned short)(rank + lane + 1);
+        if (o == 0u || o < before) L.orank[j] = (unsigned short)(o | 0x8000u);
+      }
+      {
+        const uint32_t all = rl_u32(omax, 63);
+        if (all > runmax) runmax = all;
+      }
+      rank += M;
+      if (cutB == M) { truncated = true; break; }                  // a child of the last one is not in the list: stop behind it
+      if (cutC != M && cutA == M) { truncated = true; break; }     // the next one is poisoned / beyond the rank limit
+      // the children of the M records enter their buckets: per bucket present, the lanes count who is in front of them
+      const uint32_t T = M ? rl_u32(inc, (int)M - 1) : 0u;
+      for (uint32_t x0 = 0; x0 < T; x0 += 64) {
+        const bool has = x0 + lane < T;
+        const uint32_t v = has ? scr[x0 + lane] : 0xFFFFFFFFu;
+        const uint32_t kb = v >> 16;
+        unsigned long long rem = __ballot(has);
+        while (rem) {
+          const uint32_t q = rl_u32(kb, __ffsll((long long)rem) - 1);
+          const unsigned long long same = __ballot(has && kb == q);
+          const uint32_t to = rl_u32(qs + tl, (int)q);
+          if (has && kb == q) L.next[to + __popcll(same & lt)] = (unsigned short)(v & 0xFFFFu);
+          if ((uint32_t)lane == q) tl += (uint32_t)__popcll(same);
+          rem &= ~same;
+        }
+      }
+      if (lane == b) hd += M;
     }
     R = rank;
   } else if (tid < 64 && !truncated) {
@@ -691,13 +822,9 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     R = rank;
   }
   tk2 = wall_clock64();
+  uint32_t popped = 0;
   if (tid == 0) {
-    if (a.c.stats) {
-      const uint32_t popped = R - (L.flag_rank <= p ? L.flag_rank : p);   // pops this ranking replayed (behind the restart point)
-      atomicAdd(&c.st_sim_members, (unsigned long long)n);
-      atomicAdd(&c.st_sim_pops, (unsigned long long)popped);
-      atomicAdd(&c.st_sim_hist[popped < 16u ? 0 : popped < 64u ? 1 : popped < 256u ? 2 : 3], 1ull);
-    }
+    popped = R - (L.flag_rank <= p ? L.flag_rank : p);   // pops this ranking replayed (behind the restart point)
     L.n_ranked = R;
     L.truncated = truncated ? 1u : 0u;
   }
@@ -714,10 +841,11 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     const uint32_t o_rk = L.orank[j] & 0x7FFFu, n_rk = rk == 0xFFFF ? 0u : rk;
     bool moved = o_rk != n_rk;                                                  // mark_moved = 1: every pop time that moved
     if (a.c.mark_moved >= 2) moved = rk == 0xFFFF ? (o_rk != 0u) : ((L.orank[j] & 0x8000u) != 0u);   // 2: order changes only (rp_phase_sim)
-    if (a.c.mark_moved && moved && rp::rp_moved_needs_mark(a, r)) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;
+    if (a.c.mark_moved && moved && (L.info[j] & (1u << 30))) L.moved[atomicAdd(&L.n_moved, 1u)] = (unsigned short)j;   // (bit 30: rp::rp_moved_needs_mark)
     if (o_rk != n_rk) a.rec_T[r] = Tn;
   }
   __syncthreads();
+  const unsigned long long tk3 = wall_clock64();
   // one (moved record, target) pair per thread: 27 dependent atomics in a row on one lane would be most of a small ranking's time.
   // The marks are collected in LDS (the pending-queue tables are dead by now) and filed with ONE atomic on Ctl::n_dirty per
   // ranking: every wave with a mark used to increment that word — eight increments per ranking, a hundred rankings per launch,
@@ -725,15 +853,30 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   if (tid == 0) L.n_pend = 0;
   __syncthreads();
   const uint32_t wl = 1u - c.read;
-  for (uint32_t i = tid; i < L.n_moved * 27u; i += kRpThreads) {
-    const uint32_t t = a.rec_tgts[(size_t)L.memr[L.moved[i / 27u]] * 27 + i % 27u];
-    if (t >= rp::kSkip) continue;
-    if (atomicExch(&a.tgt_dirty[t], 1u) != 0u) continue;
-    const uint32_t k = atomicAdd(&L.n_pend, 1u);
-    if (k < kSimMax) L.pend_key[k] = t;
-    else a.dl[wl][atomicAdd(&c.n_dirty[wl], 1u)] = t;
+  {
+    // kMarkB (moved record, target) pairs per thread at a time: their targets in one trip, their marks in a second
+    constexpr int kMarkB = 8;
+    const uint32_t pairs = L.n_moved * 27u;
+    for (uint32_t i0 = 0; i0 < pairs; i0 += kMarkB * kRpThreads) {
+      uint32_t t8[kMarkB], was[kMarkB];
+#pragma unroll
+      for (int k = 0; k < kMarkB; ++k) {
+        const uint32_t i = i0 + k * kRpThreads + tid;
+        t8[k] = i < pairs ? a.rec_tgts[(size_t)L.memr[L.moved[i / 27u]] * 27 + i % 27u] : rp::kSkip;
+      }
+#pragma unroll
+      for (int k = 0; k < kMarkB; ++k) was[k] = t8[k] < rp::kSkip ? atomicExch(&a.tgt_dirty[t8[k]], 1u) : 1u;
+#pragma unroll
+      for (int k = 0; k < kMarkB; ++k) {
+        if (was[k] != 0u) continue;
+        const uint32_t q = atomicAdd(&L.n_pend, 1u);
+        if (q < kSimMax) L.pend_key[q] = t8[k];
+        else a.dl[wl][atomicAdd(&c.n_dirty[wl], 1u)] = t8[k];
+      }
+    }
   }
   __syncthreads();
+  const unsigned long long tk4 = wall_clock64();
   {
     const uint32_t nd = L.n_pend < kSimMax ? L.n_pend : kSimMax;
     if (tid == 0 && nd) L.flag_rank = atomicAdd(&c.n_dirty[wl], nd);
@@ -748,10 +891,22 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       atomicMin(&c.smax_cut, ((unsigned long long)base << rp::kRankBits) | (L.n_ranked + 1));
       atomicAdd(&c.st_trunc_rank, 1ull);
     }
-    if (a.c.stats) {
-      atomicAdd(&c.st_sim_ticks[0], tk1 - tk0);
-      atomicAdd(&c.st_sim_ticks[1], tk2 - tk1);
-      atomicAdd(&c.st_sim_ticks[2], wall_clock64() - tk2);
+    if (a.wg_stats && blockIdx.x < 4096u) {   // (kept per workgroup: atomics on Ctl's lines slowed down what they measured)
+      const unsigned long long tk5 = wall_clock64();
+      unsigned long long* w = a.wg_stats + (size_t)blockIdx.x * rp::kWgStats;
+      w[0] += n;
+      w[1] += popped;
+      w[2 + (popped < 16u ? 0 : popped < 64u ? 1 : popped < 256u ? 2 : 3)] += 1;
+      w[6] += ta - tk0;
+      w[7] += tb - ta;
+      w[8] += te - tb;
+      w[9] += tk1 - te;
+      w[10] += tk2 - tk1;
+      w[11] += tk3 - tk2;
+      w[12] += tk4 - tk3;
+      w[13] += tk5 - tk4;
+      w[14] += n_batches;
+      w[15] += 1;
     }
   }
   __syncthreads();
