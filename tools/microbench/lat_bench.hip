@@ -73,6 +73,18 @@ __global__ void k_busy(float* x, int iters) {   // background load: other workgr
   x[blockIdx.x * blockDim.x + threadIdx.x] = v;
 }
 
+// hot counters: every wave of a 1,024 x 256 grid takes `per` tickets (lane 0, returning atomicAdd, the ticket is used for a store) from
+// one of `shards` counters `stride` words apart
+__global__ void k_tickets(uint32_t* counters, uint32_t* sink, int shards, int stride, int per) {
+  if ((threadIdx.x & 63) != 0) return;
+  const uint32_t wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t* c = counters + (size_t)(wv % shards) * stride;
+  for (int k = 0; k < per; ++k) {
+    const uint32_t t = atomicAdd(c, 1u);
+    sink[(wv * 64 + (t & 63)) & 0xFFFFF] = t;
+  }
+}
+
 static std::vector<uint32_t> cycle(size_t n, uint32_t seed) {
   std::vector<uint32_t> perm(n), next(n);
   std::iota(perm.begin(), perm.end(), 0u);
@@ -123,6 +135,22 @@ int main() {
     uint32_t* buf; CK(hipMalloc(&buf, size_t(2000) * 4096 * 4));
     k_store_barrier<<<1, 256>>>(buf, 2000, out); report("store + __syncthreads, 256 threads", 2000);
     CK(hipFree(buf));
+  }
+  {
+    uint32_t *cn, *sink; CK(hipMalloc(&cn, 1 << 20)); CK(hipMalloc(&sink, (1 << 20) * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int per : {1, 4}) for (int stride : {1, 32, 1024}) for (int shards : {1, 4, 16, 64}) {
+      if (shards == 1 && stride != 1) continue;
+      CK(hipMemset(cn, 0, 1 << 20));
+      k_tickets<<<1024, 256>>>(cn, sink, shards, stride, per);   // warm
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      for (int rep = 0; rep < 20; ++rep) k_tickets<<<1024, 256>>>(cn, sink, shards, stride, per);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("tickets: 4096 waves x %d, %2d counters %4d words apart: %7.2f us per launch (%.0f tickets per us)\n", per, shards, stride, ms * 1000 / 20,
+             4096.0 * per / (ms * 1000 / 20));
+    }
   }
   // with the rest of the chip busy
   {

@@ -118,19 +118,26 @@ struct Ctl {
   uint32_t push_b[kScanC], push_n;                // buckets of the current PH_PUSH pass
   uint32_t push_next;                        // first bucket not yet handled by a PH_PUSH pass
   uint32_t chunk_top;
-  // ---- B
-  uint32_t error;                            // 1 record capacity, 2 target capacity, 4 queue arena, 8 no progress, 16 event overflow at base record 0
-  uint32_t n_tgt, n_dirty[2];
-  uint32_t n_chg, n_born, n_sd, n_cp;
-  uint32_t k_limit;                          // base records from here on cannot take part (event list overflow)
-  unsigned long long first_change, smax_cut;
   // (device wrapper) n_threads | phase << 32 | launch number mod 64 << 40 of the step the NEXT launch runs, stored and read
   // as one word: a workgroup the dispatcher starts after its own launch's control step already ran must not take the next
-  // step's phase for its own
+  // step's phase for its own.  (With part A: every workgroup of a launch reads it, nothing writes here while a phase runs.)
   unsigned long long hdr;
-  uint32_t arrive;                           // (device wrapper) workgroups that finished the phase
+  // ---- B.  A 128-byte line takes ~87 returning atomics per microsecond NO MATTER HOW MANY WORDS OF IT they address, and lines
+  // take them side by side (tools/microbench/lat_bench.hip: 16 counters one word apart 85 tickets per us, 128 bytes apart 850).
+  // Until round 6 every counter below sat in the same two lines — the fold's changed / born records, the apply's lists and the
+  // workgroups' arrivals queued up behind each other.  One line per counter that a phase hammers.
+  alignas(128) uint32_t error;               // 1 record capacity, 2 target capacity, 4 queue arena, 8 no progress, 16 event overflow at base record 0
+  uint32_t k_limit;                          // base records from here on cannot take part (event list overflow)
+  unsigned long long first_change, smax_cut;
+  alignas(128) uint32_t n_tgt;
+  alignas(128) uint32_t n_dirty[2];
+  alignas(128) uint32_t n_chg;
+  alignas(128) uint32_t n_born;
+  alignas(128) uint32_t n_sd;
+  alignas(128) uint32_t n_cp;
+  alignas(128) uint32_t arrive;              // (device wrapper) workgroups that finished the phase
   // statistics
-  unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
+  alignas(128) unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
   unsigned long long st_sim_members, st_sim_pops, st_sim_hist[4], st_sim_ticks[5];   // (device ranking) members loaded, pops replayed, rankings by pops replayed: < 16, < 64, < 256, more
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16], t_prev;
   // ---- per queue (bucket 0 .. num_buckets - 1, raise_ = num_buckets); the device wrapper moves the first num_buckets + 1 of each

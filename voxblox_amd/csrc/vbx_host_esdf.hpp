@@ -448,8 +448,8 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   const bool fresh = !ctx->rp_ctl.p;
   HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl)));
   if (getenv("VBX_RP_STATS")) {   // what the rankings cost, per workgroup (rp::Args::wg_stats), zero at the start of an update
-    HIP_TRY(ctx->rp_wg_stats.ensure((size_t)4096 * rp::kWgStats * 8));
-    HIP_TRY(hipMemsetAsync(ctx->rp_wg_stats.p, 0, (size_t)4096 * rp::kWgStats * 8, s));
+    HIP_TRY(ctx->rp_wg_stats.ensure((size_t)4096 * (rp::kWgStats + 32) * 8));
+    HIP_TRY(hipMemsetAsync(ctx->rp_wg_stats.p, 0, (size_t)4096 * (rp::kWgStats + 32) * 8, s));
   }
   HIP_TRY(ctx->rp_nbslot.ensure((size_t)std::max<uint32_t>(used, 1) * 27 * 4));
   HIP_TRY(ctx->rp_hazard.ensure((size_t)std::max<uint32_t>(used, 1) * m.nvox));
@@ -629,9 +629,12 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
             hc.st_poison, hc.error);
     for (int k = 1; k < 13; ++k) fprintf(stderr, " %s %llu(%llu, %.2f ms)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k], hc.st_phase_ticks[k] * 1e-5);
     if (a.wg_stats) {
-      std::vector<unsigned long long> ws((size_t)4096 * rp::kWgStats), tot(rp::kWgStats, 0);
+      std::vector<unsigned long long> ws((size_t)4096 * (rp::kWgStats + 32)), tot(rp::kWgStats, 0), ft(8, 0);
       HIP_TRY(hipMemcpy(ws.data(), a.wg_stats, ws.size() * 8, hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < ws.size(); ++i) tot[i % rp::kWgStats] += ws[i];
+      for (size_t i = 0; i < (size_t)4096 * rp::kWgStats; ++i) tot[i % rp::kWgStats] += ws[i];
+      for (size_t i = 0; i < (size_t)4096 * 32; ++i) ft[i % 8] += ws[(size_t)4096 * rp::kWgStats + i];
+      fprintf(stderr, "\n[rp] folds: %llu, events %llu, lists of 64 or more %llu, of 192 or more %llu; wave-ms summed over folds: loads %.2f, order %.2f, replay %.2f, outputs %.2f",
+              ft[0], ft[1], ft[6], ft[7], ft[2] * 1e-5, ft[3] * 1e-5, ft[4] * 1e-5, ft[5] * 1e-5);
       fprintf(stderr, "\n[rp] rankings: %llu, members loaded %llu, pops replayed %llu, by pops replayed <16: %llu <64: %llu <256: %llu more: %llu", tot[15], tot[0], tot[1],
               tot[2], tot[3], tot[4], tot[5]);
       fprintf(stderr, "; workgroup-ms summed over rankings: header %.2f, records %.2f, tables %.2f, queue at the restart point %.2f, queue replay %.2f, pop times written %.2f, "

@@ -151,6 +151,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
   using namespace rp;
   constexpr int Q = (int)kEvQ;     // events per lane: event e of the target lives in lane e % 64, slot e / 64
   Ctl& c = *a.ctl;
+  const unsigned long long fk0 = wall_clock64();
   const uint32_t gid = a.tgt_gid[t];
   if (gid == kNone) return;
   const int b = (int)c.bucket;
@@ -180,6 +181,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
       valid[q] = rp_meta_live(emeta[q]) && !epoison[q] && eT[q] < limit;
     }
   }
+  const unsigned long long fk1 = wall_clock64();
   // rank of every valid event = valid events with a smaller pop time (pop times of valid events are distinct)
   uint32_t rank[Q];
 #pragma unroll
@@ -207,6 +209,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     }
   }
   rp_wave_sync();
+  const unsigned long long fk2 = wall_clock64();
   float d = d0;
   uint32_t s = s0;
   const bool usable = (s0 & kObserved) && !(s0 & kFixed);
@@ -306,6 +309,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     return;
   }
   rp_wave_sync();   // (lane 0's moved flags)
+  const unsigned long long fk3 = wall_clock64();
   bool pop_moved[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) pop_moved[q] = (q < slots && valid[q] && (code[q] & 31u) == kOwn) ? ws[4u * rank[q] + 3u] != 0u : false;
@@ -366,6 +370,12 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
       a.born[(size_t)k * 6 + 5] = lp_s;
       }
     }
+  }
+  if (a.wg_stats && lane == 0 && blockIdx.x < 4096u) {   // (VBX_RP_STATS) what the folds of this wave cost
+    unsigned long long* w = a.wg_stats + (size_t)4096 * rp::kWgStats + ((size_t)blockIdx.x * (kRpThreads / 64) + (threadIdx.x >> 6)) * 8;
+    w[0] += 1; w[1] += n_all;
+    w[2] += fk1 - fk0; w[3] += fk2 - fk1; w[4] += fk3 - fk2; w[5] += wall_clock64() - fk3;
+    w[6] += n_all >= 64u ? 1 : 0; w[7] += n_all >= 192u ? 1 : 0;
   }
 }
 
@@ -1122,9 +1132,18 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   {
     uint32_t* src = reinterpret_cast<uint32_t*>(a.ctl);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_ctl);
-    for (uint32_t i = threadIdx.x; i < n_copy; i += kRpThreads) {
-      const uint32_t w = i < n_scalar ? i : n_scalar + ((i - n_scalar) / nq) * (rp::kMaxBuckets + 1) + (i - n_scalar) % nq;
-      dst[w] = atomicAdd(&src[w], 0u);
+    // (four words per thread in flight: the block is a dozen lines, a word at a time would be as many trips in a row)
+    for (uint32_t i0 = 0; i0 < n_copy; i0 += 4 * kRpThreads) {
+      uint32_t v[4], wv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + k * kRpThreads + threadIdx.x;
+        wv[k] = i < n_scalar ? i : n_scalar + ((i - n_scalar) / nq) * (rp::kMaxBuckets + 1) + (i - n_scalar) % nq;
+        v[k] = i < n_copy ? atomicAdd(&src[wv[k]], 0u) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i0 + k * kRpThreads + threadIdx.x < n_copy) dst[wv[k]] = v[k];
     }
   }
   __syncthreads();
