@@ -94,7 +94,7 @@ struct Cfg {
   uint32_t slot_by_base; // 1: the list of base record i's excursion is slot i + 1 (sub_slots_cap >= kmax); 0: slots are handed out as excursions appear
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
-  uint32_t stats;        // (device) 1: the rankings keep their statistics (Ctl::st_sim_*: six atomics per ranking on a few words — measurement runs only)
+  uint32_t stats;        // (device) 1: VBX_RP_STATS — the rankings and folds keep what they cost per workgroup (Args::wg_stats)
   uint32_t mark_moved;   // a ranking marks the targets of 2: the records whose order it changed, 1: every record whose pop time it moved (rp_mark_rec_targets); 0: nothing (round 4)
 };
 
@@ -122,6 +122,8 @@ struct Ctl {
   // as one word: a workgroup the dispatcher starts after its own launch's control step already ran must not take the next
   // step's phase for its own.  (With part A: every workgroup of a launch reads it, nothing writes here while a phase runs.)
   unsigned long long hdr;
+  unsigned long long st_iters;               // iterations so far (PH_APPLY stamps the records it makes with it: Args::rec_born_it)
+  unsigned long long t_prev;                 // (device wrapper) clock at the last control step
   // ---- B.  A 128-byte line takes ~87 returning atomics per microsecond NO MATTER HOW MANY WORDS OF IT they address, and lines
   // take them side by side (tools/microbench/lat_bench.hip: 16 counters one word apart 85 tickets per us, 128 bytes apart 850).
   // Until round 6 every counter below sat in the same two lines — the fold's changed / born records, the apply's lists and the
@@ -136,15 +138,17 @@ struct Ctl {
   alignas(128) uint32_t n_sd;
   alignas(128) uint32_t n_cp;
   alignas(128) uint32_t arrive;              // (device wrapper) workgroups that finished the phase
-  // statistics
-  alignas(128) unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_iters, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
-  unsigned long long st_sim_members, st_sim_pops, st_sim_hist[4], st_sim_ticks[5];   // (device ranking) members loaded, pops replayed, rankings by pops replayed: < 16, < 64, < 256, more
-  unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16], t_prev;
   // ---- per queue (bucket 0 .. num_buckets - 1, raise_ = num_buckets); the device wrapper moves the first num_buckets + 1 of each
   uint32_t head[kMaxBuckets + 1], tail[kMaxBuckets + 1];  // A: FIFO indices (entries ever popped / pushed)
   uint32_t reserved[kMaxBuckets + 1];        // A: chunks of the queue's FIFO that are backed by the arena
   uint32_t k_cur[kMaxBuckets + 1];           // A: base records the bucket's next super-step may take (slow start after a cut)
   uint32_t push_cnt[kMaxBuckets + 1];        // B: pushes per queue seen by COMMIT_FOLD (upper bound of what gets queued)
+  // ---- statistics, LAST: the device's control step does not load them — it starts from zeros in its LDS copy and ADDS what it
+  // counted to these words when it stores the block back (a third of the block's words, and a launch pays for every word the
+  // control step moves).  What decides anything is not here: st_iters and t_prev are in part A.
+  alignas(128) unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
+  unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16];
+  unsigned long long st_bin_steps[4][8], st_bin_ticks[4][8];   // (device) launches of FOLD / APPLY / SIM / PLACE by items: < 64, < 256, < 1 Ki, < 4 Ki, < 16 Ki, < 64 Ki, < 256 Ki, more
 };
 
 struct Args {

@@ -628,6 +628,13 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
             hc.st_pops, hc.st_relax, hc.st_supersteps, hc.st_iters, hc.st_folds, hc.st_exc, hc.st_cut_iters, hc.st_cut_smax, hc.st_steps,
             hc.st_poison, hc.error);
     for (int k = 1; k < 13; ++k) fprintf(stderr, " %s %llu(%llu, %.2f ms)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k], hc.st_phase_ticks[k] * 1e-5);
+    {
+      static const char* rows[] = {"fold", "apply", "sim", "place"};
+      for (int r = 0; r < 4; ++r) {
+        fprintf(stderr, "\n[rp] %s launches by items (<64 <256 <1Ki <4Ki <16Ki <64Ki <256Ki more): ", rows[r]);
+        for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu x %.1f us", hc.st_bin_steps[r][b], hc.st_bin_steps[r][b] ? hc.st_bin_ticks[r][b] * 0.01 / hc.st_bin_steps[r][b] : 0.0);
+      }
+    }
     if (a.wg_stats) {
       std::vector<unsigned long long> ws((size_t)4096 * (rp::kWgStats + 32)), tot(rp::kWgStats, 0), ft(8, 0);
       HIP_TRY(hipMemcpy(ws.data(), a.wg_stats, ws.size() * 8, hipMemcpyDeviceToHost));

@@ -1127,30 +1127,49 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   if (!s_last) return;
   __syncthreads();   // (everybody is done with the phase's part of the shared region)
   rp::Ctl& s_ctl = s_u.ctl;
-  // (the scalar part and the first num_buckets + 1 entries of the five per-queue arrays)
-  const uint32_t n_scalar = offsetof(rp::Ctl, head) / 4, nq = (uint32_t)a.c.num_buckets + 1u, n_copy = n_scalar + 5u * nq;
+  // What the control step needs of the block, a word per thread and ONE trip: part A, the words in use of part B's lines, the
+  // first num_buckets + 1 entries of the five per-queue arrays.  (Until round 6 all of it, statistics and — once the counters
+  // had a line each — padding included: 725 words read with atomics and stored back; a launch pays ~1 us per 128 of them.)
+  // The statistics are not loaded: zeros in the LDS copy, and what the step counted is ADDED to the block afterwards.
+  constexpr uint32_t kA = offsetof(rp::Ctl, error) / 4, kB = 6 + 2 * 7;
+  const uint32_t nq = (uint32_t)a.c.num_buckets + 1u, n_copy = kA + kB + 5u * nq;
+  const auto ctl_word = [&](uint32_t i) -> uint32_t {
+    if (i < kA) return i;
+    i -= kA;
+    if (i < 6) return (uint32_t)(offsetof(rp::Ctl, error) / 4) + i;   // error, k_limit, first_change, smax_cut
+    if (i < kB) {
+      constexpr uint32_t line[7] = {offsetof(rp::Ctl, n_tgt) / 4, offsetof(rp::Ctl, n_dirty) / 4, offsetof(rp::Ctl, n_chg) / 4, offsetof(rp::Ctl, n_born) / 4,
+                                    offsetof(rp::Ctl, n_sd) / 4,  offsetof(rp::Ctl, n_cp) / 4,    offsetof(rp::Ctl, arrive) / 4};
+      return line[(i - 6) >> 1] + ((i - 6) & 1u);
+    }
+    i -= kB;
+    return (uint32_t)(offsetof(rp::Ctl, head) / 4) + (i / nq) * (rp::kMaxBuckets + 1) + i % nq;
+  };
+  constexpr uint32_t kStat0 = offsetof(rp::Ctl, st_raise_pops) / 8, kStat1 = sizeof(rp::Ctl) / 8;
   {
     uint32_t* src = reinterpret_cast<uint32_t*>(a.ctl);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_ctl);
-    // (four words per thread in flight: the block is a dozen lines, a word at a time would be as many trips in a row)
-    for (uint32_t i0 = 0; i0 < n_copy; i0 += 4 * kRpThreads) {
-      uint32_t v[4], wv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t i = i0 + k * kRpThreads + threadIdx.x;
-        wv[k] = i < n_scalar ? i : n_scalar + ((i - n_scalar) / nq) * (rp::kMaxBuckets + 1) + (i - n_scalar) % nq;
-        v[k] = i < n_copy ? atomicAdd(&src[wv[k]], 0u) : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (i0 + k * kRpThreads + threadIdx.x < n_copy) dst[wv[k]] = v[k];
+    for (uint32_t i = threadIdx.x; i < n_copy; i += kRpThreads) {   // (one pass: n_copy <= 256 with the reference's 20 buckets)
+      const uint32_t w = ctl_word(i);
+      dst[w] = atomicAdd(&src[w], 0u);
     }
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(&s_ctl);
+    for (uint32_t i = kStat0 + threadIdx.x; i < kStat1; i += kRpThreads) st[i] = 0ull;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     s_ctl.arrive = 0;
     const unsigned long long now = wall_clock64();   // 100 MHz
-    if (s_ctl.t_prev) s_ctl.st_phase_ticks[phase & 15] += now - s_ctl.t_prev;
+    if (s_ctl.t_prev) {
+      s_ctl.st_phase_ticks[phase & 15] += now - s_ctl.t_prev;
+      const int row = phase == rp::PH_FOLD ? 0 : phase == rp::PH_APPLY ? 1 : phase == rp::PH_SIM ? 2 : phase == rp::PH_PLACE_BASE ? 3 : -1;
+      if (row >= 0) {
+        int bin = 0;
+        for (uint32_t lim = 64; bin < 7 && n >= lim; lim <<= 2) ++bin;
+        s_ctl.st_bin_steps[row][bin] += 1;
+        s_ctl.st_bin_ticks[row][bin] += now - s_ctl.t_prev;
+      }
+    }
     s_ctl.t_prev = now;
     if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
       sc.ticket[0] = 0;
@@ -1167,9 +1186,13 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_ctl);
     const uint32_t w_hdr = offsetof(rp::Ctl, hdr) / 4;
     for (uint32_t i = threadIdx.x; i < n_copy; i += kRpThreads) {
-      const uint32_t w = i < n_scalar ? i : n_scalar + ((i - n_scalar) / nq) * (rp::kMaxBuckets + 1) + (i - n_scalar) % nq;
+      const uint32_t w = ctl_word(i);
       if (w != w_hdr && w != w_hdr + 1) dst[w] = src[w];
     }
+    unsigned long long* gst = reinterpret_cast<unsigned long long*>(a.ctl);
+    const unsigned long long* st = reinterpret_cast<const unsigned long long*>(&s_ctl);
+    for (uint32_t i = kStat0 + threadIdx.x; i < kStat1; i += kRpThreads)
+      if (st[i]) atomicAdd(&gst[i], st[i]);
   }
   // the header in one piece (a workgroup that is late only ever reads this word)
   if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned long long*>(&a.ctl->hdr) = s_ctl.hdr;
