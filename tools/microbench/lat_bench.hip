@@ -85,6 +85,36 @@ __global__ void k_tickets(uint32_t* counters, uint32_t* sink, int shards, int st
   }
 }
 
+// the replay's step kernel reduced to its skeleton: every workgroup reads a header word; the first `active` ones do `trips` dependent
+// loads, arrive at a counter, and the last one copies `words` words through LDS with atomic reads, lets thread 0 do some scalar work on
+// them and stores them back
+__global__ void __launch_bounds__(256) k_step(uint32_t* ctl, const uint32_t* next, uint32_t active, int trips, int words, uint32_t seq) {
+  __shared__ uint32_t lds[1024];
+  __shared__ uint32_t last;
+  const uint32_t hdr = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  if (hdr != seq) return;
+  if (blockIdx.x >= active) return;
+  uint32_t i = (blockIdx.x * 256 + threadIdx.x) & 0xFFFFF;
+  for (int t = 0; t < trips; ++t) i = next[i];
+  if (i == 0xdeadbeef) ctl[2000] = i;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&ctl[64], 1u) == active - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  for (int w = threadIdx.x; w < words; w += 256) lds[w] = atomicAdd(&ctl[128 + w], 0u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int k = 0; k < 200; ++k) acc += lds[(k * 7) & 127];
+    lds[1] = acc;
+    lds[0] = seq + 1;
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < words; w += 256) ctl[128 + w] = lds[w];
+  if (threadIdx.x == 0) { ctl[64] = 0; *reinterpret_cast<volatile uint32_t*>(&ctl[0]) = seq + 1; }
+}
+
 static std::vector<uint32_t> cycle(size_t n, uint32_t seed) {
   std::vector<uint32_t> perm(n), next(n);
   std::iota(perm.begin(), perm.end(), 0u);
@@ -150,6 +180,27 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       printf("tickets: 4096 waves x %d, %2d counters %4d words apart: %7.2f us per launch (%.0f tickets per us)\n", per, shards, stride, ms * 1000 / 20,
              4096.0 * per / (ms * 1000 / 20));
+    }
+  }
+  {
+    uint32_t* ctl; CK(hipMalloc(&ctl, 1 << 16));
+    auto nx = cycle(size_t(1) << 20, 7);
+    uint32_t* d; CK(hipMalloc(&d, nx.size() * 4)); CK(hipMemcpy(d, nx.data(), nx.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int grid : {1024, 512, 256, 64}) for (int active : {1, 64, 1024}) for (int trips : {0, 4}) for (int words : {0, 190, 725}) {
+      if (active > grid) continue;
+      if (words == 725 && !(active == 1 && trips == 0)) continue;
+      CK(hipMemset(ctl, 0, 1 << 16));
+      const int N = 2000;
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemset(ctl, 0, 1 << 16));
+        CK(hipEventRecord(e0));
+        for (int k = 0; k < N; ++k) k_step<<<grid, 256>>>(ctl, d, active, trips, words, k);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      }
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      uint32_t h; CK(hipMemcpy(&h, ctl, 4, hipMemcpyDeviceToHost));
+      printf("step kernel: grid %4d, %4d workgroups with work of %d trips, control moves %3d words: %6.2f us per launch%s\n", grid, active, trips, words, ms * 1000 / N, h == N ? "" : "  (header wrong!)");
     }
   }
   // with the rest of the chip busy

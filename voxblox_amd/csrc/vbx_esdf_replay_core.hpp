@@ -45,6 +45,7 @@ namespace rp {
 constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kWgStats = 16;
+constexpr uint32_t kArriveSubs = 32;
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
 #ifndef RP_EVQ
@@ -101,6 +102,7 @@ struct Cfg {
 // control block (device memory, one instance).  Part A is written by rp_control only (every workgroup reads it at
 // the start of a launch); part B is updated with atomics while a phase runs, and rp_control reads it through RP_LD
 // (an atomic read-modify-write: the per-XCD L2s are not coherent, a plain load may see an old line).
+struct alignas(128) CtlLine { uint32_t v; uint32_t pad[31]; };
 struct Ctl {
   // ---- A
   uint32_t phase, done;
@@ -143,6 +145,9 @@ struct Ctl {
   uint32_t reserved[kMaxBuckets + 1];        // A: chunks of the queue's FIFO that are backed by the arena
   uint32_t k_cur[kMaxBuckets + 1];           // A: base records the bucket's next super-step may take (slow start after a cut)
   uint32_t push_cnt[kMaxBuckets + 1];        // B: pushes per queue seen by COMMIT_FOLD (upper bound of what gets queued)
+  // (device wrapper) arrivals in two levels: workgroup w arrives at counter w % kArriveSubs, the last one there at `arrive` — 1,024
+  // arrivals on one line are 12 us (lat_bench's step kernel: 16.9 us per launch against 5.8 with 64 workgroups arriving)
+  CtlLine arrive_sub[kArriveSubs];
   // ---- statistics, LAST: the device's control step does not load them — it starts from zeros in its LDS copy and ADDS what it
   // counted to these words when it stores the block back (a third of the block's words, and a launch pays for every word the
   // control step moves).  What decides anything is not here: st_iters and t_prev are in part A.

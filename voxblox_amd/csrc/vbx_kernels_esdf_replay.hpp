@@ -1122,7 +1122,23 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(&c.arrive, 1u) == active - 1) ? 1u : 0u;
+  if (threadIdx.x == 0) {
+    // the last workgroup to arrive runs the control step.  More than 64 of them arrive in two levels (Ctl::arrive_sub): a line
+    // takes ~87 arrivals per microsecond
+    uint32_t last;
+    if (active <= 64u) {
+      last = atomicAdd(&c.arrive, 1u) == active - 1 ? 1u : 0u;
+    } else {
+      const uint32_t sub = blockIdx.x & (rp::kArriveSubs - 1);
+      const uint32_t expect = (active - sub + rp::kArriveSubs - 1) / rp::kArriveSubs;   // workgroups sub, sub + 32, ... below `active`
+      last = 0;
+      if (atomicAdd(&c.arrive_sub[sub].v, 1u) == expect - 1) {
+        atomicExch(&c.arrive_sub[sub].v, 0u);
+        last = atomicAdd(&c.arrive, 1u) == rp::kArriveSubs - 1 ? 1u : 0u;
+      }
+    }
+    s_last = last;
+  }
   __syncthreads();
   if (!s_last) return;
   __syncthreads();   // (everybody is done with the phase's part of the shared region)
