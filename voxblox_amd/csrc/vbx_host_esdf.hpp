@@ -631,7 +631,7 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
     {
       static const char* rows[] = {"fold", "apply", "sim", "place"};
       for (int r = 0; r < 4; ++r) {
-        fprintf(stderr, "\n[rp] %s launches by items (<64 <256 <1Ki <4Ki <16Ki <64Ki <256Ki more): ", rows[r]);
+        fprintf(stderr, "\n[rp] %s launches by items (<4 <16 <64 <256 <1Ki <4Ki <16Ki more): ", rows[r]);
         for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu x %.1f us", hc.st_bin_steps[r][b], hc.st_bin_steps[r][b] ? hc.st_bin_ticks[r][b] * 0.01 / hc.st_bin_steps[r][b] : 0.0);
       }
     }

@@ -1181,7 +1181,7 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
       const int row = phase == rp::PH_FOLD ? 0 : phase == rp::PH_APPLY ? 1 : phase == rp::PH_SIM ? 2 : phase == rp::PH_PLACE_BASE ? 3 : -1;
       if (row >= 0) {
         int bin = 0;
-        for (uint32_t lim = 64; bin < 7 && n >= lim; lim <<= 2) ++bin;
+        for (uint32_t lim = 4; bin < 7 && n >= lim; lim <<= 2) ++bin;
         s_ctl.st_bin_steps[row][bin] += 1;
         s_ctl.st_bin_ticks[row][bin] += now - s_ctl.t_prev;
       }
