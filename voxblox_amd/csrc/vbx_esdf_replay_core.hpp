@@ -44,7 +44,7 @@ namespace rp {
 
 constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kWgStats = 16;
+constexpr uint32_t kWgStats = 32;
 constexpr uint32_t kArriveSubs = 32;
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;

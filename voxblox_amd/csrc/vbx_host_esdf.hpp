@@ -642,6 +642,13 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
       for (size_t i = 0; i < (size_t)4096 * 32; ++i) ft[i % 8] += ws[(size_t)4096 * rp::kWgStats + i];
       fprintf(stderr, "\n[rp] folds: %llu, events %llu, lists of 64 or more %llu, of 192 or more %llu; wave-ms summed over folds: loads %.2f, order %.2f, replay %.2f, outputs %.2f",
               ft[0], ft[1], ft[6], ft[7], ft[2] * 1e-5, ft[3] * 1e-5, ft[4] * 1e-5, ft[5] * 1e-5);
+      {
+        const unsigned long long slow = tot[19] + tot[20] + tot[21];
+        fprintf(stderr, "\n[rp] rankings by duration (<8 <12 <16 <24 <32 us, more): %llu %llu %llu %llu %llu %llu; the %llu of 16 us or more: loads %.2f us, tables and queue %.2f, "
+                "replay %.2f, write-back %.2f each, %.0f members, %.1f batches, %.0f pops", tot[16], tot[17], tot[18], tot[19], tot[20], tot[21], slow,
+                slow ? tot[22] * 0.01 / slow : 0.0, slow ? tot[23] * 0.01 / slow : 0.0, slow ? tot[24] * 0.01 / slow : 0.0, slow ? tot[25] * 0.01 / slow : 0.0,
+                slow ? (double)tot[26] / slow : 0.0, slow ? (double)tot[27] / slow : 0.0, slow ? (double)tot[28] / slow : 0.0);
+      }
       fprintf(stderr, "\n[rp] rankings: %llu, members loaded %llu, pops replayed %llu, by pops replayed <16: %llu <64: %llu <256: %llu more: %llu", tot[15], tot[0], tot[1],
               tot[2], tot[3], tot[4], tot[5]);
       fprintf(stderr, "; workgroup-ms summed over rankings: header %.2f, records %.2f, tables %.2f, queue at the restart point %.2f, queue replay %.2f, pop times written %.2f, "

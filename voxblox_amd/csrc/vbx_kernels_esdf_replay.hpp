@@ -462,11 +462,11 @@ __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lan
 // so a ranking costs what changed, not what exists.
 constexpr uint32_t kSimMax = 1024;   // records of one excursion the ranking handles (Cfg::smax <= this)
 struct SimLds {
-  // the live children of every record as CSR: kids[first[pl] .. first[pl + 1]) in LUT order, pl = position of the pusher in
+  // the live children of every record as CSR: kidw[first[pl] .. first[pl + 1]) in LUT order, pl = position of the pusher in
   // the member list + 1 (0: the base record)
   uint32_t cnt[kSimMax + 2];
-  unsigned short first[kSimMax + 2], kids[kSimMax];
-  unsigned short kidb[kSimMax];               // bucket of kids[x] (read with it: one LDS round trip less per pop)
+  unsigned short first[kSimMax + 2];
+  uint32_t kidw[kSimMax];                     // kids[]: position of the child in the member list | its bucket << 16
   uint32_t wave_tot[kRpThreads / 64];
   uint32_t info[kSimMax];                     // lut | bucket << 8 | live << 16 | poisoned << 17 | has an unlisted child << 18 | pusher's position << 19 (11 bits) | rp_moved_needs_mark << 30
   unsigned short next[kSimMax], rank[kSimMax];
@@ -578,17 +578,17 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     L.next[j] = (unsigned short)0xFFFF;
     L.rank[j] = (unsigned short)rk;
     L.orank[j] = T != rp::kNever ? (unsigned short)(T & 0x7FFFu) : (unsigned short)0;   // (ranks stay below smax <= 1024)
-    if (rp::rp_meta_live(m)) atomicAdd(&L.cnt[pl], 1u);
+    if (rp::rp_meta_live(m)) atomicOr(&L.cnt[pl], 1u << (m & 0x1Fu));   // the LUT indices of pl's live children (a pusher has one child per neighbour)
     if (rk != 0xFFFF && (m & (1u << 18))) atomicMin(&L.flag_rank, rk);   // ranked, but a child of it is not in the list
   }
   __syncthreads();
   {
-    // first[] = exclusive prefix of cnt[0 .. n]: five consecutive entries per thread, wave scan, wave totals
+    // first[] = exclusive prefix of the children per record (bits of cnt[0 .. n]): five consecutive entries per thread, wave scan, wave totals
     constexpr int kPer = (kSimMax + 2 + kRpThreads - 1) / kRpThreads;
     uint32_t v[kPer], sum = 0;
     for (int k = 0; k < kPer; ++k) {
       const uint32_t i = tid * kPer + k;
-      v[k] = i <= n ? L.cnt[i] : 0u;
+      v[k] = i <= n ? (uint32_t)__popc(L.cnt[i]) : 0u;
       sum += v[k];
     }
     uint32_t inc = sum;
@@ -608,25 +608,15 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
     }
   }
   __syncthreads();
-  for (uint32_t i = tid; i < n + 2; i += kRpThreads) L.cnt[i] = 0;
-  __syncthreads();
+  // a record's children in LUT order: a child's place is the number of its siblings with a smaller LUT index.  (Until round 6 the
+  // children were filed in arrival order and every record's run was insertion-sorted through LDS — two dependent reads per
+  // comparison, 26 children of a base record ~170 of them; the rankings a launch waits for spent as long here as in the replay.)
   for (uint32_t j = tid; j < n; j += kRpThreads) {
     const uint32_t inf = L.info[j];
-    if ((inf >> 16) & 1u) L.kids[L.first[(inf >> 19) & 0x7FFu] + atomicAdd(&L.cnt[(inf >> 19) & 0x7FFu], 1u)] = (unsigned short)j;
+    const uint32_t pl = (inf >> 19) & 0x7FFu;
+    if ((inf >> 16) & 1u) L.kidw[L.first[pl] + (uint32_t)__popc(L.cnt[pl] & ((1u << (inf & 0x1Fu)) - 1u))] = j | (((inf >> 8) & 0xFFu) << 16);
   }
   __syncthreads();
-  for (uint32_t pl = tid; pl <= n; pl += kRpThreads) {   // a record's children in LUT order (26 at most)
-    const uint32_t f = L.first[pl], e = L.first[pl + 1];
-    for (uint32_t x = f + 1; x < e; ++x) {
-      const unsigned short jj = L.kids[x];
-      const uint32_t key = L.info[jj] & 0x1F;
-      uint32_t y = x;
-      while (y > f && (L.info[L.kids[y - 1]] & 0x1F) > key) { L.kids[y] = L.kids[y - 1]; --y; }
-      L.kids[y] = jj;
-    }
-  }
-  __syncthreads();
-  for (uint32_t x = tid; x < (uint32_t)L.first[n + 1]; x += kRpThreads) L.kidb[x] = (unsigned short)((L.info[L.kids[x]] >> 8) & 0xFF);
   const bool arrays = nb <= 64;   // the bucket FIFOs as arrays (below); more buckets than lanes: linked lists, one pop at a time
   if (arrays && tid < 64) { L.cnt[tid] = 0; L.tail[tid] = 0; L.moved[tid] = 0; }   // (cnt is free since the child table was filled)
   // a record with an unlisted child in front of the restart point: the ranking ends behind it
@@ -736,14 +726,17 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       // the children of the batch, in (pusher, LUT) order
       bool low = false;
       const uint32_t off = inc - nk;
-      for (uint32_t ci = 0;; ++ci) {
-        const bool act = (uint32_t)lane < M && ci < nk;
-        if (!__ballot(act)) break;
-        if (act) {
-          const uint32_t kb = L.kidb[f + ci];
-          scr[off + ci] = (uint32_t)L.kids[f + ci] | (kb << 16);
-          low = low || kb < (uint32_t)b;
-        }
+      for (uint32_t c0 = 0;; c0 += 4) {   // (four at a time: the reads of a trip go out together)
+        if (!__ballot((uint32_t)lane < M && c0 < nk)) break;
+        uint32_t w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w4[k] = ((uint32_t)lane < M && c0 + k < nk) ? L.kidw[f + c0 + k] : 0xFFFF0000u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((uint32_t)lane < M && c0 + k < nk) {
+            scr[off + c0 + k] = w4[k];
+            low = low || (w4[k] >> 16) < (uint32_t)b;
+          }
       }
       const unsigned long long mC = __ballot(low);   // a child in a bucket below this one pops next
       const uint32_t cutC = mC ? (uint32_t)__ffsll((long long)mC) : 65u;
@@ -811,7 +804,7 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       {
         const uint32_t f = L.first[j + 1], e = L.first[j + 2];
         if ((uint32_t)lane < e - f) {
-          jv = L.kids[f + lane];
+          jv = L.kidw[f + lane] & 0xFFFFu;
           jinfo = L.info[jv];
         }
       }
@@ -917,6 +910,14 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
       w[13] += tk5 - tk4;
       w[14] += n_batches;
       w[15] += 1;
+      {   // rankings by what they took: < 8, < 12, < 16, < 24, < 32 us, more; and what the ones of 16 us or more were made of
+        const unsigned long long all = tk5 - tk0;   // (10 ns units)
+        w[16 + (all < 800 ? 0 : all < 1200 ? 1 : all < 1600 ? 2 : all < 2400 ? 3 : all < 3200 ? 4 : 5)] += 1;
+        if (all >= 1600) {
+          w[22] += tb - tk0; w[23] += tk1 - tb; w[24] += tk2 - tk1; w[25] += tk5 - tk2;
+          w[26] += n; w[27] += n_batches; w[28] += popped;
+        }
+      }
     }
   }
   __syncthreads();
