@@ -153,7 +153,7 @@ struct Ctl {
   // control step moves).  What decides anything is not here: st_iters and t_prev are in part A.
   alignas(128) unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16];
-  unsigned long long st_bin_steps[4][8], st_bin_ticks[4][8];   // (device) launches of FOLD / APPLY / SIM / PLACE by items: < 4, < 16, < 64, < 256, < 1 Ki, < 4 Ki, < 16 Ki, more
+  unsigned long long st_bin_steps[8][8], st_bin_ticks[8][8];   // (device) launches of FOLD / APPLY / SIM / PLACE / PUSH / COMMIT_FOLD / CLEANUP / RAISE_FOLD by items: < 4, < 16, < 64, < 256, < 1 Ki, < 4 Ki, < 16 Ki, more
 };
 
 struct Args {

@@ -448,8 +448,8 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   const bool fresh = !ctx->rp_ctl.p;
   HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl)));
   if (getenv("VBX_RP_STATS")) {   // what the rankings cost, per workgroup (rp::Args::wg_stats), zero at the start of an update
-    HIP_TRY(ctx->rp_wg_stats.ensure((size_t)4096 * (rp::kWgStats + 32) * 8));
-    HIP_TRY(hipMemsetAsync(ctx->rp_wg_stats.p, 0, (size_t)4096 * (rp::kWgStats + 32) * 8, s));
+    HIP_TRY(ctx->rp_wg_stats.ensure((size_t)4096 * (rp::kWgStats + 40) * 8));
+    HIP_TRY(hipMemsetAsync(ctx->rp_wg_stats.p, 0, (size_t)4096 * (rp::kWgStats + 40) * 8, s));
   }
   HIP_TRY(ctx->rp_nbslot.ensure((size_t)std::max<uint32_t>(used, 1) * 27 * 4));
   HIP_TRY(ctx->rp_hazard.ensure((size_t)std::max<uint32_t>(used, 1) * m.nvox));
@@ -629,17 +629,21 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
             hc.st_poison, hc.error);
     for (int k = 1; k < 13; ++k) fprintf(stderr, " %s %llu(%llu, %.2f ms)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k], hc.st_phase_ticks[k] * 1e-5);
     {
-      static const char* rows[] = {"fold", "apply", "sim", "place"};
-      for (int r = 0; r < 4; ++r) {
+      static const char* rows[] = {"fold", "apply", "sim", "place", "push", "cfold", "cleanup", "raise"};
+      for (int r = 0; r < 8; ++r) {
         fprintf(stderr, "\n[rp] %s launches by items (<4 <16 <64 <256 <1Ki <4Ki <16Ki more): ", rows[r]);
         for (int b = 0; b < 8; ++b) fprintf(stderr, " %llu x %.1f us", hc.st_bin_steps[r][b], hc.st_bin_steps[r][b] ? hc.st_bin_ticks[r][b] * 0.01 / hc.st_bin_steps[r][b] : 0.0);
       }
     }
     if (a.wg_stats) {
-      std::vector<unsigned long long> ws((size_t)4096 * (rp::kWgStats + 32)), tot(rp::kWgStats, 0), ft(8, 0);
+      std::vector<unsigned long long> ws((size_t)4096 * (rp::kWgStats + 40)), tot(rp::kWgStats, 0), ft(8, 0), pt(8, 0);
       HIP_TRY(hipMemcpy(ws.data(), a.wg_stats, ws.size() * 8, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < (size_t)4096 * rp::kWgStats; ++i) tot[i % rp::kWgStats] += ws[i];
       for (size_t i = 0; i < (size_t)4096 * 32; ++i) ft[i % 8] += ws[(size_t)4096 * rp::kWgStats + i];
+      for (size_t i = 0; i < (size_t)4096 * 8; ++i) pt[i % 8] += ws[(size_t)4096 * (rp::kWgStats + 32) + i];
+      fprintf(stderr, "\n[rp] push tiles: %llu (%.1f buckets per pass); us per tile: ticket %.2f, counts %.2f, scan %.2f, look-back %.2f, apply %.2f; last ticket %.2f us per workgroup-launch",
+              pt[6], pt[6] ? (double)pt[7] / pt[6] : 0.0, pt[6] ? pt[0] * 0.01 / pt[6] : 0.0, pt[6] ? pt[1] * 0.01 / pt[6] : 0.0, pt[6] ? pt[2] * 0.01 / pt[6] : 0.0,
+              pt[6] ? pt[3] * 0.01 / pt[6] : 0.0, pt[6] ? pt[4] * 0.01 / pt[6] : 0.0, pt[6] ? pt[5] * 0.01 / pt[6] : 0.0);
       fprintf(stderr, "\n[rp] folds: %llu, events %llu, lists of 64 or more %llu, of 192 or more %llu; wave-ms summed over folds: loads %.2f, order %.2f, replay %.2f, outputs %.2f",
               ft[0], ft[1], ft[6], ft[7], ft[2] * 1e-5, ft[3] * 1e-5, ft[4] * 1e-5, ft[5] * 1e-5);
       {

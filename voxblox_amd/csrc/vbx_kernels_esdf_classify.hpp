@@ -362,14 +362,16 @@ struct ClsPushScan {
     }
     return m;
   }
-  __device__ rp::Cnt4 count(uint32_t i) const {
+  using State = uint32_t;   // (the item's mask: count() leaves it to apply())
+  __device__ rp::Cnt4 count(uint32_t i, State& st) const {
     const uint32_t m = mask(i);
+    st = m;
     rp::Cnt4 c{};
     for (int k = 0; k < rp::kScanC; ++k) c.v[k] = (m >> k) & 1u;
     return c;
   }
-  __device__ void apply(uint32_t i, const rp::Cnt4& ex) const {
-    const uint32_t m = mask(i);
+  __device__ void apply(uint32_t i, const rp::Cnt4& ex, const State& st) const {
+    const uint32_t m = st;
     if (!m) return;
     const uint32_t gid = a.list_slots[i / a.m.nvox] * a.m.nvox + i % a.m.nvox;
     for (int k = 0; k < rp::kScanC; ++k)

@@ -923,13 +923,21 @@ __device__ inline void rp_sim_block(const rp::Args& a, uint32_t base, SimLds& L)
   __syncthreads();
 }
 
-// SCAN: tiles of kRpThreads items by ticket; exclusive prefix of the first nc (<= rp::kScanC) counts per item, F::count / F::apply per item,
-// totals -> tot[0..3] (atomic stores), a wait that does not end -> *err |= 64
+// SCAN: tiles of kRpThreads items; exclusive prefix of the first nc (<= rp::kScanC) counts per item, F::count / F::apply per item (with
+// an F::State between them: what count() found out need not be asked again), totals -> tot[0..nc) (atomic stores), a wait that
+// does not end -> *err |= 64.  Tiles are handed out by ticket, or — by_block, for a grid that is resident as a whole, tile t's
+// predecessors are then running or done as well — tile = workgroup: two trips to a shared counter less per workgroup.
+// Round 6, after the stages were timed per tile (VBX_RP_STATS: ticket 0.8, counts 9, scan 5, look-back 5-10, apply 9.7, last
+// ticket 2 us): the scan inside the tile on the DPP path with the per-component loops unrolled (runtime-indexed register arrays
+// had gone to scratch), a wave's two components looked back together, the reduction of a look-back window on the DPP path.
 template <class F>
-__device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, uint32_t* tot, uint32_t* err, int nc = rp::kScanC) {
+__device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, uint32_t* tot, uint32_t* err, int nc = rp::kScanC, bool by_block = false,
+                                     unsigned long long* stats = nullptr) {
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_wave[kRpThreads / 64][rp::kScanC];
   __shared__ uint32_t s_prefix[rp::kScanC];
+  constexpr int kWaves = kRpThreads / 64;
+  static_assert(rp::kScanC <= 2 * kWaves, "a wave looks back for two components");
   const uint32_t tiles = (n + kRpThreads - 1) / kRpThreads;
   if (tiles > sc.max_tiles) {   // more tiles than descriptors: fail loudly instead of indexing past the buffer
     if (threadIdx.x == 0) atomicOr(err, 64u);
@@ -937,99 +945,235 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
   }
   const uint32_t gen = sc.ticket[1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) s_tile = atomicAdd(&sc.ticket[0], 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (tile >= tiles) break;
+  for (uint32_t round = 0;; ++round) {
+    const unsigned long long sk0 = wall_clock64();
+    uint32_t tile;
+    if (by_block) {
+      tile = blockIdx.x + round * gridDim.x;
+      if (tile >= tiles) break;
+      if (round) __syncthreads();   // (the tables below are used again)
+    } else {
+      __syncthreads();
+      if (threadIdx.x == 0) s_tile = atomicAdd(&sc.ticket[0], 1u);
+      __syncthreads();
+      tile = s_tile;
+      if (tile >= tiles) { if (stats && threadIdx.x == 0) stats[5] += wall_clock64() - sk0; break; }
+    }
+    const unsigned long long sk1 = wall_clock64();
     const uint32_t i = tile * kRpThreads + threadIdx.x;
     rp::Cnt4 cnt{};
-    if (i < n) cnt = f.count(i);
-    // exclusive scan inside the tile: wave scan by shuffles, wave totals through LDS
+    typename F::State st{};
+    if (i < n) cnt = f.count(i, st);
+    const unsigned long long sk2 = wall_clock64();
+    // exclusive scan inside the tile: wave scans on the DPP path, wave totals through LDS
     rp::Cnt4 ex{};
-    for (int k = 0; k < nc; ++k) {
-      uint32_t v = cnt.v[k];
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane >= d) v += o;
+#pragma unroll
+    for (int k = 0; k < (int)rp::kScanC; ++k) {
+      if (k < nc) {
+        const uint32_t inc = rp_wave_scan_add(cnt.v[k]);
+        if (lane == 63) s_wave[wave][k] = inc;
+        ex.v[k] = inc - cnt.v[k];
       }
-      if (lane == 63) s_wave[wave][k] = v;
-      ex.v[k] = v - cnt.v[k];
     }
     __syncthreads();
-    uint32_t agg[rp::kScanC];
-    for (int k = 0; k < nc; ++k) {
-      uint32_t before = 0, total = 0;
-      for (int w = 0; w < kRpThreads / 64; ++w) {
-        if (w < wave) before += s_wave[w][k];
-        total += s_wave[w][k];
-      }
-      ex.v[k] += before;
-      agg[k] = total;
-    }
-    // publish the aggregates, look back: wave k owns components k, k + 4 and reads 64 predecessors at a time (a tile's wait is
-    // for aggregates only, which every tile publishes before it looks back — no chain of waits through the tiles)
-    // (four waves, up to eight components: a wave owns k and k + 4; all of a tile's aggregates go out before it waits for anybody)
-    for (int k = wave; k < nc; k += kRpThreads / 64)
-      if (lane == 0)
-        __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k, ((unsigned long long)((gen << 2) | (tile == 0 ? 2u : 1u)) << 32) | agg[k], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    for (int k = wave; k < nc; k += kRpThreads / 64) {
-      unsigned long long* d = sc.desc + (size_t)tile * rp::kScanC + k;
-      uint32_t prefix = 0;
-      uint32_t t = tile;   // tiles [0, t) are still to be summed
-      uint32_t spins = 0;
-      while (t > 0) {
-        const bool mine = (uint32_t)lane < t;
-        unsigned long long w = 0;
-        if (mine) w = __hip_atomic_load(sc.desc + (size_t)(t - 1 - lane) * rp::kScanC + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t tag = (uint32_t)(w >> 32);
-        const bool ready = mine && (tag >> 2) == gen && (tag & 3u) != 0u;
-        const bool incl = ready && (tag & 3u) == 2u;
-        const unsigned long long m_incl = __ballot(incl), m_ready = __ballot(ready), m_mine = __ballot(mine);
-        // lanes up to the first inclusive prefix (or all of mine) must be there
-        const int stop = m_incl ? (__ffsll((long long)m_incl) - 1) : 63;
-        const unsigned long long need = (stop == 63 ? ~0ull : ((2ull << stop) - 1ull)) & m_mine;
-        if ((m_ready & need) != need) {
-          if (++spins > kRpSpinMax) { if (lane == 0) atomicOr(err, 64u); break; }
-          __builtin_amdgcn_s_sleep(1);
-          continue;
+    // the components this wave publishes and looks back for: wave and wave + kWaves
+    uint32_t agg0 = 0, agg1 = 0;
+#pragma unroll
+    for (int k = 0; k < (int)rp::kScanC; ++k) {
+      if (k < nc) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          const uint32_t x = s_wave[w][k];
+          if (w < wave) before += x;
+          total += x;
         }
-        uint32_t v = ((need >> lane) & 1ull) ? (uint32_t)w : 0u;
-        for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_xor(v, dd);
-        prefix += v;
-        if (m_incl) break;
-        t -= (uint32_t)__popcll(m_mine);
+        ex.v[k] += before;
+        if (k == wave) agg0 = total;
+        if (k == wave + kWaves) agg1 = total;
       }
-      if (lane == 0) {
-        if (tile != 0)
-          __hip_atomic_store(d, ((unsigned long long)((gen << 2) | 2u) << 32) | (prefix + agg[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_prefix[k] = prefix;
-        if (tile == tiles - 1) atomicExch(&tot[k], prefix + agg[k]);
+    }
+    const unsigned long long sk3 = wall_clock64();
+    // publish the aggregates, look back 64 predecessors at a time (a tile's wait is for aggregates only, which every tile
+    // publishes before it looks back — no chain of waits through the tiles)
+    const int k0 = wave, k1 = wave + kWaves;
+    const bool on0 = k0 < nc, on1 = k1 < nc;
+    const unsigned long long tag_agg = (unsigned long long)((gen << 2) | (tile == 0 ? 2u : 1u)) << 32, tag_inc = (unsigned long long)((gen << 2) | 2u) << 32;
+    if (lane == 0) {
+      if (on0) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k0, tag_agg | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (on1) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k1, tag_agg | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t prefix0 = 0, prefix1 = 0, t0 = on0 ? tile : 0u, t1 = on1 ? tile : 0u;   // tiles [0, t) are still to be summed
+    uint32_t spins = 0;
+    // one window of one component: true when it was summed (t moves on, or to 0 behind an inclusive prefix)
+    const auto window = [&](unsigned long long w, uint32_t& t, uint32_t& prefix) -> bool {
+      const bool mine = (uint32_t)lane < t;
+      const uint32_t tag = (uint32_t)(w >> 32);
+      const bool ready = mine && (tag >> 2) == gen && (tag & 3u) != 0u;
+      const bool incl = ready && (tag & 3u) == 2u;
+      const unsigned long long m_incl = __ballot(incl), m_ready = __ballot(ready), m_mine = __ballot(mine);
+      // lanes up to the first inclusive prefix (or all of mine) must be there
+      const int stop = m_incl ? (__ffsll((long long)m_incl) - 1) : 63;
+      const unsigned long long need = (stop == 63 ? ~0ull : ((2ull << stop) - 1ull)) & m_mine;
+      if ((m_ready & need) != need) return false;
+      prefix += rl_u32(rp_wave_scan_add(((need >> lane) & 1ull) ? (uint32_t)w : 0u), 63);
+      t = m_incl ? 0u : t - (uint32_t)__popcll(m_mine);
+      return true;
+    };
+    while (t0 > 0 || t1 > 0) {
+      unsigned long long w0 = 0, w1 = 0;
+      if ((uint32_t)lane < t0) w0 = __hip_atomic_load(sc.desc + (size_t)(t0 - 1 - lane) * rp::kScanC + k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)lane < t1) w1 = __hip_atomic_load(sc.desc + (size_t)(t1 - 1 - lane) * rp::kScanC + k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool moved = false;
+      if (t0 > 0) moved = window(w0, t0, prefix0) || moved;
+      if (t1 > 0) moved = window(w1, t1, prefix1) || moved;
+      if (!moved) {
+        if (++spins > kRpSpinMax) { if (lane == 0) atomicOr(err, 64u); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (lane == 0) {
+      if (on0) {
+        if (tile != 0) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k0, tag_inc | (prefix0 + agg0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix[k0] = prefix0;
+        if (tile == tiles - 1) atomicExch(&tot[k0], prefix0 + agg0);
+      }
+      if (on1) {
+        if (tile != 0) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k1, tag_inc | (prefix1 + agg1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix[k1] = prefix1;
+        if (tile == tiles - 1) atomicExch(&tot[k1], prefix1 + agg1);
       }
     }
     __syncthreads();
+    const unsigned long long sk4 = wall_clock64();
     if (i < n) {
-      for (int k = 0; k < nc; ++k) ex.v[k] += s_prefix[k];
-      f.apply(i, ex);
+#pragma unroll
+      for (int k = 0; k < (int)rp::kScanC; ++k)
+        if (k < nc) ex.v[k] += s_prefix[k];
+      f.apply(i, ex, st);
+    }
+    if (stats && threadIdx.x == 0) {   // (VBX_RP_STATS) ticket, counts, scan inside the tile, look-back, apply (issue only), the ticket that ends the loop
+      stats[0] += sk1 - sk0; stats[1] += sk2 - sk1; stats[2] += sk3 - sk2; stats[3] += sk4 - sk3; stats[4] += wall_clock64() - sk4; stats[6] += 1; stats[7] += (unsigned long long)nc;
     }
   }
   if (n == 0 && blockIdx.x == 0 && (int)threadIdx.x < nc) atomicExch(&tot[threadIdx.x], 0u);
 }
-struct RpPhaseScan {   // PH_RANK / PH_PUSH
+
+// PH_RANK / PH_PUSH.  The push pass on the device does not walk rp::rp_for_pushes twice: count() fetches the record's seven push
+// words at once, finds the (few: 1.3 on average) pushes of this pass with the buckets' components from an LDS table, asks for
+// their children's records four at a time, and leaves what it found — LUT indices taken, their components — to apply().  (The
+// serial form went to memory once per word, then per push for the child, then for the child's record: 9 us per tile and stage.)
+struct RpPhaseScan {
   const rp::Args& a;
-  __device__ rp::Cnt4 count(uint32_t i) const { return rp::rp_scan_count(a, i); }
-  __device__ void apply(uint32_t i, const rp::Cnt4& ex) const { rp::rp_scan_apply(a, i, ex); }
+  uint32_t phase;
+  const uint32_t* comp_of;     // LDS [256]: bucket -> component of this pass (0xFF: another pass)
+  const uint32_t* comp_bucket; // LDS [kScanC]: the component's bucket,
+  const uint32_t* comp_tail;   // ... that bucket's FIFO tail
+  struct State { uint32_t take, kk[3], r, gid; };
+  __device__ static uint32_t kk_get(const State& st, uint32_t lut) { return (st.kk[lut / 10] >> (3 * (lut % 10))) & 7u; }
+  __device__ rp::Cnt4 count(uint32_t i, State& st) const {
+    const rp::Ctl& c = *a.ctl;
+    rp::Cnt4 n{};
+    if (phase == rp::PH_RANK) {
+      const unsigned long long T0 = (unsigned long long)i << rp::kRankBits;
+      if (T0 < c.cut) {
+        n.v[0] = 1 + a.sub_n[i];
+        if ((c.cut >> rp::kRankBits) == i) n.v[0] = (uint32_t)(c.cut & rp::kRankMask);  // ranks in front of the cut's, plus the base record
+      }
+      return n;
+    }
+    const uint32_t r = a.ord[i];
+    st.r = r;
+    st.gid = a.rec_vox[r];
+    uint32_t w[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) w[k] = a.rec_push[r * 7 + k];
+    // candidates: the pushes into a bucket of this pass
+    uint32_t cand = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      uint32_t word = w[k];
+      for (uint32_t j = 0; word != 0u; ++j, word >>= 8) {
+        const uint32_t v = word & 0xFFu;
+        if (v == 0u) continue;
+        const uint32_t comp = comp_of[v - 1u];
+        if (comp == 0xFFu) continue;
+        const uint32_t lut = (uint32_t)k * 4 + j;
+        cand |= 1u << lut;
+        st.kk[lut / 10] |= comp << (3 * (lut % 10));
+      }
+    }
+    // an entry that was popped inside this super-step is not queued: four candidates' children per trip
+    const unsigned long long cut = c.cut;
+    while (cand) {
+      uint32_t lut4[4], kid4[4], m4[4];
+      unsigned long long T4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        lut4[q] = cand ? (uint32_t)__ffs((int)cand) - 1u : 32u;
+        if (cand) cand &= cand - 1u;
+        kid4[q] = lut4[q] < 32u ? a.rec_kid[(size_t)r * 26 + lut4[q]] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        m4[q] = kid4[q] ? a.rec_meta[kid4[q] - 1u] : 0u;
+        T4[q] = kid4[q] ? a.rec_T[kid4[q] - 1u] : rp::kNever;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (lut4[q] >= 32u) continue;
+        if (kid4[q] != 0u && rp::rp_meta_live(m4[q]) && T4[q] < cut) continue;
+        st.take |= 1u << lut4[q];
+        const uint32_t comp = kk_get(st, lut4[q]);
+#pragma unroll
+        for (int k = 0; k < (int)rp::kScanC; ++k)
+          if ((uint32_t)k == comp) ++n.v[k];
+      }
+    }
+    return n;
+  }
+  __device__ void apply(uint32_t i, const rp::Cnt4& prefix, const State& st) const {
+    if (phase == rp::PH_RANK) {
+      a.off0[i] = prefix.v[0];
+      return;
+    }
+    rp::Cnt4 pos = prefix;   // (LUT indices come in ascending order: the entries of a bucket land in LUT order)
+    uint32_t take = st.take;
+    while (take) {
+      const uint32_t lut = (uint32_t)__ffs((int)take) - 1u;
+      take &= take - 1u;
+      const uint32_t comp = kk_get(st, lut);
+      uint32_t at = 0;
+#pragma unroll
+      for (int k = 0; k < (int)rp::kScanC; ++k)
+        if ((uint32_t)k == comp) at = pos.v[k]++;
+      rp::rp_queue_store(a, (int)comp_bucket[comp], comp_tail[comp] + at, rp::rp_neighbour(a, st.gid, (int)lut));
+    }
+  }
 };
 __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32_t n, uint32_t phase) {
-  RpPhaseScan f{a};
+  __shared__ uint32_t s_comp_of[256];
+  __shared__ uint32_t s_comp_bucket[rp::kScanC], s_comp_tail[rp::kScanC];
   // PH_RANK counts one thing per item, a PH_PUSH pass one per bucket it fills (Ctl::push_n: part A, written by the control
   // step of an earlier launch)
-  int nc = phase == rp::PH_RANK ? 1 : (int)a.ctl->push_n;
+  const rp::Ctl& c = *a.ctl;
+  int nc = phase == rp::PH_RANK ? 1 : (int)c.push_n;
   if (nc < 1) nc = 1;
   if (nc > rp::kScanC) nc = rp::kScanC;
-  rp_scan_tiles(f, sc, n, a.ctl->scan_tot, &a.ctl->error, nc);
+  if (phase == rp::PH_PUSH) {
+    s_comp_of[threadIdx.x] = 0xFFu;   // (kRpThreads == 256 buckets at most)
+    __syncthreads();
+    if ((int)threadIdx.x < nc && threadIdx.x < c.push_n) {
+      const uint32_t b = c.push_b[threadIdx.x];
+      s_comp_of[b & 0xFFu] = threadIdx.x;
+      s_comp_bucket[threadIdx.x] = b;
+      s_comp_tail[threadIdx.x] = c.tail[b];
+    }
+    __syncthreads();
+  }
+  RpPhaseScan f{a, phase, s_comp_of, s_comp_bucket, s_comp_tail};
+  rp_scan_tiles(f, sc, n, a.ctl->scan_tot, &a.ctl->error, nc, /*by_block=*/true,
+                (a.wg_stats && phase == rp::PH_PUSH && blockIdx.x < 4096u) ? a.wg_stats + (size_t)4096 * (rp::kWgStats + 32) + (size_t)blockIdx.x * 8 : nullptr);
 }
 
 __host__ __device__ inline unsigned long long rp_hdr(uint32_t seq, uint32_t phase, uint32_t n) {
@@ -1179,7 +1323,7 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
     const unsigned long long now = wall_clock64();   // 100 MHz
     if (s_ctl.t_prev) {
       s_ctl.st_phase_ticks[phase & 15] += now - s_ctl.t_prev;
-      const int row = phase == rp::PH_FOLD ? 0 : phase == rp::PH_APPLY ? 1 : phase == rp::PH_SIM ? 2 : phase == rp::PH_PLACE_BASE ? 3 : -1;
+      const int row = phase == rp::PH_FOLD ? 0 : phase == rp::PH_APPLY ? 1 : phase == rp::PH_SIM ? 2 : phase == rp::PH_PLACE_BASE ? 3 : phase == rp::PH_PUSH ? 4 : phase == rp::PH_COMMIT_FOLD ? 5 : phase == rp::PH_CLEANUP ? 6 : phase == rp::PH_RAISE_FOLD ? 7 : -1;
       if (row >= 0) {
         int bin = 0;
         for (uint32_t lim = 4; bin < 7 && n >= lim; lim <<= 2) ++bin;
