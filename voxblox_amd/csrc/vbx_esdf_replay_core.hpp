@@ -343,7 +343,6 @@ constexpr uint32_t kTgtSpin = 1u << 14;
 RP_FN uint32_t rp_target(const Args& a, uint32_t gid, uint32_t v) {
   Ctl& c = *a.ctl;
   if (v != 0u && v != kBusyTgt) return v - 1u;
-  if (c.n_tgt >= a.tgt_cap) return kNone;   // (racy look, the exact test follows; keeps the counter from running away)
   if (a.c.tgt_claim) {
     for (uint32_t spin = 0; spin < kTgtSpin; ++spin) {
       // (a voxel somebody else is busy with is WATCHED with reads — RP_LD_RO: a coherent load where the includer has one —
