@@ -38,6 +38,7 @@ static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4
 static int g_filter_level = 3;
 #define RP_INC(p) atomicAdd((p), 1u)
 #define RP_LD(x) (x)
+#define RP_SHARD 0u
 #define RP_LD64(x) (x)
 #include "../voxblox_amd/csrc/vbx_esdf_replay_core.hpp"
 

@@ -46,6 +46,7 @@ constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kWgStats = 32;
 constexpr uint32_t kArriveSubs = 32;
+constexpr uint32_t kTgtShards = 8;      // most counters PH_PLACE_BASE hands target ids out of (Cfg::tgt_shards)
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
 #ifndef RP_EVQ
@@ -96,6 +97,7 @@ struct Cfg {
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
   uint32_t stats;        // (device) 1: VBX_RP_STATS — the rankings and folds keep what they cost per workgroup (Args::wg_stats)
+  uint32_t tgt_shards;   // target ids in PH_PLACE_BASE come from this many counters, interleaved (id = k * shards + shard; 1: one counter)
   uint32_t mark_moved;   // a ranking marks the targets of 2: the records whose order it changed, 1: every record whose pop time it moved (rp_mark_rec_targets); 0: nothing (round 4)
 };
 
@@ -148,6 +150,9 @@ struct Ctl {
   // (device wrapper) arrivals in two levels: workgroup w arrives at counter w % kArriveSubs, the last one there at `arrive` — 1,024
   // arrivals on one line are 12 us (lat_bench's step kernel: 16.9 us per launch against 5.8 with 64 workgroups arriving)
   CtlLine arrive_sub[kArriveSubs];
+  // B: PH_PLACE_BASE's target ids, shard s hands out s, s + shards, s + 2 shards ... (a super-step of 16 k base records asks for ~100 k ids
+  // in one launch; the control step behind it sets n_tgt to the largest id in use + 1 and the later phases go on from there)
+  CtlLine tgt_n[kTgtShards];
   // ---- statistics, LAST: the device's control step does not load them — it starts from zeros in its LDS copy and ADDS what it
   // counted to these words when it stores the block back (a third of the block's words, and a launch pays for every word the
   // control step moves).  What decides anything is not here: st_iters and t_prev are in part A.
@@ -340,6 +345,17 @@ constexpr uint32_t kTgtSpin = 1u << 14;
 #ifndef RP_LD_RO
 #define RP_LD_RO(x) RP_LD(x)
 #endif
+// a new target id.  PH_PLACE_BASE: from the caller's shard of Cfg::tgt_shards interleaved sequences (the ids a shard leaves unused
+// below the largest one stay holes: tgt_gid is kNone there — PH_CLEANUP leaves it so)
+RP_FN uint32_t rp_target_id(const Args& a) {
+  Ctl& c = *a.ctl;
+  const uint32_t S = a.c.tgt_shards;
+  if (S > 1u && c.phase == PH_PLACE_BASE) {
+    const uint32_t sh = (uint32_t)(RP_SHARD) % S;
+    return RP_INC(&c.tgt_n[sh].v) * S + sh;
+  }
+  return RP_INC(&c.n_tgt);
+}
 RP_FN uint32_t rp_target(const Args& a, uint32_t gid, uint32_t v) {
   Ctl& c = *a.ctl;
   if (v != 0u && v != kBusyTgt) return v - 1u;
@@ -356,7 +372,7 @@ RP_FN uint32_t rp_target(const Args& a, uint32_t gid, uint32_t v) {
       const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, kBusyTgt);
       v = old;
       if (old == 0u) {
-        const uint32_t id = RP_INC(&c.n_tgt);
+        const uint32_t id = rp_target_id(a);
         if (id >= a.tgt_cap) {
           atomicExch(&a.vox2tgt[gid], 0u);
           return kNone;
@@ -369,7 +385,7 @@ RP_FN uint32_t rp_target(const Args& a, uint32_t gid, uint32_t v) {
     }
     return kNone;
   }
-  const uint32_t id = RP_INC(&c.n_tgt);
+  const uint32_t id = rp_target_id(a);
   if (id >= a.tgt_cap) return kNone;
   const uint32_t old = atomicCAS(&a.vox2tgt[gid], 0u, id + 1u);
   if (old != 0u) {  // somebody else made it: `id` stays an empty hole
@@ -1018,6 +1034,7 @@ RP_FN void rp_phase_cleanup(const Args& a, uint32_t tid) {
   if (tid < c.a_tgt) {
     const uint32_t gid = a.tgt_gid[tid];
     if (gid != kNone) a.vox2tgt[gid] = 0;
+    a.tgt_gid[tid] = kNone;   // (an id nobody takes in the next super-step is a hole)
     a.tgt_cnt[tid] = 0;
     a.tgt_dirty[tid] = 0;
   }
@@ -1051,6 +1068,7 @@ RP_FN void rp_begin_superstep(const Args& a) {
   c.base_head = c.head[b];
   c.n_rec = K;
   c.n_tgt = 0;
+  for (uint32_t k = 0; k < kTgtShards; ++k) c.tgt_n[k].v = 0;
   c.iter = 0;
   c.read = 1;            // PLACE_BASE marks into list 0
   c.n_dirty[0] = c.n_dirty[1] = 0;
@@ -1139,6 +1157,14 @@ RP_FN void rp_control(const Args& a) {
       rp_begin_superstep(a);
       break;
     case PH_PLACE_BASE:
+      if (a.c.tgt_shards > 1u) {   // the ids in use end at the longest shard's last one
+        uint32_t top = RP_LD(c.n_tgt);
+        for (uint32_t k = 0; k < a.c.tgt_shards && k < kTgtShards; ++k) {
+          const uint32_t nk = RP_LD(c.tgt_n[k].v);
+          if (nk && (nk - 1u) * a.c.tgt_shards + k + 1u > top) top = (nk - 1u) * a.c.tgt_shards + k + 1u;
+        }
+        c.n_tgt = top;
+      }
       if (RP_LD(c.k_limit) == 0) { rp_retry_smaller(a); break; }
       if (c.raise) {
         c.a_tgt = RP_LD(c.n_tgt);

@@ -475,6 +475,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_kid.p, 0, (size_t)rec_cap * 26 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_rec_push.p, 0, (size_t)rec_cap * 7 * 4, s));
     HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0, (size_t)tgt_cap * 4 * 3, s));
+    HIP_TRY(hipMemsetAsync(ctx->rp_tgt_u32.p, 0xFF, (size_t)tgt_cap * 4, s));   // tgt_gid: kNone — an id nobody took is a hole (PH_CLEANUP keeps it so)
     HIP_TRY(hipMemsetAsync(ctx->rp_sub.p, 0, (size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4, s));
     if (getenv("VBX_RP_POISON")) {   // debug: nothing may depend on what a fresh allocation happens to hold
       DBuf* junk[] = {&ctx->rp_rec_T, &ctx->rp_rec_tgts, &ctx->rp_tgt_ev, &ctx->rp_dl, &ctx->rp_lists, &ctx->rp_sub_list, &ctx->rp_sim_q, &ctx->rp_ord};
@@ -552,6 +553,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.rec_d = reinterpret_cast<float*>(ru + (size_t)8 * R); a.rec_d_n = reinterpret_cast<float*>(ru + (size_t)9 * R);
   a.rec_born_it = ru + (size_t)10 * R;
   a.rec_plocal = ru + (size_t)11 * R;
+  a.c.tgt_shards = std::min<uint32_t>(std::max<uint32_t>(rp_env_u32("VBX_RP_TGT_SHARDS", rp::kTgtShards), 1u), rp::kTgtShards);
   a.c.stats = getenv("VBX_RP_STATS") ? 1u : 0u;
   a.wg_stats = (a.c.stats && ctx->rp_wg_stats.p) ? ctx->rp_wg_stats.as<unsigned long long>() : nullptr;
   a.rec_T = ctx->rp_rec_T.as<unsigned long long>();

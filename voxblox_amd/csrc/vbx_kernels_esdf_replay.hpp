@@ -26,6 +26,7 @@ __device__ inline uint32_t rp_wave_inc(uint32_t* ctr) {
 __device__ inline bool rp_wg_dirty_push(uint32_t t);
 #define RP_WG_DIRTY_PUSH(t) rp_wg_dirty_push(t)
 #define RP_LD(x) atomicAdd(&(x), 0u)
+#define RP_SHARD (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))   // the wave's number: which of a sharded counter's lines it uses
 #define RP_LD64(x) atomicAdd(&(x), 0ull)
 #define RP_LD_RO(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // a coherent READ (no read-modify-write)
 #include "vbx_esdf_replay_core.hpp"
@@ -1292,7 +1293,7 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   // first num_buckets + 1 entries of the five per-queue arrays.  (Until round 6 all of it, statistics and — once the counters
   // had a line each — padding included: 725 words read with atomics and stored back; a launch pays ~1 us per 128 of them.)
   // The statistics are not loaded: zeros in the LDS copy, and what the step counted is ADDED to the block afterwards.
-  constexpr uint32_t kA = offsetof(rp::Ctl, error) / 4, kB = 6 + 2 * 7;
+  constexpr uint32_t kA = offsetof(rp::Ctl, error) / 4, kB = 6 + 2 * 7 + rp::kTgtShards;
   const uint32_t nq = (uint32_t)a.c.num_buckets + 1u, n_copy = kA + kB + 5u * nq;
   const auto ctl_word = [&](uint32_t i) -> uint32_t {
     if (i < kA) return i;
@@ -1301,7 +1302,8 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
     if (i < kB) {
       constexpr uint32_t line[7] = {offsetof(rp::Ctl, n_tgt) / 4, offsetof(rp::Ctl, n_dirty) / 4, offsetof(rp::Ctl, n_chg) / 4, offsetof(rp::Ctl, n_born) / 4,
                                     offsetof(rp::Ctl, n_sd) / 4,  offsetof(rp::Ctl, n_cp) / 4,    offsetof(rp::Ctl, arrive) / 4};
-      return line[(i - 6) >> 1] + ((i - 6) & 1u);
+      if (i < 6 + 2 * 7) return line[(i - 6) >> 1] + ((i - 6) & 1u);
+      return (uint32_t)(offsetof(rp::Ctl, tgt_n) / 4) + (i - (6 + 2 * 7)) * (uint32_t)(sizeof(rp::CtlLine) / 4);
     }
     i -= kB;
     return (uint32_t)(offsetof(rp::Ctl, head) / 4) + (i / nq) * (rp::kMaxBuckets + 1) + i % nq;
