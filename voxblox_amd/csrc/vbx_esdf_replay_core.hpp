@@ -767,7 +767,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
         point = a.rec_pusher[r];
         rp_mark_sub_dirty(a, point);
       }
-      a.cp[RP_INC(&c.n_cp)] = point;
+      a.cp[item] = point;   // (one change point per item: its place is the item's — the counter this list had took one atomic per record of every PH_APPLY, for the sake of the few PH_MINCUTs)
       a.rec_d[r] = a.rec_d_n[r];
       a.rec_s[r] = a.rec_s_n[r];
       if (mn != m) {   // (change the other bits only)
@@ -787,7 +787,10 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
   const uint32_t pusher = a.born[(size_t)j * 6], lut = a.born[(size_t)j * 6 + 1], bucket = a.born[(size_t)j * 6 + 2];
   if (c.cap_stop) {
     // no record for this push: the super-step ends in front of the pop that made it
-    if (p == 26) atomicMin(&c.first_change, a.rec_T[pusher]);
+    if (p == 26) {
+      atomicMin(&c.first_change, a.rec_T[pusher]);
+      a.cp[item] = pusher;
+    }
     return;
   }
   const uint32_t gid = a.born[(size_t)j * 6 + 3];
@@ -804,7 +807,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     a.rec_s_n[r] = a.rec_s[r];
     a.rec_kid[(size_t)pusher * 26 + lut] = r + 1;
     if (a.rec_born_it) a.rec_born_it[r] = (uint32_t)c.st_iters;
-    a.cp[RP_INC(&c.n_cp)] = pusher;
+    a.cp[item] = pusher;
     rp_mark_sub_dirty(a, pusher);
     if (a.sub_mem) {
       const uint32_t base = a.rec_base[pusher];
@@ -1179,7 +1182,8 @@ RP_FN void rp_control(const Args& a) {
       // fall through
     case PH_SIM:
     case PH_APPLY: {
-      const uint32_t n_cp = RP_LD(c.n_cp);
+      if (c.phase == PH_APPLY) c.n_cp = c.a_chg + c.a_born;   // PH_APPLY leaves one change point per item (Args::cp[item])
+      const uint32_t n_cp = c.n_cp;
       if (c.phase == PH_APPLY) {
         if (!c.cap_stop) {
           c.n_rec += c.a_born;
