@@ -39,6 +39,7 @@
 // with atomics) and provides atomicAdd / atomicCAS / atomicMin / atomicOr / atomicExch on uint32_t and unsigned long long.
 // Optional: RP_WG_DIRTY_PUSH(t) -> bool, a per-workgroup collector of dirty marks (true: taken, the includer files it later).
 #pragma once
+#include <cstddef>
 
 namespace rp {
 
@@ -160,6 +161,12 @@ struct Ctl {
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16];
   unsigned long long st_bin_steps[8][8], st_bin_ticks[8][8];   // (device) launches of FOLD / APPLY / SIM / PLACE / PUSH / COMMIT_FOLD / CLEANUP / RAISE_FOLD by items: < 4, < 16, < 64, < 256, < 1 Ki, < 4 Ki, < 16 Ki, more
 };
+
+static_assert(offsetof(Ctl, error) % 128 == 0 && offsetof(Ctl, n_tgt) % 128 == 0 && offsetof(Ctl, n_dirty) % 128 == 0 && offsetof(Ctl, n_chg) % 128 == 0 &&
+              offsetof(Ctl, n_born) % 128 == 0 && offsetof(Ctl, n_sd) % 128 == 0 && offsetof(Ctl, n_cp) % 128 == 0 && offsetof(Ctl, arrive) % 128 == 0 &&
+              offsetof(Ctl, arrive_sub) % 128 == 0 && offsetof(Ctl, tgt_n) % 128 == 0 && offsetof(Ctl, st_raise_pops) % 128 == 0,
+              "a counter that a phase hammers has a 128-byte line of its own");
+static_assert(offsetof(Ctl, hdr) < offsetof(Ctl, error), "the header is read by every workgroup of a launch: with part A, not on a line that takes atomics");
 
 struct Args {
   Cfg c;
