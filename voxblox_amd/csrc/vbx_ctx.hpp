@@ -89,6 +89,8 @@ struct vbx_ctx {
   bool startset_init = false;
   std::vector<int32_t> h_by_s;  // scratch of merged_reference_order
   PBuf h_mkeys, h_mperm;                                 // its read-back / upload staging
+  PBuf rp_h_done;                                        // ESDF replay: page-locked landing place of the looks at Ctl::done (two in flight)
+  hipEvent_t rp_look_ev[2] = {nullptr, nullptr};
   std::vector<uint32_t> h_midx, h_mhash, h_morder, h_mseq, h_mruns;
   std::vector<int32_t> h_mnxt;
   std::vector<uint32_t> h_poff;  // scratch of the blocked observed-set replay

@@ -211,8 +211,11 @@ void vbx_destroy(vbx_ctx* ctx) {
   DBuf* rp_bufs[] = {&ctx->rp_ctl, &ctx->rp_nbslot, &ctx->rp_chunk_tab, &ctx->rp_rec_u32, &ctx->rp_rec_T, &ctx->rp_rec_kid,
                      &ctx->rp_rec_tgts, &ctx->rp_rec_push, &ctx->rp_vox2tgt, &ctx->rp_tgt_u32, &ctx->rp_tgt_ev, &ctx->rp_dl,
                      &ctx->rp_lists, &ctx->rp_sub, &ctx->rp_sub_list, &ctx->rp_sim_q, &ctx->rp_ord, &ctx->rp_scan_desc,
-                     &ctx->rp_hazard, &ctx->cls_pos, &ctx->cls_nb27, &ctx->cls_shadow, &ctx->cls_counters};
+                     &ctx->rp_hazard, &ctx->cls_pos, &ctx->cls_nb27, &ctx->cls_shadow, &ctx->cls_counters, &ctx->rp_wg_stats};
   for (DBuf* b : rp_bufs) b->release();
+  ctx->rp_h_done.release();
+  for (hipEvent_t e : ctx->rp_look_ev)
+    if (e) (void)hipEventDestroy(e);
   ctx->h_mkeys.release();
   ctx->h_mperm.release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);

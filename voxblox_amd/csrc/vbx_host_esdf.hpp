@@ -597,28 +597,36 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   as.sub_mem = nullptr; as.sub_restart = nullptr;
   KLAUNCH(k_rp_begin, dim3(1), dim3(1), 0, s, a);
   const uint32_t rp_grid = std::max<uint32_t>(64u, rp_env_u32("VBX_RP_GRID", kRpGrid));   // (measurement switch)
-  uint32_t h_done[2] = {0, 0};
+  // The host does not know how many steps an update takes: it queues batches of kRpGraphSteps launches and looks at Ctl::done.
+  // A look does not drain the stream (until round 6 every fourth batch ended in a synchronize, and the device sat idle until the
+  // host had seen it and queued the next batch): behind every batch the two words are copied into page-locked memory and an
+  // event is recorded; the host waits for the look of batch g - 2 before it queues batch g, so two batches are always queued
+  // behind the one that is running, and an update ends with at most two batches of launches that find nothing to do.
+  HIP_TRY(ctx->rp_h_done.ensure(64));
+  volatile uint32_t* h_done = ctx->rp_h_done.as<uint32_t>();   // [look & 1][phase, done]
+  for (int k = 0; k < 2; ++k)
+    if (!ctx->rp_look_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->rp_look_ev[k], hipEventDisableTiming));
+  h_done[1] = h_done[3] = 0;
   const uint64_t max_graphs = 1u << 20;
+  const bool sync_debug = getenv("VBX_RP_SYNC") != nullptr;
   for (uint64_t g = 0; g < max_graphs; ++g) {
-    // (a look at Ctl::done is a drain of the stream: the first ones after 4 batches of launches, later ones after 8)
-    const bool look = (g % (g < 32 ? 4 : 8)) == (g < 32 ? 3u : 7u);
-    {
-      for (uint32_t i = 0; i < kRpGraphSteps; ++i) {
-        if (getenv("VBX_RP_SYNC")) {   // debug: which phase faults
-          rp::Ctl hc;
-          (void)hipMemcpy(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost);
-          fprintf(stderr, "[rp-sync] step %llu phase %u n %u K %u b %u n_rec %u n_tgt %u n_chg %u n_born %u n_sd %u n_cp %u iter %u\n", hc.st_steps, hc.phase, hc.n_threads, hc.K,
-                  hc.bucket, hc.n_rec, hc.n_tgt, hc.n_chg, hc.n_born, hc.n_sd, hc.n_cp, hc.iter);
-        }
-        if (serial) KLAUNCH(k_rp_step<true>, dim3(rp_grid), dim3(kRpThreads), 0, s, as, sc, i);
-        else KLAUNCH(k_rp_step<false>, dim3(rp_grid), dim3(kRpThreads), 0, s, a, sc, i);
-        if (getenv("VBX_RP_SYNC") && hipStreamSynchronize(s) != hipSuccess) { fprintf(stderr, "[rp-sync] fault\n"); }
-      }
+    if (g >= 2) {
+      HIP_TRY(hipEventSynchronize(ctx->rp_look_ev[g & 1]));   // the look behind batch g - 2
+      if (h_done[(g & 1) * 2 + 1]) break;
     }
-    if (!look) continue;
-    HIP_TRY(hipMemcpyAsync(h_done, &a.ctl->phase, 8, hipMemcpyDeviceToHost, s));   // phase, done
-    HIP_TRY(hipStreamSynchronize(s));
-    if (h_done[1]) break;
+    for (uint32_t i = 0; i < kRpGraphSteps; ++i) {
+      if (sync_debug) {   // debug: which phase faults
+        rp::Ctl hc;
+        (void)hipMemcpy(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[rp-sync] step %llu phase %u n %u K %u b %u n_rec %u n_tgt %u n_chg %u n_born %u n_sd %u n_cp %u iter %u\n", hc.st_steps, hc.phase, hc.n_threads, hc.K,
+                hc.bucket, hc.n_rec, hc.n_tgt, hc.n_chg, hc.n_born, hc.n_sd, hc.n_cp, hc.iter);
+      }
+      if (serial) KLAUNCH(k_rp_step<true>, dim3(rp_grid), dim3(kRpThreads), 0, s, as, sc, i);
+      else KLAUNCH(k_rp_step<false>, dim3(rp_grid), dim3(kRpThreads), 0, s, a, sc, i);
+      if (sync_debug && hipStreamSynchronize(s) != hipSuccess) { fprintf(stderr, "[rp-sync] fault\n"); }
+    }
+    HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(h_done) + (g & 1) * 2, &a.ctl->phase, 8, hipMemcpyDeviceToHost, s));   // phase, done
+    HIP_TRY(hipEventRecord(ctx->rp_look_ev[g & 1], s));
   }
   rp::Ctl hc;
   HIP_TRY(hipMemcpyAsync(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost, s));
