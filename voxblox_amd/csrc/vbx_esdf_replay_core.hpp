@@ -364,7 +364,6 @@ RP_FN uint32_t rp_target_id(const Args& a) {
   return RP_INC(&c.n_tgt);
 }
 RP_FN uint32_t rp_target(const Args& a, uint32_t gid, uint32_t v) {
-  Ctl& c = *a.ctl;
   if (v != 0u && v != kBusyTgt) return v - 1u;
   if (a.c.tgt_claim) {
     for (uint32_t spin = 0; spin < kTgtSpin; ++spin) {
