@@ -327,6 +327,20 @@ def test_reference_order_small_super_steps_and_capacities(oracle):
     assert pops == st["open_pops"] + st["raised"], (pops, st)
 
 
+@pytest.mark.parametrize("env", [
+    {"VBX_RP_GRID": "96"},                               # tiles of a scan > workgroups (rounds of tile = workgroup), arrivals in two levels with a ragged last group
+    {"VBX_RP_GRID": "200", "VBX_RP_TGT_SHARDS": "1"},    # one target-id counter (no holes)
+    {"VBX_RP_TGT_SHARDS": "3", "VBX_RP_KMAX": "4096"},   # a shard count that does not divide the wave numbers evenly
+    {"VBX_RP_SMAX": "128"},                              # rankings that hit the rank limit inside a batch of pops
+], ids=["grid96", "grid200-1shard", "3shards-kmax4096", "smax128"])
+def test_reference_order_under_the_step_kernels_switches(oracle, env):
+    """Round 6's step kernel has paths the defaults do not take (a scan with more tiles than workgroups, a grid that is not a
+    multiple of the arrival groups, one / three target-id shards, a rank limit that cuts batches of pops): the same
+    full-resolution stream must come out bit for bit under each of them."""
+    pops, st = _full_resolution_lockstep(3, env=env)
+    assert pops == st["open_pops"] + st["raised"], (pops, st)
+
+
 def test_reference_order_one_wave_form_still_agrees(oracle):
     """VBX_ESDF_REPLAY=0 selects the round-3 form (one wave pops open_ voxel by voxel): kept as the cross-check of the
     parallel replay, so it has to stay bit-exact too."""
