@@ -317,6 +317,14 @@ RP_FN uint32_t rp_meta_bucket(uint32_t m) { return (m >> 8) & 0xFF; }
 RP_FN bool rp_meta_live(uint32_t m) { return (m >> 16) & 1; }
 RP_FN uint32_t rp_meta(uint32_t lut, uint32_t bucket, bool live) { return lut | (bucket << 8) | ((uint32_t)live << 16); }
 
+// the block of voxel gid has changed.  A look first: the bit is set once per block and update, and a fold per committed voxel
+// or-ing it in again is a few hundred thousand atomics per update on the half dozen lines that hold the blocks' words (a look
+// that misses the bit — another XCD's L2 may hold the old line — sets it once more: harmless)
+RP_FN void rp_mark_block(const Args& a, uint32_t gid) {
+  if (!a.blk_dirty) return;
+  uint32_t* w = &a.blk_dirty[gid / a.nvox];
+  if ((*w & a.dirty_bit) != a.dirty_bit) atomicOr(w, a.dirty_bit);
+}
 RP_FN void rp_mark_dirty(const Args& a, uint32_t t) {
   if (t >= kSkip) return;
   Ctl& c = *a.ctl;
@@ -590,7 +598,7 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
     if (d != d0 || s != s0) {
       a.dist[gid] = d;
       a.state[gid] = s;
-      if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+      rp_mark_block(a, gid);
     }
     if (relax) atomicAdd(&c.st_relax, (unsigned long long)relax);
     return;
@@ -707,7 +715,7 @@ RP_FN void rp_fold_raise(const Args& a, uint32_t t) {
   if (d != d0 || s != s0) {
     a.dist[gid] = d;
     a.state[gid] = s;
-    if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+    rp_mark_block(a, gid);
   }
 }
 

@@ -300,7 +300,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
       if (d != d0 || s != s0) {
         a.dist[gid] = d;
         a.state[gid] = s;
-        if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+        rp::rp_mark_block(a, gid);
       }
       if (relax) {
         if (relax_acc) *relax_acc += relax;
@@ -448,7 +448,7 @@ __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lan
   if (lane == 0 && (d != d0 || s != s0)) {
     a.dist[gid] = d;
     a.state[gid] = s;
-    if (a.blk_dirty) atomicOr(&a.blk_dirty[gid / a.nvox], a.dirty_bit);
+    rp::rp_mark_block(a, gid);
   }
 }
 
