@@ -47,6 +47,7 @@ constexpr uint32_t kChunk = 1024;          // queue arena chunk, entries
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kWgStats = 32;
 constexpr uint32_t kArriveSubs = 32;
+constexpr uint32_t kPushShards = 8;
 constexpr uint32_t kTgtShards = 8;      // most counters PH_PLACE_BASE hands target ids out of (Cfg::tgt_shards)
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
@@ -225,6 +226,8 @@ struct Args {
   uint32_t* sub_mem;        // [slots][smax]
   uint32_t* sub_mem_n;      // [kmax]
   uint32_t* rec_local;      // [rec] 1 + index in its excursion's member list (0: the base record)
+  uint32_t* push_shards;    // (device, Cfg::lds_counts) [kPushShards][kMaxBuckets + 2]: the workgroups' push counts per queue and, last, their relaxations, by workgroup number —
+                            // 1,024 workgroups x a handful of queues on ONE line of Ctl::push_cnt were what a large COMMIT_FOLD launch lasted; the control step sums the shards into Ctl::push_cnt and zeroes them
   unsigned long long* wg_stats;   // (VBX_RP_STATS, may be null) [workgroup][kWgStats]: what a ranking cost, kept per workgroup — atomics on Ctl's lines slow down what they measure
   uint32_t* rec_plocal;     // [rec] rec_local of the record's pusher, noted at birth (may be null: the ranking then asks rec_local[rec_pusher[r]] — one more dependent trip to memory per member)
   uint32_t* sub_restart;    // [kmax] smallest rank at which the excursion's structure changed since its last ranking

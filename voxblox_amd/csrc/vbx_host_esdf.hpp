@@ -446,7 +446,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
   const uint32_t kmax = rp_env_u32("VBX_RP_KMAX", 16384), smax = std::min<uint32_t>(rp_env_u32("VBX_RP_SMAX", 1024), kSimMax);
   const uint32_t rec_cap = kmax * 12 + 65536, tgt_cap = rec_cap * 2;
   const bool fresh = !ctx->rp_ctl.p;
-  HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl)));
+  HIP_TRY(ctx->rp_ctl.ensure(sizeof(rp::Ctl) + (size_t)rp::kPushShards * (rp::kMaxBuckets + 2) * 4));   // + Args::push_shards behind the block
   if (getenv("VBX_RP_STATS")) {   // what the rankings cost, per workgroup (rp::Args::wg_stats), zero at the start of an update
     HIP_TRY(ctx->rp_wg_stats.ensure((size_t)4096 * (rp::kWgStats + 40) * 8));
     HIP_TRY(hipMemsetAsync(ctx->rp_wg_stats.p, 0, (size_t)4096 * (rp::kWgStats + 40) * 8, s));
@@ -528,6 +528,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.c.smax = ctx->rp_smax;
   a.c.max_iters = rp_env_u32("VBX_RP_MAX_ITERS", 64);
   a.ctl = ctx->rp_ctl.as<rp::Ctl>();
+  a.push_shards = reinterpret_cast<uint32_t*>(a.ctl + 1);
   a.dist = e.dist;
   a.state = e.state;
   a.nbslot = ctx->rp_nbslot.as<uint32_t>();
@@ -882,7 +883,7 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0 && cfg->num_buckets <= 254;   // (a push table entry is one byte: bucket + 1, raise_ = num_buckets)
   rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used, n);
   if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(ctx->rp_ctl.p, 0, sizeof(rp::Ctl), s));
+  HIP_TRY(hipMemsetAsync(ctx->rp_ctl.p, 0, sizeof(rp::Ctl) + (size_t)rp::kPushShards * (rp::kMaxBuckets + 2) * 4, s));
   if (n_seed) {
     // the queues as addNewRobotPosition left them: chunk table rows, arena image, FIFO tails (both forms of the voxel
     // walk start from the control block's tails / chunk_top instead of empty queues)

@@ -1254,9 +1254,10 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   // trips to memory otherwise, 10 - 20 us per step) and the copy is stored back.
   if (lds_counts) {
     __syncthreads();
+    uint32_t* row = a.push_shards + (size_t)(blockIdx.x % rp::kPushShards) * (rp::kMaxBuckets + 2);   // (Args::push_shards)
     for (uint32_t i = threadIdx.x; i <= rp::kMaxBuckets; i += kRpThreads)
-      if (s_push[i]) atomicAdd(&c.push_cnt[i], s_push[i]);
-    if (threadIdx.x == 0 && s_relax) atomicAdd(&c.st_relax, (unsigned long long)s_relax);
+      if (s_push[i]) atomicAdd(&row[i], s_push[i]);
+    if (threadIdx.x == 0 && s_relax) atomicAdd(&row[rp::kMaxBuckets + 1], s_relax);
   }
   if (collect) {
     __syncthreads();
@@ -1320,6 +1321,19 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
     for (uint32_t i = kStat0 + threadIdx.x; i < kStat1; i += kRpThreads) st[i] = 0ull;
   }
   __syncthreads();
+  if (lds_counts) {   // the workgroups' push counts and relaxations: summed out of their shards, which are left at zero
+    const uint32_t i = threadIdx.x <= (uint32_t)a.c.num_buckets ? threadIdx.x : (threadIdx.x == kRpThreads - 1 ? rp::kMaxBuckets + 1 : ~0u);
+    if (i != ~0u) {
+      uint32_t v[rp::kPushShards], sum = 0;
+#pragma unroll
+      for (uint32_t sh = 0; sh < rp::kPushShards; ++sh) v[sh] = atomicExch(&a.push_shards[(size_t)sh * (rp::kMaxBuckets + 2) + i], 0u);
+#pragma unroll
+      for (uint32_t sh = 0; sh < rp::kPushShards; ++sh) sum += v[sh];
+      if (i <= rp::kMaxBuckets) s_ctl.push_cnt[i] += sum;
+      else s_ctl.st_relax += sum;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     s_ctl.arrive = 0;
     const unsigned long long now = wall_clock64();   // 100 MHz
