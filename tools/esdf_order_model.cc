@@ -644,7 +644,7 @@ class ModelEsdf : public EsdfIntegrator {
     std::vector<uint32_t> vox2tgt(nv), tgt_gid(tgt_cap), tgt_cnt(tgt_cap), tgt_ev((size_t)tgt_cap * kEvMax), tgt_dirty(tgt_cap), dl0(tgt_cap), dl1(tgt_cap);
     a.vox2tgt = vox2tgt.data(); a.tgt_gid = tgt_gid.data(); a.tgt_cnt = tgt_cnt.data(); a.tgt_ev = tgt_ev.data(); a.tgt_dirty = tgt_dirty.data();
     a.dl[0] = dl0.data(); a.dl[1] = dl1.data();
-    std::vector<uint32_t> chg(rec_cap), born((size_t)rec_cap * 6), cp(rec_cap * 2), sd_list(a.c.kmax), sub_dirty(a.c.kmax), sub_n(a.c.kmax), sub_slot(a.c.kmax);
+    std::vector<uint32_t> chg(rec_cap), born((size_t)rec_cap * 6), cp((size_t)rec_cap * 4), sd_list(a.c.kmax), sub_dirty(a.c.kmax), sub_n(a.c.kmax), sub_slot(a.c.kmax);
     const uint32_t sub_slots_cap = std::max<uint32_t>(a.c.kmax, 4096);
     std::vector<uint32_t> sub_list((size_t)sub_slots_cap * a.c.smax), ord(rec_cap), off0(a.c.kmax);
     std::vector<unsigned long long> sim_q((size_t)sub_slots_cap * a.c.smax);
@@ -733,7 +733,7 @@ class ModelEsdf : public EsdfIntegrator {
         if (n_exc > 1000) std::fprintf(stderr, "[slots] superstep %llu b=%u K=%u: %u excursions, %u records\n", c.st_supersteps, c.bucket, c.K, n_exc, c.n_rec);
       }
       if (std::getenv("EOM_TRACE2")) std::fprintf(stderr, "phase %u n=%u iter=%u rec=%u tgt=%u\n", c.phase, n, c.iter, c.n_rec, c.n_tgt);
-      const bool was_fold = c.phase == PH_FOLD && c.n_chg == 0 && c.n_born == 0;
+      const bool was_fold = c.phase == PH_FOLD && c.chg_n[0].v == 0 && c.born_n[0].v == 0;
 
       if (std::getenv("EOM_TRACE") && c.phase == PH_CLEANUP) std::fprintf(stderr, "superstep b=%u K=%u recs=%u tgts=%u iters=%u cut=%llx commit=%u\n", c.bucket, c.K, c.n_rec, c.a_tgt, c.iter, c.cut, c.n_commit);
       rp_control(a);
@@ -744,18 +744,18 @@ class ModelEsdf : public EsdfIntegrator {
         const uint32_t nt = c.n_tgt < a.tgt_cap ? c.n_tgt : a.tgt_cap;
         for (uint32_t t = 0; t < nt; ++t) rp_fold(a, t, kNever, false);
         uint32_t bad_chg = 0, bad_born = 0;
-        for (uint32_t k = 0; k < c.n_chg; ++k) {
+        for (uint32_t k = 0; k < c.chg_n[0].v; ++k) {
           const uint32_t r = a.chg[k];
           unsigned long long T = a.rec_T[r];
           if (a.rec_pusher[r] != kNone && (a.rec_meta_n[r] & ~(1u << 18)) != (a.rec_meta[r] & ~(1u << 18))) T = a.rec_T[a.rec_pusher[r]];   // liveness: decided at the pusher's pop
           if (T < c.cut) ++bad_chg;
         }
-        for (uint32_t k = 0; k < c.n_born && k < a.rec_cap; ++k) if (a.rec_T[a.born[(size_t)k * 6]] < c.cut) ++bad_born;
+        for (uint32_t k = 0; k < c.born_n[0].v && k < a.rec_cap; ++k) if (a.rec_T[a.born[(size_t)k * 6]] < c.cut) ++bad_born;
         if (bad_chg || bad_born)
-          std::fprintf(stderr, "[check] superstep %llu b=%u K=%u iter=%u cut=%llx: a full refold at the fixed point changes %u records, bears %u in front of the cut (%u / %u anywhere)\n", c.st_supersteps, c.bucket, c.K, c.iter, c.cut, bad_chg, bad_born, c.n_chg, c.n_born);
+          std::fprintf(stderr, "[check] superstep %llu b=%u K=%u iter=%u cut=%llx: a full refold at the fixed point changes %u records, bears %u in front of the cut (%u / %u anywhere)\n", c.st_supersteps, c.bucket, c.K, c.iter, c.cut, bad_chg, bad_born, c.chg_n[0].v, c.born_n[0].v);
         if (bad_chg || bad_born) ++check_failures;
         ++check_runs;
-        c.n_chg = c.n_born = 0;
+        c.chg_n[0].v = c.born_n[0].v = 0;
       }
     }
     if (c.error) std::fprintf(stderr, "EMUL ERROR %u\n", c.error);

@@ -48,6 +48,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kWgStats = 32;
 constexpr uint32_t kArriveSubs = 32;
 constexpr uint32_t kPushShards = 8;
+constexpr uint32_t kShards = 8;         // of the changed / born record lists (Ctl::chg_n, born_n)
 constexpr uint32_t kTgtShards = 8;      // most counters PH_PLACE_BASE hands target ids out of (Cfg::tgt_shards)
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
@@ -117,6 +118,7 @@ struct Ctl {
   uint32_t read;                             // dirty target lists: FOLD reads list `read`, marks go to 1 - read
   uint32_t fold_all;                         // 1: the FOLD phase that follows PH_PLACE_BASE folds targets 0 .. n_threads - 1 (no list: PLACE_BASE does not mark)
   uint32_t a_chg, a_born, a_tgt;             // copies of n_chg / n_born / n_tgt as the last phase left them
+  uint32_t chg_pre[kShards + 1], born_pre[kShards + 1];   // where shard s of the changed / born lists starts in PH_APPLY's item numbers (a_chg / a_born: all shards)
   uint32_t cap_stop;                         // 1: the records (or their list) are full — no births any more, the super-step commits what stands
   unsigned long long cut;
   uint32_t n_commit;                         // committed records
@@ -139,8 +141,6 @@ struct Ctl {
   unsigned long long first_change, smax_cut;
   alignas(128) uint32_t n_tgt;
   alignas(128) uint32_t n_dirty[2];
-  alignas(128) uint32_t n_chg;
-  alignas(128) uint32_t n_born;
   alignas(128) uint32_t n_sd;
   alignas(128) uint32_t n_cp;
   alignas(128) uint32_t arrive;              // (device wrapper) workgroups that finished the phase
@@ -155,6 +155,10 @@ struct Ctl {
   // B: PH_PLACE_BASE's target ids, shard s hands out s, s + shards, s + 2 shards ... (a super-step of 16 k base records asks for ~100 k ids
   // in one launch; the control step behind it sets n_tgt to the largest id in use + 1 and the later phases go on from there)
   CtlLine tgt_n[kTgtShards];
+  // B: entries of the changed / born record lists per shard (RP_SHARD: the device takes the wave's number).  A FOLD launch over
+  // 8 k targets appends a few thousand changed records — on one line that is what the launch lasted.  Shard s of a list is
+  // Args::chg + s * rec_cap (born: * 6); PH_APPLY numbers its items through the shards one behind the other (chg_pre / born_pre)
+  CtlLine chg_n[kShards], born_n[kShards];
   // ---- statistics, LAST: the device's control step does not load them — it starts from zeros in its LDS copy and ADDS what it
   // counted to these words when it stores the block back (a third of the block's words, and a launch pays for every word the
   // control step moves).  What decides anything is not here: st_iters and t_prev are in part A.
@@ -163,8 +167,8 @@ struct Ctl {
   unsigned long long st_bin_steps[8][8], st_bin_ticks[8][8];   // (device) launches of FOLD / APPLY / SIM / PLACE / PUSH / COMMIT_FOLD / CLEANUP / RAISE_FOLD by items: < 4, < 16, < 64, < 256, < 1 Ki, < 4 Ki, < 16 Ki, more
 };
 
-static_assert(offsetof(Ctl, error) % 128 == 0 && offsetof(Ctl, n_tgt) % 128 == 0 && offsetof(Ctl, n_dirty) % 128 == 0 && offsetof(Ctl, n_chg) % 128 == 0 &&
-              offsetof(Ctl, n_born) % 128 == 0 && offsetof(Ctl, n_sd) % 128 == 0 && offsetof(Ctl, n_cp) % 128 == 0 && offsetof(Ctl, arrive) % 128 == 0 &&
+static_assert(offsetof(Ctl, error) % 128 == 0 && offsetof(Ctl, n_tgt) % 128 == 0 && offsetof(Ctl, n_dirty) % 128 == 0 && offsetof(Ctl, chg_n) % 128 == 0 &&
+              offsetof(Ctl, born_n) % 128 == 0 && offsetof(Ctl, n_sd) % 128 == 0 && offsetof(Ctl, n_cp) % 128 == 0 && offsetof(Ctl, arrive) % 128 == 0 &&
               offsetof(Ctl, arrive_sub) % 128 == 0 && offsetof(Ctl, tgt_n) % 128 == 0 && offsetof(Ctl, st_raise_pops) % 128 == 0,
               "a counter that a phase hammers has a 128-byte line of its own");
 static_assert(offsetof(Ctl, hdr) < offsetof(Ctl, error), "the header is read by every workgroup of a launch: with part A, not on a line that takes atomics");
@@ -320,6 +324,32 @@ RP_FN uint32_t rp_meta_bucket(uint32_t m) { return (m >> 8) & 0xFF; }
 RP_FN bool rp_meta_live(uint32_t m) { return (m >> 16) & 1; }
 RP_FN uint32_t rp_meta(uint32_t lut, uint32_t bucket, bool live) { return lut | (bucket << 8) | ((uint32_t)live << 16); }
 
+// item i of a sharded list -> its place (pre[]: where the shards start in item numbers; RP_PRE reads it — the device keeps a
+// copy in LDS for the phase, three reads decide among eight shards)
+#ifndef RP_PRE
+#define RP_PRE(arr, k) (arr)[k]
+#endif
+RP_FN size_t rp_shard_pos(const uint32_t* pre, uint32_t i, uint32_t cap) {
+  static_assert(kShards == 8, "three halvings");
+  uint32_t sh = i >= RP_PRE(pre, 4) ? 4u : 0u;
+  sh += i >= RP_PRE(pre, sh + 2) ? 2u : 0u;
+  sh += i >= RP_PRE(pre, sh + 1) ? 1u : 0u;
+  return (size_t)sh * cap + (i - RP_PRE(pre, sh));
+}
+// appends to the changed / born record lists, on the caller's shard
+RP_FN void rp_chg_push(const Args& a, uint32_t r) {
+  const uint32_t sh = (uint32_t)(RP_SHARD) % kShards;
+  const uint32_t k = atomicAdd(&a.ctl->chg_n[sh].v, 1u);
+  if (k < a.rec_cap) a.chg[(size_t)sh * a.rec_cap + k] = r;   // (a record is listed once or twice per iteration)
+  else atomicOr(&a.ctl->error, 1u);
+}
+// a place in the born list for a push of record `pusher` (null: no room even to note it — the cut falls in front of the pusher)
+RP_FN uint32_t* rp_born_slot(const Args& a, uint32_t pusher) {
+  const uint32_t sh = (uint32_t)(RP_SHARD) % kShards;
+  const uint32_t k = atomicAdd(&a.ctl->born_n[sh].v, 1u);
+  if (k >= a.rec_cap) { atomicMin(&a.ctl->first_change, a.rec_T[pusher]); return nullptr; }
+  return a.born + ((size_t)sh * a.rec_cap + k) * 6;
+}
 // the block of voxel gid has changed.  A look first: the bit is set once per block and update, and a fold per committed voxel
 // or-ing it in again is a few hundred thousand atomics per update on the half dozen lines that hold the blocks' words (a look
 // that misses the bit — another XCD's L2 may hold the old line — sets it once more: harmless)
@@ -587,7 +617,7 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
             if (r < c.K) atomicMin(&c.k_limit, r);
             const uint32_t base = a.rec_base[r];
             if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
-            a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+            rp_chg_push(a, r);
           }
           continue;
         }
@@ -632,20 +662,20 @@ RP_FN void rp_fold(const Args& a, uint32_t t, unsigned long long limit, bool com
       a.rec_s_n[r] = a.rec_s[r];
     }
     a.rec_meta_n[r] = mn;
-    if (changed) a.chg[RP_INC(&c.n_chg)] = r;
+    if (changed) rp_chg_push(a, r);
   }
   for (uint32_t j = 0; j < n_lp; ++j) {
     if (lp_rec[j] == kNone) continue;  // matched an existing record
     // a push below b without a record yet (an existing record for (pusher, lut) sits on THIS voxel and was matched above)
     if (a.rec_kid[(size_t)lp_rec[j] * 26 + (lp_lb[j] & 0xFF)] != 0u) continue;  // (dead record that is not on this list cannot happen; be safe)
-    const uint32_t k = atomicAdd(&c.n_born, 1u);
-    if (k >= a.rec_cap) { atomicMin(&c.first_change, a.rec_T[lp_rec[j]]); continue; }   // no room even to note it: the cut falls in front of its pusher
-    a.born[(size_t)k * 6 + 0] = lp_rec[j];
-    a.born[(size_t)k * 6 + 1] = lp_lb[j] & 0xFF;
-    a.born[(size_t)k * 6 + 2] = lp_lb[j] >> 8;
-    a.born[(size_t)k * 6 + 3] = gid;
-    a.born[(size_t)k * 6 + 4] = __float_as_uint(lp_d[j]);   // first guess of the record's pop-time state: the voxel as this push left it
-    a.born[(size_t)k * 6 + 5] = lp_s[j];
+    uint32_t* bw = rp_born_slot(a, lp_rec[j]);
+    if (!bw) continue;
+    bw[0] = lp_rec[j];
+    bw[1] = lp_lb[j] & 0xFF;
+    bw[2] = lp_lb[j] >> 8;
+    bw[3] = gid;
+    bw[4] = __float_as_uint(lp_d[j]);   // first guess of the record's pop-time state: the voxel as this push left it
+    bw[5] = lp_s[j];
   }
 }
 
@@ -773,7 +803,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
   Ctl& c = *a.ctl;
   const uint32_t item = tid / 27, p = tid % 27;
   if (item < c.a_chg) {
-    const uint32_t r = a.chg[item];
+    const uint32_t r = a.chg[rp_shard_pos(c.chg_pre, item, a.rec_cap)];
     if (p == 26) {
       // (bit 18 of rec_meta may be set by a birth in this very phase, after FOLD copied the word to rec_meta_n: it is not
       // part of the comparison — a base record, whose other bits never change, would be sent to its pusher otherwise)
@@ -801,7 +831,8 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
   const uint32_t j = item - c.a_chg;
   if (j >= c.a_born) return;
   const uint32_t r = c.n_rec + j;   // (control checked the capacity)
-  const uint32_t pusher = a.born[(size_t)j * 6], lut = a.born[(size_t)j * 6 + 1], bucket = a.born[(size_t)j * 6 + 2];
+  const uint32_t* bw = a.born + rp_shard_pos(c.born_pre, j, a.rec_cap) * 6;
+  const uint32_t pusher = bw[0], lut = bw[1], bucket = bw[2];
   if (c.cap_stop) {
     // no record for this push: the super-step ends in front of the pop that made it
     if (p == 26) {
@@ -810,7 +841,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     }
     return;
   }
-  const uint32_t gid = a.born[(size_t)j * 6 + 3];
+  const uint32_t gid = bw[3];
   if (p == 26) {
     a.rec_vox[r] = gid;
     a.rec_pusher[r] = pusher;
@@ -818,8 +849,8 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     a.rec_meta[r] = rp_meta(lut, bucket, true);
     a.rec_meta_n[r] = a.rec_meta[r];
     a.rec_T[r] = kNever;
-    a.rec_d[r] = __uint_as_float(a.born[(size_t)j * 6 + 4]);
-    a.rec_s[r] = a.born[(size_t)j * 6 + 5];
+    a.rec_d[r] = __uint_as_float(bw[4]);
+    a.rec_s[r] = bw[5];
     a.rec_d_n[r] = a.rec_d[r];
     a.rec_s_n[r] = a.rec_s[r];
     a.rec_kid[(size_t)pusher * 26 + lut] = r + 1;
@@ -855,7 +886,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
       }
     }
   }
-  rp_place(a, r, a.rec_base[pusher], gid, p, __uint_as_float(a.born[(size_t)j * 6 + 4]), a.born[(size_t)j * 6 + 5]);
+  rp_place(a, r, a.rec_base[pusher], gid, p, __uint_as_float(bw[4]), bw[5]);
 }
 
 // A ranking that moves a record's pop time changes the ORDER of the events on the targets that record talks to.  PH_APPLY
@@ -1092,7 +1123,8 @@ RP_FN void rp_begin_superstep(const Args& a) {
   c.iter = 0;
   c.read = 1;            // PLACE_BASE marks into list 0
   c.n_dirty[0] = c.n_dirty[1] = 0;
-  c.n_chg = c.n_born = c.n_sd = c.n_cp = 0;
+  for (uint32_t k = 0; k < kShards; ++k) c.chg_n[k].v = c.born_n[k].v = 0;
+  c.n_sd = c.n_cp = 0;
   c.cap_stop = 0;
   c.k_limit = kNone;
   c.first_change = kNever;
@@ -1206,7 +1238,7 @@ RP_FN void rp_control(const Args& a) {
           c.n_rec += c.a_born;
           c.st_exc += c.a_born;
         }
-        c.n_chg = c.n_born = 0;
+        for (uint32_t k = 0; k < kShards; ++k) c.chg_n[k].v = c.born_n[k].v = 0;
         const uint32_t n_sd = RP_LD(c.n_sd);
         if (n_sd) { c.phase = PH_SIM; c.n_threads = n_sd; break; }
       }
@@ -1231,13 +1263,21 @@ RP_FN void rp_control(const Args& a) {
       break;
     }
     case PH_FOLD: {
-      c.a_chg = RP_LD(c.n_chg);
-      c.a_born = RP_LD(c.n_born);
-      if (c.a_chg == 0 && c.a_born == 0) { c.n_cp = 0; rp_start_commit(a); break; }   // fixed point
-      if (c.a_born > a.rec_cap || c.n_rec + c.a_born > a.rec_cap) {
-        c.cap_stop = 1;   // PH_APPLY applies the changes, notes the pushers of the births it cannot make, and the prefix commits
-        if (c.a_born > a.rec_cap) c.a_born = a.rec_cap;
+      c.a_chg = c.a_born = 0;
+      for (uint32_t k = 0; k < kShards; ++k) {
+        uint32_t nc = RP_LD(c.chg_n[k].v), nbn = RP_LD(c.born_n[k].v);
+        if (nc > a.rec_cap) nc = a.rec_cap;      // (what a shard could not hold was dealt with where it was found)
+        if (nbn > a.rec_cap) nbn = a.rec_cap;
+        c.chg_pre[k] = c.a_chg;
+        c.born_pre[k] = c.a_born;
+        c.a_chg += nc;
+        c.a_born += nbn;
       }
+      c.chg_pre[kShards] = c.a_chg;
+      c.born_pre[kShards] = c.a_born;
+      if (c.a_chg + c.a_born > 4u * a.rec_cap) { c.error |= 1u; rp_stop(c); break; }   // (Args::cp holds 4 * rec_cap change points: a record is listed at most twice, born at most rec_cap)
+      if (c.a_chg == 0 && c.a_born == 0) { c.n_cp = 0; rp_start_commit(a); break; }   // fixed point
+      if (c.n_rec + c.a_born > a.rec_cap) c.cap_stop = 1;   // PH_APPLY applies the changes, notes the pushers of the births it cannot make, and the prefix commits
       c.phase = PH_APPLY;
       c.n_threads = (c.a_chg + c.a_born) * 27;
       break;

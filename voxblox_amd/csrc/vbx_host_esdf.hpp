@@ -463,7 +463,7 @@ int rp_ensure(vbx_ctx* ctx, uint32_t num_buckets, size_t n_chunks, uint32_t used
     HIP_TRY(ctx->rp_tgt_u32.ensure((size_t)tgt_cap * 4 * 3));
     HIP_TRY(ctx->rp_tgt_ev.ensure((size_t)tgt_cap * rp::kEvMax * 4));   // (sized for the largest Cfg::ev)
     HIP_TRY(ctx->rp_dl.ensure((size_t)tgt_cap * 4 * 2));
-    HIP_TRY(ctx->rp_lists.ensure((size_t)rec_cap * 4 * (1 + 6 + 2) + (size_t)kmax * 4));
+    HIP_TRY(ctx->rp_lists.ensure((size_t)rec_cap * 4 * (7 * rp::kShards + 4) + (size_t)kmax * 4));   // changed / born lists (kShards shards each), change points (one per item), dirty excursions
     HIP_TRY(ctx->rp_sub.ensure((size_t)kmax * 4 * 6 + 64 + (size_t)rec_cap * 4));
     const uint32_t sub_slots = rp_sub_slots(kmax);
     HIP_TRY(ctx->rp_sub_list.ensure((size_t)sub_slots * smax * 4));
@@ -568,7 +568,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.tgt_ev = ctx->rp_tgt_ev.as<uint32_t>();
   a.dl[0] = ctx->rp_dl.as<uint32_t>(); a.dl[1] = a.dl[0] + (size_t)T;
   uint32_t* l = ctx->rp_lists.as<uint32_t>();
-  a.chg = l; a.born = l + (size_t)R; a.cp = l + (size_t)7 * R; a.sd_list = l + (size_t)9 * R;
+  a.chg = l; a.born = l + (size_t)rp::kShards * R; a.cp = l + (size_t)7 * rp::kShards * R; a.sd_list = l + (size_t)(7 * rp::kShards + 4) * R;
   uint32_t* su = ctx->rp_sub.as<uint32_t>();
   a.sub_dirty = su; a.sub_n = su + (size_t)K; a.sub_slot = su + (size_t)2 * K; a.off0 = su + (size_t)3 * K;
   a.sub_slots_used = su + (size_t)4 * K;
@@ -619,8 +619,8 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
       if (sync_debug) {   // debug: which phase faults
         rp::Ctl hc;
         (void)hipMemcpy(&hc, a.ctl, sizeof(rp::Ctl), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[rp-sync] step %llu phase %u n %u K %u b %u n_rec %u n_tgt %u n_chg %u n_born %u n_sd %u n_cp %u iter %u\n", hc.st_steps, hc.phase, hc.n_threads, hc.K,
-                hc.bucket, hc.n_rec, hc.n_tgt, hc.n_chg, hc.n_born, hc.n_sd, hc.n_cp, hc.iter);
+        fprintf(stderr, "[rp-sync] step %llu phase %u n %u K %u b %u n_rec %u n_tgt %u chg %u born %u n_sd %u n_cp %u iter %u\n", hc.st_steps, hc.phase, hc.n_threads, hc.K,
+                hc.bucket, hc.n_rec, hc.n_tgt, hc.a_chg, hc.a_born, hc.n_sd, hc.n_cp, hc.iter);
       }
       if (serial) KLAUNCH(k_rp_step<true>, dim3(rp_grid), dim3(kRpThreads), 0, s, as, sc, i);
       else KLAUNCH(k_rp_step<false>, dim3(rp_grid), dim3(kRpThreads), 0, s, a, sc, i);

@@ -25,10 +25,17 @@ __device__ inline uint32_t rp_wave_inc(uint32_t* ctr) {
 // LDS layout
 __device__ inline bool rp_wg_dirty_push(uint32_t t);
 #define RP_WG_DIRTY_PUSH(t) rp_wg_dirty_push(t)
-#define RP_LD(x) atomicAdd(&(x), 0u)
+// (the control functions' reads of counters that phases update: on the device rp_control runs on the LDS copy k_rp_step has just made
+// with coherent reads — or, k_rp_begin, before anything else runs —, so these are plain reads; as LDS atomics they were a dozen
+// to two dozen dependent round trips per control step)
+#define RP_LD(x) (x)
 #define RP_SHARD (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))   // the wave's number: which of a sharded counter's lines it uses
-#define RP_LD64(x) atomicAdd(&(x), 0ull)
+#define RP_LD64(x) (x)
 #define RP_LD_RO(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // a coherent READ (no read-modify-write)
+// PH_APPLY finds an item's shard of the changed / born lists from Ctl::chg_pre / born_pre: a copy in LDS for the phase (g_rp_pre,
+// filled by k_rp_step before the phase runs): [0 .. kShards] changed, [kShards + 1 ..] born
+__device__ inline uint32_t rp_pre_lds(const uint32_t* arr, uint32_t k);
+#define RP_PRE(arr, k) rp_pre_lds(arr, k)
 #include "vbx_esdf_replay_core.hpp"
 
 namespace {
@@ -285,7 +292,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
               const unsigned long long Tr = a.rec_T[r];
               if (Tr != kNever && (Tr & kRankMask) != 0) atomicMin(&a.sub_restart[base_r], (uint32_t)(Tr & kRankMask) - 1u);
               if (atomicExch(&a.sub_dirty[base_r], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base_r;
-              a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+              rp_chg_push(a, r);
             }
             continue;
           }
@@ -351,7 +358,7 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
       a.rec_s_n[r] = es[q];
     }
     a.rec_meta_n[r] = mn[q];
-    if (chg[q]) a.chg[atomicAdd(&c.n_chg, 1u)] = r;
+    if (chg[q]) rp_chg_push(a, r);
   }
   // pushes below b that no record stands for yet
   unsigned long long any_matched = 0;
@@ -359,16 +366,14 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
     if (__ballot((matched >> j) & 1ull)) any_matched |= 1ull << j;
   if ((uint32_t)lane < n_lp && !((any_matched >> lane) & 1ull)) {
     if (a.rec_kid[(size_t)lp_rec * 26 + (lp_lb & 0xFF)] == 0u) {
-      const uint32_t k = atomicAdd(&c.n_born, 1u);
-      if (k >= a.rec_cap) {
-        atomicMin(&c.first_change, a.rec_T[lp_rec]);   // no room even to note it: the cut falls in front of its pusher
-      } else {
-      a.born[(size_t)k * 6 + 0] = lp_rec;
-      a.born[(size_t)k * 6 + 1] = lp_lb & 0xFF;
-      a.born[(size_t)k * 6 + 2] = lp_lb >> 8;
-      a.born[(size_t)k * 6 + 3] = gid;
-      a.born[(size_t)k * 6 + 4] = __float_as_uint(lp_d);
-      a.born[(size_t)k * 6 + 5] = lp_s;
+      uint32_t* bw = rp_born_slot(a, lp_rec);   // (null: no room even to note it — the cut falls in front of its pusher)
+      if (bw) {
+        bw[0] = lp_rec;
+        bw[1] = lp_lb & 0xFF;
+        bw[2] = lp_lb >> 8;
+        bw[3] = gid;
+        bw[4] = __float_as_uint(lp_d);
+        bw[5] = lp_s;
       }
     }
   }
@@ -492,7 +497,13 @@ union RpLds {
   rp::Ctl ctl;
 };
 __shared__ RpLds g_rp_lds;
+__shared__ uint32_t g_rp_pre[2 * (rp::kShards + 1)];   // PH_APPLY: Ctl::chg_pre, Ctl::born_pre
+__shared__ const uint32_t* g_rp_pre_born;            // ... the address of Ctl::born_pre (tells the two arrays apart)
 __shared__ uint32_t g_rp_collect;   // 1 while a phase runs whose marks are collected (outside the union: the hook reads it in every phase)
+__device__ inline uint32_t rp_pre_lds(const uint32_t* arr, uint32_t k) {
+  // (arr is Ctl::chg_pre or Ctl::born_pre of the block in memory: which one it is follows from its address)
+  return g_rp_pre[(arr == g_rp_pre_born ? rp::kShards + 1 : 0) + k];
+}
 __device__ inline bool rp_wg_dirty_push(uint32_t t) {
   if (!g_rp_collect) return false;
   const uint32_t k = atomicAdd(&g_rp_lds.dirty.cnt, 1u);
@@ -1195,6 +1206,10 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   rp::Ctl& c = *a.ctl;
   // Only the workgroups with work are waited for, so the control step of this launch can run before the dispatcher has
   // started the rest of the grid; those find the header of the next launch and leave.
+  // (asked for with the header — part A, as the last launch's control step left it: PH_APPLY's copy of the lists' shard starts,
+  // on its way while the header is awaited instead of in a trip of its own behind it)
+  uint32_t pre_v = 0;
+  if (threadIdx.x < 2 * (rp::kShards + 1)) pre_v = threadIdx.x <= rp::kShards ? c.chg_pre[threadIdx.x] : c.born_pre[threadIdx.x - (rp::kShards + 1)];
   const unsigned long long hdr = __hip_atomic_load(&c.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   if (rp_hdr_seq(hdr) != seq) return;
   const uint32_t phase = rp_hdr_phase(hdr);
@@ -1219,7 +1234,9 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   if (threadIdx.x == 0) {
     g_rp_collect = collect ? 1u : 0u;
     if (collect) s_u.dirty.cnt = 0;
+    g_rp_pre_born = c.born_pre;
   }
+  if (threadIdx.x < 2 * (rp::kShards + 1)) g_rp_pre[threadIdx.x] = pre_v;
   __syncthreads();
   if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
     rp_scan_phase(a, sc, n, phase);
@@ -1294,17 +1311,22 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   // first num_buckets + 1 entries of the five per-queue arrays.  (Until round 6 all of it, statistics and — once the counters
   // had a line each — padding included: 725 words read with atomics and stored back; a launch pays ~1 us per 128 of them.)
   // The statistics are not loaded: zeros in the LDS copy, and what the step counted is ADDED to the block afterwards.
-  constexpr uint32_t kA = offsetof(rp::Ctl, error) / 4, kB = 6 + 2 * 7 + rp::kTgtShards;
+  constexpr uint32_t kL = 5, kB = 6 + 2 * kL + rp::kTgtShards + 2 * rp::kShards;
+  constexpr uint32_t kA = offsetof(rp::Ctl, error) / 4;
   const uint32_t nq = (uint32_t)a.c.num_buckets + 1u, n_copy = kA + kB + 5u * nq;
   const auto ctl_word = [&](uint32_t i) -> uint32_t {
     if (i < kA) return i;
     i -= kA;
     if (i < 6) return (uint32_t)(offsetof(rp::Ctl, error) / 4) + i;   // error, k_limit, first_change, smax_cut
     if (i < kB) {
-      constexpr uint32_t line[7] = {offsetof(rp::Ctl, n_tgt) / 4, offsetof(rp::Ctl, n_dirty) / 4, offsetof(rp::Ctl, n_chg) / 4, offsetof(rp::Ctl, n_born) / 4,
-                                    offsetof(rp::Ctl, n_sd) / 4,  offsetof(rp::Ctl, n_cp) / 4,    offsetof(rp::Ctl, arrive) / 4};
-      if (i < 6 + 2 * 7) return line[(i - 6) >> 1] + ((i - 6) & 1u);
-      return (uint32_t)(offsetof(rp::Ctl, tgt_n) / 4) + (i - (6 + 2 * 7)) * (uint32_t)(sizeof(rp::CtlLine) / 4);
+      constexpr uint32_t line[kL] = {offsetof(rp::Ctl, n_tgt) / 4, offsetof(rp::Ctl, n_dirty) / 4, offsetof(rp::Ctl, n_sd) / 4, offsetof(rp::Ctl, n_cp) / 4, offsetof(rp::Ctl, arrive) / 4};
+      constexpr uint32_t kW = sizeof(rp::CtlLine) / 4;
+      if (i < 6 + 2 * kL) return line[(i - 6) >> 1] + ((i - 6) & 1u);
+      i -= 6 + 2 * kL;
+      if (i < rp::kTgtShards) return (uint32_t)(offsetof(rp::Ctl, tgt_n) / 4) + i * kW;
+      i -= rp::kTgtShards;
+      if (i < rp::kShards) return (uint32_t)(offsetof(rp::Ctl, chg_n) / 4) + i * kW;
+      return (uint32_t)(offsetof(rp::Ctl, born_n) / 4) + (i - rp::kShards) * kW;
     }
     i -= kB;
     return (uint32_t)(offsetof(rp::Ctl, head) / 4) + (i / nq) * (rp::kMaxBuckets + 1) + i % nq;
