@@ -83,7 +83,7 @@ enum Phase : uint32_t {
 // A SCAN phase is collective and lives outside this file: for i = 0 .. n_threads - 1 in order, c = rp_scan_count(i),
 // rp_scan_apply(i, running sums), running sums += c; the totals go to Ctl::scan_tot.
 #ifndef RP_SCANC
-#define RP_SCANC 8
+#define RP_SCANC 16
 #endif
 constexpr int kScanC = RP_SCANC;   // components a SCAN phase carries per item: bucket FIFOs filled by one PH_PUSH pass (four until round 5)
 struct Cnt4 { uint32_t v[kScanC]; };

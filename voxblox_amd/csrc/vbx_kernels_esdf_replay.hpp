@@ -949,7 +949,7 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
   __shared__ uint32_t s_wave[kRpThreads / 64][rp::kScanC];
   __shared__ uint32_t s_prefix[rp::kScanC];
   constexpr int kWaves = kRpThreads / 64;
-  static_assert(rp::kScanC <= 2 * kWaves, "a wave looks back for two components");
+  constexpr int kPerWave = (rp::kScanC + kWaves - 1) / kWaves;   // components a wave publishes and looks back for
   const uint32_t tiles = (n + kRpThreads - 1) / kRpThreads;
   if (tiles > sc.max_tiles) {   // more tiles than descriptors: fail loudly instead of indexing past the buffer
     if (threadIdx.x == 0) atomicOr(err, 64u);
@@ -988,8 +988,10 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
       }
     }
     __syncthreads();
-    // the components this wave publishes and looks back for: wave and wave + kWaves
-    uint32_t agg0 = 0, agg1 = 0;
+    // the components this wave publishes and looks back for: wave, wave + kWaves, ...
+    uint32_t agg[kPerWave];
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) agg[j] = 0;
 #pragma unroll
     for (int k = 0; k < (int)rp::kScanC; ++k) {
       if (k < nc) {
@@ -1001,24 +1003,24 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
           total += x;
         }
         ex.v[k] += before;
-        if (k == wave) agg0 = total;
-        if (k == wave + kWaves) agg1 = total;
+        if (k % kWaves == wave) agg[k / kWaves] = total;   // (k / kWaves is a constant of the unrolled loop)
       }
     }
     const unsigned long long sk3 = wall_clock64();
     // publish the aggregates, look back 64 predecessors at a time (a tile's wait is for aggregates only, which every tile
-    // publishes before it looks back — no chain of waits through the tiles)
-    const int k0 = wave, k1 = wave + kWaves;
-    const bool on0 = k0 < nc, on1 = k1 < nc;
+    // publishes before it looks back — no chain of waits through the tiles); the wave's components look back together
     const unsigned long long tag_agg = (unsigned long long)((gen << 2) | (tile == 0 ? 2u : 1u)) << 32, tag_inc = (unsigned long long)((gen << 2) | 2u) << 32;
-    if (lane == 0) {
-      if (on0) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k0, tag_agg | agg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (on1) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k1, tag_agg | agg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prefix[kPerWave], left[kPerWave];   // tiles [0, left) are still to be summed
+#pragma unroll
+    for (int j = 0; j < kPerWave; ++j) {
+      const int k = wave + j * kWaves;
+      prefix[j] = 0;
+      left[j] = k < nc ? tile : 0u;
+      if (lane == 0 && k < nc) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k, tag_agg | agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    uint32_t prefix0 = 0, prefix1 = 0, t0 = on0 ? tile : 0u, t1 = on1 ? tile : 0u;   // tiles [0, t) are still to be summed
     uint32_t spins = 0;
     // one window of one component: true when it was summed (t moves on, or to 0 behind an inclusive prefix)
-    const auto window = [&](unsigned long long w, uint32_t& t, uint32_t& prefix) -> bool {
+    const auto window = [&](unsigned long long w, uint32_t& t, uint32_t& pre) -> bool {
       const bool mine = (uint32_t)lane < t;
       const uint32_t tag = (uint32_t)(w >> 32);
       const bool ready = mine && (tag >> 2) == gen && (tag & 3u) != 0u;
@@ -1028,32 +1030,40 @@ __device__ inline void rp_scan_tiles(const F& f, const RpScan& sc, uint32_t n, u
       const int stop = m_incl ? (__ffsll((long long)m_incl) - 1) : 63;
       const unsigned long long need = (stop == 63 ? ~0ull : ((2ull << stop) - 1ull)) & m_mine;
       if ((m_ready & need) != need) return false;
-      prefix += rl_u32(rp_wave_scan_add(((need >> lane) & 1ull) ? (uint32_t)w : 0u), 63);
+      pre += rl_u32(rp_wave_scan_add(((need >> lane) & 1ull) ? (uint32_t)w : 0u), 63);
       t = m_incl ? 0u : t - (uint32_t)__popcll(m_mine);
       return true;
     };
-    while (t0 > 0 || t1 > 0) {
-      unsigned long long w0 = 0, w1 = 0;
-      if ((uint32_t)lane < t0) w0 = __hip_atomic_load(sc.desc + (size_t)(t0 - 1 - lane) * rp::kScanC + k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)lane < t1) w1 = __hip_atomic_load(sc.desc + (size_t)(t1 - 1 - lane) * rp::kScanC + k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < kPerWave; ++j) any = any || left[j] > 0;
+      if (!any) break;
+      unsigned long long w[kPerWave];
+#pragma unroll
+      for (int j = 0; j < kPerWave; ++j) {
+        w[j] = 0;
+        if ((uint32_t)lane < left[j])
+          w[j] = __hip_atomic_load(sc.desc + (size_t)(left[j] - 1 - lane) * rp::kScanC + (wave + j * kWaves), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       bool moved = false;
-      if (t0 > 0) moved = window(w0, t0, prefix0) || moved;
-      if (t1 > 0) moved = window(w1, t1, prefix1) || moved;
+#pragma unroll
+      for (int j = 0; j < kPerWave; ++j)
+        if (left[j] > 0) moved = window(w[j], left[j], prefix[j]) || moved;
       if (!moved) {
         if (++spins > kRpSpinMax) { if (lane == 0) atomicOr(err, 64u); break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
     if (lane == 0) {
-      if (on0) {
-        if (tile != 0) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k0, tag_inc | (prefix0 + agg0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_prefix[k0] = prefix0;
-        if (tile == tiles - 1) atomicExch(&tot[k0], prefix0 + agg0);
-      }
-      if (on1) {
-        if (tile != 0) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k1, tag_inc | (prefix1 + agg1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_prefix[k1] = prefix1;
-        if (tile == tiles - 1) atomicExch(&tot[k1], prefix1 + agg1);
+#pragma unroll
+      for (int j = 0; j < kPerWave; ++j) {
+        const int k = wave + j * kWaves;
+        if (k < nc) {
+          if (tile != 0) __hip_atomic_store(sc.desc + (size_t)tile * rp::kScanC + k, tag_inc | (prefix[j] + agg[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_prefix[k] = prefix[j];
+          if (tile == tiles - 1) atomicExch(&tot[k], prefix[j] + agg[j]);
+        }
       }
     }
     __syncthreads();
@@ -1081,8 +1091,9 @@ struct RpPhaseScan {
   const uint32_t* comp_of;     // LDS [256]: bucket -> component of this pass (0xFF: another pass)
   const uint32_t* comp_bucket; // LDS [kScanC]: the component's bucket,
   const uint32_t* comp_tail;   // ... that bucket's FIFO tail
-  struct State { uint32_t take, kk[3], r, gid; };
-  __device__ static uint32_t kk_get(const State& st, uint32_t lut) { return (st.kk[lut / 10] >> (3 * (lut % 10))) & 7u; }
+  struct State { uint32_t take, kk[4], r, gid; };   // kk: the component of LUT index l in bits 4 (l % 8) .. of word l / 8
+  static_assert(rp::kScanC <= 16, "four bits per component");
+  __device__ static uint32_t kk_get(const State& st, uint32_t lut) { return (st.kk[lut / 8] >> (4 * (lut % 8))) & 15u; }
   __device__ rp::Cnt4 count(uint32_t i, State& st) const {
     const rp::Ctl& c = *a.ctl;
     rp::Cnt4 n{};
@@ -1112,7 +1123,7 @@ struct RpPhaseScan {
         if (comp == 0xFFu) continue;
         const uint32_t lut = (uint32_t)k * 4 + j;
         cand |= 1u << lut;
-        st.kk[lut / 10] |= comp << (3 * (lut % 10));
+        st.kk[lut / 8] |= comp << (4 * (lut % 8));
       }
     }
     // an entry that was popped inside this super-step is not queued: four candidates' children per trip
@@ -1335,9 +1346,17 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   {
     uint32_t* src = reinterpret_cast<uint32_t*>(a.ctl);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_ctl);
-    for (uint32_t i = threadIdx.x; i < n_copy; i += kRpThreads) {   // (one pass: n_copy <= 256 with the reference's 20 buckets)
-      const uint32_t w = ctl_word(i);
-      dst[w] = atomicAdd(&src[w], 0u);
+    for (uint32_t i0 = 0; i0 < n_copy; i0 += 2 * kRpThreads) {   // (one trip: n_copy <= 512 with the reference's 20 buckets)
+      uint32_t v[2], wv[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const uint32_t i = i0 + k * kRpThreads + threadIdx.x;
+        wv[k] = ctl_word(i < n_copy ? i : 0u);
+        v[k] = i < n_copy ? atomicAdd(&src[wv[k]], 0u) : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (i0 + k * kRpThreads + threadIdx.x < n_copy) dst[wv[k]] = v[k];
     }
     unsigned long long* st = reinterpret_cast<unsigned long long*>(&s_ctl);
     for (uint32_t i = kStat0 + threadIdx.x; i < kStat1; i += kRpThreads) st[i] = 0ull;
