@@ -674,12 +674,15 @@ class ModelEsdf : public EsdfIntegrator {
       const uint32_t n = c.n_threads;
       if (c.phase == PH_RANK || c.phase == PH_PUSH) {
         Cnt4 run{};
-        for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t n_scan = c.phase == PH_PUSH ? c.scan_n : n;
+        for (uint32_t i = 0; i < n_scan; ++i) {
           const Cnt4 cnt = rp_scan_count(a, i);
           rp_scan_apply(a, i, run);
           for (int k = 0; k < kScanC; ++k) run.v[k] += cnt.v[k];
         }
         for (int k = 0; k < kScanC; ++k) c.scan_tot[k] = run.v[k];
+        if (c.phase == PH_PUSH && c.push_last)   // the last pass cleans up behind itself
+          for (uint32_t tid = 0; tid < n; ++tid) rp_phase_cleanup(a, tid);
       } else {
         order.resize(n);
         for (uint32_t i = 0; i < n; ++i) order[i] = i;

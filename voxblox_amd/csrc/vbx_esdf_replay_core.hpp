@@ -125,6 +125,7 @@ struct Ctl {
   uint32_t scan_tot[kScanC];
   uint32_t push_b[kScanC], push_n;                // buckets of the current PH_PUSH pass
   uint32_t push_next;                        // first bucket not yet handled by a PH_PUSH pass
+  uint32_t push_last, scan_n, ord_identity;  // 1: this PH_PUSH pass is the last and cleans up behind itself (no PH_CLEANUP launch); items of the pass's scan; 1: ord[r] = r (no dense ranking ran)
   uint32_t chunk_top;
   // (device wrapper) n_threads | phase << 32 | launch number mod 64 << 40 of the step the NEXT launch runs, stored and read
   // as one word: a workgroup the dispatcher starts after its own launch's control step already ran must not take the next
@@ -1080,7 +1081,15 @@ RP_FN void rp_phase_rank_write(const Args& a, uint32_t tid) {
   const uint32_t base = (uint32_t)(T >> kRankBits);
   a.ord[a.off0[base] + (uint32_t)(T & kRankMask)] = tid;
 }
-RP_FN void rp_phase_cleanup(const Args& a, uint32_t tid) {
+// is record r one of ord[0 .. n_commit)?  (what rp_phase_rank_write files, or the identity when no dense ranking ran)
+RP_FN bool rp_rec_committed(const Args& a, uint32_t r) {
+  const Ctl& c = *a.ctl;
+  if (c.ord_identity) return r < c.n_commit;
+  return rp_meta_live(a.rec_meta[r]) && a.rec_T[r] < c.cut;
+}
+// (skip_committed: the last PH_PUSH pass of the device cleans up in the same launch — the thread that files a committed record's
+// pushes clears that record's words itself when it has read them, everybody else's are cleared here)
+RP_FN void rp_phase_cleanup(const Args& a, uint32_t tid, bool skip_committed = false) {
   Ctl& c = *a.ctl;
   if (tid < c.a_tgt) {
     const uint32_t gid = a.tgt_gid[tid];
@@ -1089,7 +1098,7 @@ RP_FN void rp_phase_cleanup(const Args& a, uint32_t tid) {
     a.tgt_cnt[tid] = 0;
     a.tgt_dirty[tid] = 0;
   }
-  if (tid < c.n_rec) {
+  if (tid < c.n_rec && !(skip_committed && rp_rec_committed(a, tid))) {
     for (int k = 0; k < 26; ++k) a.rec_kid[(size_t)tid * 26 + k] = 0;
     for (int k = 0; k < 7; ++k) a.rec_push[tid * 7 + k] = 0;
     a.rec_poison[tid] = 0;
@@ -1195,7 +1204,16 @@ RP_FN void rp_next_push_pass(const Args& a) {
     return;
   }
   c.phase = PH_PUSH;
+  c.scan_n = c.n_commit;
   c.n_threads = c.n_commit;
+  // the last pass cleans up behind itself: one launch less per super-step
+  c.push_last = 1;
+  for (int b2 = b; b2 < nq; ++b2)
+    if (RP_LD(c.push_cnt[b2]) != 0) { c.push_last = 0; break; }
+  if (c.push_last) {
+    const uint32_t items = c.a_tgt > c.n_rec ? c.a_tgt : c.n_rec;
+    if (items > c.n_threads) c.n_threads = items;
+  }
 }
 
 RP_FN void rp_control(const Args& a) {
@@ -1297,9 +1315,11 @@ RP_FN void rp_control(const Args& a) {
         unsigned long long nb = c.cut >> kRankBits;
         c.n_commit = (c.cut == kNever || nb > c.K) ? c.K : (uint32_t)nb;
         c.push_next = 0;
+        c.ord_identity = 1;
         rp_next_push_pass(a);
         break;
       }
+      c.ord_identity = 0;
       c.phase = PH_RANK;
       c.n_threads = c.K;
       break;
@@ -1314,8 +1334,12 @@ RP_FN void rp_control(const Args& a) {
       break;
     case PH_PUSH:
       for (uint32_t k = 0; k < c.push_n; ++k) c.tail[c.push_b[k]] += RP_LD(c.scan_tot[k]);
-      rp_next_push_pass(a);
-      break;
+      if (!c.push_last) {
+        rp_next_push_pass(a);
+        break;
+      }
+      c.push_last = 0;
+      // fall through: the pass cleaned up
     case PH_CLEANUP: {
       // the committed base records leave their FIFO
       uint32_t nb = (uint32_t)(c.cut >> kRankBits);

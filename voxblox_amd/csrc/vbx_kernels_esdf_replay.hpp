@@ -1091,6 +1091,7 @@ struct RpPhaseScan {
   const uint32_t* comp_of;     // LDS [256]: bucket -> component of this pass (0xFF: another pass)
   const uint32_t* comp_bucket; // LDS [kScanC]: the component's bucket,
   const uint32_t* comp_tail;   // ... that bucket's FIFO tail
+  bool push_last;              // the pass cleans up behind itself: a record's push words, children and poison flag are cleared by the thread that has just read them
   struct State { uint32_t take, kk[4], r, gid; };   // kk: the component of LUT index l in bits 4 (l % 8) .. of word l / 8
   static_assert(rp::kScanC <= 16, "four bits per component");
   __device__ static uint32_t kk_get(const State& st, uint32_t lut) { return (st.kk[lut / 8] >> (4 * (lut % 8))) & 15u; }
@@ -1172,6 +1173,14 @@ struct RpPhaseScan {
         if ((uint32_t)k == comp) at = pos.v[k]++;
       rp::rp_queue_store(a, (int)comp_bucket[comp], comp_tail[comp] + at, rp::rp_neighbour(a, st.gid, (int)lut));
     }
+    if (push_last) {   // (rp::rp_phase_cleanup's part for this record: nobody else reads its words in this launch)
+      const uint32_t r = st.r;
+#pragma unroll
+      for (int k = 0; k < 26; ++k) a.rec_kid[(size_t)r * 26 + k] = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) a.rec_push[r * 7 + k] = 0;
+      a.rec_poison[r] = 0;
+    }
   }
 };
 __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32_t n, uint32_t phase) {
@@ -1194,7 +1203,7 @@ __device__ inline void rp_scan_phase(const rp::Args& a, const RpScan& sc, uint32
     }
     __syncthreads();
   }
-  RpPhaseScan f{a, phase, s_comp_of, s_comp_bucket, s_comp_tail};
+  RpPhaseScan f{a, phase, s_comp_of, s_comp_bucket, s_comp_tail, phase == rp::PH_PUSH && c.push_last != 0};
   rp_scan_tiles(f, sc, n, a.ctl->scan_tot, &a.ctl->error, nc, /*by_block=*/true,
                 (a.wg_stats && phase == rp::PH_PUSH && blockIdx.x < 4096u) ? a.wg_stats + (size_t)4096 * (rp::kWgStats + 32) + (size_t)blockIdx.x * 8 : nullptr);
 }
@@ -1250,7 +1259,11 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   if (threadIdx.x < 2 * (rp::kShards + 1)) g_rp_pre[threadIdx.x] = pre_v;
   __syncthreads();
   if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
-    rp_scan_phase(a, sc, n, phase);
+    rp_scan_phase(a, sc, phase == rp::PH_PUSH ? c.scan_n : n, phase);
+    if (phase == rp::PH_PUSH && c.push_last) {   // the last pass cleans up behind itself (n: the larger of the two item counts)
+      const uint32_t stride = active * kRpThreads;
+      for (uint32_t tid = blockIdx.x * kRpThreads + threadIdx.x; tid < n; tid += stride) rp::rp_phase_cleanup(a, tid, /*skip_committed=*/true);
+    }
   } else if (!SERIAL && phase == rp::PH_RAISE_FOLD) {
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
     for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves)
