@@ -142,7 +142,9 @@ def test_reference_order_reproduces_the_golden_batch_digest(oracle):
     dict(full_euclidean_distance=1),
     dict(full_euclidean_distance=1, multi_queue=1, min_diff_m=0.0),
     dict(max_distance_m=1.0, default_distance_m=1.0),
-], ids=["default", "multi_queue", "three_buckets", "one_bucket", "full_euclidean", "full_multi_min_diff0", "short_range"])
+    dict(num_buckets=100),                               # more buckets than lanes: the ranking's linked-list form, seven push passes per super-step, a control block of 670 words
+    dict(num_buckets=40, multi_queue=1),                 # three push passes, the batched ranking at 40 buckets
+], ids=["default", "multi_queue", "three_buckets", "one_bucket", "full_euclidean", "full_multi_min_diff0", "short_range", "hundred_buckets", "forty_buckets_multi"])
 def test_reference_order_variants_bit_exact_vs_oracle(oracle, esdf_kw):
     """Config variants the queue order depends on, fast integrator at 0.1 m, 5 frames, compared after every frame."""
     sc = dict(kind="fast", voxel=0.1, n=5, cfg={})
