@@ -466,7 +466,7 @@ RP_FN bool rp_offer_possible(const Args& a, float vd, uint32_t vs, uint32_t sn, 
 
 // record `r` (voxel gid, guessed pop-time state vd / vs) announces itself to the target at position p (0..25 LUT
 // neighbour, 26 the voxel itself)
-RP_FN void rp_place(const Args& a, uint32_t r, uint32_t base, uint32_t gid, uint32_t p, float vd, uint32_t vs) {
+RP_FN void rp_place(const Args& a, uint32_t r, uint32_t base_rec, uint32_t gid, uint32_t p, float vd, uint32_t vs) {
   Ctl& c = *a.ctl;
   const uint32_t ngid = p == 26 ? gid : rp_neighbour(a, gid, (int)p);
   uint32_t t = kNone;
@@ -496,7 +496,10 @@ RP_FN void rp_place(const Args& a, uint32_t r, uint32_t base, uint32_t gid, uint
     if (r < c.K) {
       atomicMin(&c.k_limit, r);
     } else {
-      // (base: the caller's — a record's own fields may still be on their way when a sibling thread gets here)
+      // (base_rec: a record whose excursion is r's and whose fields stand — r itself, or its pusher while PH_APPLY is still making
+      // r: a record's own fields may be on their way when a sibling thread gets here.  Looked up here, where it is needed: as an
+      // argument it was a trip to memory in front of every placement of a new record)
+      const uint32_t base = a.rec_base[base_rec];
       const unsigned long long T = a.rec_T[r];
       if (a.sub_restart && T != kNever && (T & kRankMask) != 0) atomicMin(&a.sub_restart[base], (uint32_t)(T & kRankMask) - 1u);
       if (atomicExch(&a.sub_dirty[base], 1u) == 0u) a.sd_list[atomicAdd(&c.n_sd, 1u)] = base;
@@ -825,7 +828,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
     }
     const uint32_t t = a.rec_tgts[(size_t)r * 27 + p];
     // (rec_d_n / rec_s_n: the new guess; thread 26 of this record is copying it over the old one right now)
-    if (t == kSkip) rp_place(a, r, a.rec_base[r], a.rec_vox[r], p, a.rec_d_n[r], a.rec_s_n[r]);   // an offer left out so far may count now
+    if (t == kSkip) rp_place(a, r, r, a.rec_vox[r], p, a.rec_d_n[r], a.rec_s_n[r]);   // an offer left out so far may count now
     else rp_mark_dirty(a, t);
     return;
   }
@@ -887,7 +890,7 @@ RP_FN void rp_phase_apply(const Args& a, uint32_t tid) {
       }
     }
   }
-  rp_place(a, r, a.rec_base[pusher], gid, p, __uint_as_float(bw[4]), bw[5]);
+  rp_place(a, r, pusher, gid, p, __uint_as_float(bw[4]), bw[5]);
 }
 
 // A ranking that moves a record's pop time changes the ORDER of the events on the targets that record talks to.  PH_APPLY
