@@ -600,6 +600,7 @@ class ModelEsdf : public EsdfIntegrator {
     Args a{};
     a.hazard = std::getenv("EOM_NO_FILTER") ? nullptr : hazard.data();
     a.c.filter = (uint32_t)g_filter_level;
+    a.c.stats = 1;   // (steps per phase: printed below)
     a.c.mark_moved = std::getenv("EOM_NO_MARK_MOVED") ? 0u : (std::getenv("EOM_MARK_MOVED") ? (uint32_t)std::atoi(std::getenv("EOM_MARK_MOVED")) : 2u);
     a.c.fold_all = std::getenv("EOM_NO_FOLD_ALL") ? 0u : 1u;
     a.c.ev = std::getenv("EOM_EV") ? (uint32_t)std::atoi(std::getenv("EOM_EV")) : 256u;

@@ -99,7 +99,7 @@ struct Cfg {
   uint32_t slot_by_base; // 1: the list of base record i's excursion is slot i + 1 (sub_slots_cap >= kmax); 0: slots are handed out as excursions appear
   uint32_t tgt_claim;    // 1: rp_target claims the voxel before it takes an id (no holes); 0: id first, a lost race leaves a hole
   uint32_t fold_all;     // 1: PH_PLACE_BASE leaves the dirty list alone, the first FOLD of a super-step takes every target; 0: round 5a's lists
-  uint32_t stats;        // (device) 1: VBX_RP_STATS — the rankings and folds keep what they cost per workgroup (Args::wg_stats)
+  uint32_t stats;        // 1: VBX_RP_STATS — steps per phase are counted and timed, the rankings and folds keep what they cost per workgroup (Args::wg_stats)
   uint32_t tgt_shards;   // target ids in PH_PLACE_BASE come from this many counters, interleaved (id = k * shards + shard; 1: one counter)
   uint32_t mark_moved;   // a ranking marks the targets of 2: the records whose order it changed, 1: every record whose pop time it moved (rp_mark_rec_targets); 0: nothing (round 4)
 };
@@ -165,6 +165,7 @@ struct Ctl {
   // control step moves).  What decides anything is not here: st_iters and t_prev are in part A.
   alignas(128) unsigned long long st_raise_pops, st_raise_steps, st_pops, st_relax, st_supersteps, st_folds, st_exc, st_cut_iters, st_cut_smax, st_steps, st_poison, st_trunc_q, st_trunc_rank, st_retries;
   unsigned long long st_phase_steps[16], st_phase_threads[16], st_phase_ticks[16];
+  unsigned long long st_ctl_ticks[4];   // (device) the control step by stage: arrival -> copy in, rp_control, copy out (10 ns units)
   unsigned long long st_bin_steps[8][8], st_bin_ticks[8][8];   // (device) launches of FOLD / APPLY / SIM / PLACE / PUSH / COMMIT_FOLD / CLEANUP / RAISE_FOLD by items: < 4, < 16, < 64, < 256, < 1 Ki, < 4 Ki, < 16 Ki, more
 };
 
@@ -1221,9 +1222,11 @@ RP_FN void rp_next_push_pass(const Args& a) {
 
 RP_FN void rp_control(const Args& a) {
   Ctl& c = *a.ctl;
-  ++c.st_steps;
-  ++c.st_phase_steps[c.phase & 15];
-  c.st_phase_threads[c.phase & 15] += c.n_threads;
+  if (a.c.stats) {   // (per-step diagnostics: three read-modify-writes of the control block per step otherwise — 0.2 us of every launch)
+    ++c.st_steps;
+    ++c.st_phase_steps[c.phase & 15];
+    c.st_phase_threads[c.phase & 15] += c.n_threads;
+  }
   if (RP_LD(c.error)) { rp_stop(c); return; }
   switch (c.phase) {
     case PH_BEGIN:

@@ -639,6 +639,8 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
             hc.st_pops, hc.st_relax, hc.st_supersteps, hc.st_iters, hc.st_folds, hc.st_exc, hc.st_cut_iters, hc.st_cut_smax, hc.st_steps,
             hc.st_poison, hc.error);
     for (int k = 1; k < 13; ++k) fprintf(stderr, " %s %llu(%llu, %.2f ms)", names[k], hc.st_phase_steps[k], hc.st_phase_threads[k], hc.st_phase_ticks[k] * 1e-5);
+    fprintf(stderr, "\n[rp] control step, us per step: copy in %.2f, statistics %.2f, rp_control %.2f", hc.st_steps ? hc.st_ctl_ticks[0] * 0.01 / hc.st_steps : 0.0,
+            hc.st_steps ? hc.st_ctl_ticks[2] * 0.01 / hc.st_steps : 0.0, hc.st_steps ? hc.st_ctl_ticks[1] * 0.01 / hc.st_steps : 0.0);
     {
       static const char* rows[] = {"fold", "apply", "sim", "place", "push", "cfold", "cleanup", "raise"};
       for (int r = 0; r < 8; ++r) {

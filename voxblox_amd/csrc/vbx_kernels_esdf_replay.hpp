@@ -1314,7 +1314,9 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
     // the last workgroup to arrive runs the control step.  More than 64 of them arrive in two levels (Ctl::arrive_sub): a line
     // takes ~87 arrivals per microsecond
     uint32_t last;
-    if (active <= 64u) {
+    if (active == 1u) {
+      last = 1u;   // (the only workgroup with work need not ask whether it is the last one)
+    } else if (active <= 64u) {
       last = atomicAdd(&c.arrive, 1u) == active - 1 ? 1u : 0u;
     } else {
       const uint32_t sub = blockIdx.x & (rp::kArriveSubs - 1);
@@ -1329,6 +1331,7 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   }
   __syncthreads();
   if (!s_last) return;
+  const unsigned long long t_arrive = a.c.stats ? wall_clock64() : 0ull;
   __syncthreads();   // (everybody is done with the phase's part of the shared region)
   rp::Ctl& s_ctl = s_u.ctl;
   // What the control step needs of the block, a word per thread and ONE trip: part A, the words in use of part B's lines, the
@@ -1390,8 +1393,8 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
   }
   if (threadIdx.x == 0) {
     s_ctl.arrive = 0;
-    const unsigned long long now = wall_clock64();   // 100 MHz
-    if (s_ctl.t_prev) {
+    const unsigned long long now = a.c.stats ? wall_clock64() : 0ull;   // 100 MHz
+    if (a.c.stats && s_ctl.t_prev) {
       s_ctl.st_phase_ticks[phase & 15] += now - s_ctl.t_prev;
       const int row = phase == rp::PH_FOLD ? 0 : phase == rp::PH_APPLY ? 1 : phase == rp::PH_SIM ? 2 : phase == rp::PH_PLACE_BASE ? 3 : phase == rp::PH_PUSH ? 4 : phase == rp::PH_COMMIT_FOLD ? 5 : phase == rp::PH_CLEANUP ? 6 : phase == rp::PH_RAISE_FOLD ? 7 : -1;
       if (row >= 0) {
@@ -1401,14 +1404,21 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
         s_ctl.st_bin_ticks[row][bin] += now - s_ctl.t_prev;
       }
     }
-    s_ctl.t_prev = now;
+    if (a.c.stats) s_ctl.t_prev = now;
     if (phase == rp::PH_RANK || phase == rp::PH_PUSH) {
       sc.ticket[0] = 0;
       sc.ticket[1] = sc.ticket[1] + 1;
     }
     rp::Args a2 = a;
     a2.ctl = &s_ctl;
+    const unsigned long long tc0 = a.c.stats ? wall_clock64() : 0ull;
     rp::rp_control(a2);
+    if (a.c.stats) {
+      const unsigned long long tc1 = wall_clock64();
+      s_ctl.st_ctl_ticks[0] += now - t_arrive;   // arrival of the last workgroup -> copy in done
+      s_ctl.st_ctl_ticks[1] += tc1 - tc0;        // rp_control
+      s_ctl.st_ctl_ticks[2] += tc0 - now;        // statistics in front of it
+    }
     s_ctl.hdr = rp_hdr(seq + 1, s_ctl.phase, s_ctl.n_threads);
   }
   __syncthreads();
