@@ -101,7 +101,7 @@ typedef struct vbx_esdf_cfg {
    * depends on an implementation detail): the reference's OWN result — updateFromTsdfBlocks' voxel walk, the FIFO raise
    * queue, BucketQueue pop order with num_buckets / multi_queue, min_diff_m gating, updateVoxelFromNeighbors incl. its
    * unscaled LUT distance, the sign-mismatch rule as written (esdf_integrator.cc:124-530, bucket_queue.h:41-80) — replayed
-   * in parallel, thousands of pops at a time, with the reference's bits as the result (~26 ms per update on
+   * in parallel, thousands of pops at a time, with the reference's bits as the result (~25.5 ms per update on
    * the 640x480 / 0.05 m stream where the reference build needs ~77 ms on one core of the same box).  The blocks are
    * visited in the order of the list given to vbx_esdf_update_blocks; vbx_esdf_update visits them in the iteration order
    * the reference's Layer would have (Layer::getAllUpdatedBlocks over its unordered_map, layer.h:194-203): the library
