@@ -526,7 +526,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.c.num_buckets = cfg->num_buckets;
   a.c.kmax = ctx->rp_kmax;
   a.c.smax = ctx->rp_smax;
-  a.c.max_iters = rp_env_u32("VBX_RP_MAX_ITERS", 64);
+  a.c.max_iters = rp_env_u32("VBX_RP_MAX_ITERS", 128);
   a.ctl = ctx->rp_ctl.as<rp::Ctl>();
   a.push_shards = reinterpret_cast<uint32_t*>(a.ctl + 1);
   a.dist = e.dist;
