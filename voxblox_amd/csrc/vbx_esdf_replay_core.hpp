@@ -53,7 +53,7 @@ constexpr uint32_t kTgtShards = 8;      // most counters PH_PLACE_BASE hands tar
 constexpr uint32_t kSkip = 0xFFFFFFFEu;     // rec_tgts: the neighbour exists but the record's offer cannot change it (as the record stands)
 constexpr int kMaxBuckets = 255;
 #ifndef RP_EVQ
-#define RP_EVQ 4
+#define RP_EVQ 8
 #endif
 constexpr uint32_t kEvQ = RP_EVQ;          // events of a target one lane of the wave-per-target fold holds
 constexpr uint32_t kEvMax = 64 * kEvQ;     // most events a target can hold (Cfg::ev <= this: the capacity in use, and the stride of tgt_ev)
