@@ -786,7 +786,10 @@ int vbx_clear(vbx_ctx* ctx, int layer) {
     int rc = sync_state(ctx);
     if (rc) return rc;
     const uint32_t used = ctx->h_state.pool_used;
-    if (layer == VBX_LAYER_ESDF) ctx->esdf_robot_forget();  // (queue entries name voxels of the layer that goes)
+    if (layer == VBX_LAYER_ESDF) {
+      ctx->esdf_robot_forget();  // (queue entries name voxels of the layer that goes)
+      ctx->rp_walked_total = 0;
+    }
     if (layer == VBX_LAYER_TSDF) {   // block_map_.clear() (layer.h:168): the keys go, the bucket array stays
       ctx->published_since_clear = 0;
       rc = discard_new_blocks(ctx);

@@ -526,7 +526,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.c.num_buckets = cfg->num_buckets;
   a.c.kmax = ctx->rp_kmax;
   a.c.smax = ctx->rp_smax;
-  a.c.max_iters = rp_env_u32("VBX_RP_MAX_ITERS", 128);
+  a.c.max_iters = rp_env_u32("VBX_RP_MAX_ITERS", ctx->rp_bulk ? 64 : 128);   // (vbx_ctx::rp_bulk)
   a.ctl = ctx->rp_ctl.as<rp::Ctl>();
   a.push_shards = reinterpret_cast<uint32_t*>(a.ctl + 1);
   a.dist = e.dist;
@@ -882,6 +882,8 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
                           n_seed / kSqChunk + (size_t)NB + 2;
   HIP_TRY(ctx->b_keys0.ensure(n_chunks * kSqChunk * 4));
   HIP_TRY(ctx->b_vals0.ensure(64));
+  ctx->rp_bulk = batch || n > ctx->rp_walked_total;
+  ctx->rp_walked_total += n;
   const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0 && cfg->num_buckets <= 254;   // (a push table entry is one byte: bucket + 1, raise_ = num_buckets)
   rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used, n);
   if (rc) return rc;
