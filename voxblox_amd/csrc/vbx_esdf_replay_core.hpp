@@ -92,6 +92,7 @@ struct Cfg {
   float max_distance, min_diff, voxel_size, default_distance;
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
+  uint32_t fold_pairs;   // (device) fold launches over more targets than waves take lists of up to 32 events two at a time, a half-wave each (VBX_RP_FOLD_PAIRS; off in bulk updates)
   uint32_t ev;       // events a target can hold (<= kEvMax); a record whose event does not fit is poisoned and the super-step ends in front of it
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
   uint32_t lds_counts;   // (device) 1: COMMIT_FOLD / RAISE_FOLD count pushes and relaxations per workgroup in LDS, one atomic per queue and workgroup

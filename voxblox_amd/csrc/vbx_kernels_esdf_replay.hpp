@@ -385,6 +385,183 @@ __device__ inline void rp_fold_wave(const rp::Args& a, uint32_t t, unsigned long
   }
 }
 
+// rp_fold_wave for TWO targets at once, a half-wave each (round 6, last session).  A launch over more than 4,096 targets gives
+// every wave several folds in a row, and a fold is latency — five microseconds of dependent trips and LDS round trips with a
+// handful of events in 64 lanes (a steady update's lists hold six on average) — so such a launch lasts folds-per-wave times
+// that.  Lists of up to 32 events are folded in pairs: lanes 0-31 hold the events of one target, lanes 32-63 of the other, one
+// event per lane; ballots are taken apart per half, broadcasts go through ds_bpermute (the source lane is always a lane of the
+// reader's own half, and a half's lanes leave every loop together: its trip counts are half-uniform), each half has half of the
+// wave's scratch.  Same steps, same results; a pair with a longer list goes through rp_fold_wave one target after the other.
+// (act: this half has a target; t, gid, n_all: half-uniform)
+__device__ inline uint32_t rp_hshfl(uint32_t x, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)x); }
+template <int G>   // lanes per target: 32 (two targets per wave) or 16 (four)
+__device__ inline void rp_fold_pair(const rp::Args& a, uint32_t t, uint32_t gid, uint32_t n_all, bool act, unsigned long long limit, bool commit, int lane,
+                                    uint32_t* ws_wave, uint32_t* push_acc, uint32_t* relax_acc) {
+  using namespace rp;
+  Ctl& c = *a.ctl;
+  constexpr uint32_t kGm = G == 32 ? 0xFFFFFFFFu : (1u << (G & 31)) - 1u;
+  const uint32_t h = (uint32_t)lane / G, hl = (uint32_t)lane % G, hb = h * G;
+  uint32_t* ws = ws_wave + h * (kFoldLdsWords / (64 / G));
+  act = act && gid != kNone;
+  if (!act) n_all = 0;
+  const int b = (int)c.bucket;
+  const float d0 = act ? a.dist[gid] : 0.f;
+  const uint32_t s0 = act ? a.state[gid] : 0u;
+  uint32_t code = 0, es = 0, emeta = 0;
+  unsigned long long eT = kNever;
+  float ed = 0.f;
+  bool valid = false, epoison = false;
+  const bool have = hl < n_all;
+  if (have) {
+    code = a.tgt_ev[(size_t)t * a.c.ev + hl];
+    const uint32_t r = code >> 5;
+    emeta = a.rec_meta[r];
+    eT = a.rec_T[r];
+    epoison = a.rec_poison[r] != 0u;
+    ed = a.rec_d[r];
+    es = a.rec_s[r];
+    valid = rp_meta_live(emeta) && !epoison && eT < limit;
+  }
+  // rank among the half's valid events (pop times of valid events are distinct; (base record, rank) fits 32 bits: a rank stays below kSimMax)
+  const uint32_t key = (uint32_t)((eT >> kRankBits) << 11) | (uint32_t)(eT & 0x7FFull);
+  const uint32_t vmask = (uint32_t)(__ballot(valid) >> hb) & kGm;
+  const uint32_t n = (uint32_t)__popc(vmask);
+  uint32_t rank = 0;
+  for (uint32_t m = vmask; m; m &= m - 1u) {
+    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+    rank += rp_hshfl(key, hb + k) < key ? 1u : 0u;
+  }
+  if (valid) {
+    uint32_t* w = ws + 4u * rank;
+    w[0] = code; w[1] = __float_as_uint(ed); w[2] = es; w[3] = 0u;
+  }
+  rp_wave_sync();
+  float d = d0;
+  uint32_t s = s0;
+  const bool usable = (s0 & kObserved) && !(s0 & kFixed);
+  uint32_t relax = 0;
+  uint32_t lp_rec = kNone, lp_lb = 0, lp_s = 0;   // pushes below b seen in this fold: the j-th lives in lane j of the half
+  float lp_d = 0.f;
+  uint32_t n_lp = 0;
+  {
+    uint32_t mcode = 0, ms = 0;
+    float md = 0.f;
+    if (hl < n) {
+      const uint32_t* w = ws + 4u * hl;
+      mcode = w[0]; md = __uint_as_float(w[1]); ms = w[2];
+    }
+    const uint32_t mlut = mcode & 31u;
+    const bool is_pop = mlut == kOwn;
+    const bool dead = !is_pop && (!(ms & kObserved) || md >= a.c.max_distance || md <= -a.c.max_distance || !usable);
+    uint32_t cur = 0;
+    for (;;) {
+      bool chg = false;
+      float nd = 0.f;
+      uint32_t np = 0;
+      if (hl >= cur && hl < n) {
+        if (is_pop) chg = true;
+        else if (!dead) chg = rp_relax(a.c, md, ms, d, (int)mlut, &nd, &np);
+      }
+      const uint32_t cm = (uint32_t)(__ballot(chg) >> hb) & kGm;
+      if (!cm) break;
+      const uint32_t f = (uint32_t)__ffs((int)cm) - 1u;   // events cur .. f - 1 leave the state as it is
+      cur = f + 1u;
+      const uint32_t fcode = rp_hshfl(mcode, hb + f);
+      const uint32_t fndb = rp_hshfl(__float_as_uint(nd), hb + f), fnp = rp_hshfl(np, hb + f);
+      const uint32_t evdb = rp_hshfl(__float_as_uint(md), hb + f), evs = rp_hshfl(ms, hb + f);
+      const uint32_t r = fcode >> 5, lut = fcode & 31u;
+      if (lut == kOwn) {
+        if (!commit && hl == 0) {
+          a.rec_d_n[r] = d;
+          a.rec_s_n[r] = s;
+          if (__float_as_uint(d) != evdb || s != evs) ws[4u * f + 3u] = 1u;
+        }
+        s &= ~kInQueue;
+        continue;
+      }
+      const float fnd = __uint_as_float(fndb);
+      ++relax;
+      d = fnd;
+      s = (s & 0xFFu) | fnp;
+      if (a.c.multi_queue || !(s & kInQueue)) {
+        s |= kInQueue;
+        const int nb = rp_bucket_of(a.c, fnd);
+        if (commit) {
+          if (hl == 0) {
+            const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
+            atomicOr(&a.rec_push[w], (uint32_t)(nb + 1) << sh);
+            atomicAdd(push_acc ? &push_acc[nb] : &c.push_cnt[nb], 1u);
+          }
+        } else if (nb < b) {
+          // (a list of at most G events makes at most G pushes: there is a lane for every one of them)
+          if (hl == n_lp) { lp_rec = r; lp_lb = lut | ((uint32_t)nb << 8); lp_d = d; lp_s = s; }
+          ++n_lp;
+        }
+      }
+    }
+  }
+  if (commit) {
+    if (hl == 0 && act) {
+      if (d != d0 || s != s0) {
+        a.dist[gid] = d;
+        a.state[gid] = s;
+        rp::rp_mark_block(a, gid);
+      }
+      if (relax) {
+        if (relax_acc) *relax_acc += relax;
+        else atomicAdd(&c.st_relax, (unsigned long long)relax);
+      }
+    }
+    return;
+  }
+  rp_wave_sync();   // (lane 0's moved flags)
+  const bool own = have && (code & 31u) == kOwn && !epoison;
+  const bool pop_moved = (valid && (code & 31u) == kOwn) ? ws[4u * rank + 3u] != 0u : false;
+  bool chg = false, found = false;
+  uint32_t fbucket = rp_meta_bucket(emeta);
+  uint32_t pusher = kNone;
+  if (own) pusher = a.rec_pusher[code >> 5];
+  uint32_t matched = 0;   // push j was matched by a record of mine
+  for (uint32_t j = 0; j < n_lp; ++j) {
+    const uint32_t lr = rp_hshfl(lp_rec, hb + j), llb = rp_hshfl(lp_lb, hb + j);
+    if (own && pusher != kNone && lr == pusher && (llb & 0xFF) == rp_meta_lut(emeta)) {
+      found = true; fbucket = llb >> 8; matched |= 1u << j;
+    }
+  }
+  if (own) {
+    const uint32_t r = code >> 5;
+    uint32_t mn = emeta;
+    if (pusher != kNone) {
+      mn = rp_meta(rp_meta_lut(emeta), fbucket, found) | (emeta & (1u << 18));
+      if (mn != emeta) chg = true;
+    }
+    if (rp_meta_live(emeta) && eT != kNever) {
+      if (pop_moved) chg = true;
+    } else {
+      a.rec_d_n[r] = ed;
+      a.rec_s_n[r] = es;
+    }
+    a.rec_meta_n[r] = mn;
+    if (chg) rp_chg_push(a, r);
+  }
+  uint32_t any_matched = 0;
+  for (uint32_t j = 0; j < n_lp; ++j)
+    if ((uint32_t)(__ballot((matched >> j) & 1u) >> hb) & kGm) any_matched |= 1u << j;
+  if (hl < n_lp && !((any_matched >> hl) & 1u)) {
+    if (a.rec_kid[(size_t)lp_rec * 26 + (lp_lb & 0xFF)] == 0u) {
+      uint32_t* bw = rp_born_slot(a, lp_rec);
+      if (bw) {
+        bw[0] = lp_rec;
+        bw[1] = lp_lb & 0xFF;
+        bw[2] = lp_lb >> 8;
+        bw[3] = gid;
+        bw[4] = __float_as_uint(lp_d);
+        bw[5] = lp_s;
+      }
+    }
+  }
+}
+
 // rp_fold_raise as one wave per target (same layout as rp_fold_wave)
 __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lane, uint32_t* push_acc = nullptr) {
   using namespace rp;
@@ -451,6 +628,57 @@ __device__ inline void rp_fold_raise_wave(const rp::Args& a, uint32_t t, int lan
     }
   }
   if (lane == 0 && (d != d0 || s != s0)) {
+    a.dist[gid] = d;
+    a.state[gid] = s;
+    rp::rp_mark_block(a, gid);
+  }
+}
+
+// rp_fold_raise_wave for two targets at once, a half-wave each (lists of up to G events; see rp_fold_pair)
+template <int G>
+__device__ inline void rp_fold_raise_pair(const rp::Args& a, uint32_t t, uint32_t gid, uint32_t n_all, bool act, int lane, uint32_t* push_acc) {
+  using namespace rp;
+  Ctl& c = *a.ctl;
+  constexpr uint32_t kGm = G == 32 ? 0xFFFFFFFFu : (1u << (G & 31)) - 1u;
+  const uint32_t h = (uint32_t)lane / G, hl = (uint32_t)lane % G, hb = h * G;
+  act = act && gid != kNone;
+  if (!act) n_all = 0;
+  uint32_t code = 0;
+  unsigned long long eT = kNever;
+  bool valid = false;
+  if (hl < n_all) {
+    code = a.tgt_ev[(size_t)t * a.c.ev + hl];
+    eT = a.rec_T[code >> 5];
+    valid = (code & 31) != kOwn && eT < c.cut;
+  }
+  const float d0 = act ? a.dist[gid] : 0.f;
+  const uint32_t s0 = act ? a.state[gid] : 0u;
+  const uint32_t key = (uint32_t)((eT >> kRankBits) << 11) | (uint32_t)(eT & 0x7FFull);
+  const uint32_t vmask = (uint32_t)(__ballot(valid) >> hb) & kGm;
+  const uint32_t n = (uint32_t)__popc(vmask);
+  uint32_t rank = 0;
+  for (uint32_t m = vmask; m; m &= m - 1u) {
+    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+    rank += rp_hshfl(key, hb + k) < key ? 1u : 0u;
+  }
+  float d = d0;
+  uint32_t s = s0;
+  const int RQ = a.c.num_buckets;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t m = (uint32_t)(__ballot(valid && rank == i) >> hb) & kGm;
+    if (!m) break;
+    const uint32_t ecode = rp_hshfl(code, hb + (uint32_t)__ffs((int)m) - 1u);
+    const uint32_t r = ecode >> 5, lut = ecode & 31;
+    bool to_raise;
+    if (!rp_raise_event(a.c, &d, &s, (int)lut, &to_raise)) continue;
+    if (hl == 0) {
+      const int q = to_raise ? RQ : rp_bucket_of(a.c, d);
+      const uint32_t w = r * 7 + lut / 4, sh = (lut % 4) * 8;
+      atomicOr(&a.rec_push[w], (uint32_t)(q + 1) << sh);
+      atomicAdd(push_acc ? &push_acc[q] : &c.push_cnt[q], 1u);
+    }
+  }
+  if (hl == 0 && act && (d != d0 || s != s0)) {
     a.dist[gid] = d;
     a.state[gid] = s;
     rp::rp_mark_block(a, gid);
@@ -1264,10 +1492,78 @@ __global__ void __launch_bounds__(kRpThreads) k_rp_step(rp::Args a, RpScan sc, u
       const uint32_t stride = active * kRpThreads;
       for (uint32_t tid = blockIdx.x * kRpThreads + threadIdx.x; tid < n; tid += stride) rp::rp_phase_cleanup(a, tid, /*skip_committed=*/true);
     }
+  } else if (!SERIAL && phase == rp::PH_RAISE_FOLD && a.c.fold_pairs && n > gridDim.x * (kRpThreads / 64) && n <= gridDim.x * (kRpThreads / 64) * 128u) {
+    // (more targets than waves: two at a time, as in PH_FOLD below)
+    const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
+    const int lane = threadIdx.x & 63;
+    uint32_t def_p = 0, n_def = 0;
+    for (uint32_t p = blockIdx.x * (kRpThreads / 64) + wave; 2u * p < n; p += waves) {
+      const uint32_t w = 2u * p + ((uint32_t)lane >> 5);
+      const bool act = w < n;
+      const uint32_t gid = act ? a.tgt_gid[w] : rp::kNone;
+      uint32_t cnt = act ? a.tgt_cnt[w] : 0u;
+      if (cnt > a.c.ev) cnt = a.c.ev;
+      if (__ballot(act && gid != rp::kNone && cnt > 32u)) {
+        if ((uint32_t)lane == n_def) def_p = p;
+        ++n_def;
+        continue;
+      }
+      rp_fold_raise_pair<32>(a, w, gid, cnt, act, lane, lds_counts ? s_push : nullptr);
+    }
+    for (uint32_t i = 0; i < 2u * n_def; ++i) {
+      const uint32_t w = 2u * rl_u32(def_p, (int)(i >> 1)) + (i & 1u);
+      if (w < n) rp_fold_raise_wave(a, w, lane, lds_counts ? s_push : nullptr);
+    }
   } else if (!SERIAL && phase == rp::PH_RAISE_FOLD) {
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
     for (uint32_t w = blockIdx.x * (kRpThreads / 64) + wave; w < n; w += waves)
       rp_fold_raise_wave(a, w, threadIdx.x & 63, lds_counts ? s_push : nullptr);
+  } else if (!SERIAL && (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD) && a.c.fold_pairs && n > gridDim.x * (kRpThreads / 64) &&
+             n <= gridDim.x * (kRpThreads / 64) * 128u) {
+    // more targets than waves: lists of up to 32 events are folded two at a time, a half-wave each (rp_fold_pair).  A pair
+    // with a longer list is noted (the i-th such pair in lane i: a wave sees at most 64 pairs) and folded afterwards, one
+    // target after the other with the whole wave — apart from the pairs' loop, so that rp_fold_wave's registers are not held
+    // on top of it.  (Four targets per wave, 16 lanes and events each, were measured too: too many lists are longer, the
+    // groups folded singly after all cost what the quads gain.)
+    const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
+    const int lane = threadIdx.x & 63;
+    const bool is_fold = phase == rp::PH_FOLD;
+    const uint32_t* dl = (is_fold && !c.fold_all) ? a.dl[c.read] : nullptr;
+    constexpr uint32_t per = 2u, gl = 32u;   // targets per wave at a time, lanes (= most events) per target
+    uint32_t relax = 0, def_p = 0, n_def = 0;
+    {
+      const uint32_t h = (uint32_t)lane / gl;
+      const unsigned long long limit = is_fold ? rp::kNever : c.cut;
+      for (uint32_t p = blockIdx.x * (kRpThreads / 64) + wave; per * p < n; p += waves) {
+        const uint32_t w = per * p + h;
+        const bool act = w < n;
+        const uint32_t t = act ? (dl ? dl[w] : w) : 0u;
+        const uint32_t gid = act ? a.tgt_gid[t] : rp::kNone;
+        uint32_t cnt = act ? a.tgt_cnt[t] : 0u;
+        if (cnt > a.c.ev) cnt = a.c.ev;
+        if (__ballot(act && gid != rp::kNone && cnt > gl)) {
+          if ((uint32_t)lane == n_def) def_p = p;
+          ++n_def;
+          continue;
+        }
+        if (is_fold && act && (uint32_t)lane % gl == 0u) a.tgt_dirty[t] = 0;
+        rp_fold_pair<32>(a, t, gid, cnt, act, limit, !is_fold, lane, s_u.fold[wave], lds_counts ? s_push : nullptr, lds_counts ? &relax : nullptr);
+      }
+      if (!is_fold && (uint32_t)lane % gl == 0u && relax) atomicAdd(&s_relax, relax);
+    }
+    for (uint32_t i = 0; i < per * n_def; ++i) {
+      const uint32_t w = per * rl_u32(def_p, (int)(i / per)) + i % per;
+      if (w >= n) continue;
+      if (is_fold) {
+        const uint32_t t = dl ? dl[w] : w;
+        if (lane == 0) a.tgt_dirty[t] = 0;
+        rp_fold_wave(a, t, rp::kNever, false, lane, s_u.fold[wave]);
+      } else {
+        uint32_t rl = 0;
+        rp_fold_wave(a, w, c.cut, true, lane, s_u.fold[wave], lds_counts ? s_push : nullptr, lds_counts ? &rl : nullptr);
+        if (lane == 0 && rl) atomicAdd(&s_relax, rl);
+      }
+    }
   } else if (!SERIAL && (phase == rp::PH_FOLD || phase == rp::PH_COMMIT_FOLD)) {
     // one wave per target
     const uint32_t wave = threadIdx.x >> 6, waves = active * (kRpThreads / 64);
