@@ -611,6 +611,7 @@ class ModelEsdf : public EsdfIntegrator {
     a.c.max_distance = config_.max_distance_m; a.c.min_diff = config_.min_diff_m; a.c.voxel_size = voxel_size_; a.c.default_distance = config_.default_distance_m;
     a.c.full = config_.full_euclidean_distance; a.c.multi_queue = config_.multi_queue; a.c.num_buckets = config_.num_buckets;
     a.c.kmax = (uint32_t)std::min<size_t>(kmax, 1u << 20); a.c.smax = (uint32_t)smax; a.c.max_iters = (uint32_t)max_iters;
+    a.c.cut_mult = 2; a.c.ramp_mult = 4;
     Ctl& c = emul_ctl;
     c = Ctl{};
     a.ctl = &c;

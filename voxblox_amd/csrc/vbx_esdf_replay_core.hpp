@@ -92,6 +92,7 @@ struct Cfg {
   float max_distance, min_diff, voxel_size, default_distance;
   int full, multi_queue, num_buckets;
   uint32_t kmax, smax, max_iters;
+  uint32_t cut_mult, ramp_mult;   // a bucket's next super-step after a cut takes cut_mult x what got through (at least 32), after a clean one ramp_mult x as many
   uint32_t fold_pairs;   // (device) fold launches over more targets than waves take lists of up to 32 events two at a time, a half-wave each (VBX_RP_FOLD_PAIRS; off in bulk updates)
   uint32_t ev;       // events a target can hold (<= kEvMax); a record whose event does not fit is poisoned and the super-step ends in front of it
   uint32_t filter;   // rp_offer_possible: 0 every offer is an event, 1 + usable neighbours only, 2 + pops that offer at all, 3 + offers that can beat the neighbour
@@ -1357,8 +1358,8 @@ RP_FN void rp_control(const Args& a) {
       // a cut throws the work behind it away: take about as much as got through next time, ramp up after clean steps
       if (c.cut == 0) c.k_cur[c.bucket] = c.K / 4 > 1 ? c.K / 4 : 1;   // rp_retry_smaller
       else if (c.raise) c.k_cur[c.bucket] = c.k_cur[c.bucket] * 4 > a.c.kmax ? a.c.kmax : c.k_cur[c.bucket] * 4;   // (raise super-steps only cut at a full event list)
-      else if (c.cut != kNever) c.k_cur[c.bucket] = nb * 2 > 32 ? nb * 2 : 32;
-      else c.k_cur[c.bucket] = c.k_cur[c.bucket] * 4 > a.c.kmax ? a.c.kmax : c.k_cur[c.bucket] * 4;
+      else if (c.cut != kNever) c.k_cur[c.bucket] = nb * a.c.cut_mult > 32 ? nb * a.c.cut_mult : 32;
+      else c.k_cur[c.bucket] = c.k_cur[c.bucket] * a.c.ramp_mult > a.c.kmax ? a.c.kmax : c.k_cur[c.bucket] * a.c.ramp_mult;
       rp_begin_superstep(a);
       break;
     }

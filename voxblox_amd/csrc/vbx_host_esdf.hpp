@@ -535,6 +535,8 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.hazard = ctx->rp_hazard.as<uint8_t>();
   a.c.filter = rp_env_u32("VBX_RP_FILTER", 3);
   a.c.ev = std::min<uint32_t>(std::max<uint32_t>(rp_env_u32("VBX_RP_EV", 512), 32), rp::kEvMax);   // events per target (128 until round 5a, 256 until the end of round 6: a list that fills up poisons the record that does not fit and cuts the super-step)
+  a.c.cut_mult = std::max<uint32_t>(1u, rp_env_u32("VBX_RP_CUT_MULT", 2));
+  a.c.ramp_mult = std::max<uint32_t>(2u, rp_env_u32("VBX_RP_RAMP_MULT", 8));
   a.c.fold_pairs = rp_env_u32("VBX_RP_FOLD_PAIRS", ctx->rp_bulk ? 0 : 1);   // (a bulk update's lists are long: more than half of its pairs would be folded singly after all — first update 398 -> 405 ms with pairs)
   a.c.lds_counts = rp_env_u32("VBX_RP_LDS_COUNTS", 1);   // (0: one atomic per push and per target on Ctl::push_cnt / st_relax — rounds 4 / 5a)
   a.c.tgt_claim = rp_env_u32("VBX_RP_TGT_CLAIM", 1);     // (0: a target id is taken before the voxel is known to be free: lost races leave holes)
