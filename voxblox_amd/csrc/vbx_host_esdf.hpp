@@ -535,7 +535,10 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.hazard = ctx->rp_hazard.as<uint8_t>();
   a.c.filter = rp_env_u32("VBX_RP_FILTER", 3);
   a.c.ev = std::min<uint32_t>(std::max<uint32_t>(rp_env_u32("VBX_RP_EV", 512), 32), rp::kEvMax);   // events per target (128 until round 5a, 256 until the end of round 6: a list that fills up poisons the record that does not fit and cuts the super-step)
-  a.c.cut_mult = std::max<uint32_t>(1u, rp_env_u32("VBX_RP_CUT_MULT", 2));
+  // (after a cut: a bulk update's cuts come in clusters — full event lists in crowded space — and twice what got through is
+  // the size that passes; an incremental update's rare cuts are single excursions that outgrew smax, and the bucket goes on
+  // at full size: first update 394 / 452 / 517 ms at 2 / 16 / 64, mean of updates 3-22 24.5 / 24.2 / 24.1 ms)
+  a.c.cut_mult = std::max<uint32_t>(1u, rp_env_u32("VBX_RP_CUT_MULT", ctx->rp_bulk ? 2 : 64));
   a.c.ramp_mult = std::max<uint32_t>(2u, rp_env_u32("VBX_RP_RAMP_MULT", 8));
   a.c.fold_pairs = rp_env_u32("VBX_RP_FOLD_PAIRS", ctx->rp_bulk ? 0 : 1);   // (a bulk update's lists are long: more than half of its pairs would be folded singly after all — first update 398 -> 405 ms with pairs)
   a.c.lds_counts = rp_env_u32("VBX_RP_LDS_COUNTS", 1);   // (0: one atomic per push and per target on Ctl::push_cnt / st_relax — rounds 4 / 5a)
