@@ -175,6 +175,12 @@ int vbx_tsdf_integrate_device(vbx_ctx* ctx, int kind, const vbx_tsdf_cfg* cfg,
 /* EsdfIntegrator::updateFromTsdfLayer(clear_updated_flag) (esdf_integrator.cc:104-122) when
  * batch == 0, EsdfIntegrator::updateFromTsdfLayerBatch() (:94-102) when batch != 0. */
 int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_updated_flag);
+/* EsdfIntegrator::EsdfIntegrator (esdf_integrator.cc:7-21) is where the reference sets its queues up; the device side of
+ * that is workspace: the ESDF layer's device arrays (9 B per voxel of the map's capacity) and, with cfg->reference_order,
+ * the replay's pools (~1.5 GB, sized by the super-step, not by the map).  Optional — the first vbx_esdf_update /
+ * vbx_esdf_update_blocks / vbx_esdf_add_new_robot_position allocates whatever is missing — but a first update that has to
+ * allocate spends 30-100 ms in hipMalloc with the device idle.  Call it where the application constructs its integrator. */
+int vbx_esdf_reserve(vbx_ctx* ctx, const vbx_esdf_cfg* cfg);
 
 /* EsdfIntegrator::updateFromTsdfBlocks(tsdf_blocks, incremental) (esdf_integrator.cc:124-302): the
  * same update restricted to the listed TSDF blocks (blocks not in the TSDF layer are skipped); no

@@ -384,3 +384,36 @@ def test_reference_order_list_longer_than_the_pool_naming_absent_blocks(oracle):
         gm.esdf_update_blocks(ge, lst, incremental=True)
         gm.clear_updated(capi.UPDATE_ESDF, capi.LAYER_TSDF)
         _assert_same_esdf(_gpu_esdf_dict(gm), om.esdf_dict(), f"frame {f}")
+
+
+@pytest.mark.gpu
+def test_reserved_workspace_changes_nothing_but_the_first_updates_allocations():
+    """vbx_esdf_reserve (the device side of EsdfIntegrator's constructor, esdf_integrator.cc:7-21): a map whose workspace was
+    reserved before the first frame ends on the same ESDF words, parents included, as one that allocates inside its first
+    update; reserving twice, and on a map that already holds blocks, is harmless."""
+    import numpy as np, torch
+    from voxblox_amd import capi, scenes
+    dev = torch.device("cuda", 0)
+    cfg = capi.tsdf_cfg(default_truncation_distance=0.4)
+    ecfg = capi.esdf_cfg(min_distance_m=0.2, reference_order=1)
+    frames = [scenes.room_frame(k, 16) for k in range(3)]
+    words = []
+    for reserve in (False, True):
+        gm = capi.Map(0.1, 16, max_blocks=2048)
+        if reserve:
+            gm.esdf_reserve(ecfg)
+            gm.esdf_reserve(ecfg)
+        for i, (pose, pts, col) in enumerate(frames):
+            dp, dc = torch.from_numpy(pts).to(dev), torch.from_numpy(col).to(dev)
+            gm.integrate_device(capi.TSDF_FAST, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), dp.shape[0])
+            if reserve and i == 1:
+                gm.esdf_reserve(ecfg)
+            gm.esdf_update(ecfg, batch=False, clear_updated_flag=True)
+        idx = np.asarray(gm.block_indices(capi.LAYER_ESDF), np.int32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx[np.lexsort((idx[:, 0], idx[:, 1], idx[:, 2]))])
+        vox, _, _ = gm.blocks_download(idx, layer=capi.LAYER_ESDF)
+        words.append((idx.copy(), np.ascontiguousarray(vox).view(np.uint8).copy()))
+        gm.close()
+    assert len(words[0][0]) > 20
+    assert np.array_equal(words[0][0], words[1][0])
+    assert np.array_equal(words[0][1], words[1][1])

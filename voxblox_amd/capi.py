@@ -23,7 +23,7 @@ UPDATE_MAP, UPDATE_MESH, UPDATE_ESDF = 1, 2, 4
 EXPORTED_SYMBOLS = (
     "vbx_tsdf_cfg_default", "vbx_esdf_cfg_default", "vbx_create", "vbx_destroy",
     "vbx_last_error", "vbx_get_map_cfg", "vbx_set_stream", "vbx_set_pool_limit", "vbx_tsdf_integrate", "vbx_tsdf_integrate_device",
-    "vbx_esdf_update", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_esdf_robot_updated_blocks", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated", "vbx_blocks_new_ordered", "vbx_block_indices_layer_order", "vbx_set_block_order_tracking",
+    "vbx_esdf_update", "vbx_esdf_reserve", "vbx_esdf_update_blocks", "vbx_esdf_integrator_clear", "vbx_esdf_add_new_robot_position", "vbx_esdf_robot_updated_blocks", "vbx_num_blocks", "vbx_block_indices", "vbx_blocks_updated", "vbx_blocks_new_ordered", "vbx_block_indices_layer_order", "vbx_set_block_order_tracking",
     "vbx_block_download", "vbx_blocks_download", "vbx_host_alloc", "vbx_host_free", "vbx_block_upload", "vbx_blocks_upload", "vbx_block_remove", "vbx_blocks_remove", "vbx_remove_distant_blocks",
     "vbx_clear", "vbx_clear_keep_slots", "vbx_clear_updated", "vbx_blocks_export_sums", "vbx_blocks_merge_sums", "vbx_blocks_serialize", "vbx_blocks_deserialize", "vbx_get_counters", "vbx_selftest_sort", "vbx_selftest_scan", "vbx_fast_reset_counter_get", "vbx_fast_reset_counter_set", "vbx_enable_timing", "vbx_get_timing",
     "vbx_profile_enable", "vbx_profile_reset", "vbx_profile_get",
@@ -120,6 +120,7 @@ def lib():
         "vbx_tsdf_integrate_device": (C.c_int, [vp, C.c_int, C.POINTER(TsdfCfg), f32p, f32p, vp, vp,
                                                 C.c_size_t, C.c_int]),
         "vbx_esdf_update": (C.c_int, [vp, C.POINTER(EsdfCfg), C.c_int, C.c_int]),
+        "vbx_esdf_reserve": (C.c_int, [vp, C.POINTER(EsdfCfg)]),
         "vbx_esdf_add_new_robot_position": (C.c_int, [vp, C.POINTER(EsdfCfg), f32p]),
         "vbx_esdf_update_blocks": (C.c_int, [vp, C.POINTER(EsdfCfg), i32p, C.c_size_t, C.c_int]),
         "vbx_esdf_robot_updated_blocks": (C.c_int, [vp, C.c_int, i32p, C.c_size_t, szp, C.c_int]),
@@ -271,6 +272,10 @@ class Map:
 
     def esdf_update(self, cfg, batch=False, clear_updated_flag=True):
         self._chk(self.L.vbx_esdf_update(self.h, C.byref(cfg), int(batch), int(clear_updated_flag)))
+
+    def esdf_reserve(self, cfg):
+        """Workspace of the ESDF updates before the first one needs it (EsdfIntegrator's constructor, esdf_integrator.cc:7-21)."""
+        self._chk(self.L.vbx_esdf_reserve(self.h, C.byref(cfg)))
 
     def esdf_update_blocks(self, cfg, indices, incremental=False):
         """EsdfIntegrator::updateFromTsdfBlocks (esdf_integrator.cc:124-302)."""

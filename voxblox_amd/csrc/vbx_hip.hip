@@ -283,6 +283,11 @@ int vbx_esdf_update(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int clear_
   return rc;
 }
 
+int vbx_esdf_reserve(vbx_ctx* ctx, const vbx_esdf_cfg* cfg) {
+  if (!ctx || !cfg) return VBX_ERR_INVALID;
+  return esdf_reserve(ctx, cfg);
+}
+
 int vbx_esdf_update_blocks(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const int32_t* idx_xyz, size_t n, int incremental) {
   if (!ctx || !cfg || (n && !idx_xyz)) return VBX_ERR_INVALID;
   static const int32_t kNone[3] = {0, 0, 0};

@@ -524,7 +524,7 @@ rp::Args rp_args(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, const EsdfDev& e, size_t
   a.c.full = cfg->full_euclidean_distance != 0;
   a.c.multi_queue = cfg->multi_queue != 0;
   a.c.num_buckets = cfg->num_buckets;
-  a.c.kmax = ctx->rp_kmax;
+  a.c.kmax = ctx->rp_bulk ? std::min<uint32_t>(ctx->rp_kmax, std::max<uint32_t>(64u, rp_env_u32("VBX_RP_KMAX_BULK", 12288))) : ctx->rp_kmax;   // (a bulk update's super-steps: fewer base records at a time)
   a.c.smax = ctx->rp_smax;
   a.c.max_iters = rp_env_u32("VBX_RP_MAX_ITERS", ctx->rp_bulk ? 64 : 128);   // (vbx_ctx::rp_bulk)
   a.ctl = ctx->rp_ctl.as<rp::Ctl>();
@@ -891,7 +891,9 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
   ctx->rp_bulk = batch || n > 2 * ctx->rp_walked_total;
   ctx->rp_walked_total += n;
   const bool replay = rp_env_u32("VBX_ESDF_REPLAY", 1) != 0 && cfg->num_buckets <= 254;   // (a push table entry is one byte: bucket + 1, raise_ = num_buckets)
+  const auto t_ens0 = std::chrono::steady_clock::now();
   rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, n_chunks, used, n);
+  if (getenv("VBX_RP_ALLOC_MS")) fprintf(stderr, "[rp] rp_ensure %.2f ms (host)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ens0).count());
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(ctx->rp_ctl.p, 0, sizeof(rp::Ctl) + (size_t)rp::kPushShards * (rp::kMaxBuckets + 2) * 4, s));
   if (n_seed) {
@@ -1037,6 +1039,25 @@ int esdf_update_strict(vbx_ctx* ctx, const vbx_esdf_cfg* cfg, int batch, int cle
     o = vbx_timing{};
     (void)hipEventElapsedTime(&o.total_ms, ctx->ev[0], ctx->ev[7]);
   }
+  return VBX_OK;
+}
+
+// vbx_esdf_reserve: the ESDF layer's device arrays and, in reference order, the replay's pools (sized by the super-step, not by
+// the map: ~1.5 GB) before the first update needs them — 30 ms of hipMalloc in a fresh process, up to 100 ms behind the frees
+// of another handle, that the first update of a map otherwise spends with the device idle
+int esdf_reserve(vbx_ctx* ctx, const vbx_esdf_cfg* cfg) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = esdf_ensure(ctx);
+  if (rc || !cfg->reference_order) return rc;
+  if (cfg->num_buckets < 1 || cfg->num_buckets > kStrictMaxBuckets) {
+    ctx->fail("ESDF reference order: num_buckets must be in 1..%d", kStrictMaxBuckets);
+    return VBX_ERR_INVALID;
+  }
+  rc = sync_state(ctx);
+  if (rc) return rc;
+  rc = rp_ensure(ctx, (uint32_t)cfg->num_buckets, 1024, ctx->h_state.pool_used, 0);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));   // (the pools' clears)
   return VBX_OK;
 }
 
