@@ -13,6 +13,8 @@ ecfg = capi.esdf_cfg(min_distance_m=0.1, reference_order=1)
 frames = [scenes.room_frame(k, 100) for k in range(n)]
 d = [(p, torch.from_numpy(a).to(dev), torch.from_numpy(c).to(dev)) for p, a, c in frames]
 gm.enable_timing(True)
+if not os.environ.get("VBX_NO_RESERVE"):
+    gm.esdf_reserve(ecfg)   # (the integrator's workspace, as bench.py: outside the first update)
 ts = []
 for i, (pose, dp, dc) in enumerate(d):
     gm.integrate_device(capi.TSDF_FAST, cfg, pose[0], pose[1], dp.data_ptr(), dc.data_ptr(), dp.shape[0])
