@@ -627,6 +627,7 @@ def run_stream(args, gm, kind, cfg, d_frames, steps, warmup, barrier, esdf_cfg=N
         gm.enable_timing(True)      # per-update device times of the warm-up frames too (the first update of a map)
         # the integrator's workspace is reserved where the reference constructs its EsdfIntegrator (vbx_esdf_reserve), outside the
         # first update; what the reservation cost is reported next to it (esdf.workspace_reserve_ms)
+        import torch
         torch.cuda.synchronize()
         _t0 = time.perf_counter()
         gm.esdf_reserve(esdf_cfg)
