@@ -111,7 +111,7 @@ struct vbx_ctx {
   size_t rp_vox2tgt_zeroed = 0;   // bytes of rp_vox2tgt known to be zero
   uint32_t rp_rec_cap = 0, rp_tgt_cap = 0, rp_kmax = 0, rp_smax = 0, rp_scan_tiles_cap = 0;
   // Blocks the reference-order updates of this ESDF layer have walked so far, and whether the update in hand walks more than
-  // all of them together (the first update of a map, a batch rebuild): such an update's few floods run for hundreds of rings
+  // all of them together (the first update of a map): such an update's few floods run for hundreds of rings
   // and are cheaper cut at 64 iterations and continued from the queues, while the 70-ring floods of an incremental update
   // want their 128 (first update of the configs[3] stream 405 -> 398 ms, later ones 25.0 against 25.7 ms at 64).
   size_t rp_walked_total = 0;
