@@ -101,8 +101,8 @@ typedef struct vbx_esdf_cfg {
    * depends on an implementation detail): the reference's OWN result — updateFromTsdfBlocks' voxel walk, the FIFO raise
    * queue, BucketQueue pop order with num_buckets / multi_queue, min_diff_m gating, updateVoxelFromNeighbors incl. its
    * unscaled LUT distance, the sign-mismatch rule as written (esdf_integrator.cc:124-530, bucket_queue.h:41-80) — replayed
-   * in parallel, thousands of pops at a time, with the reference's bits as the result (~25 ms per update on
-   * the 640x480 / 0.05 m stream where the reference build needs ~77 ms on one core of the same box).  The blocks are
+   * in parallel, thousands of pops at a time, with the reference's bits as the result (~24 ms per update on
+   * the 640x480 / 0.05 m stream where the reference build needs ~78 ms on one core of the same box).  The blocks are
    * visited in the order of the list given to vbx_esdf_update_blocks; vbx_esdf_update visits them in the iteration order
    * the reference's Layer would have (Layer::getAllUpdatedBlocks over its unordered_map, layer.h:194-203): the library
    * replays that container from the sequence in which the integrators hand blocks to the Layer
@@ -115,7 +115,7 @@ typedef struct vbx_esdf_cfg {
    * COST OF THIS DEFAULT: latency ~100x the fast mode's (tens of ms per update instead of 0.3); device memory ~1.3 GB
    * of replay pools per handle whatever the size of the map (1.07 GB of it the targets' event lists) + ~21 B per pool
    * voxel for the queue arena and the target / hazard maps (64 B with multi_queue) = ~2.3 GB for a 20 k-block map,
-   * allocated at the first reference-order update and kept until vbx_destroy.  Handles that never run a
+   * allocated at the first reference-order update (or by vbx_esdf_reserve) and kept until vbx_destroy.  Handles that never run a
    * reference-order update allocate none of it.
    * 0: the fast mode — order-free wavefronts run to their exact fixed points on the whole chip (0.3 ms per update; NOT
    * the reference's result where it depends on the queue order: bit-exact for batch updates with min_diff_m = 0, inside
