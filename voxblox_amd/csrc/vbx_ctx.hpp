@@ -91,6 +91,10 @@ struct vbx_ctx {
   PBuf h_mkeys, h_mperm;                                 // its read-back / upload staging
   PBuf rp_h_done;                                        // ESDF replay: page-locked landing place of the looks at Ctl::done (two in flight)
   hipEvent_t rp_look_ev[2] = {nullptr, nullptr};
+  // a batch of the replay's launches as ONE graph launch (VBX_RP_GRAPH=0: plain launches): the executable graph and the arguments it was built for
+  hipGraph_t rp_graph = nullptr;
+  hipGraphExec_t rp_graph_exec = nullptr;
+  std::vector<unsigned char> rp_graph_key;
   std::vector<uint32_t> h_midx, h_mhash, h_morder, h_mseq, h_mruns;
   std::vector<int32_t> h_mnxt;
   std::vector<uint32_t> h_poff;  // scratch of the blocked observed-set replay

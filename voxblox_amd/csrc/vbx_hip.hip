@@ -214,6 +214,8 @@ void vbx_destroy(vbx_ctx* ctx) {
                      &ctx->rp_hazard, &ctx->cls_pos, &ctx->cls_nb27, &ctx->cls_shadow, &ctx->cls_counters, &ctx->rp_wg_stats};
   for (DBuf* b : rp_bufs) b->release();
   ctx->rp_h_done.release();
+  if (ctx->rp_graph_exec) (void)hipGraphExecDestroy(ctx->rp_graph_exec);
+  if (ctx->rp_graph) (void)hipGraphDestroy(ctx->rp_graph);
   for (hipEvent_t e : ctx->rp_look_ev)
     if (e) (void)hipEventDestroy(e);
   ctx->h_mkeys.release();

@@ -616,10 +616,50 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
   h_done[1] = h_done[3] = 0;
   const uint64_t max_graphs = 1u << 20;
   const bool sync_debug = getenv("VBX_RP_SYNC") != nullptr;
+  // The batch as ONE graph of kRpGraphSteps kernel nodes with their arguments by value (VBX_RP_GRAPH=0: 64 launches),
+  // rebuilt when the arguments change (a handful of times in a map's life): one host call per batch instead of 64
+  static const bool use_graph = rp_env_u32("VBX_RP_GRAPH", 1) != 0;
+  const bool graph_batch = use_graph && !serial && !ctx->prof && !getenv("VBX_RP_SYNC");
+  if (graph_batch) {
+    std::vector<unsigned char> key(sizeof(rp::Args) + sizeof(RpScan) + 4);
+    std::memcpy(key.data(), &a, sizeof(rp::Args));
+    std::memcpy(key.data() + sizeof(rp::Args), &sc, sizeof(RpScan));
+    std::memcpy(key.data() + sizeof(rp::Args) + sizeof(RpScan), &rp_grid, 4);
+    if (!ctx->rp_graph_exec || key != ctx->rp_graph_key) {
+      if (ctx->rp_graph_exec) { (void)hipGraphExecDestroy(ctx->rp_graph_exec); ctx->rp_graph_exec = nullptr; }
+      if (ctx->rp_graph) { (void)hipGraphDestroy(ctx->rp_graph); ctx->rp_graph = nullptr; }
+      HIP_TRY(hipGraphCreate(&ctx->rp_graph, 0));
+      hipGraphNode_t prev = nullptr;
+      rp::Args ga = a;
+      RpScan gsc = sc;
+      for (uint32_t i = 0; i < kRpGraphSteps; ++i) {
+        uint32_t seq = i;
+        void* params[3] = {&ga, &gsc, &seq};
+        hipKernelNodeParams kp{};
+        kp.func = reinterpret_cast<void*>(&k_rp_step<false>);
+        kp.gridDim = dim3(rp_grid);
+        kp.blockDim = dim3(kRpThreads);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = params;
+        kp.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        HIP_TRY(hipGraphAddKernelNode(&node, ctx->rp_graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+        prev = node;
+      }
+      HIP_TRY(hipGraphInstantiate(&ctx->rp_graph_exec, ctx->rp_graph, nullptr, nullptr, 0));
+      ctx->rp_graph_key = key;
+    }
+  }
   for (uint64_t g = 0; g < max_graphs; ++g) {
     if (g >= 2) {
       HIP_TRY(hipEventSynchronize(ctx->rp_look_ev[g & 1]));   // the look behind batch g - 2
       if (h_done[(g & 1) * 2 + 1]) break;
+    }
+    if (graph_batch) {
+      HIP_TRY(hipGraphLaunch(ctx->rp_graph_exec, s));
+      HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(h_done) + (g & 1) * 2, &a.ctl->phase, 8, hipMemcpyDeviceToHost, s));   // phase, done
+      HIP_TRY(hipEventRecord(ctx->rp_look_ev[g & 1], s));
+      continue;
     }
     for (uint32_t i = 0; i < kRpGraphSteps; ++i) {
       if (sync_debug) {   // debug: which phase faults
