@@ -334,7 +334,10 @@ def test_reference_order_small_super_steps_and_capacities(oracle):
     {"VBX_RP_GRID": "200", "VBX_RP_TGT_SHARDS": "1"},    # one target-id counter (no holes)
     {"VBX_RP_TGT_SHARDS": "3", "VBX_RP_KMAX": "4096"},   # a shard count that does not divide the wave numbers evenly
     {"VBX_RP_SMAX": "128"},                              # rankings that hit the rank limit inside a batch of pops
-], ids=["grid96", "grid200-1shard", "3shards-kmax4096", "smax128"])
+    {"VBX_RP_GRAPH": "0"},                               # a batch as 64 plain launches instead of one graph launch
+    {"VBX_RP_GRID": "96", "VBX_RP_FOLD_PAIRS": "0"},     # folds one wave per target where the default folds lists of up to 32 events in pairs (grid96 above runs the pairs)
+    {"VBX_RP_GRID": "64", "VBX_RP_CUT_MULT": "1", "VBX_RP_RAMP_MULT": "2", "VBX_RP_KMAX_BULK": "256"},   # the slow start after a cut at its slowest, small bulk super-steps
+], ids=["grid96", "grid200-1shard", "3shards-kmax4096", "smax128", "plain-launches", "no-pairs", "slow-start"])
 def test_reference_order_under_the_step_kernels_switches(oracle, env):
     """Round 6's step kernel has paths the defaults do not take (a scan with more tiles than workgroups, a grid that is not a
     multiple of the arrival groups, one / three target-id shards, a rank limit that cuts batches of pops): the same
