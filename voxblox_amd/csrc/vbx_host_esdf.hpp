@@ -626,6 +626,7 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
     std::memcpy(key.data() + sizeof(rp::Args), &sc, sizeof(RpScan));
     std::memcpy(key.data() + sizeof(rp::Args) + sizeof(RpScan), &rp_grid, 4);
     if (!ctx->rp_graph_exec || key != ctx->rp_graph_key) {
+      const auto t_g0 = std::chrono::steady_clock::now();
       if (ctx->rp_graph_exec) { (void)hipGraphExecDestroy(ctx->rp_graph_exec); ctx->rp_graph_exec = nullptr; }
       if (ctx->rp_graph) { (void)hipGraphDestroy(ctx->rp_graph); ctx->rp_graph = nullptr; }
       HIP_TRY(hipGraphCreate(&ctx->rp_graph, 0));
@@ -648,6 +649,7 @@ int rp_run(vbx_ctx* ctx, const rp::Args& a, unsigned long long* pops, unsigned l
       }
       HIP_TRY(hipGraphInstantiate(&ctx->rp_graph_exec, ctx->rp_graph, nullptr, nullptr, 0));
       ctx->rp_graph_key = key;
+      if (getenv("VBX_RP_ALLOC_MS")) fprintf(stderr, "[rp] batch graph built in %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_g0).count());
     }
   }
   for (uint64_t g = 0; g < max_graphs; ++g) {
